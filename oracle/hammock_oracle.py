@@ -1,0 +1,541 @@
+"""Pure-Python restatement of the reference's greedy initial-clustering path.
+
+TEST INFRASTRUCTURE ONLY -- a second, independently structured restatement
+(object style, mirroring the Java classes one to one) used to cross-check the C
+oracle (oracle/hammock_oracle.c) on small inputs.  Only tests/,
+``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import it;
+the product package ``hammock_amd`` never does.
+
+PARITY STATUS: "parity unpinned" -- the reference (Java 7) cannot be run in
+this image and has no tests for this path; see oracle/hammock_oracle.h.
+
+Citations are relative to /root/reference/src/cz/krejciadam/hammock/.
+"""
+from __future__ import annotations
+
+import re
+from collections import OrderedDict
+from functools import cmp_to_key
+
+INT_MIN = -(2 ** 31)
+INT_MAX = 2 ** 31 - 1
+
+AMINO_ACIDS = "ARNDCQEGHILKMFPSTWYVBZX*"  # UniqueSequence.java:23-26
+NAME_TO_NUM = {c: i for i, c in enumerate(AMINO_ACIDS)}
+
+
+class HammockException(Exception):
+    pass
+
+
+class DataException(HammockException):
+    pass
+
+
+class FileFormatException(HammockException):
+    pass
+
+
+class ReferenceWouldCrash(Exception):
+    """The reference dereferences a null Cluster here."""
+
+    def __init__(self, case, index):
+        super().__init__(f"NullPointerException case {case} at index {index}")
+        self.case = case
+        self.index = index
+
+
+def _java_int_decode(text):
+    """Integer.decode: optional sign, then 0x/0X/# hex, leading-0 octal, decimal."""
+    t = text
+    neg = False
+    if t.startswith("-"):
+        neg, t = True, t[1:]
+    elif t.startswith("+"):
+        t = t[1:]
+    if t.startswith(("0x", "0X")):
+        v = int(t[2:], 16)
+    elif t.startswith("#"):
+        v = int(t[1:], 16)
+    elif t.startswith("0") and len(t) > 1:
+        v = int(t[1:], 8)
+    else:
+        if not re.fullmatch(r"[0-9]+", t):
+            raise ValueError(f"NumberFormatException: {text!r}")
+        v = int(t)
+    return -v if neg else v
+
+
+class UniqueSequence:
+    """UniqueSequence.java:19-171."""
+
+    def __init__(self, sequence, labels_map=None):
+        if labels_map is None:  # :65-74
+            labels_map = {"no_label": 1}
+        self.labels_map = labels_map
+        self.sequence = []
+        for ch in sequence.upper():  # :49-56
+            if ch not in NAME_TO_NUM:
+                raise FileFormatException(f"Error, character {ch} is not a valid letter")
+            self.sequence.append(NAME_TO_NUM[ch])
+
+    def size(self):  # :82-88
+        return sum(self.labels_map.values())
+
+    def get_sequence_string(self):  # :103-109
+        return "".join(AMINO_ACIDS[i] for i in self.sequence)
+
+    def __repr__(self):
+        return f"UniqueSequence({self.get_sequence_string()}, {self.labels_map})"
+
+
+def _string_compare(a, b):
+    """java.lang.String.compareTo for ASCII strings."""
+    for x, y in zip(a, b):
+        if x != y:
+            return ord(x) - ord(y)
+    return len(a) - len(b)
+
+
+def _alphabetic_cmp(o1, o2):  # UniqueSequence.java:255-261
+    return _string_compare(o1.get_sequence_string(), o2.get_sequence_string())
+
+
+def _size_alphabetic_cmp(o1, o2):  # :238-248
+    r = o1.size() - o2.size()
+    if r == 0:
+        r = _alphabetic_cmp(o1, o2)
+    return r
+
+
+class JavaRandom:
+    """java.util.Random (48-bit LCG), enough for Collections.shuffle."""
+
+    def __init__(self, seed):
+        self.seed = (seed ^ 0x5DEECE66D) & ((1 << 48) - 1)
+
+    def next(self, bits):
+        self.seed = (self.seed * 0x5DEECE66D + 0xB) & ((1 << 48) - 1)
+        v = self.seed >> (48 - bits)
+        if v >= 1 << 31:  # (int) cast of the 48-bit shift result
+            v -= 1 << 32
+        return v
+
+    def next_int(self, bound):
+        r = self.next(31)
+        m = bound - 1
+        if (bound & m) == 0:
+            return (bound * r) >> 31
+        u = r
+        while True:
+            r = u % bound
+            # overflow check of u - r + m in 32-bit arithmetic
+            if u - r + m < 2 ** 31:
+                return r
+            u = self.next(31)
+
+
+def java_shuffle(lst, rnd):
+    """Collections.shuffle(list, rnd): for i=size..2 swap(i-1, nextInt(i))."""
+    for i in range(len(lst), 1, -1):
+        j = rnd.next_int(i)
+        lst[i - 1], lst[j] = lst[j], lst[i - 1]
+
+
+def sort_sequences(sequences, order, seed=42, labels=None):
+    """UniqueSequence.sortSequences, UniqueSequence.java:176-203 (in place, returns the list)."""
+    rev = lambda cmp: cmp_to_key(lambda a, b: cmp(b, a))  # Collections.reverseOrder
+    if order == "size":
+        sequences.sort(key=rev(_size_alphabetic_cmp))  # list.sort is stable like Collections.sort
+    elif order == "alphabetic":
+        sequences.sort(key=rev(_alphabetic_cmp))
+    elif order == "random":
+        java_shuffle(sequences, JavaRandom(seed))
+    elif order == "input":
+        pass
+    else:
+        if labels is None or order not in labels:
+            raise DataException("Incorrect sequence order defined.")
+        sequences.sort(key=rev(_size_alphabetic_cmp))
+        sequences.sort(key=rev(lambda a, b: a.labels_map.get(order, 0) - b.labels_map.get(order, 0)))
+    return sequences
+
+
+class Cluster:
+    """Cluster.java:21-204 (members, id, size)."""
+
+    def __init__(self, sequences, cid):
+        self.sequences = list(sequences)
+        self.id = cid
+        self._size = sum(s.size() for s in self.sequences)
+
+    def insert(self, seq):  # :50-63
+        if any(s.sequence == seq.sequence for s in self.sequences):
+            raise DataException("Trying to insert unique sequence twice")
+        self.sequences.append(seq)
+        self._size += seq.size()
+
+    def insert_all(self, seqs):  # :70-74
+        for s in list(seqs):
+            self.insert(s)
+
+    def size(self):  # :156-158
+        return self._size
+
+    def get_unique_size(self):  # :113-115
+        return len(self.sequences)
+
+
+class ShiftedScorer:
+    """ShiftedScorer.java:12-114."""
+
+    def __init__(self, scoring_matrix, shift_penalty, max_shift):
+        self.m = scoring_matrix
+        self.shift_penalty = shift_penalty
+        self.max_shift = max_shift
+        self.calls = 0
+
+    def score_with_shift(self, seq1, seq2):
+        a, b = seq1.sequence, seq2.sequence
+        if len(a) >= len(b):  # :51-57
+            shorter, longer, shorter_is_seq2 = b, a, True
+        else:
+            shorter, longer, shorter_is_seq2 = a, b, False
+        if self.max_shift >= len(shorter):  # :59-62
+            raise DataException("Shift too big")
+        best, best_shift = INT_MIN, 0
+        diff = len(longer) - len(shorter)
+        for shift in range(-self.max_shift, self.max_shift + diff + 1):  # :67
+            score = 0
+            if shift <= 0:  # :69-72
+                for i in range(len(shorter) + shift):
+                    score += self.m[shorter[i - shift]][longer[i]]
+            else:  # :73-77
+                for i in range(min(len(shorter), len(longer) - shift)):
+                    score += self.m[shorter[i]][longer[i + shift]]
+            score += diff * self.shift_penalty  # :79
+            if shift < 0:
+                score += -shift * 2 * self.shift_penalty  # :80-82
+            if shift > diff:
+                score += (shift - diff) * 2 * self.shift_penalty  # :83-85
+            if score > best:  # :86-89
+                best, best_shift = score, shift
+        if not shorter_is_seq2:
+            best_shift = -best_shift  # :91-93
+        return best, best_shift
+
+    def sequence_score(self, seq1, seq2):  # :98-100
+        self.calls += 1
+        return self.score_with_shift(seq1, seq2)[0]
+
+
+class LocalAlignmentScorer:
+    """LocalAlignmentScorer.java:10-155."""
+
+    LEFT, UP, DIAGONAL, NOWHERE = "LEFT", "UP", "DIAGONAL", "NOWHERE"
+
+    def __init__(self, scoring_matrix, gap_open_penalty, gap_extend_penalty):
+        self.m = scoring_matrix
+        self.gap_open = gap_open_penalty
+        self.gap_extend = gap_extend_penalty
+        self.calls = 0
+
+    def sequence_score(self, seq1, seq2):  # :27-29
+        self.calls += 1
+        s1, s2 = seq1.sequence, seq2.sequence
+        d1, d2 = len(s1) + 1, len(s2) + 1
+        score = [[0] * d2 for _ in range(d1)]  # :88-101
+        direction = [[None] * d2 for _ in range(d1)]
+        for i in range(1, d1):
+            direction[i][0] = self.UP
+        for j in range(1, d2):
+            direction[0][j] = self.LEFT
+        global_max = 0
+        for line in range(1, d1):  # :40
+            for column in range(1, d2):  # :41
+                up_pen = self.gap_extend if direction[line - 1][column] == self.UP else self.gap_open
+                left_pen = self.gap_extend if direction[line][column - 1] == self.LEFT else self.gap_open
+                up = score[line - 1][column] + up_pen
+                left = score[line][column - 1] + left_pen
+                diag = score[line - 1][column - 1] + self.m[s1[line - 1]][s2[column - 1]]
+                mx = max(diag, max(up, left))
+                if mx < 0:  # :63-65
+                    score[line][column] = 0
+                    direction[line][column] = self.NOWHERE
+                else:
+                    score[line][column] = mx
+                    if mx > global_max:
+                        global_max = mx
+                    if mx == left:
+                        direction[line][column] = self.LEFT
+                    if mx == up:
+                        direction[line][column] = self.UP
+                    if mx == diag:
+                        direction[line][column] = self.DIAGONAL
+        return global_max
+
+
+class ClinkageClusterScorer:
+    """ClinkageClusterScorer.java:10-50."""
+
+    def __init__(self, scorer, threshold):
+        self.scorer = scorer
+        self.threshold = threshold
+
+    def cluster_score(self, cl1, cl2):
+        result = INT_MAX
+        for seq1 in cl1.sequences:
+            for seq2 in cl2.sequences:
+                r = self.scorer.sequence_score(seq1, seq2)
+                if r < result:
+                    result = r
+                    if result < self.threshold:
+                        return INT_MIN + 1
+        return result
+
+
+class NearestCluster:
+    def __init__(self, cluster, score):
+        self.cluster = cluster
+        self.score = score
+
+
+def _nearest_cluster_runner(database, compared, scorer):
+    """NearestClusterRunner.call, ClinkageSequenceClusterer.java:258-293."""
+    max_score = INT_MIN
+    nearest = None
+    for i in database:
+        score = scorer.cluster_score(i, compared)
+        if score < max_score:
+            continue
+        if score > max_score:
+            if i is not compared:
+                max_score = score
+                nearest = i
+        else:
+            if i is not compared:
+                if i.size() > nearest.size():
+                    nearest = i
+                elif i.size() < nearest.size():
+                    pass
+                elif i.id < nearest.id:
+                    nearest = i
+    return NearestCluster(nearest, max_score)
+
+
+def find_nearest_cluster_parallel(input_clusters, compared, scorer, sum_commodity, n_threads=4):
+    """ClinkageSequenceClusterer.java:137-223 (parts evaluated serially)."""
+    input_clusters = list(input_clusters)
+    if not input_clusters:
+        return NearestCluster(None, INT_MIN)  # :138-140 non-null dummy
+    n_parts = n_threads * 4  # :186-192
+    if len(input_clusters) < n_threads * 4 + 1:
+        n_parts = max(len(input_clusters) - 1, 1)
+    parts, current = [], []  # :202-223
+    for_one = sum_commodity // n_parts + 1
+    portion = for_one
+    for cl in input_clusters:
+        current.append(cl)
+        portion -= cl.get_unique_size()
+        if portion <= 0:
+            parts.append(current)
+            current = []
+            portion = for_one
+    if current:
+        parts.append(current)
+    max_score = INT_MIN + 42  # :151
+    nearest = None
+    for part in parts:
+        cur = _nearest_cluster_runner(part, compared, scorer)
+        if cur.score < max_score:
+            continue
+        if cur.score > max_score:
+            nearest = cur
+            max_score = cur.score
+        else:
+            if cur.cluster.size() > nearest.cluster.size():
+                nearest = cur
+            elif cur.cluster.size() == nearest.cluster.size() and cur.cluster.id < nearest.cluster.id:
+                nearest = cur
+    return nearest
+
+
+class LimitedGreedySequenceClusterer:
+    """LimitedGreedySequenceClusterer.java:17-121."""
+
+    def __init__(self, sequence_scorer, threshold, max_clusters, n_threads=4):
+        self.threshold = threshold
+        self.max_clusters = max_clusters
+        self.sequence_scorer = sequence_scorer
+        self.n_threads = n_threads
+        self.stats = {}
+
+    def cluster(self, sequences):  # :39-69
+        cluster_scorer = ClinkageClusterScorer(self.sequence_scorer, self.threshold)
+        clusters = self._first_phase(sequences, self.max_clusters, cluster_scorer)
+        index = len(clusters)
+        for i, c in enumerate(clusters):
+            if c.get_unique_size() == 1:
+                index = i
+                break
+        actual_clusters = list(clusters[:index])
+        actual_sequences = list(clusters[index:])
+        remaining = []
+        sum_commodity = sum(c.get_unique_size() for c in actual_clusters)
+        calls0 = self.sequence_scorer.calls
+        for cl in actual_sequences:
+            found = find_nearest_cluster_parallel(actual_clusters, cl, cluster_scorer, sum_commodity, self.n_threads)
+            if found is not None and found.score >= self.threshold:
+                found.cluster.insert_all(cl.sequences)  # NPE impossible: dummy score is MIN_VALUE
+            else:
+                remaining.append(cl)
+        self.stats["score_calls_phase2"] = self.sequence_scorer.calls - calls0
+        actual_clusters.extend(remaining)
+        return actual_clusters
+
+    def _first_phase(self, sequences, max_clusters, cluster_scorer):  # :77-120
+        initial = [Cluster([s], i) for i, s in enumerate(sequences)]
+        actual_clusters, actual_sequences = [], []
+        sum_commodity_clusters = 0
+        index = 0
+        calls0 = self.sequence_scorer.calls
+        while index < len(initial) and len(actual_clusters) < max_clusters:
+            compared = initial[index]
+            a = find_nearest_cluster_parallel(actual_clusters, compared, cluster_scorer, sum_commodity_clusters, self.n_threads)
+            b = find_nearest_cluster_parallel(initial[index + 1:], compared, cluster_scorer, len(initial) - index - 1, self.n_threads)
+            if a is not None:
+                if b is not None:
+                    if a.score >= b.score:
+                        if a.cluster is None:
+                            raise ReferenceWouldCrash(2, index)  # :97
+                        a.cluster.insert_all(compared.sequences)
+                    else:
+                        compared.insert_all(b.cluster.sequences)
+                        actual_clusters.append(compared)
+                        initial.remove(b.cluster)
+                else:
+                    if a.cluster is None:
+                        raise ReferenceWouldCrash(1, index)  # :104
+                    a.cluster.insert_all(compared.sequences)
+            else:
+                if b is not None:
+                    if b.cluster is None:
+                        raise ReferenceWouldCrash(3, index)  # :108
+                    compared.insert_all(b.cluster.sequences)
+                    actual_clusters.append(compared)
+                    initial.remove(b.cluster)
+                else:
+                    actual_sequences.append(compared)
+            index += 1
+        self.stats["score_calls_phase1"] = self.sequence_scorer.calls - calls0
+        self.stats["phase1_stop_index"] = index
+        self.stats["phase1_clusters"] = len(actual_clusters)
+        self.stats["phase1_orphans"] = len(actual_sequences)
+        return actual_clusters + actual_sequences + initial[index:]
+
+
+# ---------------------------------------------------------------------------
+# loaders (FileIOManager.java)
+# ---------------------------------------------------------------------------
+def _java_split_ws(line):
+    """String.split("\\s+"): leading empty token kept, trailing empties dropped."""
+    parts = re.split(r"\s+", line)
+    while parts and parts[-1] == "":
+        parts.pop()
+    return parts
+
+
+def load_scoring_matrix(path):
+    """FileIOManager.loadScoringMatrix, FileIOManager.java:46-81."""
+    matrix = [[0] * 24 for _ in range(24)]
+    line_counter = 0
+    with open(path, "r") as fh:
+        for raw in fh.read().splitlines():
+            line = raw
+            if not (line.startswith("#") or line.startswith(" ") or line.startswith("\t")):
+                parts = _java_split_ws(line)
+                if len(parts) != 25:
+                    raise FileFormatException("Scoring matrix should always have 24 columns")
+                if line_counter >= 24:  # ArrayIndexOutOfBounds -> FileFormatException, :76-79
+                    raise FileFormatException("Scoring matrix should always have 24 rows")
+                for i in range(1, 25):
+                    matrix[line_counter][i - 1] = int(parts[i])
+                line_counter += 1
+                if line_counter > 24:
+                    raise FileFormatException("Scoring matrix should always have 24 rows")
+    return matrix
+
+
+def load_unique_sequences_from_fasta(path):
+    """FileIOManager.loadUniqueSequencesFromFasta, FileIOManager.java:159-216."""
+    sequence_map = OrderedDict()
+    sequence = ""
+    label = None
+    count = None
+
+    def update(seq):
+        lm = sequence_map.get(seq)
+        if lm is None:
+            lm = {label: count}
+        else:
+            lm[label] = lm.get(label, 0) + count
+        sequence_map[seq] = lm
+
+    with open(path, "r") as fh:
+        for raw in fh.read().splitlines():
+            line = raw
+            if line.startswith(">"):
+                if len(sequence) > 0:
+                    update(sequence)
+                    sequence = ""
+                split = line.strip()[1:].split("|")
+                while len(split) > 1 and split[-1] == "":  # Java split drops trailing empties
+                    split.pop()
+                if len(split) >= 2:
+                    count = _java_int_decode(split[1].strip())
+                    if count < 1:
+                        raise FileFormatException("Fasta header defines sequence count lower than 1.")
+                else:
+                    count = 1
+                label = split[2] if len(split) >= 3 else "no_label"
+            else:
+                if label is None or count is None:
+                    raise FileFormatException("Incorrect fasta format.")
+                sequence += line.strip()
+    if label is None or count is None:
+        raise ReferenceWouldCrash(0, -1)  # NPE unboxing null count, :193
+    update(sequence)
+    return [UniqueSequence(k, v) for k, v in sequence_map.items()]
+
+
+def load_unique_sequences_from_table(path, sep="\t"):
+    """FileIOManager.loadUniqueSequencesFromTable, FileIOManager.java:227-255."""
+    result = []
+    with open(path, "r") as fh:
+        lines = fh.read().splitlines()
+    labels = lines[0].split(sep)[1:]
+    for line in lines[1:]:
+        parts = line.split(sep)
+        lm = {}
+        for i, v in enumerate(parts[1:]):
+            value = _java_int_decode(v)
+            if value != 0:
+                lm[labels[i]] = value
+        result.append(UniqueSequence(parts[0], lm))
+    return result
+
+
+def java_round(x):
+    """Math.round(double): floor(x + 0.5)."""
+    import math
+    return int(math.floor(x + 0.5))
+
+
+def greedy_defaults(sequences):
+    """Hammock.java:394-401, :1409-1434: (threshold, max_shift, max_clusters)."""
+    lengths = [len(s.sequence) for s in sequences]
+    mean = sum(lengths) / len(lengths)
+    threshold = java_round(mean * 1.7)
+    max_shift = min(java_round(mean / 4), min(lengths) - 1)
+    max_clusters = java_round(len(sequences) * 0.025)
+    return threshold, max_shift, max_clusters

@@ -1,0 +1,54 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def matrices():
+    with open(os.path.join(GOLDEN, "matrices.json")) as fh:
+        d = json.load(fh)
+    return {k: np.asarray(v, dtype=np.int32) for k, v in d["matrices"].items()}
+
+
+@pytest.fixture(scope="session")
+def blosum62(matrices):
+    return matrices["blosum62"]
+
+
+@pytest.fixture(scope="session")
+def known_answers():
+    with open(os.path.join(GOLDEN, "known_answers.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope="session")
+def coracle():
+    from oracle import c_oracle
+    c_oracle.lib()
+    return c_oracle
+
+
+def random_peptides(rng, n, len_lo, len_hi, alphabet=20):
+    """n DISTINCT random peptides as a list of uint8 arrays."""
+    seen, out = set(), []
+    while len(out) < n:
+        L = int(rng.integers(len_lo, len_hi + 1))
+        p = rng.integers(0, alphabet, size=L, dtype=np.uint8)
+        key = p.tobytes()
+        if key in seen:
+            continue
+        seen.add(key)
+        out.append(p)
+    return out

@@ -1,0 +1,297 @@
+"""CPU tests of the oracle itself: known answers, agreement of
+the two independent restatements (C and pure Python), crash parity, ordering."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, random_peptides
+from oracle import hammock_oracle as po
+
+AA = po.AMINO_ACIDS
+
+
+def to_str(p):
+    return "".join(AA[int(x)] for x in p)
+
+
+def per_shift_sums(M, s1, s2, X, p):
+    """Per-shift list exactly as SURVEY 8(c) tabulates it (shift of the shorter)."""
+    sc = po.ShiftedScorer(M, p, X)
+    a, b = po.UniqueSequence(s1), po.UniqueSequence(s2)
+    A, B = a.sequence, b.sequence
+    shorter, longer = (B, A) if len(A) >= len(B) else (A, B)
+    d = len(longer) - len(shorter)
+    out = []
+    for s in range(-X, X + d + 1):
+        if s <= 0:
+            v = sum(M[shorter[i - s]][longer[i]] for i in range(len(shorter) + s))
+        else:
+            v = sum(M[shorter[i]][longer[i + s]] for i in range(min(len(shorter), len(longer) - s)))
+        v += d * p + (-s * 2 * p if s < 0 else 0) + ((s - d) * 2 * p if s > d else 0)
+        out.append(v)
+    assert max(out) == sc.sequence_score(a, b)
+    return out
+
+
+def test_known_answers_shifted(known_answers, blosum62, coracle):
+    M = blosum62.tolist()
+    for row in known_answers["shifted_blosum62"]:
+        st, score, _ = coracle.shifted_score(blosum62, row["seq1"], row["seq2"], row["X"], row["p"])
+        assert st == 0 and score == row["score"], row
+        py = po.ShiftedScorer(M, row["p"], row["X"]).sequence_score(
+            po.UniqueSequence(row["seq1"]), po.UniqueSequence(row["seq2"]))
+        assert py == row["score"], row
+        if "per_shift" in row:
+            assert per_shift_sums(M, row["seq1"], row["seq2"], row["X"], row["p"]) == row["per_shift"]
+
+
+def test_known_answers_local(known_answers, blosum62, coracle):
+    M = blosum62.tolist()
+    for row in known_answers["local_blosum62_open-5_ext-1"]:
+        assert coracle.local_score(blosum62, row["seq1"], row["seq2"], -5, -1) == row["score"], row
+        sc = po.LocalAlignmentScorer(M, -5, -1)
+        assert sc.sequence_score(po.UniqueSequence(row["seq1"]), po.UniqueSequence(row["seq2"])) == row["score"]
+        if "swapped" in row:  # order dependence of the direction-matrix rule
+            assert coracle.local_score(blosum62, row["seq2"], row["seq1"], -5, -1) == row["swapped"]
+
+
+def test_shift_too_big(blosum62, coracle):
+    # ShiftedScorer.java:59-62: maxShift >= shorter length -> DataException
+    st, _, _ = coracle.shifted_score(blosum62, "ACDEFGH", "CDEFGHIKLM", 7, 0)
+    assert st == coracle.HMO_ERR_SHIFT_TOO_BIG
+    st, _, _ = coracle.shifted_score(blosum62, "ACDEFGH", "CDEFGHIKLM", 6, 0)
+    assert st == 0
+    with pytest.raises(po.DataException):
+        po.ShiftedScorer(blosum62.tolist(), 0, 7).sequence_score(po.UniqueSequence("ACDEFGH"),
+                                                                 po.UniqueSequence("CDEFGHIKLM"))
+
+
+@pytest.mark.parametrize("mat", ["blosum62", "pam250", "blosum30", "mcla71"])
+def test_c_vs_python_scorers_random(matrices, coracle, mat):
+    rng = np.random.default_rng(7)
+    M = matrices[mat]
+    Ml = M.tolist()
+    peps = random_peptides(rng, 60, 7, 20, alphabet=24)
+    for X, p in [(0, 0), (3, 0), (3, -1), (6, -4), (1, 2)]:
+        sc = po.ShiftedScorer(Ml, p, X)
+        for _ in range(150):
+            i, j = rng.integers(0, len(peps), 2)
+            a, b = peps[i], peps[j]
+            st, score, shift = coracle.shifted_score(M, a, b, X, p)
+            ua, ub = po.UniqueSequence(to_str(a)), po.UniqueSequence(to_str(b))
+            pscore, pshift = sc.score_with_shift(ua, ub)
+            assert st == 0 and (score, shift) == (pscore, pshift)
+    for go, ge in [(-5, -1), (-10, -2), (-3, -3), (0, 0)]:
+        sc = po.LocalAlignmentScorer(Ml, go, ge)
+        for _ in range(100):
+            i, j = rng.integers(0, len(peps), 2)
+            a, b = peps[i], peps[j]
+            assert coracle.local_score(M, a, b, go, ge) == sc.sequence_score(
+                po.UniqueSequence(to_str(a)), po.UniqueSequence(to_str(b)))
+
+
+def test_shifted_properties(blosum62, coracle):
+    """SURVEY 7.5 property tests (symmetric M): symmetry, X=0 = plain sum, monotone in p."""
+    rng = np.random.default_rng(11)
+    peps = random_peptides(rng, 40, 7, 20)
+    for _ in range(300):
+        i, j = rng.integers(0, len(peps), 2)
+        a, b = peps[i], peps[j]
+        X = int(rng.integers(0, 7))
+        _, s_ab, _ = coracle.shifted_score(blosum62, a, b, X, -1)
+        _, s_ba, _ = coracle.shifted_score(blosum62, b, a, X, -1)
+        assert s_ab == s_ba
+        _, s_p0, _ = coracle.shifted_score(blosum62, a, b, X, 0)
+        _, s_p2, _ = coracle.shifted_score(blosum62, a, b, X, -2)
+        assert s_p0 >= s_ab >= s_p2
+        if len(a) == len(b):
+            _, s0, _ = coracle.shifted_score(blosum62, a, b, 0, -3)
+            assert s0 == int(sum(blosum62[x, y] for x, y in zip(b, a)))
+
+
+def test_local_never_above_gotoh(blosum62, coracle):
+    """ref <= 3-matrix Gotoh; equality is NOT required."""
+    def gotoh(a, b, go, ge):
+        NEG = -10 ** 9
+        n, m = len(a), len(b)
+        H = [[0] * (m + 1) for _ in range(n + 1)]
+        E = [[NEG] * (m + 1) for _ in range(n + 1)]
+        F = [[NEG] * (m + 1) for _ in range(n + 1)]
+        best = 0
+        for i in range(1, n + 1):
+            for j in range(1, m + 1):
+                E[i][j] = max(E[i][j - 1] + ge, H[i][j - 1] + go)
+                F[i][j] = max(F[i - 1][j] + ge, H[i - 1][j] + go)
+                H[i][j] = max(0, H[i - 1][j - 1] + int(blosum62[a[i - 1], b[j - 1]]), E[i][j], F[i][j])
+                best = max(best, H[i][j])
+        return best
+    rng = np.random.default_rng(5)
+    peps = random_peptides(rng, 50, 7, 20)
+    lower = 0
+    for _ in range(400):
+        i, j = rng.integers(0, len(peps), 2)
+        r = coracle.local_score(blosum62, peps[i], peps[j], -5, -1)
+        g = gotoh(peps[i], peps[j], -5, -1)
+        assert r <= g
+        lower += r < g
+    assert lower > 0  # the direction-matrix rule does differ from Gotoh
+
+
+def _greedy_both(coracle, M, peps, sizes, X, p, thr, maxc, n_threads=1, scorer=0):
+    res, off = coracle.pack(peps)
+    st, cid, order, stats = coracle.greedy_cluster(M, res, off, sizes, scorer, X, p, thr, maxc, n_threads)
+    seqs = [po.UniqueSequence(to_str(q), {"no_label": int(sizes[k]) if sizes is not None else 1})
+            for k, q in enumerate(peps)]
+    sc = po.ShiftedScorer(M.tolist(), p, X) if scorer == 0 else po.LocalAlignmentScorer(M.tolist(), X, p)
+    cl = po.LimitedGreedySequenceClusterer(sc, thr, maxc, n_threads=3)
+    try:
+        result = cl.cluster(seqs)
+    except po.ReferenceWouldCrash as e:
+        assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH
+        assert (stats.crash_case, stats.crash_index) == (e.case, e.index)
+        return st, None, stats
+    assert st == 0
+    index_of = {id(s): k for k, s in enumerate(seqs)}
+    py_cid = np.full(len(peps), -1, dtype=np.int32)
+    for c in result:
+        for s in c.sequences:
+            py_cid[index_of[id(s)]] = c.id
+    assert np.array_equal(py_cid, cid)
+    assert [c.id for c in result] == order.tolist()
+    assert cl.stats["score_calls_phase1"] == stats.score_calls_phase1
+    assert cl.stats["score_calls_phase2"] == stats.score_calls_phase2
+    assert cl.stats["phase1_stop_index"] == stats.phase1_stop_index
+    return st, cid, stats
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_greedy_c_vs_python_random(blosum62, coracle, seed):
+    rng = np.random.default_rng(seed)
+    # low-complexity alphabet -> dense neighbourhoods, real clusters
+    peps = random_peptides(rng, 220, 9, 12, alphabet=4 + seed)
+    sizes = rng.integers(1, 6, size=len(peps)).astype(np.int32)
+    res, off = coracle.pack(peps)
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [peps[k] for k in perm]
+    sizes = sizes[perm]
+    thr = 14 + 2 * seed
+    st, cid, stats = _greedy_both(coracle, blosum62, peps, sizes, 2, -1 if seed % 2 else 0, thr, 12)
+    if st == 0:
+        assert stats.n_multi > 0
+
+
+def test_greedy_thread_count_independent(blosum62, coracle):
+    rng = np.random.default_rng(3)
+    peps = random_peptides(rng, 400, 12, 12, alphabet=5)
+    res, off = coracle.pack(peps)
+    ref = None
+    for t in (1, 2, 8):
+        st, cid, order, stats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 20, 25, t)
+        assert st == 0
+        cur = (cid.tolist(), order.tolist(), stats.score_calls_phase1, stats.score_calls_phase2)
+        if ref is None:
+            ref = cur
+        assert cur == ref
+
+
+def test_greedy_local_scorer(blosum62, coracle):
+    rng = np.random.default_rng(9)
+    peps = random_peptides(rng, 120, 7, 14, alphabet=5)
+    st, cid, stats = _greedy_both(coracle, blosum62, peps, None, -5, -1, 18, 10, scorer=1)
+    assert st == 0
+
+
+def test_crash_parity(blosum62, coracle):
+    """The three NullPointerException rows of SURVEY.md section 3.2."""
+    far = ["WWWWWWWW", "CCCCCCCC", "PPPPPPPP", "GGGGGGGG"]  # mutually far below thr
+    # case 1: clusters empty, x has no later neighbour
+    st, _, stats = _greedy_both(coracle, blosum62, [coracle.encode(s) for s in far], None, 2, 0, 30, 3)
+    assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH and stats.crash_case == 1 and stats.crash_index == 0
+    # case 2: clusters empty and x is the last element (single sequence)
+    st, _, stats = _greedy_both(coracle, blosum62, [coracle.encode("WWWWWWWW")], None, 2, 0, 30, 3)
+    assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH and stats.crash_case == 2
+    # case 3: a cluster exists, nothing feasible, x is the last element
+    seqs = ["WWWWWWWW", "WWWWWWWF", "CCCCCCCC"]
+    st, _, stats = _greedy_both(coracle, blosum62, [coracle.encode(s) for s in seqs], None, 2, 0, 30, 3)
+    assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH and stats.crash_case == 3 and stats.crash_index == 1
+    # maxClusters reached before the last element: no crash, last stays a singleton
+    st, cid, stats = _greedy_both(coracle, blosum62, [coracle.encode(s) for s in seqs], None, 2, 0, 30, 1)
+    assert st == 0 and cid.tolist() == [0, 0, 2]
+    # empty input and maxClusters == 0: loop never runs
+    st, cid, order, stats = coracle.greedy_cluster(blosum62, *coracle.pack([]), None, 0, 2, 0, 30, 3, 1)
+    assert st == 0 and len(cid) == 0
+    st, cid, stats = _greedy_both(coracle, blosum62, [coracle.encode(s) for s in seqs], None, 2, 0, 30, 0)
+    assert st == 0 and cid.tolist() == [0, 1, 2]
+
+
+def test_musi_matches_survey_provisional(known_answers, blosum62, coracle):
+    """The C oracle reproduces every provisional MUSI figure of SURVEY.md 8(c)."""
+    exp = known_answers["musi_greedy_provisional"]
+    seqs = po.load_unique_sequences_from_fasta(os.path.join(GOLDEN, "musi.fa"))
+    assert len(seqs) == exp["n"]
+    thr, X, maxc = po.greedy_defaults(seqs)
+    assert (thr, X, maxc) == (exp["threshold"], exp["max_shift"], exp["max_clusters"])
+    po.sort_sequences(seqs, "size")
+    strings = [s.get_sequence_string() for s in seqs]
+    assert strings[:5] == exp["first_five"]
+    res, off = coracle.pack(strings)
+    n = len(strings)
+    for k, want in enumerate(exp["neighbours_ge20_first_three"]):
+        others = np.array([j for j in range(n) if j != k])
+        st, sc = coracle.score_pairs(blosum62, res, off, others, np.full(n - 1, k), 0, X, 0)
+        assert st == 0 and int((sc >= thr).sum()) == want
+    st, cid, order, stats = coracle.greedy_cluster(blosum62, res, off, None, 0, X, 0, thr, maxc, 2)
+    assert st == 0
+    assert stats.phase1_stop_index == exp["phase1_stop_index"]
+    assert stats.phase1_clusters == exp["phase1_clusters"] and stats.phase1_orphans == exp["phase1_orphans"]
+    assert stats.score_calls_phase1 == exp["score_calls_phase1"]
+    assert stats.score_calls_phase2 == exp["score_calls_phase2"]
+    sizes = np.bincount(cid)
+    sizes = np.sort(sizes[sizes > 1])[::-1]
+    assert len(sizes) == exp["final_clusters"]
+    assert int((np.bincount(cid) == 1).sum()) == exp["final_singletons"]
+    assert sizes[:10].tolist() == exp["ten_largest_unique_sizes"]
+    with open(os.path.join(GOLDEN, "musi_greedy_oracle.json")) as fh:
+        pin = json.load(fh)
+    assert pin["order"] == strings and pin["cluster_id"] == cid.tolist()
+
+
+def test_sort_orders(coracle):
+    rng = np.random.default_rng(2)
+    peps = random_peptides(rng, 300, 7, 12, alphabet=24)
+    sizes = rng.integers(1, 4, size=len(peps)).astype(np.int32)
+    res, off = coracle.pack(peps)
+    for order in ("size", "alphabetic", "input"):
+        perm = coracle.sort_order(res, off, sizes, order)
+        seqs = [po.UniqueSequence(to_str(p), {"x": int(sizes[k])}) for k, p in enumerate(peps)]
+        idx = {id(s): k for k, s in enumerate(seqs)}
+        po.sort_sequences(seqs, order)
+        assert [idx[id(s)] for s in seqs] == perm.tolist()
+
+
+def test_java_random_shuffle_known_values():
+    # java.util.Random(42): first nextInt() values are a widely published sequence
+    r = po.JavaRandom(42)
+    assert [r.next(32) for _ in range(3)] == [-1170105035, 234785527, -1360544799]
+    r = po.JavaRandom(42)
+    assert [r.next_int(10) for _ in range(5)] == [0, 3, 8, 4, 0]
+
+
+def test_loaders_manual_example():
+    seqs = po.load_unique_sequences_from_fasta(os.path.join(GOLDEN, "manual_example.fa"))
+    with open(os.path.join(GOLDEN, "manual_example_expected.json")) as fh:
+        exp = json.load(fh)["sequences"]
+    assert [[s.get_sequence_string(), s.labels_map] for s in seqs] == exp
+    tab = po.load_unique_sequences_from_table(os.path.join(GOLDEN, "manual_example.tsv"))
+    assert [[s.get_sequence_string(), s.labels_map] for s in tab] == exp
+
+
+def test_synth_generator(coracle):
+    res, off = coracle.synth(1, 1000, 12)
+    assert len(res) == 12000 and res.max() < 20
+    assert len({res[off[k]:off[k + 1]].tobytes() for k in range(1000)}) == 1000
+    res2, off2 = coracle.synth(1, 500, 7, 20)
+    L = np.diff(off2.astype(np.int64))
+    assert L.min() >= 7 and L.max() <= 20 and len(set(L.tolist())) == 14
