@@ -1,0 +1,84 @@
+"""ctypes binding of libhammock_hip.so (include/hammock_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C hammock_amd/csrc``.  There is no fallback of any kind: if the shared
+object is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhammock_hip.so")
+
+HMK_OK = 0
+HMK_ERR_BAD_ARG = 1
+HMK_ERR_SHIFT_TOO_BIG = 2
+HMK_ERR_DEVICE = 3
+HMK_ERR_OOM = 4
+HMK_ERR_REFERENCE_WOULD_CRASH = 5
+HMK_ERR_CAPACITY = 6
+HMK_ERR_NO_SEQUENCES = 7
+HMK_EDGE_SHARDS = 16
+HMK_MAX_LEN = 32
+
+# every symbol include/hammock_hip.h declares
+SYMBOLS = [
+    "hmk_abi_version", "hmk_create", "hmk_destroy", "hmk_last_error", "hmk_set_sequences",
+    "hmk_score_pairs_shifted", "hmk_score_pairs_local", "hmk_score_block_shifted", "hmk_score_block_local",
+    "hmk_neighbors_shifted", "hmk_neighbors_shifted_dev", "hmk_neighbors_last_plan",
+    "hmk_greedy_cluster", "hmk_greedy_from_edges",
+]
+
+
+class NeighborStats(C.Structure):
+    _fields_ = [
+        ("n_edges", C.c_uint64), ("pairs_scored", C.c_uint64), ("n_tiles", C.c_uint32),
+        ("symmetric", C.c_uint32), ("classes_u8", C.c_uint32), ("classes_u16", C.c_uint32),
+        ("classes_direct", C.c_uint32), ("reserved", C.c_uint32), ("kernel_ms", C.c_double),
+    ]
+
+
+class GreedyStats(C.Structure):
+    _fields_ = [
+        ("n_edges", C.c_uint64), ("phase1_stop_index", C.c_int32), ("phase1_clusters", C.c_int32),
+        ("phase1_orphans", C.c_int32), ("crash_case", C.c_int32), ("crash_index", C.c_int32),
+        ("n_result_clusters", C.c_int32), ("n_multi", C.c_int32), ("reserved", C.c_int32),
+        ("neighbors_ms", C.c_double), ("greedy_ms", C.c_double),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C hammock_amd/csrc`.  hammock_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64
+    p_i32, p_u32, p_u64, p_u8 = (C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                 C.POINTER(C.c_uint8))
+    L.hmk_abi_version.restype = i32
+    L.hmk_create.argtypes = [p_i32, i32, C.POINTER(vp)]
+    L.hmk_destroy.argtypes = [vp]
+    L.hmk_destroy.restype = None
+    L.hmk_last_error.argtypes = [vp]
+    L.hmk_last_error.restype = C.c_char_p
+    L.hmk_set_sequences.argtypes = [vp, p_u8, p_u32, p_i32, u32]
+    L.hmk_score_pairs_shifted.argtypes = [vp, p_u32, p_u32, u64, i32, i32, p_i32]
+    L.hmk_score_pairs_local.argtypes = [vp, p_u32, p_u32, u64, i32, i32, p_i32]
+    L.hmk_score_block_shifted.argtypes = [vp, u32, u32, u32, u32, i32, i32, p_i32]
+    L.hmk_score_block_local.argtypes = [vp, u32, u32, u32, u32, i32, i32, p_i32]
+    L.hmk_neighbors_shifted.argtypes = [vp, i32, i32, i32, u32, u32, p_u64, u64, p_u64, C.POINTER(NeighborStats)]
+    L.hmk_neighbors_shifted_dev.argtypes = [vp, i32, i32, i32, u32, u32, vp, u64, vp, vp]
+    L.hmk_neighbors_last_plan.argtypes = [vp, C.POINTER(NeighborStats)]
+    L.hmk_greedy_cluster.argtypes = [vp, i32, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
+    L.hmk_greedy_from_edges.argtypes = [vp, p_u64, u64, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("hmk_destroy", "hmk_last_error"):
+            fn.restype = i32
+    return L
+
+
+lib = _load()

@@ -1,0 +1,670 @@
+// hmk_api.cpp -- the C ABI of libhammock_hip.so (include/hammock_hip.h):
+// context, sequence upload, neighbour-kernel planning, launches, host buffers.
+// Host code only; the kernels live in hmk_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "hmk_internal.h"
+#include "hmk_kernels.h"
+
+using namespace hmk;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Group {
+    int path;
+    int nw;
+    uint32_t base, count;
+};
+
+struct Plan {
+    bool valid = false;
+    int X = 0, p = 0, thr = 0;
+    uint32_t part = 0, n_parts = 1;
+    int lbmax = 12, lpad = 16;
+    bool exact = false;
+    uint8_t *d_res_sorted = nullptr;
+    uint32_t *d_perm = nullptr;
+    uint8_t *d_mb = nullptr;
+    TileClass *d_classes = nullptr;
+    Tile *d_tiles = nullptr;
+    std::vector<Group> groups;
+    hmk_neighbor_stats stats{};
+};
+
+}  // namespace
+
+struct hmk_ctx {
+    int32_t M[HMK_ALPHABET * HMK_ALPHABET];
+    bool symmetric = true;
+    int min_m = 0, max_m = 0;
+    int device = -1;
+    bool has_device = false;
+
+    uint32_t n = 0;
+    std::vector<uint8_t> res;
+    std::vector<uint32_t> off;
+    std::vector<int32_t> sizes;
+    bool has_sizes = false;
+    std::vector<uint8_t> len;
+    int min_len = 0, max_len = 0;
+
+    uint8_t *d_res32 = nullptr;
+    uint8_t *d_len = nullptr;
+    int32_t *d_M = nullptr;
+
+    Plan plan;
+    uint64_t *d_edges = nullptr;  // internal buffer of the host-buffer entry points
+    uint64_t d_edges_cap = 0;
+    unsigned long long *d_counts = nullptr;
+
+    std::string err;
+    std::mutex mu;
+};
+
+namespace {
+
+int fail(hmk_ctx *ctx, int code, const std::string &msg) {
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,          \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+int need_device(hmk_ctx *ctx) {
+    if (!ctx->has_device)
+        return fail(ctx, HMK_ERR_DEVICE,
+                    "this context has no GPU (created with device = -1); scoring has no CPU fallback");
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return fail(ctx, HMK_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return HMK_OK;
+}
+
+void free_plan(Plan &pl) {
+    if (pl.d_res_sorted) (void)hipFree(pl.d_res_sorted);
+    if (pl.d_perm) (void)hipFree(pl.d_perm);
+    if (pl.d_mb) (void)hipFree(pl.d_mb);
+    if (pl.d_classes) (void)hipFree(pl.d_classes);
+    if (pl.d_tiles) (void)hipFree(pl.d_tiles);
+    pl = Plan();
+}
+
+// Lane layout of one (row length, column length) class; see DESIGN.md "SWAR tables".
+void classify(const hmk_ctx *ctx, int la, int lb, int X, int p, int thr, TileClass *out) {
+    TileClass c{};
+    const int m = std::min(la, lb), nl = std::max(la, lb);
+    const int d = nl - m;
+    const int nd = 2 * X + d + 1;
+    c.la = (uint8_t)la;
+    c.lb = (uint8_t)lb;
+    c.nd = (uint8_t)std::min(nd, 255);
+    c.case_b = lb < la;
+    c.x = (uint8_t)X;
+    c.d = d;
+    const int bias = ctx->min_m < 0 ? -ctx->min_m : 0;
+    const long long cell_max = (long long)ctx->max_m + bias;
+    c.path = PATH_DIRECT;
+    for (int attempt = 0; attempt < 2 && c.path == PATH_DIRECT; attempt++) {
+        const bool u16 = attempt == 1;
+        const long long lane_max = u16 ? 65535 : 255;
+        const long long g = (u16 ? 32768LL : 128LL) - thr;
+        const int max_nd = u16 ? 16 : 32;
+        if (nd > max_nd || cell_max > 255) continue;
+        bool ok = true;
+        long long ci[32];
+        for (int t = 0; t < nd && ok; t++) {
+            const int s = t - X;
+            const long long ncell = s <= 0 ? m + s : std::min(m, nl - s);
+            long long pen = (long long)d * p;                       // ShiftedScorer.java:79
+            if (s < 0) pen += (long long)(-s) * 2 * p;              // :80-82
+            if (s > d) pen += (long long)(s - d) * 2 * p;           // :83-85
+            const long long c0 = g + pen - bias * ncell;
+            if (c0 < 0 || c0 + ncell * cell_max > lane_max) ok = false;
+            ci[t] = c0;
+        }
+        if (!ok) continue;
+        c.path = u16 ? PATH_U16 : PATH_U8;
+        c.g = (int32_t)g;
+        const int lpd = u16 ? 2 : 4, bits = u16 ? 16 : 8;
+        const int ndw = (nd + lpd - 1) / lpd;
+        c.nw = ndw <= 1 ? 1 : ndw <= 2 ? 2 : ndw <= 4 ? 4 : 8;
+        for (int t = 0; t < nd; t++) c.cinit[t / lpd] |= (uint32_t)ci[t] << ((t % lpd) * bits);
+    }
+    *out = c;
+}
+
+int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts) {
+    Plan &pl = ctx->plan;
+    if (pl.valid && pl.X == X && pl.p == p && pl.thr == thr && pl.part == part && pl.n_parts == n_parts)
+        return HMK_OK;
+    free_plan(pl);
+    const uint32_t n = ctx->n;
+    if (n == 0) return fail(ctx, HMK_ERR_NO_SEQUENCES, "no sequences set (hmk_set_sequences)");
+    if (X < 0) return fail(ctx, HMK_ERR_BAD_ARG, "max_shift must be >= 0");
+    if (n_parts == 0 || part >= n_parts) return fail(ctx, HMK_ERR_BAD_ARG, "part must be < n_parts");
+    if (X >= ctx->min_len)
+        return fail(ctx, HMK_ERR_SHIFT_TOO_BIG,
+                    "Shift too big: " + std::to_string(ctx->min_len - 1) + " is maximum, but " + std::to_string(X) +
+                        " found");  // ShiftedScorer.java:59-62
+    if (thr < -30000 || thr > 30000) return fail(ctx, HMK_ERR_BAD_ARG, "threshold outside [-30000, 30000]");
+
+    // ---- bucket by length ("sorted order") --------------------------------------
+    uint32_t bucket[HMK_MAX_LEN + 2] = {0};
+    for (uint32_t k = 0; k < n; k++) bucket[ctx->len[k] + 1]++;
+    for (int l = 0; l <= HMK_MAX_LEN; l++) bucket[l + 1] += bucket[l];
+    std::vector<uint32_t> perm(n);
+    {
+        uint32_t fill[HMK_MAX_LEN + 2];
+        std::memcpy(fill, bucket, sizeof(fill));
+        for (uint32_t k = 0; k < n; k++) perm[fill[ctx->len[k]]++] = k;
+    }
+    pl.lbmax = ctx->max_len <= 12 ? 12 : ctx->max_len <= 20 ? 20 : 32;
+    pl.lpad = pl.lbmax == 12 ? 16 : 32;
+    pl.exact = ctx->min_len == 12 && ctx->max_len == 12;
+
+    // ---- classes and tiles --------------------------------------------------------
+    std::vector<TileClass> classes;
+    std::map<int, int> class_of;  // la * 64 + lb
+    std::map<std::pair<int, int>, std::vector<Tile>> grouped;  // (path, nw)
+    const uint32_t COLS = 4096;
+    hmk_neighbor_stats &S = pl.stats;
+    S = hmk_neighbor_stats{};
+    S.symmetric = ctx->symmetric;
+    uint64_t row_chunk_counter = 0;
+    for (int la = 1; la <= HMK_MAX_LEN; la++) {
+        const uint32_t rb = bucket[la], re = bucket[la + 1];
+        if (rb == re) continue;
+        for (int lb = 1; lb <= HMK_MAX_LEN; lb++) {
+            const uint32_t cb = bucket[lb], ce = bucket[lb + 1];
+            if (cb == ce) continue;
+            if (ctx->symmetric && lb < la) continue;  // unordered pairs: shorter bucket supplies the rows
+            const bool same = la == lb;
+            if (same && re - rb < 2) continue;
+            TileClass tc;
+            classify(ctx, la, lb, X, p, thr, &tc);
+            const int cls = (int)classes.size();
+            classes.push_back(tc);
+            class_of[la * 64 + lb] = cls;
+            if (tc.path == PATH_U8) S.classes_u8++;
+            else if (tc.path == PATH_U16) S.classes_u16++;
+            else S.classes_direct++;
+            const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(pl.lbmax, tc.nw);
+            std::vector<Tile> &dst = grouped[{tc.path, tc.path == PATH_DIRECT ? 0 : tc.nw}];
+            for (uint32_t r0 = rb; r0 < re; r0 += R) {
+                const bool mine = (row_chunk_counter++ % n_parts) == part;
+                if (!mine) continue;
+                const uint32_t nr = std::min(R, re - r0);
+                uint32_t c_lo = cb, c_hi = ce;
+                if (same && ctx->symmetric) c_lo = r0 + 1;  // triangle: columns after the first row of the chunk
+                for (uint32_t c0 = c_lo; c0 < c_hi; c0 += COLS) {
+                    Tile t{};
+                    t.row0 = r0; t.nrows = nr;
+                    t.col0 = c0; t.ncols = std::min(COLS, c_hi - c0);
+                    t.cls = (uint32_t)cls;
+                    const bool overlap = same && c0 < r0 + nr && c0 + t.ncols > r0;
+                    t.diag = overlap ? (ctx->symmetric ? 1u : 2u) : 0u;
+                    uint64_t pairs = (uint64_t)nr * t.ncols;
+                    if (t.diag == 1) {
+                        pairs = 0;
+                        for (uint32_t r = r0; r < r0 + nr; r++) {
+                            const uint32_t lo = std::max(c0, r + 1), hi = c0 + t.ncols;
+                            if (hi > lo) pairs += hi - lo;
+                        }
+                    } else if (t.diag == 2) {
+                        for (uint32_t r = r0; r < r0 + nr; r++)
+                            if (r >= c0 && r < c0 + t.ncols) pairs--;
+                    }
+                    if (pairs == 0) continue;
+                    S.pairs_scored += pairs;
+                    dst.push_back(t);
+                }
+            }
+        }
+    }
+    std::vector<Tile> tiles;
+    for (auto &kv : grouped) {
+        if (kv.second.empty()) continue;
+        pl.groups.push_back(Group{kv.first.first, kv.first.second, (uint32_t)tiles.size(), (uint32_t)kv.second.size()});
+        tiles.insert(tiles.end(), kv.second.begin(), kv.second.end());
+    }
+    S.n_tiles = (uint32_t)tiles.size();
+
+    // ---- device copies ------------------------------------------------------------
+    std::vector<uint8_t> res_sorted((size_t)n * pl.lpad, 0);
+    for (uint32_t s = 0; s < n; s++) {
+        const uint32_t k = perm[s];
+        std::memcpy(&res_sorted[(size_t)s * pl.lpad], &ctx->res[ctx->off[k]], ctx->len[k]);
+    }
+    const int bias = ctx->min_m < 0 ? -ctx->min_m : 0;
+    uint8_t mb[576];
+    for (int e = 0; e < 576; e++) {
+        const long long v = (long long)ctx->M[e] + bias;
+        mb[e] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);  // only read by classes that passed the range check
+    }
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_res_sorted, res_sorted.size()));
+    HIPCHK(ctx, hipMemcpy(pl.d_res_sorted, res_sorted.data(), res_sorted.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_perm, (size_t)n * 4));
+    HIPCHK(ctx, hipMemcpy(pl.d_perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_mb, 576));
+    HIPCHK(ctx, hipMemcpy(pl.d_mb, mb, 576, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_classes, std::max<size_t>(1, classes.size()) * sizeof(TileClass)));
+    if (!classes.empty())
+        HIPCHK(ctx, hipMemcpy(pl.d_classes, classes.data(), classes.size() * sizeof(TileClass), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_tiles, std::max<size_t>(1, tiles.size()) * sizeof(Tile)));
+    if (!tiles.empty())
+        HIPCHK(ctx, hipMemcpy(pl.d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    pl.X = X; pl.p = p; pl.thr = thr; pl.part = part; pl.n_parts = n_parts;
+    pl.valid = true;
+    return HMK_OK;
+}
+
+int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
+                         uint64_t capacity, void *d_counts, hipStream_t stream) {
+    int st = need_device(ctx);
+    if (st) return st;
+    if (!d_edges || !d_counts || capacity < HMK_EDGE_SHARDS)
+        return fail(ctx, HMK_ERR_BAD_ARG, "d_edges/d_counts must be device buffers, capacity >= HMK_EDGE_SHARDS");
+    st = build_plan(ctx, X, p, thr, part, n_parts);
+    if (st) return st;
+    Plan &pl = ctx->plan;
+    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), stream));
+    NeighborParams P{};
+    P.res_sorted = pl.d_res_sorted;
+    P.perm = pl.d_perm;
+    P.mb = pl.d_mb;
+    P.classes = pl.d_classes;
+    P.tiles = pl.d_tiles;
+    P.edges = (uint64_t *)d_edges;
+    P.counts = (unsigned long long *)d_counts;
+    P.cap_per_shard = capacity / HMK_EDGE_SHARDS;
+    P.n_tiles = pl.stats.n_tiles;
+    P.lpad = (uint32_t)pl.lpad;
+    P.symmetric = ctx->symmetric ? 1u : 0u;
+    for (const Group &g : pl.groups) {
+        if (g.path == PATH_DIRECT)
+            HIPCHK(ctx, launch_neighbors_direct(P, g.base, g.count, ctx->d_M, X, p, thr, stream));
+        else
+            HIPCHK(ctx, launch_neighbors_swar(pl.lbmax, g.nw, pl.exact, P, g.base, g.count, stream));
+    }
+    return HMK_OK;
+}
+
+// Runs the neighbour pass into the context's own device buffer, growing it until
+// every segment fits, and returns the per-segment counts.
+int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, uint64_t want_cap,
+                       unsigned long long counts[HMK_EDGE_SHARDS], double *kernel_ms) {
+    int st = need_device(ctx);
+    if (st) return st;
+    if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
+    uint64_t cap = std::max<uint64_t>(want_cap, (uint64_t)HMK_EDGE_SHARDS * 65536);
+    cap = (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (ctx->d_edges_cap < cap) {
+            if (ctx->d_edges) (void)hipFree(ctx->d_edges);
+            ctx->d_edges = nullptr;
+            ctx->d_edges_cap = 0;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t)));
+            ctx->d_edges_cap = cap;
+        }
+        HIPCHK(ctx, hipEventRecord(e0, nullptr));
+        st = neighbors_dev_locked(ctx, X, p, thr, part, n_parts, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, nullptr);
+        if (st) break;
+        HIPCHK(ctx, hipEventRecord(e1, nullptr));
+        HIPCHK(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (kernel_ms) *kernel_ms = ms;
+        HIPCHK(ctx, hipMemcpy(counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long mx = 0;
+        for (int s = 0; s < HMK_EDGE_SHARDS; s++) mx = std::max(mx, counts[s]);
+        if (mx <= ctx->d_edges_cap / HMK_EDGE_SHARDS) {
+            st = HMK_OK;
+            break;
+        }
+        cap = (uint64_t)HMK_EDGE_SHARDS * (mx + mx / 8 + 1024);  // a segment overflowed: grow and rescore
+        st = HMK_ERR_CAPACITY;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (st == HMK_ERR_CAPACITY) return fail(ctx, st, "internal edge buffer kept overflowing");
+    return st;
+}
+
+int check_pairs(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, bool shifted, int X) {
+    if (ctx->n == 0) return fail(ctx, HMK_ERR_NO_SEQUENCES, "no sequences set (hmk_set_sequences)");
+    if (n_pairs && (!i || !j)) return fail(ctx, HMK_ERR_BAD_ARG, "null index array");
+    for (uint64_t k = 0; k < n_pairs; k++) {
+        if (i[k] >= ctx->n || j[k] >= ctx->n) return fail(ctx, HMK_ERR_BAD_ARG, "pair index out of range");
+        if (shifted && X >= std::min(ctx->len[i[k]], ctx->len[j[k]]))
+            return fail(ctx, HMK_ERR_SHIFT_TOO_BIG,
+                        "Shift too big: " + std::to_string(std::min(ctx->len[i[k]], ctx->len[j[k]]) - 1) +
+                            " is maximum, but " + std::to_string(X) + " found");
+    }
+    return HMK_OK;
+}
+
+int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, int a, int b,
+                int32_t *out) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int st = need_device(ctx);
+    if (st) return st;
+    if (scorer == 0 && a < 0) return fail(ctx, HMK_ERR_BAD_ARG, "max_shift must be >= 0");
+    st = check_pairs(ctx, i, j, n_pairs, scorer == 0, a);
+    if (st) return st;
+    if (n_pairs && !out) return fail(ctx, HMK_ERR_BAD_ARG, "null output");
+    const uint64_t CH = 1ull << 24;
+    uint32_t *d_i = nullptr, *d_j = nullptr;
+    int32_t *d_out = nullptr;
+    const uint64_t ch = std::min<uint64_t>(CH, std::max<uint64_t>(n_pairs, 1));
+    HIPCHK(ctx, hipMalloc((void **)&d_i, ch * 4));
+    HIPCHK(ctx, hipMalloc((void **)&d_j, ch * 4));
+    HIPCHK(ctx, hipMalloc((void **)&d_out, ch * 4));
+    st = HMK_OK;
+    for (uint64_t o = 0; o < n_pairs && st == HMK_OK; o += ch) {
+        const uint64_t m = std::min(ch, n_pairs - o);
+        hipError_t e = hipMemcpy(d_i, i + o, m * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_j, j + o, m * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, d_i, d_j, m, 0, 0, 1, a, b, d_out, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(out + o, d_out, m * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = fail(ctx, HMK_ERR_DEVICE, std::string("score_pairs: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_i);
+    (void)hipFree(d_j);
+    (void)hipFree(d_out);
+    return st;
+}
+
+int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int a, int b,
+                int32_t *out) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int st = need_device(ctx);
+    if (st) return st;
+    if (ctx->n == 0) return fail(ctx, HMK_ERR_NO_SEQUENCES, "no sequences set (hmk_set_sequences)");
+    if (r0 > r1 || c0 > c1 || r1 > ctx->n || c1 > ctx->n) return fail(ctx, HMK_ERR_BAD_ARG, "block outside [0, n)");
+    const uint64_t n_pairs = (uint64_t)(r1 - r0) * (c1 - c0);
+    if (n_pairs == 0) return HMK_OK;
+    if (!out) return fail(ctx, HMK_ERR_BAD_ARG, "null output");
+    if (scorer == 0) {
+        if (a < 0) return fail(ctx, HMK_ERR_BAD_ARG, "max_shift must be >= 0");
+        int mn = 255;
+        for (uint32_t r = r0; r < r1; r++) mn = std::min<int>(mn, ctx->len[r]);
+        for (uint32_t c = c0; c < c1; c++) mn = std::min<int>(mn, ctx->len[c]);
+        if (a >= mn)
+            return fail(ctx, HMK_ERR_SHIFT_TOO_BIG, "Shift too big: " + std::to_string(mn - 1) + " is maximum, but " +
+                                                        std::to_string(a) + " found");
+    }
+    int32_t *d_out = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_out, n_pairs * 4));
+    hipError_t e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, nullptr, nullptr, n_pairs, r0, c0, c1 - c0, a, b,
+                                d_out, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, n_pairs * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(ctx, HMK_ERR_DEVICE, std::string("score_block: ") + hipGetErrorString(e));
+    return HMK_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" {
+
+int hmk_abi_version(void) { return HMK_ABI_VERSION; }
+
+const char *hmk_last_error(const hmk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
+    if (!matrix || !out) return fail(nullptr, HMK_ERR_BAD_ARG, "hmk_create: null argument");
+    *out = nullptr;
+    hmk_ctx *ctx = new (std::nothrow) hmk_ctx();
+    if (!ctx) return fail(nullptr, HMK_ERR_OOM, "out of memory");
+    std::memcpy(ctx->M, matrix, sizeof(ctx->M));
+    ctx->min_m = ctx->max_m = matrix[0];
+    for (int e = 0; e < 576; e++) {
+        ctx->min_m = std::min(ctx->min_m, matrix[e]);
+        ctx->max_m = std::max(ctx->max_m, matrix[e]);
+        if (matrix[e] != matrix[(e % 24) * 24 + e / 24]) ctx->symmetric = false;
+        if (matrix[e] < -1000 || matrix[e] > 1000) {
+            delete ctx;
+            return fail(nullptr, HMK_ERR_BAD_ARG, "matrix entries must lie in [-1000, 1000] (int16 edge scores)");
+        }
+    }
+    ctx->device = device;
+    if (device >= 0) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || device >= count) {
+            delete ctx;
+            return fail(nullptr, HMK_ERR_DEVICE,
+                        "no HIP device " + std::to_string(device) + " (" +
+                            (e != hipSuccess ? hipGetErrorString(e) : "device count " + std::to_string(count)) + ")");
+        }
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        if (e != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            std::string arch = e == hipSuccess ? prop.gcnArchName : "?";
+            delete ctx;
+            return fail(nullptr, HMK_ERR_DEVICE, "libhammock_hip is built for gfx950 (MI355X) only; device is " + arch);
+        }
+        e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_M, sizeof(ctx->M));
+        if (e == hipSuccess) e = hipMemcpy(ctx->d_M, ctx->M, sizeof(ctx->M), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            delete ctx;
+            return fail(nullptr, HMK_ERR_DEVICE, std::string("hmk_create: ") + hipGetErrorString(e));
+        }
+        ctx->has_device = true;
+    } else if (device != -1) {
+        delete ctx;
+        return fail(nullptr, HMK_ERR_BAD_ARG, "device must be >= 0 or -1 (host-only)");
+    }
+    *out = ctx;
+    return HMK_OK;
+}
+
+void hmk_destroy(hmk_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->has_device) {
+        (void)hipSetDevice(ctx->device);
+        free_plan(ctx->plan);
+        if (ctx->d_res32) (void)hipFree(ctx->d_res32);
+        if (ctx->d_len) (void)hipFree(ctx->d_len);
+        if (ctx->d_M) (void)hipFree(ctx->d_M);
+        if (ctx->d_edges) (void)hipFree(ctx->d_edges);
+        if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    }
+    delete ctx;
+}
+
+int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *offsets, const int32_t *sizes,
+                      uint32_t n) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (n > HMK_MAX_SEQUENCES) return fail(ctx, HMK_ERR_BAD_ARG, "more than 2^24 sequences");
+    if (n && (!residues || !offsets)) return fail(ctx, HMK_ERR_BAD_ARG, "null residues/offsets");
+    if (n && offsets[0] != 0) return fail(ctx, HMK_ERR_BAD_ARG, "offsets[0] must be 0");
+    std::vector<uint8_t> len(n);
+    int mn = 1 << 30, mx = 0;
+    for (uint32_t k = 0; k < n; k++) {
+        if (offsets[k + 1] < offsets[k]) return fail(ctx, HMK_ERR_BAD_ARG, "offsets must be non-decreasing");
+        const uint32_t l = offsets[k + 1] - offsets[k];
+        if (l < 1 || l > HMK_MAX_LEN)
+            return fail(ctx, HMK_ERR_BAD_ARG, "sequence " + std::to_string(k) + " has length " + std::to_string(l) +
+                                                  "; the GPU kernels take 1.." + std::to_string(HMK_MAX_LEN));
+        len[k] = (uint8_t)l;
+        mn = std::min<int>(mn, l);
+        mx = std::max<int>(mx, l);
+        if (sizes && sizes[k] < 1) return fail(ctx, HMK_ERR_BAD_ARG, "sizes must be >= 1");
+    }
+    const uint32_t total = n ? offsets[n] : 0;
+    for (uint32_t q = 0; q < total; q++)
+        if (residues[q] >= HMK_ALPHABET) return fail(ctx, HMK_ERR_BAD_ARG, "residue index >= 24");
+    if (ctx->has_device) {
+        int st = need_device(ctx);
+        if (st) return st;
+        free_plan(ctx->plan);
+        if (ctx->d_res32) (void)hipFree(ctx->d_res32);
+        if (ctx->d_len) (void)hipFree(ctx->d_len);
+        ctx->d_res32 = nullptr;
+        ctx->d_len = nullptr;
+        if (n) {
+            std::vector<uint8_t> res32((size_t)n * 32, 0);
+            for (uint32_t k = 0; k < n; k++) std::memcpy(&res32[(size_t)k * 32], residues + offsets[k], len[k]);
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_res32, res32.size()));
+            HIPCHK(ctx, hipMemcpy(ctx->d_res32, res32.data(), res32.size(), hipMemcpyHostToDevice));
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_len, n));
+            HIPCHK(ctx, hipMemcpy(ctx->d_len, len.data(), n, hipMemcpyHostToDevice));
+        }
+    }
+    ctx->n = n;
+    ctx->res.assign(residues, residues + total);
+    ctx->off.assign(offsets, offsets + (n ? n + 1 : 0));
+    if (!n) ctx->off.assign(1, 0);
+    ctx->has_sizes = sizes != nullptr;
+    if (sizes) ctx->sizes.assign(sizes, sizes + n);
+    else ctx->sizes.clear();
+    ctx->len.swap(len);
+    ctx->min_len = n ? mn : 0;
+    ctx->max_len = mx;
+    return HMK_OK;
+}
+
+int hmk_score_pairs_shifted(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, int max_shift,
+                            int shift_penalty, int32_t *out) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    return score_pairs(ctx, 0, i, j, n_pairs, max_shift, shift_penalty, out);
+}
+
+int hmk_score_pairs_local(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, int gap_open,
+                          int gap_extend, int32_t *out) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    return score_pairs(ctx, 1, i, j, n_pairs, gap_open, gap_extend, out);
+}
+
+int hmk_score_block_shifted(hmk_ctx *ctx, uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int max_shift,
+                            int shift_penalty, int32_t *out) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    return score_block(ctx, 0, r0, r1, c0, c1, max_shift, shift_penalty, out);
+}
+
+int hmk_score_block_local(hmk_ctx *ctx, uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int gap_open,
+                          int gap_extend, int32_t *out) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    return score_block(ctx, 1, r0, r1, c0, c1, gap_open, gap_extend, out);
+}
+
+int hmk_neighbors_shifted_dev(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, uint32_t part,
+                              uint32_t n_parts, void *d_edges, uint64_t capacity, void *d_counts, void *stream) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, part, n_parts, d_edges, capacity, d_counts,
+                                (hipStream_t)stream);
+}
+
+int hmk_neighbors_last_plan(hmk_ctx *ctx, hmk_neighbor_stats *stats) {
+    if (!ctx || !stats) return fail(ctx, HMK_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->plan.valid) return fail(ctx, HMK_ERR_BAD_ARG, "no neighbour pass has been planned yet");
+    *stats = ctx->plan.stats;
+    return HMK_OK;
+}
+
+int hmk_neighbors_shifted(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, uint32_t part,
+                          uint32_t n_parts, uint64_t *edges, uint64_t capacity, uint64_t *n_edges,
+                          hmk_neighbor_stats *stats) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!n_edges) return fail(ctx, HMK_ERR_BAD_ARG, "n_edges must not be null");
+    unsigned long long counts[HMK_EDGE_SHARDS];
+    double ms = 0;
+    int st = neighbors_internal(ctx, max_shift, shift_penalty, threshold, part, n_parts, capacity, counts, &ms);
+    if (st) return st;
+    uint64_t total = 0;
+    for (int s = 0; s < HMK_EDGE_SHARDS; s++) total += counts[s];
+    *n_edges = total;
+    if (stats) {
+        *stats = ctx->plan.stats;
+        stats->n_edges = total;
+        stats->kernel_ms = ms;
+    }
+    if (total > capacity) return fail(ctx, HMK_ERR_CAPACITY, "edge buffer too small: " + std::to_string(total) + " needed");
+    if (total && !edges) return fail(ctx, HMK_ERR_BAD_ARG, "null edge buffer");
+    const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
+    uint64_t o = 0;
+    for (int s = 0; s < HMK_EDGE_SHARDS; s++) {
+        if (counts[s])
+            HIPCHK(ctx, hipMemcpy(edges + o, ctx->d_edges + (uint64_t)s * seg, counts[s] * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        o += counts[s];
+    }
+    return HMK_OK;
+}
+
+int hmk_greedy_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges, int symmetric, int threshold,
+                          int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
+                          hmk_greedy_stats *stats) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->n && !cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
+    if (n_edges && !edges) return fail(ctx, HMK_ERR_BAD_ARG, "null edge list");
+    std::string err;
+    int st = greedy_from_edges(ctx->n, ctx->has_sizes ? ctx->sizes.data() : nullptr, edges, n_edges, symmetric != 0,
+                               threshold, max_clusters, cluster_id, result_order, member_rank, stats, &err);
+    if (st) return fail(ctx, st, err);
+    return HMK_OK;
+}
+
+int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters,
+                       int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->n && !cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
+    hmk_greedy_stats local;
+    if (!stats) stats = &local;
+    std::memset(stats, 0, sizeof(*stats));
+    if (ctx->n == 0) return HMK_OK;  // cluster() of an empty list returns an empty list
+    unsigned long long counts[HMK_EDGE_SHARDS];
+    double ms = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    int st = neighbors_internal(ctx, max_shift, shift_penalty, threshold, 0, 1, 0, counts, &ms);
+    if (st) return st;
+    uint64_t total = 0;
+    for (int s = 0; s < HMK_EDGE_SHARDS; s++) total += counts[s];
+    std::vector<uint64_t> edges(total);
+    const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
+    uint64_t o = 0;
+    for (int s = 0; s < HMK_EDGE_SHARDS; s++) {
+        if (counts[s])
+            HIPCHK(ctx, hipMemcpy(edges.data() + o, ctx->d_edges + (uint64_t)s * seg, counts[s] * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        o += counts[s];
+    }
+    const double nb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::string err;
+    st = greedy_from_edges(ctx->n, ctx->has_sizes ? ctx->sizes.data() : nullptr, edges.data(), total, ctx->symmetric,
+                           threshold, max_clusters, cluster_id, result_order, member_rank, stats, &err);
+    stats->neighbors_ms = nb_ms;
+    if (st) return fail(ctx, st, err);
+    return HMK_OK;
+}
+
+}  // extern "C"

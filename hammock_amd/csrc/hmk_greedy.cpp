@@ -1,0 +1,236 @@
+// hmk_greedy.cpp -- host-side exact greedy merge on the GPU's thresholded
+// neighbour graph.  Pure C++ (no HIP): part of the product path, it is what
+// north_star calls "the host-side greedy merge".
+//
+// It reproduces LimitedGreedySequenceClusterer.cluster
+// (LimitedGreedySequenceClusterer.java:39-120) exactly, but instead of calling
+// the scorer pair by pair it reads the edge list the neighbour kernel produced:
+//
+//   ClinkageClusterScorer.clusterScore(c, x) (ClinkageClusterScorer.java:30-49)
+//     = min over members m of score(m, x), or MIN_VALUE+1 as soon as one
+//       score is below the threshold
+//   => c is "feasible" for x  <=>  every member of c is a neighbour of x in the
+//      >= threshold graph, and then the cluster score is the min of the stored
+//      edge scores.  One pass over adj[x] with a per-cluster counter decides
+//      all clusters at once.
+//
+//   findNearestClusterParallel (ClinkageSequenceClusterer.java:137-177,258-293)
+//     = arg-max over feasible clusters of (score, Cluster.size(), -id);
+//       null when nothing is feasible; a non-null dummy (cluster == null,
+//       score == MIN_VALUE) when the candidate list is empty.
+//
+// The three branches where the reference dereferences the dummy's null cluster
+// (:97, :104, :108) are reported as HMK_ERR_REFERENCE_WOULD_CRASH.
+#include "hmk_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cstring>
+#include <vector>
+
+namespace hmk {
+
+namespace {
+
+struct Nbr {
+    uint32_t m;
+    int32_t s;
+};
+
+enum : uint8_t { ST_FREE = 0, ST_IN_CLUSTER = 1, ST_ORPHAN = 2 };
+enum { NEAR_NULL = 0, NEAR_DUMMY = 1, NEAR_REAL = 2 };
+
+struct ClusterRec {
+    int32_t id;      // seed index (LimitedGreedySequenceClusterer.java:82)
+    int32_t usize;   // Cluster.getUniqueSize()
+    int64_t size;    // Cluster.size(): sum of member counts (Cluster.java:156)
+};
+
+struct Found {
+    int kind;
+    int32_t slot;   // cluster slot (A / phase 2) or sequence index (B)
+    int32_t score;
+};
+
+// (score, size, -id) total order of NearestClusterRunner.call :265-289
+inline bool better(int32_t s, int64_t size, int32_t id, int32_t bs, int64_t bsize, int32_t bid) {
+    if (s != bs) return s > bs;
+    if (size != bsize) return size > bsize;
+    return id < bid;
+}
+
+}  // namespace
+
+int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
+                      bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,
+                      int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
+    auto t0 = std::chrono::steady_clock::now();
+    hmk_greedy_stats local;
+    if (!st) st = &local;
+    std::memset(st, 0, sizeof(*st));
+    st->n_edges = n_edges;
+    (void)threshold;  // every stored edge already satisfies score >= threshold
+
+    // ---- CSR adjacency: adj[x] = {(m, sequenceScore(m, x))} -----------------
+    std::vector<uint64_t> start((size_t)n + 1, 0);
+    for (uint64_t e = 0; e < n_edges; e++) {
+        uint32_t x = HMK_EDGE_X(edges[e]), m = HMK_EDGE_M(edges[e]);
+        if (x >= n || m >= n || x == m) {
+            if (err) *err = "edge list references a sequence outside [0, n) or a self pair";
+            return HMK_ERR_BAD_ARG;
+        }
+        start[x + 1]++;
+        if (symmetric) start[m + 1]++;
+    }
+    for (uint32_t k = 0; k < n; k++) start[k + 1] += start[k];
+    std::vector<Nbr> adj(start[n]);
+    {
+        std::vector<uint64_t> fill(start.begin(), start.end() - 1);
+        for (uint64_t e = 0; e < n_edges; e++) {
+            uint32_t x = HMK_EDGE_X(edges[e]), m = HMK_EDGE_M(edges[e]);
+            int32_t s = HMK_EDGE_SCORE(edges[e]);
+            adj[fill[x]++] = Nbr{m, s};
+            if (symmetric) adj[fill[m]++] = Nbr{x, s};
+        }
+    }
+
+    std::vector<uint8_t> state(n, ST_FREE);
+    std::vector<int32_t> cluster_of(n, -1);
+    std::vector<ClusterRec> clusters;
+    std::vector<int32_t> cnt, mn;          // per-cluster scratch of the feasibility pass
+    std::vector<int32_t> touched;
+    std::vector<uint32_t> orphans;
+    auto seq_size = [&](uint32_t k) -> int64_t { return sizes ? sizes[k] : 1; };
+
+    // nearest(clusters, x): findNearestClusterParallel over actualClusters
+    auto nearest_cluster = [&](uint32_t x) -> Found {
+        if (clusters.empty()) return Found{NEAR_DUMMY, -1, INT_MIN};  // :138-140
+        touched.clear();
+        for (uint64_t q = start[x]; q < start[x + 1]; q++) {
+            int32_t c = cluster_of[adj[q].m];
+            if (c < 0) continue;
+            if (cnt[c] == 0) { touched.push_back(c); mn[c] = adj[q].s; }
+            else if (adj[q].s < mn[c]) mn[c] = adj[q].s;
+            cnt[c]++;
+        }
+        Found best{NEAR_NULL, -1, 0};
+        for (int32_t c : touched) {
+            if (cnt[c] == clusters[c].usize) {  // complete linkage: all members >= threshold
+                if (best.kind == NEAR_NULL ||
+                    better(mn[c], clusters[c].size, clusters[c].id, best.score,
+                           clusters[best.slot].size, clusters[best.slot].id))
+                    best = Found{NEAR_REAL, c, mn[c]};
+            }
+            cnt[c] = 0;
+        }
+        return best;
+    };
+
+    if (member_rank)
+        for (uint32_t q = 0; q < n; q++) member_rank[q] = 0;
+    auto insert_into = [&](int32_t c, uint32_t k) {  // Cluster.insertAll of a singleton
+        if (member_rank) member_rank[k] = clusters[c].usize;
+        cluster_of[k] = c;
+        state[k] = ST_IN_CLUSTER;
+        clusters[c].usize++;
+        clusters[c].size += seq_size(k);
+    };
+
+    // ---- firstPhase, LimitedGreedySequenceClusterer.java:77-120 ------------
+    int64_t remaining = n;  // elements of initialList at positions >= index
+    int64_t index = 0;
+    uint32_t k = 0;         // sequence behind initialList.get(index)
+    for (; k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters; k++) {
+        if (state[k] != ST_FREE) continue;  // removed from initialList (:101, :110)
+        Found A = nearest_cluster(k);                       // :92
+        Found B;                                            // :93
+        if (remaining - 1 == 0) {
+            B = Found{NEAR_DUMMY, -1, INT_MIN};
+        } else {
+            B = Found{NEAR_NULL, -1, 0};
+            for (uint64_t q = start[k]; q < start[k + 1]; q++) {
+                uint32_t m = adj[q].m;
+                if (state[m] != ST_FREE) continue;  // only untouched singletons follow x
+                if (B.kind == NEAR_NULL ||
+                    better(adj[q].s, seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot))
+                    B = Found{NEAR_REAL, (int32_t)m, adj[q].s};
+            }
+        }
+        bool absorb = false;
+        if (A.kind != NEAR_NULL) {                          // :94
+            if (B.kind != NEAR_NULL) {                      // :95
+                if (A.score >= B.score) {                   // :96
+                    if (A.kind == NEAR_DUMMY) { st->crash_case = 2; st->crash_index = (int32_t)index; goto crash; }
+                    insert_into(A.slot, k);                 // :97
+                } else {
+                    absorb = true;                          // :99-101
+                }
+            } else {
+                if (A.kind == NEAR_DUMMY) { st->crash_case = 1; st->crash_index = (int32_t)index; goto crash; }
+                insert_into(A.slot, k);                     // :104
+            }
+        } else {
+            if (B.kind != NEAR_NULL) {                      // :107
+                if (B.kind == NEAR_DUMMY) { st->crash_case = 3; st->crash_index = (int32_t)index; goto crash; }
+                absorb = true;                              // :108-110
+            } else {
+                state[k] = ST_ORPHAN;                       // :112
+                orphans.push_back(k);
+            }
+        }
+        if (absorb) {
+            int32_t c = (int32_t)clusters.size();
+            clusters.push_back(ClusterRec{(int32_t)k, 1, seq_size(k)});
+            cnt.push_back(0);
+            mn.push_back(0);
+            cluster_of[k] = c;
+            state[k] = ST_IN_CLUSTER;
+            insert_into(c, (uint32_t)B.slot);
+            remaining--;  // initialList.remove(B)
+        }
+        remaining--;
+        index++;          // :115
+    }
+    st->phase1_stop_index = (int32_t)index;
+    st->phase1_clusters = (int32_t)clusters.size();
+    st->phase1_orphans = (int32_t)orphans.size();
+
+    {
+        // ---- cluster() second loop, :59-66 ---------------------------------
+        std::vector<uint32_t> leftover(orphans);
+        for (uint32_t q = k; q < n; q++)
+            if (state[q] == ST_FREE) leftover.push_back(q);
+        std::vector<uint32_t> rest;
+        for (uint32_t y : leftover) {
+            Found F = nearest_cluster(y);                   // :60
+            if (F.kind == NEAR_REAL) insert_into(F.slot, y);  // :61-62 (score >= threshold by construction)
+            else rest.push_back(y);                         // :64
+        }
+        // ---- :67-68 ---------------------------------------------------------
+        int32_t out = 0;
+        for (const ClusterRec &c : clusters) {
+            if (result_order) result_order[out] = c.id;
+            out++;
+        }
+        for (uint32_t y : rest) {
+            if (result_order) result_order[out] = (int32_t)y;
+            out++;
+        }
+        for (uint32_t q = 0; q < n; q++)
+            cluster_id[q] = cluster_of[q] >= 0 ? clusters[cluster_of[q]].id : (int32_t)q;
+        st->n_result_clusters = out;
+        st->n_multi = (int32_t)clusters.size();
+    }
+    st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return HMK_OK;
+
+crash:
+    if (err)
+        *err = "the reference throws NullPointerException here (LimitedGreedySequenceClusterer.java:97/104/108): "
+               "case " + std::to_string(st->crash_case) + " at index " + std::to_string(st->crash_index);
+    st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return HMK_ERR_REFERENCE_WOULD_CRASH;
+}
+
+}  // namespace hmk

@@ -1,0 +1,64 @@
+// hmk_internal.h -- structures shared by the host API, the host greedy merge
+// and the HIP kernels of libhammock_hip.so.  Not part of the public ABI.
+#ifndef HMK_INTERNAL_H
+#define HMK_INTERNAL_H
+
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/hammock_hip.h"
+
+namespace hmk {
+
+// ---- neighbour kernel plan ---------------------------------------------------
+// Sequences are bucketed by length ("sorted order"); a tile is R rows x a run
+// of columns inside ONE (row length, column length) class, so everything that
+// depends on the two lengths is uniform over the workgroup.
+
+enum { PATH_U8 = 0, PATH_U16 = 1, PATH_DIRECT = 2 };
+
+struct TileClass {
+    uint8_t la, lb;    // row / column sequence length
+    uint8_t nd;        // diagonals (shifts) = 2X + |la - lb| + 1
+    uint8_t case_b;    // 1: the COLUMN sequence is the shorter one (S of ShiftedScorer.java:51-57)
+    uint8_t x;         // max shift
+    uint8_t path;      // PATH_*
+    uint8_t nw;        // dwords per table entry (1, 2, 4 or 8)
+    uint8_t pad;
+    int32_t g;         // lane value = g + score  (g = 128 - thr or 32768 - thr)
+    int32_t d;         // |la - lb|
+    uint32_t cinit[8]; // initial accumulator dwords: per lane g + penalty(s) - bias * cells(s)
+};
+
+struct Tile {
+    uint32_t row0, nrows;  // rows [row0, row0 + nrows) in sorted order, nrows <= R
+    uint32_t col0, ncols;  // columns [col0, col0 + ncols)
+    uint32_t cls;          // index into the TileClass array
+    uint32_t diag;         // 1: rows and columns come from the same bucket: keep col > row only
+    uint32_t pad0, pad1;
+};
+
+struct NeighborParams {
+    const uint8_t *res_sorted;   // [n][lpad] residues in sorted order, zero padded
+    const uint32_t *perm;        // sorted position -> caller index
+    const uint8_t *mb;           // biased matrix bytes [576]: M + bias
+    const TileClass *classes;
+    const Tile *tiles;
+    uint64_t *edges;             // HMK_EDGE_SHARDS segments of cap_per_shard
+    unsigned long long *counts;  // [HMK_EDGE_SHARDS]
+    uint64_t cap_per_shard;
+    uint32_t n_tiles;
+    uint32_t lpad;               // 16 or 32
+    uint32_t symmetric;          // 1: emit (min, max) caller indices
+    uint32_t pad;
+};
+
+// host greedy merge (hmk_greedy.cpp)
+int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
+                      bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,
+                      int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err);
+
+}  // namespace hmk
+
+#endif

@@ -1,0 +1,27 @@
+// hmk_kernels.h -- launchers of the HIP kernels (hmk_kernels.hip), used by hmk_api.cpp.
+#ifndef HMK_KERNELS_H
+#define HMK_KERNELS_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include "hmk_internal.h"
+
+namespace hmk {
+
+// rows per tile the SWAR kernel instantiation (lbmax, nw) was built with
+int swar_rows_per_tile(int lbmax, int nw);
+
+hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, const NeighborParams &P, uint32_t tile_base,
+                                 uint32_t n_tiles, hipStream_t s);
+hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
+                                   const int32_t *d_matrix, int max_shift, int shift_penalty, int threshold,
+                                   hipStream_t s);
+// scorer 0: ShiftedScorer(a = maxShift, b = shiftPenalty); 1: LocalAlignmentScorer(a = gapOpen, b = gapExtend).
+// pi == nullptr: dense block mode, pair k = (r0 + k / width, c0 + k % width).
+hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix,
+                        const uint32_t *pi, const uint32_t *pj, uint64_t n_pairs, uint32_t r0, uint32_t c0,
+                        uint32_t width, int a, int b, int32_t *out, hipStream_t s);
+
+}  // namespace hmk
+#endif

@@ -1,0 +1,520 @@
+// hmk_kernels.hip -- hand-written gfx950 (CDNA4) kernels of libhammock_hip.so.
+//
+// Integer scoring only: no MFMA, no dense contraction.  The bound that matters
+// is the LDS lookup rate (ds_read_b64: 32 lanes/clk/CU) and VALU issue, see
+// DESIGN.md "Kernels".
+//
+//   k_neighbors_swar   all-vs-all ShiftedScorer (ShiftedScorer.java:48-95) with
+//                      threshold -> edge list.  One (row, column) pair per lane
+//                      per step; the row peptide is wave-uniform and expanded
+//                      once per tile into per-position lookup tables in LDS
+//                      whose entries hold ALL shifts of one column position as
+//                      packed 8/16-bit lanes, so one ds_read_b64 + two v_add_u32
+//                      advance all 7 shift sums of a pair by one residue.
+//   k_neighbors_direct generic tier for length classes whose sums do not fit
+//                      the packed lanes.
+//   k_pairs_*          one pair per lane, literal loops: the parity probes
+//                      behind hmk_score_pairs_* / hmk_score_block_*.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hmk_internal.h"
+#include "hmk_kernels.h"
+
+namespace hmk {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS (address space 3) accesses through a 32-bit byte address, so that the
+// per-lane table offset and the compile-time row offset meet in ONE ds_read
+// (VGPR address + immediate) with no flat-pointer arithmetic in between.
+#define HMK_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const HMK_LDS uint8_t *)p;
+}
+template <typename T>
+__device__ __forceinline__ T lds_read(uint32_t addr) {
+    return *reinterpret_cast<const HMK_LDS T *>((uintptr_t)addr);
+}
+
+// -----------------------------------------------------------------------------
+// literal per-pair scorers (device), residues read through LDS pointers
+// -----------------------------------------------------------------------------
+
+// ShiftedScorer.scoreWithShift, ShiftedScorer.java:48-95.  M: int32[576] in LDS.
+__device__ __forceinline__ int shifted_score_literal(const int *M, const uint8_t *seq1, int len1,
+                                                     const uint8_t *seq2, int len2, int max_shift,
+                                                     int shift_penalty) {
+    const uint8_t *shorter, *longer;
+    int slen, llen;
+    if (len1 >= len2) { shorter = seq2; slen = len2; longer = seq1; llen = len1; }   // :51-57
+    else              { shorter = seq1; slen = len1; longer = seq2; llen = len2; }
+    int best = INT32_MIN;
+    const int diff = llen - slen;                                                      // :66
+    for (int s = -max_shift; s <= max_shift + diff; s++) {                             // :67
+        int actual = 0;
+        if (s <= 0) {                                                                  // :69-72
+            for (int i = 0; i < slen + s; i++) actual += M[shorter[i - s] * 24 + longer[i]];
+        } else {                                                                       // :73-77
+            const int lim = min(slen, llen - s);
+            for (int i = 0; i < lim; i++) actual += M[shorter[i] * 24 + longer[i + s]];
+        }
+        actual += diff * shift_penalty;                                                // :79
+        if (s < 0) actual += -s * 2 * shift_penalty;                                   // :80-82
+        if (s > diff) actual += (s - diff) * 2 * shift_penalty;                        // :83-85
+        if (actual > best) best = actual;                                              // :86-89
+    }
+    return best;
+}
+
+enum { DIR_LEFT = 0, DIR_UP = 1, DIR_DIAGONAL = 2, DIR_NOWHERE = 3 };
+
+// LocalAlignmentScorer.fillDynamicMatrices, LocalAlignmentScorer.java:31-86.
+// One DP line lives in LDS as row[col * stride], each cell packed (H << 2) | Dir.
+__device__ __forceinline__ int local_score_literal(const int *M, const uint8_t *seq1, int len1,
+                                                   const uint8_t *seq2, int len2, int gap_open,
+                                                   int gap_extend, uint32_t *row, int stride) {
+    // line 0: H = 0, Dir = LEFT (:97-100); column 0 of every line: H = 0, Dir = UP (:93-96)
+    for (int col = 1; col <= len2; col++) row[col * stride] = DIR_LEFT;
+    int global_max = 0;                                                                // :32
+    for (int line = 1; line <= len1; line++) {                                         // :40
+        const int a = seq1[line - 1] * 24;
+        int left_h = 0, left_d = DIR_UP;   // cell [line][0]
+        int diag_h = 0;                    // cell [line-1][0]
+        for (int col = 1; col <= len2; col++) {                                        // :41
+            const uint32_t upc = row[col * stride];
+            const int up_h = (int)(upc >> 2), up_d = (int)(upc & 3u);
+            const int up = up_h + (up_d == DIR_UP ? gap_extend : gap_open);            // :43-48,:57
+            const int left = left_h + (left_d == DIR_LEFT ? gap_extend : gap_open);    // :50-55,:58
+            const int diag = diag_h + M[a + seq2[col - 1]];                            // :59
+            const int mx = max(diag, max(up, left));                                   // :61
+            int h, d;
+            if (mx < 0) { h = 0; d = DIR_NOWHERE; }                                    // :63-65
+            else {
+                h = mx;                                                                // :67
+                global_max = max(global_max, mx);                                      // :68-72
+                d = DIR_LEFT;                       // one of the three always matches
+                if (mx == up) d = DIR_UP;                                              // :76-78
+                if (mx == diag) d = DIR_DIAGONAL;                                      // :79-81
+            }
+            row[col * stride] = ((uint32_t)h << 2) | (uint32_t)d;
+            diag_h = up_h;
+            left_h = h;
+            left_d = d;
+        }
+    }
+    return global_max;                                                                 // :85
+}
+
+// per-lane LDS staging of one sequence: 9-dword stride keeps the byte reads of
+// the 64 lanes on different banks
+constexpr int SEQ_STRIDE_DW = 9;
+
+__device__ __forceinline__ void stage_sequence(uint32_t *dst, const uint8_t *res32, uint32_t idx) {
+    const u32x4 *src = reinterpret_cast<const u32x4 *>(res32 + (size_t)idx * 32);
+    const u32x4 lo = src[0], hi = src[1];
+    dst[0] = lo.x; dst[1] = lo.y; dst[2] = lo.z; dst[3] = lo.w;
+    dst[4] = hi.x; dst[5] = hi.y; dst[6] = hi.z; dst[7] = hi.w;
+}
+
+template <int SCORER>  // 0 shifted, 1 local
+__global__ void __launch_bounds__(256)
+k_pairs(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len, const int32_t *__restrict__ Mg,
+        const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj, uint64_t n_pairs,
+        uint32_t block_r0, uint32_t block_c0, uint32_t block_w,  // block mode when pi == nullptr
+        int a, int b, int32_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int *M = reinterpret_cast<int *>(smem);                                   // 576 dwords
+    uint32_t *seqs = reinterpret_cast<uint32_t *>(smem + 2304);               // 256 * 2 * 9 dwords
+    uint32_t *dp = seqs + 256 * 2 * SEQ_STRIDE_DW;                            // local: 33 * 256 dwords
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 576; e += 256) M[e] = Mg[e];
+    __syncthreads();
+    uint32_t *s1 = seqs + tid * 2 * SEQ_STRIDE_DW;
+    uint32_t *s2 = s1 + SEQ_STRIDE_DW;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + tid; k < n_pairs; k += (uint64_t)gridDim.x * 256) {
+        uint32_t i, j;
+        if (pi) { i = pi[k]; j = pj[k]; }
+        else { i = block_r0 + (uint32_t)(k / block_w); j = block_c0 + (uint32_t)(k % block_w); }
+        stage_sequence(s1, res32, i);
+        stage_sequence(s2, res32, j);
+        const int l1 = len[i], l2 = len[j];
+        int score;
+        if (SCORER == 0)
+            score = shifted_score_literal(M, reinterpret_cast<const uint8_t *>(s1), l1,
+                                          reinterpret_cast<const uint8_t *>(s2), l2, a, b);
+        else
+            score = local_score_literal(M, reinterpret_cast<const uint8_t *>(s1), l1,
+                                        reinterpret_cast<const uint8_t *>(s2), l2, a, b, dp + tid, 256);
+        out[k] = score;
+    }
+}
+
+// -----------------------------------------------------------------------------
+// wave-level edge staging shared by the neighbour kernels
+// -----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Drains one wave's staged records to its output segment.  REC_DW dwords per
+// record: [0] column (sorted position), [1] row within the tile, [2..] the NW
+// accumulator dwords (SWAR) or the score itself (direct, NW == 0).
+template <int NW>
+__device__ __forceinline__ void flush_stage(const uint32_t *stage, uint32_t cnt, const NeighborParams &P,
+                                            const Tile &T, int g, bool lane16, uint32_t shard) {
+    constexpr int REC_DW = (NW == 0) ? 3 : NW + 2;
+    if (cnt == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
+    const uint32_t lane = lane_id();
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&P.counts[shard], (unsigned long long)cnt);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t *rec = stage + k * REC_DW;
+        const uint32_t col = rec[0], r = rec[1];
+        int score;
+        if (NW == 0) {
+            score = (int)rec[2];
+        } else {
+            uint32_t mx = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const uint32_t dw = rec[2 + w];
+                if (lane16) {
+                    mx = max(mx, max(dw & 0xFFFFu, dw >> 16));
+                } else {
+                    mx = max(mx, max(max(dw & 0xFFu, (dw >> 8) & 0xFFu), max((dw >> 16) & 0xFFu, dw >> 24)));
+                }
+            }
+            score = (int)mx - g;
+        }
+        uint32_t x = P.perm[T.row0 + r], m = P.perm[col];
+        if (P.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
+        const unsigned long long pos = base + k;
+        if (pos < P.cap_per_shard)
+            P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
+                ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
+}
+
+// -----------------------------------------------------------------------------
+// k_neighbors_swar
+// -----------------------------------------------------------------------------
+// LDS map (one __shared__ array):
+//   tab     R * LBMAX * 24 * NW dwords   per row r, column position j, residue c:
+//                                        NW dwords of packed lanes, lane t = shift index
+//   mb      576 B                        biased matrix bytes
+//   rowres  R * 32 B                     residues of the tile's rows
+//   stage   4 waves * STAGE_CAP records  hits waiting to be written out
+template <int NW, int R, int CPL, int LBMAX, bool EXACT>
+__global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
+    constexpr int ES = NW * 4;                 // table entry bytes
+    constexpr int ROWBYTES = LBMAX * 24 * ES;  // one row's tables
+    constexpr int TAB_BYTES = R * ROWBYTES;
+    constexpr int STAGE_CAP = 64 * CPL + 64;
+    constexpr int REC_DW = NW + 2;
+    constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;  // dwords per stored residue row (lpad 16 / 32)
+    static_assert(TAB_BYTES <= 65536, "row tables must stay addressable by the DS immediate offset");
+    // one STATIC LDS object: its base address is a compile-time constant, so table
+    // offsets fold into the ds_read immediate instead of costing a v_add per lookup
+    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * REC_DW * 4;
+    static_assert(LDS_BYTES <= 65536, "LDS budget");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
+    uint8_t *tab = smem;
+    uint8_t *mb = smem + TAB_BYTES;
+    uint8_t *rowres = mb + 576;
+    uint32_t *stage_all = reinterpret_cast<uint32_t *>(rowres + R * 32);
+
+    const Tile T = P.tiles[tile_base + blockIdx.x];
+    const TileClass *Cp = P.classes + T.cls;
+    const int la = Cp->la, lb = EXACT ? LBMAX : Cp->lb, nd = Cp->nd, X = Cp->x;
+    const bool case_b = Cp->case_b != 0;
+    const bool lane16 = Cp->path == PATH_U16;
+    const int g = Cp->g;
+    const uint32_t himask = lane16 ? 0x80008000u : 0x80808080u;
+    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    uint32_t *stage = stage_all + wave * (STAGE_CAP * REC_DW);
+
+    // ---- stage the matrix and the row residues ---------------------------------
+    for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
+    for (int e = tid; e < R * 32; e += 256) {
+        const int r = e >> 5, k = e & 31;
+        uint8_t v = 0;
+        if ((uint32_t)r < T.nrows && (uint32_t)k < P.lpad) v = P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k];
+        rowres[e] = v;
+    }
+    __syncthreads();
+
+    // ---- expand the R row peptides into lookup tables --------------------------
+    // entry (r, j, c), lane t (shift s = t - X):
+    //   column is the longer/equal one (L): cell = M[row[i]][c], i = j - s   (ShiftedScorer.java:71,75)
+    //   column is the shorter one (S):      cell = M[c][row[i]], i = j + s
+    {
+        const int per_row = lb * 24;
+        const int lanes_per_dw = lane16 ? 2 : 4;
+        const int lane_bits = lane16 ? 16 : 8;
+        for (int e = tid; e < R * per_row; e += 256) {
+            const int r = e / per_row;
+            const int rem = e - r * per_row;
+            const int j = rem / 24;
+            const int c = rem - j * 24;
+            uint32_t dw[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                uint32_t acc = 0;
+                for (int k = 0; k < lanes_per_dw; k++) {
+                    const int t = w * lanes_per_dw + k;
+                    const int i = case_b ? (j + t - X) : (j - t + X);
+                    if (t < nd && i >= 0 && i < la && (uint32_t)r < T.nrows) {
+                        const int a = rowres[r * 32 + i];
+                        const uint32_t v = case_b ? mb[c * 24 + a] : mb[a * 24 + c];
+                        acc |= v << (k * lane_bits);
+                    }
+                }
+                dw[w] = acc;
+            }
+            uint32_t *dst = reinterpret_cast<uint32_t *>(tab + r * ROWBYTES + (j * 24 + c) * ES);
+#pragma unroll
+            for (int w = 0; w < NW; w++) dst[w] = dw[w];
+        }
+    }
+    __syncthreads();
+
+    uint32_t cinit[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) cinit[w] = Cp->cinit[w];
+
+    uint32_t cnt = 0;  // staged records of this wave (wave-uniform)
+    const uint32_t tab_addr = lds_addr(tab);
+    const uint32_t col_end = T.col0 + T.ncols;
+    const uint32_t n_batches = (T.ncols + 256 * CPL - 1) / (256 * CPL);
+
+    for (uint32_t bt = 0; bt < n_batches; bt++) {
+        // ---- this lane's CPL column peptides -> per-position table offsets ------
+        uint32_t off[CPL][LBMAX];
+        uint32_t colpos[CPL];
+#pragma unroll
+        for (int p = 0; p < CPL; p++) {
+            const uint32_t col = T.col0 + (bt * CPL + p) * 256 + tid;
+            colpos[p] = col;
+            uint32_t words[LPADW];
+#pragma unroll
+            for (int q = 0; q < LPADW; q++) words[q] = 0;
+            if (col < col_end) {
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(P.res_sorted + (size_t)col * (LPADW * 4));
+                const u32x4 v0 = src[0];
+                words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+                if (LPADW == 8) {
+                    const u32x4 v1 = src[1];
+                    words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < LBMAX; j++) {
+                const uint32_t c = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+                off[p][j] = tab_addr + (uint32_t)(j * 24 * ES) + c * ES;
+            }
+        }
+
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if ((uint32_t)r < T.nrows) {
+                if (cnt > (uint32_t)(STAGE_CAP - 64 * CPL)) {  // keep room for one row of hits
+                    flush_stage<NW>(stage, cnt, P, T, g, lane16, shard);
+                    cnt = 0;
+                }
+#pragma unroll
+                for (int p = 0; p < CPL; p++) {
+                    uint32_t W[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; w++) W[w] = cinit[w];
+#pragma unroll
+                    for (int j = 0; j < LBMAX; j++) {
+                        if (EXACT || j < lb) {
+                            const uint32_t ea = off[p][j] + (uint32_t)(r * ROWBYTES);
+                            if (NW == 1) {
+                                W[0] += lds_read<uint32_t>(ea);
+                            } else if (NW == 2) {
+                                const u32x2 e = lds_read<u32x2>(ea);
+                                W[0] += e.x; W[1] += e.y;
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < NW / 4; q++) {
+                                    const u32x4 e = lds_read<u32x4>(ea + 16 * q);
+                                    W[4 * q + 0] += e.x; W[4 * q + 1] += e.y;
+                                    W[4 * q + 2] += e.z; W[4 * q + 3] += e.w;
+                                }
+                            }
+                        }
+                    }
+                    uint32_t any = W[0];
+#pragma unroll
+                    for (int w = 1; w < NW; w++) any |= W[w];
+                    const bool hit = (any & himask) != 0;  // some shift reached score >= threshold
+                    if (__ballot(hit) != 0) {              // wave-uniform, rare
+                        const uint32_t col = colpos[p];
+                        bool keep = hit && col < col_end;
+                        if (T.diag == 1) keep = keep && col > T.row0 + r;   // triangle: column after row
+                        if (T.diag == 2) keep = keep && col != T.row0 + r;  // full square minus the diagonal
+                        const uint64_t mask = __ballot(keep);
+                        if (keep) {
+                            uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                            rec[0] = col;
+                            rec[1] = (uint32_t)r;
+#pragma unroll
+                            for (int w = 0; w < NW; w++) rec[2 + w] = W[w];
+                        }
+                        cnt += (uint32_t)__popcll(mask);
+                    }
+                }
+            }
+        }
+    }
+    flush_stage<NW>(stage, cnt, P, T, g, lane16, shard);
+}
+
+// -----------------------------------------------------------------------------
+// k_neighbors_direct: generic tier (same tiles, literal scorer, one column per lane)
+// -----------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32_t *__restrict__ Mg,
+                   int max_shift, int shift_penalty, int threshold) {
+    constexpr int R = 16;
+    constexpr int STAGE_CAP = 128;
+    constexpr int REC_DW = 3;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int *M = reinterpret_cast<int *>(smem);                                   // 2304 B
+    uint32_t *colseq = reinterpret_cast<uint32_t *>(smem + 2304);             // 256 * 9 dwords
+    uint32_t *rowseq = colseq + 256 * SEQ_STRIDE_DW;                          // R * 8 dwords
+    uint32_t *stage_all = rowseq + R * 8;
+
+    const Tile T = P.tiles[tile_base + blockIdx.x];
+    const TileClass *Cp = P.classes + T.cls;
+    const int la = Cp->la, lb = Cp->lb;
+    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const int tid = threadIdx.x;
+    uint32_t *stage = stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+
+    for (int e = tid; e < 576; e += 256) M[e] = Mg[e];
+    for (int e = tid; e < R * 8; e += 256) {
+        const int r = e >> 3, q = e & 7;
+        uint32_t v = 0;
+        if ((uint32_t)r < T.nrows && (uint32_t)(q * 4) < P.lpad)
+            v = reinterpret_cast<const uint32_t *>(P.res_sorted + (size_t)(T.row0 + r) * P.lpad)[q];
+        rowseq[e] = v;
+    }
+    __syncthreads();
+
+    uint32_t cnt = 0;
+    const uint32_t col_end = T.col0 + T.ncols;
+    uint32_t *mine = colseq + tid * SEQ_STRIDE_DW;
+    for (uint32_t c0 = T.col0; c0 < col_end; c0 += 256) {
+        const uint32_t col = c0 + tid;
+        if (col < col_end) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.res_sorted + (size_t)col * P.lpad);
+            for (uint32_t q = 0; q < P.lpad / 4; q++) mine[q] = src[q];
+        }
+        for (uint32_t r = 0; r < T.nrows; r++) {
+            if (cnt > (uint32_t)(STAGE_CAP - 64)) {
+                flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+                cnt = 0;
+            }
+            bool keep = col < col_end;
+            if (T.diag == 1) keep = keep && col > T.row0 + r;
+            if (T.diag == 2) keep = keep && col != T.row0 + r;
+            int score = 0;
+            if (keep) {
+                // edge (x = row, m = column) carries sequenceScore(seq1 = m, seq2 = x)
+                score = shifted_score_literal(M, reinterpret_cast<const uint8_t *>(mine), lb,
+                                              reinterpret_cast<const uint8_t *>(rowseq + r * 8), la,
+                                              max_shift, shift_penalty);
+                keep = score >= threshold;
+            }
+            const uint64_t mask = __ballot(keep);
+            if (mask != 0) {
+                if (keep) {
+                    uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                    rec[0] = col;
+                    rec[1] = r;
+                    rec[2] = (uint32_t)score;
+                }
+                cnt += (uint32_t)__popcll(mask);
+            }
+        }
+    }
+    flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+}
+
+// -----------------------------------------------------------------------------
+// launchers
+// -----------------------------------------------------------------------------
+template <int NW, int R, int CPL, int LBMAX, bool EXACT>
+static hipError_t launch_swar_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
+    hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+    return hipGetLastError();
+}
+
+int swar_rows_per_tile(int lbmax, int nw) {
+    const int rowbytes = lbmax * 24 * nw * 4;
+    int r = 16;
+    while (r > 1 && r * rowbytes > 40960) r >>= 1;
+    return r;
+}
+
+hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, const NeighborParams &P, uint32_t tile_base,
+                                 uint32_t n_tiles, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+#define HMK_CASE(LB, NWV, RV, CPLV)                                                              \
+    if (lbmax == LB && nw == NWV) {                                                              \
+        if constexpr (LB == 12 && NWV == 2) {                                                    \
+            if (exact) return launch_swar_t<NWV, RV, CPLV, LB, true>(P, tile_base, n_tiles, s);  \
+        }                                                                                        \
+        return launch_swar_t<NWV, RV, CPLV, LB, false>(P, tile_base, n_tiles, s);                \
+    }
+    HMK_CASE(12, 1, 16, 2) HMK_CASE(12, 2, 16, 2) HMK_CASE(12, 4, 8, 1) HMK_CASE(12, 8, 4, 1)
+    HMK_CASE(20, 1, 16, 2) HMK_CASE(20, 2, 8, 2)  HMK_CASE(20, 4, 4, 1) HMK_CASE(20, 8, 2, 1)
+    HMK_CASE(32, 1, 8, 2)  HMK_CASE(32, 2, 4, 2)  HMK_CASE(32, 4, 2, 1) HMK_CASE(32, 8, 1, 1)
+#undef HMK_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
+                                   const int32_t *d_matrix, int max_shift, int shift_penalty, int threshold,
+                                   hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    const size_t lds = 2304 + 256 * SEQ_STRIDE_DW * 4 + 16 * 8 * 4 + 4 * 128 * 3 * 4;
+    hipLaunchKernelGGL(k_neighbors_direct, dim3(n_tiles), dim3(256), lds, s, P, tile_base, d_matrix, max_shift,
+                       shift_penalty, threshold);
+    return hipGetLastError();
+}
+
+hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix,
+                        const uint32_t *pi, const uint32_t *pj, uint64_t n_pairs, uint32_t r0, uint32_t c0,
+                        uint32_t width, int a, int b, int32_t *out, hipStream_t s) {
+    if (n_pairs == 0) return hipSuccess;
+    uint64_t blocks = (n_pairs + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    const size_t lds_shift = 2304 + 256 * 2 * SEQ_STRIDE_DW * 4;
+    const size_t lds_local = lds_shift + 33 * 256 * 4;
+    if (scorer == 0)
+        hipLaunchKernelGGL(k_pairs<0>, dim3((uint32_t)blocks), dim3(256), lds_shift, s, res32, len, d_matrix, pi, pj,
+                           n_pairs, r0, c0, width, a, b, out);
+    else
+        hipLaunchKernelGGL(k_pairs<1>, dim3((uint32_t)blocks), dim3(256), lds_local, s, res32, len, d_matrix, pi, pj,
+                           n_pairs, r0, c0, width, a, b, out);
+    return hipGetLastError();
+}
+
+}  // namespace hmk

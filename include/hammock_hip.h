@@ -1,0 +1,177 @@
+/*
+ * hammock_hip.h -- C ABI of libhammock_hip.so, the MI355X (gfx950) drop-in for
+ * the greedy initial-clustering hot path of krejciadam/hammock v1.2.0.
+ *
+ * The reference has no FFI seam of its own; its seams are the Java interfaces
+ * below (paths relative to src/cz/krejciadam/hammock/).  Each entry point names
+ * the reference interface it replaces.  A JNI / cgo / ctypes binding binds
+ * exactly these symbols (INTEGRATION.md shows the Java side).
+ *
+ * Conventions
+ *   - plain C types only; every output buffer is caller-allocated
+ *   - residues are indices 0..23 over "ARNDCQEGHILKMFPSTWYVBZX*"
+ *     (UniqueSequence.java:23-26); the scoring matrix is int[24][24] row-major
+ *     exactly as FileIOManager.loadScoringMatrix returns it (FileIOManager.java:46-81)
+ *   - score(i, j) always means SequenceScorer.sequenceScore(seq1 = sequence i,
+ *     seq2 = sequence j) (SequenceScorer.java:14)
+ *   - every function returns an hmk_status; hmk_last_error() gives the text
+ *   - there is no CPU fallback: a scoring call on a context without a usable
+ *     GPU returns HMK_ERR_DEVICE
+ */
+#ifndef HAMMOCK_HIP_H
+#define HAMMOCK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMK_ABI_VERSION 1
+#define HMK_ALPHABET 24
+#define HMK_MAX_LEN 32          /* longest sequence the GPU kernels accept */
+#define HMK_MAX_SEQUENCES (1u << 24)
+#define HMK_EDGE_SHARDS 16      /* output segments of the neighbour kernel */
+
+typedef enum {
+    HMK_OK = 0,
+    HMK_ERR_BAD_ARG = 1,
+    HMK_ERR_SHIFT_TOO_BIG = 2,          /* DataException, ShiftedScorer.java:59-62 */
+    HMK_ERR_DEVICE = 3,                 /* HIP error / no usable gfx950 device */
+    HMK_ERR_OOM = 4,
+    HMK_ERR_REFERENCE_WOULD_CRASH = 5,  /* NullPointerException in
+                                           LimitedGreedySequenceClusterer.java:97/104/108
+                                           (surfaces at Hammock.java:153-157) */
+    HMK_ERR_CAPACITY = 6,               /* caller's edge buffer too small; *n_edges = needed */
+    HMK_ERR_NO_SEQUENCES = 7
+} hmk_status;
+
+typedef struct hmk_ctx hmk_ctx;
+
+/* Edge of the thresholded neighbour graph, packed in one uint64:
+ *   bits 63..40  x      (sequence index, 24 bit)
+ *   bits 39..16  m      (sequence index, 24 bit)
+ *   bits 15..0   score  (int16, two's complement)
+ * meaning  sequenceScore(seq1 = m, seq2 = x) = score >= threshold.
+ * With a symmetric matrix each unordered pair appears once with x < m. */
+#define HMK_EDGE_X(e) ((uint32_t)((e) >> 40))
+#define HMK_EDGE_M(e) ((uint32_t)(((e) >> 16) & 0xFFFFFFu))
+#define HMK_EDGE_SCORE(e) ((int32_t)(int16_t)((e) & 0xFFFFu))
+
+/* ---- context ---------------------------------------------------------- */
+
+/* Replaces `new ShiftedScorer(scoringMatrix, ..)` / `new LocalAlignmentScorer`
+ * construction state (ShiftedScorer.java:28-32, LocalAlignmentScorer.java:20-24):
+ * holds the matrix (Hammock.scoringMatrix, Hammock.java:46,1264) on `device`.
+ * device >= 0: HIP device ordinal.  device == -1: host-only context (only the
+ * host-side calls hmk_greedy_from_edges / hmk_set_sequences work). */
+int hmk_create(const int32_t matrix[HMK_ALPHABET * HMK_ALPHABET], int device, hmk_ctx **ctx);
+void hmk_destroy(hmk_ctx *ctx);
+const char *hmk_last_error(const hmk_ctx *ctx); /* ctx may be NULL */
+int hmk_abi_version(void);
+
+/* The List<UniqueSequence> handed to SequenceClusterer.cluster
+ * (SequenceClusterer.java:24), flattened in the caller's (greedy) order:
+ * residues concatenated, offsets[n+1], sizes[n] = UniqueSequence.size()
+ * (UniqueSequence.java:82-88; NULL = all 1).  Copies everything. */
+int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *offsets,
+                      const int32_t *sizes, uint32_t n);
+
+/* ---- pairwise scorers (parity probes of SequenceScorer.sequenceScore) ---- */
+
+/* out[k] = ShiftedScorer(matrix, shift_penalty, max_shift).sequenceScore(i[k], j[k])
+ * (ShiftedScorer.java:48-100).  HMK_ERR_SHIFT_TOO_BIG if max_shift >= the
+ * shorter length of any pair. */
+int hmk_score_pairs_shifted(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs,
+                            int max_shift, int shift_penalty, int32_t *out);
+/* out[k] = LocalAlignmentScorer(matrix, gap_open, gap_extend).sequenceScore(i[k], j[k])
+ * (LocalAlignmentScorer.java:27-86); i = seq1 = lines, j = seq2 = columns. */
+int hmk_score_pairs_local(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs,
+                          int gap_open, int gap_extend, int32_t *out);
+/* Dense block: out[(r - r0) * (c1 - c0) + (c - c0)] = score(r, c), r0<=r<r1, c0<=c<c1. */
+int hmk_score_block_shifted(hmk_ctx *ctx, uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1,
+                            int max_shift, int shift_penalty, int32_t *out);
+int hmk_score_block_local(hmk_ctx *ctx, uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1,
+                          int gap_open, int gap_extend, int32_t *out);
+
+/* ---- all-vs-all thresholded neighbour graph (the hot kernel) ------------ */
+
+typedef struct {
+    uint64_t n_edges;        /* edges produced by this call */
+    uint64_t pairs_scored;   /* pairs the kernels evaluated (unordered unless asymmetric) */
+    uint32_t n_tiles;        /* workgroups launched */
+    uint32_t symmetric;      /* 1: matrix symmetric, triangle only */
+    uint32_t classes_u8;     /* (row length, column length) classes on the 8-bit lane path */
+    uint32_t classes_u16;    /* ... on the 16-bit lane path */
+    uint32_t classes_direct; /* ... on the generic one-cell-at-a-time path */
+    uint32_t reserved;
+    double kernel_ms;        /* device time of the scoring kernels (HIP events) */
+} hmk_neighbor_stats;
+
+/* Scores every pair with ShiftedScorer semantics and returns the pairs with
+ * score >= threshold as packed edges (see HMK_EDGE_*).  This is the batch
+ * form of what ClinkageClusterScorer.clusterScore's early exit
+ * (ClinkageClusterScorer.java:36-48) asks of the scorer pair by pair.
+ * The pair space is split row-block-wise into n_parts shards; this call
+ * computes shard `part` (single GPU: part = 0, n_parts = 1).
+ * edges: host buffer of `capacity` entries; *n_edges receives the count
+ * (HMK_ERR_CAPACITY and the needed count if it does not fit). */
+int hmk_neighbors_shifted(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold,
+                          uint32_t part, uint32_t n_parts, uint64_t *edges, uint64_t capacity,
+                          uint64_t *n_edges, hmk_neighbor_stats *stats);
+
+/* Device-resident form: asynchronous on `stream` (a hipStream_t, may be NULL),
+ * no host synchronisation.  d_edges: device buffer of `capacity` uint64,
+ * logically HMK_EDGE_SHARDS segments of capacity / HMK_EDGE_SHARDS entries;
+ * d_counts: device uint64[HMK_EDGE_SHARDS], zeroed by the call, receives the
+ * number of edges each segment WANTED to hold (may exceed the segment size:
+ * overflow, entries beyond the segment are dropped). */
+int hmk_neighbors_shifted_dev(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold,
+                              uint32_t part, uint32_t n_parts, void *d_edges, uint64_t capacity,
+                              void *d_counts, void *stream);
+/* pairs / tiles of the plan the last hmk_neighbors_shifted[_dev] call used */
+int hmk_neighbors_last_plan(hmk_ctx *ctx, hmk_neighbor_stats *stats);
+
+/* ---- greedy clustering -------------------------------------------------- */
+
+typedef struct {
+    uint64_t n_edges;            /* neighbour edges consumed */
+    int32_t phase1_stop_index;   /* `index` when firstPhase ends (LimitedGreedy..java:90) */
+    int32_t phase1_clusters;
+    int32_t phase1_orphans;
+    int32_t crash_case;          /* 0; or 1,2,3 = which NPE the reference would throw */
+    int32_t crash_index;
+    int32_t n_result_clusters;   /* size of the returned List<Cluster> */
+    int32_t n_multi;             /* clusters with more than one member */
+    int32_t reserved;
+    double neighbors_ms;         /* GPU scoring (hmk_greedy_cluster only) */
+    double greedy_ms;            /* host greedy merge */
+} hmk_greedy_stats;
+
+/* Replaces LimitedGreedySequenceClusterer(scorer, threshold, maxClusters).cluster(sequences)
+ * (LimitedGreedySequenceClusterer.java:22,39-69) with scorer =
+ * ShiftedScorer(matrix, shift_penalty, max_shift), on the sequences of
+ * hmk_set_sequences (already in greedy order, UniqueSequence.sortSequences).
+ *   cluster_id[n]   : id of the cluster holding sequence k (= index of its seed,
+ *                     LimitedGreedySequenceClusterer.java:82)
+ *   result_order[n] : ids of the returned clusters in list order (clusters first,
+ *                     then singletons); first n_result_clusters entries valid; may be NULL
+ *   member_rank[n]  : position of sequence k inside Cluster.getSequences() of its
+ *                     cluster (insertion order, seed = 0); may be NULL
+ * Returns HMK_ERR_REFERENCE_WOULD_CRASH where the reference throws
+ * NullPointerException (stats->crash_case says which). */
+int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold,
+                       int max_clusters, int32_t *cluster_id, int32_t *result_order,
+                       int32_t *member_rank, hmk_greedy_stats *stats);
+
+/* The host-side greedy merge alone, on an edge list produced by
+ * hmk_neighbors_shifted (all shards concatenated, any order).
+ * symmetric != 0: each edge stands for both directions. */
+int hmk_greedy_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges, int symmetric,
+                          int threshold, int max_clusters, int32_t *cluster_id,
+                          int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAMMOCK_HIP_H */

