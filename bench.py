@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- pairwise ShiftedScorer (BLOSUM62) scores per second on MI355X.
+
+Workload (BASELINE.json configs[2], the one `metric` is quoted on): 10^5 synthetic
+length-12 peptides (SplitMix64 seed 1), BLOSUM62, max shift 3, shift penalty 0,
+threshold 20 -- the defaults Hammock's greedy mode derives for this input
+(Hammock.java:394-401,1409-1434).
+
+A "step" is one pass of the hot path over the whole pair space: every unordered
+pair {i, j} is scored on the GPU with the reference's ShiftedScorer semantics and
+the pairs with score >= threshold are written to HBM as the neighbour list the
+host greedy merge consumes.  Inputs are resident in HBM before the timed region.
+With N > 1 ranks the pair space is sharded row-block-wise (no data-path
+collective inside the scoring); each step ends with the RCCL all-gather of the
+ranks' edge blocks, so every rank holds the whole neighbour graph.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_SEQ = 100_000
+SEQ_LEN = 12
+MAX_SHIFT, SHIFT_PENALTY, THRESHOLD = 3, 0, 20
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+LDS_LOOKUP_PEAK = 256 * 32 * 2.4e9   # ds_read_b64: 32 lanes/clk/CU x 256 CUs x 2.4 GHz
+
+
+def load_blosum62():
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        return np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+
+
+def cpu_baseline(M, res, off, n_sample, threads):
+    """The oracle's literal greedy (the reference's algorithm, OpenMP over the
+    reference's own 4*T partitions) on the first n_sample peptides of the workload:
+    counted sequenceScore calls / wall time."""
+    from oracle import c_oracle
+    sub_off = off[:n_sample + 1].copy()
+    sub_res = res[:sub_off[-1]].copy()
+    perm = c_oracle.sort_order(sub_res, sub_off, None, "size")
+    peps = [sub_res[sub_off[k]:sub_off[k + 1]] for k in perm]
+    sres, soff = c_oracle.pack(peps)
+    t0 = time.perf_counter()
+    st, cid, order, stats = c_oracle.greedy_cluster(M, sres, soff, None, 0, MAX_SHIFT, SHIFT_PENALTY, THRESHOLD,
+                                                    int(np.floor(n_sample * 0.025 + 0.5)), threads)
+    dt = time.perf_counter() - t0
+    calls = int(stats.score_calls_phase1 + stats.score_calls_phase2)
+    return {"value": calls / dt, "unit": "pair scores/s", "cores": threads, "kind": "port",
+            "sample": f"oracle greedy (sort + cluster, Hammock.java:406-411) on the first {n_sample} peptides of the "
+                      f"workload: {calls} sequenceScore calls in {dt:.2f} s, status {st}",
+            "seconds": dt, "score_calls": calls,
+            "pair_space_fraction": calls / (n_sample * (n_sample - 1) / 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=N_SEQ, help="number of synthetic peptides (default: the BASELINE workload)")
+    ap.add_argument("--cpu-sample", type=int, default=30000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-greedy", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import hammock_amd
+    from hammock_amd import _native
+    from hammock_amd.synth import synth_peptides
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    M = load_blosum62()
+    n = args.n
+    res, off = synth_peptides(1, n, SEQ_LEN)
+    ctx = hammock_amd.Context(M, device=local_rank)
+    ctx.set_sequences(residues=res, offsets=off)
+
+    # device buffers (torch = plumbing: memory, stream, collectives)
+    pairs_total = n * (n - 1) // 2
+    expect_edges = int(pairs_total * 3.2e-3 / world) + 65536
+    cap = (max(expect_edges * 2, 1 << 20) // _native.HMK_EDGE_SHARDS) * _native.HMK_EDGE_SHARDS
+    d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
+    d_counts = torch.zeros(_native.HMK_EDGE_SHARDS, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    seg = cap // _native.HMK_EDGE_SHARDS
+
+    def score_pass():
+        ctx.neighbors_shifted_dev(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, rank, world, d_edges.data_ptr(), cap,
+                                  d_counts.data_ptr(), stream.cuda_stream)
+
+    def exchange():
+        """RCCL all-gather of the ranks' compacted edge blocks (N > 1 only)."""
+        counts = d_counts.clone()
+        mine = torch.cat([d_edges[s * seg:s * seg + int(c)] for s, c in enumerate(counts.tolist())])
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, torch.tensor([mine.numel()], dtype=torch.int64, device=dev))
+        mx = int(sizes.max().item())
+        padded = torch.zeros(mx, dtype=torch.int64, device=dev)
+        padded[:mine.numel()] = mine
+        gathered = torch.empty(world * mx, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered, padded)
+        return gathered, sizes, mx
+
+    def step():
+        score_pass()
+        if world > 1:
+            exchange()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    plan = ctx.last_plan()
+    counts = d_counts.cpu().numpy().astype(np.int64)
+    if counts.max() > seg:
+        sys.exit(f"edge segment overflow: {counts.max()} > {seg}")
+    n_edges_rank = int(counts.sum())
+
+    # ---- timed region: exactly K steps -----------------------------------------------
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)   # HIP events on the stream the kernel is launched on
+        score_pass()
+        ev[k][1].record(stream)
+        if world > 1:
+            exchange()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    kern_ms = torch.tensor([float(np.mean([a.elapsed_time(b) for a, b in ev]))], dtype=torch.float64, device=dev)
+    tot_edges = torch.tensor([n_edges_rank], dtype=torch.int64, device=dev)
+    tot_pairs = torch.tensor([int(plan.pairs_scored)], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kern_ms, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot_edges)
+        dist.all_reduce(tot_pairs)
+    elapsed = float(elapsed.item())
+    kern_ms = float(kern_ms.item())
+    assert int(tot_pairs.item()) == pairs_total, (int(tot_pairs.item()), pairs_total)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = pairs_total / (elapsed / args.steps)
+        # dominant kernel: k_neighbors_swar<2,16,2,12,true>.  Algorithmic HBM bytes per launch
+        # (DESIGN.md "Roofline"): 8 B per emitted edge + 16 B per peptide read once.
+        pairs_rank = int(plan.pairs_scored)
+        alg_bytes = 8 * n_edges_rank + 16 * n
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        lookups = pairs_rank * SEQ_LEN / (kern_ms * 1e-3)
+        line = {
+            "metric": "pairwise BLOSUM62 ShiftedScorer scores/sec (all-vs-all, thresholded neighbour list)",
+            "value": value, "unit": "pair scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{n} synthetic length-{SEQ_LEN} peptides (SplitMix64 seed 1), BLOSUM62, max_shift "
+                                   f"{MAX_SHIFT}, shift_penalty {SHIFT_PENALTY}, threshold {THRESHOLD}; "
+                                   f"{pairs_total} unordered pairs per step",
+                       "parallelism": f"row-block sharding over {world} GPU(s)" + (", RCCL all-gather of edge blocks"
+                                                                                  if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_neighbors_swar<NW=2,R=16,CPL=2,LB=12>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "HBM does not bind this path (SURVEY.md 8d): the kernel is bound by LDS lookups",
+                         "lds": {"achieved_lookups_per_s": lookups, "peak_lookups_per_s": LDS_LOOKUP_PEAK,
+                                 "frac": lookups / LDS_LOOKUP_PEAK,
+                                 "definition": "12 ds_read_b64 table lookups per pair / (32 lanes/clk/CU x 256 CU x 2.4 GHz)"}},
+            "edges_per_step": int(tot_edges.item()),
+        }
+        if world == 1:
+            if not args.no_greedy:
+                t = time.perf_counter()
+                cid, order, gstats = ctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, int(np.floor(n * 0.025 + 0.5)))
+                line["greedy_end_to_end"] = {
+                    "wall_s": time.perf_counter() - t, "neighbors_ms_incl_d2h": gstats.neighbors_ms,
+                    "host_merge_ms": gstats.greedy_ms, "clusters": int(gstats.n_multi),
+                    "result_list": int(gstats.n_result_clusters),
+                    "note": "input order as generated (Hammock -R input); score + D2H + host greedy merge"}
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(M, res, off, min(args.cpu_sample, n), min(16, os.cpu_count() or 1))
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,14 @@ def _load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C hammock_amd/csrc`.  hammock_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so
+    # (same SONAME, libamdhip64.so.7).  If torch is importable, load it FIRST so that
+    # our NEEDED libamdhip64.so.7 resolves to the copy torch uses; two copies in one
+    # process cannot both open the GPU ("no ROCm-capable device is detected").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, u32, u64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64
     p_i32, p_u32, p_u64, p_u8 = (C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),

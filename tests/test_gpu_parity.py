@@ -118,8 +118,11 @@ def test_blocks_and_edge_cases(gpu, blosum62, coracle):
     assert np.array_equal(got, want)
     assert ctx.score_block_shifted(5, 5, 0, 10, 3, 0).shape == (0, 10)      # empty block
     assert ctx.score_pairs_shifted([], [], 3, 0).size == 0                   # empty pair list
+    lens = np.diff(off.astype(np.int64))
+    short = int(np.argmin(lens))
     with pytest.raises(hammock_amd.DataException):
-        ctx.score_pairs_shifted([0], [1], 7, 0)                              # shift >= shortest
+        ctx.score_pairs_shifted([0], [short], int(lens[short]), 0)           # shift >= shortest
+    assert ctx.score_pairs_shifted([short], [short], int(lens[short]) - 1, 0).size == 1
     with pytest.raises(ValueError):
         ctx.score_pairs_shifted([0], [300], 3, 0)                            # index out of range
     empty = hammock_amd.Context(blosum62, device=0)
@@ -226,9 +229,10 @@ def test_greedy_musi_matches_oracle_pin(gpu, blosum62):
     assert clusterer.stats.phase1_stop_index == pin["phase1_stop_index"]
 
 
-@pytest.mark.parametrize("cfg", [(1, 10000, 12, 12, 0), (2, 6000, 7, 20, -1)])
+@pytest.mark.parametrize("cfg", [(1, 10000, 12, 12, 0, 0), (2, 6000, 7, 20, -1, 0), (2, 6000, 7, 20, -1, -7),
+                                 (3, 20000, 12, 12, 0, 0)])
 def test_greedy_synthetic_vs_oracle(gpu, blosum62, coracle, cfg):
-    seed, n, lo, hi, p = cfg
+    seed, n, lo, hi, p, dthr = cfg
     res, off = synth_peptides(seed, n, lo, hi)
     rng = np.random.default_rng(seed)
     sizes = np.ones(n, dtype=np.int32)
@@ -239,10 +243,16 @@ def test_greedy_synthetic_vs_oracle(gpu, blosum62, coracle, cfg):
     res, off = hammock_amd.pack_sequences(peps)
     L = np.diff(off.astype(np.int64))
     thr, X, maxc = po.java_round(L.mean() * 1.7), min(po.java_round(L.mean() / 4), int(L.min()) - 1), po.java_round(n * 0.025)
+    thr += dthr
     ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
-    cid, order, stats = ctx.greedy_cluster(X, p, thr, maxc)
     st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, X, p, thr, maxc, 8)
+    if st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH:  # the reference's NPE is part of the contract
+        with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
+            ctx.greedy_cluster(X, p, thr, maxc)
+        assert (ei.value.case, ei.value.index) == (ostats.crash_case, ostats.crash_index)
+        return
     assert st == 0
+    cid, order, stats = ctx.greedy_cluster(X, p, thr, maxc)
     assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
     assert stats.phase1_stop_index == ostats.phase1_stop_index and stats.n_multi == ostats.n_multi
 
