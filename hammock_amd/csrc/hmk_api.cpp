@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -33,6 +34,8 @@ struct Plan {
     uint32_t part = 0, n_parts = 1;
     int lbmax = 12, lpad = 16;
     bool exact = false;
+    int hot_variant = 1;
+    uint32_t cols_per_tile = 16384;
     uint8_t *d_res_sorted = nullptr;
     uint32_t *d_perm = nullptr;
     uint8_t *d_mb = nullptr;
@@ -178,12 +181,21 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     pl.lbmax = ctx->max_len <= 12 ? 12 : ctx->max_len <= 20 ? 20 : 32;
     pl.lpad = pl.lbmax == 12 ? 16 : 32;
     pl.exact = ctx->min_len == 12 && ctx->max_len == 12;
+    // Tiling (measured on MI355X, tools/tune_hot.py): 8 rows x 2 columns per lane and long
+    // column runs win (5 workgroups/CU, table build amortised); shrink the runs for small
+    // inputs so the grid still has a few thousand workgroups.
+    pl.hot_variant = 1;
+    pl.cols_per_tile = 16384;
+    while (pl.cols_per_tile > 1024 && ((uint64_t)n / 8 + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
+        pl.cols_per_tile /= 2;
+    if (const char *v = getenv("HMK_HOT_VARIANT")) pl.hot_variant = atoi(v);   // tuning knobs
+    if (const char *v = getenv("HMK_COLS_PER_TILE")) pl.cols_per_tile = (uint32_t)std::max(256, atoi(v));
 
     // ---- classes and tiles --------------------------------------------------------
     std::vector<TileClass> classes;
     std::map<int, int> class_of;  // la * 64 + lb
     std::map<std::pair<int, int>, std::vector<Tile>> grouped;  // (path, nw)
-    const uint32_t COLS = 4096;
+    const uint32_t COLS = pl.cols_per_tile;
     hmk_neighbor_stats &S = pl.stats;
     S = hmk_neighbor_stats{};
     S.symmetric = ctx->symmetric;
@@ -205,7 +217,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
             if (tc.path == PATH_U8) S.classes_u8++;
             else if (tc.path == PATH_U16) S.classes_u16++;
             else S.classes_direct++;
-            const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(pl.lbmax, tc.nw);
+            const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(pl.lbmax, tc.nw, pl.exact, pl.hot_variant);
             std::vector<Tile> &dst = grouped[{tc.path, tc.path == PATH_DIRECT ? 0 : tc.nw}];
             for (uint32_t r0 = rb; r0 < re; r0 += R) {
                 const bool mine = (row_chunk_counter++ % n_parts) == part;
@@ -301,7 +313,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
         if (g.path == PATH_DIRECT)
             HIPCHK(ctx, launch_neighbors_direct(P, g.base, g.count, ctx->d_M, X, p, thr, stream));
         else
-            HIPCHK(ctx, launch_neighbors_swar(pl.lbmax, g.nw, pl.exact, P, g.base, g.count, stream));
+            HIPCHK(ctx, launch_neighbors_swar(pl.lbmax, g.nw, pl.exact, pl.hot_variant, P, g.base, g.count, stream));
     }
     return HMK_OK;
 }

@@ -10,10 +10,10 @@
 namespace hmk {
 
 // rows per tile the SWAR kernel instantiation (lbmax, nw) was built with
-int swar_rows_per_tile(int lbmax, int nw);
+int swar_rows_per_tile(int lbmax, int nw, bool exact, int hot_variant);
 
-hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, const NeighborParams &P, uint32_t tile_base,
-                                 uint32_t n_tiles, hipStream_t s);
+hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant, const NeighborParams &P,
+                                 uint32_t tile_base, uint32_t n_tiles, hipStream_t s);
 hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
                                    const int32_t *d_matrix, int max_shift, int shift_penalty, int threshold,
                                    hipStream_t s);

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
     constexpr int ES = NW * 4;                 // table entry bytes
     constexpr int ROWBYTES = LBMAX * 24 * ES;  // one row's tables
     constexpr int TAB_BYTES = R * ROWBYTES;
-    constexpr int STAGE_CAP = 64 * CPL + 64;
+    constexpr int STAGE_CAP = 128;             // records per wave; flushed when fewer than 64 slots are free
     constexpr int REC_DW = NW + 2;
     constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;  // dwords per stored residue row (lpad 16 / 32)
     static_assert(TAB_BYTES <= 65536, "row tables must stay addressable by the DS immediate offset");
@@ -300,6 +300,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
     const uint32_t tab_addr = lds_addr(tab);
     const uint32_t col_end = T.col0 + T.ncols;
     const uint32_t n_batches = (T.ncols + 256 * CPL - 1) / (256 * CPL);
+    const bool interior = T.diag == 0 && T.ncols % (256 * CPL) == 0;  // every lane's column is a real pair
 
     for (uint32_t bt = 0; bt < n_batches; bt++) {
         // ---- this lane's CPL column peptides -> per-position table offsets ------
@@ -331,50 +332,57 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if ((uint32_t)r < T.nrows) {
-                if (cnt > (uint32_t)(STAGE_CAP - 64 * CPL)) {  // keep room for one row of hits
-                    flush_stage<NW>(stage, cnt, P, T, g, lane16, shard);
-                    cnt = 0;
-                }
+                // all CPL accumulations first (CPL * LB independent LDS reads in flight), tests after
+                uint32_t W[CPL][NW];
 #pragma unroll
                 for (int p = 0; p < CPL; p++) {
-                    uint32_t W[NW];
 #pragma unroll
-                    for (int w = 0; w < NW; w++) W[w] = cinit[w];
+                    for (int w = 0; w < NW; w++) W[p][w] = cinit[w];
 #pragma unroll
                     for (int j = 0; j < LBMAX; j++) {
                         if (EXACT || j < lb) {
                             const uint32_t ea = off[p][j] + (uint32_t)(r * ROWBYTES);
                             if (NW == 1) {
-                                W[0] += lds_read<uint32_t>(ea);
+                                W[p][0] += lds_read<uint32_t>(ea);
                             } else if (NW == 2) {
                                 const u32x2 e = lds_read<u32x2>(ea);
-                                W[0] += e.x; W[1] += e.y;
+                                W[p][0] += e.x; W[p][1] += e.y;
                             } else {
 #pragma unroll
                                 for (int q = 0; q < NW / 4; q++) {
                                     const u32x4 e = lds_read<u32x4>(ea + 16 * q);
-                                    W[4 * q + 0] += e.x; W[4 * q + 1] += e.y;
-                                    W[4 * q + 2] += e.z; W[4 * q + 3] += e.w;
+                                    W[p][4 * q + 0] += e.x; W[p][4 * q + 1] += e.y;
+                                    W[p][4 * q + 2] += e.z; W[p][4 * q + 3] += e.w;
                                 }
                             }
                         }
                     }
-                    uint32_t any = W[0];
+                }
 #pragma unroll
-                    for (int w = 1; w < NW; w++) any |= W[w];
+                for (int p = 0; p < CPL; p++) {
+                    uint32_t any = W[p][0];
+#pragma unroll
+                    for (int w = 1; w < NW; w++) any |= W[p][w];
                     const bool hit = (any & himask) != 0;  // some shift reached score >= threshold
                     if (__ballot(hit) != 0) {              // wave-uniform, rare
+                        if (cnt > (uint32_t)(STAGE_CAP - 64)) {  // keep room for one wave of hits
+                            flush_stage<NW>(stage, cnt, P, T, g, lane16, shard);
+                            cnt = 0;
+                        }
                         const uint32_t col = colpos[p];
-                        bool keep = hit && col < col_end;
-                        if (T.diag == 1) keep = keep && col > T.row0 + r;   // triangle: column after row
-                        if (T.diag == 2) keep = keep && col != T.row0 + r;  // full square minus the diagonal
+                        bool keep = hit;
+                        if (!interior) {  // wave-uniform: only edge tiles filter
+                            keep = keep && col < col_end;
+                            if (T.diag == 1) keep = keep && col > T.row0 + r;   // triangle: column after row
+                            if (T.diag == 2) keep = keep && col != T.row0 + r;  // full square minus the diagonal
+                        }
                         const uint64_t mask = __ballot(keep);
                         if (keep) {
                             uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
                             rec[0] = col;
                             rec[1] = (uint32_t)r;
 #pragma unroll
-                            for (int w = 0; w < NW; w++) rec[2 + w] = W[w];
+                            for (int w = 0; w < NW; w++) rec[2 + w] = W[p][w];
                         }
                         cnt += (uint32_t)__popcll(mask);
                     }
@@ -466,23 +474,40 @@ static hipError_t launch_swar_t(const NeighborParams &P, uint32_t tile_base, uin
     return hipGetLastError();
 }
 
-int swar_rows_per_tile(int lbmax, int nw) {
+// Hot-path tilings of the exact length-12, NW = 2 kernel: {rows per tile, columns per lane}.
+static const int kHotVariants[][2] = {{16, 2}, {8, 2}, {12, 2}, {8, 4}, {16, 4}, {12, 4}, {4, 2}, {6, 2}, {8, 3}, {8, 1}, {10, 2}};
+constexpr int kNumHotVariants = sizeof(kHotVariants) / sizeof(kHotVariants[0]);
+
+int swar_rows_per_tile(int lbmax, int nw, bool exact, int hot_variant) {
+    if (exact && lbmax == 12 && nw == 2 && hot_variant >= 0 && hot_variant < kNumHotVariants)
+        return kHotVariants[hot_variant][0];
     const int rowbytes = lbmax * 24 * nw * 4;
     int r = 16;
     while (r > 1 && r * rowbytes > 40960) r >>= 1;
     return r;
 }
 
-hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, const NeighborParams &P, uint32_t tile_base,
-                                 uint32_t n_tiles, hipStream_t s) {
+hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant, const NeighborParams &P,
+                                 uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-#define HMK_CASE(LB, NWV, RV, CPLV)                                                              \
-    if (lbmax == LB && nw == NWV) {                                                              \
-        if constexpr (LB == 12 && NWV == 2) {                                                    \
-            if (exact) return launch_swar_t<NWV, RV, CPLV, LB, true>(P, tile_base, n_tiles, s);  \
-        }                                                                                        \
-        return launch_swar_t<NWV, RV, CPLV, LB, false>(P, tile_base, n_tiles, s);                \
+    if (exact && lbmax == 12 && nw == 2) {
+        switch (hot_variant) {
+            case 0: return launch_swar_t<2, 16, 2, 12, true>(P, tile_base, n_tiles, s);
+            case 1: return launch_swar_t<2, 8, 2, 12, true>(P, tile_base, n_tiles, s);
+            case 2: return launch_swar_t<2, 12, 2, 12, true>(P, tile_base, n_tiles, s);
+            case 3: return launch_swar_t<2, 8, 4, 12, true>(P, tile_base, n_tiles, s);
+            case 4: return launch_swar_t<2, 16, 4, 12, true>(P, tile_base, n_tiles, s);
+            case 5: return launch_swar_t<2, 12, 4, 12, true>(P, tile_base, n_tiles, s);
+            case 6: return launch_swar_t<2, 4, 2, 12, true>(P, tile_base, n_tiles, s);
+            case 7: return launch_swar_t<2, 6, 2, 12, true>(P, tile_base, n_tiles, s);
+            case 8: return launch_swar_t<2, 8, 3, 12, true>(P, tile_base, n_tiles, s);
+            case 9: return launch_swar_t<2, 8, 1, 12, true>(P, tile_base, n_tiles, s);
+            case 10: return launch_swar_t<2, 10, 2, 12, true>(P, tile_base, n_tiles, s);
+            default: return hipErrorInvalidValue;
+        }
     }
+#define HMK_CASE(LB, NWV, RV, CPLV) \
+    if (lbmax == LB && nw == NWV) return launch_swar_t<NWV, RV, CPLV, LB, false>(P, tile_base, n_tiles, s);
     HMK_CASE(12, 1, 16, 2) HMK_CASE(12, 2, 16, 2) HMK_CASE(12, 4, 8, 1) HMK_CASE(12, 8, 4, 1)
     HMK_CASE(20, 1, 16, 2) HMK_CASE(20, 2, 8, 2)  HMK_CASE(20, 4, 4, 1) HMK_CASE(20, 8, 2, 1)
     HMK_CASE(32, 1, 8, 2)  HMK_CASE(32, 2, 4, 2)  HMK_CASE(32, 4, 2, 1) HMK_CASE(32, 8, 1, 1)
