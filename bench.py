@@ -80,6 +80,7 @@ def main():
 
     import hammock_amd
     from hammock_amd import _native
+    from hammock_amd import dist as hd
     from hammock_amd.synth import synth_peptides
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,17 +116,9 @@ def main():
                                   d_counts.data_ptr(), stream.cuda_stream)
 
     def exchange():
-        """RCCL all-gather of the ranks' compacted edge blocks (N > 1 only)."""
-        counts = d_counts.clone()
-        mine = torch.cat([d_edges[s * seg:s * seg + int(c)] for s, c in enumerate(counts.tolist())])
-        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(sizes, torch.tensor([mine.numel()], dtype=torch.int64, device=dev))
-        mx = int(sizes.max().item())
-        padded = torch.zeros(mx, dtype=torch.int64, device=dev)
-        padded[:mine.numel()] = mine
-        gathered = torch.empty(world * mx, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gathered, padded)
-        return gathered, sizes, mx
+        """RCCL all-gather of the ranks' compacted edge blocks (N > 1 only): afterwards every
+        rank holds the whole neighbour graph in HBM, ready for the host-side greedy merge."""
+        return hd.all_gather_edges(hd.compact_shards(d_edges, d_counts))
 
     def step():
         score_pass()

@@ -1,0 +1,109 @@
+"""Multi-GPU form of the hot path: one process per GPU (torch.distributed, backend
+"nccl" = RCCL over xGMI; "gloo" on CPU for the tests).
+
+The pair space is sharded row-block-wise: rank r scores the row blocks with
+(block index mod world) == r against all their columns -- no collective in the
+scoring itself.  The only exchange is the all-gather of the ranks' edge blocks
+(the thresholded neighbour lists) before the host-side greedy merge; after it
+every rank holds the whole neighbour graph, rank 0 merges and broadcasts the
+cluster ids.  torch is plumbing here: device memory, the stream and the
+collectives.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+from .api import Context
+
+
+def compact_shards(d_edges: torch.Tensor, d_counts: torch.Tensor) -> torch.Tensor:
+    """The kernel writes HMK_EDGE_SHARDS segments; returns their valid prefixes concatenated."""
+    seg = d_edges.numel() // N.HMK_EDGE_SHARDS
+    counts = d_counts.tolist()
+    if max(counts) > seg:
+        raise BufferError(f"edge segment overflow: {max(counts)} > {seg}")
+    return torch.cat([d_edges[s * seg:s * seg + int(c)] for s, c in enumerate(counts)])
+
+
+def neighbors_local(ctx: Context, max_shift, shift_penalty, threshold, rank, world, device, capacity=None):
+    """This rank's shard of the neighbour graph as a device tensor of packed edges (int64 view of uint64)."""
+    n = ctx.n
+    if capacity is None:
+        capacity = int(n * (n - 1) // 2 * 6e-3 / world) + (1 << 20)
+    capacity = (capacity // N.HMK_EDGE_SHARDS + 1) * N.HMK_EDGE_SHARDS
+    while True:
+        d_edges = torch.empty(capacity, dtype=torch.int64, device=device)
+        d_counts = torch.zeros(N.HMK_EDGE_SHARDS, dtype=torch.int64, device=device)
+        stream = torch.cuda.current_stream(device)
+        ctx.neighbors_shifted_dev(max_shift, shift_penalty, threshold, rank, world, d_edges.data_ptr(), capacity,
+                                  d_counts.data_ptr(), stream.cuda_stream)
+        mx = int(d_counts.max().item())
+        if mx <= capacity // N.HMK_EDGE_SHARDS:
+            return compact_shards(d_edges, d_counts)
+        capacity = (mx + mx // 8 + 1024) * N.HMK_EDGE_SHARDS  # a segment overflowed: rescore with room
+
+
+def all_gather_edges(local: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather of variable-length edge blocks: one small all-gather of the lengths,
+    then one all-gather of blocks padded to the longest.  Returns every rank's edges
+    concatenated in rank order (same on all ranks)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    sizes = torch.zeros(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=local.device),
+                                group=group)
+    sizes_h = sizes.tolist()
+    mx = max(max(sizes_h), 1)
+    padded = torch.zeros(mx, dtype=torch.int64, device=local.device)
+    padded[:local.numel()] = local
+    gathered = torch.empty(world * mx, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+    return torch.cat([gathered[r * mx:r * mx + sizes_h[r]] for r in range(world)])
+
+
+def merge_and_broadcast(ctx: Context, edges_all: torch.Tensor, symmetric: bool, threshold, max_clusters, group=None):
+    """Host greedy merge on rank 0 (hmk_greedy_from_edges), result broadcast to every rank.
+    -> (cluster_id int32[n], result_order int32[n_result], status dict).  A reference crash
+    (NullPointerException parity) is raised on every rank."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = ctx.n
+    dev = edges_all.device
+    header = torch.zeros(4, dtype=torch.int64, device=dev)  # status, n_result, crash_case, crash_index
+    cid = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    order = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    err = None
+    if rank == 0:
+        from .api import ReferenceWouldCrash
+        edges = edges_all.cpu().numpy().view(np.uint64)
+        try:
+            c, o, st = ctx.greedy_from_edges(edges, symmetric, threshold, max_clusters)
+            header[1] = len(o)
+            cid[:n] = torch.from_numpy(c).to(dev)
+            order[:len(o)] = torch.from_numpy(o).to(dev)
+        except ReferenceWouldCrash as e:
+            err = e
+            header[0], header[2], header[3] = N.HMK_ERR_REFERENCE_WOULD_CRASH, e.case, e.index
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(header, 0, group=group)
+        dist.broadcast(cid, 0, group=group)
+        dist.broadcast(order, 0, group=group)
+    h = header.tolist()
+    if h[0] == N.HMK_ERR_REFERENCE_WOULD_CRASH:
+        from .api import ReferenceWouldCrash
+        raise err or ReferenceWouldCrash("the reference throws NullPointerException here", h[2], h[3])
+    return cid[:n].cpu().numpy(), order[:h[1]].cpu().numpy(), {"n_result_clusters": h[1]}
+
+
+def greedy_cluster_distributed(ctx: Context, max_shift, shift_penalty, threshold, max_clusters, device, group=None):
+    """LimitedGreedySequenceClusterer.cluster over all ranks of `group`: identical result on every rank,
+    identical to the single-GPU hmk_greedy_cluster."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    local = neighbors_local(ctx, max_shift, shift_penalty, threshold, rank, world, device)
+    edges_all = all_gather_edges(local, group) if world > 1 else local
+    symmetric = bool((ctx.matrix == ctx.matrix.T).all())
+    return merge_and_broadcast(ctx, edges_all, symmetric, threshold, max_clusters, group)

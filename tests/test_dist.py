@@ -1,0 +1,115 @@
+"""The N > 1 path.  CPU: world_size-2 gloo run of the exchange + merge + broadcast with the
+ranks' edge shards supplied by the oracle scorer (the product has no CPU scorer).  GPU: two
+ranks sharing the one MI355X of the box over RCCL, end to end through the kernel."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, random_peptides
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import json
+    import hammock_amd
+    from hammock_amd import dist as hd
+    from oracle import c_oracle
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+    rng = np.random.default_rng(42)
+    peps = random_peptides(rng, 600, 12, 12, alphabet=5)
+    res, off = c_oracle.pack(peps)
+    n, X, p, thr, maxc = len(peps), 3, 0, 20, 15
+    # this rank's row blocks (16 rows each, cyclic), scored by the ORACLE
+    rows = np.array([r for r in range(n) if (r // 16) % world == rank], dtype=np.uint32)
+    xs, ms, ss = [], [], []
+    for x in rows:
+        m = np.arange(x + 1, n, dtype=np.uint32)
+        st, sc = c_oracle.score_pairs(M, res, off, m, np.full(len(m), x, np.uint32), 0, X, p)
+        keep = sc >= thr
+        xs.append(np.full(int(keep.sum()), x)); ms.append(m[keep]); ss.append(sc[keep])
+    local = hammock_amd.pack_edges(np.concatenate(xs), np.concatenate(ms), np.concatenate(ss))
+    local_t = torch.from_numpy(local.view(np.int64).copy())
+    allv = hd.all_gather_edges(local_t)
+    ctx = hammock_amd.Context(M, device=-1)
+    ctx.set_sequences(residues=res, offsets=off)
+    cid, order, info = hd.merge_and_broadcast(ctx, allv, True, thr, maxc)
+    st, ocid, oorder, _ = c_oracle.greedy_cluster(M, res, off, None, 0, X, p, thr, maxc, 1)
+    ok = st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    q.put((rank, bool(ok), int(allv.numel()), int(local_t.numel())))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_exchange_and_merge():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort()
+    assert all(o[1] for o in out), out
+    assert out[0][2] == out[1][2] == out[0][3] + out[1][3]  # every rank holds the union
+
+
+def _gpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share ONE GPU: gloo carries the exchange
+    import json
+    import hammock_amd
+    from hammock_amd import dist as hd
+    from hammock_amd.synth import synth_peptides
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+    res, off = synth_peptides(1, 20000, 12)
+    ctx = hammock_amd.Context(M, device=0)
+    ctx.set_sequences(residues=res, offsets=off)
+    local = hd.neighbors_local(ctx, 3, 0, 20, rank, world, dev).cpu()
+    allv = hd.all_gather_edges(local)
+    cid, order, info = hd.merge_and_broadcast(ctx, allv, True, 20, 500)
+    single_cid, single_order, _ = ctx.greedy_cluster(3, 0, 20, 500)
+    ok = np.array_equal(cid, single_cid) and np.array_equal(order, single_order)
+    q.put((rank, bool(ok), int(allv.numel()), int(local.numel())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_match_single_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out.sort()
+    assert all(o[1] for o in out), out
+    assert out[0][2] == out[1][2] == out[0][3] + out[1][3]
