@@ -26,7 +26,7 @@ HMK_MAX_LEN = 32
 # every symbol include/hammock_hip.h declares
 SYMBOLS = [
     "hmk_abi_version", "hmk_create", "hmk_destroy", "hmk_last_error", "hmk_set_sequences",
-    "hmk_score_pairs_shifted", "hmk_score_pairs_local", "hmk_score_block_shifted", "hmk_score_block_local",
+    "hmk_score_pairs_shifted", "hmk_score_with_shift", "hmk_score_pairs_local", "hmk_score_block_shifted", "hmk_score_block_local",
     "hmk_neighbors_shifted", "hmk_neighbors_shifted_dev", "hmk_neighbors_last_plan",
     "hmk_greedy_cluster", "hmk_greedy_from_edges",
 ]
@@ -75,6 +75,7 @@ def _load():
     L.hmk_set_sequences.argtypes = [vp, p_u8, p_u32, p_i32, u32]
     L.hmk_score_pairs_shifted.argtypes = [vp, p_u32, p_u32, u64, i32, i32, p_i32]
     L.hmk_score_pairs_local.argtypes = [vp, p_u32, p_u32, u64, i32, i32, p_i32]
+    L.hmk_score_with_shift.argtypes = [vp, p_u32, p_u32, u64, i32, i32, p_i32, p_i32]
     L.hmk_score_block_shifted.argtypes = [vp, u32, u32, u32, u32, i32, i32, p_i32]
     L.hmk_score_block_local.argtypes = [vp, u32, u32, u32, u32, i32, i32, p_i32]
     L.hmk_neighbors_shifted.argtypes = [vp, i32, i32, i32, u32, u32, p_u64, u64, p_u64, C.POINTER(NeighborStats)]

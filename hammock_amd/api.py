@@ -167,6 +167,18 @@ class Context:
     def score_pairs_shifted(self, i, j, max_shift, shift_penalty):
         return self._pairs(N.lib.hmk_score_pairs_shifted, i, j, max_shift, shift_penalty)
 
+    def score_with_shift(self, i, j, max_shift, shift_penalty):
+        """-> (score, shift) arrays: AligningSequenceScorer.scoreWithShift for every pair."""
+        i = np.ascontiguousarray(i, dtype=np.uint32)
+        j = np.ascontiguousarray(j, dtype=np.uint32)
+        score = np.empty(i.size, dtype=np.int32)
+        shift = np.empty(i.size, dtype=np.int32)
+        st = N.lib.hmk_score_with_shift(self._h, _ptr(i, C.c_uint32), _ptr(j, C.c_uint32), i.size, int(max_shift),
+                                        int(shift_penalty), _ptr(score, C.c_int32), _ptr(shift, C.c_int32))
+        if st:
+            self._raise(st)
+        return score.reshape(i.shape), shift.reshape(i.shape)
+
     def score_pairs_local(self, i, j, gap_open, gap_extend):
         return self._pairs(N.lib.hmk_score_pairs_local, i, j, gap_open, gap_extend)
 
@@ -333,6 +345,11 @@ class ShiftedScorer(_GpuScorer):
 
     def sequenceScore(self, seq1, seq2):  # :98-100; throws DataException (:59-62)
         return self._score(seq1, seq2)
+
+    def scoreWithShift(self, seq1, seq2):  # :48-95 -> (score, shift), AligningScorerResult
+        self._ctx.set_sequences([seq1.sequence, seq2.sequence])
+        score, shift = self._ctx.score_with_shift([0], [1], self.maxShift, self.shiftPenalty)
+        return int(score[0]), int(shift[0])
 
 
 class LocalAlignmentScorer(_GpuScorer):

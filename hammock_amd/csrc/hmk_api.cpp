@@ -376,7 +376,7 @@ int check_pairs(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_p
 }
 
 int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, int a, int b,
-                int32_t *out) {
+                int32_t *out, int32_t *out_shift = nullptr) {
     std::lock_guard<std::mutex> lock(ctx->mu);
     int st = need_device(ctx);
     if (st) return st;
@@ -386,23 +386,26 @@ int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, 
     if (n_pairs && !out) return fail(ctx, HMK_ERR_BAD_ARG, "null output");
     const uint64_t CH = 1ull << 24;
     uint32_t *d_i = nullptr, *d_j = nullptr;
-    int32_t *d_out = nullptr;
+    int32_t *d_out = nullptr, *d_shift = nullptr;
     const uint64_t ch = std::min<uint64_t>(CH, std::max<uint64_t>(n_pairs, 1));
     HIPCHK(ctx, hipMalloc((void **)&d_i, ch * 4));
     HIPCHK(ctx, hipMalloc((void **)&d_j, ch * 4));
     HIPCHK(ctx, hipMalloc((void **)&d_out, ch * 4));
+    if (out_shift) HIPCHK(ctx, hipMalloc((void **)&d_shift, ch * 4));
     st = HMK_OK;
     for (uint64_t o = 0; o < n_pairs && st == HMK_OK; o += ch) {
         const uint64_t m = std::min(ch, n_pairs - o);
         hipError_t e = hipMemcpy(d_i, i + o, m * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_j, j + o, m * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, d_i, d_j, m, 0, 0, 1, a, b, d_out, nullptr);
+        if (e == hipSuccess) e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, d_i, d_j, m, 0, 0, 1, a, b, d_out, d_shift, nullptr);
         if (e == hipSuccess) e = hipMemcpy(out + o, d_out, m * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && out_shift) e = hipMemcpy(out_shift + o, d_shift, m * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) st = fail(ctx, HMK_ERR_DEVICE, std::string("score_pairs: ") + hipGetErrorString(e));
     }
     (void)hipFree(d_i);
     (void)hipFree(d_j);
     (void)hipFree(d_out);
+    if (d_shift) (void)hipFree(d_shift);
     return st;
 }
 
@@ -428,7 +431,7 @@ int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0,
     int32_t *d_out = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&d_out, n_pairs * 4));
     hipError_t e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, nullptr, nullptr, n_pairs, r0, c0, c1 - c0, a, b,
-                                d_out, nullptr);
+                                d_out, nullptr, nullptr);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, n_pairs * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, HMK_ERR_DEVICE, std::string("score_block: ") + hipGetErrorString(e));
@@ -566,6 +569,13 @@ int hmk_score_pairs_shifted(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, 
                             int shift_penalty, int32_t *out) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     return score_pairs(ctx, 0, i, j, n_pairs, max_shift, shift_penalty, out);
+}
+
+int hmk_score_with_shift(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, int max_shift,
+                         int shift_penalty, int32_t *score, int32_t *shift) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    if (n_pairs && !shift) return fail(ctx, HMK_ERR_BAD_ARG, "null shift output");
+    return score_pairs(ctx, 0, i, j, n_pairs, max_shift, shift_penalty, score, shift);
 }
 
 int hmk_score_pairs_local(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, int gap_open,

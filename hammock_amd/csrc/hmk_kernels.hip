@@ -45,12 +45,13 @@ __device__ __forceinline__ T lds_read(uint32_t addr) {
 // ShiftedScorer.scoreWithShift, ShiftedScorer.java:48-95.  M: int32[576] in LDS.
 __device__ __forceinline__ int shifted_score_literal(const int *M, const uint8_t *seq1, int len1,
                                                      const uint8_t *seq2, int len2, int max_shift,
-                                                     int shift_penalty) {
+                                                     int shift_penalty, int *shift_out = nullptr) {
     const uint8_t *shorter, *longer;
     int slen, llen;
     if (len1 >= len2) { shorter = seq2; slen = len2; longer = seq1; llen = len1; }   // :51-57
     else              { shorter = seq1; slen = len1; longer = seq2; llen = len2; }
     int best = INT32_MIN;
+    int best_shift = 0;                                                                // :65
     const int diff = llen - slen;                                                      // :66
     for (int s = -max_shift; s <= max_shift + diff; s++) {                             // :67
         int actual = 0;
@@ -63,8 +64,9 @@ __device__ __forceinline__ int shifted_score_literal(const int *M, const uint8_t
         actual += diff * shift_penalty;                                                // :79
         if (s < 0) actual += -s * 2 * shift_penalty;                                   // :80-82
         if (s > diff) actual += (s - diff) * 2 * shift_penalty;                        // :83-85
-        if (actual > best) best = actual;                                              // :86-89
+        if (actual > best) { best = actual; best_shift = s; }                          // :86-89
     }
+    if (shift_out) *shift_out = (len1 >= len2) ? best_shift : -best_shift;             // :91-93
     return best;
 }
 
@@ -123,7 +125,7 @@ __global__ void __launch_bounds__(256)
 k_pairs(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len, const int32_t *__restrict__ Mg,
         const uint32_t *__restrict__ pi, const uint32_t *__restrict__ pj, uint64_t n_pairs,
         uint32_t block_r0, uint32_t block_c0, uint32_t block_w,  // block mode when pi == nullptr
-        int a, int b, int32_t *__restrict__ out) {
+        int a, int b, int32_t *__restrict__ out, int32_t *__restrict__ out_shift) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     int *M = reinterpret_cast<int *>(smem);                                   // 576 dwords
     uint32_t *seqs = reinterpret_cast<uint32_t *>(smem + 2304);               // 256 * 2 * 9 dwords
@@ -141,10 +143,12 @@ k_pairs(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len, cons
         stage_sequence(s2, res32, j);
         const int l1 = len[i], l2 = len[j];
         int score;
-        if (SCORER == 0)
+        if (SCORER == 0) {
+            int shift = 0;
             score = shifted_score_literal(M, reinterpret_cast<const uint8_t *>(s1), l1,
-                                          reinterpret_cast<const uint8_t *>(s2), l2, a, b);
-        else
+                                          reinterpret_cast<const uint8_t *>(s2), l2, a, b, &shift);
+            if (out_shift) out_shift[k] = shift;
+        } else
             score = local_score_literal(M, reinterpret_cast<const uint8_t *>(s1), l1,
                                         reinterpret_cast<const uint8_t *>(s2), l2, a, b, dp + tid, 256);
         out[k] = score;
@@ -527,7 +531,7 @@ hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, 
 
 hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix,
                         const uint32_t *pi, const uint32_t *pj, uint64_t n_pairs, uint32_t r0, uint32_t c0,
-                        uint32_t width, int a, int b, int32_t *out, hipStream_t s) {
+                        uint32_t width, int a, int b, int32_t *out, int32_t *out_shift, hipStream_t s) {
     if (n_pairs == 0) return hipSuccess;
     uint64_t blocks = (n_pairs + 255) / 256;
     if (blocks > 65536) blocks = 65536;
@@ -535,10 +539,10 @@ hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, co
     const size_t lds_local = lds_shift + 33 * 256 * 4;
     if (scorer == 0)
         hipLaunchKernelGGL(k_pairs<0>, dim3((uint32_t)blocks), dim3(256), lds_shift, s, res32, len, d_matrix, pi, pj,
-                           n_pairs, r0, c0, width, a, b, out);
+                           n_pairs, r0, c0, width, a, b, out, out_shift);
     else
         hipLaunchKernelGGL(k_pairs<1>, dim3((uint32_t)blocks), dim3(256), lds_local, s, res32, len, d_matrix, pi, pj,
-                           n_pairs, r0, c0, width, a, b, out);
+                           n_pairs, r0, c0, width, a, b, out, out_shift);
     return hipGetLastError();
 }
 

@@ -1,0 +1,326 @@
+// hammock_cli.cpp -- `hammock-hip greedy ...`: the C++ counterpart of
+// `java -jar Hammock.jar greedy ...` (Hammock.java:142-172, :217-234, :392-437) that drives
+// the same C ABI the Java shim binds.  Flags, defaults, log lines and result files follow the
+// reference's greedy mode; everything after initial clustering (Clustal Omega MSAs, HMM stage)
+// is out of scope.
+//
+// Extra flags that the reference does not have: --device <k> (HIP ordinal, default 0).
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <climits>
+
+#include "hammock_host.hpp"
+
+using namespace hammock;
+
+namespace {
+
+const char *VERSION = "1.2.0";  // the Hammock version whose greedy mode this mirrors (Hammock.java:39)
+
+std::string parentDir() {  // PARENT_DIR (Hammock.java:36): two levels above the binary
+    char buf[PATH_MAX];
+    const ssize_t n = readlink("/proc/self/exe", buf, sizeof(buf) - 1);
+    std::string p = n > 0 ? std::string(buf, (size_t)n) : std::string("./hammock-hip");
+    for (int k = 0; k < 2; k++) {
+        const size_t s = p.find_last_of('/');
+        p = s == std::string::npos ? std::string(".") : p.substr(0, s);
+    }
+    return p;
+}
+
+bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+struct Options {
+    // common (Hammock.java:40-67)
+    std::string inputFileName, workingDirectory, matrixFile, labelString, tempDirectory = "/tmp";
+    bool haveInput = false, haveDir = false, haveLabels = false;
+    int nThreads = 4;
+    int seed = 42;
+    // greedy (Hammock.java:79-85)
+    std::string inputType = "fasta", order = "size";
+    bool haveThreshold = false, haveMaxShift = false, haveLimit = false;
+    int sequenceClusteringThreshold = 0, shiftPenalty = 0, maxShift = 0, initialClustersLimit = 0;
+    int device = 0;
+};
+
+void parseCommonArgs(const std::vector<std::string> &args, Options &o) {  // Hammock.java:824-908
+    for (size_t i = 1; i < args.size(); i++) {
+        const std::string &a = args[i];
+        const bool more = args.size() > i + 1;
+        if ((a == "-i" || a == "--input") && more) { o.inputFileName = args[++i]; o.haveInput = true; continue; }
+        if ((a == "-d" || a == "--outputDirectory") && more) { o.workingDirectory = args[++i]; o.haveDir = true; continue; }  // :834
+        if ((a == "-m" || a == "--matrix") && more) { o.matrixFile = args[++i]; continue; }
+        if ((a == "-t" || a == "--threads") && more) {
+            try { size_t u = 0; o.nThreads = std::stoi(args[i + 1], &u); if (u != args[i + 1].size()) throw 0; }
+            catch (...) { throw HammockException("NumberFormatException: For input string: \"" + args[i + 1] + "\""); }
+            i++;
+            continue;
+        }
+        if ((a == "-l" || a == "--labels") && more) { o.labelString = args[++i]; o.haveLabels = true; continue; }
+        if (a == "--temp" && more) { o.tempDirectory = args[i + 1]; }  // :903-905 (no skip, as in the reference)
+        if (a == "--device" && more) { o.device = javaIntegerDecode(args[++i]); continue; }
+    }
+}
+
+void parseGreedyArgs(const std::vector<std::string> &args, Options &o) {  // Hammock.java:915-970
+    for (size_t i = 1; i < args.size(); i++) {
+        const std::string &a = args[i];
+        const bool more = args.size() > i + 1;
+        if ((a == "-f" || a == "--file_format") && more) { o.inputType = args[++i]; continue; }
+        if ((a == "-g" || a == "--greedy_threshold" || a == "--alignment_threshold") && more) {
+            o.sequenceClusteringThreshold = javaIntegerDecode(args[++i]); o.haveThreshold = true; continue;
+        }
+        if ((a == "-x" || a == "--max_shift") && more) { o.maxShift = javaIntegerDecode(args[++i]); o.haveMaxShift = true; continue; }
+        if ((a == "-R" || a == "--order") && more) { o.order = args[++i]; continue; }
+        if ((a == "-S" || a == "--seed") && more) { o.seed = javaIntegerDecode(args[++i]); continue; }
+        if ((a == "-p" || a == "--gap_penalty") && more) { o.shiftPenalty = javaIntegerDecode(args[++i]); }
+        else if (a == "--initial_clusters_limit" && more) { o.initialClustersLimit = javaIntegerDecode(args[++i]); o.haveLimit = true; }
+    }
+}
+
+void printHelp() {  // Hammock.java:295-320 (greedy-relevant part)
+    std::cerr << "\nhammock-hip: MI355X-native greedy mode of Hammock version " << VERSION << "\n\n"
+              << "Synopsis: hammock-hip greedy <param1> <param2> ...\n\n"
+              << "-i, --input <file>\n\tA path to an input file\n\n"
+              << "-d, --output_directory <directory>\n\tA directory to store all output files in\n\n"
+              << "-t, --threads <int>\n\tAccepted for compatibility (the GPU path ignores it)\n\n"
+              << "-l, --labels <str,str,str...>\n\tA list of sequence labels to use\n\n"
+              << "-f, --file_format <[fasta,tab]>\n\tThe file format of input file specified by -i\n\n"
+              << "-m, --matrix <file>\n\tA path to a substitution matrix file\n\n"
+              << "-g, --alignment_threshold, (--greedy_threshold) <int>\n\tMinimal score needed for a sequence to join a cluster\n\n"
+              << "-x, --max_shift <int>\n\tMaximal sequence-sequence shift. A nonnegative int\n\n"
+              << "-p, --gap_penalty <int>\n\tThe penalty for each position of the sequence-sequence shift. A nonpositive int\n\n"
+              << "-R, --order [size, alphabetic, random, input, <label>]\n\tThe order of sequences during greedy clustering\n\n"
+              << "-S, --seed <int>\n\tA seed to make random processes deterministic (if -R random is in use)\n\n"
+              << "--initial_clusters_limit <int>\n\tThe max. number of clusters resulting from gredy clustering\n\n"
+              << "--device <int>\n\tHIP device ordinal (default 0)\n\n";
+}
+
+std::string labelsToString(bool have, const std::vector<std::string> &labels) {  // List.toString() / "null"
+    if (!have) return "null";
+    std::string s = "[";
+    for (size_t k = 0; k < labels.size(); k++) s += (k ? ", " : "") + labels[k];
+    return s + "]";
+}
+
+double meanSequenceLength(const std::vector<UniqueSequencePtr> &seqs) {  // Hammock.java:1554-1563
+    long long sum = 0;
+    for (auto &s : seqs) sum += (long long)s->getSequence().size();
+    return (double)sum / (double)seqs.size();
+}
+
+int checkMaxShift(const std::vector<UniqueSequencePtr> &seqs, int maxShift) {  // Hammock.java:1421-1427
+    int minLength = INT_MAX;
+    for (auto &s : seqs) minLength = std::min(minLength, (int)s->getSequence().size());
+    return std::min(maxShift, minLength - 1);
+}
+
+int runGreedy(const std::vector<std::string> &args) {
+    Options o;
+    const std::string PARENT_DIR = parentDir();
+    o.matrixFile = PARENT_DIR + "/matrices/blosum62.txt";  // Hammock.java:45
+    parseCommonArgs(args, o);
+    parseGreedyArgs(args, o);
+
+    // ---- checkCommonArgs, Hammock.java:1207-1266 ------------------------------------------------
+    if (!o.haveInput) throw CLIException("Error. Parameter input file (-i or --input) missing with no default.");
+    if (o.haveDir) {
+        if (exists(o.workingDirectory)) throw CLIException("Error. Output directory exists. Exiting to prevent data loss.");
+        mkdir(o.workingDirectory.c_str(), 0777);
+    } else {
+        std::string name;
+        mkdir((PARENT_DIR + "/dist").c_str(), 0777);
+        for (int i = 1; i < 9999; i++) {
+            name = PARENT_DIR + "/dist/Hammock_result_" + std::to_string(i);
+            if (!exists(name)) { mkdir(name.c_str(), 0777); break; }
+        }
+        o.workingDirectory = name;
+        std::cerr << "Creating default output directory: " << name << std::endl;
+    }
+    Logger logger(o.workingDirectory + "/run.log", false);
+    try {
+        logger.logAndStderr(std::string("\nHammock version ") + VERSION +
+                            " Run with --help for a brief description of command line parameters.\n");
+        std::vector<std::string> labels;
+        if (o.haveLabels) labels = FileIOManager::splitChar(o.labelString, ',', true);
+        const std::string initialClustersSequencesCsv = o.workingDirectory + "/initial_clusters_sequences.tsv";
+        const std::string initialClustersSequencesOrderedCsv = o.workingDirectory + "/initial_clusters_sequences_original_order.tsv";
+        const std::string initialClusters = o.workingDirectory + "/initial_clusters.tsv";
+        const std::string inputStatistics = o.workingDirectory + "/input_statistics.tsv";
+        const std::vector<std::vector<int>> scoringMatrix = FileIOManager::loadScoringMatrix(o.matrixFile);  // :1264
+        // ---- checkGreedyOrClinkageArgs, :1272-1277 ------------------------------------------------
+        if (!(o.inputType == "fasta" || o.inputType == "seq" || o.inputType == "tab"))
+            throw CLIException("Error. Parameter -f value may be either \"fasta\", \"seq\" or \"tab\". No other values are allowed");
+
+        logger.logWithTime("Program started in mode \"greedy\".");  // :225-229
+        std::string argsString;
+        for (auto &a : args) argsString += " " + a;
+        logger.logWithoutTime("Command-line arguments: \n" + argsString + "\n");
+        logger.logWithoutTime("\nComplete list of input/output parameters: \n-i, --input " + o.inputFileName +
+                              "\n-d, --output_directory " + o.workingDirectory + "\n-t, --thread " + std::to_string(o.nThreads) +
+                              "\n-l, --labels " + labelsToString(o.haveLabels, labels) + "\n\n");
+        logger.logWithoutTime("\nComplete list of greedy clustering parameters: \n-f, --file_format " + o.inputType +
+                              "\n-m, --matrix " + o.matrixFile + "\n-g, --greedy_threshold " +
+                              (o.haveThreshold ? std::to_string(o.sequenceClusteringThreshold) : std::string("null")) +
+                              "\n-x, --max_shift " + (o.haveMaxShift ? std::to_string(o.maxShift) : std::string("null")) +
+                              "\n-p, --gap_penalty " + std::to_string(o.shiftPenalty) + "\n-R, --order " + o.order +
+                              "\n-S, --seed " + std::to_string(o.seed) + "\n\n");
+
+        // ---- loadInputSequences, :749-787 -----------------------------------------------------------
+        logger.logAndStderr("Loading input sequences...");
+        std::vector<UniqueSequencePtr> sequences;
+        if (o.inputType == "fasta") sequences = FileIOManager::loadUniqueSequencesFromFasta(o.inputFileName);
+        else if (o.inputType == "tab") sequences = FileIOManager::loadUniqueSequencesFromTable(o.inputFileName);
+        else throw HammockException("Error, this should have been checked.");  // "seq", :759-761
+        logger.logAndStderr(std::to_string(sequences.size()) + " unique sequences loaded.");
+        long long total = 0;
+        for (auto &s : sequences) total += s->size();
+        logger.logAndStderr(std::to_string(total) + " total sequences loaded.");
+        if (o.haveLabels) {  // filterSequencesForLabels, :1661-1675
+            std::vector<UniqueSequencePtr> kept;
+            for (auto &s : sequences) {
+                std::vector<std::pair<std::string, int>> lm;
+                for (auto &label : labels) {
+                    bool present = false;
+                    const int c = s->labelCount(label, &present);
+                    if (present) lm.push_back({label, c});
+                }
+                if (!lm.empty()) kept.push_back(std::make_shared<UniqueSequence>(s->getSequenceString(), lm));
+            }
+            sequences = kept;
+        }
+        logger.logAndStderr(std::to_string(sequences.size()) + " unique sequences after non-specified labels filtered out");
+        total = 0;
+        for (auto &s : sequences) total += s->size();
+        logger.logAndStderr(std::to_string(total) + " total sequences after non-specified labels fileterd out");
+        int minLength = INT_MAX, maxLength = INT_MIN;
+        for (auto &s : sequences) {
+            maxLength = std::max(maxLength, (int)s->getSequence().size());
+            minLength = std::min(minLength, (int)s->getSequence().size());
+        }
+        logger.logAndStderr("Shortest sequence: " + std::to_string(minLength) + " AA. Longest sequence: " + std::to_string(maxLength) + " AA.");
+        if (sequences.empty()) throw FileFormatException("Error. No sequences (with specified labels) to cluster.");
+
+        // ---- runGreedyClustering, :392-437 ------------------------------------------------------------
+        if (!o.haveLabels) labels = FileIOManager::getSortedLabels(sequences);                 // :796-798
+        const std::vector<UniqueSequencePtr> initialSequences(sequences);                       // :800-801
+        if (!o.haveMaxShift) {                                                                  // :803-811
+            o.maxShift = checkMaxShift(sequences, (int)javaRound(meanSequenceLength(sequences) / 4));
+            logger.logAndStderr("Max shift not set. Setting automatically to: " + std::to_string(o.maxShift));
+        } else {
+            const int correct = checkMaxShift(sequences, o.maxShift);
+            if (o.maxShift != correct) {
+                o.maxShift = correct;
+                logger.logAndStderr("Setting max shift to " + std::to_string(correct) +
+                                    " as the length of the shortest sequence is only " + std::to_string(correct + 1));
+            }
+        }
+        logger.logAndStderr("Generating input statistics...");
+        FileIOManager::saveInputStatistics(sequences, labels, inputStatistics);                 // :814-816
+        if (!o.haveThreshold) {                                                                 // :394-397
+            o.sequenceClusteringThreshold = (int)javaRound(meanSequenceLength(sequences) * 1.7);
+            logger.logAndStderr("Greedy clustering threshold not set. Setting automatically to: " +
+                                std::to_string(o.sequenceClusteringThreshold));
+        }
+        if (!o.haveLimit) {                                                                     // :398-401
+            o.initialClustersLimit = (int)javaRound((double)sequences.size() * 0.025);
+            logger.logAndStderr("Initial greedy clusters limit not set. Setting automatically to: " +
+                                std::to_string(o.initialClustersLimit));
+        }
+        auto scorer = std::make_shared<ShiftedScorer>(scoringMatrix, o.shiftPenalty, o.maxShift, o.device);  // :402
+        HipGreedySequenceClusterer clusterer(scorer, o.sequenceClusteringThreshold, o.initialClustersLimit);  // :403
+
+        logger.logAndStderr("Greedy clustering...");
+        const auto time0 = std::chrono::steady_clock::now();
+        sortSequences(sequences, o.order, o.seed, labels);                                      // :407
+        std::vector<ClusterPtr> clusters = clusterer.cluster(sequences);                        // :409
+        auto ms = [&]() {
+            return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - time0).count();
+        };
+        logger.logAndStderr("Ready. Clustering time: " + std::to_string(ms()));                // :411
+        logger.logAndStderr("Resulting clusers: " + std::to_string(clusters.size()));          // :412
+        logger.logAndStderr("GPU scoring + transfer: " + std::to_string(clusterer.stats.neighbors_ms) + " ms, host greedy merge: " +
+                            std::to_string(clusterer.stats.greedy_ms) + " ms, neighbour edges: " +
+                            std::to_string(clusterer.stats.n_edges));
+        logger.logAndStderr("Building MSAs... (skipped: Clustal Omega is outside the scope of hammock-hip; the alignment "
+                            "column of multi-member clusters is NA)");
+        logger.logAndStderr("Ready. Total time: " + std::to_string(ms()));                     // :427
+        logger.logAndStderr("Saving results to output files...");
+        FileIOManager::saveClusterSequencesToCsv(clusters, initialClustersSequencesCsv, labels);                              // :429
+        FileIOManager::saveClusterSequencesToCsvOrdered(clusters, initialClustersSequencesOrderedCsv, labels, initialSequences);  // :431
+        FileIOManager::SaveClustersToCsv(clusters, initialClusters, labels);                                                  // :432
+        logger.logAndStderr("Greedy clustering results in: " + initialClusters);
+        logger.logAndStderr("and: " + initialClustersSequencesCsv);
+        logger.logAndStderr("and: " + initialClustersSequencesOrderedCsv);
+        logger.logWithTime("Program successfully ended.");
+        return 0;
+    } catch (const CLIException &) {
+        throw;
+    } catch (const FileFormatException &e) {  // Hammock.java:148-152
+        logger.logAndStderr("Error. Probably wrong input file format? Run with --help for a brief description of command line parameters. Trace: \n");
+        logger.logAndStderr(std::string("cz.krejciadam.hammock.FileFormatException: ") + e.what());
+        return 3;
+    } catch (const NullPointerException &e) {  // :153-157
+        logger.logAndStderr("Error. Maybe wrong input file format? Run with --help for a brief description of command line parameters. Trace: \n");
+        logger.logAndStderr(std::string("java.lang.NullPointerException: ") + e.what());
+        return 4;
+    } catch (const DataException &e) {  // :158-162
+        logger.logAndStderr("Error. Maybe wrong input file format or wrong set of labels? Run with --help for a brief description of command line parameters. Trace: \n");
+        logger.logAndStderr(std::string("cz.krejciadam.hammock.DataException: ") + e.what());
+        return 5;
+    } catch (const std::exception &e) {  // :163-167
+        logger.logAndStderr("Error. Run with --help for a brief description of command line parameters. Trace: \n");
+        logger.logAndStderr(e.what());
+        return 6;
+    }
+}
+
+// `hammock-hip io-selftest ...`: exposes the loaders / orderings to the CPU test-suite (no GPU involved)
+int ioSelftest(const std::vector<std::string> &args) {
+    if (args.size() >= 3 && args[1] == "matrix") {
+        for (auto &row : FileIOManager::loadScoringMatrix(args[2])) {
+            for (size_t c = 0; c < row.size(); c++) std::cout << (c ? " " : "") << row[c];
+            std::cout << "\n";
+        }
+        return 0;
+    }
+    if (args.size() >= 5 && args[1] == "sequences") {  // sequences <fasta|tab> <file> <order> [seed]
+        auto seqs = args[2] == "tab" ? FileIOManager::loadUniqueSequencesFromTable(args[3])
+                                     : FileIOManager::loadUniqueSequencesFromFasta(args[3]);
+        const std::vector<std::string> labels = FileIOManager::getSortedLabels(seqs);
+        sortSequences(seqs, args[4], args.size() > 5 ? javaIntegerDecode(args[5]) : 42, labels);
+        std::cout << "labels";
+        for (auto &l : labels) std::cout << "\t" << l;
+        std::cout << "\n";
+        for (auto &s : seqs) std::cout << s->getSequenceString() << "\t" << FileIOManager::sequenceLine(*s, labels) << "\n";
+        return 0;
+    }
+    std::cerr << "usage: hammock-hip io-selftest matrix <file> | sequences <fasta|tab> <file> <order> [seed]\n";
+    return 2;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    std::vector<std::string> args(argv + 1, argv + argc);
+    if (args.empty() || args[0] == "--help" || args[0] == "-h") { printHelp(); return args.empty() ? 2 : 0; }
+    try {
+        if (args[0] == "greedy") return runGreedy(args);
+        if (args[0] == "io-selftest") return ioSelftest(args);
+        std::cerr << "hammock-hip implements Hammock's `greedy` mode only (modes full, clinkage, cluster are outside "
+                     "the scope of the MI355X hot path); got mode \"" << args[0] << "\"\n";
+        return 2;
+    } catch (const CLIException &e) {  // Hammock.java:146-147
+        std::cerr << "Error in command line arguments: " << e.what() << std::endl;
+        return 2;
+    } catch (const FileFormatException &e) {
+        std::cerr << "Error. Probably wrong input file format? Run with --help for a brief description of command line parameters. Trace: \n"
+                  << e.what() << std::endl;
+        return 3;
+    } catch (const std::exception &e) {
+        std::cerr << "Error. Run with --help for a brief description of command line parameters. Trace: \n" << e.what() << std::endl;
+        return 6;
+    }
+}

@@ -1,0 +1,698 @@
+// hammock_host.hpp -- C++ host-side mirror of the reference's Java interfaces for the
+// greedy initial-clustering path, on top of the C ABI of include/hammock_hip.h.
+//
+// The reference is Java; this image has no JDK, so the host side above the C ABI
+// is C++ (the Java shim a Hammock maintainer would add is shipped as source under
+// hammock_amd/java/).  Class names, argument order and error
+// behaviour follow the reference (paths relative to src/cz/krejciadam/hammock/):
+//
+//   UniqueSequence            UniqueSequence.java:19
+//   Cluster                   Cluster.java:21
+//   SequenceScorer / AligningSequenceScorer / SequenceClusterer   (interfaces)
+//   ShiftedScorer             ShiftedScorer.java:12          sequenceScore runs on the GPU
+//   LocalAlignmentScorer      LocalAlignmentScorer.java:10   sequenceScore runs on the GPU
+//   HipGreedySequenceClusterer  drop-in for LimitedGreedySequenceClusterer.java:17
+//   FileIOManager             loaders / stage-1 writers, FileIOManager.java
+//   Logger                    Logger.java
+//
+// Nothing in this header computes a score on the CPU.
+#ifndef HAMMOCK_HOST_HPP
+#define HAMMOCK_HOST_HPP
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../include/hammock_hip.h"
+
+namespace hammock {
+
+// ---- exceptions (HammockException.java and subclasses) ---------------------------------
+struct HammockException : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DataException : HammockException { using HammockException::HammockException; };
+struct FileFormatException : HammockException { using HammockException::HammockException; };
+struct CLIException : HammockException { using HammockException::HammockException; };
+struct DeviceException : HammockException { using HammockException::HammockException; };
+// The reference throws java.lang.NullPointerException here
+// (LimitedGreedySequenceClusterer.java:97/104/108, caught at Hammock.java:153-157).
+struct NullPointerException : std::runtime_error {
+    int crashCase, crashIndex;
+    NullPointerException(const std::string &m, int c, int i) : std::runtime_error(m), crashCase(c), crashIndex(i) {}
+};
+
+static const char AMINO_ACIDS[25] = "ARNDCQEGHILKMFPSTWYVBZX*";  // UniqueSequence.java:23-26
+static const char CSV_SEPARATOR = '\t';                          // Hammock.java:35
+
+// ---- small Java-semantics helpers ------------------------------------------------------------
+// Integer.decode: sign, then 0x / 0X / # hex, leading-0 octal, else decimal
+inline int javaIntegerDecode(const std::string &text) {
+    std::string t = text;
+    bool neg = false;
+    size_t p = 0;
+    if (!t.empty() && (t[0] == '-' || t[0] == '+')) { neg = t[0] == '-'; p = 1; }
+    int base = 10;
+    if (t.compare(p, 2, "0x") == 0 || t.compare(p, 2, "0X") == 0) { base = 16; p += 2; }
+    else if (t.compare(p, 1, "#") == 0) { base = 16; p += 1; }
+    else if (t.size() > p + 1 && t[p] == '0') { base = 8; p += 1; }
+    if (p >= t.size()) throw HammockException("NumberFormatException: For input string: \"" + text + "\"");
+    long long v = 0;
+    for (; p < t.size(); p++) {
+        int d;
+        const char c = t[p];
+        if (c >= '0' && c <= '9') d = c - '0';
+        else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+        else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+        else d = 99;
+        if (d >= base) throw HammockException("NumberFormatException: For input string: \"" + text + "\"");
+        v = v * base + d;
+        if (v > 2147483648LL) throw HammockException("NumberFormatException: For input string: \"" + text + "\"");
+    }
+    v = neg ? -v : v;
+    if (v > 2147483647LL || v < -2147483648LL) throw HammockException("NumberFormatException: For input string: \"" + text + "\"");
+    return (int)v;
+}
+
+inline long long javaRound(double x) { return (long long)std::floor(x + 0.5); }  // Math.round(double)
+
+inline int32_t javaStringHash(const std::string &s) {
+    uint32_t h = 0;
+    for (unsigned char c : s) h = 31u * h + c;
+    return (int32_t)h;
+}
+
+// Iteration order of a java.util.HashMap<String, ?> (Java 8+: spread hash, power-of-two
+// table that doubles when size exceeds 0.75 * capacity, buckets keep insertion order)
+// holding `keys` (distinct, in insertion order).
+inline std::vector<std::string> javaHashMapOrder(const std::vector<std::string> &keys) {
+    size_t cap = 16;
+    while (keys.size() > cap * 3 / 4) cap *= 2;
+    std::vector<std::pair<std::pair<uint32_t, size_t>, std::string>> v;
+    for (size_t k = 0; k < keys.size(); k++) {
+        const uint32_t h = (uint32_t)javaStringHash(keys[k]);
+        v.push_back({{(h ^ (h >> 16)) & (uint32_t)(cap - 1), k}, keys[k]});
+    }
+    std::sort(v.begin(), v.end());
+    std::vector<std::string> out;
+    for (auto &e : v) out.push_back(e.second);
+    return out;
+}
+
+// java.util.Random (48-bit LCG) and Collections.shuffle, for `-R random`
+class JavaRandom {
+    uint64_t seed_;
+public:
+    explicit JavaRandom(int64_t seed) : seed_(((uint64_t)seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1)) {}
+    int32_t next(int bits) {
+        seed_ = (seed_ * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+        return (int32_t)(int64_t)(seed_ >> (48 - bits));
+    }
+    int32_t nextInt(int32_t bound) {
+        int32_t bits = next(31);
+        const int32_t m = bound - 1;
+        if ((bound & m) == 0) return (int32_t)(((int64_t)bound * (int64_t)bits) >> 31);
+        int32_t val = bits % bound;
+        while ((int32_t)((uint32_t)bits - (uint32_t)val + (uint32_t)m) < 0) {  // int overflow test of Random.nextInt
+            bits = next(31);
+            val = bits % bound;
+        }
+        return val;
+    }
+};
+
+// ---- UniqueSequence.java -------------------------------------------------------------------------
+class UniqueSequence {
+    std::vector<int> sequence_;
+    std::vector<std::pair<std::string, int>> labels_;  // labelsMap, insertion order kept
+public:
+    explicit UniqueSequence(const std::string &sequence) : UniqueSequence(sequence, {{"no_label", 1}}) {}  // :65-74
+    UniqueSequence(const std::string &sequence, std::vector<std::pair<std::string, int>> labelsMap)  // :46-57
+        : labels_(std::move(labelsMap)) {
+        for (char ch : sequence) {
+            char up = (ch >= 'a' && ch <= 'z') ? (char)(ch - 'a' + 'A') : ch;
+            const char *f = std::strchr(AMINO_ACIDS, up);
+            if (!f || up == '\0')
+                throw FileFormatException(std::string("Error, character ") + ch +
+                                          " is not a valid letter from the amino acid alphabet code.");
+            sequence_.push_back((int)(f - AMINO_ACIDS));
+        }
+    }
+    int size() const { int s = 0; for (auto &e : labels_) s += e.second; return s; }  // :82-88
+    const std::vector<int> &getSequence() const { return sequence_; }
+    std::string getSequenceString() const {  // :103-109
+        std::string s;
+        for (int r : sequence_) s.push_back(AMINO_ACIDS[r]);
+        return s;
+    }
+    const std::vector<std::pair<std::string, int>> &getLabelsMap() const { return labels_; }
+    int labelCount(const std::string &label, bool *present = nullptr) const {
+        for (auto &e : labels_) if (e.first == label) { if (present) *present = true; return e.second; }
+        if (present) *present = false;
+        return 0;
+    }
+    void addLabelCount(const std::string &label, int count) {  // FileIOManager.updateLabelsMap :204-216
+        for (auto &e : labels_) if (e.first == label) { e.second += count; return; }
+        labels_.push_back({label, count});
+    }
+    bool operator==(const UniqueSequence &o) const { return sequence_ == o.sequence_; }  // :143-153
+};
+using UniqueSequencePtr = std::shared_ptr<UniqueSequence>;
+
+// String.compareTo on ASCII strings
+inline int javaStringCompare(const std::string &a, const std::string &b) {
+    const size_t lim = std::min(a.size(), b.size());
+    for (size_t k = 0; k < lim; k++)
+        if (a[k] != b[k]) return (int)(unsigned char)a[k] - (int)(unsigned char)b[k];
+    return (int)a.size() - (int)b.size();
+}
+// UniqueSequenceSizeAlphabeticComparator, UniqueSequence.java:238-248
+inline int sizeAlphabeticCompare(const UniqueSequence &a, const UniqueSequence &b) {
+    const int r = a.size() - b.size();
+    return r != 0 ? r : javaStringCompare(a.getSequenceString(), b.getSequenceString());
+}
+
+// UniqueSequence.sortSequences, UniqueSequence.java:176-203 (Collections.sort is stable)
+inline void sortSequences(std::vector<UniqueSequencePtr> &seqs, const std::string &order, int seed,
+                          const std::vector<std::string> &labels) {
+    auto sizeAlphaDesc = [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+        return sizeAlphabeticCompare(*b, *a) < 0;  // Collections.reverseOrder(cmp)
+    };
+    if (order == "size") {
+        std::stable_sort(seqs.begin(), seqs.end(), sizeAlphaDesc);
+    } else if (order == "alphabetic") {
+        std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+            return javaStringCompare(b->getSequenceString(), a->getSequenceString()) < 0;
+        });
+    } else if (order == "random") {  // Collections.shuffle(list, Hammock.random), Hammock.java:1252
+        JavaRandom rnd(seed);
+        for (size_t i = seqs.size(); i > 1; i--) std::swap(seqs[i - 1], seqs[(size_t)rnd.nextInt((int32_t)i)]);
+    } else if (order == "input") {
+    } else {
+        if (std::find(labels.begin(), labels.end(), order) == labels.end())
+            throw DataException("Incorrect sequence order defined. Use one of: size, alphabetic, random, input, or a label");
+        std::stable_sort(seqs.begin(), seqs.end(), sizeAlphaDesc);
+        std::stable_sort(seqs.begin(), seqs.end(), [&](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+            return b->labelCount(order) - a->labelCount(order) < 0;  // reverseOrder(LabelComparator) :209-228
+        });
+    }
+}
+
+// ---- Cluster.java ---------------------------------------------------------------------------------
+class Cluster {
+    std::vector<UniqueSequencePtr> sequences_;
+    int id_;
+    int size_ = 0;
+public:
+    Cluster(const std::vector<UniqueSequencePtr> &sequences, int id) : sequences_(sequences), id_(id) {  // :31-41
+        for (auto &s : sequences_) size_ += s->size();
+    }
+    void insert(const UniqueSequencePtr &sequence) {  // :50-63
+        for (auto &s : sequences_)
+            if (*s == *sequence)
+                throw DataException("Trying to insert unique sequence " + sequence->getSequenceString() + " into cluster " +
+                                    std::to_string(id_) + ", which already contains this sequence. ");
+        sequences_.push_back(sequence);
+        size_ += sequence->size();
+    }
+    void insertAll(const std::vector<UniqueSequencePtr> &sequences) { for (auto &s : sequences) insert(s); }  // :70-74
+    int getUniqueSize() const { return (int)sequences_.size(); }  // :113-115
+    std::vector<UniqueSequencePtr> &getSequences() { return sequences_; }
+    const std::vector<UniqueSequencePtr> &getSequences() const { return sequences_; }
+    int getId() const { return id_; }
+    int size() const { return size_; }  // :156-158
+    int compareTo(const Cluster &o) const { return size_ != o.size_ ? size_ - o.size_ : id_ - o.id_; }  // :198-204
+};
+using ClusterPtr = std::shared_ptr<Cluster>;
+
+struct AligningScorerResult {  // AligningScorerResult.java:11-44
+    int score, shift;
+    UniqueSequencePtr sequence;
+    int getScore() const { return score; }
+    int getShift() const { return shift; }
+};
+
+// ---- interfaces -----------------------------------------------------------------------------------------
+struct SequenceScorer {  // SequenceScorer.java:12-15
+    virtual ~SequenceScorer() = default;
+    virtual int sequenceScore(const UniqueSequencePtr &seq1, const UniqueSequencePtr &seq2) = 0;
+};
+struct AligningSequenceScorer : SequenceScorer {  // AligningSequenceScorer.java:10-12
+    virtual AligningScorerResult scoreWithShift(const UniqueSequencePtr &seq1, const UniqueSequencePtr &seq2) = 0;
+};
+struct SequenceClusterer {  // SequenceClusterer.java:15-26
+    virtual ~SequenceClusterer() = default;
+    virtual std::vector<ClusterPtr> cluster(const std::vector<UniqueSequencePtr> &sequences) = 0;
+};
+
+// ---- the native context ----------------------------------------------------------------------------------
+class NativeContext {
+    hmk_ctx *ctx_ = nullptr;
+public:
+    NativeContext(const std::vector<std::vector<int>> &scoringMatrix, int device) {
+        if (scoringMatrix.size() != 24) throw HammockException("scoring matrix must be 24 x 24");
+        int32_t m[576];
+        for (int r = 0; r < 24; r++) {
+            if (scoringMatrix[r].size() != 24) throw HammockException("scoring matrix must be 24 x 24");
+            for (int c = 0; c < 24; c++) m[r * 24 + c] = scoringMatrix[r][c];
+        }
+        const int st = hmk_create(m, device, &ctx_);
+        if (st) raise(st, nullptr);
+    }
+    ~NativeContext() { hmk_destroy(ctx_); }
+    NativeContext(const NativeContext &) = delete;
+    NativeContext &operator=(const NativeContext &) = delete;
+    hmk_ctx *get() const { return ctx_; }
+    [[noreturn]] void raise(int st, const hmk_greedy_stats *gs) const {
+        const std::string msg = hmk_last_error(ctx_);
+        switch (st) {
+            case HMK_ERR_SHIFT_TOO_BIG: throw DataException(msg);
+            case HMK_ERR_REFERENCE_WOULD_CRASH:
+                throw NullPointerException(msg, gs ? gs->crash_case : 0, gs ? gs->crash_index : -1);
+            case HMK_ERR_DEVICE: case HMK_ERR_OOM: throw DeviceException(msg);
+            default: throw HammockException(msg);
+        }
+    }
+    void setSequences(const std::vector<UniqueSequencePtr> &seqs, bool withSizes) const {
+        std::vector<uint8_t> res;
+        std::vector<uint32_t> off(1, 0);
+        std::vector<int32_t> sizes;
+        for (auto &s : seqs) {
+            for (int r : s->getSequence()) res.push_back((uint8_t)r);
+            off.push_back((uint32_t)res.size());
+            sizes.push_back(s->size());
+        }
+        const int st = hmk_set_sequences(ctx_, res.data(), off.data(), withSizes ? sizes.data() : nullptr, (uint32_t)seqs.size());
+        if (st) raise(st, nullptr);
+    }
+};
+
+// ---- ShiftedScorer.java ---------------------------------------------------------------------------------
+class ShiftedScorer : public AligningSequenceScorer {
+    std::shared_ptr<NativeContext> ctx_;
+    int shiftPenalty_, maxShift_;
+public:
+    // ShiftedScorer(int[][] scoringMatrix, int shiftPenalty, int maxShift), ShiftedScorer.java:28-32
+    ShiftedScorer(const std::vector<std::vector<int>> &scoringMatrix, int shiftPenalty, int maxShift, int device = 0)
+        : ctx_(std::make_shared<NativeContext>(scoringMatrix, device)), shiftPenalty_(shiftPenalty), maxShift_(maxShift) {}
+    AligningScorerResult scoreWithShift(const UniqueSequencePtr &seq1, const UniqueSequencePtr &seq2) override {  // :48-95
+        ctx_->setSequences({seq1, seq2}, false);
+        const uint32_t i = 0, j = 1;
+        int32_t score = 0, shift = 0;
+        const int st = hmk_score_with_shift(ctx_->get(), &i, &j, 1, maxShift_, shiftPenalty_, &score, &shift);
+        if (st) ctx_->raise(st, nullptr);
+        return AligningScorerResult{score, shift, seq2};
+    }
+    int sequenceScore(const UniqueSequencePtr &seq1, const UniqueSequencePtr &seq2) override {  // :98-100
+        return scoreWithShift(seq1, seq2).getScore();
+    }
+    int getShiftPenalty() const { return shiftPenalty_; }
+    int getMaxShift() const { return maxShift_; }
+    const std::shared_ptr<NativeContext> &native() const { return ctx_; }
+};
+
+// ---- LocalAlignmentScorer.java --------------------------------------------------------------------------
+class LocalAlignmentScorer : public SequenceScorer {
+    std::shared_ptr<NativeContext> ctx_;
+    int gapOpenPenalty_, gapExtendPenalty_;
+public:
+    LocalAlignmentScorer(const std::vector<std::vector<int>> &scoringMatrix, int gapOpenPenalty, int gapExtendPenalty,
+                         int device = 0)  // LocalAlignmentScorer.java:20-24
+        : ctx_(std::make_shared<NativeContext>(scoringMatrix, device)), gapOpenPenalty_(gapOpenPenalty),
+          gapExtendPenalty_(gapExtendPenalty) {}
+    int sequenceScore(const UniqueSequencePtr &seq1, const UniqueSequencePtr &seq2) override {  // :27-29
+        ctx_->setSequences({seq1, seq2}, false);
+        const uint32_t i = 0, j = 1;
+        int32_t score = 0;
+        const int st = hmk_score_pairs_local(ctx_->get(), &i, &j, 1, gapOpenPenalty_, gapExtendPenalty_, &score);
+        if (st) ctx_->raise(st, nullptr);
+        return score;
+    }
+};
+
+// ---- HipGreedySequenceClusterer: LimitedGreedySequenceClusterer.java:17-121 on the GPU ----------------------
+class HipGreedySequenceClusterer : public SequenceClusterer {
+    std::shared_ptr<ShiftedScorer> scorer_;
+    int threshold_, maxClusters_;
+public:
+    hmk_greedy_stats stats{};
+    // same constructor shape as LimitedGreedySequenceClusterer(sequenceScorer, threshold, maxClusters), :22-26
+    HipGreedySequenceClusterer(std::shared_ptr<ShiftedScorer> sequenceScorer, int threshold, int maxClusters)
+        : scorer_(std::move(sequenceScorer)), threshold_(threshold), maxClusters_(maxClusters) {}
+    // cluster(List<UniqueSequence>) -> List<Cluster>, :39-69: clusters in creation order (id = index of the
+    // seed), then the remaining singletons; members in Cluster.getSequences() insertion order.
+    std::vector<ClusterPtr> cluster(const std::vector<UniqueSequencePtr> &sequences) override {
+        const auto &nc = scorer_->native();
+        nc->setSequences(sequences, true);
+        const size_t n = sequences.size();
+        std::vector<int32_t> cid(std::max<size_t>(n, 1)), order(std::max<size_t>(n, 1)), rank(std::max<size_t>(n, 1));
+        const int st = hmk_greedy_cluster(nc->get(), scorer_->getMaxShift(), scorer_->getShiftPenalty(), threshold_,
+                                          maxClusters_, cid.data(), order.data(), rank.data(), &stats);
+        if (st) nc->raise(st, &stats);
+        std::unordered_map<int, std::vector<std::pair<int, size_t>>> members;  // id -> (rank, index)
+        for (size_t k = 0; k < n; k++) members[cid[k]].push_back({rank[k], k});
+        std::vector<ClusterPtr> result;
+        for (int q = 0; q < stats.n_result_clusters; q++) {
+            auto &mv = members[order[q]];
+            std::sort(mv.begin(), mv.end());
+            std::vector<UniqueSequencePtr> seqs;
+            for (auto &e : mv) seqs.push_back(sequences[e.second]);
+            result.push_back(std::make_shared<Cluster>(seqs, order[q]));
+        }
+        return result;
+    }
+};
+
+// ---- Logger.java ---------------------------------------------------------------------------------------------
+class Logger {
+    std::string filePath_;
+    bool dummy_;
+public:
+    Logger(std::string filePath, bool dummyLogger) : filePath_(std::move(filePath)), dummy_(dummyLogger) {}  // :39-42
+    void logWithoutTime(const std::string &line) const {  // :49-60
+        if (dummy_ || filePath_.empty()) return;
+        std::ofstream f(filePath_, std::ios::app);
+        if (!f) { std::cerr << "Warning: Failed to log follwoing message. Run will continue, message will not be appended run.log\n"; return; }
+        f << line << "\n";
+    }
+    void logWithTime(const std::string &line) const {  // :67-74, "yyyy-MM-dd HH:mm:ss.SSS"
+        if (dummy_) return;
+        using namespace std::chrono;
+        const auto now = system_clock::now();
+        const std::time_t t = system_clock::to_time_t(now);
+        const int ms = (int)(duration_cast<milliseconds>(now.time_since_epoch()).count() % 1000);
+        std::tm tm{};
+        localtime_r(&t, &tm);
+        char buf[64];
+        std::snprintf(buf, sizeof(buf), "%04d-%02d-%02d %02d:%02d:%02d.%03d", tm.tm_year + 1900, tm.tm_mon + 1, tm.tm_mday,
+                      tm.tm_hour, tm.tm_min, tm.tm_sec, ms);
+        logWithoutTime(std::string(buf) + ":\t" + line);
+    }
+    void logAndStderr(const std::string &line) const {  // :81-87
+        if (dummy_) return;
+        logWithTime(line);
+        std::cerr << line << std::endl;
+    }
+};
+
+// ---- FileIOManager.java (greedy-path subset) ----------------------------------------------------------------------
+namespace FileIOManager {
+
+// String.split("\\s+"): a leading empty token is kept, trailing empty tokens are dropped
+inline std::vector<std::string> splitWhitespace(const std::string &line) {
+    std::vector<std::string> out;
+    size_t p = 0;
+    bool first = true;
+    while (p <= line.size()) {
+        size_t q = p;
+        while (q < line.size() && !std::isspace((unsigned char)line[q])) q++;
+        if (q > p || first) out.push_back(line.substr(p, q - p));
+        first = false;
+        while (q < line.size() && std::isspace((unsigned char)line[q])) q++;
+        if (q >= line.size()) break;
+        p = q;
+    }
+    while (!out.empty() && out.back().empty()) out.pop_back();
+    return out;
+}
+
+inline std::vector<std::string> splitChar(const std::string &line, char sep, bool dropTrailingEmpty) {
+    std::vector<std::string> out;
+    std::string cur;
+    for (char c : line) { if (c == sep) { out.push_back(cur); cur.clear(); } else cur.push_back(c); }
+    out.push_back(cur);
+    if (dropTrailingEmpty) while (out.size() > 1 && out.back().empty()) out.pop_back();
+    return out;
+}
+
+inline std::vector<std::string> readLines(const std::string &path) {  // BufferedReader.readLine semantics
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw HammockException("java.io.FileNotFoundException: " + path + " (No such file or directory)");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string all = ss.str();
+    std::vector<std::string> lines;
+    std::string cur;
+    for (size_t k = 0; k < all.size(); k++) {
+        if (all[k] == '\n') { lines.push_back(cur); cur.clear(); }
+        else if (all[k] == '\r') { lines.push_back(cur); cur.clear(); if (k + 1 < all.size() && all[k + 1] == '\n') k++; }
+        else cur.push_back(all[k]);
+    }
+    if (!cur.empty()) lines.push_back(cur);
+    return lines;
+}
+
+inline std::string trim(const std::string &s) {  // String.trim(): strips chars <= ' '
+    size_t a = 0, b = s.size();
+    while (a < b && (unsigned char)s[a] <= ' ') a++;
+    while (b > a && (unsigned char)s[b - 1] <= ' ') b--;
+    return s.substr(a, b - a);
+}
+
+// loadScoringMatrix, FileIOManager.java:46-81
+inline std::vector<std::vector<int>> loadScoringMatrix(const std::string &matrixFilePath) {
+    std::vector<std::vector<int>> m(24, std::vector<int>(24, 0));
+    int lineCounter = 0;
+    for (const std::string &line : readLines(matrixFilePath)) {
+        if (!line.empty() && (line[0] == '#' || line[0] == ' ' || line[0] == '\t')) continue;  // :58
+        const std::vector<std::string> parts = splitWhitespace(line);                          // :59
+        if (parts.size() != 25)
+            throw FileFormatException("Error in scoring matrix file: " + matrixFilePath + ". Scoring matrix "
+                                      "should always have 24 columns (plus 1 column describing AAs).");
+        if (lineCounter >= 24)  // ArrayIndexOutOfBoundsException -> :76-79
+            throw FileFormatException("Error in scoring matrix file: " + matrixFilePath + ". Scoring matrix "
+                                      "should always have 24 rows (plus 1 column describing AAs).");
+        for (int i = 1; i < 25; i++) {
+            try {
+                size_t used = 0;
+                m[lineCounter][i - 1] = std::stoi(parts[i], &used);  // Integer.parseInt
+                if (used != parts[i].size()) throw std::invalid_argument("");
+            } catch (const std::exception &) {
+                throw HammockException("NumberFormatException: For input string: \"" + parts[i] + "\"");
+            }
+        }
+        lineCounter++;
+    }
+    return m;
+}
+
+// loadUniqueSequencesFromFasta, FileIOManager.java:159-202
+inline std::vector<UniqueSequencePtr> loadUniqueSequencesFromFasta(const std::string &fileName) {
+    std::vector<std::pair<std::string, std::vector<std::pair<std::string, int>>>> order;  // LinkedHashMap
+    std::unordered_map<std::string, size_t> index;
+    std::string sequence, label;
+    int count = 0;
+    bool haveLabel = false, haveCount = false;
+    auto add = [&](const std::string &seq) {
+        auto it = index.find(seq);
+        if (it == index.end()) {
+            index[seq] = order.size();
+            order.push_back({seq, {{label, count}}});
+        } else {
+            auto &lm = order[it->second].second;
+            bool found = false;
+            for (auto &e : lm) if (e.first == label) { e.second += count; found = true; break; }
+            if (!found) lm.push_back({label, count});
+        }
+    };
+    for (const std::string &line : readLines(fileName)) {
+        if (!line.empty() && line[0] == '>') {
+            if (!sequence.empty()) { add(sequence); sequence.clear(); }              // :168-172
+            const std::vector<std::string> split = splitChar(trim(line).substr(1), '|', true);  // :173
+            if (split.size() >= 2) {
+                count = javaIntegerDecode(trim(split[1]));                           // :175
+                if (count < 1) throw FileFormatException("Error while loading input file. Fasta header defines sequence count lower than 1.");
+            } else count = 1;
+            haveCount = true;
+            label = split.size() >= 3 ? split[2] : "no_label";                       // :182-186
+            haveLabel = true;
+        } else {
+            if (!haveLabel || !haveCount)
+                throw FileFormatException("Error. Incorrect fasta format. Maybe header or sequence line missing?");
+            sequence += trim(line);                                                  // :191
+        }
+    }
+    if (!haveLabel || !haveCount)  // :193 unboxes a null Integer
+        throw NullPointerException("java.lang.NullPointerException (empty input file, FileIOManager.java:193)", 0, -1);
+    add(sequence);                                                                   // :193-195
+    std::vector<UniqueSequencePtr> result;
+    for (auto &e : order) result.push_back(std::make_shared<UniqueSequence>(e.first, e.second));
+    return result;
+}
+
+// loadUniqueSequencesFromTable, FileIOManager.java:227-255
+inline std::vector<UniqueSequencePtr> loadUniqueSequencesFromTable(const std::string &fileName) {
+    const std::vector<std::string> lines = readLines(fileName);
+    if (lines.empty()) throw NullPointerException("java.lang.NullPointerException (empty table, FileIOManager.java:231)", 0, -1);
+    std::vector<std::string> header = splitChar(lines[0], CSV_SEPARATOR, true);
+    std::vector<std::string> labels(header.begin() + 1, header.end());
+    std::vector<UniqueSequencePtr> result;
+    for (size_t k = 1; k < lines.size(); k++) {
+        const std::vector<std::string> parts = splitChar(lines[k], CSV_SEPARATOR, true);
+        std::vector<std::pair<std::string, int>> lm;
+        for (size_t i = 1; i < parts.size(); i++) {
+            const int value = javaIntegerDecode(parts[i]);
+            if (value != 0) {
+                if (i - 1 >= labels.size()) throw HammockException("java.lang.IndexOutOfBoundsException (more columns than labels)");
+                lm.push_back({labels[i - 1], value});
+            }
+        }
+        result.push_back(std::make_shared<UniqueSequence>(parts[0], lm));
+    }
+    return result;
+}
+
+// Hammock.getSortedLabels, Hammock.java:1586-1605 with ValueComparator (FileIOManager.java:1464-1480):
+// total count descending; among equal totals the label put LATER (in HashMap iteration order) comes first.
+inline std::vector<std::string> getSortedLabels(const std::vector<UniqueSequencePtr> &sequences) {
+    std::vector<std::string> insertion;
+    std::unordered_map<std::string, long long> total;
+    for (auto &s : sequences) {
+        std::vector<std::string> keys;
+        for (auto &e : s->getLabelsMap()) keys.push_back(e.first);
+        for (const std::string &k : javaHashMapOrder(keys)) {
+            if (!total.count(k)) insertion.push_back(k);
+            total[k] += s->labelCount(k);
+        }
+    }
+    std::vector<std::string> result;
+    for (const std::string &k : javaHashMapOrder(insertion)) {
+        size_t pos = 0;
+        while (pos < result.size() && total[result[pos]] > total[k]) pos++;  // first element with count <= new
+        result.insert(result.begin() + (long)pos, k);
+    }
+    return result;
+}
+
+inline std::string sequenceLine(const UniqueSequence &seq, const std::vector<std::string> &labels) {
+    std::string out = std::to_string(seq.size());
+    for (const std::string &label : labels) out += CSV_SEPARATOR + std::to_string(seq.labelCount(label));
+    return out;
+}
+
+// writeClusterSequencesToCsv, FileIOManager.java:594-638.  The `alignment` column: the reference fills
+// it from Clustal Omega output for multi-member clusters (external process, out of scope) and with the
+// bare sequence for singletons (:770-776); members of multi-member clusters get "NA" (:617-618).
+inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &sequences, const std::vector<ClusterPtr> &clusters,
+                                       const std::string &filePath, const std::vector<std::string> &labels) {
+    std::unordered_map<std::string, ClusterPtr> sequenceClusterMap;
+    std::unordered_map<std::string, std::string> msaMap;
+    for (auto &cl : clusters) {
+        for (auto &s : cl->getSequences()) sequenceClusterMap[s->getSequenceString()] = cl;
+        if (cl->getUniqueSize() == 1) {
+            const std::string s = cl->getSequences()[0]->getSequenceString();
+            std::string stripped;
+            for (char c : s) if (c != '-') stripped.push_back(c);
+            msaMap[stripped] = s;
+        }
+    }
+    std::ofstream w(filePath, std::ios::binary);
+    if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
+    w << "cluster_id" << CSV_SEPARATOR << "sequence" << CSV_SEPARATOR << "alignment" << CSV_SEPARATOR << "sum";
+    for (const std::string &label : labels) w << CSV_SEPARATOR << label;
+    w << "\n";
+    for (auto &seq : sequences) {
+        const std::string str = seq->getSequenceString();
+        auto it = sequenceClusterMap.find(str);
+        if (it != sequenceClusterMap.end()) {
+            w << it->second->getId() << CSV_SEPARATOR << str << CSV_SEPARATOR;
+            auto m = msaMap.find(str);
+            w << (m != msaMap.end() ? m->second : std::string("NA")) << CSV_SEPARATOR;
+        } else {
+            w << "NA" << CSV_SEPARATOR << str << CSV_SEPARATOR << "NA" << CSV_SEPARATOR;
+        }
+        w << sequenceLine(*seq, labels) << "\n";
+    }
+}
+
+inline std::vector<ClusterPtr> clustersSortedDescending(const std::vector<ClusterPtr> &clusters) {
+    std::vector<ClusterPtr> sorted(clusters);  // Collections.sort(list, Collections.reverseOrder()): size desc, id desc
+    std::stable_sort(sorted.begin(), sorted.end(), [](const ClusterPtr &a, const ClusterPtr &b) { return b->compareTo(*a) < 0; });
+    return sorted;
+}
+
+// saveClusterSequencesToCsv, FileIOManager.java:398-404 + getSortedSequences :530-538 (sorts each
+// cluster's own member list in place, as the reference does)
+inline void saveClusterSequencesToCsv(const std::vector<ClusterPtr> &clusters, const std::string &filePath,
+                                      const std::vector<std::string> &labels) {
+    std::vector<UniqueSequencePtr> sortedSequences;
+    for (auto &cl : clustersSortedDescending(clusters)) {
+        auto &seqs = cl->getSequences();
+        std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+            return sizeAlphabeticCompare(*b, *a) < 0;
+        });
+        sortedSequences.insert(sortedSequences.end(), seqs.begin(), seqs.end());
+    }
+    writeClusterSequencesToCsv(sortedSequences, clusters, filePath, labels);
+}
+
+// saveClusterSequencesToCsvOrdered, FileIOManager.java:371-374
+inline void saveClusterSequencesToCsvOrdered(const std::vector<ClusterPtr> &clusters, const std::string &filePath,
+                                             const std::vector<std::string> &labels,
+                                             const std::vector<UniqueSequencePtr> &orderedSequences) {
+    writeClusterSequencesToCsv(orderedSequences, clusters, filePath, labels);
+}
+
+// SaveClustersToCsv, FileIOManager.java:649-676
+inline void SaveClustersToCsv(const std::vector<ClusterPtr> &clusters, const std::string &filePath,
+                              const std::vector<std::string> &labels) {
+    std::ofstream w(filePath, std::ios::binary);
+    if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
+    w << "cluster_id" << CSV_SEPARATOR << "main_sequence" << CSV_SEPARATOR << "sum";
+    for (const std::string &label : labels) w << CSV_SEPARATOR << label;
+    w << "\n";
+    for (auto &cl : clustersSortedDescending(clusters)) {
+        auto &seqs = cl->getSequences();  // Collections.sort(sequences, reverseOrder()): UniqueSequence.compareTo :161-171
+        std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+            auto cmp = [](const UniqueSequence &x, const UniqueSequence &y) {
+                if (x.size() != y.size()) return x.size() - y.size();
+                return -javaStringCompare(x.getSequenceString(), y.getSequenceString());
+            };
+            return cmp(*b, *a) < 0;
+        });
+        w << cl->getId() << CSV_SEPARATOR << seqs[0]->getSequenceString() << CSV_SEPARATOR << cl->size();
+        for (const std::string &label : labels) {
+            long long c = 0;
+            for (auto &s : seqs) c += s->labelCount(label);
+            w << CSV_SEPARATOR << c;
+        }
+        w << "\n";
+    }
+}
+
+// saveInputStatistics, FileIOManager.java:709-729 (no newline after the last row)
+inline void saveInputStatistics(const std::vector<UniqueSequencePtr> &sequences, const std::vector<std::string> &labels,
+                                const std::string &filePath) {
+    std::ofstream w(filePath, std::ios::binary);
+    if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
+    for (const std::string &label : labels) w << CSV_SEPARATOR << label;
+    w << "\n" << "total_count";
+    for (const std::string &label : labels) {
+        long long c = 0;
+        for (auto &s : sequences) c += s->labelCount(label);
+        w << CSV_SEPARATOR << c;
+    }
+    w << "\n" << "unique_count";
+    for (const std::string &label : labels) {
+        long long c = 0;
+        for (auto &s : sequences) { bool present = false; s->labelCount(label, &present); c += present; }
+        w << CSV_SEPARATOR << c;
+    }
+}
+
+}  // namespace FileIOManager
+}  // namespace hammock
+
+#endif

@@ -84,6 +84,11 @@ int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *off
  * shorter length of any pair. */
 int hmk_score_pairs_shifted(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs,
                             int max_shift, int shift_penalty, int32_t *out);
+/* AligningSequenceScorer.scoreWithShift (AligningSequenceScorer.java:11, ShiftedScorer.java:48-95):
+ * score[k] and shift[k] = AligningScorerResult.getScore() / getShift() for the pair (i[k], j[k]);
+ * the first strict maximum wins (:86-89), the sign follows :91-93. */
+int hmk_score_with_shift(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs,
+                         int max_shift, int shift_penalty, int32_t *score, int32_t *shift);
 /* out[k] = LocalAlignmentScorer(matrix, gap_open, gap_extend).sequenceScore(i[k], j[k])
  * (LocalAlignmentScorer.java:27-86); i = seq1 = lines, j = seq2 = columns. */
 int hmk_score_pairs_local(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs,

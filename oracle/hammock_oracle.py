@@ -539,3 +539,107 @@ def greedy_defaults(sequences):
     max_shift = min(java_round(mean / 4), min(lengths) - 1)
     max_clusters = java_round(len(sequences) * 0.025)
     return threshold, max_shift, max_clusters
+
+
+# ---------------------------------------------------------------------------
+# label ordering and stage-1 writers (Hammock.java:1586-1605, FileIOManager.java)
+# ---------------------------------------------------------------------------
+def java_string_hash(s):
+    h = 0
+    for ch in s:
+        h = (31 * h + ord(ch)) & 0xFFFFFFFF
+    return h
+
+
+def java_hashmap_order(keys):
+    """Iteration order of a Java 8+ HashMap<String, ?> holding `keys` (insertion order given)."""
+    cap = 16
+    while len(keys) > cap * 3 // 4:
+        cap *= 2
+    def bucket(k):
+        h = java_string_hash(k)
+        return (h ^ (h >> 16)) & (cap - 1)
+    return [k for _, _, k in sorted((bucket(k), i, k) for i, k in enumerate(keys))]
+
+
+def get_sorted_labels(sequences):
+    """Hammock.getSortedLabels: TreeMap with ValueComparator (never returns 0): total count
+    descending, among equal totals the label put later comes first."""
+    insertion, total = [], {}
+    for s in sequences:
+        for k in java_hashmap_order(list(s.labels_map.keys())):
+            if k not in total:
+                insertion.append(k)
+                total[k] = 0
+            total[k] += s.labels_map[k]
+    result = []
+    for k in java_hashmap_order(insertion):
+        pos = 0
+        while pos < len(result) and total[result[pos]] > total[k]:
+            pos += 1
+        result.insert(pos, k)
+    return result
+
+
+def _cluster_compare(a, b):  # Cluster.compareTo, Cluster.java:198-204
+    return a.size() - b.size() if a.size() != b.size() else a.id - b.id
+
+
+def _seq_line(seq, labels):
+    return "\t".join([str(seq.size())] + [str(seq.labels_map.get(l, 0)) for l in labels])
+
+
+def write_cluster_sequences_csv(sequences, clusters, path, labels):
+    """writeClusterSequencesToCsv, FileIOManager.java:594-638, without Clustal: singletons carry
+    their own sequence as alignment (:770-776), members of multi-member clusters "NA"."""
+    seq_cluster, msa = {}, {}
+    for cl in clusters:
+        for s in cl.sequences:
+            seq_cluster[s.get_sequence_string()] = cl
+        if cl.get_unique_size() == 1:
+            s = cl.sequences[0].get_sequence_string()
+            msa[s.replace("-", "")] = s
+    with open(path, "w") as fh:
+        fh.write("\t".join(["cluster_id", "sequence", "alignment", "sum"] + labels) + "\n")
+        for seq in sequences:
+            s = seq.get_sequence_string()
+            cl = seq_cluster.get(s)
+            if cl is not None:
+                fh.write(f"{cl.id}\t{s}\t{msa.get(s, 'NA')}\t")
+            else:
+                fh.write(f"NA\t{s}\tNA\t")
+            fh.write(_seq_line(seq, labels) + "\n")
+
+
+def save_cluster_sequences_csv(clusters, path, labels):
+    """saveClusterSequencesToCsv, FileIOManager.java:398-404 (+ getSortedSequences :530-538)."""
+    ordered = sorted(clusters, key=cmp_to_key(lambda a, b: _cluster_compare(b, a)))
+    seqs = []
+    for cl in ordered:
+        cl.sequences.sort(key=cmp_to_key(lambda a, b: _size_alphabetic_cmp(b, a)))
+        seqs.extend(cl.sequences)
+    write_cluster_sequences_csv(seqs, clusters, path, labels)
+
+
+def save_clusters_csv(clusters, path, labels):
+    """SaveClustersToCsv, FileIOManager.java:649-676."""
+    def seq_cmp(a, b):  # UniqueSequence.compareTo :161-171
+        if a.size() != b.size():
+            return a.size() - b.size()
+        return -_string_compare(a.get_sequence_string(), b.get_sequence_string())
+    ordered = sorted(clusters, key=cmp_to_key(lambda a, b: _cluster_compare(b, a)))
+    with open(path, "w") as fh:
+        fh.write("\t".join(["cluster_id", "main_sequence", "sum"] + labels) + "\n")
+        for cl in ordered:
+            cl.sequences.sort(key=cmp_to_key(lambda a, b: seq_cmp(b, a)))
+            counts = [sum(s.labels_map.get(l, 0) for s in cl.sequences) for l in labels]
+            fh.write("\t".join([str(cl.id), cl.sequences[0].get_sequence_string(), str(cl.size())] +
+                               [str(c) for c in counts]) + "\n")
+
+
+def save_input_statistics(sequences, labels, path):
+    """saveInputStatistics, FileIOManager.java:709-729 (no trailing newline)."""
+    with open(path, "w") as fh:
+        fh.write("".join("\t" + l for l in labels) + "\n")
+        fh.write("total_count" + "".join("\t" + str(sum(s.labels_map.get(l, 0) for s in sequences)) for l in labels) + "\n")
+        fh.write("unique_count" + "".join("\t" + str(sum(1 for s in sequences if l in s.labels_map)) for l in labels))

@@ -285,3 +285,73 @@ def test_full_size_properties_1e5(gpu, blosum62, coracle):
         assert int((sc >= 20).sum()) == deg[r]
     # density of uniform random 12-mers at thr 20 (about 2.5e-3)
     assert 1.5e-3 < len(edges) / stats.pairs_scored < 4e-3
+
+
+def test_score_with_shift_vs_oracle(gpu, blosum62, coracle):
+    """AligningSequenceScorer.scoreWithShift: score AND shift (first strict maximum, sign rule :91-93)."""
+    rng = np.random.default_rng(8)
+    peps = random_peptides(rng, 300, 7, 20)
+    ctx, res, off = ctx_for(blosum62, peps)
+    i = rng.integers(0, len(peps), 5000).astype(np.uint32)
+    j = rng.integers(0, len(peps), 5000).astype(np.uint32)
+    for X, p in [(3, 0), (3, -1), (6, -2)]:
+        score, shift = ctx.score_with_shift(i, j, X, p)
+        for k in range(0, 5000, 7):
+            st, s, sh = coracle.shifted_score(blosum62, peps[i[k]], peps[j[k]], X, p)
+            assert (score[k], shift[k]) == (s, sh)
+
+
+# --------------------------------------------------------------------------------------
+# the C++ host side + CLI end to end (hammock-hip greedy == `java -jar Hammock.jar greedy`)
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dataset", ["musi", "manual_counts"])
+def test_cli_greedy_writes_reference_files(gpu, blosum62, coracle, tmp_path, dataset):
+    import subprocess
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "hammock_amd", "bin", "hammock-hip")
+    if dataset == "musi":
+        fa = os.path.join(GOLDEN, "musi.fa")
+        extra = []
+    else:  # counts + labels in the headers: size order, size tie-break, label columns
+        res, off = synth_peptides(11, 3000, 12)
+        rng = np.random.default_rng(11)
+        fa = str(tmp_path / "in.fa")
+        with open(fa, "w") as fh:
+            for k in range(3000):
+                s = "".join(hammock_amd.AMINO_ACIDS[int(c)] for c in res[off[k]:off[k + 1]])
+                if k % 4 == 0:
+                    fh.write(f">{k}|{1 + int(rng.integers(0, 64))}|{'lab_a' if k % 8 else 'lab_b'}\n{s}\n")
+                else:
+                    fh.write(f">{k}\n{s}\n")
+        extra = ["-g", "18", "--initial_clusters_limit", "40"]
+    out = str(tmp_path / "out")
+    r = subprocess.run([cli, "greedy", "-i", fa, "-d", out] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # expected files from the oracle clustering + the writers' restatement
+    seqs = po.load_unique_sequences_from_fasta(fa)
+    labels = po.get_sorted_labels(seqs)
+    initial = list(seqs)
+    thr, X, maxc = po.greedy_defaults(seqs)
+    if extra:
+        thr, maxc = 18, 40
+    po.sort_sequences(seqs, "size")
+    res, off = coracle.pack([s.get_sequence_string() for s in seqs])
+    sizes = np.array([s.size() for s in seqs], dtype=np.int32)
+    st, cid, order, stats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, X, 0, thr, maxc, 4)
+    assert st == 0
+    clusters = {}
+    for k, c in enumerate(cid.tolist()):
+        clusters.setdefault(c, []).append(seqs[k])
+    cl_list = [po.Cluster(clusters[c], c) for c in order.tolist()]
+    exp = tmp_path / "exp"
+    exp.mkdir()
+    po.save_input_statistics(initial, labels, str(exp / "input_statistics.tsv"))
+    po.save_cluster_sequences_csv(cl_list, str(exp / "initial_clusters_sequences.tsv"), labels)
+    po.write_cluster_sequences_csv(initial, cl_list, str(exp / "initial_clusters_sequences_original_order.tsv"), labels)
+    po.save_clusters_csv(cl_list, str(exp / "initial_clusters.tsv"), labels)
+    for name in ("input_statistics.tsv", "initial_clusters_sequences.tsv",
+                 "initial_clusters_sequences_original_order.tsv", "initial_clusters.tsv"):
+        with open(os.path.join(out, name), "rb") as a, open(exp / name, "rb") as b:
+            assert a.read() == b.read(), name
+    log = open(os.path.join(out, "run.log")).read()
+    assert "Ready. Clustering time: " in log and f"Resulting clusers: {len(cl_list)}" in log
