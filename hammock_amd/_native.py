@@ -25,7 +25,7 @@ HMK_MAX_LEN = 32
 
 # every symbol include/hammock_hip.h declares
 SYMBOLS = [
-    "hmk_abi_version", "hmk_create", "hmk_destroy", "hmk_last_error", "hmk_set_sequences",
+    "hmk_abi_version", "hmk_last_kernel_ms", "hmk_create", "hmk_destroy", "hmk_last_error", "hmk_set_sequences",
     "hmk_score_pairs_shifted", "hmk_score_with_shift", "hmk_score_pairs_local", "hmk_score_block_shifted", "hmk_score_block_local",
     "hmk_neighbors_shifted", "hmk_neighbors_shifted_dev", "hmk_neighbors_last_plan",
     "hmk_greedy_cluster", "hmk_greedy_from_edges",
@@ -67,6 +67,8 @@ def _load():
     p_i32, p_u32, p_u64, p_u8 = (C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
                                  C.POINTER(C.c_uint8))
     L.hmk_abi_version.restype = i32
+    L.hmk_last_kernel_ms.argtypes = [vp]
+    L.hmk_last_kernel_ms.restype = C.c_double
     L.hmk_create.argtypes = [p_i32, i32, C.POINTER(vp)]
     L.hmk_destroy.argtypes = [vp]
     L.hmk_destroy.restype = None
@@ -85,7 +87,7 @@ def _load():
     L.hmk_greedy_from_edges.argtypes = [vp, p_u64, u64, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("hmk_destroy", "hmk_last_error"):
+        if name not in ("hmk_destroy", "hmk_last_error", "hmk_last_kernel_ms"):
             fn.restype = i32
     return L
 

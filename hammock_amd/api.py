@@ -118,6 +118,10 @@ class Context:
             raise BufferError(msg)
         raise ValueError(msg)
 
+    def last_kernel_ms(self):
+        """device time of the probe kernel(s) of the last score_pairs_* / score_block_* call"""
+        return float(N.lib.hmk_last_kernel_ms(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             N.lib.hmk_destroy(self._h)

@@ -71,6 +71,11 @@ struct hmk_ctx {
     uint64_t d_edges_cap = 0;
     unsigned long long *d_counts = nullptr;
 
+    double last_kernel_ms = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void *h_csr = nullptr;  // pinned staging of the CSR adjacency (hmk_greedy_cluster)
+    size_t h_csr_cap = 0;
+
     std::string err;
     std::mutex mu;
 };
@@ -362,6 +367,19 @@ int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint3
     return st;
 }
 
+// HIP-event bracket around the probe kernels (hmk_last_kernel_ms)
+void timer_start(hmk_ctx *ctx) {
+    if (!ctx->ev0) { (void)hipEventCreate(&ctx->ev0); (void)hipEventCreate(&ctx->ev1); }
+    ctx->last_kernel_ms = 0;
+    (void)hipEventRecord(ctx->ev0, nullptr);
+}
+void timer_stop(hmk_ctx *ctx) {
+    float ms = 0;
+    if (hipEventRecord(ctx->ev1, nullptr) == hipSuccess && hipEventSynchronize(ctx->ev1) == hipSuccess &&
+        hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess)
+        ctx->last_kernel_ms += ms;
+}
+
 int check_pairs(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, bool shifted, int X) {
     if (ctx->n == 0) return fail(ctx, HMK_ERR_NO_SEQUENCES, "no sequences set (hmk_set_sequences)");
     if (n_pairs && (!i || !j)) return fail(ctx, HMK_ERR_BAD_ARG, "null index array");
@@ -397,7 +415,11 @@ int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, 
         const uint64_t m = std::min(ch, n_pairs - o);
         hipError_t e = hipMemcpy(d_i, i + o, m * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_j, j + o, m * 4, hipMemcpyHostToDevice);
+        double acc = ctx->last_kernel_ms;
+        timer_start(ctx);
         if (e == hipSuccess) e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, d_i, d_j, m, 0, 0, 1, a, b, d_out, d_shift, nullptr);
+        timer_stop(ctx);
+        ctx->last_kernel_ms += (o == 0 ? 0.0 : acc);
         if (e == hipSuccess) e = hipMemcpy(out + o, d_out, m * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess && out_shift) e = hipMemcpy(out_shift + o, d_shift, m * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) st = fail(ctx, HMK_ERR_DEVICE, std::string("score_pairs: ") + hipGetErrorString(e));
@@ -430,8 +452,17 @@ int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0,
     }
     int32_t *d_out = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&d_out, n_pairs * 4));
-    hipError_t e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, nullptr, nullptr, n_pairs, r0, c0, c1 - c0, a, b,
-                                d_out, nullptr, nullptr);
+    hipError_t e;
+    timer_start(ctx);
+    // LocalAlignmentScorer: the register-resident striped kernel when its preconditions hold
+    const bool fast_local = scorer == 1 && a <= 0 && b <= 0 && ctx->min_m >= -127 && ctx->max_m <= 127 &&
+                            getenv("HMK_LOCAL_LITERAL") == nullptr;
+    if (fast_local)
+        e = launch_local_block(ctx->max_len, ctx->d_res32, ctx->d_len, ctx->d_M, r0, r1, c0, c1, a, b, d_out, nullptr);
+    else
+        e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, nullptr, nullptr, n_pairs, r0, c0, c1 - c0, a, b,
+                         d_out, nullptr, nullptr);
+    timer_stop(ctx);
     if (e == hipSuccess) e = hipMemcpy(out, d_out, n_pairs * 4, hipMemcpyDeviceToHost);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(ctx, HMK_ERR_DEVICE, std::string("score_block: ") + hipGetErrorString(e));
@@ -446,6 +477,8 @@ int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0,
 extern "C" {
 
 int hmk_abi_version(void) { return HMK_ABI_VERSION; }
+
+double hmk_last_kernel_ms(const hmk_ctx *ctx) { return ctx ? ctx->last_kernel_ms : 0.0; }
 
 const char *hmk_last_error(const hmk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
@@ -508,6 +541,9 @@ void hmk_destroy(hmk_ctx *ctx) {
         if (ctx->d_M) (void)hipFree(ctx->d_M);
         if (ctx->d_edges) (void)hipFree(ctx->d_edges);
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+        if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
+        if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+        if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     }
     delete ctx;
 }
@@ -672,18 +708,48 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (st) return st;
     uint64_t total = 0;
     for (int s = 0; s < HMK_EDGE_SHARDS; s++) total += counts[s];
-    std::vector<uint64_t> edges(total);
+    // edge segments -> CSR on the device, then ONE pinned D2H of start[] and adj[]
+    const uint32_t n = ctx->n;
+    const uint64_t n_adj = ctx->symmetric ? 2 * total : total;
     const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
-    uint64_t o = 0;
-    for (int s = 0; s < HMK_EDGE_SHARDS; s++) {
-        if (counts[s])
-            HIPCHK(ctx, hipMemcpy(edges.data() + o, ctx->d_edges + (uint64_t)s * seg, counts[s] * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        o += counts[s];
+    uint32_t *d_deg = nullptr, *d_cursor = nullptr;
+    uint64_t *d_start = nullptr;
+    Nbr *d_adj = nullptr;
+    auto cleanup = [&]() {
+        if (d_deg) (void)hipFree(d_deg);
+        if (d_cursor) (void)hipFree(d_cursor);
+        if (d_start) (void)hipFree(d_start);
+        if (d_adj) (void)hipFree(d_adj);
+    };
+    hipError_t e = hipMalloc((void **)&d_deg, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_start, ((size_t)n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_adj, std::max<uint64_t>(n_adj, 1) * sizeof(Nbr));
+    if (e == hipSuccess) e = hipMemsetAsync(d_deg, 0, (size_t)n * 4, nullptr);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)n * 4, nullptr);
+    if (e == hipSuccess) e = launch_csr_degree_scan(ctx->d_edges, seg, ctx->d_counts, n, ctx->symmetric, d_deg, d_start, nullptr);
+    if (e == hipSuccess) e = launch_csr_scatter(ctx->d_edges, seg, ctx->d_counts, ctx->symmetric, d_start, d_cursor, d_adj, nullptr);
+    if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + n_adj * sizeof(Nbr)) {
+        if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
+        ctx->h_csr = nullptr;
+        ctx->h_csr_cap = 0;
+        const size_t want = ((size_t)n + 1) * 8 + n_adj * sizeof(Nbr) + (1 << 20);
+        e = hipHostMalloc(&ctx->h_csr, want, hipHostMallocDefault);
+        if (e == hipSuccess) ctx->h_csr_cap = want;
     }
+    uint64_t *h_start = (uint64_t *)ctx->h_csr;
+    Nbr *h_adj = (Nbr *)((char *)ctx->h_csr + ((size_t)n + 1) * 8);
+    if (e == hipSuccess) e = hipMemcpy(h_start, d_start, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_adj) e = hipMemcpy(h_adj, d_adj, n_adj * sizeof(Nbr), hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,
+                                     std::string("hmk_greedy_cluster (CSR build): ") + hipGetErrorString(e));
+    if (h_start[n] != n_adj) return fail(ctx, HMK_ERR_DEVICE, "CSR build: adjacency size mismatch");
     const double nb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::string err;
-    st = greedy_from_edges(ctx->n, ctx->has_sizes ? ctx->sizes.data() : nullptr, edges.data(), total, ctx->symmetric,
-                           threshold, max_clusters, cluster_id, result_order, member_rank, stats, &err);
+    st = greedy_from_csr(n, ctx->has_sizes ? ctx->sizes.data() : nullptr, h_start, h_adj, max_clusters, cluster_id,
+                         result_order, member_rank, stats, &err);
+    stats->n_edges = total;
     stats->neighbors_ms = nb_ms;
     if (st) return fail(ctx, st, err);
     return HMK_OK;

@@ -33,11 +33,6 @@ namespace hmk {
 
 namespace {
 
-struct Nbr {
-    uint32_t m;
-    int32_t s;
-};
-
 enum : uint8_t { ST_FREE = 0, ST_IN_CLUSTER = 1, ST_ORPHAN = 2 };
 enum { NEAR_NULL = 0, NEAR_DUMMY = 1, NEAR_REAL = 2 };
 
@@ -66,12 +61,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
                       bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,
                       int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
     auto t0 = std::chrono::steady_clock::now();
-    hmk_greedy_stats local;
-    if (!st) st = &local;
-    std::memset(st, 0, sizeof(*st));
-    st->n_edges = n_edges;
     (void)threshold;  // every stored edge already satisfies score >= threshold
-
     // ---- CSR adjacency: adj[x] = {(m, sequenceScore(m, x))} -----------------
     std::vector<uint64_t> start((size_t)n + 1, 0);
     for (uint64_t e = 0; e < n_edges; e++) {
@@ -94,6 +84,24 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
             if (symmetric) adj[fill[m]++] = Nbr{x, s};
         }
     }
+    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), max_clusters, cluster_id, result_order,
+                                   member_rank, st, err);
+    if (st) {
+        st->n_edges = n_edges;
+        st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return rc;
+}
+
+// The merge proper, on a CSR adjacency: start[n + 1], adj[start[x] .. start[x + 1]) = neighbours of x.
+int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, int max_clusters,
+                    int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
+                    std::string *err) {
+    auto t0 = std::chrono::steady_clock::now();
+    hmk_greedy_stats local;
+    if (!st) st = &local;
+    std::memset(st, 0, sizeof(*st));
+    st->n_edges = start[n];
 
     std::vector<uint8_t> state(n, ST_FREE);
     std::vector<int32_t> cluster_of(n, -1);

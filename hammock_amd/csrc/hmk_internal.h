@@ -54,7 +54,16 @@ struct NeighborParams {
     uint32_t pad;
 };
 
+// one directed neighbour: sequenceScore(seq1 = m, seq2 = x) = s for the row x it is stored under
+struct Nbr {
+    uint32_t m;
+    int32_t s;
+};
+
 // host greedy merge (hmk_greedy.cpp)
+int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, int max_clusters,
+                    int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
+                    std::string *err);
 int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
                       bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,
                       int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err);

@@ -23,5 +23,16 @@ hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, co
                         const uint32_t *pi, const uint32_t *pj, uint64_t n_pairs, uint32_t r0, uint32_t c0,
                         uint32_t width, int a, int b, int32_t *out, int32_t *out_shift, hipStream_t s);
 
+// edge segments -> CSR (start[n + 1], adj[]) on the device: deg and cursor are zeroed uint32[n] scratch
+hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
+                                  bool symmetric, uint32_t *deg, uint64_t *start, hipStream_t s);
+hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
+                              bool symmetric, const uint64_t *start, uint32_t *cursor, Nbr *adj, hipStream_t s);
+
+// LocalAlignmentScorer dense block, register-resident DP (needs |M| <= 127, gap penalties <= 0, len <= lbmax)
+hipError_t launch_local_block(int lbmax, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,
+                              uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
+                              hipStream_t s);
+
 }  // namespace hmk
 #endif

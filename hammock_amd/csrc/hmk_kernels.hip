@@ -470,6 +470,187 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
 }
 
 // -----------------------------------------------------------------------------
+// k_local_block: LocalAlignmentScorer for a dense block, register-resident DP
+// -----------------------------------------------------------------------------
+// score(seq1 = row, seq2 = column) for rows [r0, r1) x columns [c0, c1)
+// (LocalAlignmentScorer.java:27-86).  One COLUMN sequence per lane (its DP state lives in
+// VGPRs), the ROW sequence is wave-uniform.  Per row the workgroup keeps a "query profile"
+// in LDS: Q[c][iq] = the substitution scores M[row[4 iq + k]][c], k = 0..3, as four int8 in one
+// dword, so one ds_read_b32 feeds four cells.  The DP runs in strips of four lines, column by
+// column; per column only H and the "up candidate" of the strip's last line survive:
+//     H[j]   score of cell (line, j)
+//     U[j]   H[j] + (Dir[j] == UP   ? gapExtend : gapOpen)   -- what the cell below adds (:43-48,:57)
+//     lcand  H    + (Dir    == LEFT ? gapExtend : gapOpen)   -- what the cell to the right adds (:50-58)
+// Dir follows the reference's assignment order (:73-81): DIAGONAL if mx == diag, else UP if
+// mx == up, else LEFT; NOWHERE (neither flag) when mx < 0.
+// Padding (lines >= len1, columns >= the lane's len2) uses score -128: with gap penalties <= 0 a
+// padded cell can never exceed the largest real cell, so the running maximum is unaffected.
+// Preconditions checked by the host: |M| <= 127, gapOpen <= 0, gapExtend <= 0 (else k_pairs<1>).
+template <int LBMAX>
+__global__ void __launch_bounds__(256)
+k_local_block(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len, const int32_t *__restrict__ Mg,
+              uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend,
+              int32_t *__restrict__ out) {
+    constexpr int R = 16;                 // rows per workgroup pass
+    constexpr int QROW = 25 * 8 * 4;      // profile bytes per row: 25 residues (24 + pad) x 8 dwords
+    __shared__ __attribute__((aligned(16))) uint8_t smem[R * QROW + 576 + R * 32];
+    int8_t *m8 = reinterpret_cast<int8_t *>(smem + R * QROW);
+    uint8_t *rowres = smem + R * QROW + 576;
+    const int tid = threadIdx.x;
+    const uint32_t width = c1 - c0;
+    const uint32_t col = c0 + blockIdx.x * 256 + tid;
+    const bool col_ok = col < c1;
+    const uint32_t row_base = r0 + blockIdx.y * R;
+    const uint32_t nrows = min((uint32_t)R, r1 - row_base);
+
+    for (int e = tid; e < 576; e += 256) m8[e] = (int8_t)Mg[e];
+    for (int e = tid; e < R * 32; e += 256) {
+        const uint32_t r = (uint32_t)e >> 5;
+        rowres[e] = r < nrows ? res32[(size_t)(row_base + r) * 32 + (e & 31)] : 0;
+    }
+    __syncthreads();
+    // profiles: entry (r, c, iq)
+    for (int e = tid; e < R * 25 * 8; e += 256) {
+        const int r = e / 200, rem = e - r * 200, c = rem >> 3, iq = rem & 7;
+        const int l1 = (uint32_t)r < nrows ? len[row_base + r] : 0;
+        uint32_t dw = 0;
+        for (int k = 0; k < 4; k++) {
+            const int i = iq * 4 + k;
+            int v = -128;
+            if (i < l1 && c < 24) v = m8[rowres[r * 32 + i] * 24 + c];
+            dw |= ((uint32_t)v & 0xFFu) << (8 * k);
+        }
+        reinterpret_cast<uint32_t *>(smem)[e] = dw;
+    }
+    __syncthreads();
+
+    // this lane's column sequence -> profile byte offsets (pad residue 24 beyond its length)
+    uint32_t boff[LBMAX];
+    int len2 = 0;
+    {
+        uint32_t words[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) words[q] = 0;
+        if (col_ok) {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(res32 + (size_t)col * 32);
+            const u32x4 v0 = src[0], v1 = src[1];
+            words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+            words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
+            len2 = len[col];
+        }
+#pragma unroll
+        for (int j = 0; j < LBMAX; j++) {
+            const uint32_t c = j < len2 ? ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu) : 24u;
+            boff[j] = c * 32u;
+        }
+    }
+    // widest column of the wave: columns beyond it are skipped wave-uniformly
+    int wmax = len2;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+
+    const uint32_t q_addr = lds_addr(smem);
+    for (uint32_t r = 0; r < nrows; r++) {
+        const int len1 = len[row_base + r];
+        int H[LBMAX], U[LBMAX];
+#pragma unroll
+        for (int j = 0; j < LBMAX; j++) { H[j] = 0; U[j] = gap_open; }   // line 0: H = 0, Dir = LEFT (:97-100)
+        int gmax = 0;
+        const int strips = (len1 + 3) >> 2;
+        for (int st = 0; st < strips; st++) {
+            const uint32_t strip_addr = q_addr + r * QROW + (uint32_t)st * 4u;
+            int hd[4], lc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hd[k] = 0; lc[k] = gap_open; }  // column 0: H = 0, Dir = UP (:93-96)
+#pragma unroll
+            for (int j = 0; j < LBMAX; j++) {
+                if (j < wmax) {
+                    const uint32_t q = lds_read<uint32_t>(strip_addr + boff[j]);
+                    int up = U[j];
+                    int habove = H[j];          // H[line-1][j]: the next column's diagonal for line k = 0
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int sc = (int)(int8_t)(q >> (8 * k));
+                        const int diag = hd[k] + sc;                      // :59
+                        const int left = lc[k];
+                        const int mx = max(diag, max(up, left));         // :61
+                        const bool neg = mx < 0;                          // :63
+                        const bool d_eq = mx == diag, u_eq = mx == up;
+                        const int h = max(mx, 0);                         // :64,:67
+                        const bool is_up = u_eq && !d_eq && !neg;         // :76-81
+                        const bool is_left = !(u_eq || d_eq || neg);      // :73-81
+                        gmax = max(gmax, h);                              // :68-72
+                        hd[k] = habove;
+                        habove = h;
+                        up = h + (is_up ? gap_extend : gap_open);
+                        lc[k] = h + (is_left ? gap_extend : gap_open);
+                    }
+                    H[j] = habove;
+                    U[j] = up;
+                }
+            }
+        }
+        if (col_ok) out[(size_t)(row_base + r - r0) * width + (col - c0)] = gmax;
+    }
+}
+
+// -----------------------------------------------------------------------------
+// edge list -> CSR adjacency on the device (feeds the host greedy merge)
+// -----------------------------------------------------------------------------
+// The neighbour kernel leaves HMK_EDGE_SHARDS segments of packed edges.  Three small
+// passes turn them into start[n + 1] / adj[] (each undirected edge stored under both
+// ends when the matrix is symmetric): degree count, exclusive scan, scatter.  Order
+// inside a row is arbitrary (atomic cursors); the merge does not depend on it.
+__global__ void __launch_bounds__(256)
+k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
+              uint32_t *__restrict__ deg, int symmetric) {
+    const uint32_t shard = blockIdx.y;
+    const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
+    const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256) {
+        const uint64_t e = seg[k];
+        atomicAdd(&deg[HMK_EDGE_X(e)], 1u);
+        if (symmetric) atomicAdd(&deg[HMK_EDGE_M(e)], 1u);
+    }
+}
+
+__global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t *__restrict__ deg, uint64_t *__restrict__ start, uint32_t n) {
+    __shared__ uint64_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (n + 1023) / 1024;
+    const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+    uint64_t sum = 0;
+    for (uint32_t k = lo; k < hi; k++) sum += deg[k];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+        const uint64_t v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t k = lo; k < hi; k++) { start[k] = run; run += deg[k]; }
+    if (tid == 1023) start[n] = part[1023];
+}
+
+__global__ void __launch_bounds__(256)
+k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
+               const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, Nbr *__restrict__ adj, int symmetric) {
+    const uint32_t shard = blockIdx.y;
+    const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
+    const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256) {
+        const uint64_t e = seg[k];
+        const uint32_t x = HMK_EDGE_X(e), m = HMK_EDGE_M(e);
+        const int32_t s = HMK_EDGE_SCORE(e);
+        adj[start[x] + atomicAdd(&cursor[x], 1u)] = Nbr{m, s};
+        if (symmetric) adj[start[m] + atomicAdd(&cursor[m], 1u)] = Nbr{x, s};
+    }
+}
+
+// -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------
 template <int NW, int R, int CPL, int LBMAX, bool EXACT>
@@ -526,6 +707,35 @@ hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, 
     const size_t lds = 2304 + 256 * SEQ_STRIDE_DW * 4 + 16 * 8 * 4 + 4 * 128 * 3 * 4;
     hipLaunchKernelGGL(k_neighbors_direct, dim3(n_tiles), dim3(256), lds, s, P, tile_base, d_matrix, max_shift,
                        shift_penalty, threshold);
+    return hipGetLastError();
+}
+
+hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
+                                  bool symmetric, uint32_t *deg, uint64_t *start, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_degree, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg,
+                       symmetric ? 1 : 0);
+    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, deg, start, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
+                              bool symmetric, const uint64_t *start, uint32_t *cursor, Nbr *adj, hipStream_t s) {
+    hipLaunchKernelGGL(k_edge_scatter, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, start,
+                       cursor, adj, symmetric ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_local_block(int lbmax, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,
+                              uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
+                              hipStream_t s) {
+    if (r1 <= r0 || c1 <= c0) return hipSuccess;
+    const dim3 grid((c1 - c0 + 255) / 256, (r1 - r0 + 15) / 16);
+    if (lbmax <= 20)
+        hipLaunchKernelGGL(k_local_block<20>, grid, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, gap_open,
+                           gap_extend, out);
+    else
+        hipLaunchKernelGGL(k_local_block<32>, grid, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, gap_open,
+                           gap_extend, out);
     return hipGetLastError();
 }
 

@@ -69,6 +69,9 @@ int hmk_create(const int32_t matrix[HMK_ALPHABET * HMK_ALPHABET], int device, hm
 void hmk_destroy(hmk_ctx *ctx);
 const char *hmk_last_error(const hmk_ctx *ctx); /* ctx may be NULL */
 int hmk_abi_version(void);
+/* Device time (HIP events, milliseconds) of the scoring kernel(s) the last hmk_score_pairs_* /
+ * hmk_score_block_* / hmk_score_with_shift call launched; excludes the host<->device copies. */
+double hmk_last_kernel_ms(const hmk_ctx *ctx);
 
 /* The List<UniqueSequence> handed to SequenceClusterer.cluster
  * (SequenceClusterer.java:24), flattened in the caller's (greedy) order:

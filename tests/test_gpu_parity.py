@@ -355,3 +355,24 @@ def test_cli_greedy_writes_reference_files(gpu, blosum62, coracle, tmp_path, dat
             assert a.read() == b.read(), name
     log = open(os.path.join(out, "run.log")).read()
     assert "Ready. Clustering time: " in log and f"Resulting clusers: {len(cl_list)}" in log
+
+
+@pytest.mark.parametrize("cfg", [("blosum62", 7, 20), ("blosum62", 1, 32), ("pam250", 5, 12), ("blosum100", 12, 12)])
+def test_local_block_striped_kernel_vs_oracle(gpu, matrices, coracle, cfg):
+    """The register-resident striped SW kernel (dense blocks) against the oracle, incl. the
+    argument-order dependence and penalties that force the literal fallback (positive gaps)."""
+    mat, lo, hi = cfg
+    M = matrices[mat]
+    rng = np.random.default_rng(4)
+    peps = random_peptides(rng, 700, lo, hi, alphabet=24)
+    ctx, res, off = ctx_for(M, peps)
+    for go, ge in [(-5, -1), (-11, -1), (-2, -2), (0, 0), (-1, -6), (2, 1)]:
+        got = ctx.score_block_local(3, 403, 0, 700, go, ge)
+        st, want = coracle.score_block(M, res, off, np.arange(3, 403), np.arange(0, 700), 1, go, ge)
+        assert st == 0 and np.array_equal(got, want), (cfg, go, ge)
+    t = ctx.score_block_local(0, 300, 300, 600, -5, -1)
+    tt = ctx.score_block_local(300, 600, 0, 300, -5, -1)
+    st, want = coracle.score_block(M, res, off, np.arange(300, 600), np.arange(0, 300), 1, -5, -1)
+    assert np.array_equal(tt, want)
+    if lo != hi:
+        assert (t != tt.T).any()  # score(a, b) != score(b, a) for some pairs
