@@ -42,6 +42,21 @@ def load_blosum62():
         return np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
 
 
+def pmc_traffic(n, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/round1_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
+    command, gfx950 x2 read correction applied).  Counters cannot be read from inside the timed
+    run, so the value is only reported for the workload it was collected on; otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")) as fh:
+            d = json.load(fh)
+        if n == N_SEQ and world == 1:
+            return d["hbm_traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(M, res, off, n_sample, threads):
     """The oracle's literal greedy (the reference's algorithm, OpenMP over the
     reference's own 4*T partitions) on the first n_sample peptides of the workload:
@@ -70,7 +85,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=N_SEQ, help="number of synthetic peptides (default: the BASELINE workload)")
-    ap.add_argument("--cpu-sample", type=int, default=30000)
+    ap.add_argument("--cpu-sample", type=int, default=100000,
+                    help="peptides in the CPU baseline sample (default: the whole workload, about 4 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-greedy", action="store_true")
     args = ap.parse_args()
@@ -166,7 +182,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total / (elapsed / args.steps)
-        # dominant kernel: k_neighbors_swar<2,16,2,12,true>.  Algorithmic HBM bytes per launch
+        # dominant kernel: k_neighbors_swar<2,8,2,12,true>.  Algorithmic HBM bytes per launch
         # (DESIGN.md "Roofline"): 8 B per emitted edge + 16 B per peptide read once.
         pairs_rank = int(plan.pairs_scored)
         alg_bytes = 8 * n_edges_rank + 16 * n
@@ -183,8 +199,8 @@ def main():
                        "parallelism": f"row-block sharding over {world} GPU(s)" + (", RCCL all-gather of edge blocks"
                                                                                   if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_neighbors_swar<NW=2,R=16,CPL=2,LB=12>", "kernel_ms": kern_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
+                         "kernel": "k_neighbors_swar<NW=2,R=8,CPL=2,LB=12,exact>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "HBM does not bind this path (SURVEY.md 8d): the kernel is bound by LDS lookups",
                          "lds": {"achieved_lookups_per_s": lookups, "peak_lookups_per_s": LDS_LOOKUP_PEAK,

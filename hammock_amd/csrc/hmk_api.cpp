@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "hmk_internal.h"
@@ -25,6 +26,7 @@ thread_local std::string g_last_error;
 struct Group {
     int path;
     int nw;
+    int lbk;  // column-length capacity of the kernel instantiation
     uint32_t base, count;
 };
 
@@ -183,8 +185,8 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         std::memcpy(fill, bucket, sizeof(fill));
         for (uint32_t k = 0; k < n; k++) perm[fill[ctx->len[k]]++] = k;
     }
-    pl.lbmax = ctx->max_len <= 12 ? 12 : ctx->max_len <= 20 ? 20 : 32;
-    pl.lpad = pl.lbmax == 12 ? 16 : 32;
+    pl.lbmax = swar_lbmax_for(ctx->max_len);
+    pl.lpad = ctx->max_len <= 16 ? 16 : 32;
     pl.exact = ctx->min_len == 12 && ctx->max_len == 12;
     // Tiling (measured on MI355X, tools/tune_hot.py): 8 rows x 2 columns per lane and long
     // column runs win (5 workgroups/CU, table build amortised); shrink the runs for small
@@ -199,7 +201,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     // ---- classes and tiles --------------------------------------------------------
     std::vector<TileClass> classes;
     std::map<int, int> class_of;  // la * 64 + lb
-    std::map<std::pair<int, int>, std::vector<Tile>> grouped;  // (path, nw)
+    std::map<std::tuple<int, int, int>, std::vector<Tile>> grouped;  // (path, nw, column capacity)
     const uint32_t COLS = pl.cols_per_tile;
     hmk_neighbor_stats &S = pl.stats;
     S = hmk_neighbor_stats{};
@@ -211,7 +213,9 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         for (int lb = 1; lb <= HMK_MAX_LEN; lb++) {
             const uint32_t cb = bucket[lb], ce = bucket[lb + 1];
             if (cb == ce) continue;
-            if (ctx->symmetric && lb < la) continue;  // unordered pairs: shorter bucket supplies the rows
+            // unordered pairs: the LONGER bucket supplies the rows, so a pair costs one table lookup per
+            // residue of its SHORTER sequence (the column), ShiftedScorer.java:51-57 decides S/L by length anyway
+            if (ctx->symmetric && lb > la) continue;
             const bool same = la == lb;
             if (same && re - rb < 2) continue;
             TileClass tc;
@@ -222,8 +226,10 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
             if (tc.path == PATH_U8) S.classes_u8++;
             else if (tc.path == PATH_U16) S.classes_u16++;
             else S.classes_direct++;
-            const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(pl.lbmax, tc.nw, pl.exact, pl.hot_variant);
-            std::vector<Tile> &dst = grouped[{tc.path, tc.path == PATH_DIRECT ? 0 : tc.nw}];
+            const int lbk = pl.exact ? 12 : swar_lbmax_for(lb);
+            const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(lbk, tc.nw, pl.exact, pl.hot_variant);
+            std::vector<Tile> &dst = grouped[std::make_tuple((int)tc.path, tc.path == PATH_DIRECT ? 0 : (int)tc.nw,
+                                                             tc.path == PATH_DIRECT ? 0 : lbk)];
             for (uint32_t r0 = rb; r0 < re; r0 += R) {
                 const bool mine = (row_chunk_counter++ % n_parts) == part;
                 if (!mine) continue;
@@ -258,7 +264,8 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     std::vector<Tile> tiles;
     for (auto &kv : grouped) {
         if (kv.second.empty()) continue;
-        pl.groups.push_back(Group{kv.first.first, kv.first.second, (uint32_t)tiles.size(), (uint32_t)kv.second.size()});
+        pl.groups.push_back(Group{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),
+                                  (uint32_t)tiles.size(), (uint32_t)kv.second.size()});
         tiles.insert(tiles.end(), kv.second.begin(), kv.second.end());
     }
     S.n_tiles = (uint32_t)tiles.size();
@@ -318,7 +325,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
         if (g.path == PATH_DIRECT)
             HIPCHK(ctx, launch_neighbors_direct(P, g.base, g.count, ctx->d_M, X, p, thr, stream));
         else
-            HIPCHK(ctx, launch_neighbors_swar(pl.lbmax, g.nw, pl.exact, pl.hot_variant, P, g.base, g.count, stream));
+            HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, g.base, g.count, stream));
     }
     return HMK_OK;
 }

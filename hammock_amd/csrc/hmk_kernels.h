@@ -11,6 +11,8 @@ namespace hmk {
 
 // rows per tile the SWAR kernel instantiation (lbmax, nw) was built with
 int swar_rows_per_tile(int lbmax, int nw, bool exact, int hot_variant);
+// smallest instantiated column-length capacity that holds columns of length lb
+int swar_lbmax_for(int lb);
 
 hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant, const NeighborParams &P,
                                  uint32_t tile_base, uint32_t n_tiles, hipStream_t s);

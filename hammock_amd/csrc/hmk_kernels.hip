@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
     constexpr int TAB_BYTES = R * ROWBYTES;
     constexpr int STAGE_CAP = 128;             // records per wave; flushed when fewer than 64 slots are free
     constexpr int REC_DW = NW + 2;
-    constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;  // dwords per stored residue row (lpad 16 / 32)
+    constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;  // residue dwords a lane needs (rows are P.lpad bytes apart)
     static_assert(TAB_BYTES <= 65536, "row tables must stay addressable by the DS immediate offset");
     // one STATIC LDS object: its base address is a compile-time constant, so table
     // offsets fold into the ds_read immediate instead of costing a v_add per lookup
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
 #pragma unroll
             for (int q = 0; q < LPADW; q++) words[q] = 0;
             if (col < col_end) {
-                const u32x4 *src = reinterpret_cast<const u32x4 *>(P.res_sorted + (size_t)col * (LPADW * 4));
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(P.res_sorted + (size_t)col * P.lpad);
                 const u32x4 v0 = src[0];
                 words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
                 if (LPADW == 8) {
@@ -660,16 +660,23 @@ static hipError_t launch_swar_t(const NeighborParams &P, uint32_t tile_base, uin
 }
 
 // Hot-path tilings of the exact length-12, NW = 2 kernel: {rows per tile, columns per lane}.
-static const int kHotVariants[][2] = {{16, 2}, {8, 2}, {12, 2}, {8, 4}, {16, 4}, {12, 4}, {4, 2}, {6, 2}, {8, 3}, {8, 1}, {10, 2}};
+static const int kHotVariants[][2] = {{16, 2}, {8, 2}, {12, 2}, {8, 4}, {16, 4}, {12, 4}, {4, 2}, {6, 2}};
 constexpr int kNumHotVariants = sizeof(kHotVariants) / sizeof(kHotVariants[0]);
+
+// Generic instantiations: column-length capacity LBMAX x dwords per entry NW.  Rows per tile
+// R = what fits a 40 KB table budget (<= 16); 2 columns per lane for the narrow entries.
+constexpr int swar_r(int lbmax, int nw) {
+    const int rowbytes = lbmax * 24 * nw * 4;
+    int r = 40960 / rowbytes;
+    return r > 16 ? 16 : (r < 1 ? 1 : r);
+}
+
+int swar_lbmax_for(int lb) { return lb <= 8 ? 8 : lb <= 12 ? 12 : lb <= 16 ? 16 : lb <= 20 ? 20 : 32; }
 
 int swar_rows_per_tile(int lbmax, int nw, bool exact, int hot_variant) {
     if (exact && lbmax == 12 && nw == 2 && hot_variant >= 0 && hot_variant < kNumHotVariants)
         return kHotVariants[hot_variant][0];
-    const int rowbytes = lbmax * 24 * nw * 4;
-    int r = 16;
-    while (r > 1 && r * rowbytes > 40960) r >>= 1;
-    return r;
+    return swar_r(lbmax, nw);
 }
 
 hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant, const NeighborParams &P,
@@ -681,21 +688,19 @@ hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant,
             case 1: return launch_swar_t<2, 8, 2, 12, true>(P, tile_base, n_tiles, s);
             case 2: return launch_swar_t<2, 12, 2, 12, true>(P, tile_base, n_tiles, s);
             case 3: return launch_swar_t<2, 8, 4, 12, true>(P, tile_base, n_tiles, s);
-            case 4: return launch_swar_t<2, 16, 4, 12, true>(P, tile_base, n_tiles, s);
-            case 5: return launch_swar_t<2, 12, 4, 12, true>(P, tile_base, n_tiles, s);
             case 6: return launch_swar_t<2, 4, 2, 12, true>(P, tile_base, n_tiles, s);
             case 7: return launch_swar_t<2, 6, 2, 12, true>(P, tile_base, n_tiles, s);
-            case 8: return launch_swar_t<2, 8, 3, 12, true>(P, tile_base, n_tiles, s);
-            case 9: return launch_swar_t<2, 8, 1, 12, true>(P, tile_base, n_tiles, s);
-            case 10: return launch_swar_t<2, 10, 2, 12, true>(P, tile_base, n_tiles, s);
             default: return hipErrorInvalidValue;
         }
     }
-#define HMK_CASE(LB, NWV, RV, CPLV) \
-    if (lbmax == LB && nw == NWV) return launch_swar_t<NWV, RV, CPLV, LB, false>(P, tile_base, n_tiles, s);
-    HMK_CASE(12, 1, 16, 2) HMK_CASE(12, 2, 16, 2) HMK_CASE(12, 4, 8, 1) HMK_CASE(12, 8, 4, 1)
-    HMK_CASE(20, 1, 16, 2) HMK_CASE(20, 2, 8, 2)  HMK_CASE(20, 4, 4, 1) HMK_CASE(20, 8, 2, 1)
-    HMK_CASE(32, 1, 8, 2)  HMK_CASE(32, 2, 4, 2)  HMK_CASE(32, 4, 2, 1) HMK_CASE(32, 8, 1, 1)
+#define HMK_CASE(LB, NWV) \
+    if (lbmax == LB && nw == NWV) \
+        return launch_swar_t<NWV, swar_r(LB, NWV), (NWV <= 2 ? 2 : 1), LB, false>(P, tile_base, n_tiles, s);
+    HMK_CASE(8, 1)  HMK_CASE(8, 2)  HMK_CASE(8, 4)  HMK_CASE(8, 8)
+    HMK_CASE(12, 1) HMK_CASE(12, 2) HMK_CASE(12, 4) HMK_CASE(12, 8)
+    HMK_CASE(16, 1) HMK_CASE(16, 2) HMK_CASE(16, 4) HMK_CASE(16, 8)
+    HMK_CASE(20, 1) HMK_CASE(20, 2) HMK_CASE(20, 4) HMK_CASE(20, 8)
+    HMK_CASE(32, 1) HMK_CASE(32, 2) HMK_CASE(32, 4) HMK_CASE(32, 8)
 #undef HMK_CASE
     return hipErrorInvalidValue;
 }

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""BASELINE config 4a only (1e5 peptides, lengths 7..20, ShiftedScorer X=3 p=-1 thr=23): 3 passes.
+For `rocprofv3 --kernel-trace --stats -- python3 tools/run_config4a.py`."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import hammock_amd
+from hammock_amd import _native
+from hammock_amd.synth import synth_peptides
+from bench import load_blosum62
+
+res, off = synth_peptides(1, 100000, 7, 20)
+ctx = hammock_amd.Context(load_blosum62(), device=0)
+ctx.set_sequences(residues=res, offsets=off)
+dev = torch.device("cuda", 0)
+cap = 1 << 24
+d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
+d_counts = torch.zeros(_native.HMK_EDGE_SHARDS, dtype=torch.int64, device=dev)
+for _ in range(3):
+    ctx.neighbors_shifted_dev(3, -1, 23, 0, 1, d_edges.data_ptr(), cap, d_counts.data_ptr(),
+                              torch.cuda.current_stream(dev).cuda_stream)
+torch.cuda.synchronize()
+print(int(d_counts.sum().item()), ctx.last_plan().n_tiles)
