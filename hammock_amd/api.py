@@ -224,6 +224,13 @@ class Context:
         if st:
             self._raise(st)
 
+    def compact_edges_dev(self, d_edges_ptr, capacity, d_counts_ptr, d_out_ptr, out_capacity, d_total_ptr, stream=0):
+        st = N.lib.hmk_compact_edges_dev(self._h, C.c_void_p(d_edges_ptr), int(capacity), C.c_void_p(d_counts_ptr),
+                                         C.c_void_p(d_out_ptr), int(out_capacity), C.c_void_p(d_total_ptr),
+                                         C.c_void_p(stream))
+        if st:
+            self._raise(st)
+
     def last_plan(self):
         stats = N.NeighborStats()
         st = N.lib.hmk_neighbors_last_plan(self._h, C.byref(stats))

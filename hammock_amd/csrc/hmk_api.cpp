@@ -647,6 +647,20 @@ int hmk_neighbors_shifted_dev(hmk_ctx *ctx, int max_shift, int shift_penalty, in
                                 (hipStream_t)stream);
 }
 
+int hmk_compact_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t capacity, const void *d_counts, void *d_out,
+                          uint64_t out_capacity, void *d_total, void *stream) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int st = need_device(ctx);
+    if (st) return st;
+    if (!d_edges || !d_counts || !d_out || !d_total || capacity < HMK_EDGE_SHARDS)
+        return fail(ctx, HMK_ERR_BAD_ARG, "hmk_compact_edges_dev: null buffer or capacity < HMK_EDGE_SHARDS");
+    HIPCHK(ctx, launch_compact_edges((const uint64_t *)d_edges, capacity / HMK_EDGE_SHARDS,
+                                     (const unsigned long long *)d_counts, (uint64_t *)d_out, out_capacity,
+                                     (unsigned long long *)d_total, (hipStream_t)stream));
+    return HMK_OK;
+}
+
 int hmk_neighbors_last_plan(hmk_ctx *ctx, hmk_neighbor_stats *stats) {
     if (!ctx || !stats) return fail(ctx, HMK_ERR_BAD_ARG, "null argument");
     std::lock_guard<std::mutex> lock(ctx->mu);

@@ -31,6 +31,9 @@ hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard,
 hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                               bool symmetric, const uint64_t *start, uint32_t *cursor, Nbr *adj, hipStream_t s);
 
+hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
+                                uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);
+
 // LocalAlignmentScorer dense block, register-resident DP (needs |M| <= 127, gap penalties <= 0, len <= lbmax)
 hipError_t launch_local_block(int lbmax, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,
                               uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,

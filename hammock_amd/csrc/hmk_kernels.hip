@@ -650,6 +650,25 @@ k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const
     }
 }
 
+// The HMK_EDGE_SHARDS output segments -> one contiguous block (device to device), so a
+// fixed-size collective can ship a rank's edges without any host round trip.
+__global__ void __launch_bounds__(256)
+k_compact_edges(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
+                uint64_t *__restrict__ out, uint64_t out_capacity, unsigned long long *__restrict__ total) {
+    const uint32_t shard = blockIdx.y;
+    uint64_t base = 0, all = 0;
+    for (uint32_t q = 0; q < HMK_EDGE_SHARDS; q++) {
+        const uint64_t c = min((uint64_t)counts[q], cap_per_shard);
+        if (q < shard) base += c;
+        all += c;
+    }
+    if (blockIdx.x == 0 && shard == 0 && threadIdx.x == 0) *total = all;
+    const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
+    const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256)
+        if (base + k < out_capacity) out[base + k] = seg[k];
+}
+
 // -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------
@@ -727,6 +746,13 @@ hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, con
                               bool symmetric, const uint64_t *start, uint32_t *cursor, Nbr *adj, hipStream_t s) {
     hipLaunchKernelGGL(k_edge_scatter, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, start,
                        cursor, adj, symmetric ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
+                                uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s) {
+    hipLaunchKernelGGL(k_compact_edges, dim3(128, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, out,
+                       out_capacity, total);
     return hipGetLastError();
 }
 

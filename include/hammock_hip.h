@@ -137,6 +137,11 @@ int hmk_neighbors_shifted(hmk_ctx *ctx, int max_shift, int shift_penalty, int th
 int hmk_neighbors_shifted_dev(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold,
                               uint32_t part, uint32_t n_parts, void *d_edges, uint64_t capacity,
                               void *d_counts, void *stream);
+/* Device to device, asynchronous on `stream`: packs the HMK_EDGE_SHARDS segments of a
+ * hmk_neighbors_shifted_dev result into one contiguous block d_out[0 .. *d_total) (at most
+ * out_capacity entries are written) -- the block a fixed-size all-gather ships to the other ranks. */
+int hmk_compact_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t capacity, const void *d_counts,
+                          void *d_out, uint64_t out_capacity, void *d_total, void *stream);
 /* pairs / tiles of the plan the last hmk_neighbors_shifted[_dev] call used */
 int hmk_neighbors_last_plan(hmk_ctx *ctx, hmk_neighbor_stats *stats);
 
