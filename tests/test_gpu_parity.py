@@ -376,3 +376,66 @@ def test_local_block_striped_kernel_vs_oracle(gpu, matrices, coracle, cfg):
     assert np.array_equal(tt, want)
     if lo != hi:
         assert (t != tt.T).any()  # score(a, b) != score(b, a) for some pairs
+
+
+def test_greedy_asymmetric_matrix_end_to_end(gpu, blosum62, coracle):
+    """Asymmetric matrix: the kernel scores the full square and the merge uses directed edges."""
+    rng = np.random.default_rng(21)
+    M = blosum62.copy()
+    M[np.triu_indices(24, 1)] += rng.integers(-2, 3, size=276).astype(np.int32)
+    res, off = synth_peptides(6, 4000, 11, 13)
+    sizes = rng.integers(1, 9, size=4000).astype(np.int32)
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [res[off[k]:off[k + 1]] for k in perm]
+    sizes = sizes[perm]
+    res, off = hammock_amd.pack_sequences(peps)
+    ctx, _, _ = ctx_for(M, res=res, off=off, sizes=sizes)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(M, res, off, sizes, 0, 3, -1, 17, 100, 8)
+    assert st == 0
+    cid, order, stats = ctx.greedy_cluster(3, -1, 17, 100)
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert stats.phase1_stop_index == ostats.phase1_stop_index
+
+
+def test_cli_greedy_random_order_and_label_filter(gpu, blosum62, coracle, tmp_path):
+    """`-R random -S 7 -l lab_a,no_label -p -1 -x 2`: Java shuffle, label filter (counts rebuilt), flags."""
+    import subprocess
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "hammock_amd", "bin", "hammock-hip")
+    res, off = synth_peptides(13, 2500, 12)
+    rng = np.random.default_rng(13)
+    fa = str(tmp_path / "in.fa")
+    with open(fa, "w") as fh:
+        for k in range(2500):
+            s = "".join(hammock_amd.AMINO_ACIDS[int(c)] for c in res[off[k]:off[k + 1]])
+            lab = ["lab_a", "lab_b", None][k % 3]
+            fh.write(f">{k}|{1 + int(rng.integers(0, 9))}|{lab}\n{s}\n" if lab else f">{k}\n{s}\n")
+    out = str(tmp_path / "out")
+    r = subprocess.run([cli, "greedy", "-i", fa, "-d", out, "-R", "random", "-S", "7", "-l", "lab_a,no_label",
+                        "-p", "-1", "-x", "2", "-g", "0x12"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    labels = ["lab_a", "no_label"]
+    seqs = []
+    for s in po.load_unique_sequences_from_fasta(fa):  # filterSequencesForLabels, Hammock.java:1661-1675
+        lm = {l: s.labels_map[l] for l in labels if l in s.labels_map}
+        if lm:
+            seqs.append(po.UniqueSequence(s.get_sequence_string(), lm))
+    initial = list(seqs)
+    maxc = po.java_round(len(seqs) * 0.025)
+    po.sort_sequences(seqs, "random", seed=7)
+    pres, poff = coracle.pack([s.get_sequence_string() for s in seqs])
+    sizes = np.array([s.size() for s in seqs], dtype=np.int32)
+    st, cid, order, _ = coracle.greedy_cluster(blosum62, pres, poff, sizes, 0, 2, -1, 18, maxc, 4)
+    assert st == 0
+    clusters = {}
+    for k, c in enumerate(cid.tolist()):
+        clusters.setdefault(c, []).append(seqs[k])
+    cl_list = [po.Cluster(clusters[c], c) for c in order.tolist()]
+    exp = tmp_path / "exp"
+    exp.mkdir()
+    po.save_cluster_sequences_csv(cl_list, str(exp / "initial_clusters_sequences.tsv"), labels)
+    po.write_cluster_sequences_csv(initial, cl_list, str(exp / "initial_clusters_sequences_original_order.tsv"), labels)
+    po.save_clusters_csv(cl_list, str(exp / "initial_clusters.tsv"), labels)
+    for name in ("initial_clusters_sequences.tsv", "initial_clusters_sequences_original_order.tsv", "initial_clusters.tsv"):
+        with open(os.path.join(out, name), "rb") as a, open(exp / name, "rb") as b:
+            assert a.read() == b.read(), name
