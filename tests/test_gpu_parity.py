@@ -439,3 +439,41 @@ def test_cli_greedy_random_order_and_label_filter(gpu, blosum62, coracle, tmp_pa
     for name in ("initial_clusters_sequences.tsv", "initial_clusters_sequences_original_order.tsv", "initial_clusters.tsv"):
         with open(os.path.join(out, name), "rb") as a, open(exp / name, "rb") as b:
             assert a.read() == b.read(), name
+
+
+def test_greedy_full_size_1e5_vs_oracle(gpu, blosum62, coracle):
+    """BASELINE config 3 end to end: identical cluster membership at 10^5 peptides (with counts, size order)."""
+    n = 100000
+    res, off = synth_peptides(1, n, 12)
+    rng = np.random.default_rng(1)
+    sizes = np.ones(n, dtype=np.int32)
+    sizes[::4] = 1 + rng.integers(0, 64, size=len(sizes[::4]))
+    perm = coracle.sort_order(res, off, sizes, "size")
+    res = np.ascontiguousarray(res.reshape(n, 12)[perm].reshape(-1))
+    sizes = sizes[perm]
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
+    cid, order, stats = ctx.greedy_cluster(3, 0, 20, 2500)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, 3, 0, 20, 2500, 16)
+    assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert stats.n_multi == 2500 and stats.phase1_stop_index == ostats.phase1_stop_index
+
+
+def test_million_peptide_shard_properties(gpu, blosum62, coracle):
+    """BASELINE config 5 size (10^6 x 12), one of 8 row-block shards: pair count, density, sampled oracle parity."""
+    n = 1000000
+    res, off = synth_peptides(1, n, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(3, 0, 20, part=3, n_parts=8, capacity=200_000_000)
+    assert 0.12 < stats.pairs_scored / (n * (n - 1) // 2) < 0.13
+    assert 1.5e-3 < len(edges) / stats.pairs_scored < 4e-3
+    x, m, s = hammock_amd.edge_fields(edges)
+    assert (x < m).all() and (s >= 20).all()
+    pick = np.random.default_rng(0).choice(len(edges), 300000, replace=False)
+    st, want = coracle.score_pairs(blosum62, res, off, m[pick], x[pick], 0, 3, 0)
+    assert st == 0 and np.array_equal(want, s[pick])
+    # rows owned by this shard are complete: all neighbours of 10 of its rows (x = smaller index side)
+    rows = np.unique(x)[:: max(1, len(np.unique(x)) // 10)][:10]
+    for r in rows:
+        st, sc = coracle.score_pairs(blosum62, res, off, np.arange(r + 1, n, dtype=np.uint32),
+                                     np.full(n - r - 1, r, np.uint32), 0, 3, 0)
+        assert int((sc >= 20).sum()) == int((x == r).sum())
