@@ -301,6 +301,50 @@ int ioSelftest(const std::vector<std::string> &args) {
     return 2;
 }
 
+// `hammock-hip api-selftest <known_answers.tsv> <matrix>`: drives the mirrored C++ classes
+// (ShiftedScorer, LocalAlignmentScorer, Cluster, HipGreedySequenceClusterer) the way a unit test of the
+// reference would -- one sequenceScore / cluster call at a time -- and prints the results.
+// Lines: "shifted seq1 seq2 X p" | "local seq1 seq2 open ext" | "greedy thr maxShift penalty maxClusters seq..."
+int apiSelftest(const std::vector<std::string> &args) {
+    if (args.size() < 3) { std::cerr << "usage: hammock-hip api-selftest <cases.tsv> <matrix file> [device]\n"; return 2; }
+    const auto M = FileIOManager::loadScoringMatrix(args[2]);
+    const int device = args.size() > 3 ? javaIntegerDecode(args[3]) : 0;
+    for (const std::string &line : FileIOManager::readLines(args[1])) {
+        const std::vector<std::string> f = FileIOManager::splitChar(line, '\t', true);
+        if (f.empty() || f[0].empty() || f[0][0] == '#') continue;
+        try {
+            if (f[0] == "shifted" && f.size() >= 5) {
+                ShiftedScorer sc(M, javaIntegerDecode(f[4]), javaIntegerDecode(f[3]), device);
+                const AligningScorerResult r = sc.scoreWithShift(std::make_shared<UniqueSequence>(f[1]),
+                                                                 std::make_shared<UniqueSequence>(f[2]));
+                std::cout << "shifted\t" << f[1] << "\t" << f[2] << "\t" << r.getScore() << "\t" << r.getShift() << "\n";
+            } else if (f[0] == "local" && f.size() >= 5) {
+                LocalAlignmentScorer sc(M, javaIntegerDecode(f[3]), javaIntegerDecode(f[4]), device);
+                std::cout << "local\t" << f[1] << "\t" << f[2] << "\t"
+                          << sc.sequenceScore(std::make_shared<UniqueSequence>(f[1]), std::make_shared<UniqueSequence>(f[2])) << "\n";
+            } else if (f[0] == "greedy" && f.size() >= 6) {
+                auto scorer = std::make_shared<ShiftedScorer>(M, javaIntegerDecode(f[3]), javaIntegerDecode(f[2]), device);
+                HipGreedySequenceClusterer clusterer(scorer, javaIntegerDecode(f[1]), javaIntegerDecode(f[4]));
+                std::vector<UniqueSequencePtr> seqs;
+                for (size_t k = 5; k < f.size(); k++) seqs.push_back(std::make_shared<UniqueSequence>(f[k]));
+                std::ostringstream os;
+                os << "greedy";
+                for (auto &cl : clusterer.cluster(seqs)) {
+                    os << "\t" << cl->getId() << ":";
+                    for (size_t k = 0; k < cl->getSequences().size(); k++)
+                        os << (k ? "," : "") << cl->getSequences()[k]->getSequenceString();
+                }
+                std::cout << os.str() << "\n";
+            }
+        } catch (const DataException &e) {
+            std::cout << f[0] << "\tDataException\t" << e.what() << "\n";
+        } catch (const NullPointerException &e) {
+            std::cout << f[0] << "\tNullPointerException\tcase " << e.crashCase << " index " << e.crashIndex << "\n";
+        }
+    }
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -309,6 +353,7 @@ int main(int argc, char **argv) {
     try {
         if (args[0] == "greedy") return runGreedy(args);
         if (args[0] == "io-selftest") return ioSelftest(args);
+        if (args[0] == "api-selftest") return apiSelftest(args);
         std::cerr << "hammock-hip implements Hammock's `greedy` mode only (modes full, clinkage, cluster are outside "
                      "the scope of the MI355X hot path); got mode \"" << args[0] << "\"\n";
         return 2;

@@ -477,3 +477,33 @@ def test_million_peptide_shard_properties(gpu, blosum62, coracle):
         st, sc = coracle.score_pairs(blosum62, res, off, np.arange(r + 1, n, dtype=np.uint32),
                                      np.full(n - r - 1, r, np.uint32), 0, 3, 0)
         assert int((sc >= 20).sum()) == int((x == r).sum())
+
+
+def test_cpp_host_classes_known_answers(gpu, known_answers, blosum62, coracle, tmp_path):
+    """The C++ mirror (hammock_amd/host/hammock_host.hpp) used the way a unit test of the reference would:
+    ShiftedScorer.scoreWithShift, LocalAlignmentScorer.sequenceScore, HipGreedySequenceClusterer.cluster."""
+    import subprocess
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "hammock_amd", "bin", "hammock-hip")
+    cases, expect = [], []
+    for row in known_answers["shifted_blosum62"]:
+        cases.append(f"shifted\t{row['seq1']}\t{row['seq2']}\t{row['X']}\t{row['p']}")
+        st, score, shift = coracle.shifted_score(blosum62, row["seq1"], row["seq2"], row["X"], row["p"])
+        assert score == row["score"]
+        expect.append(f"shifted\t{row['seq1']}\t{row['seq2']}\t{score}\t{shift}")
+    for row in known_answers["local_blosum62_open-5_ext-1"]:
+        cases.append(f"local\t{row['seq1']}\t{row['seq2']}\t-5\t-1")
+        expect.append(f"local\t{row['seq1']}\t{row['seq2']}\t{row['score']}")
+    cases.append("shifted\tACDEFGH\tCDEFGHIKLM\t7\t0")           # ShiftedScorer.java:59-62
+    expect.append("shifted\tDataException\tShift too big: 6 is maximum, but 7 found")
+    three = ["WWWWWWWW", "WWWWWWWF", "CCCCCCCC"]
+    cases.append("greedy\t30\t2\t0\t1\t" + "\t".join(three))
+    expect.append("greedy\t0:WWWWWWWW,WWWWWWWF\t2:CCCCCCCC")
+    cases.append("greedy\t30\t2\t0\t3\t" + "\t".join(three))    # the reference's NPE, LimitedGreedy...java:108
+    expect.append("greedy\tNullPointerException\tcase 3 index 1")
+    f = tmp_path / "cases.tsv"
+    f.write_text("\n".join(cases) + "\n")
+    r = subprocess.run([cli, "api-selftest", str(f), os.path.join(ROOT, "hammock_amd", "matrices", "blosum62.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.splitlines() == expect
