@@ -216,6 +216,22 @@ class Context:
                 self._raise(st)
             return buf[:n_edges.value].copy(), stats
 
+    def neighbors_local(self, gap_open, gap_extend, threshold, part=0, n_parts=1, capacity=None):
+        """LocalAlignmentScorer, all ordered pairs >= threshold -> (edges uint64[n_edges], NeighborStats)"""
+        stats = N.NeighborStats()
+        n_edges = C.c_uint64(0)
+        cap = int(capacity) if capacity is not None else 1 << 20
+        while True:
+            buf = np.empty(max(cap, 1), dtype=np.uint64)
+            st = N.lib.hmk_neighbors_local(self._h, int(gap_open), int(gap_extend), int(threshold), part, n_parts,
+                                           _ptr(buf, C.c_uint64), cap, C.byref(n_edges), C.byref(stats))
+            if st == N.HMK_ERR_CAPACITY and capacity is None:
+                cap = int(n_edges.value)
+                continue
+            if st:
+                self._raise(st)
+            return buf[:n_edges.value].copy(), stats
+
     def neighbors_shifted_dev(self, max_shift, shift_penalty, threshold, part, n_parts, d_edges_ptr, capacity,
                               d_counts_ptr, stream=0):
         st = N.lib.hmk_neighbors_shifted_dev(self._h, int(max_shift), int(shift_penalty), int(threshold), part, n_parts,

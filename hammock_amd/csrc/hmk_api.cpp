@@ -47,6 +47,17 @@ struct Plan {
     hmk_neighbor_stats stats{};
 };
 
+struct PlanLocal {
+    bool valid = false;
+    uint32_t part = 0, n_parts = 1;
+    uint8_t *d_res_sorted = nullptr;
+    uint32_t *d_perm = nullptr;
+    TileClass *d_classes = nullptr;
+    Tile *d_tiles = nullptr;
+    uint32_t n_tiles = 0;
+    uint64_t pairs = 0;
+};
+
 }  // namespace
 
 struct hmk_ctx {
@@ -69,6 +80,7 @@ struct hmk_ctx {
     int32_t *d_M = nullptr;
 
     Plan plan;
+    PlanLocal plan_local;
     uint64_t *d_edges = nullptr;  // internal buffer of the host-buffer entry points
     uint64_t d_edges_cap = 0;
     unsigned long long *d_counts = nullptr;
@@ -332,8 +344,9 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
 
 // Runs the neighbour pass into the context's own device buffer, growing it until
 // every segment fits, and returns the per-segment counts.
-int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, uint64_t want_cap,
-                       unsigned long long counts[HMK_EDGE_SHARDS], double *kernel_ms) {
+template <typename LaunchFn>
+int neighbors_grow(hmk_ctx *ctx, uint64_t want_cap, unsigned long long counts[HMK_EDGE_SHARDS], double *kernel_ms,
+                   LaunchFn launch) {
     int st = need_device(ctx);
     if (st) return st;
     if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
@@ -351,7 +364,7 @@ int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint3
             ctx->d_edges_cap = cap;
         }
         HIPCHK(ctx, hipEventRecord(e0, nullptr));
-        st = neighbors_dev_locked(ctx, X, p, thr, part, n_parts, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, nullptr);
+        st = launch(ctx->d_edges, ctx->d_edges_cap, ctx->d_counts);
         if (st) break;
         HIPCHK(ctx, hipEventRecord(e1, nullptr));
         HIPCHK(ctx, hipEventSynchronize(e1));
@@ -372,6 +385,119 @@ int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint3
     (void)hipEventDestroy(e1);
     if (st == HMK_ERR_CAPACITY) return fail(ctx, st, "internal edge buffer kept overflowing");
     return st;
+}
+
+int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, uint64_t want_cap,
+                       unsigned long long counts[HMK_EDGE_SHARDS], double *kernel_ms) {
+    return neighbors_grow(ctx, want_cap, counts, kernel_ms, [&](uint64_t *d_edges, uint64_t cap, unsigned long long *d_counts) {
+        return neighbors_dev_locked(ctx, X, p, thr, part, n_parts, d_edges, cap, d_counts, nullptr);
+    });
+}
+
+// ---- LocalAlignmentScorer neighbour pass: plan (tiles of ordered length classes) + launch ----------------
+void free_plan_local(PlanLocal &pl) {
+    if (pl.d_res_sorted) (void)hipFree(pl.d_res_sorted);
+    if (pl.d_perm) (void)hipFree(pl.d_perm);
+    if (pl.d_classes) (void)hipFree(pl.d_classes);
+    if (pl.d_tiles) (void)hipFree(pl.d_tiles);
+    pl = PlanLocal();
+}
+
+int build_plan_local(hmk_ctx *ctx, uint32_t part, uint32_t n_parts) {
+    PlanLocal &pl = ctx->plan_local;
+    if (pl.valid && pl.part == part && pl.n_parts == n_parts) return HMK_OK;
+    free_plan_local(pl);
+    const uint32_t n = ctx->n;
+    if (n == 0) return fail(ctx, HMK_ERR_NO_SEQUENCES, "no sequences set (hmk_set_sequences)");
+    if (n_parts == 0 || part >= n_parts) return fail(ctx, HMK_ERR_BAD_ARG, "part must be < n_parts");
+    uint32_t bucket[HMK_MAX_LEN + 2] = {0};
+    for (uint32_t k = 0; k < n; k++) bucket[ctx->len[k] + 1]++;
+    for (int l = 0; l <= HMK_MAX_LEN; l++) bucket[l + 1] += bucket[l];
+    std::vector<uint32_t> perm(n);
+    {
+        uint32_t fill[HMK_MAX_LEN + 2];
+        std::memcpy(fill, bucket, sizeof(fill));
+        for (uint32_t k = 0; k < n; k++) perm[fill[ctx->len[k]]++] = k;
+    }
+    std::vector<TileClass> classes;
+    std::vector<Tile> tiles;
+    const uint32_t R = 16, COLS = 16384;
+    uint64_t row_chunk_counter = 0;
+    pl.pairs = 0;
+    for (int la = 1; la <= HMK_MAX_LEN; la++) {          // rows = seq1 (lines)
+        const uint32_t rb = bucket[la], re = bucket[la + 1];
+        if (rb == re) continue;
+        for (int lb = 1; lb <= HMK_MAX_LEN; lb++) {      // columns = seq2
+            const uint32_t cb = bucket[lb], ce = bucket[lb + 1];
+            if (cb == ce) continue;
+            TileClass tc{};
+            tc.la = (uint8_t)la;
+            tc.lb = (uint8_t)lb;
+            const uint32_t cls = (uint32_t)classes.size();
+            classes.push_back(tc);
+            for (uint32_t r0 = rb; r0 < re; r0 += R) {
+                if ((row_chunk_counter++ % n_parts) != part) continue;
+                const uint32_t nr = std::min(R, re - r0);
+                for (uint32_t c0 = cb; c0 < ce; c0 += COLS) {
+                    Tile t{};
+                    t.row0 = r0; t.nrows = nr; t.col0 = c0; t.ncols = std::min(COLS, ce - c0); t.cls = cls;
+                    const bool overlap = la == lb && c0 < r0 + nr && c0 + t.ncols > r0;
+                    t.diag = overlap ? 2u : 0u;
+                    uint64_t pairs = (uint64_t)nr * t.ncols;
+                    if (overlap)
+                        for (uint32_t r = r0; r < r0 + nr; r++)
+                            if (r >= c0 && r < c0 + t.ncols) pairs--;
+                    if (pairs == 0) continue;
+                    pl.pairs += pairs;
+                    tiles.push_back(t);
+                }
+            }
+        }
+    }
+    pl.n_tiles = (uint32_t)tiles.size();
+    std::vector<uint8_t> res_sorted((size_t)n * 32, 0);
+    for (uint32_t s = 0; s < n; s++) std::memcpy(&res_sorted[(size_t)s * 32], &ctx->res[ctx->off[perm[s]]], ctx->len[perm[s]]);
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_res_sorted, res_sorted.size()));
+    HIPCHK(ctx, hipMemcpy(pl.d_res_sorted, res_sorted.data(), res_sorted.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_perm, (size_t)n * 4));
+    HIPCHK(ctx, hipMemcpy(pl.d_perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_classes, std::max<size_t>(1, classes.size()) * sizeof(TileClass)));
+    if (!classes.empty())
+        HIPCHK(ctx, hipMemcpy(pl.d_classes, classes.data(), classes.size() * sizeof(TileClass), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&pl.d_tiles, std::max<size_t>(1, tiles.size()) * sizeof(Tile)));
+    if (!tiles.empty())
+        HIPCHK(ctx, hipMemcpy(pl.d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
+    pl.part = part; pl.n_parts = n_parts;
+    pl.valid = true;
+    return HMK_OK;
+}
+
+int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int thr, uint32_t part, uint32_t n_parts,
+                               uint64_t *d_edges, uint64_t capacity, unsigned long long *d_counts, hipStream_t stream) {
+    int st = need_device(ctx);
+    if (st) return st;
+    if (gap_open > 0 || gap_extend > 0 || ctx->min_m < -127 || ctx->max_m > 127)
+        return fail(ctx, HMK_ERR_BAD_ARG,
+                    "hmk_neighbors_local needs gap penalties <= 0 and matrix entries in [-127, 127] "
+                    "(use hmk_score_block_local, which has a literal fallback, otherwise)");
+    st = build_plan_local(ctx, part, n_parts);
+    if (st) return st;
+    PlanLocal &pl = ctx->plan_local;
+    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), stream));
+    NeighborParams P{};
+    P.res_sorted = pl.d_res_sorted;
+    P.perm = pl.d_perm;
+    P.classes = pl.d_classes;
+    P.tiles = pl.d_tiles;
+    P.edges = d_edges;
+    P.counts = d_counts;
+    P.cap_per_shard = capacity / HMK_EDGE_SHARDS;
+    P.n_tiles = pl.n_tiles;
+    P.lpad = 32;
+    P.symmetric = 0;
+    P.row_is_m = 1;
+    HIPCHK(ctx, launch_neighbors_local(ctx->max_len, P, 0, pl.n_tiles, ctx->d_M, gap_open, gap_extend, thr, stream));
+    return HMK_OK;
 }
 
 // HIP-event bracket around the probe kernels (hmk_last_kernel_ms)
@@ -543,6 +669,7 @@ void hmk_destroy(hmk_ctx *ctx) {
     if (ctx->has_device) {
         (void)hipSetDevice(ctx->device);
         free_plan(ctx->plan);
+        free_plan_local(ctx->plan_local);
         if (ctx->d_res32) (void)hipFree(ctx->d_res32);
         if (ctx->d_len) (void)hipFree(ctx->d_len);
         if (ctx->d_M) (void)hipFree(ctx->d_M);
@@ -582,6 +709,7 @@ int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *off
         int st = need_device(ctx);
         if (st) return st;
         free_plan(ctx->plan);
+        free_plan_local(ctx->plan_local);
         if (ctx->d_res32) (void)hipFree(ctx->d_res32);
         if (ctx->d_len) (void)hipFree(ctx->d_len);
         ctx->d_res32 = nullptr;
@@ -685,6 +813,39 @@ int hmk_neighbors_shifted(hmk_ctx *ctx, int max_shift, int shift_penalty, int th
     if (stats) {
         *stats = ctx->plan.stats;
         stats->n_edges = total;
+        stats->kernel_ms = ms;
+    }
+    if (total > capacity) return fail(ctx, HMK_ERR_CAPACITY, "edge buffer too small: " + std::to_string(total) + " needed");
+    if (total && !edges) return fail(ctx, HMK_ERR_BAD_ARG, "null edge buffer");
+    const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
+    uint64_t o = 0;
+    for (int s = 0; s < HMK_EDGE_SHARDS; s++) {
+        if (counts[s])
+            HIPCHK(ctx, hipMemcpy(edges + o, ctx->d_edges + (uint64_t)s * seg, counts[s] * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        o += counts[s];
+    }
+    return HMK_OK;
+}
+
+int hmk_neighbors_local(hmk_ctx *ctx, int gap_open, int gap_extend, int threshold, uint32_t part, uint32_t n_parts,
+                        uint64_t *edges, uint64_t capacity, uint64_t *n_edges, hmk_neighbor_stats *stats) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!n_edges) return fail(ctx, HMK_ERR_BAD_ARG, "n_edges must not be null");
+    unsigned long long counts[HMK_EDGE_SHARDS];
+    double ms = 0;
+    int st = neighbors_grow(ctx, capacity, counts, &ms, [&](uint64_t *d_edges, uint64_t cap, unsigned long long *d_counts) {
+        return neighbors_local_dev_locked(ctx, gap_open, gap_extend, threshold, part, n_parts, d_edges, cap, d_counts, nullptr);
+    });
+    if (st) return st;
+    uint64_t total = 0;
+    for (int s = 0; s < HMK_EDGE_SHARDS; s++) total += counts[s];
+    *n_edges = total;
+    if (stats) {
+        *stats = hmk_neighbor_stats{};
+        stats->n_edges = total;
+        stats->pairs_scored = ctx->plan_local.pairs;
+        stats->n_tiles = ctx->plan_local.n_tiles;
         stats->kernel_ms = ms;
     }
     if (total > capacity) return fail(ctx, HMK_ERR_CAPACITY, "edge buffer too small: " + std::to_string(total) + " needed");

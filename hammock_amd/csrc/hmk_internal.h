@@ -51,7 +51,7 @@ struct NeighborParams {
     uint32_t n_tiles;
     uint32_t lpad;               // 16 or 32
     uint32_t symmetric;          // 1: emit (min, max) caller indices
-    uint32_t pad;
+    uint32_t row_is_m;           // 1: the tile's ROW is seq1 (= m of the edge), LocalAlignmentScorer tiles
 };
 
 // one directed neighbour: sequenceScore(seq1 = m, seq2 = x) = s for the row x it is stored under

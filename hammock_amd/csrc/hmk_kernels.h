@@ -25,6 +25,10 @@ hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, co
                         const uint32_t *pi, const uint32_t *pj, uint64_t n_pairs, uint32_t r0, uint32_t c0,
                         uint32_t width, int a, int b, int32_t *out, int32_t *out_shift, hipStream_t s);
 
+// LocalAlignmentScorer all ordered pairs, thresholded (tiles of one (row length, column length) class, lpad 32)
+hipError_t launch_neighbors_local(int lbmax, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
+                                  const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s);
+
 // edge segments -> CSR (start[n + 1], adj[]) on the device: deg and cursor are zeroed uint32[n] scratch
 hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
                                   bool symmetric, uint32_t *deg, uint64_t *start, hipStream_t s);

@@ -201,7 +201,7 @@ __device__ __forceinline__ void flush_stage(const uint32_t *stage, uint32_t cnt,
             score = (int)mx - g;
         }
         uint32_t x = P.perm[T.row0 + r], m = P.perm[col];
-        if (P.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
+        if (P.row_is_m || (P.symmetric && x > m)) { const uint32_t t = x; x = m; m = t; }
         const unsigned long long pos = base + k;
         if (pos < P.cap_per_shard)
             P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
@@ -596,6 +596,137 @@ k_local_block(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len
 }
 
 // -----------------------------------------------------------------------------
+// k_neighbors_local: all ORDERED pairs with LocalAlignmentScorer, thresholded -> edge list
+// -----------------------------------------------------------------------------
+// Same striped register DP as k_local_block, on the length-bucketed tiles of the neighbour plan:
+// one (row length, column length) class per tile, so no padding columns and a wave-uniform column
+// bound.  Rows are seq1 (lines), columns seq2; the edge (x = column, m = row) carries
+// sequenceScore(seq1 = m, seq2 = x) like every other edge (row_is_m = 1 swaps them at flush).
+template <int LBMAX>
+__global__ void __launch_bounds__(256)
+k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_t *__restrict__ Mg, int gap_open,
+                  int gap_extend, int threshold) {
+    constexpr int R = 16;
+    constexpr int QROW = 25 * 8 * 4;
+    constexpr int STAGE_CAP = 128;
+    constexpr int REC_DW = 3;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[R * QROW + 576 + R * 32 + 4 * STAGE_CAP * REC_DW * 4];
+    int8_t *m8 = reinterpret_cast<int8_t *>(smem + R * QROW);
+    uint8_t *rowres = smem + R * QROW + 576;
+    uint32_t *stage_all = reinterpret_cast<uint32_t *>(smem + R * QROW + 576 + R * 32);
+    const Tile T = P.tiles[tile_base + blockIdx.x];
+    const TileClass *Cp = P.classes + T.cls;
+    const int la = Cp->la, lb = Cp->lb;   // la: row (seq1) length, lb: column (seq2) length
+    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const int tid = threadIdx.x;
+    uint32_t *stage = stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+
+    for (int e = tid; e < 576; e += 256) m8[e] = (int8_t)Mg[e];
+    for (int e = tid; e < R * 32; e += 256) {
+        const uint32_t r = (uint32_t)e >> 5, k = e & 31;
+        rowres[e] = (r < T.nrows && k < P.lpad) ? P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k] : 0;
+    }
+    __syncthreads();
+    for (int e = tid; e < R * 25 * 8; e += 256) {
+        const int r = e / 200, rem = e - r * 200, c = rem >> 3, iq = rem & 7;
+        uint32_t dw = 0;
+        for (int k = 0; k < 4; k++) {
+            const int i = iq * 4 + k;
+            int v = -128;
+            if ((uint32_t)r < T.nrows && i < la && c < 24) v = m8[rowres[r * 32 + i] * 24 + c];
+            dw |= ((uint32_t)v & 0xFFu) << (8 * k);
+        }
+        reinterpret_cast<uint32_t *>(smem)[e] = dw;
+    }
+    __syncthreads();
+
+    const uint32_t q_addr = lds_addr(smem);
+    const uint32_t col_end = T.col0 + T.ncols;
+    const int strips = (la + 3) >> 2;
+    uint32_t cnt = 0;
+    for (uint32_t c0 = T.col0; c0 < col_end; c0 += 256) {
+        const uint32_t col = c0 + tid;
+        const bool col_ok = col < col_end;
+        uint32_t boff[LBMAX];
+        {
+            uint32_t words[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) words[q] = 0;
+            if (col_ok) {
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(P.res_sorted + (size_t)col * P.lpad);
+                const u32x4 v0 = src[0];
+                words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+                if (LBMAX > 16) {
+                    const u32x4 v1 = src[1];
+                    words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < LBMAX; j++) {
+                const uint32_t c = (col_ok && j < lb) ? ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu) : 24u;
+                boff[j] = c * 32u;
+            }
+        }
+        for (uint32_t r = 0; r < T.nrows; r++) {
+            int H[LBMAX], U[LBMAX];
+#pragma unroll
+            for (int j = 0; j < LBMAX; j++) { H[j] = 0; U[j] = gap_open; }
+            int gmax = 0;
+            for (int st = 0; st < strips; st++) {
+                const uint32_t strip_addr = q_addr + r * QROW + (uint32_t)st * 4u;
+                int hd[4], lc[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { hd[k] = 0; lc[k] = gap_open; }
+#pragma unroll
+                for (int j = 0; j < LBMAX; j++) {
+                    if (j < lb) {
+                        const uint32_t q = lds_read<uint32_t>(strip_addr + boff[j]);
+                        int up = U[j];
+                        int habove = H[j];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int sc = (int)(int8_t)(q >> (8 * k));
+                            const int diag = hd[k] + sc;
+                            const int left = lc[k];
+                            const int mx = max(diag, max(up, left));
+                            const bool neg = mx < 0;
+                            const bool d_eq = mx == diag, u_eq = mx == up;
+                            const int h = max(mx, 0);
+                            const bool is_up = u_eq && !d_eq && !neg;
+                            const bool is_left = !(u_eq || d_eq || neg);
+                            gmax = max(gmax, h);
+                            hd[k] = habove;
+                            habove = h;
+                            up = h + (is_up ? gap_extend : gap_open);
+                            lc[k] = h + (is_left ? gap_extend : gap_open);
+                        }
+                        H[j] = habove;
+                        U[j] = up;
+                    }
+                }
+            }
+            bool keep = col_ok && gmax >= threshold;
+            if (T.diag) keep = keep && col != T.row0 + r;   // a sequence is never paired with itself
+            const uint64_t mask = __ballot(keep);
+            if (mask != 0) {
+                if (cnt > (uint32_t)(STAGE_CAP - 64)) {
+                    flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+                    cnt = 0;
+                }
+                if (keep) {
+                    uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                    rec[0] = col;
+                    rec[1] = r;
+                    rec[2] = (uint32_t)gmax;
+                }
+                cnt += (uint32_t)__popcll(mask);
+            }
+        }
+    }
+    flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+}
+
+// -----------------------------------------------------------------------------
 // edge list -> CSR adjacency on the device (feeds the host greedy merge)
 // -----------------------------------------------------------------------------
 // The neighbour kernel leaves HMK_EDGE_SHARDS segments of packed edges.  Three small
@@ -731,6 +862,18 @@ hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, 
     const size_t lds = 2304 + 256 * SEQ_STRIDE_DW * 4 + 16 * 8 * 4 + 4 * 128 * 3 * 4;
     hipLaunchKernelGGL(k_neighbors_direct, dim3(n_tiles), dim3(256), lds, s, P, tile_base, d_matrix, max_shift,
                        shift_penalty, threshold);
+    return hipGetLastError();
+}
+
+hipError_t launch_neighbors_local(int lbmax, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
+                                  const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    if (lbmax <= 12)
+        hipLaunchKernelGGL(k_neighbors_local<12>, dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, gap_open, gap_extend, threshold);
+    else if (lbmax <= 20)
+        hipLaunchKernelGGL(k_neighbors_local<20>, dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, gap_open, gap_extend, threshold);
+    else
+        hipLaunchKernelGGL(k_neighbors_local<32>, dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, gap_open, gap_extend, threshold);
     return hipGetLastError();
 }
 

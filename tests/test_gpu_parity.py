@@ -507,3 +507,28 @@ def test_cpp_host_classes_known_answers(gpu, known_answers, blosum62, coracle, t
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert r.stdout.splitlines() == expect
+
+
+@pytest.mark.parametrize("cfg", [("blosum62", 7, 20, -5, -1, 22), ("blosum62", 12, 12, -5, -1, 25),
+                                 ("pam250", 5, 32, -3, -3, 30), ("blosum62", 9, 11, 0, 0, 26)])
+def test_neighbors_local_vs_oracle(gpu, matrices, coracle, cfg):
+    """LocalAlignmentScorer over ALL ordered pairs, thresholded: exact edge set (both orders, since
+    score(a, b) != score(b, a) in general) against the oracle."""
+    mat, lo, hi, go, ge, thr = cfg
+    M = matrices[mat]
+    res, off = synth_peptides(4, 1200, lo, hi)
+    ctx, _, _ = ctx_for(M, res=res, off=off)
+    edges, stats = ctx.neighbors_local(go, ge, thr)
+    n = 1200
+    assert stats.pairs_scored == n * (n - 1)
+    idx = np.arange(n, dtype=np.uint32)
+    st, sc = coracle.score_block(M, res, off, idx, idx, 1, go, ge)   # [m (seq1), x (seq2)]
+    mm, xx = np.meshgrid(idx, idx, indexing="ij")
+    keep = (sc >= thr) & (mm != xx)
+    want = np.sort(hammock_amd.pack_edges(xx[keep], mm[keep], sc[keep]))
+    assert np.array_equal(np.sort(edges), want), cfg
+    # sharding partitions the edge set
+    parts = [ctx.neighbors_local(go, ge, thr, part=k, n_parts=3)[0] for k in range(3)]
+    assert np.array_equal(np.sort(np.concatenate(parts)), want)
+    with pytest.raises(ValueError):
+        ctx.neighbors_local(1, 0, thr)   # positive gap penalty: outside the striped kernel's contract
