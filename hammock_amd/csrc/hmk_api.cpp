@@ -344,6 +344,12 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
 
 // Runs the neighbour pass into the context's own device buffer, growing it until
 // every segment fits, and returns the per-segment counts.
+// the tagged-max SW kernels carry 4 * value + direction in int8 table bytes
+bool local_enc(const hmk_ctx *ctx, int gap_open, int gap_extend) {
+    return ctx->min_m >= -31 && ctx->max_m <= 31 && gap_open >= -31 && gap_extend >= -31 && gap_open <= 0 &&
+           gap_extend <= 0 && getenv("HMK_LOCAL_PLAIN") == nullptr;
+}
+
 template <typename LaunchFn>
 int neighbors_grow(hmk_ctx *ctx, uint64_t want_cap, unsigned long long counts[HMK_EDGE_SHARDS], double *kernel_ms,
                    LaunchFn launch) {
@@ -496,7 +502,7 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
     P.lpad = 32;
     P.symmetric = 0;
     P.row_is_m = 1;
-    HIPCHK(ctx, launch_neighbors_local(ctx->max_len, P, 0, pl.n_tiles, ctx->d_M, gap_open, gap_extend, thr, stream));
+    HIPCHK(ctx, launch_neighbors_local(ctx->max_len, local_enc(ctx, gap_open, gap_extend), P, 0, pl.n_tiles, ctx->d_M, gap_open, gap_extend, thr, stream));
     return HMK_OK;
 }
 
@@ -591,7 +597,7 @@ int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0,
     const bool fast_local = scorer == 1 && a <= 0 && b <= 0 && ctx->min_m >= -127 && ctx->max_m <= 127 &&
                             getenv("HMK_LOCAL_LITERAL") == nullptr;
     if (fast_local)
-        e = launch_local_block(ctx->max_len, ctx->d_res32, ctx->d_len, ctx->d_M, r0, r1, c0, c1, a, b, d_out, nullptr);
+        e = launch_local_block(ctx->max_len, local_enc(ctx, a, b), ctx->d_res32, ctx->d_len, ctx->d_M, r0, r1, c0, c1, a, b, d_out, nullptr);
     else
         e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, nullptr, nullptr, n_pairs, r0, c0, c1 - c0, a, b,
                          d_out, nullptr, nullptr);

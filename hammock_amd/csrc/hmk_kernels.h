@@ -26,7 +26,7 @@ hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, co
                         uint32_t width, int a, int b, int32_t *out, int32_t *out_shift, hipStream_t s);
 
 // LocalAlignmentScorer all ordered pairs, thresholded (tiles of one (row length, column length) class, lpad 32)
-hipError_t launch_neighbors_local(int lbmax, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
+hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
                                   const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s);
 
 // edge segments -> CSR (start[n + 1], adj[]) on the device: deg and cursor are zeroed uint32[n] scratch
@@ -39,7 +39,8 @@ hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, c
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);
 
 // LocalAlignmentScorer dense block, register-resident DP (needs |M| <= 127, gap penalties <= 0, len <= lbmax)
-hipError_t launch_local_block(int lbmax, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,
+// enc: the tagged-max DP (needs |M| <= 31 and -31 <= gap penalties <= 0)
+hipError_t launch_local_block(int lbmax, bool enc, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,
                               uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
                               hipStream_t s);
 

@@ -470,6 +470,125 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
 }
 
 // -----------------------------------------------------------------------------
+// LocalAlignmentScorer DP core shared by k_local_block and k_neighbors_local
+// -----------------------------------------------------------------------------
+// One row sequence (wave-uniform, as a query profile in LDS at row_q_addr: Q[c][iq] = four int8 per
+// dword for lines 4 iq .. 4 iq + 3) against this lane's column sequence (boff[j] = residue * 32).
+//
+// ENC = false: the plain form -- H, U = H + (Dir == UP ? ext : open), lcand = H + (Dir == LEFT ? ext : open),
+//   direction flags from compares (LocalAlignmentScorer.java:43-81).
+// ENC = true ("tagged max"): every candidate is carried as 4 * value + tag, tag 3 = DIAGONAL, 2 = UP,
+//   1 = LEFT, so ONE max3 yields the cell value AND the reference's direction priority on ties
+//   (DIAGONAL > UP > LEFT, :73-81); max(.., 0) gives NOWHERE (tag 0) for mx < 0 (:63-65).  The gap
+//   penalty of the next cell is a byte-table lookup by tag (v_perm_b32), not compares:
+//       U' = he + PU[tag],  PU[tag] = 4 * (tag == UP   ? ext : open) + 2 - tag
+//       L' = he + PL[tag],  PL[tag] = 4 * (tag == LEFT ? ext : open) + 1 - tag
+//   Profile bytes hold 4 * score.  Needs |M| <= 31 and -31 <= penalties <= 0.
+template <int LBMAX, bool ENC>
+__device__ __forceinline__ int sw_row(uint32_t row_q_addr, int strips, int ncols, const uint32_t (&boff)[LBMAX],
+                                      int gap_open, int gap_extend) {
+    if (ENC) {
+        auto b = [](int v) { return (uint32_t)v & 0xFFu; };
+        const uint32_t PU = b(4 * gap_open + 2) | (b(4 * gap_open + 1) << 8) | (b(4 * gap_extend) << 16) | (b(4 * gap_open - 1) << 24);
+        const uint32_t PL = b(4 * gap_open + 1) | (b(4 * gap_extend) << 8) | (b(4 * gap_open - 1) << 16) | (b(4 * gap_open - 2) << 24);
+        int H[LBMAX], U[LBMAX];
+#pragma unroll
+        for (int j = 0; j < LBMAX; j++) { H[j] = 3; U[j] = 4 * gap_open + 2; }   // line 0: H = 0, Dir = LEFT (:97-100)
+        int gm = 0;
+        for (int st = 0; st < strips; st++) {
+            const uint32_t strip_addr = row_q_addr + (uint32_t)st * 4u;
+            int hd[4], lc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hd[k] = 3; lc[k] = 4 * gap_open + 1; }  // column 0: H = 0, Dir = UP (:93-96)
+            uint32_t qnext = lds_read<uint32_t>(strip_addr + boff[0]);
+#pragma unroll
+            for (int j = 0; j < LBMAX; j++) {
+                if (j < ncols) {
+                    const uint32_t q = qnext;   // profile dword of column j, fetched one column ahead
+                    if (j + 1 < LBMAX) qnext = lds_read<uint32_t>(strip_addr + boff[j + 1]);
+                    int up = U[j];
+                    int habove = H[j];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int diag = hd[k] + (int)(int8_t)(q >> (8 * k));        // 4 * (H[l-1][c-1] + M) + 3   (:59)
+                        const int he = max(max(diag, max(up, lc[k])), 0);            // :61-67 with the direction in the low bits
+                        gm = max(gm, he);                                            // :68-72
+                        const uint32_t tag = (uint32_t)he & 3u;
+                        const int pu = (int)(int8_t)__builtin_amdgcn_perm(0u, PU, tag);
+                        const int pl = (int)(int8_t)__builtin_amdgcn_perm(0u, PL, tag);
+                        hd[k] = habove;
+                        habove = he | 3;
+                        up = he + pu;                                                // :43-48,:57 for the cell below
+                        lc[k] = he + pl;                                             // :50-55,:58 for the cell to the right
+                    }
+                    H[j] = habove;
+                    U[j] = up;
+                }
+            }
+        }
+        return gm >> 2;
+    } else {
+        int H[LBMAX], U[LBMAX];
+#pragma unroll
+        for (int j = 0; j < LBMAX; j++) { H[j] = 0; U[j] = gap_open; }   // line 0: H = 0, Dir = LEFT (:97-100)
+        int gmax = 0;
+        for (int st = 0; st < strips; st++) {
+            const uint32_t strip_addr = row_q_addr + (uint32_t)st * 4u;
+            int hd[4], lc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hd[k] = 0; lc[k] = gap_open; }  // column 0: H = 0, Dir = UP (:93-96)
+#pragma unroll
+            for (int j = 0; j < LBMAX; j++) {
+                if (j < ncols) {
+                    const uint32_t q = lds_read<uint32_t>(strip_addr + boff[j]);
+                    int up = U[j];
+                    int habove = H[j];          // H[line-1][j]: the next column's diagonal for line k = 0
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int sc = (int)(int8_t)(q >> (8 * k));
+                        const int diag = hd[k] + sc;                      // :59
+                        const int left = lc[k];
+                        const int mx = max(diag, max(up, left));         // :61
+                        const bool neg = mx < 0;                          // :63
+                        const bool d_eq = mx == diag, u_eq = mx == up;
+                        const int h = max(mx, 0);                         // :64,:67
+                        const bool is_up = u_eq && !d_eq && !neg;         // :76-81
+                        const bool is_left = !(u_eq || d_eq || neg);      // :73-81
+                        gmax = max(gmax, h);                              // :68-72
+                        hd[k] = habove;
+                        habove = h;
+                        up = h + (is_up ? gap_extend : gap_open);
+                        lc[k] = h + (is_left ? gap_extend : gap_open);
+                    }
+                    H[j] = habove;
+                    U[j] = up;
+                }
+            }
+        }
+        return gmax;
+    }
+}
+
+// query profiles of R rows into LDS: entry (r, c, iq) = four int8 (score * scale) for lines 4 iq .. 4 iq + 3;
+// -128 for the pad residue (c == 24) and for lines beyond the row's length
+template <int R>
+__device__ __forceinline__ void build_profiles(uint32_t *q, const int8_t *m8, const uint8_t *rowres, const int *row_len,
+                                               uint32_t nrows, int scale, int tid) {
+    for (int e = tid; e < R * 25 * 8; e += 256) {
+        const int r = e / 200, rem = e - r * 200, c = rem >> 3, iq = rem & 7;
+        const int l1 = (uint32_t)r < nrows ? row_len[r] : 0;
+        uint32_t dw = 0;
+        for (int k = 0; k < 4; k++) {
+            const int i = iq * 4 + k;
+            int v = -128;
+            if (i < l1 && c < 24) v = m8[rowres[r * 32 + i] * 24 + c] * scale;
+            dw |= ((uint32_t)v & 0xFFu) << (8 * k);
+        }
+        q[e] = dw;
+    }
+}
+
+// -----------------------------------------------------------------------------
 // k_local_block: LocalAlignmentScorer for a dense block, register-resident DP
 // -----------------------------------------------------------------------------
 // score(seq1 = row, seq2 = column) for rows [r0, r1) x columns [c0, c1)
@@ -486,7 +605,7 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
 // Padding (lines >= len1, columns >= the lane's len2) uses score -128: with gap penalties <= 0 a
 // padded cell can never exceed the largest real cell, so the running maximum is unaffected.
 // Preconditions checked by the host: |M| <= 127, gapOpen <= 0, gapExtend <= 0 (else k_pairs<1>).
-template <int LBMAX>
+template <int LBMAX, bool ENC>
 __global__ void __launch_bounds__(256)
 k_local_block(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len, const int32_t *__restrict__ Mg,
               uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend,
@@ -509,19 +628,10 @@ k_local_block(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len
         rowres[e] = r < nrows ? res32[(size_t)(row_base + r) * 32 + (e & 31)] : 0;
     }
     __syncthreads();
-    // profiles: entry (r, c, iq)
-    for (int e = tid; e < R * 25 * 8; e += 256) {
-        const int r = e / 200, rem = e - r * 200, c = rem >> 3, iq = rem & 7;
-        const int l1 = (uint32_t)r < nrows ? len[row_base + r] : 0;
-        uint32_t dw = 0;
-        for (int k = 0; k < 4; k++) {
-            const int i = iq * 4 + k;
-            int v = -128;
-            if (i < l1 && c < 24) v = m8[rowres[r * 32 + i] * 24 + c];
-            dw |= ((uint32_t)v & 0xFFu) << (8 * k);
-        }
-        reinterpret_cast<uint32_t *>(smem)[e] = dw;
-    }
+    __shared__ int row_len[R];
+    if (tid < R) row_len[tid] = (uint32_t)tid < nrows ? len[row_base + tid] : 0;
+    __syncthreads();
+    build_profiles<R>(reinterpret_cast<uint32_t *>(smem), m8, rowres, row_len, nrows, ENC ? 4 : 1, tid);
     __syncthreads();
 
     // this lane's column sequence -> profile byte offsets (pad residue 24 beyond its length)
@@ -552,45 +662,8 @@ k_local_block(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len
 
     const uint32_t q_addr = lds_addr(smem);
     for (uint32_t r = 0; r < nrows; r++) {
-        const int len1 = len[row_base + r];
-        int H[LBMAX], U[LBMAX];
-#pragma unroll
-        for (int j = 0; j < LBMAX; j++) { H[j] = 0; U[j] = gap_open; }   // line 0: H = 0, Dir = LEFT (:97-100)
-        int gmax = 0;
-        const int strips = (len1 + 3) >> 2;
-        for (int st = 0; st < strips; st++) {
-            const uint32_t strip_addr = q_addr + r * QROW + (uint32_t)st * 4u;
-            int hd[4], lc[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { hd[k] = 0; lc[k] = gap_open; }  // column 0: H = 0, Dir = UP (:93-96)
-#pragma unroll
-            for (int j = 0; j < LBMAX; j++) {
-                if (j < wmax) {
-                    const uint32_t q = lds_read<uint32_t>(strip_addr + boff[j]);
-                    int up = U[j];
-                    int habove = H[j];          // H[line-1][j]: the next column's diagonal for line k = 0
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int sc = (int)(int8_t)(q >> (8 * k));
-                        const int diag = hd[k] + sc;                      // :59
-                        const int left = lc[k];
-                        const int mx = max(diag, max(up, left));         // :61
-                        const bool neg = mx < 0;                          // :63
-                        const bool d_eq = mx == diag, u_eq = mx == up;
-                        const int h = max(mx, 0);                         // :64,:67
-                        const bool is_up = u_eq && !d_eq && !neg;         // :76-81
-                        const bool is_left = !(u_eq || d_eq || neg);      // :73-81
-                        gmax = max(gmax, h);                              // :68-72
-                        hd[k] = habove;
-                        habove = h;
-                        up = h + (is_up ? gap_extend : gap_open);
-                        lc[k] = h + (is_left ? gap_extend : gap_open);
-                    }
-                    H[j] = habove;
-                    U[j] = up;
-                }
-            }
-        }
+        const int len1 = row_len[r];
+        const int gmax = sw_row<LBMAX, ENC>(q_addr + r * QROW, (len1 + 3) >> 2, wmax, boff, gap_open, gap_extend);
         if (col_ok) out[(size_t)(row_base + r - r0) * width + (col - c0)] = gmax;
     }
 }
@@ -602,7 +675,7 @@ k_local_block(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len
 // one (row length, column length) class per tile, so no padding columns and a wave-uniform column
 // bound.  Rows are seq1 (lines), columns seq2; the edge (x = column, m = row) carries
 // sequenceScore(seq1 = m, seq2 = x) like every other edge (row_is_m = 1 swaps them at flush).
-template <int LBMAX>
+template <int LBMAX, bool ENC>
 __global__ void __launch_bounds__(256)
 k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_t *__restrict__ Mg, int gap_open,
                   int gap_extend, int threshold) {
@@ -627,17 +700,10 @@ k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_
         rowres[e] = (r < T.nrows && k < P.lpad) ? P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k] : 0;
     }
     __syncthreads();
-    for (int e = tid; e < R * 25 * 8; e += 256) {
-        const int r = e / 200, rem = e - r * 200, c = rem >> 3, iq = rem & 7;
-        uint32_t dw = 0;
-        for (int k = 0; k < 4; k++) {
-            const int i = iq * 4 + k;
-            int v = -128;
-            if ((uint32_t)r < T.nrows && i < la && c < 24) v = m8[rowres[r * 32 + i] * 24 + c];
-            dw |= ((uint32_t)v & 0xFFu) << (8 * k);
-        }
-        reinterpret_cast<uint32_t *>(smem)[e] = dw;
-    }
+    __shared__ int row_len[R];
+    if (tid < R) row_len[tid] = (uint32_t)tid < T.nrows ? la : 0;
+    __syncthreads();
+    build_profiles<R>(reinterpret_cast<uint32_t *>(smem), m8, rowres, row_len, T.nrows, ENC ? 4 : 1, tid);
     __syncthreads();
 
     const uint32_t q_addr = lds_addr(smem);
@@ -668,43 +734,7 @@ k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_
             }
         }
         for (uint32_t r = 0; r < T.nrows; r++) {
-            int H[LBMAX], U[LBMAX];
-#pragma unroll
-            for (int j = 0; j < LBMAX; j++) { H[j] = 0; U[j] = gap_open; }
-            int gmax = 0;
-            for (int st = 0; st < strips; st++) {
-                const uint32_t strip_addr = q_addr + r * QROW + (uint32_t)st * 4u;
-                int hd[4], lc[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) { hd[k] = 0; lc[k] = gap_open; }
-#pragma unroll
-                for (int j = 0; j < LBMAX; j++) {
-                    if (j < lb) {
-                        const uint32_t q = lds_read<uint32_t>(strip_addr + boff[j]);
-                        int up = U[j];
-                        int habove = H[j];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int sc = (int)(int8_t)(q >> (8 * k));
-                            const int diag = hd[k] + sc;
-                            const int left = lc[k];
-                            const int mx = max(diag, max(up, left));
-                            const bool neg = mx < 0;
-                            const bool d_eq = mx == diag, u_eq = mx == up;
-                            const int h = max(mx, 0);
-                            const bool is_up = u_eq && !d_eq && !neg;
-                            const bool is_left = !(u_eq || d_eq || neg);
-                            gmax = max(gmax, h);
-                            hd[k] = habove;
-                            habove = h;
-                            up = h + (is_up ? gap_extend : gap_open);
-                            lc[k] = h + (is_left ? gap_extend : gap_open);
-                        }
-                        H[j] = habove;
-                        U[j] = up;
-                    }
-                }
-            }
+            const int gmax = sw_row<LBMAX, ENC>(q_addr + r * QROW, strips, lb, boff, gap_open, gap_extend);
             bool keep = col_ok && gmax >= threshold;
             if (T.diag) keep = keep && col != T.row0 + r;   // a sequence is never paired with itself
             const uint64_t mask = __ballot(keep);
@@ -865,15 +895,15 @@ hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, 
     return hipGetLastError();
 }
 
-hipError_t launch_neighbors_local(int lbmax, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
+hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
                                   const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    if (lbmax <= 12)
-        hipLaunchKernelGGL(k_neighbors_local<12>, dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, gap_open, gap_extend, threshold);
-    else if (lbmax <= 20)
-        hipLaunchKernelGGL(k_neighbors_local<20>, dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, gap_open, gap_extend, threshold);
-    else
-        hipLaunchKernelGGL(k_neighbors_local<32>, dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, gap_open, gap_extend, threshold);
+#define HMK_NL(LB, E) hipLaunchKernelGGL((k_neighbors_local<LB, E>), dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, \
+                                         gap_open, gap_extend, threshold)
+    if (lbmax <= 12) { if (enc) HMK_NL(12, true); else HMK_NL(12, false); }
+    else if (lbmax <= 20) { if (enc) HMK_NL(20, true); else HMK_NL(20, false); }
+    else { if (enc) HMK_NL(32, true); else HMK_NL(32, false); }
+#undef HMK_NL
     return hipGetLastError();
 }
 
@@ -899,17 +929,16 @@ hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, c
     return hipGetLastError();
 }
 
-hipError_t launch_local_block(int lbmax, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,
-                              uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
+hipError_t launch_local_block(int lbmax, bool enc, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix,
+                              uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
                               hipStream_t s) {
     if (r1 <= r0 || c1 <= c0) return hipSuccess;
     const dim3 grid((c1 - c0 + 255) / 256, (r1 - r0 + 15) / 16);
-    if (lbmax <= 20)
-        hipLaunchKernelGGL(k_local_block<20>, grid, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, gap_open,
-                           gap_extend, out);
-    else
-        hipLaunchKernelGGL(k_local_block<32>, grid, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, gap_open,
-                           gap_extend, out);
+#define HMK_LB(LB, E) hipLaunchKernelGGL((k_local_block<LB, E>), grid, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, \
+                                         gap_open, gap_extend, out)
+    if (lbmax <= 20) { if (enc) HMK_LB(20, true); else HMK_LB(20, false); }
+    else { if (enc) HMK_LB(32, true); else HMK_LB(32, false); }
+#undef HMK_LB
     return hipGetLastError();
 }
 
