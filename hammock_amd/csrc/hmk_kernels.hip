@@ -228,6 +228,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
     constexpr int REC_DW = NW + 2;
     constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;  // residue dwords a lane needs (rows are P.lpad bytes apart)
     static_assert(TAB_BYTES <= 65536, "row tables must stay addressable by the DS immediate offset");
+    static_assert(!EXACT || (NW == 2 && LBMAX == 12), "the exact path is length 12, max shift 3, 8-bit lanes");
     // one STATIC LDS object: its base address is a compile-time constant, so table
     // offsets fold into the ds_read immediate instead of costing a v_add per lookup
     constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * REC_DW * 4;
@@ -257,7 +258,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
         const int r = e >> 5, k = e & 31;
         uint8_t v = 0;
         if ((uint32_t)r < T.nrows && (uint32_t)k < P.lpad) v = P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k];
-        rowres[e] = v;
+        rowres[e] = EXACT ? (uint8_t)(v >> 3) : v;   // the exact path stores residues pre-multiplied by the entry size
     }
     __syncthreads();
 
@@ -265,7 +266,30 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
     // entry (r, j, c), lane t (shift s = t - X):
     //   column is the longer/equal one (L): cell = M[row[i]][c], i = j - s   (ShiftedScorer.java:71,75)
     //   column is the shorter one (S):      cell = M[c][row[i]], i = j + s
-    {
+    if (EXACT) {
+        // length 12, max shift 3, 8-bit lanes: one thread per (row, residue) gathers the 12 cells
+        // P[i] = M[row[i]][c] once, reversed and zero padded, and cuts the 12 per-position entries out of
+        // it as byte windows (lane t of position j is P[j + 3 - t]; lane 7 is unused)
+        for (int e = tid; e < R * 24; e += 256) {
+            const int r = e / 24, c = e - r * 24;
+            uint32_t pp[6] = {0, 0, 0, 0, 0, 0};
+            if ((uint32_t)r < T.nrows) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    const uint32_t v = mb[rowres[r * 32 + i] * 24 + c];
+                    pp[(14 - i) >> 2] |= v << (((14 - i) & 3) * 8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int v0 = 11 - j;
+                const uint32_t lo = __builtin_amdgcn_alignbyte(pp[(v0 >> 2) + 1], pp[v0 >> 2], v0 & 3);
+                const uint32_t hi = __builtin_amdgcn_alignbyte(pp[(v0 >> 2) + 2], pp[(v0 >> 2) + 1], v0 & 3) & 0x00FFFFFFu;
+                *reinterpret_cast<u32x2 *>(tab + r * ROWBYTES + (j * 24 + c) * ES) = u32x2{lo, hi};
+            }
+        }
+    } else {
         const int per_row = lb * 24;
         const int lanes_per_dw = lane16 ? 2 : 4;
         const int lane_bits = lane16 ? 16 : 8;
@@ -329,7 +353,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
 #pragma unroll
             for (int j = 0; j < LBMAX; j++) {
                 const uint32_t c = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-                off[p][j] = tab_addr + (uint32_t)(j * 24 * ES) + c * ES;
+                off[p][j] = tab_addr + (uint32_t)(j * 24 * ES) + (EXACT ? c : c * ES);   // EXACT: stored as c * 8
             }
         }
 
