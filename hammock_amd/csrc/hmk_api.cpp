@@ -36,7 +36,7 @@ struct Plan {
     uint32_t part = 0, n_parts = 1;
     int lbmax = 12, lpad = 16;
     bool exact = false;
-    int hot_variant = 1;
+    int hot_variant = 7;
     uint32_t cols_per_tile = 16384;
     uint8_t *d_res_sorted = nullptr;
     uint32_t *d_perm = nullptr;
@@ -207,12 +207,12 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         classify(ctx, 12, 12, X, p, thr, &t12);
         pl.exact = t12.path == PATH_U8 && t12.nw == 2;
     }
-    // Tiling (measured on MI355X, tools/tune_hot.py): 8 rows x 2 columns per lane and long
-    // column runs win (5 workgroups/CU, table build amortised); shrink the runs for small
+    // Tiling (measured on MI355X, tools/tune_hot.py): 6 rows x 2 columns per lane and long
+    // column runs win (7 workgroups/CU, table build amortised); shrink the runs for small
     // inputs so the grid still has a few thousand workgroups.
-    pl.hot_variant = 1;
+    pl.hot_variant = 7;
     pl.cols_per_tile = 16384;
-    while (pl.cols_per_tile > 1024 && ((uint64_t)n / 8 + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
+    while (pl.cols_per_tile > 1024 && ((uint64_t)n / 6 + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
         pl.cols_per_tile /= 2;
     if (const char *v = getenv("HMK_HOT_VARIANT")) pl.hot_variant = atoi(v);   // tuning knobs
     if (const char *v = getenv("HMK_COLS_PER_TILE")) pl.cols_per_tile = (uint32_t)std::max(256, atoi(v));

@@ -864,7 +864,7 @@ static hipError_t launch_swar_t(const NeighborParams &P, uint32_t tile_base, uin
 }
 
 // Hot-path tilings of the exact length-12, NW = 2 kernel: {rows per tile, columns per lane}.
-static const int kHotVariants[][2] = {{16, 2}, {8, 2}, {12, 2}, {8, 4}, {16, 4}, {12, 4}, {4, 2}, {6, 2}};
+static const int kHotVariants[][2] = {{16, 2}, {8, 2}, {12, 2}, {8, 4}, {5, 2}, {7, 2}, {4, 2}, {6, 2}, {6, 3}, {6, 1}};
 constexpr int kNumHotVariants = sizeof(kHotVariants) / sizeof(kHotVariants[0]);
 
 // Generic instantiations: column-length capacity LBMAX x dwords per entry NW.  Rows per tile
@@ -892,8 +892,12 @@ hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant,
             case 1: return launch_swar_t<2, 8, 2, 12, true>(P, tile_base, n_tiles, s);
             case 2: return launch_swar_t<2, 12, 2, 12, true>(P, tile_base, n_tiles, s);
             case 3: return launch_swar_t<2, 8, 4, 12, true>(P, tile_base, n_tiles, s);
+            case 4: return launch_swar_t<2, 5, 2, 12, true>(P, tile_base, n_tiles, s);
+            case 5: return launch_swar_t<2, 7, 2, 12, true>(P, tile_base, n_tiles, s);
             case 6: return launch_swar_t<2, 4, 2, 12, true>(P, tile_base, n_tiles, s);
             case 7: return launch_swar_t<2, 6, 2, 12, true>(P, tile_base, n_tiles, s);
+            case 8: return launch_swar_t<2, 6, 3, 12, true>(P, tile_base, n_tiles, s);
+            case 9: return launch_swar_t<2, 6, 1, 12, true>(P, tile_base, n_tiles, s);
             default: return hipErrorInvalidValue;
         }
     }

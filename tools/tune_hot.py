@@ -53,7 +53,7 @@ for _ in range(rounds):
         torch.cuda.synchronize()
         times[k].append(a.elapsed_time(b))
 pairs = n * (n - 1) // 2
-names = {0: "R16C2", 1: "R8C2", 2: "R12C2", 3: "R8C4", 6: "R4C2", 7: "R6C2"}
+names = {0: "R16C2", 1: "R8C2", 2: "R12C2", 3: "R8C4", 4: "R5C2", 5: "R7C2", 6: "R4C2", 7: "R6C2", 8: "R6C3", 9: "R6C1"}
 for k in sorted(times, key=lambda k: np.median(times[k])):
     t = times[k]
     print(f"variant {k[0]} {names[k[0]]:6s} cols {k[1]:5d} tiles {ctxs[k][2]:6d} edges {ctxs[k][1]:9d} "
