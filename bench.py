@@ -200,7 +200,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total / (elapsed / args.steps)
-        # dominant kernel: k_neighbors_swar<2,8,2,12,true>.  Algorithmic HBM bytes per launch
+        # dominant kernel: k_neighbors_swar<2,6,2,12,true>.  Algorithmic HBM bytes per launch
         # (DESIGN.md "Roofline"): 8 B per emitted edge + 16 B per peptide read once.
         pairs_rank = int(plan.pairs_scored)
         alg_bytes = 8 * n_edges_rank + 16 * n
@@ -219,7 +219,8 @@ def main():
                            if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
-                         "kernel": "k_neighbors_swar<NW=2,R=8,CPL=2,LB=12,exact>", "kernel_ms": kern_ms,
+                         "kernel": "k_neighbors_swar<2, 6, 2, 12, true> (NW=2 dwords/entry, 6 rows/tile, 2 columns/lane, length 12 exact)",
+                         "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "HBM does not bind this path (SURVEY.md 8d): the kernel is bound by LDS lookups",
                          "lds": {"achieved_lookups_per_s": lookups, "peak_lookups_per_s": LDS_LOOKUP_PEAK,
