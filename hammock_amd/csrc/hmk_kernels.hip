@@ -17,6 +17,7 @@
 //                      behind hmk_score_pairs_* / hmk_score_block_*.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "hmk_internal.h"
 #include "hmk_kernels.h"
@@ -781,6 +782,175 @@ k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_
 }
 
 // -----------------------------------------------------------------------------
+// k_neighbors_local_pk: the tagged-max DP on TWO column sequences per lane (packed int16 halves)
+// -----------------------------------------------------------------------------
+// Every value of the tagged-max DP fits 16 bits (4 * 32 * 31 + 3 < 2^15), so one VGPR carries the
+// cells of two column sequences and v_pk_add_i16 / v_pk_max_i16 advance both: 13 VALU instructions
+// per PAIR of cells instead of 10-11 per cell (the kernel sits on the integer VALU-issue roofline,
+// DESIGN.md 5.3b).  Profiles hold 4 * score as int16, four lines per ds_read_b64; one v_perm_b32 per
+// line zips the two sequences' scores.  The gap-penalty table lookup returns both halves at once:
+// selector byte 2h = tag_h (low-byte table in S1), byte 2h + 1 = tag_h + 4 (high-byte table in S0).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s16x2 pk(uint32_t u) { return __builtin_bit_cast(s16x2, u); }
+__device__ __forceinline__ uint32_t un(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+template <int LBMAX>
+__device__ __forceinline__ uint32_t sw_row_pk(uint32_t row_q_addr, int strips, int ncols, const uint32_t (&boff_lo)[LBMAX],
+                                              const uint32_t (&boff_hi)[LBMAX], int gap_open, int gap_extend) {
+    // 16-bit table entries by tag (0 NOWHERE, 1 LEFT, 2 UP, 3 DIAGONAL), split into low / high bytes
+    const int pu[4] = {4 * gap_open + 2, 4 * gap_open + 1, 4 * gap_extend, 4 * gap_open - 1};
+    const int pl[4] = {4 * gap_open + 1, 4 * gap_extend, 4 * gap_open - 1, 4 * gap_open - 2};
+    uint32_t PUlo = 0, PUhi = 0, PLlo = 0, PLhi = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        PUlo |= ((uint32_t)pu[t] & 0xFFu) << (8 * t); PUhi |= (((uint32_t)pu[t] >> 8) & 0xFFu) << (8 * t);
+        PLlo |= ((uint32_t)pl[t] & 0xFFu) << (8 * t); PLhi |= (((uint32_t)pl[t] >> 8) & 0xFFu) << (8 * t);
+    }
+    const uint32_t both = 0x00010001u;
+    const s16x2 zero = pk(0u);
+    uint32_t H[LBMAX], U[LBMAX];
+#pragma unroll
+    for (int j = 0; j < LBMAX; j++) { H[j] = 3u * both; U[j] = (uint32_t)((4 * gap_open + 2) & 0xFFFF) * both; }
+    s16x2 gm = zero;
+    for (int st = 0; st < strips; st++) {
+        const uint32_t strip_addr = row_q_addr + (uint32_t)st * 8u;
+        uint32_t hd[4], lc[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { hd[k] = 3u * both; lc[k] = (uint32_t)((4 * gap_open + 1) & 0xFFFF) * both; }
+#pragma unroll
+        for (int j = 0; j < LBMAX; j++) {
+            if (j < ncols) {
+                const u32x2 qa = lds_read<u32x2>(strip_addr + boff_lo[j]);   // lines 0,1 | 2,3 of sequence "lo"
+                const u32x2 qb = lds_read<u32x2>(strip_addr + boff_hi[j]);   // ... of sequence "hi"
+                uint32_t sc[4];
+                sc[0] = __builtin_amdgcn_perm(qb.x, qa.x, 0x05040100u);
+                sc[1] = __builtin_amdgcn_perm(qb.x, qa.x, 0x07060302u);
+                sc[2] = __builtin_amdgcn_perm(qb.y, qa.y, 0x05040100u);
+                sc[3] = __builtin_amdgcn_perm(qb.y, qa.y, 0x07060302u);
+                uint32_t up = U[j];
+                uint32_t habove = H[j];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const s16x2 diag = pk(hd[k]) + pk(sc[k]);                                        // :59
+                    const s16x2 m1 = __builtin_elementwise_max(pk(up), pk(lc[k]));
+                    const s16x2 he = __builtin_elementwise_max(__builtin_elementwise_max(diag, m1), zero);  // :61-67
+                    gm = __builtin_elementwise_max(gm, he);                                          // :68-72
+                    const uint32_t heu = un(he);
+                    const uint32_t sel = (heu & 0x00030003u) * 0x0101u + 0x04000400u;
+                    const uint32_t padd_u = __builtin_amdgcn_perm(PUhi, PUlo, sel);
+                    const uint32_t padd_l = __builtin_amdgcn_perm(PLhi, PLlo, sel);
+                    hd[k] = habove;
+                    habove = heu | 0x00030003u;
+                    up = un(he + pk(padd_u));                                                         // :43-48,:57
+                    lc[k] = un(he + pk(padd_l));                                                      // :50-55,:58
+                }
+                H[j] = habove;
+                U[j] = up;
+            }
+        }
+    }
+    const uint32_t g = un(gm);
+    return ((g & 0xFFFFu) >> 2) | (((g >> 16) >> 2) << 16);   // both maxima are >= 0
+}
+
+template <int LBMAX>
+__global__ void __launch_bounds__(256)
+k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int32_t *__restrict__ Mg, int gap_open,
+                     int gap_extend, int threshold) {
+    constexpr int R = 16;
+    constexpr int QROW = 25 * 8 * 8;      // 25 residues x 8 strips x (4 lines x int16)
+    constexpr int STAGE_CAP = 192;        // room for two flush-free appends (lo and hi halves)
+    constexpr int REC_DW = 3;
+    __shared__ __attribute__((aligned(16))) uint8_t smem[R * QROW + 576 + R * 32 + 4 * STAGE_CAP * REC_DW * 4];
+    int8_t *m8 = reinterpret_cast<int8_t *>(smem + R * QROW);
+    uint8_t *rowres = smem + R * QROW + 576;
+    uint32_t *stage_all = reinterpret_cast<uint32_t *>(smem + R * QROW + 576 + R * 32);
+    const Tile T = P.tiles[tile_base + blockIdx.x];
+    const TileClass *Cp = P.classes + T.cls;
+    const int la = Cp->la, lb = Cp->lb;
+    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const int tid = threadIdx.x;
+    uint32_t *stage = stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+
+    for (int e = tid; e < 576; e += 256) m8[e] = (int8_t)Mg[e];
+    for (int e = tid; e < R * 32; e += 256) {
+        const uint32_t r = (uint32_t)e >> 5, k = e & 31;
+        rowres[e] = (r < T.nrows && k < P.lpad) ? P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k] : 0;
+    }
+    __syncthreads();
+    // profiles: entry (r, c, strip) = four int16 (4 * score; -128 for padding lines / the pad residue)
+    for (int e = tid; e < R * 25 * 8; e += 256) {
+        const int r = e / 200, rem = e - r * 200, c = rem >> 3, iq = rem & 7;
+        uint32_t w[2] = {0, 0};
+        for (int k = 0; k < 4; k++) {
+            const int i = iq * 4 + k;
+            int v = -128;
+            if ((uint32_t)r < T.nrows && i < la && c < 24) v = m8[rowres[r * 32 + i] * 24 + c] * 4;
+            w[k >> 1] |= ((uint32_t)v & 0xFFFFu) << (16 * (k & 1));
+        }
+        reinterpret_cast<u32x2 *>(smem)[e] = u32x2{w[0], w[1]};
+    }
+    __syncthreads();
+
+    const uint32_t q_addr = lds_addr(smem);
+    const uint32_t col_end = T.col0 + T.ncols;
+    const int strips = (la + 3) >> 2;
+    uint32_t cnt = 0;
+    for (uint32_t c0 = T.col0; c0 < col_end; c0 += 512) {
+        uint32_t colv[2];
+        bool okv[2];
+        uint32_t boff[2][LBMAX];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            colv[h] = c0 + h * 256 + tid;
+            okv[h] = colv[h] < col_end;
+            uint32_t words[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) words[q] = 0;
+            if (okv[h]) {
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(P.res_sorted + (size_t)colv[h] * P.lpad);
+                const u32x4 v0 = src[0];
+                words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+                if (LBMAX > 16) {
+                    const u32x4 v1 = src[1];
+                    words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < LBMAX; j++) {
+                const uint32_t c = (okv[h] && j < lb) ? ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu) : 24u;
+                boff[h][j] = c * 64u;   // 8 strips x 8 bytes per residue
+            }
+        }
+        for (uint32_t r = 0; r < T.nrows; r++) {
+            const uint32_t g2 = sw_row_pk<LBMAX>(q_addr + r * QROW, strips, lb, boff[0], boff[1], gap_open, gap_extend);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int gmax = (int)((g2 >> (16 * h)) & 0xFFFFu);
+                bool keep = okv[h] && gmax >= threshold;
+                if (T.diag) keep = keep && colv[h] != T.row0 + r;
+                const uint64_t mask = __ballot(keep);
+                if (mask != 0) {
+                    if (cnt > (uint32_t)(STAGE_CAP - 64)) {
+                        flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+                        cnt = 0;
+                    }
+                    if (keep) {
+                        uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                        rec[0] = colv[h];
+                        rec[1] = r;
+                        rec[2] = (uint32_t)gmax;
+                    }
+                    cnt += (uint32_t)__popcll(mask);
+                }
+            }
+        }
+    }
+    flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+}
+
+// -----------------------------------------------------------------------------
 // edge list -> CSR adjacency on the device (feeds the host greedy merge)
 // -----------------------------------------------------------------------------
 // The neighbour kernel leaves HMK_EDGE_SHARDS segments of packed edges.  Three small
@@ -928,9 +1098,13 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
     if (n_tiles == 0) return hipSuccess;
 #define HMK_NL(LB, E) hipLaunchKernelGGL((k_neighbors_local<LB, E>), dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, \
                                          gap_open, gap_extend, threshold)
-    if (lbmax <= 12) { if (enc) HMK_NL(12, true); else HMK_NL(12, false); }
-    else if (lbmax <= 20) { if (enc) HMK_NL(20, true); else HMK_NL(20, false); }
-    else { if (enc) HMK_NL(32, true); else HMK_NL(32, false); }
+#define HMK_NLP(LB) hipLaunchKernelGGL((k_neighbors_local_pk<LB>), dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, \
+                                       gap_open, gap_extend, threshold)
+    const bool packed = enc && getenv("HMK_LOCAL_NO_PK") == nullptr;   // two column sequences per lane
+    if (lbmax <= 12) { if (packed) HMK_NLP(12); else if (enc) HMK_NL(12, true); else HMK_NL(12, false); }
+    else if (lbmax <= 20) { if (packed) HMK_NLP(20); else if (enc) HMK_NL(20, true); else HMK_NL(20, false); }
+    else { if (packed) HMK_NLP(32); else if (enc) HMK_NL(32, true); else HMK_NL(32, false); }
+#undef HMK_NLP
 #undef HMK_NL
     return hipGetLastError();
 }
