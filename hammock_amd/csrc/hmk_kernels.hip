@@ -807,6 +807,10 @@ __device__ __forceinline__ uint32_t sw_row_pk(uint32_t row_q_addr, int strips, i
         PUlo |= ((uint32_t)pu[t] & 0xFFu) << (8 * t); PUhi |= (((uint32_t)pu[t] >> 8) & 0xFFu) << (8 * t);
         PLlo |= ((uint32_t)pl[t] & 0xFFu) << (8 * t); PLhi |= (((uint32_t)pl[t] >> 8) & 0xFFu) << (8 * t);
     }
+    // v_perm_b32 reads at most one SGPR: pin one table of each pair in a VGPR once instead of a
+    // v_mov per use
+    asm volatile("" : "+v"(PUlo));
+    asm volatile("" : "+v"(PLlo));
     const uint32_t both = 0x00010001u;
     const s16x2 zero = pk(0u);
     uint32_t H[LBMAX], U[LBMAX];
