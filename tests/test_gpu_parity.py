@@ -532,3 +532,80 @@ def test_neighbors_local_vs_oracle(gpu, matrices, coracle, cfg):
     assert np.array_equal(np.sort(np.concatenate(parts)), want)
     with pytest.raises(ValueError):
         ctx.neighbors_local(1, 0, thr)   # positive gap penalty: outside the striped kernel's contract
+
+
+def test_neighbors_fuzz_lane_classification(gpu, matrices, coracle):
+    """Randomised sweep over matrices (shipped, random, asymmetric, extreme), length ranges, max shift,
+    shift penalty (either sign) and thresholds: exercises the 8-bit / 16-bit / literal lane classification
+    and every kernel capacity.  The edge set must equal the oracle's exactly each time."""
+    rng = np.random.default_rng(2024)
+    names = sorted(matrices)
+    used = {"u8": 0, "u16": 0, "direct": 0}
+    for trial in range(48):
+        kind = trial % 4
+        if kind == 0:
+            M = matrices[names[int(rng.integers(len(names)))]].copy()
+        elif kind == 1:  # random symmetric
+            A = rng.integers(-8, 16, size=(24, 24)).astype(np.int32)
+            M = np.minimum(A, A.T)
+        elif kind == 2:  # asymmetric
+            M = matrices["blosum62"].copy()
+            M += rng.integers(-2, 3, size=(24, 24)).astype(np.int32)
+        else:            # extreme range: forces 16-bit lanes or the literal tier
+            M = rng.integers(-120, 121, size=(24, 24)).astype(np.int32)
+            M = np.minimum(M, M.T) if trial % 8 == 3 else M
+        lo = int(rng.integers(1, 14))
+        hi = int(min(32, lo + rng.integers(0, 20)))
+        n = int(rng.integers(150, 420))
+        res, off = synth_peptides(int(rng.integers(1, 10 ** 6)), n, lo, hi)
+        lens = np.diff(off.astype(np.int64))
+        X = int(rng.integers(0, min(int(lens.min()), 9)))
+        p = int(rng.integers(-6, 3))
+        # threshold from the score distribution of a sample of pairs
+        i = rng.integers(0, n, 4000).astype(np.uint32)
+        j = rng.integers(0, n, 4000).astype(np.uint32)
+        st, sc = coracle.score_pairs(M, res, off, i, j, 0, X, p)
+        thr = int(np.quantile(sc, float(rng.choice([0.0, 0.5, 0.9, 0.99, 0.999]))))
+        ctx, _, _ = ctx_for(M, res=res, off=off)
+        edges, stats = ctx.neighbors_shifted(X, p, thr)
+        want = oracle_edges(coracle, M, res, off, X, p, thr)
+        assert np.array_equal(sorted_edges(edges), want), (trial, kind, lo, hi, n, X, p, thr, stats.classes_u8,
+                                                          stats.classes_u16, stats.classes_direct)
+        used["u8"] += stats.classes_u8
+        used["u16"] += stats.classes_u16
+        used["direct"] += stats.classes_direct
+    assert used["u8"] and used["u16"] and used["direct"], used  # all three tiers were exercised
+
+
+def test_local_fuzz(gpu, matrices, coracle):
+    """Randomised sweep of the LocalAlignmentScorer kernels (packed / tagged / plain / literal are chosen by the
+    matrix and penalty ranges): dense block and thresholded ordered pairs against the oracle."""
+    rng = np.random.default_rng(77)
+    names = sorted(matrices)
+    for trial in range(24):
+        if trial % 3 == 0:
+            M = matrices[names[int(rng.integers(len(names)))]].copy()
+        elif trial % 3 == 1:
+            M = rng.integers(-31, 32, size=(24, 24)).astype(np.int32)     # tagged-max range, asymmetric
+        else:
+            M = rng.integers(-127, 128, size=(24, 24)).astype(np.int32)   # plain striped kernel range
+        lo = int(rng.integers(1, 14))
+        hi = int(min(32, lo + rng.integers(0, 20)))
+        n = int(rng.integers(100, 300))
+        res, off = synth_peptides(int(rng.integers(1, 10 ** 6)), n, lo, hi)
+        go = -int(rng.integers(0, 40))
+        ge = -int(rng.integers(0, 40))
+        if trial % 8 == 7:
+            go, ge = 3, -1   # positive penalty: literal kernel for blocks, error for the neighbour pass
+        ctx, _, _ = ctx_for(M, res=res, off=off)
+        idx = np.arange(n, dtype=np.uint32)
+        st, want = coracle.score_block(M, res, off, idx, idx, 1, go, ge)
+        got = ctx.score_block_local(0, n, 0, n, go, ge)
+        assert np.array_equal(got, want), (trial, lo, hi, go, ge)
+        if go <= 0 and ge <= 0:
+            thr = int(np.quantile(want, 0.9))
+            edges, _ = ctx.neighbors_local(go, ge, thr)
+            mm, xx = np.meshgrid(idx, idx, indexing="ij")
+            keep = (want >= thr) & (mm != xx)
+            assert np.array_equal(np.sort(edges), np.sort(hammock_amd.pack_edges(xx[keep], mm[keep], want[keep]))), (
+                trial, lo, hi, go, ge, thr)
