@@ -943,7 +943,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (h_start[n] != n_adj) return fail(ctx, HMK_ERR_DEVICE, "CSR build: adjacency size mismatch");
     const double nb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::string err;
-    st = greedy_from_csr(n, ctx->has_sizes ? ctx->sizes.data() : nullptr, h_start, h_adj, max_clusters, cluster_id,
+    st = greedy_from_csr(n, ctx->has_sizes ? ctx->sizes.data() : nullptr, h_start, h_adj, ctx->symmetric, max_clusters, cluster_id,
                          result_order, member_rank, stats, &err);
     stats->n_edges = total;
     stats->neighbors_ms = nb_ms;

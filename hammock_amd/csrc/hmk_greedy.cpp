@@ -26,7 +26,10 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace hmk {
@@ -84,7 +87,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
             if (symmetric) adj[fill[m]++] = Nbr{x, s};
         }
     }
-    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), max_clusters, cluster_id, result_order,
+    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), symmetric, max_clusters, cluster_id, result_order,
                                    member_rank, st, err);
     if (st) {
         st->n_edges = n_edges;
@@ -94,7 +97,8 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
 }
 
 // The merge proper, on a CSR adjacency: start[n + 1], adj[start[x] .. start[x + 1]) = neighbours of x.
-int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, int max_clusters,
+int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, bool symmetric_scores,
+                    int max_clusters,
                     int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                     std::string *err) {
     auto t0 = std::chrono::steady_clock::now();
@@ -102,6 +106,7 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
     if (!st) st = &local;
     std::memset(st, 0, sizeof(*st));
     st->n_edges = start[n];
+    double t_phase1 = 0;
 
     std::vector<uint8_t> state(n, ST_FREE);
     std::vector<int32_t> cluster_of(n, -1);
@@ -200,6 +205,7 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         remaining--;
         index++;          // :115
     }
+    t_phase1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     st->phase1_stop_index = (int32_t)index;
     st->phase1_clusters = (int32_t)clusters.size();
     st->phase1_orphans = (int32_t)orphans.size();
@@ -209,11 +215,106 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         std::vector<uint32_t> leftover(orphans);
         for (uint32_t q = k; q < n; q++)
             if (state[q] == ST_FREE) leftover.push_back(q);
+        // Complete linkage is monotone: clusters only GROW in this loop, so a sequence whose neighbours
+        // do not cover some cluster's members at the START of the loop can never join that cluster later.
+        // (1) Pre-check, independent per sequence and read-only, on all host threads: the clusters that
+        //     are feasible against the start-of-loop membership, with their min score (at most 4 kept
+        //     inline; more -> that sequence falls back to the full scan).
+        // (2) Sequential, order-dependent part (:60-62) only for the survivors.  With symmetric scores a
+        //     survivor does not rescan its neighbours: every sequence that joins a cluster pushes
+        //     (cluster, score) to its later neighbours' inboxes, and a candidate cluster is still feasible
+        //     iff the inbox holds as many entries for it as members joined since the pre-check.
+        constexpr int KC = 4;
+        struct Cand { int32_t c, mn; };
+        const size_t nl = leftover.size();
+        std::vector<uint8_t> cand_cnt(nl, 255);          // 255: full scan at its turn
+        std::vector<Cand> cand(nl * KC);
+        const bool fast = !clusters.empty() && nl > 512;
+        if (fast) {
+            const unsigned hw = std::thread::hardware_concurrency();
+            const unsigned T = std::max(1u, std::min(16u, hw ? hw : 1u));
+            const size_t nc = clusters.size();
+            auto work = [&](unsigned t) {
+                std::vector<int32_t> c2(nc, 0), m2(nc, 0);
+                std::vector<int32_t> seen;
+                const size_t lo = nl * t / T, hi = nl * (t + 1) / T;
+                for (size_t q = lo; q < hi; q++) {
+                    const uint32_t y = leftover[q];
+                    seen.clear();
+                    for (uint64_t e = start[y]; e < start[y + 1]; e++) {
+                        const int32_t c = cluster_of[adj[e].m];
+                        if (c < 0) continue;
+                        if (c2[c]++ == 0) { seen.push_back(c); m2[c] = adj[e].s; }
+                        else if (adj[e].s < m2[c]) m2[c] = adj[e].s;
+                    }
+                    int k = 0;
+                    for (int32_t c : seen) {
+                        if (c2[c] == clusters[c].usize) {
+                            if (k < KC) cand[q * KC + k] = Cand{c, m2[c]};
+                            k++;
+                        }
+                        c2[c] = 0;
+                    }
+                    cand_cnt[q] = k <= KC ? (uint8_t)k : 255;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
+            work(0);
+            for (auto &th : pool) th.join();
+        }
+        const double t_pre = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (getenv("HMK_GREEDY_TIMING"))
+            fprintf(stderr, "[hmk greedy] phase1 %.2f ms, pre-check %.2f ms (%zu leftovers)\n", t_phase1, t_pre - t_phase1, nl);
+        const bool use_inbox = fast && symmetric_scores;
+        std::vector<int32_t> pos_of;                     // sequence -> index in `leftover`
+        std::vector<std::vector<Cand>> inbox;
+        std::vector<int32_t> joined;                     // members that joined each cluster in this loop
+        if (use_inbox) {
+            pos_of.assign(n, -1);
+            for (size_t q = 0; q < nl; q++) pos_of[leftover[q]] = (int32_t)q;
+            inbox.resize(nl);
+            joined.assign(clusters.size(), 0);
+        }
         std::vector<uint32_t> rest;
-        for (uint32_t y : leftover) {
-            Found F = nearest_cluster(y);                   // :60
-            if (F.kind == NEAR_REAL) insert_into(F.slot, y);  // :61-62 (score >= threshold by construction)
-            else rest.push_back(y);                         // :64
+        for (size_t q = 0; q < nl; q++) {
+            const uint32_t y = leftover[q];
+            Found F{NEAR_NULL, -1, 0};                                              // :60
+            if (cand_cnt[q] == 255 || !use_inbox) {
+                if (cand_cnt[q] != 0) F = nearest_cluster(y);
+            } else {
+                for (int k = 0; k < cand_cnt[q]; k++) {
+                    const Cand cd = cand[q * KC + k];
+                    int32_t got = 0, mnv = cd.mn;
+                    for (const Cand &ib : inbox[q])
+                        if (ib.c == cd.c) { got++; if (ib.mn < mnv) mnv = ib.mn; }
+                    if (got != joined[cd.c]) continue;       // some new member is not a neighbour of y
+                    if (F.kind == NEAR_NULL ||
+                        better(mnv, clusters[cd.c].size, clusters[cd.c].id, F.score, clusters[F.slot].size, clusters[F.slot].id))
+                        F = Found{NEAR_REAL, cd.c, mnv};
+                }
+            }
+            if (F.kind == NEAR_REAL) {
+                insert_into(F.slot, y);                     // :61-62 (score >= threshold by construction)
+                if (use_inbox) {
+                    joined[F.slot]++;
+                    for (uint64_t e = start[y]; e < start[y + 1]; e++) {
+                        const int32_t qw = pos_of[adj[e].m];
+                        if (qw > (int32_t)q && cand_cnt[qw] != 0 && cand_cnt[qw] != 255)
+                            inbox[qw].push_back(Cand{F.slot, adj[e].s});
+                    }
+                }
+            } else {
+                rest.push_back(y);                          // :64
+            }
+        }
+        const std::vector<uint8_t> &may_join = cand_cnt;
+        if (getenv("HMK_GREEDY_TIMING")) {
+            size_t surv = 0;
+            for (uint8_t v : may_join) surv += v != 0;
+            fprintf(stderr, "[hmk greedy] sequential part done at %.2f ms (%zu of %zu passed the pre-check)\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), surv,
+                    leftover.size());
         }
         // ---- :67-68 ---------------------------------------------------------
         int32_t out = 0;
@@ -231,6 +332,7 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         st->n_multi = (int32_t)clusters.size();
     }
     st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("HMK_GREEDY_TIMING")) fprintf(stderr, "[hmk greedy] total %.2f ms\n", st->greedy_ms);
     return HMK_OK;
 
 crash:

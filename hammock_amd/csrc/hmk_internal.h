@@ -61,7 +61,8 @@ struct Nbr {
 };
 
 // host greedy merge (hmk_greedy.cpp)
-int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, int max_clusters,
+// symmetric_scores: adj holds every edge under both ends with the same score (symmetric matrix)
+int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, bool symmetric_scores, int max_clusters,
                     int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                     std::string *err);
 int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,

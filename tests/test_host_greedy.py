@@ -127,3 +127,20 @@ def test_greedy_from_edges_musi(blosum62, coracle):
     peps = [coracle.encode(s.get_sequence_string()) for s in seqs]
     cid = run_both(coracle, blosum62, peps, None, X, 0, thr, maxc)
     assert int((np.bincount(cid) > 1).sum()) == 61
+
+
+@pytest.mark.parametrize("asym", [False, True])
+def test_greedy_from_edges_large_uses_precheck_and_inbox(blosum62, coracle, asym):
+    """> 512 leftovers: the threaded monotone pre-check and (symmetric scores) the inbox form of the
+    second loop run; the result must still equal the oracle's literal sequential greedy."""
+    rng = np.random.default_rng(9 if asym else 8)
+    M = blosum62.copy()
+    if asym:
+        M[np.triu_indices(24, 1)] += rng.integers(-1, 2, size=276).astype(np.int32)
+    peps = random_peptides(rng, 3000, 12, 12, alphabet=6)   # low complexity: dense graph, clusters keep growing
+    sizes = rng.integers(1, 4, size=len(peps)).astype(np.int32)
+    res, off = coracle.pack(peps)
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [peps[k] for k in perm]
+    cid = run_both(coracle, M, peps, sizes[perm], 3, 0, 24, 60)
+    assert cid is not None and int((np.bincount(cid) > 1).sum()) == 60
