@@ -218,13 +218,11 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         // Complete linkage is monotone: clusters only GROW in this loop, so a sequence whose neighbours
         // do not cover some cluster's members at the START of the loop can never join that cluster later.
         // (1) Pre-check, independent per sequence and read-only, on all host threads: the clusters that
-        //     are feasible against the start-of-loop membership, with their min score (at most 4 kept
+        //     are feasible against the start-of-loop membership, with their min score (at most 8 kept
         //     inline; more -> that sequence falls back to the full scan).
-        // (2) Sequential, order-dependent part (:60-62) only for the survivors.  With symmetric scores a
-        //     survivor does not rescan its neighbours: every sequence that joins a cluster pushes
-        //     (cluster, score) to its later neighbours' inboxes, and a candidate cluster is still feasible
-        //     iff the inbox holds as many entries for it as members joined since the pre-check.
-        constexpr int KC = 4;
+        // (2) Sequential, order-dependent part (:60-62) only for the survivors; with symmetric scores a
+        //     survivor does not rescan its neighbours (see "Subscribers" below).
+        constexpr int KC = 8;
         struct Cand { int32_t c, mn; };
         const size_t nl = leftover.size();
         std::vector<uint8_t> cand_cnt(nl, 255);          // 255: full scan at its turn
@@ -266,52 +264,89 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         const double t_pre = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (getenv("HMK_GREEDY_TIMING"))
             fprintf(stderr, "[hmk greedy] phase1 %.2f ms, pre-check %.2f ms (%zu leftovers)\n", t_phase1, t_pre - t_phase1, nl);
-        const bool use_inbox = fast && symmetric_scores;
-        std::vector<int32_t> pos_of;                     // sequence -> index in `leftover`
-        std::vector<std::vector<Cand>> inbox;
+        // "Subscribers": per cluster, the leftovers that listed it as a candidate.  When y joins cluster c,
+        // y's neighbours are stamped into a sequence-indexed scratch (one sequential pass over adj[y]) and
+        // only c's later subscribers are visited: a subscriber that is a neighbour of y counts one more
+        // covered member (and folds the score into its min); at its own turn a candidate is still feasible
+        // iff covered == members joined since the pre-check.
+        const bool use_subs = fast && symmetric_scores;
+        struct Sub { int32_t q; int32_t k; };            // leftover index, slot in its candidate list
+        std::vector<uint32_t> sub_start;                 // CSR of subscribers per cluster
+        std::vector<Sub> subs;
+        std::vector<int32_t> covered;                    // per (leftover, candidate slot): joined members that are neighbours
         std::vector<int32_t> joined;                     // members that joined each cluster in this loop
-        if (use_inbox) {
-            pos_of.assign(n, -1);
-            for (size_t q = 0; q < nl; q++) pos_of[leftover[q]] = (int32_t)q;
-            inbox.resize(nl);
-            joined.assign(clusters.size(), 0);
+        std::vector<uint32_t> stamp_of;                  // sequence -> stamp of the join that last touched it
+        std::vector<int32_t> stamp_score;
+        if (use_subs) {
+            const size_t nc = clusters.size();
+            sub_start.assign(nc + 1, 0);
+            for (size_t q = 0; q < nl; q++)
+                if (cand_cnt[q] != 255)
+                    for (int k = 0; k < cand_cnt[q]; k++) sub_start[cand[q * KC + k].c + 1]++;
+            for (size_t c = 0; c < nc; c++) sub_start[c + 1] += sub_start[c];
+            subs.resize(sub_start[nc]);
+            std::vector<uint32_t> fill(sub_start.begin(), sub_start.end() - 1);
+            for (size_t q = 0; q < nl; q++)
+                if (cand_cnt[q] != 255)
+                    for (int k = 0; k < cand_cnt[q]; k++) subs[fill[cand[q * KC + k].c]++] = Sub{(int32_t)q, k};
+            covered.assign(nl * KC, 0);
+            joined.assign(nc, 0);
+            stamp_of.assign(n, 0);
+            stamp_score.assign(n, 0);
         }
+        uint32_t stamp = 0;
         std::vector<uint32_t> rest;
+        double t_scan = 0, t_push = 0;
+        const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+        auto now = []() { return std::chrono::steady_clock::now(); };
         for (size_t q = 0; q < nl; q++) {
             const uint32_t y = leftover[q];
             Found F{NEAR_NULL, -1, 0};                                              // :60
-            if (cand_cnt[q] == 255 || !use_inbox) {
+            if (cand_cnt[q] == 255 || !use_subs) {
+                auto ta = now();
                 if (cand_cnt[q] != 0) F = nearest_cluster(y);
+                if (timing) t_scan += std::chrono::duration<double, std::milli>(now() - ta).count();
             } else {
                 for (int k = 0; k < cand_cnt[q]; k++) {
                     const Cand cd = cand[q * KC + k];
-                    int32_t got = 0, mnv = cd.mn;
-                    for (const Cand &ib : inbox[q])
-                        if (ib.c == cd.c) { got++; if (ib.mn < mnv) mnv = ib.mn; }
-                    if (got != joined[cd.c]) continue;       // some new member is not a neighbour of y
+                    if (covered[q * KC + k] != joined[cd.c]) continue;   // some new member is not a neighbour of y
                     if (F.kind == NEAR_NULL ||
-                        better(mnv, clusters[cd.c].size, clusters[cd.c].id, F.score, clusters[F.slot].size, clusters[F.slot].id))
-                        F = Found{NEAR_REAL, cd.c, mnv};
+                        better(cd.mn, clusters[cd.c].size, clusters[cd.c].id, F.score, clusters[F.slot].size, clusters[F.slot].id))
+                        F = Found{NEAR_REAL, cd.c, cd.mn};
                 }
             }
             if (F.kind == NEAR_REAL) {
                 insert_into(F.slot, y);                     // :61-62 (score >= threshold by construction)
-                if (use_inbox) {
+                if (use_subs) {
+                    auto tb = now();
                     joined[F.slot]++;
+                    stamp++;
                     for (uint64_t e = start[y]; e < start[y + 1]; e++) {
-                        const int32_t qw = pos_of[adj[e].m];
-                        if (qw > (int32_t)q && cand_cnt[qw] != 0 && cand_cnt[qw] != 255)
-                            inbox[qw].push_back(Cand{F.slot, adj[e].s});
+                        stamp_of[adj[e].m] = stamp;
+                        stamp_score[adj[e].m] = adj[e].s;
                     }
+                    for (uint32_t u = sub_start[F.slot]; u < sub_start[F.slot + 1]; u++) {
+                        const Sub sb = subs[u];
+                        if ((size_t)sb.q <= q) continue;    // already decided
+                        const uint32_t w = leftover[sb.q];
+                        if (stamp_of[w] != stamp) continue; // w is not a neighbour of the new member
+                        covered[(size_t)sb.q * KC + sb.k]++;
+                        Cand &cw = cand[(size_t)sb.q * KC + sb.k];
+                        if (stamp_score[w] < cw.mn) cw.mn = stamp_score[w];
+                    }
+                    if (timing) t_push += std::chrono::duration<double, std::milli>(now() - tb).count();
                 }
             } else {
                 rest.push_back(y);                          // :64
             }
         }
-        const std::vector<uint8_t> &may_join = cand_cnt;
         if (getenv("HMK_GREEDY_TIMING")) {
             size_t surv = 0;
-            for (uint8_t v : may_join) surv += v != 0;
+            size_t hist[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (uint8_t v : cand_cnt) { surv += v != 0; hist[v == 255 ? KC + 1 > 6 ? 6 : 5 : (v > 4 ? 4 : v)]++; }
+            fprintf(stderr, "[hmk greedy] full scans %.2f ms, join propagation %.2f ms (%zu subscriptions)\n", t_scan, t_push, subs.size());
+            fprintf(stderr, "[hmk greedy] candidates per sequence 0:%zu 1:%zu 2:%zu 3:%zu >=4:%zu overflow:%zu, subscribers=%d\n", hist[0],
+                    hist[1], hist[2], hist[3], hist[4], hist[5] + hist[6], (int)use_subs);
             fprintf(stderr, "[hmk greedy] sequential part done at %.2f ms (%zu of %zu passed the pre-check)\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), surv,
                     leftover.size());
