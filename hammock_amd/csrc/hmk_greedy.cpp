@@ -218,20 +218,20 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         // Complete linkage is monotone: clusters only GROW in this loop, so a sequence whose neighbours
         // do not cover some cluster's members at the START of the loop can never join that cluster later.
         // (1) Pre-check, independent per sequence and read-only, on all host threads: the clusters that
-        //     are feasible against the start-of-loop membership, with their min score (at most 8 kept
-        //     inline; more -> that sequence falls back to the full scan).
+        //     are feasible against the start-of-loop membership, with their min score (a CSR list per
+        //     sequence, filled by the threads in order).
         // (2) Sequential, order-dependent part (:60-62) only for the survivors; with symmetric scores a
         //     survivor does not rescan its neighbours (see "Subscribers" below).
-        constexpr int KC = 8;
         struct Cand { int32_t c, mn; };
         const size_t nl = leftover.size();
-        std::vector<uint8_t> cand_cnt(nl, 255);          // 255: full scan at its turn
-        std::vector<Cand> cand(nl * KC);
+        std::vector<uint32_t> cand_start(nl + 1, 0);     // CSR of candidate clusters per leftover
+        std::vector<Cand> cand;
         const bool fast = !clusters.empty() && nl > 512;
         if (fast) {
             const unsigned hw = std::thread::hardware_concurrency();
             const unsigned T = std::max(1u, std::min(16u, hw ? hw : 1u));
             const size_t nc = clusters.size();
+            std::vector<std::vector<Cand>> found(T);     // thread t covers a contiguous run of leftovers
             auto work = [&](unsigned t) {
                 std::vector<int32_t> c2(nc, 0), m2(nc, 0);
                 std::vector<int32_t> seen;
@@ -245,21 +245,21 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
                         if (c2[c]++ == 0) { seen.push_back(c); m2[c] = adj[e].s; }
                         else if (adj[e].s < m2[c]) m2[c] = adj[e].s;
                     }
-                    int k = 0;
+                    uint32_t k = 0;
                     for (int32_t c : seen) {
-                        if (c2[c] == clusters[c].usize) {
-                            if (k < KC) cand[q * KC + k] = Cand{c, m2[c]};
-                            k++;
-                        }
+                        if (c2[c] == clusters[c].usize) { found[t].push_back(Cand{c, m2[c]}); k++; }
                         c2[c] = 0;
                     }
-                    cand_cnt[q] = k <= KC ? (uint8_t)k : 255;
+                    cand_start[q + 1] = k;
                 }
             };
             std::vector<std::thread> pool;
             for (unsigned t = 1; t < T; t++) pool.emplace_back(work, t);
             work(0);
             for (auto &th : pool) th.join();
+            for (size_t q = 0; q < nl; q++) cand_start[q + 1] += cand_start[q];
+            cand.reserve(cand_start[nl]);
+            for (unsigned t = 0; t < T; t++) cand.insert(cand.end(), found[t].begin(), found[t].end());
         }
         const double t_pre = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (getenv("HMK_GREEDY_TIMING"))
@@ -270,7 +270,7 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         // covered member (and folds the score into its min); at its own turn a candidate is still feasible
         // iff covered == members joined since the pre-check.
         const bool use_subs = fast && symmetric_scores;
-        struct Sub { int32_t q; int32_t k; };            // leftover index, slot in its candidate list
+        struct Sub { int32_t q; int32_t k; };            // leftover index, index of the candidate in `cand`
         std::vector<uint32_t> sub_start;                 // CSR of subscribers per cluster
         std::vector<Sub> subs;
         std::vector<int32_t> covered;                    // per (leftover, candidate slot): joined members that are neighbours
@@ -280,16 +280,13 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         if (use_subs) {
             const size_t nc = clusters.size();
             sub_start.assign(nc + 1, 0);
-            for (size_t q = 0; q < nl; q++)
-                if (cand_cnt[q] != 255)
-                    for (int k = 0; k < cand_cnt[q]; k++) sub_start[cand[q * KC + k].c + 1]++;
+            for (const Cand &cd : cand) sub_start[cd.c + 1]++;
             for (size_t c = 0; c < nc; c++) sub_start[c + 1] += sub_start[c];
             subs.resize(sub_start[nc]);
             std::vector<uint32_t> fill(sub_start.begin(), sub_start.end() - 1);
             for (size_t q = 0; q < nl; q++)
-                if (cand_cnt[q] != 255)
-                    for (int k = 0; k < cand_cnt[q]; k++) subs[fill[cand[q * KC + k].c]++] = Sub{(int32_t)q, k};
-            covered.assign(nl * KC, 0);
+                for (uint32_t k = cand_start[q]; k < cand_start[q + 1]; k++) subs[fill[cand[k].c]++] = Sub{(int32_t)q, (int32_t)k};
+            covered.assign(cand.size(), 0);
             joined.assign(nc, 0);
             stamp_of.assign(n, 0);
             stamp_score.assign(n, 0);
@@ -302,14 +299,14 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         for (size_t q = 0; q < nl; q++) {
             const uint32_t y = leftover[q];
             Found F{NEAR_NULL, -1, 0};                                              // :60
-            if (cand_cnt[q] == 255 || !use_subs) {
+            if (!use_subs) {
                 auto ta = now();
-                if (cand_cnt[q] != 0) F = nearest_cluster(y);
+                if (!fast || cand_start[q + 1] > cand_start[q]) F = nearest_cluster(y);
                 if (timing) t_scan += std::chrono::duration<double, std::milli>(now() - ta).count();
             } else {
-                for (int k = 0; k < cand_cnt[q]; k++) {
-                    const Cand cd = cand[q * KC + k];
-                    if (covered[q * KC + k] != joined[cd.c]) continue;   // some new member is not a neighbour of y
+                for (uint32_t k = cand_start[q]; k < cand_start[q + 1]; k++) {
+                    const Cand cd = cand[k];
+                    if (covered[k] != joined[cd.c]) continue;            // some new member is not a neighbour of y
                     if (F.kind == NEAR_NULL ||
                         better(cd.mn, clusters[cd.c].size, clusters[cd.c].id, F.score, clusters[F.slot].size, clusters[F.slot].id))
                         F = Found{NEAR_REAL, cd.c, cd.mn};
@@ -330,8 +327,8 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
                         if ((size_t)sb.q <= q) continue;    // already decided
                         const uint32_t w = leftover[sb.q];
                         if (stamp_of[w] != stamp) continue; // w is not a neighbour of the new member
-                        covered[(size_t)sb.q * KC + sb.k]++;
-                        Cand &cw = cand[(size_t)sb.q * KC + sb.k];
+                        covered[sb.k]++;
+                        Cand &cw = cand[sb.k];
                         if (stamp_score[w] < cw.mn) cw.mn = stamp_score[w];
                     }
                     if (timing) t_push += std::chrono::duration<double, std::milli>(now() - tb).count();
@@ -342,11 +339,9 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         }
         if (getenv("HMK_GREEDY_TIMING")) {
             size_t surv = 0;
-            size_t hist[7] = {0, 0, 0, 0, 0, 0, 0};
-            for (uint8_t v : cand_cnt) { surv += v != 0; hist[v == 255 ? KC + 1 > 6 ? 6 : 5 : (v > 4 ? 4 : v)]++; }
-            fprintf(stderr, "[hmk greedy] full scans %.2f ms, join propagation %.2f ms (%zu subscriptions)\n", t_scan, t_push, subs.size());
-            fprintf(stderr, "[hmk greedy] candidates per sequence 0:%zu 1:%zu 2:%zu 3:%zu >=4:%zu overflow:%zu, subscribers=%d\n", hist[0],
-                    hist[1], hist[2], hist[3], hist[4], hist[5] + hist[6], (int)use_subs);
+            for (size_t q = 0; q < nl; q++) surv += !fast || cand_start[q + 1] > cand_start[q];
+            fprintf(stderr, "[hmk greedy] full scans %.2f ms, join propagation %.2f ms (%zu candidate subscriptions, subscribers=%d)\n",
+                    t_scan, t_push, subs.size(), (int)use_subs);
             fprintf(stderr, "[hmk greedy] sequential part done at %.2f ms (%zu of %zu passed the pre-check)\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), surv,
                     leftover.size());
