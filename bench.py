@@ -215,8 +215,8 @@ def main():
                                    f"{MAX_SHIFT}, shift_penalty {SHIFT_PENALTY}, threshold {THRESHOLD}; "
                                    f"{pairs_total} unordered pairs per step",
                        "parallelism": f"row-block sharding over {world} GPU(s)" + (
-                           ", per-step RCCL all-gather of the edge blocks on a second stream (overlaps the next pass)"
-                           if world > 1 else "")},
+                           ", per-step RCCL all-gather of the edge blocks (4-byte row-block format) on a second stream "
+                           "(overlaps the next pass)" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
                          "kernel": "k_neighbors_swar<2, 6, 2, 12, true> (NW=2 dwords/entry, 6 rows/tile, 2 columns/lane, length 12 exact)",
@@ -228,6 +228,9 @@ def main():
                                  "definition": "12 ds_read_b64 table lookups per pair / (32 lanes/clk/CU x 256 CU x 2.4 GHz)"}},
             "edges_per_step": int(tot_edges.item()),
         }
+        if px is not None:
+            line["exchange"] = {"format": px.fmt, "gathered_bytes_per_rank_per_step": px.bytes_per_step,
+                                "collectives_per_step": 2}
         if world == 1:
             if not args.no_greedy:
                 t = time.perf_counter()

@@ -27,7 +27,8 @@ HMK_MAX_LEN = 32
 SYMBOLS = [
     "hmk_abi_version", "hmk_last_kernel_ms", "hmk_create", "hmk_destroy", "hmk_last_error", "hmk_set_sequences",
     "hmk_score_pairs_shifted", "hmk_score_with_shift", "hmk_score_pairs_local", "hmk_score_block_shifted", "hmk_score_block_local",
-    "hmk_neighbors_shifted", "hmk_neighbors_local", "hmk_neighbors_shifted_dev", "hmk_compact_edges_dev", "hmk_neighbors_last_plan",
+    "hmk_neighbors_shifted", "hmk_neighbors_local", "hmk_neighbors_shifted_dev", "hmk_compact_edges_dev", "hmk_pack_rows_dev", "hmk_unpack_rows_dev",
+    "hmk_neighbors_last_plan",
     "hmk_greedy_cluster", "hmk_greedy_from_edges",
 ]
 
@@ -84,6 +85,8 @@ def _load():
     L.hmk_neighbors_local.argtypes = [vp, i32, i32, i32, u32, u32, p_u64, u64, p_u64, C.POINTER(NeighborStats)]
     L.hmk_neighbors_shifted_dev.argtypes = [vp, i32, i32, i32, u32, u32, vp, u64, vp, vp]
     L.hmk_compact_edges_dev.argtypes = [vp, vp, u64, vp, vp, u64, vp, vp]
+    L.hmk_pack_rows_dev.argtypes = [vp, vp, u64, vp, i32, vp, vp, u64, vp]
+    L.hmk_unpack_rows_dev.argtypes = [vp, vp, vp, i32, vp, u64, vp]
     L.hmk_neighbors_last_plan.argtypes = [vp, C.POINTER(NeighborStats)]
     L.hmk_greedy_cluster.argtypes = [vp, i32, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
     L.hmk_greedy_from_edges.argtypes = [vp, p_u64, u64, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]

@@ -247,6 +247,18 @@ class Context:
         if st:
             self._raise(st)
 
+    def pack_rows_dev(self, d_edges_ptr, capacity, d_counts_ptr, threshold, d_row_start_ptr, d_adj_ptr, adj_capacity, stream=0):
+        st = N.lib.hmk_pack_rows_dev(self._h, C.c_void_p(d_edges_ptr), int(capacity), C.c_void_p(d_counts_ptr), int(threshold),
+                                     C.c_void_p(d_row_start_ptr), C.c_void_p(d_adj_ptr), int(adj_capacity), C.c_void_p(stream))
+        if st:
+            self._raise(st)
+
+    def unpack_rows_dev(self, d_row_start_ptr, d_adj_ptr, threshold, d_edges_out_ptr, out_capacity, stream=0):
+        st = N.lib.hmk_unpack_rows_dev(self._h, C.c_void_p(d_row_start_ptr), C.c_void_p(d_adj_ptr), int(threshold),
+                                       C.c_void_p(d_edges_out_ptr), int(out_capacity), C.c_void_p(stream))
+        if st:
+            self._raise(st)
+
     def last_plan(self):
         stats = N.NeighborStats()
         st = N.lib.hmk_neighbors_last_plan(self._h, C.byref(stats))

@@ -84,6 +84,8 @@ struct hmk_ctx {
     uint64_t *d_edges = nullptr;  // internal buffer of the host-buffer entry points
     uint64_t d_edges_cap = 0;
     unsigned long long *d_counts = nullptr;
+    uint32_t *d_rows_scratch = nullptr;  // deg[n], cursor[n], misfit of hmk_pack_rows_dev
+    uint32_t d_rows_scratch_n = 0;
 
     double last_kernel_ms = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -255,10 +257,18 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                 const uint32_t nr = std::min(R, re - r0);
                 uint32_t c_lo = cb, c_hi = ce;
                 if (same && ctx->symmetric) c_lo = r0 + 1;  // triangle: columns after the first row of the chunk
-                for (uint32_t c0 = c_lo; c0 < c_hi; c0 += COLS) {
+                // equal column runs (whole 256-column batches) instead of full runs + one short rest:
+                // no tiny tiles whose table build is not amortised, and an even tail
+                uint32_t run = COLS;
+                if (c_hi > c_lo && getenv("HMK_NO_EQUAL_RUNS") == nullptr) {
+                    const uint32_t k_runs = (c_hi - c_lo + COLS - 1) / COLS;
+                    run = ((c_hi - c_lo + k_runs - 1) / k_runs + 255u) & ~255u;
+                    run = std::min(run, COLS);
+                }
+                for (uint32_t c0 = c_lo; c0 < c_hi; c0 += run) {
                     Tile t{};
                     t.row0 = r0; t.nrows = nr;
-                    t.col0 = c0; t.ncols = std::min(COLS, c_hi - c0);
+                    t.col0 = c0; t.ncols = std::min(run, c_hi - c0);
                     t.cls = (uint32_t)cls;
                     const bool overlap = same && c0 < r0 + nr && c0 + t.ncols > r0;
                     t.diag = overlap ? (ctx->symmetric ? 1u : 2u) : 0u;
@@ -283,6 +293,11 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     std::vector<Tile> tiles;
     for (auto &kv : grouped) {
         if (kv.second.empty()) continue;
+        // workgroups are dispatched in tile order: biggest tiles first keeps the tail of the launch short
+        if (getenv("HMK_NO_LPT") == nullptr)
+            std::stable_sort(kv.second.begin(), kv.second.end(), [](const Tile &a, const Tile &b) {
+                return (uint64_t)a.nrows * a.ncols > (uint64_t)b.nrows * b.ncols;
+            });
         pl.groups.push_back(Group{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),
                                   (uint32_t)tiles.size(), (uint32_t)kv.second.size()});
         tiles.insert(tiles.end(), kv.second.begin(), kv.second.end());
@@ -689,6 +704,7 @@ void hmk_destroy(hmk_ctx *ctx) {
         if (ctx->d_M) (void)hipFree(ctx->d_M);
         if (ctx->d_edges) (void)hipFree(ctx->d_edges);
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+        if (ctx->d_rows_scratch) (void)hipFree(ctx->d_rows_scratch);
         if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
         if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -803,6 +819,45 @@ int hmk_compact_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t capacity, 
     return HMK_OK;
 }
 
+int hmk_pack_rows_dev(hmk_ctx *ctx, const void *d_edges, uint64_t capacity, const void *d_counts, int threshold,
+                      void *d_row_start, void *d_adj, uint64_t adj_capacity, void *stream) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int st = need_device(ctx);
+    if (st) return st;
+    if (!d_edges || !d_counts || !d_row_start || !d_adj || capacity < HMK_EDGE_SHARDS)
+        return fail(ctx, HMK_ERR_BAD_ARG, "hmk_pack_rows_dev: null buffer or capacity < HMK_EDGE_SHARDS");
+    if (!ctx->n) return fail(ctx, HMK_ERR_NO_SEQUENCES, "hmk_pack_rows_dev: no sequences set");
+    if (adj_capacity > 0xFFFFFFFFull) return fail(ctx, HMK_ERR_BAD_ARG, "hmk_pack_rows_dev: row offsets are 32 bit");
+    if (ctx->d_rows_scratch_n < ctx->n) {
+        if (ctx->d_rows_scratch) {
+            HIPCHK(ctx, hipDeviceSynchronize());  // an earlier call may still be using the old scratch
+            (void)hipFree(ctx->d_rows_scratch);
+            ctx->d_rows_scratch = nullptr;
+            ctx->d_rows_scratch_n = 0;
+        }
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_rows_scratch, pack_rows_scratch_bytes(ctx->n)));
+        ctx->d_rows_scratch_n = ctx->n;
+    }
+    HIPCHK(ctx, launch_pack_rows((const uint64_t *)d_edges, capacity / HMK_EDGE_SHARDS, (const unsigned long long *)d_counts,
+                                 ctx->n, threshold, ctx->d_rows_scratch, (uint32_t *)d_row_start, (uint32_t *)d_adj,
+                                 adj_capacity, (hipStream_t)stream));
+    return HMK_OK;
+}
+
+int hmk_unpack_rows_dev(hmk_ctx *ctx, const void *d_row_start, const void *d_adj, int threshold, void *d_edges_out,
+                        uint64_t out_capacity, void *stream) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int st = need_device(ctx);
+    if (st) return st;
+    if (!d_row_start || !d_adj || !d_edges_out) return fail(ctx, HMK_ERR_BAD_ARG, "hmk_unpack_rows_dev: null buffer");
+    if (!ctx->n) return fail(ctx, HMK_ERR_NO_SEQUENCES, "hmk_unpack_rows_dev: no sequences set");
+    HIPCHK(ctx, launch_unpack_rows((const uint32_t *)d_row_start, (const uint32_t *)d_adj, ctx->n, threshold,
+                                   (uint64_t *)d_edges_out, out_capacity, (hipStream_t)stream));
+    return HMK_OK;
+}
+
 int hmk_neighbors_last_plan(hmk_ctx *ctx, hmk_neighbor_stats *stats) {
     if (!ctx || !stats) return fail(ctx, HMK_ERR_BAD_ARG, "null argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -909,9 +964,10 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     const uint64_t n_adj = ctx->symmetric ? 2 * total : total;
     const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
     uint32_t *d_deg = nullptr, *d_cursor = nullptr;
-    uint64_t *d_start = nullptr;
+    uint64_t *d_start = nullptr, *d_tiles = nullptr;
     Nbr *d_adj = nullptr;
     auto cleanup = [&]() {
+        if (d_tiles) (void)hipFree(d_tiles);
         if (d_deg) (void)hipFree(d_deg);
         if (d_cursor) (void)hipFree(d_cursor);
         if (d_start) (void)hipFree(d_start);
@@ -920,10 +976,11 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     hipError_t e = hipMalloc((void **)&d_deg, (size_t)n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, (size_t)n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_start, ((size_t)n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_tiles, scan_scratch_bytes(n));
     if (e == hipSuccess) e = hipMalloc((void **)&d_adj, std::max<uint64_t>(n_adj, 1) * sizeof(Nbr));
     if (e == hipSuccess) e = hipMemsetAsync(d_deg, 0, (size_t)n * 4, nullptr);
     if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)n * 4, nullptr);
-    if (e == hipSuccess) e = launch_csr_degree_scan(ctx->d_edges, seg, ctx->d_counts, n, ctx->symmetric, d_deg, d_start, nullptr);
+    if (e == hipSuccess) e = launch_csr_degree_scan(ctx->d_edges, seg, ctx->d_counts, n, ctx->symmetric, d_deg, d_start, d_tiles, nullptr);
     if (e == hipSuccess) e = launch_csr_scatter(ctx->d_edges, seg, ctx->d_counts, ctx->symmetric, d_start, d_cursor, d_adj, nullptr);
     if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + n_adj * sizeof(Nbr)) {
         if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);

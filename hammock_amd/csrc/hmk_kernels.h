@@ -31,12 +31,22 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
 
 // edge segments -> CSR (start[n + 1], adj[]) on the device: deg and cursor are zeroed uint32[n] scratch
 hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
-                                  bool symmetric, uint32_t *deg, uint64_t *start, hipStream_t s);
+                                  bool symmetric, uint32_t *deg, uint64_t *start, uint64_t *tile_scratch, hipStream_t s);
+size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
+size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                               bool symmetric, const uint64_t *start, uint32_t *cursor, Nbr *adj, hipStream_t s);
 
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);
+
+// edge segments <-> "row blocks" (uint32 row_start[n + 2], uint32 adj[] = m << 8 | score - threshold);
+// scratch: pack_rows_scratch_bytes(n), used in stream order
+hipError_t launch_pack_rows(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
+                            int threshold, uint32_t *scratch, uint32_t *row_start, uint32_t *adj, uint64_t adj_capacity,
+                            hipStream_t s);
+hipError_t launch_unpack_rows(const uint32_t *row_start, const uint32_t *adj, uint32_t n, int threshold, uint64_t *out,
+                              uint64_t out_capacity, hipStream_t s);
 
 // LocalAlignmentScorer dense block, register-resident DP (needs |M| <= 127, gap penalties <= 0, len <= lbmax)
 // enc: the tagged-max DP (needs |M| <= 31 and -31 <= gap penalties <= 0)

@@ -974,13 +974,32 @@ k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const 
     }
 }
 
-__global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t *__restrict__ deg, uint64_t *__restrict__ start, uint32_t n) {
+// Exclusive scan of deg[n] -> start[n + 1] in three coalesced passes over tiles of 2048 counters:
+// tile sums, scan of the tile sums (one block), tile-local scan + offset.  T = uint32 or uint64.
+constexpr uint32_t SCAN_TILE = 2048;
+
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *__restrict__ deg, uint64_t *__restrict__ tile_sum, uint32_t n) {
+    __shared__ uint64_t red[4];
+    const uint32_t base = blockIdx.x * SCAN_TILE;
+    uint64_t v = 0;
+    for (uint32_t j = 0; j < SCAN_TILE / 256; j++) {
+        const uint32_t k = base + j * 256 + threadIdx.x;
+        if (k < n) v += deg[k];
+    }
+    for (int o = 32; o; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// one block: exclusive scan of the n_tiles tile sums in place; tile_sum[n_tiles] = grand total
+__global__ void __launch_bounds__(1024) k_scan_tile_offsets(uint64_t *__restrict__ tile_sum, uint32_t n_tiles) {
     __shared__ uint64_t part[1024];
     const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = (n + 1023) / 1024;
-    const uint32_t lo = min(n, tid * chunk), hi = min(n, lo + chunk);
+    const uint32_t chunk = (n_tiles + 1023) / 1024;
+    const uint32_t lo = min(n_tiles, tid * chunk), hi = min(n_tiles, lo + chunk);
     uint64_t sum = 0;
-    for (uint32_t k = lo; k < hi; k++) sum += deg[k];
+    for (uint32_t k = lo; k < hi; k++) sum += tile_sum[k];
     part[tid] = sum;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
@@ -990,8 +1009,56 @@ __global__ void __launch_bounds__(1024) k_scan_exclusive(const uint32_t *__restr
         __syncthreads();
     }
     uint64_t run = tid ? part[tid - 1] : 0;
-    for (uint32_t k = lo; k < hi; k++) { start[k] = run; run += deg[k]; }
-    if (tid == 1023) start[n] = part[1023];
+    for (uint32_t k = lo; k < hi; k++) { const uint64_t d = tile_sum[k]; tile_sum[k] = run; run += d; }
+    if (tid == 1023) tile_sum[n_tiles] = part[1023];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_scan_tiles(const uint32_t *__restrict__ deg, const uint64_t *__restrict__ tile_off, T *__restrict__ start, uint32_t n,
+             uint32_t n_tiles, const uint32_t *__restrict__ tail_word) {
+    __shared__ uint32_t v[SCAN_TILE];
+    __shared__ uint32_t wsum[4];
+    const uint32_t base = blockIdx.x * SCAN_TILE, tid = threadIdx.x;
+    for (uint32_t j = 0; j < SCAN_TILE / 256; j++) {  // coalesced load
+        const uint32_t k = base + j * 256 + tid;
+        v[j * 256 + tid] = k < n ? deg[k] : 0;
+    }
+    __syncthreads();
+    uint32_t loc[SCAN_TILE / 256], sum = 0;           // thread tid owns the 8 consecutive counters tid * 8 ..
+    for (uint32_t j = 0; j < SCAN_TILE / 256; j++) { loc[j] = sum; sum += v[tid * (SCAN_TILE / 256) + j]; }
+    uint32_t inc = sum;                               // inclusive scan of the thread sums inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= (uint32_t)o) inc += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (uint32_t w = 0; w < (tid >> 6); w++) woff += wsum[w];
+    const uint32_t excl = woff + inc - sum;
+    __syncthreads();
+    for (uint32_t j = 0; j < SCAN_TILE / 256; j++) v[tid * (SCAN_TILE / 256) + j] = excl + loc[j];
+    __syncthreads();
+    const uint64_t off = tile_off[blockIdx.x];
+    for (uint32_t j = 0; j < SCAN_TILE / 256; j++) {  // coalesced store
+        const uint32_t k = base + j * 256 + tid;
+        if (k < n) start[k] = (T)(off + v[j * 256 + tid]);
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        start[n] = (T)tile_off[n_tiles];
+        if (tail_word) start[n + 1] = (T)*tail_word;
+    }
+}
+
+// tile_scratch: uint64[ceil(n / SCAN_TILE) + 1]
+template <typename T>
+static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *tile_scratch, const uint32_t *tail_word,
+                        hipStream_t s) {
+    const uint32_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, deg, tile_scratch, n);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(1024), 0, s, tile_scratch, n_tiles);
+    hipLaunchKernelGGL((k_scan_tiles<T>), dim3(n_tiles), dim3(256), 0, s, deg, tile_scratch, start, n, n_tiles, tail_word);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1026,6 +1093,119 @@ k_compact_edges(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, cons
     const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
     for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256)
         if (base + k < out_capacity) out[base + k] = seg[k];
+}
+
+// -----------------------------------------------------------------------------
+// "row blocks": the 4-byte-per-edge exchange format of the multi-GPU path
+// -----------------------------------------------------------------------------
+// A rank's edge segments regrouped by x: row_start[n + 2] (uint32; [n] = total, [n + 1] =
+// number of edges whose score - threshold did not fit 8 bits, must be 0) and one uint32 per
+// edge, m << 8 | (score - threshold).  Halves the bytes the all-gather ships over xGMI.
+// One atomicAdd per distinct key of a wave instead of one per lane (a wave's 64 consecutive edges come
+// from a handful of tile rows).  wave_groups() finds, without touching memory, each lane's group
+// (lanes holding the same key): the group's first lane, this lane's rank in it and the group size.
+// Must be called by all 64 lanes (wave-uniform control flow); lanes with valid == false take no part.
+struct WaveGroup { uint32_t leader, rank, size; };
+__device__ __forceinline__ WaveGroup wave_groups(uint32_t key, bool valid) {
+    const uint32_t lane = threadIdx.x & 63;
+    WaveGroup g{lane, 0, 0};
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const bool mine = valid && key == k0;
+        const uint64_t same = __ballot(mine);
+        if (mine) {
+            g.leader = (uint32_t)leader;
+            g.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            g.size = (uint32_t)__popcll(same);
+        }
+        todo &= ~same;
+    }
+    return g;
+}
+
+constexpr int ROWS_UNROLL = 4;  // independent 64-edge groups per wave iteration (memory-level parallelism)
+
+__global__ void __launch_bounds__(256)
+k_rows_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
+              uint32_t *__restrict__ deg, uint32_t *__restrict__ misfit, int threshold) {
+    const uint32_t shard = blockIdx.y, lane = threadIdx.x & 63;
+    const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
+    const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t k0 = wave * (64 * ROWS_UNROLL); k0 < cnt; k0 += n_waves * (64 * ROWS_UNROLL)) {
+        uint64_t e[ROWS_UNROLL];
+        bool valid[ROWS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ROWS_UNROLL; u++) {
+            const uint64_t k = k0 + u * 64 + lane;
+            valid[u] = k < cnt;
+            e[u] = valid[u] ? seg[k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < ROWS_UNROLL; u++) {
+            const uint32_t x = HMK_EDGE_X(e[u]);
+            const WaveGroup g = wave_groups(x, valid[u]);
+            if (valid[u] && g.rank == 0) atomicAdd(&deg[x], g.size);
+            const int32_t rel = HMK_EDGE_SCORE(e[u]) - threshold;
+            if (valid[u] && (rel < 0 || rel > 255)) atomicAdd(misfit, 1u);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_rows_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
+               const uint32_t *__restrict__ start, uint32_t *__restrict__ cursor, uint32_t *__restrict__ adj,
+               uint64_t adj_capacity, int threshold) {
+    const uint32_t shard = blockIdx.y, lane = threadIdx.x & 63;
+    const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
+    const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4;
+    for (uint64_t k0 = wave * (64 * ROWS_UNROLL); k0 < cnt; k0 += n_waves * (64 * ROWS_UNROLL)) {
+        uint64_t e[ROWS_UNROLL];
+        bool valid[ROWS_UNROLL];
+        WaveGroup g[ROWS_UNROLL];
+        uint32_t base[ROWS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ROWS_UNROLL; u++) {
+            const uint64_t k = k0 + u * 64 + lane;
+            valid[u] = k < cnt;
+            e[u] = valid[u] ? seg[k] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < ROWS_UNROLL; u++) {  // the group leaders' atomics of all groups are in flight together
+            const uint32_t x = HMK_EDGE_X(e[u]);
+            g[u] = wave_groups(x, valid[u]);
+            base[u] = 0;
+            if (valid[u] && g[u].rank == 0) base[u] = start[x] + atomicAdd(&cursor[x], g[u].size);
+        }
+#pragma unroll
+        for (int u = 0; u < ROWS_UNROLL; u++) {
+            const uint32_t b = (uint32_t)__shfl((int)base[u], (int)g[u].leader, 64);
+            if (valid[u]) {
+                const uint64_t pos = (uint64_t)b + g[u].rank;
+                if (pos < adj_capacity)
+                    adj[pos] = (HMK_EDGE_M(e[u]) << 8) | (uint32_t)((HMK_EDGE_SCORE(e[u]) - threshold) & 0xFF);
+            }
+        }
+    }
+}
+
+// row blocks -> packed 8-byte edges, out[start[x] + k]; one wave per row, rows strided over the grid
+__global__ void __launch_bounds__(256)
+k_rows_unpack(const uint32_t *__restrict__ start, const uint32_t *__restrict__ adj, uint32_t n, int threshold,
+              uint64_t *__restrict__ out, uint64_t out_capacity) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (uint32_t x = wave; x < n; x += n_waves) {
+        const uint32_t b = start[x], e = start[x + 1];
+        for (uint32_t k = b + lane; k < e; k += 64) {
+            const uint32_t a = adj[k];
+            const int32_t sc = (int32_t)(a & 0xFF) + threshold;
+            if (k < out_capacity) out[k] = ((uint64_t)x << 40) | ((uint64_t)(a >> 8) << 16) | (uint64_t)(uint16_t)(int16_t)sc;
+        }
+    }
 }
 
 // -----------------------------------------------------------------------------
@@ -1114,10 +1294,10 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
 }
 
 hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
-                                  bool symmetric, uint32_t *deg, uint64_t *start, hipStream_t s) {
+                                  bool symmetric, uint32_t *deg, uint64_t *start, uint64_t *tile_scratch, hipStream_t s) {
     hipLaunchKernelGGL(k_edge_degree, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg,
                        symmetric ? 1 : 0);
-    hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, s, deg, start, n);
+    launch_scan<uint64_t>(deg, start, n, tile_scratch, nullptr, s);
     return hipGetLastError();
 }
 
@@ -1132,6 +1312,31 @@ hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, c
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s) {
     hipLaunchKernelGGL(k_compact_edges, dim3(128, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, out,
                        out_capacity, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_rows(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
+                            int threshold, uint32_t *scratch, uint32_t *row_start, uint32_t *adj, uint64_t adj_capacity,
+                            hipStream_t s) {
+    // scratch: uint32 deg[n], cursor[n], misfit, pad to 8 bytes, then the scan's uint64 tile sums
+    hipError_t e = hipMemsetAsync(scratch, 0, ((size_t)2 * n + 1) * 4, s);
+    if (e != hipSuccess) return e;
+    uint32_t *deg = scratch, *cursor = scratch + n, *misfit = scratch + 2 * (size_t)n;
+    uint64_t *tile_scratch = (uint64_t *)(scratch + 2 * (size_t)n + 2);
+    hipLaunchKernelGGL(k_rows_degree, dim3(128, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg, misfit,
+                       threshold);
+    launch_scan<uint32_t>(deg, row_start, n, tile_scratch, misfit, s);
+    hipLaunchKernelGGL(k_rows_scatter, dim3(128, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, row_start,
+                       cursor, adj, adj_capacity, threshold);
+    return hipGetLastError();
+}
+
+size_t pack_rows_scratch_bytes(uint32_t n) { return ((size_t)2 * n + 2) * 4 + scan_scratch_bytes(n); }
+size_t scan_scratch_bytes(uint32_t n) { return ((size_t)(n + SCAN_TILE - 1) / SCAN_TILE + 1) * 8; }
+
+hipError_t launch_unpack_rows(const uint32_t *row_start, const uint32_t *adj, uint32_t n, int threshold, uint64_t *out,
+                              uint64_t out_capacity, hipStream_t s) {
+    hipLaunchKernelGGL(k_rows_unpack, dim3(1024), dim3(256), 0, s, row_start, adj, n, threshold, out, out_capacity);
     return hipGetLastError();
 }
 

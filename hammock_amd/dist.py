@@ -112,23 +112,36 @@ def greedy_cluster_distributed(ctx: Context, max_shift, shift_penalty, threshold
 class PipelinedExchange:
     """Steady-state form of score -> exchange for repeated passes (bench.py, N > 1 ranks).
 
-    No host round trip inside a step: the neighbour kernel runs on a compute stream; a tiny
-    device kernel packs its 16 output segments into one block (hmk_compact_edges_dev) and ONE
-    fixed-size all_gather_into_tensor ships it on a communication stream, double buffered so the
-    exchange of pass k overlaps the scoring of pass k + 1.  The block size `pad` is the largest
-    per-rank edge count (identical every pass for the same input), found by one warm-up pass."""
+    No host round trip inside a step: the neighbour kernel runs on a compute stream; on a
+    communication stream small device kernels turn its 16 output segments into one exchange block and
+    fixed-size all_gather_into_tensor calls ship it, double buffered so the exchange of pass k overlaps
+    the scoring of pass k + 1.  Two block formats:
 
-    def __init__(self, ctx: Context, max_shift, shift_penalty, threshold, rank, world, device, group=None):
+      "rows"   (default) 4 bytes per edge: hmk_pack_rows_dev groups the edges by x into
+               row_start[n + 2] + adj[] = m << 8 | score - threshold; half the xGMI bytes
+      "edges"  8 bytes per edge: hmk_compact_edges_dev, the packed edges as they are
+
+    The block size `pad` is the largest per-rank edge count (identical every pass for the same input),
+    found by one warm-up pass."""
+
+    def __init__(self, ctx: Context, max_shift, shift_penalty, threshold, rank, world, device, group=None, fmt="rows",
+                 shard=None):
+        if fmt not in ("rows", "edges"):
+            raise ValueError(fmt)
         self.ctx, self.args = ctx, (int(max_shift), int(shift_penalty), int(threshold))
-        self.rank, self.world, self.device, self.group = rank, world, device, group
+        self.rank, self.world, self.device, self.group, self.fmt = rank, world, device, group, fmt
+        # shard = (part, n_parts) of the pair space this rank scores; default: one shard per rank.
+        # (tools/px_step_time.py overrides it to time a 1/8 shard's step on a single GPU.)
+        self.part, self.n_parts = shard if shard is not None else (rank, world)
         n = ctx.n
-        self.capacity = ((int(n * (n - 1) // 2 * 6e-3 / world) + (1 << 20)) // N.HMK_EDGE_SHARDS + 1) * N.HMK_EDGE_SHARDS
+        self.capacity = ((int(n * (n - 1) // 2 * 6e-3 / self.n_parts) + (1 << 20)) // N.HMK_EDGE_SHARDS + 1) * N.HMK_EDGE_SHARDS
         self.comp = torch.cuda.Stream(device)
         self.comm = torch.cuda.Stream(device)
         self.buf = [self._alloc_score() for _ in range(2)]
         # warm-up pass sizes the exchange block
         e, c = self.buf[0]
-        ctx.neighbors_shifted_dev(*self.args, rank, world, e.data_ptr(), self.capacity, c.data_ptr(), self.comp.cuda_stream)
+        ctx.neighbors_shifted_dev(*self.args, self.part, self.n_parts, e.data_ptr(), self.capacity, c.data_ptr(),
+                                  self.comp.cuda_stream)
         self.comp.synchronize()
         cnt = c.tolist()
         if max(cnt) > self.capacity // N.HMK_EDGE_SHARDS:
@@ -138,12 +151,22 @@ class PipelinedExchange:
         if world > 1:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
         self.pad = int(mx.item()) + 64
-        self.block = [torch.zeros(self.pad, dtype=torch.int64, device=device) for _ in range(2)]
-        self.total = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(2)]
-        self.gathered = [torch.empty(world * self.pad, dtype=torch.int64, device=device) for _ in range(2)]
-        self.totals_all = [torch.zeros(world, dtype=torch.int64, device=device) for _ in range(2)]
+        if fmt == "rows":
+            # block = adj (uint32 per edge); head = row_start[n + 2]
+            self.block = [torch.zeros(self.pad, dtype=torch.int32, device=device) for _ in range(2)]
+            self.head = [torch.zeros(n + 2, dtype=torch.int32, device=device) for _ in range(2)]
+            self.gathered = [torch.empty(world * self.pad, dtype=torch.int32, device=device) for _ in range(2)]
+            self.heads_all = [torch.zeros(world * (n + 2), dtype=torch.int32, device=device) for _ in range(2)]
+        else:
+            # block = packed edges; head = the valid count
+            self.block = [torch.zeros(self.pad, dtype=torch.int64, device=device) for _ in range(2)]
+            self.head = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(2)]
+            self.gathered = [torch.empty(world * self.pad, dtype=torch.int64, device=device) for _ in range(2)]
+            self.heads_all = [torch.zeros(world, dtype=torch.int64, device=device) for _ in range(2)]
+        self.bytes_per_step = (self.gathered[0].numel() * self.gathered[0].element_size()
+                               + self.heads_all[0].numel() * self.heads_all[0].element_size())
         self.scored = [torch.cuda.Event() for _ in range(2)]
-        self.shipped = [torch.cuda.Event() for _ in range(2)]
+        self.packed = [torch.cuda.Event() for _ in range(2)]
         self.k = 0
 
     def _alloc_score(self):
@@ -156,25 +179,30 @@ class PipelinedExchange:
         b = self.k & 1
         e, c = self.buf[b]
         if self.k >= 2:
-            self.comp.wait_event(self.shipped[b])  # buffer b was shipped two passes ago
+            self.comp.wait_event(self.packed[b])  # score buffer b was packed into its block two passes ago
         if t0 is not None:
             t0.record(self.comp)
-        self.ctx.neighbors_shifted_dev(*self.args, self.rank, self.world, e.data_ptr(), self.capacity, c.data_ptr(),
+        self.ctx.neighbors_shifted_dev(*self.args, self.part, self.n_parts, e.data_ptr(), self.capacity, c.data_ptr(),
                                        self.comp.cuda_stream)
         if t1 is not None:
             t1.record(self.comp)
         self.scored[b].record(self.comp)
         self.comm.wait_event(self.scored[b])
         with torch.cuda.stream(self.comm):
-            self.ctx.compact_edges_dev(e.data_ptr(), self.capacity, c.data_ptr(), self.block[b].data_ptr(), self.pad,
-                                       self.total[b].data_ptr(), self.comm.cuda_stream)
+            # block[b] / head[b] / gathered[b] are only touched on the communication stream (serial)
+            if self.fmt == "rows":
+                self.ctx.pack_rows_dev(e.data_ptr(), self.capacity, c.data_ptr(), self.args[2], self.head[b].data_ptr(),
+                                       self.block[b].data_ptr(), self.pad, self.comm.cuda_stream)
+            else:
+                self.ctx.compact_edges_dev(e.data_ptr(), self.capacity, c.data_ptr(), self.block[b].data_ptr(), self.pad,
+                                           self.head[b].data_ptr(), self.comm.cuda_stream)
+            self.packed[b].record(self.comm)
             if self.world > 1:
                 dist.all_gather_into_tensor(self.gathered[b], self.block[b], group=self.group)
-                dist.all_gather_into_tensor(self.totals_all[b], self.total[b], group=self.group)
+                dist.all_gather_into_tensor(self.heads_all[b], self.head[b], group=self.group)
             else:
                 self.gathered[b][:self.pad].copy_(self.block[b])
-                self.totals_all[b].copy_(self.total[b])
-            self.shipped[b].record(self.comm)
+                self.heads_all[b].copy_(self.head[b])
         self.k += 1
 
     def finish(self):
@@ -182,10 +210,28 @@ class PipelinedExchange:
         self.comm.synchronize()
 
     def last_result(self) -> torch.Tensor:
-        """every rank's edges of the most recent pass, concatenated in rank order"""
+        """every rank's edges of the most recent pass as packed 8-byte edges, concatenated in rank order"""
         self.finish()
         b = (self.k - 1) & 1
-        tot = self.totals_all[b].tolist()
-        if max(tot) > self.pad:
+        if self.fmt == "edges":
+            tot = self.heads_all[b].tolist()
+            if max(tot) > self.pad:
+                raise BufferError("exchange block overflow")
+            return torch.cat([self.gathered[b][r * self.pad:r * self.pad + int(tot[r])] for r in range(self.world)])
+        n = self.ctx.n
+        heads = self.heads_all[b].view(self.world, n + 2)
+        tail = heads[:, n:].tolist()   # per rank: [edges, misfits]
+        if max(t[0] for t in tail) > self.pad:
             raise BufferError("exchange block overflow")
-        return torch.cat([self.gathered[b][r * self.pad:r * self.pad + int(tot[r])] for r in range(self.world)])
+        if any(t[1] for t in tail):
+            raise OverflowError("a score - threshold does not fit 8 bits: use fmt='edges' for these parameters")
+        out = torch.empty(sum(t[0] for t in tail), dtype=torch.int64, device=self.device)
+        o = 0
+        stream = torch.cuda.current_stream(self.device)
+        for r in range(self.world):
+            if tail[r][0]:
+                self.ctx.unpack_rows_dev(heads[r].data_ptr(), self.gathered[b][r * self.pad:].data_ptr(), self.args[2],
+                                         out[o:].data_ptr(), tail[r][0], stream.cuda_stream)
+            o += tail[r][0]
+        stream.synchronize()
+        return out

@@ -151,6 +151,20 @@ int hmk_neighbors_shifted_dev(hmk_ctx *ctx, int max_shift, int shift_penalty, in
  * out_capacity entries are written) -- the block a fixed-size all-gather ships to the other ranks. */
 int hmk_compact_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t capacity, const void *d_counts,
                           void *d_out, uint64_t out_capacity, void *d_total, void *stream);
+/* "Row blocks": the 4-byte-per-edge form of a rank's edges that the multi-GPU exchange ships (half the
+ * xGMI bytes of the packed edges).  Device to device, asynchronous on `stream`; calls on one context must be
+ * stream-ordered (they share context-owned scratch).  Regroups the HMK_EDGE_SHARDS segments by x:
+ *   d_row_start  uint32[n + 2]: entries of row x are d_adj[d_row_start[x] .. d_row_start[x + 1]);
+ *                [n] = number of edges, [n + 1] = edges whose score - threshold did not fit 0..255
+ *                (must be 0 for the block to be usable; fall back to hmk_compact_edges_dev otherwise)
+ *   d_adj        uint32[adj_capacity]: m << 8 | (score - threshold); order inside a row is arbitrary.
+ * n = the sequences of hmk_set_sequences.  Part of the replacement for the per-candidate
+ * scoring loop's hand-over (NearestCluster results, LimitedGreedySequenceClusterer.java:118-180). */
+int hmk_pack_rows_dev(hmk_ctx *ctx, const void *d_edges, uint64_t capacity, const void *d_counts, int threshold,
+                      void *d_row_start, void *d_adj, uint64_t adj_capacity, void *stream);
+/* Inverse: writes the row block's edges as packed 8-byte edges to d_edges_out[0 .. d_row_start[n]). */
+int hmk_unpack_rows_dev(hmk_ctx *ctx, const void *d_row_start, const void *d_adj, int threshold, void *d_edges_out,
+                        uint64_t out_capacity, void *stream);
 /* pairs / tiles of the plan the last hmk_neighbors_shifted[_dev] call used */
 int hmk_neighbors_last_plan(hmk_ctx *ctx, hmk_neighbor_stats *stats);
 

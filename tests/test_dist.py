@@ -116,9 +116,10 @@ def test_two_ranks_one_gpu_match_single_gpu():
 
 
 @pytest.mark.gpu
-def test_pipelined_exchange_single_rank_matches_neighbors():
+@pytest.mark.parametrize("fmt", ["rows", "edges"])
+def test_pipelined_exchange_single_rank_matches_neighbors(fmt):
     """PipelinedExchange (compute stream + pack + ship on a second stream, double buffered) returns the
-    same edge set as hmk_neighbors_shifted on every pass."""
+    same edge set as hmk_neighbors_shifted on every pass, in both block formats."""
     import json
     import hammock_amd
     from hammock_amd import dist as hd
@@ -129,9 +130,103 @@ def test_pipelined_exchange_single_rank_matches_neighbors():
     ctx = hammock_amd.Context(M, device=0)
     ctx.set_sequences(residues=res, offsets=off)
     want, _ = ctx.neighbors_shifted(3, 0, 20)
-    px = hd.PipelinedExchange(ctx, 3, 0, 20, 0, 1, torch.device("cuda", 0))
+    px = hd.PipelinedExchange(ctx, 3, 0, 20, 0, 1, torch.device("cuda", 0), fmt=fmt)
     for k in range(5):
         px.step()
         if k in (0, 3, 4):
             got = px.last_result().cpu().numpy().view(np.uint64)
             assert np.array_equal(np.sort(got), np.sort(want)), k
+
+
+@pytest.mark.gpu
+def test_row_blocks_round_trip_directed_edges_and_misfit():
+    """hmk_pack_rows_dev / hmk_unpack_rows_dev: the 4-byte exchange format reproduces the packed edges
+    (asymmetric matrix: directed edges, x > m occurs; mixed lengths), and reports scores that do not
+    fit score - threshold in 8 bits instead of truncating them."""
+    import json
+    import hammock_amd
+    from hammock_amd import _native as N
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32).copy()
+    rng = np.random.default_rng(5)
+    M[:20, :20] += rng.integers(-1, 2, size=(20, 20))          # asymmetric
+    peps = random_peptides(rng, 3000, 8, 14, alphabet=6)
+    res, off = hammock_amd.pack_sequences(peps)
+    n = len(peps)
+    ctx = hammock_amd.Context(M, device=0)
+    ctx.set_sequences(residues=res, offsets=off)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev)
+    for thr, expect_misfit in ((18, False), (-300, True)):
+        want, _ = ctx.neighbors_shifted(2, -1, thr)
+        cap = (len(want) * 2 // N.HMK_EDGE_SHARDS + 4096) * N.HMK_EDGE_SHARDS
+        d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
+        d_counts = torch.zeros(N.HMK_EDGE_SHARDS, dtype=torch.int64, device=dev)
+        ctx.neighbors_shifted_dev(2, -1, thr, 0, 1, d_edges.data_ptr(), cap, d_counts.data_ptr(), stream.cuda_stream)
+        head = torch.zeros(n + 2, dtype=torch.int32, device=dev)
+        adj = torch.zeros(len(want) + 8, dtype=torch.int32, device=dev)
+        ctx.pack_rows_dev(d_edges.data_ptr(), cap, d_counts.data_ptr(), thr, head.data_ptr(), adj.data_ptr(), adj.numel(),
+                          stream.cuda_stream)
+        h = head.cpu().numpy()
+        assert h[n] == len(want)
+        assert np.all(np.diff(h[:n + 1].astype(np.int64)) >= 0)
+        if expect_misfit:
+            rel = hammock_amd.edge_fields(want)[2].astype(np.int64) - thr
+            assert h[n + 1] == int(((rel < 0) | (rel > 255)).sum()) > 0
+            continue
+        assert h[n + 1] == 0
+        out = torch.zeros(len(want), dtype=torch.int64, device=dev)
+        ctx.unpack_rows_dev(head.data_ptr(), adj.data_ptr(), thr, out.data_ptr(), out.numel(), stream.cuda_stream)
+        got = out.cpu().numpy().view(np.uint64)
+        assert np.array_equal(np.sort(got), np.sort(want))
+        x = hammock_amd.edge_fields(got)[0]
+        assert np.all(np.diff(x.astype(np.int64)) >= 0)          # grouped by x
+        assert (hammock_amd.edge_fields(got)[0] > hammock_amd.edge_fields(got)[1]).any()  # directed edges present
+
+
+def _px_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share ONE GPU: gloo carries the exchange
+    import json
+    import hammock_amd
+    from hammock_amd import dist as hd
+    from hammock_amd.synth import synth_peptides
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+    res, off = synth_peptides(2, 20000, 12)
+    ctx = hammock_amd.Context(M, device=0)
+    ctx.set_sequences(residues=res, offsets=off)
+    want, _ = ctx.neighbors_shifted(3, 0, 20)
+    oks = []
+    for fmt in ("rows", "edges"):
+        px = hd.PipelinedExchange(ctx, 3, 0, 20, rank, world, dev, fmt=fmt)
+        for _ in range(3):
+            px.step()
+        got = px.last_result().cpu().numpy().view(np.uint64)
+        oks.append(bool(np.array_equal(np.sort(got), np.sort(want))))
+        oks.append(px.bytes_per_step)
+    q.put((rank, oks))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_pipelined_exchange_two_ranks_one_gpu():
+    """Both block formats over a real 2-rank exchange: every rank ends with the whole neighbour graph;
+    the row blocks ship about half the bytes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_px_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=400) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, oks in out:
+        assert oks[0] is True and oks[2] is True, out
+        assert oks[1] < 0.6 * oks[3], out
