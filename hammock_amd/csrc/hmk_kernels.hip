@@ -211,6 +211,23 @@ __device__ __forceinline__ void flush_stage(const uint32_t *stage, uint32_t cnt,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
 }
 
+// one table entry of NW dwords from LDS byte address `addr`
+template <int NW>
+__device__ __forceinline__ void lds_read_entry(uint32_t addr, uint32_t (&e)[NW]) {
+    if constexpr (NW == 1) {
+        e[0] = lds_read<uint32_t>(addr);
+    } else if constexpr (NW == 2) {
+        const u32x2 v = lds_read<u32x2>(addr);
+        e[0] = v.x; e[1] = v.y;
+    } else {
+#pragma unroll
+        for (int q = 0; q < NW / 4; q++) {
+            const u32x4 v = lds_read<u32x4>(addr + 16 * q);
+            e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+        }
+    }
+}
+
 // -----------------------------------------------------------------------------
 // k_neighbors_swar
 // -----------------------------------------------------------------------------
@@ -358,6 +375,73 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
             }
         }
 
+        if constexpr (!EXACT) {
+            // Generic lengths: position-major.  The `j < lb` tests are wave-uniform branches; inside one
+            // branch the reads of ALL R rows for two positions are in flight together (row-major order
+            // would leave one dependent read per branch: latency bound), and a pair of positions costs
+            // one v_add3 per accumulator dword.  Rows past T.nrows read all-zero tables.
+#pragma unroll
+            for (int p = 0; p < CPL; p++) {
+                uint32_t W[R][NW];
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int w = 0; w < NW; w++) W[r][w] = cinit[w];
+#pragma unroll
+                for (int j = 0; j < LBMAX; j += 2) {
+                    if (j + 1 < lb && j + 1 < LBMAX) {
+                        uint32_t e0[R][NW], e1[R][NW];
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            lds_read_entry<NW>(off[p][j] + (uint32_t)(r * ROWBYTES), e0[r]);
+                            lds_read_entry<NW>(off[p][j + 1] + (uint32_t)(r * ROWBYTES), e1[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+#pragma unroll
+                            for (int w = 0; w < NW; w++) W[r][w] = W[r][w] + e0[r][w] + e1[r][w];
+                    } else if (j < lb) {
+                        uint32_t e0[R][NW];
+#pragma unroll
+                        for (int r = 0; r < R; r++) lds_read_entry<NW>(off[p][j] + (uint32_t)(r * ROWBYTES), e0[r]);
+#pragma unroll
+                        for (int r = 0; r < R; r++)
+#pragma unroll
+                            for (int w = 0; w < NW; w++) W[r][w] += e0[r][w];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    uint32_t any = W[r][0];
+#pragma unroll
+                    for (int w = 1; w < NW; w++) any |= W[r][w];
+                    const bool hit = (any & himask) != 0 && (uint32_t)r < T.nrows;
+                    if (__ballot(hit) != 0) {
+                        if (cnt > (uint32_t)(STAGE_CAP - 64)) {
+                            flush_stage<NW>(stage, cnt, P, T, g, lane16, shard);
+                            cnt = 0;
+                        }
+                        const uint32_t col = colpos[p];
+                        bool keep = hit;
+                        if (!interior) {
+                            keep = keep && col < col_end;
+                            if (T.diag == 1) keep = keep && col > T.row0 + r;
+                            if (T.diag == 2) keep = keep && col != T.row0 + r;
+                        }
+                        const uint64_t mask = __ballot(keep);
+                        if (keep) {
+                            uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                            rec[0] = col;
+                            rec[1] = (uint32_t)r;
+#pragma unroll
+                            for (int w = 0; w < NW; w++) rec[2 + w] = W[r][w];
+                        }
+                        cnt += (uint32_t)__popcll(mask);
+                    }
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if ((uint32_t)r < T.nrows) {
