@@ -168,7 +168,7 @@ void classify(const hmk_ctx *ctx, int la, int lb, int X, int p, int thr, TileCla
         c.g = (int32_t)g;
         const int lpd = u16 ? 2 : 4, bits = u16 ? 16 : 8;
         const int ndw = (nd + lpd - 1) / lpd;
-        c.nw = ndw <= 1 ? 1 : ndw <= 2 ? 2 : ndw <= 4 ? 4 : 8;
+        c.nw = (uint8_t)ndw;  // 1..8 dwords per table entry, each count has its own kernel
         for (int t = 0; t < nd; t++) c.cinit[t / lpd] |= (uint32_t)ci[t] << ((t % lpd) * bits);
     }
     *out = c;

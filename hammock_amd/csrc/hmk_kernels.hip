@@ -507,6 +507,238 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
 }
 
 // -----------------------------------------------------------------------------
+// k_neighbors_planes: the SWAR neighbour kernel for arbitrary lengths
+// -----------------------------------------------------------------------------
+// Same tables as k_neighbors_swar (entry (r, j, c) = NW dwords of packed shift lanes), stored as
+// PLANES so that every LDS read is bank-conflict free: NW / 2 planes of 8-byte entries plus, for odd NW,
+// one plane of 4-byte entries.  Inside a plane the 24 residues of one position are 24 consecutive
+// entries = 48 (24) consecutive banks, so lanes reading different residues never share a bank; with
+// 16- or 32-byte entries read as ds_read_b128 residues c and c + 16 (c + 8) collide and 43-59 % of the
+// LDS cycles were conflict cycles (PMC, profiles/round1_pmc_config4a.json).  Any NW from 1 to 8 is its
+// own instantiation (no rounding of the shift count up to a power of two).
+//
+// LDS map:  tab  R rows x [NP planes x LBMAX x 24 x 8 B | H x LBMAX x 24 x 4 B]
+//           mb 576 B, rowres R x 32 B, stage 4 waves x 128 records x 3 dwords (col, row, score)
+// Plane strides.  The compiler fuses two ds_reads off the same address register into ds_read2[st64]
+// when their immediates differ by < 2048 B or by a multiple of 512 B (256 B for 4-byte reads); a fused
+// read whose halves are a multiple of 256 B apart hits the same banks with both halves (measured: 43 %
+// conflict cycles with strides of 1536 / 3072 B).  Strides of 8 x odd bytes, >= 2048, rule the fusion out;
+// planes_layout_ok() checks every pair of (row, plane) offsets at compile time.
+constexpr int plane64_bytes(int lbmax) { return lbmax * 24 * 8 + 8; }
+constexpr int rows_for(int rowbytes, int nw) {  // rows per tile: 40 KB of tables, R x NW accumulators in registers
+    int r = 40960 / rowbytes;
+    if (r > 32 / nw) r = 32 / nw;
+    return r > 16 ? 16 : (r < 1 ? 1 : r);
+}
+constexpr bool planes_layout_ok(int lbmax, int nw, int pad32) {
+    const int np = nw / 2, s64 = plane64_bytes(lbmax);
+    const int rb = np * s64 + (nw & 1) * (lbmax * 24 * 4 + pad32);
+    const int r_rows = rows_for(rb, nw);
+    for (int a = 0; a < r_rows * np; a++)
+        for (int b = a + 1; b < r_rows * np; b++) {
+            const int d = ((b / np) * rb + (b % np) * s64) - ((a / np) * rb + (a % np) * s64);
+            if (d < 2048 || d % 512 == 0) return false;
+        }
+    if (nw & 1)
+        for (int k = 1; k < r_rows; k++)
+            if (k * rb < 1024 || (k * rb) % 256 == 0) return false;
+    return true;
+}
+constexpr int plane32_bytes(int lbmax, int nw) {  // smallest padding of the 4-byte plane that passes the check
+    for (int pad = 8; pad <= 256; pad += 8)
+        if (planes_layout_ok(lbmax, nw, pad)) return lbmax * 24 * 4 + pad;
+    return -1;
+}
+constexpr int planes_rowbytes(int lbmax, int nw) { return (nw / 2) * plane64_bytes(lbmax) + (nw & 1) * plane32_bytes(lbmax, nw); }
+
+template <int NW, int R, int LBMAX>
+__global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P, const uint32_t tile_base) {
+    constexpr int NP = NW / 2, H = NW & 1;
+    constexpr int CPL = NW <= 2 ? 2 : 1;
+    constexpr int PLANE64 = plane64_bytes(LBMAX);
+    constexpr int ROWBYTES = planes_rowbytes(LBMAX, NW);
+    static_assert(plane32_bytes(LBMAX, NW) > 0 && R == rows_for(ROWBYTES, NW),
+                  "no padding found that keeps table reads from being fused into a same-bank ds_read2");
+    constexpr int TAB_BYTES = R * ROWBYTES;
+    constexpr int STAGE_CAP = 128, REC_DW = 3;
+    constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;
+    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * REC_DW * 4;
+    static_assert(TAB_BYTES <= 65536 && LDS_BYTES <= 65536, "LDS budget / DS immediate range");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
+    uint8_t *tab = smem;
+    uint8_t *mb = smem + TAB_BYTES;
+    uint8_t *rowres = mb + 576;
+    uint32_t *stage_all = reinterpret_cast<uint32_t *>(rowres + R * 32);
+
+    const Tile T = P.tiles[tile_base + blockIdx.x];
+    const TileClass *Cp = P.classes + T.cls;
+    const int la = Cp->la, lb = Cp->lb, nd = Cp->nd, X = Cp->x;
+    const bool case_b = Cp->case_b != 0;
+    const bool lane16 = Cp->path == PATH_U16;
+    const int g = Cp->g;
+    const uint32_t himask = lane16 ? 0x80008000u : 0x80808080u;
+    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const int tid = threadIdx.x;
+    uint32_t *stage = stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+
+    for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
+    for (int e = tid; e < R * 32; e += 256) {
+        const int r = e >> 5, k = e & 31;
+        uint8_t v = 0;
+        if ((uint32_t)r < T.nrows && (uint32_t)k < P.lpad) v = P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k];
+        rowres[e] = v;
+    }
+    __syncthreads();
+
+    // ---- expand the R row peptides into lookup tables (same cells as k_neighbors_swar) ----
+    //   column is the longer/equal one (L): cell = M[row[i]][c], i = j - s   (ShiftedScorer.java:71,75)
+    //   column is the shorter one (S):      cell = M[c][row[i]], i = j + s
+    {
+        const int per_row = lb * 24;
+        const int lanes_per_dw = lane16 ? 2 : 4;
+        const int lane_bits = lane16 ? 16 : 8;
+        for (int e = tid; e < R * per_row; e += 256) {
+            const int r = e / per_row;
+            const int rem = e - r * per_row;
+            const int j = rem / 24;
+            const int c = rem - j * 24;
+            uint32_t dw[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                uint32_t acc = 0;
+                for (int k = 0; k < lanes_per_dw; k++) {
+                    const int t = w * lanes_per_dw + k;
+                    const int i = case_b ? (j + t - X) : (j - t + X);
+                    if (t < nd && i >= 0 && i < la && (uint32_t)r < T.nrows) {
+                        const int a = rowres[r * 32 + i];
+                        const uint32_t v = case_b ? mb[c * 24 + a] : mb[a * 24 + c];
+                        acc |= v << (k * lane_bits);
+                    }
+                }
+                dw[w] = acc;
+            }
+            uint8_t *row = tab + r * ROWBYTES;
+#pragma unroll
+            for (int q = 0; q < NP; q++)
+                *reinterpret_cast<u32x2 *>(row + q * PLANE64 + (j * 24 + c) * 8) = u32x2{dw[2 * q], dw[2 * q + 1]};
+            if (H) *reinterpret_cast<uint32_t *>(row + NP * PLANE64 + (j * 24 + c) * 4) = dw[NW - 1];
+        }
+    }
+    __syncthreads();
+
+    uint32_t cinit[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) cinit[w] = Cp->cinit[w];
+
+    uint32_t cnt = 0;  // staged records of this wave (wave-uniform)
+    const uint32_t tab_addr = lds_addr(tab);
+    const uint32_t col_end = T.col0 + T.ncols;
+    const uint32_t n_batches = (T.ncols + 256 * CPL - 1) / (256 * CPL);
+    const bool interior = T.diag == 0 && T.ncols % (256 * CPL) == 0;  // every lane's column is a real pair
+
+    for (uint32_t bt = 0; bt < n_batches; bt++) {
+#pragma unroll
+        for (int p = 0; p < CPL; p++) {
+            // ---- this lane's column peptide -> per-position entry index ----------------
+            const uint32_t col = T.col0 + (bt * CPL + p) * 256 + tid;
+            uint32_t words[LPADW];
+#pragma unroll
+            for (int q = 0; q < LPADW; q++) words[q] = 0;
+            if (col < col_end) {
+                const u32x4 *src = reinterpret_cast<const u32x4 *>(P.res_sorted + (size_t)col * P.lpad);
+                const u32x4 v0 = src[0];
+                words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+                if (LPADW == 8) {
+                    const u32x4 v1 = src[1];
+                    words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
+                }
+            }
+            uint32_t off64[NP ? LBMAX : 1], off32[H ? LBMAX : 1];
+#pragma unroll
+            for (int j = 0; j < LBMAX; j++) {
+                const uint32_t c = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
+                if (NP) off64[j] = tab_addr + (uint32_t)(j * 24 * 8) + c * 8;
+                if (H) off32[j] = tab_addr + (uint32_t)(NP * PLANE64 + j * 24 * 4) + c * 4;
+            }
+
+            // ---- position-major accumulation: the `j < lb` tests are wave-uniform branches; inside one
+            // branch the reads of all R rows for two positions are in flight together, and a pair of
+            // positions costs one v_add3 per accumulator dword.  Rows past T.nrows read zero tables.
+            uint32_t W[R][NW];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int w = 0; w < NW; w++) W[r][w] = cinit[w];
+            auto read_entry = [&](int j, int r, uint32_t (&e)[NW]) {
+#pragma unroll
+                for (int q = 0; q < NP; q++) {
+                    const u32x2 v = lds_read<u32x2>(off64[NP ? j : 0] + (uint32_t)(r * ROWBYTES + q * PLANE64));
+                    e[2 * q] = v.x; e[2 * q + 1] = v.y;
+                }
+                if (H) e[NW - 1] = lds_read<uint32_t>(off32[H ? j : 0] + (uint32_t)(r * ROWBYTES));
+            };
+#pragma unroll
+            for (int j = 0; j < LBMAX; j += 2) {
+                if (j + 1 < lb) {
+                    uint32_t e0[R][NW], e1[R][NW];
+#pragma unroll
+                    for (int r = 0; r < R; r++) { read_entry(j, r, e0[r]); read_entry(j + 1, r, e1[r]); }
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+#pragma unroll
+                        for (int w = 0; w < NW; w++) W[r][w] = W[r][w] + e0[r][w] + e1[r][w];
+                } else if (j < lb) {
+                    uint32_t e0[R][NW];
+#pragma unroll
+                    for (int r = 0; r < R; r++) read_entry(j, r, e0[r]);
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+#pragma unroll
+                        for (int w = 0; w < NW; w++) W[r][w] += e0[r][w];
+                }
+            }
+
+            // ---- threshold test: some shift lane has its top bit set <=> score >= threshold ----
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                uint32_t any = W[r][0];
+#pragma unroll
+                for (int w = 1; w < NW; w++) any |= W[r][w];
+                const bool hit = (any & himask) != 0 && (uint32_t)r < T.nrows;
+                if (__ballot(hit) != 0) {  // wave-uniform, rare
+                    if (cnt > (uint32_t)(STAGE_CAP - 64)) {
+                        flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+                        cnt = 0;
+                    }
+                    bool keep = hit;
+                    if (!interior) {
+                        keep = keep && col < col_end;
+                        if (T.diag == 1) keep = keep && col > T.row0 + r;   // triangle: column after row
+                        if (T.diag == 2) keep = keep && col != T.row0 + r;  // full square minus the diagonal
+                    }
+                    const uint64_t mask = __ballot(keep);
+                    if (keep) {
+                        uint32_t mx = 0;  // best shift = largest lane
+#pragma unroll
+                        for (int w = 0; w < NW; w++) {
+                            const uint32_t dw = W[r][w];
+                            if (lane16) mx = max(mx, max(dw & 0xFFFFu, dw >> 16));
+                            else mx = max(mx, max(max(dw & 0xFFu, (dw >> 8) & 0xFFu), max((dw >> 16) & 0xFFu, dw >> 24)));
+                        }
+                        uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                        rec[0] = col;
+                        rec[1] = (uint32_t)r;
+                        rec[2] = (uint32_t)((int)mx - g);
+                    }
+                    cnt += (uint32_t)__popcll(mask);
+                }
+            }
+        }
+    }
+    flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+}
+
+// -----------------------------------------------------------------------------
 // k_neighbors_direct: generic tier (same tiles, literal scorer, one column per lane)
 // -----------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -1308,12 +1540,10 @@ constexpr int kNumHotVariants = sizeof(kHotVariants) / sizeof(kHotVariants[0]);
 // Generic instantiations: column-length capacity LBMAX x dwords per entry NW.  Rows per tile
 // R = what fits a 40 KB table budget (<= 16); 2 columns per lane for the narrow entries.
 constexpr int swar_r(int lbmax, int nw) {
-    const int rowbytes = lbmax * 24 * nw * 4;
-    int r = 40960 / rowbytes;
-    return r > 16 ? 16 : (r < 1 ? 1 : r);
+    return rows_for(planes_rowbytes(lbmax, nw), nw);
 }
 
-int swar_lbmax_for(int lb) { return lb <= 8 ? 8 : lb <= 12 ? 12 : lb <= 16 ? 16 : lb <= 20 ? 20 : 32; }
+int swar_lbmax_for(int lb) { return lb <= 12 ? 12 : lb <= 16 ? 16 : lb <= 20 ? 20 : 32; }  // plane strides need >= 11 positions
 
 int swar_rows_per_tile(int lbmax, int nw, bool exact, int hot_variant) {
     if (exact && lbmax == 12 && nw == 2 && hot_variant >= 0 && hot_variant < kNumHotVariants)
@@ -1339,14 +1569,15 @@ hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant,
             default: return hipErrorInvalidValue;
         }
     }
-#define HMK_CASE(LB, NWV) \
-    if (lbmax == LB && nw == NWV) \
-        return launch_swar_t<NWV, swar_r(LB, NWV), (NWV <= 2 ? 2 : 1), LB, false>(P, tile_base, n_tiles, s);
-    HMK_CASE(8, 1)  HMK_CASE(8, 2)  HMK_CASE(8, 4)  HMK_CASE(8, 8)
-    HMK_CASE(12, 1) HMK_CASE(12, 2) HMK_CASE(12, 4) HMK_CASE(12, 8)
-    HMK_CASE(16, 1) HMK_CASE(16, 2) HMK_CASE(16, 4) HMK_CASE(16, 8)
-    HMK_CASE(20, 1) HMK_CASE(20, 2) HMK_CASE(20, 4) HMK_CASE(20, 8)
-    HMK_CASE(32, 1) HMK_CASE(32, 2) HMK_CASE(32, 4) HMK_CASE(32, 8)
+#define HMK_CASE(LB, NWV)                                                                                             \
+    if (lbmax == LB && nw == NWV) {                                                                                   \
+        hipLaunchKernelGGL((k_neighbors_planes<NWV, swar_r(LB, NWV), LB>), dim3(n_tiles), dim3(256), 0, s, P, tile_base); \
+        return hipGetLastError();                                                                                     \
+    }
+#define HMK_CASES(LB) HMK_CASE(LB, 1) HMK_CASE(LB, 2) HMK_CASE(LB, 3) HMK_CASE(LB, 4) HMK_CASE(LB, 5) HMK_CASE(LB, 6) \
+                      HMK_CASE(LB, 7) HMK_CASE(LB, 8)
+    HMK_CASES(12) HMK_CASES(16) HMK_CASES(20) HMK_CASES(32)
+#undef HMK_CASES
 #undef HMK_CASE
     return hipErrorInvalidValue;
 }
