@@ -229,8 +229,9 @@ __device__ __forceinline__ void lds_read_entry(uint32_t addr, uint32_t (&e)[NW])
 }
 
 // -----------------------------------------------------------------------------
-// k_neighbors_swar
+// k_neighbors_swar: the hot kernel -- every sequence has length 12, max shift 3, 8-bit lanes
 // -----------------------------------------------------------------------------
+// (EXACT is always true; other lengths run k_neighbors_planes below.)
 // LDS map (one __shared__ array):
 //   tab     R * LBMAX * 24 * NW dwords   per row r, column position j, residue c:
 //                                        NW dwords of packed lanes, lane t = shift index
@@ -246,7 +247,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
     constexpr int REC_DW = NW + 2;
     constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;  // residue dwords a lane needs (rows are P.lpad bytes apart)
     static_assert(TAB_BYTES <= 65536, "row tables must stay addressable by the DS immediate offset");
-    static_assert(!EXACT || (NW == 2 && LBMAX == 12), "the exact path is length 12, max shift 3, 8-bit lanes");
+    static_assert(EXACT && NW == 2 && LBMAX == 12, "this kernel is the length 12, max shift 3, 8-bit lane case");
     // one STATIC LDS object: its base address is a compile-time constant, so table
     // offsets fold into the ds_read immediate instead of costing a v_add per lookup
     constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * REC_DW * 4;
@@ -259,8 +260,6 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
 
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
-    const int la = Cp->la, lb = EXACT ? LBMAX : Cp->lb, nd = Cp->nd, X = Cp->x;
-    const bool case_b = Cp->case_b != 0;
     const bool lane16 = Cp->path == PATH_U16;
     const int g = Cp->g;
     const uint32_t himask = lane16 ? 0x80008000u : 0x80808080u;
@@ -276,7 +275,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
         const int r = e >> 5, k = e & 31;
         uint8_t v = 0;
         if ((uint32_t)r < T.nrows && (uint32_t)k < P.lpad) v = P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k];
-        rowres[e] = EXACT ? (uint8_t)(v >> 3) : v;   // the exact path stores residues pre-multiplied by the entry size
+        rowres[e] = (uint8_t)(v >> 3);   // residues are stored pre-multiplied by the entry size (8)
     }
     __syncthreads();
 
@@ -306,34 +305,6 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
                 const uint32_t hi = __builtin_amdgcn_alignbyte(pp[(v0 >> 2) + 2], pp[(v0 >> 2) + 1], v0 & 3) & 0x00FFFFFFu;
                 *reinterpret_cast<u32x2 *>(tab + r * ROWBYTES + (j * 24 + c) * ES) = u32x2{lo, hi};
             }
-        }
-    } else {
-        const int per_row = lb * 24;
-        const int lanes_per_dw = lane16 ? 2 : 4;
-        const int lane_bits = lane16 ? 16 : 8;
-        for (int e = tid; e < R * per_row; e += 256) {
-            const int r = e / per_row;
-            const int rem = e - r * per_row;
-            const int j = rem / 24;
-            const int c = rem - j * 24;
-            uint32_t dw[NW];
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                uint32_t acc = 0;
-                for (int k = 0; k < lanes_per_dw; k++) {
-                    const int t = w * lanes_per_dw + k;
-                    const int i = case_b ? (j + t - X) : (j - t + X);
-                    if (t < nd && i >= 0 && i < la && (uint32_t)r < T.nrows) {
-                        const int a = rowres[r * 32 + i];
-                        const uint32_t v = case_b ? mb[c * 24 + a] : mb[a * 24 + c];
-                        acc |= v << (k * lane_bits);
-                    }
-                }
-                dw[w] = acc;
-            }
-            uint32_t *dst = reinterpret_cast<uint32_t *>(tab + r * ROWBYTES + (j * 24 + c) * ES);
-#pragma unroll
-            for (int w = 0; w < NW; w++) dst[w] = dw[w];
         }
     }
     __syncthreads();
@@ -371,77 +342,10 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
 #pragma unroll
             for (int j = 0; j < LBMAX; j++) {
                 const uint32_t c = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-                off[p][j] = tab_addr + (uint32_t)(j * 24 * ES) + (EXACT ? c : c * ES);   // EXACT: stored as c * 8
+                off[p][j] = tab_addr + (uint32_t)(j * 24 * ES) + c;   // c is stored as residue * 8
             }
         }
 
-        if constexpr (!EXACT) {
-            // Generic lengths: position-major.  The `j < lb` tests are wave-uniform branches; inside one
-            // branch the reads of ALL R rows for two positions are in flight together (row-major order
-            // would leave one dependent read per branch: latency bound), and a pair of positions costs
-            // one v_add3 per accumulator dword.  Rows past T.nrows read all-zero tables.
-#pragma unroll
-            for (int p = 0; p < CPL; p++) {
-                uint32_t W[R][NW];
-#pragma unroll
-                for (int r = 0; r < R; r++)
-#pragma unroll
-                    for (int w = 0; w < NW; w++) W[r][w] = cinit[w];
-#pragma unroll
-                for (int j = 0; j < LBMAX; j += 2) {
-                    if (j + 1 < lb && j + 1 < LBMAX) {
-                        uint32_t e0[R][NW], e1[R][NW];
-#pragma unroll
-                        for (int r = 0; r < R; r++) {
-                            lds_read_entry<NW>(off[p][j] + (uint32_t)(r * ROWBYTES), e0[r]);
-                            lds_read_entry<NW>(off[p][j + 1] + (uint32_t)(r * ROWBYTES), e1[r]);
-                        }
-#pragma unroll
-                        for (int r = 0; r < R; r++)
-#pragma unroll
-                            for (int w = 0; w < NW; w++) W[r][w] = W[r][w] + e0[r][w] + e1[r][w];
-                    } else if (j < lb) {
-                        uint32_t e0[R][NW];
-#pragma unroll
-                        for (int r = 0; r < R; r++) lds_read_entry<NW>(off[p][j] + (uint32_t)(r * ROWBYTES), e0[r]);
-#pragma unroll
-                        for (int r = 0; r < R; r++)
-#pragma unroll
-                            for (int w = 0; w < NW; w++) W[r][w] += e0[r][w];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    uint32_t any = W[r][0];
-#pragma unroll
-                    for (int w = 1; w < NW; w++) any |= W[r][w];
-                    const bool hit = (any & himask) != 0 && (uint32_t)r < T.nrows;
-                    if (__ballot(hit) != 0) {
-                        if (cnt > (uint32_t)(STAGE_CAP - 64)) {
-                            flush_stage<NW>(stage, cnt, P, T, g, lane16, shard);
-                            cnt = 0;
-                        }
-                        const uint32_t col = colpos[p];
-                        bool keep = hit;
-                        if (!interior) {
-                            keep = keep && col < col_end;
-                            if (T.diag == 1) keep = keep && col > T.row0 + r;
-                            if (T.diag == 2) keep = keep && col != T.row0 + r;
-                        }
-                        const uint64_t mask = __ballot(keep);
-                        if (keep) {
-                            uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
-                            rec[0] = col;
-                            rec[1] = (uint32_t)r;
-#pragma unroll
-                            for (int w = 0; w < NW; w++) rec[2 + w] = W[r][w];
-                        }
-                        cnt += (uint32_t)__popcll(mask);
-                    }
-                }
-            }
-            continue;
-        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if ((uint32_t)r < T.nrows) {
@@ -453,7 +357,7 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
                     for (int w = 0; w < NW; w++) W[p][w] = cinit[w];
 #pragma unroll
                     for (int j = 0; j < LBMAX; j++) {
-                        if (EXACT || j < lb) {
+                        {
                             const uint32_t ea = off[p][j] + (uint32_t)(r * ROWBYTES);
                             if (NW == 1) {
                                 W[p][0] += lds_read<uint32_t>(ea);
@@ -699,6 +603,13 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
             }
 
             // ---- threshold test: some shift lane has its top bit set <=> score >= threshold ----
+            // one combined test for the R rows first: most batches hold no hit at all
+            uint32_t all = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++)
+#pragma unroll
+                for (int w = 0; w < NW; w++) all |= W[r][w];
+            if (__ballot((all & himask) != 0) == 0) continue;
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 uint32_t any = W[r][0];
