@@ -84,6 +84,10 @@ struct hmk_ctx {
     uint64_t *d_edges = nullptr;  // internal buffer of the host-buffer entry points
     uint64_t d_edges_cap = 0;
     unsigned long long *d_counts = nullptr;
+    // side streams of the neighbour pass: the per-class launches of a mixed-length plan overlap their tails
+    static constexpr int N_SIDE = 3;
+    hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr, nullptr, nullptr};
     uint32_t *d_rows_scratch = nullptr;  // deg[n], cursor[n], misfit of hmk_pack_rows_dev
     uint32_t d_rows_scratch_n = 0;
 
@@ -356,12 +360,39 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     P.n_tiles = pl.stats.n_tiles;
     P.lpad = (uint32_t)pl.lpad;
     P.symmetric = ctx->symmetric ? 1u : 0u;
-    for (const Group &g : pl.groups) {
-        if (g.path == PATH_DIRECT)
-            HIPCHK(ctx, launch_neighbors_direct(P, g.base, g.count, ctx->d_M, X, p, thr, stream));
-        else
-            HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, g.base, g.count, stream));
+    // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has a dozen of
+    // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
+    // start, and join back into `stream`.
+    const bool fork = pl.groups.size() > 2 && getenv("HMK_NO_SIDE_STREAMS") == nullptr;
+    if (fork) {
+        if (!ctx->ev_fork) {
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
+                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
+            }
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, stream));
+        for (int k = 0; k < hmk_ctx::N_SIDE; k++) HIPCHK(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     }
+    // biggest groups first
+    std::vector<const Group *> order;
+    for (const Group &g : pl.groups) order.push_back(&g);
+    std::stable_sort(order.begin(), order.end(), [](const Group *a, const Group *b) { return a->count > b->count; });
+    size_t q = 0;
+    for (const Group *gp : order) {
+        const Group &g = *gp;
+        hipStream_t s = fork ? ctx->side[q++ % hmk_ctx::N_SIDE] : stream;
+        if (g.path == PATH_DIRECT)
+            HIPCHK(ctx, launch_neighbors_direct(P, g.base, g.count, ctx->d_M, X, p, thr, s));
+        else
+            HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, g.base, g.count, s));
+    }
+    if (fork)
+        for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join[k], ctx->side[k]));
+            HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[k], 0));
+        }
     return HMK_OK;
 }
 
@@ -705,6 +736,11 @@ void hmk_destroy(hmk_ctx *ctx) {
         if (ctx->d_edges) (void)hipFree(ctx->d_edges);
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
         if (ctx->d_rows_scratch) (void)hipFree(ctx->d_rows_scratch);
+        for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
+            if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
+            if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
+        }
+        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
         if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

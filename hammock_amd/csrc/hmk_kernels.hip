@@ -429,9 +429,15 @@ __global__ void __launch_bounds__(256) k_neighbors_swar(const NeighborParams P, 
 // conflict cycles with strides of 1536 / 3072 B).  Strides of 8 x odd bytes, >= 2048, rule the fusion out;
 // planes_layout_ok() checks every pair of (row, plane) offsets at compile time.
 constexpr int plane64_bytes(int lbmax) { return lbmax * 24 * 8 + 8; }
-constexpr int rows_for(int rowbytes, int nw) {  // rows per tile: 40 KB of tables, R x NW accumulators in registers
-    int r = 40960 / rowbytes;
-    if (r > 32 / nw) r = 32 / nw;
+constexpr int rows_for(int rowbytes, int nw) {  // rows per tile: table bytes and R x NW accumulator registers, tuned on config 4a
+#ifndef HMK_TAB_BUDGET
+#define HMK_TAB_BUDGET 20480
+#endif
+#ifndef HMK_ACC_CAP
+#define HMK_ACC_CAP 16
+#endif
+    int r = HMK_TAB_BUDGET / rowbytes;
+    if (r > HMK_ACC_CAP / nw) r = HMK_ACC_CAP / nw;
     return r > 16 ? 16 : (r < 1 ? 1 : r);
 }
 constexpr bool planes_layout_ok(int lbmax, int nw, int pad32) {

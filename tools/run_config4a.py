@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE config 4a only (1e5 peptides, lengths 7..20, ShiftedScorer X=3 p=-1 thr=23): 3 passes.
+"""BASELINE config 4a only (1e5 peptides, lengths 7..20, ShiftedScorer X=3 p=-1 thr=23): 4 passes.
 For `rocprofv3 --kernel-trace --stats -- python3 tools/run_config4a.py`."""
 import os
 import sys
@@ -19,8 +19,13 @@ dev = torch.device("cuda", 0)
 cap = 1 << 24
 d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
 d_counts = torch.zeros(_native.HMK_EDGE_SHARDS, dtype=torch.int64, device=dev)
-for _ in range(3):
+ms = []
+for _ in range(4):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
     ctx.neighbors_shifted_dev(3, -1, 23, 0, 1, d_edges.data_ptr(), cap, d_counts.data_ptr(),
                               torch.cuda.current_stream(dev).cuda_stream)
-torch.cuda.synchronize()
-print(int(d_counts.sum().item()), ctx.last_plan().n_tiles)
+    b.record()
+    torch.cuda.synchronize()
+    ms.append(a.elapsed_time(b))
+print(int(d_counts.sum().item()), ctx.last_plan().n_tiles, "ms per pass (first includes the plan):", [round(v, 3) for v in ms])
