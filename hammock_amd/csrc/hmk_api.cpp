@@ -135,7 +135,12 @@ void free_plan(Plan &pl) {
 }
 
 // Lane layout of one (row length, column length) class; see DESIGN.md "SWAR tables".
-void classify(const hmk_ctx *ctx, int la, int lb, int X, int p, int thr, TileClass *out) {
+// row_bound < 0: lanes are proven to fit for ANY pair of the class (every cell at the matrix maximum).
+// row_bound >= 0: the caller guarantees score(row, anything) <= row_bound for the rows it will put into
+// this class (sum of the row residues' best cells), which lets long peptides keep 8-bit lanes.
+// *u8_row_limit receives the largest row_bound for which 8-bit lanes fit (or -1 if they never do).
+void classify(const hmk_ctx *ctx, int la, int lb, int X, int p, int thr, TileClass *out, long long row_bound = -1,
+              long long *u8_row_limit = nullptr) {
     TileClass c{};
     const int m = std::min(la, lb), nl = std::max(la, lb);
     const int d = nl - m;
@@ -155,19 +160,23 @@ void classify(const hmk_ctx *ctx, int la, int lb, int X, int p, int thr, TileCla
         const long long g = (u16 ? 32768LL : 128LL) - thr;
         const int max_nd = u16 ? 16 : 32;
         if (nd > max_nd || cell_max > 255) continue;
-        bool ok = true;
-        long long ci[32];
-        for (int t = 0; t < nd && ok; t++) {
+        bool ok = true, lower_ok = true;
+        long long ci[32], limit = 1LL << 40;
+        for (int t = 0; t < nd; t++) {
             const int s = t - X;
             const long long ncell = s <= 0 ? m + s : std::min(m, nl - s);
             long long pen = (long long)d * p;                       // ShiftedScorer.java:79
             if (s < 0) pen += (long long)(-s) * 2 * p;              // :80-82
             if (s > d) pen += (long long)(s - d) * 2 * p;           // :83-85
-            const long long c0 = g + pen - bias * ncell;
-            if (c0 < 0 || c0 + ncell * cell_max > lane_max) ok = false;
+            const long long c0 = g + pen - bias * ncell;            // lane value = g + pen + sum of the cells
+            if (c0 < 0) lower_ok = false;
+            const long long top = row_bound >= 0 ? g + pen + row_bound : c0 + ncell * cell_max;
+            if (top > lane_max) ok = false;
+            limit = std::min(limit, lane_max - g - pen);
             ci[t] = c0;
         }
-        if (!ok) continue;
+        if (!u16 && u8_row_limit) *u8_row_limit = lower_ok ? limit : -1;
+        if (!ok || !lower_ok) continue;
         c.path = u16 ? PATH_U16 : PATH_U8;
         c.g = (int32_t)g;
         const int lpd = u16 ? 2 : 4, bits = u16 ? 16 : 8;
@@ -202,6 +211,52 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         uint32_t fill[HMK_MAX_LEN + 2];
         std::memcpy(fill, bucket, sizeof(fill));
         for (uint32_t k = 0; k < n; k++) perm[fill[ctx->len[k]]++] = k;
+    }
+    // Per-sequence score bound: no pair involving sequence k scores above bound[k] = sum over its residues
+    // of the best (non-negative) cell of that residue's matrix row/column.  If some class does not fit
+    // 8-bit lanes for arbitrary pairs, its bucket is ordered by this bound and the rows below the class's
+    // limit still run on 8-bit lanes (for BLOSUM62 a 20-mer's bound is its self-score, ~112 +- 8, against
+    // a limit of 127 + threshold).
+    bool refine = false;
+    for (int la = 1; la <= HMK_MAX_LEN && !refine; la++)
+        for (int lb = 1; lb <= HMK_MAX_LEN && !refine; lb++) {
+            if (bucket[la] == bucket[la + 1] || bucket[lb] == bucket[lb + 1]) continue;
+            if (ctx->symmetric && lb > la) continue;
+            TileClass tc;
+            long long limit = -1;
+            classify(ctx, la, lb, X, p, thr, &tc, -1, &limit);
+            if (tc.path != PATH_U8 && limit >= 0) refine = true;
+        }
+    if (getenv("HMK_NO_ROW_BOUNDS")) refine = false;
+    std::vector<uint32_t> bound_sorted;  // bound of the sequence at each sorted position (refine only)
+    constexpr uint32_t BCAP = 4095;      // bounds are only compared with limits < 65536; clamped for the counting sort
+    if (refine) {
+        long long best[HMK_ALPHABET];
+        for (int a = 0; a < HMK_ALPHABET; a++) {
+            long long b = 0;
+            for (int y = 0; y < HMK_ALPHABET; y++)
+                b = std::max<long long>(b, std::max(ctx->M[a * HMK_ALPHABET + y], ctx->M[y * HMK_ALPHABET + a]));
+            best[a] = b;
+        }
+        std::vector<uint32_t> bound(n);
+        for (uint32_t k = 0; k < n; k++) {
+            long long b = 0;
+            for (uint32_t q = ctx->off[k]; q < ctx->off[k + 1]; q++) b += best[ctx->res[q]];
+            bound[k] = (uint32_t)std::min<long long>(b, BCAP);
+        }
+        // stable counting sort of every length bucket by bound
+        std::vector<uint32_t> sorted(n), cnt(BCAP + 2);
+        for (int l = 1; l <= HMK_MAX_LEN; l++) {
+            const uint32_t b0 = bucket[l], b1 = bucket[l + 1];
+            if (b0 == b1) continue;
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (uint32_t q = b0; q < b1; q++) cnt[bound[perm[q]] + 1]++;
+            for (uint32_t v = 0; v <= BCAP; v++) cnt[v + 1] += cnt[v];
+            for (uint32_t q = b0; q < b1; q++) sorted[b0 + cnt[bound[perm[q]]]++] = perm[q];
+        }
+        perm.swap(sorted);
+        bound_sorted.resize(n);
+        for (uint32_t q = 0; q < n; q++) bound_sorted[q] = bound[perm[q]];
     }
     pl.lbmax = swar_lbmax_for(ctx->max_len);
     pl.lpad = ctx->max_len <= 16 ? 16 : 32;
@@ -243,8 +298,30 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
             if (ctx->symmetric && lb > la) continue;
             const bool same = la == lb;
             if (same && re - rb < 2) continue;
-            TileClass tc;
-            classify(ctx, la, lb, X, p, thr, &tc);
+            // row ranges of this (la, lb) pair: all rows in one class, or -- when 8-bit lanes do not fit every
+            // conceivable pair -- the rows whose score bound fits (8-bit lanes) and the rest (16-bit / literal)
+            struct Range { uint32_t lo, hi; TileClass tc; };
+            std::vector<Range> ranges;
+            {
+                TileClass tc0;
+                long long limit = -1;
+                classify(ctx, la, lb, X, p, thr, &tc0, -1, &limit);
+                uint32_t split = rb;  // rows [rb, split) fit 8-bit lanes by their bound
+                if (refine && tc0.path != PATH_U8 && limit >= 0) {
+                    const uint32_t lim = (uint32_t)std::min<long long>(limit, BCAP - 1);  // a clamped bound never passes
+                    split = (uint32_t)(std::upper_bound(bound_sorted.begin() + rb, bound_sorted.begin() + re, lim) -
+                                       bound_sorted.begin());
+                    if (split > rb) {
+                        TileClass t8;
+                        classify(ctx, la, lb, X, p, thr, &t8, lim);
+                        if (t8.path == PATH_U8) ranges.push_back(Range{rb, split, t8});
+                        else split = rb;
+                    }
+                }
+                if (split < re) ranges.push_back(Range{split, re, tc0});
+            }
+            for (const Range &rg : ranges) {
+            const TileClass &tc = rg.tc;
             const int cls = (int)classes.size();
             classes.push_back(tc);
             class_of[la * 64 + lb] = cls;
@@ -255,10 +332,10 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
             const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(lbk, tc.nw, pl.exact, pl.hot_variant);
             std::vector<Tile> &dst = grouped[std::make_tuple((int)tc.path, tc.path == PATH_DIRECT ? 0 : (int)tc.nw,
                                                              tc.path == PATH_DIRECT ? 0 : lbk)];
-            for (uint32_t r0 = rb; r0 < re; r0 += R) {
+            for (uint32_t r0 = rg.lo; r0 < rg.hi; r0 += R) {
                 const bool mine = (row_chunk_counter++ % n_parts) == part;
                 if (!mine) continue;
-                const uint32_t nr = std::min(R, re - r0);
+                const uint32_t nr = std::min(R, rg.hi - r0);
                 uint32_t c_lo = cb, c_hi = ce;
                 if (same && ctx->symmetric) c_lo = r0 + 1;  // triangle: columns after the first row of the chunk
                 // equal column runs (whole 256-column batches) instead of full runs + one short rest:
@@ -292,6 +369,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                     dst.push_back(t);
                 }
             }
+            }  // ranges
         }
     }
     std::vector<Tile> tiles;

@@ -173,6 +173,34 @@ def test_neighbors_general(gpu, matrices, coracle, case):
                                                                                                 stats.classes_direct)
 
 
+def test_neighbors_row_bound_split(gpu, blosum62, coracle):
+    """Long peptides: 8-bit lanes do not fit every conceivable pair of 14..22-mers, so each length bucket
+    is ordered by the per-sequence score bound; rows under the limit stay on 8-bit lanes, the rest go to
+    16-bit lanes.  The input plants tryptophan/cysteine-rich peptides (bound far above the limit) and
+    near-copies of them, whose scores (> 127 + threshold) would overflow an 8-bit lane."""
+    rng = np.random.default_rng(11)
+    peps = random_peptides(rng, 1200, 14, 22)
+    rich = hammock_amd.encode("WCHWYWCWWHCWWYWFWCWWHW")
+    for k in range(60):
+        L = int(rng.integers(14, 23))
+        q = rich[:L].copy()
+        for _ in range(int(rng.integers(0, 4))):          # a few substitutions: near-identical heavy peptides
+            q[int(rng.integers(L))] = rng.integers(0, 20)
+        peps.append(q)
+    uniq = {bytes(p_): p_ for p_ in peps}
+    peps = [uniq[k] for k in sorted(uniq)]
+    order = rng.permutation(len(peps))
+    peps = [peps[i] for i in order]
+    res, off = hammock_amd.pack_sequences(peps)
+    for X, p_, thr in ((3, -1, 23), (3, 0, 20), (5, -2, 40)):
+        ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+        edges, stats = ctx.neighbors_shifted(X, p_, thr)
+        want = oracle_edges(coracle, blosum62, res, off, X, p_, thr)
+        assert np.array_equal(sorted_edges(edges), want), (X, p_, thr)
+        assert hammock_amd.edge_fields(want)[2].max() > 127 + thr   # such scores exist in the input
+        assert stats.classes_u8 > 0 and stats.classes_u16 > 0
+
+
 def test_neighbors_asymmetric_matrix(gpu, blosum62, coracle):
     rng = np.random.default_rng(5)
     M = blosum62.copy()
