@@ -1087,6 +1087,14 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         if (d_start) (void)hipFree(d_start);
         if (d_adj) (void)hipFree(d_adj);
     };
+    const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipDeviceSynchronize();
+        fprintf(stderr, "[hmk greedy] %s at %.2f ms\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
+    lap("neighbour pass (plan + kernels + counts)");
     hipError_t e = hipMalloc((void **)&d_deg, (size_t)n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, (size_t)n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_start, ((size_t)n + 1) * 8);
@@ -1096,6 +1104,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)n * 4, nullptr);
     if (e == hipSuccess) e = launch_csr_degree_scan(ctx->d_edges, seg, ctx->d_counts, n, ctx->symmetric, d_deg, d_start, d_tiles, nullptr);
     if (e == hipSuccess) e = launch_csr_scatter(ctx->d_edges, seg, ctx->d_counts, ctx->symmetric, d_start, d_cursor, d_adj, nullptr);
+    lap("CSR build on the device");
     if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + n_adj * sizeof(Nbr)) {
         if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
         ctx->h_csr = nullptr;
@@ -1108,7 +1117,9 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     Nbr *h_adj = (Nbr *)((char *)ctx->h_csr + ((size_t)n + 1) * 8);
     if (e == hipSuccess) e = hipMemcpy(h_start, d_start, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess && n_adj) e = hipMemcpy(h_adj, d_adj, n_adj * sizeof(Nbr), hipMemcpyDeviceToHost);
+    lap("D2H of the adjacency");
     cleanup();
+    lap("device buffers freed");
     if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,
                                      std::string("hmk_greedy_cluster (CSR build): ") + hipGetErrorString(e));
     if (h_start[n] != n_adj) return fail(ctx, HMK_ERR_DEVICE, "CSR build: adjacency size mismatch");
