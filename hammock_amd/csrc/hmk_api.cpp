@@ -1079,12 +1079,14 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
     uint32_t *d_deg = nullptr, *d_cursor = nullptr;
     uint64_t *d_start = nullptr, *d_tiles = nullptr;
-    Nbr *d_adj = nullptr;
+    int *d_range = nullptr;
+    void *d_adj = nullptr;
     auto cleanup = [&]() {
         if (d_tiles) (void)hipFree(d_tiles);
         if (d_deg) (void)hipFree(d_deg);
         if (d_cursor) (void)hipFree(d_cursor);
         if (d_start) (void)hipFree(d_start);
+        if (d_range) (void)hipFree(d_range);
         if (d_adj) (void)hipFree(d_adj);
     };
     const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;
@@ -1099,24 +1101,32 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, (size_t)n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_start, ((size_t)n + 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_tiles, scan_scratch_bytes(n));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_adj, std::max<uint64_t>(n_adj, 1) * sizeof(Nbr));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_range, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(d_deg, 0, (size_t)n * 4, nullptr);
     if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)n * 4, nullptr);
-    if (e == hipSuccess) e = launch_csr_degree_scan(ctx->d_edges, seg, ctx->d_counts, n, ctx->symmetric, d_deg, d_start, d_tiles, nullptr);
-    if (e == hipSuccess) e = launch_csr_scatter(ctx->d_edges, seg, ctx->d_counts, ctx->symmetric, d_start, d_cursor, d_adj, nullptr);
+    if (e == hipSuccess) e = launch_csr_degree_scan(ctx->d_edges, seg, ctx->d_counts, n, ctx->symmetric, d_deg, d_start, d_tiles,
+                                                   d_range, nullptr);
+    // 4-byte adjacency entries (m << 8 | score - lowest score) when the scores span at most 255
+    int range[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(range, d_range, sizeof(range), hipMemcpyDeviceToHost);
+    const bool packed = total == 0 || ((long long)range[1] - range[0] <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr);
+    const size_t esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
+    if (e == hipSuccess) e = hipMalloc(&d_adj, std::max<uint64_t>(n_adj, 1) * esz);
+    if (e == hipSuccess) e = launch_csr_scatter(ctx->d_edges, seg, ctx->d_counts, ctx->symmetric, d_start, d_cursor, d_adj, packed,
+                                                range[0], nullptr);
     lap("CSR build on the device");
-    if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + n_adj * sizeof(Nbr)) {
+    if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + n_adj * esz) {
         if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
         ctx->h_csr = nullptr;
         ctx->h_csr_cap = 0;
-        const size_t want = ((size_t)n + 1) * 8 + n_adj * sizeof(Nbr) + (1 << 20);
+        const size_t want = ((size_t)n + 1) * 8 + n_adj * esz + (1 << 20);
         e = hipHostMalloc(&ctx->h_csr, want, hipHostMallocDefault);
         if (e == hipSuccess) ctx->h_csr_cap = want;
     }
     uint64_t *h_start = (uint64_t *)ctx->h_csr;
-    Nbr *h_adj = (Nbr *)((char *)ctx->h_csr + ((size_t)n + 1) * 8);
+    void *h_adj = (char *)ctx->h_csr + ((size_t)n + 1) * 8;
     if (e == hipSuccess) e = hipMemcpy(h_start, d_start, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && n_adj) e = hipMemcpy(h_adj, d_adj, n_adj * sizeof(Nbr), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && n_adj) e = hipMemcpy(h_adj, d_adj, n_adj * esz, hipMemcpyDeviceToHost);
     lap("D2H of the adjacency");
     cleanup();
     lap("device buffers freed");
@@ -1125,8 +1135,11 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (h_start[n] != n_adj) return fail(ctx, HMK_ERR_DEVICE, "CSR build: adjacency size mismatch");
     const double nb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::string err;
-    st = greedy_from_csr(n, ctx->has_sizes ? ctx->sizes.data() : nullptr, h_start, h_adj, ctx->symmetric, max_clusters, cluster_id,
-                         result_order, member_rank, stats, &err);
+    const int32_t *szs = ctx->has_sizes ? ctx->sizes.data() : nullptr;
+    st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, ctx->symmetric, max_clusters, cluster_id,
+                                         result_order, member_rank, stats, &err)
+                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, ctx->symmetric, max_clusters, cluster_id, result_order,
+                                  member_rank, stats, &err);
     stats->n_edges = total;
     stats->neighbors_ms = nb_ms;
     if (st) return fail(ctx, st, err);

@@ -97,10 +97,12 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
 }
 
 // The merge proper, on a CSR adjacency: start[n + 1], adj[start[x] .. start[x + 1]) = neighbours of x.
-int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, bool symmetric_scores,
-                    int max_clusters,
-                    int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
-                    std::string *err) {
+// NbrT: Nbr (8 bytes) or NbrPacked (4 bytes); only id() and score() are used, scores only in comparisons.
+template <class NbrT>
+static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj, bool symmetric_scores,
+                                int max_clusters,
+                                int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
+                                std::string *err) {
     auto t0 = std::chrono::steady_clock::now();
     hmk_greedy_stats local;
     if (!st) st = &local;
@@ -121,10 +123,10 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         if (clusters.empty()) return Found{NEAR_DUMMY, -1, INT_MIN};  // :138-140
         touched.clear();
         for (uint64_t q = start[x]; q < start[x + 1]; q++) {
-            int32_t c = cluster_of[adj[q].m];
+            int32_t c = cluster_of[adj[q].id()];
             if (c < 0) continue;
-            if (cnt[c] == 0) { touched.push_back(c); mn[c] = adj[q].s; }
-            else if (adj[q].s < mn[c]) mn[c] = adj[q].s;
+            if (cnt[c] == 0) { touched.push_back(c); mn[c] = adj[q].score(); }
+            else if (adj[q].score() < mn[c]) mn[c] = adj[q].score();
             cnt[c]++;
         }
         Found best{NEAR_NULL, -1, 0};
@@ -163,11 +165,11 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
         } else {
             B = Found{NEAR_NULL, -1, 0};
             for (uint64_t q = start[k]; q < start[k + 1]; q++) {
-                uint32_t m = adj[q].m;
+                uint32_t m = adj[q].id();
                 if (state[m] != ST_FREE) continue;  // only untouched singletons follow x
                 if (B.kind == NEAR_NULL ||
-                    better(adj[q].s, seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot))
-                    B = Found{NEAR_REAL, (int32_t)m, adj[q].s};
+                    better(adj[q].score(), seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot))
+                    B = Found{NEAR_REAL, (int32_t)m, adj[q].score()};
             }
         }
         bool absorb = false;
@@ -240,10 +242,10 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
                     const uint32_t y = leftover[q];
                     seen.clear();
                     for (uint64_t e = start[y]; e < start[y + 1]; e++) {
-                        const int32_t c = cluster_of[adj[e].m];
+                        const int32_t c = cluster_of[adj[e].id()];
                         if (c < 0) continue;
-                        if (c2[c]++ == 0) { seen.push_back(c); m2[c] = adj[e].s; }
-                        else if (adj[e].s < m2[c]) m2[c] = adj[e].s;
+                        if (c2[c]++ == 0) { seen.push_back(c); m2[c] = adj[e].score(); }
+                        else if (adj[e].score() < m2[c]) m2[c] = adj[e].score();
                     }
                     uint32_t k = 0;
                     for (int32_t c : seen) {
@@ -319,8 +321,8 @@ int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, con
                     joined[F.slot]++;
                     stamp++;
                     for (uint64_t e = start[y]; e < start[y + 1]; e++) {
-                        stamp_of[adj[e].m] = stamp;
-                        stamp_score[adj[e].m] = adj[e].s;
+                        stamp_of[adj[e].id()] = stamp;
+                        stamp_score[adj[e].id()] = adj[e].score();
                     }
                     for (uint32_t u = sub_start[F.slot]; u < sub_start[F.slot + 1]; u++) {
                         const Sub sb = subs[u];
@@ -371,6 +373,19 @@ crash:
                "case " + std::to_string(st->crash_case) + " at index " + std::to_string(st->crash_index);
     st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return HMK_ERR_REFERENCE_WOULD_CRASH;
+}
+
+int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, bool symmetric_scores, int max_clusters,
+                    int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
+    return greedy_from_csr_impl<Nbr>(n, sizes, start, adj, symmetric_scores, max_clusters, cluster_id, result_order, member_rank,
+                                     st, err);
+}
+
+int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj, bool symmetric_scores,
+                           int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
+                           hmk_greedy_stats *st, std::string *err) {
+    return greedy_from_csr_impl<NbrPacked>(n, sizes, start, adj, symmetric_scores, max_clusters, cluster_id, result_order,
+                                           member_rank, st, err);
 }
 
 }  // namespace hmk

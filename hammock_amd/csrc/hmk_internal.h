@@ -58,6 +58,16 @@ struct NeighborParams {
 struct Nbr {
     uint32_t m;
     int32_t s;
+    uint32_t id() const { return m; }
+    int32_t score() const { return s; }
+};
+// the same in 4 bytes: m << 8 | (s - base), usable when every stored score is within base .. base + 255.
+// The merge only compares scores, so the common offset does not matter; half the bytes to copy from the
+// device and to walk on the host.
+struct NbrPacked {
+    uint32_t v;
+    uint32_t id() const { return v >> 8; }
+    int32_t score() const { return (int32_t)(v & 0xFFu); }
 };
 
 // host greedy merge (hmk_greedy.cpp)
@@ -65,6 +75,9 @@ struct Nbr {
 int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, bool symmetric_scores, int max_clusters,
                     int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                     std::string *err);
+int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj, bool symmetric_scores,
+                           int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
+                           hmk_greedy_stats *st, std::string *err);
 int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
                       bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,
                       int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err);

@@ -1194,16 +1194,29 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
 // passes turn them into start[n + 1] / adj[] (each undirected edge stored under both
 // ends when the matrix is symmetric): degree count, exclusive scan, scatter.  Order
 // inside a row is arbitrary (atomic cursors); the merge does not depend on it.
+// score_range[0] / [1]: smallest / largest edge score (decides whether the 4-byte adjacency fits)
 __global__ void __launch_bounds__(256)
 k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
-              uint32_t *__restrict__ deg, int symmetric) {
+              uint32_t *__restrict__ deg, int symmetric, int *__restrict__ score_range) {
     const uint32_t shard = blockIdx.y;
     const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
     const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
+    int lo = INT_MAX, hi = INT_MIN;
     for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256) {
         const uint64_t e = seg[k];
         atomicAdd(&deg[HMK_EDGE_X(e)], 1u);
         if (symmetric) atomicAdd(&deg[HMK_EDGE_M(e)], 1u);
+        const int sc = HMK_EDGE_SCORE(e);
+        lo = min(lo, sc);
+        hi = max(hi, sc);
+    }
+    for (int o = 32; o; o >>= 1) {
+        lo = min(lo, __shfl_down(lo, o, 64));
+        hi = max(hi, __shfl_down(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&score_range[0], lo);
+        atomicMax(&score_range[1], hi);
     }
 }
 
@@ -1294,9 +1307,12 @@ static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *til
     hipLaunchKernelGGL((k_scan_tiles<T>), dim3(n_tiles), dim3(256), 0, s, deg, tile_scratch, start, n, n_tiles, tail_word);
 }
 
+// NbrT = Nbr: {m, score}.  NbrT = NbrPacked: m << 8 | (score - base), the caller has checked the score range.
+template <class NbrT>
 __global__ void __launch_bounds__(256)
 k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
-               const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, Nbr *__restrict__ adj, int symmetric) {
+               const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, NbrT *__restrict__ adj, int symmetric,
+               int base) {
     const uint32_t shard = blockIdx.y;
     const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
     const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
@@ -1304,8 +1320,14 @@ k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const
         const uint64_t e = seg[k];
         const uint32_t x = HMK_EDGE_X(e), m = HMK_EDGE_M(e);
         const int32_t s = HMK_EDGE_SCORE(e);
-        adj[start[x] + atomicAdd(&cursor[x], 1u)] = Nbr{m, s};
-        if (symmetric) adj[start[m] + atomicAdd(&cursor[m], 1u)] = Nbr{x, s};
+        if constexpr (sizeof(NbrT) == 4) {
+            const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
+            adj[start[x] + atomicAdd(&cursor[x], 1u)] = NbrT{(m << 8) | rel};
+            if (symmetric) adj[start[m] + atomicAdd(&cursor[m], 1u)] = NbrT{(x << 8) | rel};
+        } else {
+            adj[start[x] + atomicAdd(&cursor[x], 1u)] = NbrT{m, s};
+            if (symmetric) adj[start[m] + atomicAdd(&cursor[m], 1u)] = NbrT{x, s};
+        }
     }
 }
 
@@ -1526,17 +1548,26 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
 }
 
 hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
-                                  bool symmetric, uint32_t *deg, uint64_t *start, uint64_t *tile_scratch, hipStream_t s) {
+                                  bool symmetric, uint32_t *deg, uint64_t *start, uint64_t *tile_scratch, int *score_range,
+                                  hipStream_t s) {
+    const int init[2] = {INT_MAX, INT_MIN};
+    hipError_t e = hipMemcpyAsync(score_range, init, sizeof(init), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_edge_degree, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg,
-                       symmetric ? 1 : 0);
+                       symmetric ? 1 : 0, score_range);
     launch_scan<uint64_t>(deg, start, n, tile_scratch, nullptr, s);
     return hipGetLastError();
 }
 
 hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
-                              bool symmetric, const uint64_t *start, uint32_t *cursor, Nbr *adj, hipStream_t s) {
-    hipLaunchKernelGGL(k_edge_scatter, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, start,
-                       cursor, adj, symmetric ? 1 : 0);
+                              bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj, bool packed, int base,
+                              hipStream_t s) {
+    if (packed)
+        hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard,
+                           counts, start, cursor, (NbrPacked *)adj, symmetric ? 1 : 0, base);
+    else
+        hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts,
+                           start, cursor, (Nbr *)adj, symmetric ? 1 : 0, base);
     return hipGetLastError();
 }
 

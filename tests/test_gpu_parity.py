@@ -285,6 +285,27 @@ def test_greedy_synthetic_vs_oracle(gpu, blosum62, coracle, cfg):
     assert stats.phase1_stop_index == ostats.phase1_stop_index and stats.n_multi == ostats.n_multi
 
 
+def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
+    """hmk_greedy_cluster ships the adjacency to the host as 4-byte entries when the edge scores span at
+    most 255 and as 8-byte entries otherwise; both must give the oracle's clustering.  BLOSUM62 x 12 makes
+    the span exceed 255 naturally; HMK_ADJ_8BYTE forces the wide form on the plain matrix."""
+    res, off = synth_peptides(9, 8000, 12)
+    for M, thr, env in ((blosum62, 18, None), (blosum62, 18, "1"), (blosum62 * 12, 216, None)):
+        if env:
+            monkeypatch.setenv("HMK_ADJ_8BYTE", env)
+        else:
+            monkeypatch.delenv("HMK_ADJ_8BYTE", raising=False)
+        ctx, _, _ = ctx_for(M, res=res, off=off)
+        st, ocid, oorder, ostats = coracle.greedy_cluster(M, res, off, None, 0, 3, 0, thr, 200, 8)
+        assert st == 0
+        cid, order, stats = ctx.greedy_cluster(3, 0, thr, 200)
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder), (thr, env)
+        if M is not blosum62:
+            edges, _ = ctx.neighbors_shifted(3, 0, thr)
+            sc = hammock_amd.edge_fields(edges)[2]
+            assert int(sc.max()) - int(sc.min()) > 255   # the wide form was really needed
+
+
 def test_greedy_crash_parity_on_gpu(gpu, blosum62):
     ctx, _, _ = ctx_for(blosum62, ["WWWWWWWW", "CCCCCCCC", "PPPPPPPP", "GGGGGGGG"])
     with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
