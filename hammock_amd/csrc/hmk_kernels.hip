@@ -1194,6 +1194,30 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
 // passes turn them into start[n + 1] / adj[] (each undirected edge stored under both
 // ends when the matrix is symmetric): degree count, exclusive scan, scatter.  Order
 // inside a row is arbitrary (atomic cursors); the merge does not depend on it.
+// One atomicAdd per distinct key of a wave instead of one per lane (a wave's 64 consecutive edges come
+// from a handful of tile rows).  wave_groups() finds, without touching memory, each lane's group
+// (lanes holding the same key): the group's first lane, this lane's rank in it and the group size.
+// Must be called by all 64 lanes (wave-uniform control flow); lanes with valid == false take no part.
+struct WaveGroup { uint32_t leader, rank, size; };
+__device__ __forceinline__ WaveGroup wave_groups(uint32_t key, bool valid) {
+    const uint32_t lane = threadIdx.x & 63;
+    WaveGroup g{lane, 0, 0};
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+        const bool mine = valid && key == k0;
+        const uint64_t same = __ballot(mine);
+        if (mine) {
+            g.leader = (uint32_t)leader;
+            g.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            g.size = (uint32_t)__popcll(same);
+        }
+        todo &= ~same;
+    }
+    return g;
+}
+
 // score_range[0] / [1]: smallest / largest edge score (decides whether the 4-byte adjacency fits)
 __global__ void __launch_bounds__(256)
 k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
@@ -1202,13 +1226,19 @@ k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const 
     const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
     const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
     int lo = INT_MAX, hi = INT_MIN;
-    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256) {
-        const uint64_t e = seg[k];
-        atomicAdd(&deg[HMK_EDGE_X(e)], 1u);
-        if (symmetric) atomicAdd(&deg[HMK_EDGE_M(e)], 1u);
-        const int sc = HMK_EDGE_SCORE(e);
-        lo = min(lo, sc);
-        hi = max(hi, sc);
+    // wave-uniform loop: the x side of a wave's 64 consecutive edges has a handful of distinct values
+    for (uint64_t k0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); k0 < cnt; k0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = k0 + (threadIdx.x & 63);
+        const bool valid = k < cnt;
+        const uint64_t e = valid ? seg[k] : 0;
+        const WaveGroup g = wave_groups(HMK_EDGE_X(e), valid);
+        if (valid && g.rank == 0) atomicAdd(&deg[HMK_EDGE_X(e)], g.size);
+        if (valid && symmetric) atomicAdd(&deg[HMK_EDGE_M(e)], 1u);
+        if (valid) {
+            const int sc = HMK_EDGE_SCORE(e);
+            lo = min(lo, sc);
+            hi = max(hi, sc);
+        }
     }
     for (int o = 32; o; o >>= 1) {
         lo = min(lo, __shfl_down(lo, o, 64));
@@ -1316,16 +1346,24 @@ k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const
     const uint32_t shard = blockIdx.y;
     const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
     const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
-    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256) {
-        const uint64_t e = seg[k];
+    for (uint64_t k0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); k0 < cnt; k0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t k = k0 + (threadIdx.x & 63);
+        const bool valid = k < cnt;
+        const uint64_t e = valid ? seg[k] : 0;
         const uint32_t x = HMK_EDGE_X(e), m = HMK_EDGE_M(e);
         const int32_t s = HMK_EDGE_SCORE(e);
+        const WaveGroup g = wave_groups(x, valid);   // one atomic per distinct x of the wave
+        uint32_t basex = 0;
+        if (valid && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
+        basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
+        if (!valid) continue;
+        const uint64_t px = start[x] + basex + g.rank;
         if constexpr (sizeof(NbrT) == 4) {
             const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
-            adj[start[x] + atomicAdd(&cursor[x], 1u)] = NbrT{(m << 8) | rel};
+            adj[px] = NbrT{(m << 8) | rel};
             if (symmetric) adj[start[m] + atomicAdd(&cursor[m], 1u)] = NbrT{(x << 8) | rel};
         } else {
-            adj[start[x] + atomicAdd(&cursor[x], 1u)] = NbrT{m, s};
+            adj[px] = NbrT{m, s};
             if (symmetric) adj[start[m] + atomicAdd(&cursor[m], 1u)] = NbrT{x, s};
         }
     }
@@ -1356,30 +1394,6 @@ k_compact_edges(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, cons
 // A rank's edge segments regrouped by x: row_start[n + 2] (uint32; [n] = total, [n + 1] =
 // number of edges whose score - threshold did not fit 8 bits, must be 0) and one uint32 per
 // edge, m << 8 | (score - threshold).  Halves the bytes the all-gather ships over xGMI.
-// One atomicAdd per distinct key of a wave instead of one per lane (a wave's 64 consecutive edges come
-// from a handful of tile rows).  wave_groups() finds, without touching memory, each lane's group
-// (lanes holding the same key): the group's first lane, this lane's rank in it and the group size.
-// Must be called by all 64 lanes (wave-uniform control flow); lanes with valid == false take no part.
-struct WaveGroup { uint32_t leader, rank, size; };
-__device__ __forceinline__ WaveGroup wave_groups(uint32_t key, bool valid) {
-    const uint32_t lane = threadIdx.x & 63;
-    WaveGroup g{lane, 0, 0};
-    uint64_t todo = __ballot(valid);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-        const bool mine = valid && key == k0;
-        const uint64_t same = __ballot(mine);
-        if (mine) {
-            g.leader = (uint32_t)leader;
-            g.rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            g.size = (uint32_t)__popcll(same);
-        }
-        todo &= ~same;
-    }
-    return g;
-}
-
 constexpr int ROWS_UNROLL = 4;  // independent 64-edge groups per wave iteration (memory-level parallelism)
 
 __global__ void __launch_bounds__(256)
