@@ -192,6 +192,13 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     if (pl.valid && pl.X == X && pl.p == p && pl.thr == thr && pl.part == part && pl.n_parts == n_parts)
         return HMK_OK;
     free_plan(pl);
+    const bool plan_timing = getenv("HMK_PLAN_TIMING") != nullptr;
+    const auto plan_t0 = std::chrono::steady_clock::now();
+    auto plan_lap = [&](const char *what) {
+        if (plan_timing)
+            fprintf(stderr, "[hmk plan] %s at %.2f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - plan_t0).count());
+    };
     const uint32_t n = ctx->n;
     if (n == 0) return fail(ctx, HMK_ERR_NO_SEQUENCES, "no sequences set (hmk_set_sequences)");
     if (X < 0) return fail(ctx, HMK_ERR_BAD_ARG, "max_shift must be >= 0");
@@ -258,6 +265,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         bound_sorted.resize(n);
         for (uint32_t q = 0; q < n; q++) bound_sorted[q] = bound[perm[q]];
     }
+    plan_lap("buckets and score bounds");
     pl.lbmax = swar_lbmax_for(ctx->max_len);
     pl.lpad = ctx->max_len <= 16 ? 16 : 32;
     // The exact hot kernel: every sequence has length 12, max shift 3, and the (12, 12) class fits 8-bit
@@ -283,6 +291,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     std::map<int, int> class_of;  // la * 64 + lb
     std::map<std::tuple<int, int, int>, std::vector<Tile>> grouped;  // (path, nw, column capacity)
     const uint32_t COLS = pl.cols_per_tile;
+    const bool equal_runs = getenv("HMK_NO_EQUAL_RUNS") == nullptr;
     hmk_neighbor_stats &S = pl.stats;
     S = hmk_neighbor_stats{};
     S.symmetric = ctx->symmetric;
@@ -321,57 +330,58 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                 if (split < re) ranges.push_back(Range{split, re, tc0});
             }
             for (const Range &rg : ranges) {
-            const TileClass &tc = rg.tc;
-            const int cls = (int)classes.size();
-            classes.push_back(tc);
-            class_of[la * 64 + lb] = cls;
-            if (tc.path == PATH_U8) S.classes_u8++;
-            else if (tc.path == PATH_U16) S.classes_u16++;
-            else S.classes_direct++;
-            const int lbk = pl.exact ? 12 : swar_lbmax_for(lb);
-            const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(lbk, tc.nw, pl.exact, pl.hot_variant);
-            std::vector<Tile> &dst = grouped[std::make_tuple((int)tc.path, tc.path == PATH_DIRECT ? 0 : (int)tc.nw,
-                                                             tc.path == PATH_DIRECT ? 0 : lbk)];
-            for (uint32_t r0 = rg.lo; r0 < rg.hi; r0 += R) {
-                const bool mine = (row_chunk_counter++ % n_parts) == part;
-                if (!mine) continue;
-                const uint32_t nr = std::min(R, rg.hi - r0);
-                uint32_t c_lo = cb, c_hi = ce;
-                if (same && ctx->symmetric) c_lo = r0 + 1;  // triangle: columns after the first row of the chunk
-                // equal column runs (whole 256-column batches) instead of full runs + one short rest:
-                // no tiny tiles whose table build is not amortised, and an even tail
-                uint32_t run = COLS;
-                if (c_hi > c_lo && getenv("HMK_NO_EQUAL_RUNS") == nullptr) {
-                    const uint32_t k_runs = (c_hi - c_lo + COLS - 1) / COLS;
-                    run = ((c_hi - c_lo + k_runs - 1) / k_runs + 255u) & ~255u;
-                    run = std::min(run, COLS);
-                }
-                for (uint32_t c0 = c_lo; c0 < c_hi; c0 += run) {
-                    Tile t{};
-                    t.row0 = r0; t.nrows = nr;
-                    t.col0 = c0; t.ncols = std::min(run, c_hi - c0);
-                    t.cls = (uint32_t)cls;
-                    const bool overlap = same && c0 < r0 + nr && c0 + t.ncols > r0;
-                    t.diag = overlap ? (ctx->symmetric ? 1u : 2u) : 0u;
-                    uint64_t pairs = (uint64_t)nr * t.ncols;
-                    if (t.diag == 1) {
-                        pairs = 0;
-                        for (uint32_t r = r0; r < r0 + nr; r++) {
-                            const uint32_t lo = std::max(c0, r + 1), hi = c0 + t.ncols;
-                            if (hi > lo) pairs += hi - lo;
-                        }
-                    } else if (t.diag == 2) {
-                        for (uint32_t r = r0; r < r0 + nr; r++)
-                            if (r >= c0 && r < c0 + t.ncols) pairs--;
+                const TileClass &tc = rg.tc;
+                const int cls = (int)classes.size();
+                classes.push_back(tc);
+                class_of[la * 64 + lb] = cls;
+                if (tc.path == PATH_U8) S.classes_u8++;
+                else if (tc.path == PATH_U16) S.classes_u16++;
+                else S.classes_direct++;
+                const int lbk = pl.exact ? 12 : swar_lbmax_for(lb);
+                const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(lbk, tc.nw, pl.exact, pl.hot_variant);
+                std::vector<Tile> &dst = grouped[std::make_tuple((int)tc.path, tc.path == PATH_DIRECT ? 0 : (int)tc.nw,
+                                                                 tc.path == PATH_DIRECT ? 0 : lbk)];
+                for (uint32_t r0 = rg.lo; r0 < rg.hi; r0 += R) {
+                    const bool mine = (row_chunk_counter++ % n_parts) == part;
+                    if (!mine) continue;
+                    const uint32_t nr = std::min(R, rg.hi - r0);
+                    uint32_t c_lo = cb, c_hi = ce;
+                    if (same && ctx->symmetric) c_lo = r0 + 1;  // triangle: columns after the first row of the chunk
+                    // equal column runs (whole 256-column batches) instead of full runs + one short rest:
+                    // no tiny tiles whose table build is not amortised, and an even tail
+                    uint32_t run = COLS;
+                    if (c_hi > c_lo && equal_runs) {
+                        const uint32_t k_runs = (c_hi - c_lo + COLS - 1) / COLS;
+                        run = ((c_hi - c_lo + k_runs - 1) / k_runs + 255u) & ~255u;
+                        run = std::min(run, COLS);
                     }
-                    if (pairs == 0) continue;
-                    S.pairs_scored += pairs;
-                    dst.push_back(t);
+                    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += run) {
+                        Tile t{};
+                        t.row0 = r0; t.nrows = nr;
+                        t.col0 = c0; t.ncols = std::min(run, c_hi - c0);
+                        t.cls = (uint32_t)cls;
+                        const bool overlap = same && c0 < r0 + nr && c0 + t.ncols > r0;
+                        t.diag = overlap ? (ctx->symmetric ? 1u : 2u) : 0u;
+                        uint64_t pairs = (uint64_t)nr * t.ncols;
+                        if (t.diag == 1) {
+                            pairs = 0;
+                            for (uint32_t r = r0; r < r0 + nr; r++) {
+                                const uint32_t lo = std::max(c0, r + 1), hi = c0 + t.ncols;
+                                if (hi > lo) pairs += hi - lo;
+                            }
+                        } else if (t.diag == 2) {
+                            for (uint32_t r = r0; r < r0 + nr; r++)
+                                if (r >= c0 && r < c0 + t.ncols) pairs--;
+                        }
+                        if (pairs == 0) continue;
+                        S.pairs_scored += pairs;
+                        dst.push_back(t);
+                    }
                 }
             }
-            }  // ranges
         }
     }
+    plan_lap("classes and tiles");
     std::vector<Tile> tiles;
     for (auto &kv : grouped) {
         if (kv.second.empty()) continue;
@@ -385,6 +395,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         tiles.insert(tiles.end(), kv.second.begin(), kv.second.end());
     }
     S.n_tiles = (uint32_t)tiles.size();
+    plan_lap("tile order");
 
     // ---- device copies ------------------------------------------------------------
     std::vector<uint8_t> res_sorted((size_t)n * pl.lpad, 0);
@@ -413,6 +424,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         HIPCHK(ctx, hipMemcpy(pl.d_tiles, tiles.data(), tiles.size() * sizeof(Tile), hipMemcpyHostToDevice));
     pl.X = X; pl.p = p; pl.thr = thr; pl.part = part; pl.n_parts = n_parts;
     pl.valid = true;
+    plan_lap("device copies");
     return HMK_OK;
 }
 
