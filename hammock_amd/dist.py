@@ -125,7 +125,7 @@ class PipelinedExchange:
     found by one warm-up pass."""
 
     def __init__(self, ctx: Context, max_shift, shift_penalty, threshold, rank, world, device, group=None, fmt="rows",
-                 shard=None):
+                 shard=None, use_collectives=None):
         if fmt not in ("rows", "edges"):
             raise ValueError(fmt)
         self.ctx, self.args = ctx, (int(max_shift), int(shift_penalty), int(threshold))
@@ -133,6 +133,9 @@ class PipelinedExchange:
         # shard = (part, n_parts) of the pair space this rank scores; default: one shard per rank.
         # (tools/px_step_time.py overrides it to time a 1/8 shard's step on a single GPU.)
         self.part, self.n_parts = shard if shard is not None else (rank, world)
+        # the collectives run whenever there is more than one rank; a single-rank process group can ask for
+        # them too (tests: exercises the RCCL calls, dtypes and stream order on a one-GPU box)
+        self.collectives = (world > 1) if use_collectives is None else bool(use_collectives)
         n = ctx.n
         self.capacity = ((int(n * (n - 1) // 2 * 6e-3 / self.n_parts) + (1 << 20)) // N.HMK_EDGE_SHARDS + 1) * N.HMK_EDGE_SHARDS
         self.comp = torch.cuda.Stream(device)
@@ -148,7 +151,7 @@ class PipelinedExchange:
             raise BufferError("edge segment overflow in the warm-up pass")
         self.local_total = int(sum(cnt))
         mx = torch.tensor([self.local_total], dtype=torch.int64, device=device)
-        if world > 1:
+        if self.collectives:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
         self.pad = int(mx.item()) + 64
         if fmt == "rows":
@@ -197,7 +200,7 @@ class PipelinedExchange:
                 self.ctx.compact_edges_dev(e.data_ptr(), self.capacity, c.data_ptr(), self.block[b].data_ptr(), self.pad,
                                            self.head[b].data_ptr(), self.comm.cuda_stream)
             self.packed[b].record(self.comm)
-            if self.world > 1:
+            if self.collectives:
                 dist.all_gather_into_tensor(self.gathered[b], self.block[b], group=self.group)
                 dist.all_gather_into_tensor(self.heads_all[b], self.head[b], group=self.group)
             else:

@@ -230,3 +230,45 @@ def test_pipelined_exchange_two_ranks_one_gpu():
     for rank, oks in out:
         assert oks[0] is True and oks[2] is True, out
         assert oks[1] < 0.6 * oks[3], out
+
+
+def _nccl_single_rank_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # "nccl" is RCCL on ROCm
+    import json
+    import hammock_amd
+    from hammock_amd import dist as hd
+    from hammock_amd.synth import synth_peptides
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+    res, off = synth_peptides(5, 20000, 12)
+    ctx = hammock_amd.Context(M, device=0)
+    ctx.set_sequences(residues=res, offsets=off)
+    want, _ = ctx.neighbors_shifted(3, 0, 20)
+    oks = []
+    for fmt in ("rows", "edges"):
+        px = hd.PipelinedExchange(ctx, 3, 0, 20, 0, 1, dev, fmt=fmt, use_collectives=True)
+        for _ in range(4):
+            px.step()
+        got = px.last_result().cpu().numpy().view(np.uint64)
+        oks.append(bool(np.array_equal(np.sort(got), np.sort(want))))
+    q.put(oks)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_pipelined_exchange_over_rccl_single_rank():
+    """The exchange's RCCL calls (all_reduce, all_gather_into_tensor on int32 / int64 blocks, issued on the
+    communication stream) on a one-rank "nccl" group: the only RCCL run a one-GPU box allows."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    oks = q.get(timeout=400)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert oks == [True, True], oks
