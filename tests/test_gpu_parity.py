@@ -306,6 +306,28 @@ def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
             assert int(sc.max()) - int(sc.min()) > 255   # the wide form was really needed
 
 
+def test_greedy_antibodies_example_vs_oracle(gpu, blosum62, coracle, tmp_path):
+    """The reference's own large example (examples/antibodies: 88,544 FASTA records, 74,041 unique 12-mers,
+    counts and 15 labels in the headers; real phage-display data with heavy near-duplicate families, unlike
+    the uniform synthetic sets) through the reference's greedy defaults: identical clusters and order."""
+    import gzip
+    fa = tmp_path / "antibodies.fa"
+    with gzip.open(os.path.join(GOLDEN, "antibodies.fa.gz"), "rb") as src:
+        fa.write_bytes(src.read())
+    seqs = po.load_unique_sequences_from_fasta(str(fa))
+    thr, X, maxc = po.greedy_defaults(seqs)
+    assert (len(seqs), thr, X, maxc) == (74041, 20, 3, 1851)
+    po.sort_sequences(seqs, "size")
+    res, off = coracle.pack([s.get_sequence_string() for s in seqs])
+    sizes = np.array([s.size() for s in seqs], dtype=np.int32)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, X, 0, thr, maxc, 16)
+    assert st == 0
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
+    cid, order, stats = ctx.greedy_cluster(X, 0, thr, maxc)
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert stats.phase1_stop_index == ostats.phase1_stop_index and stats.n_multi == maxc
+
+
 def test_greedy_crash_parity_on_gpu(gpu, blosum62):
     ctx, _, _ = ctx_for(blosum62, ["WWWWWWWW", "CCCCCCCC", "PPPPPPPP", "GGGGGGGG"])
     with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
