@@ -277,8 +277,8 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         std::vector<Sub> subs;
         std::vector<int32_t> covered;                    // per (leftover, candidate slot): joined members that are neighbours
         std::vector<int32_t> joined;                     // members that joined each cluster in this loop
-        std::vector<uint32_t> stamp_of;                  // sequence -> stamp of the join that last touched it
-        std::vector<int32_t> stamp_score;
+        std::vector<uint64_t> stamped;                   // sequence -> (stamp of the join that last touched it) << 32 | score,
+                                                         // one word so that stamping and testing touch one cache line
         if (use_subs) {
             const size_t nc = clusters.size();
             sub_start.assign(nc + 1, 0);
@@ -290,8 +290,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                 for (uint32_t k = cand_start[q]; k < cand_start[q + 1]; k++) subs[fill[cand[k].c]++] = Sub{(int32_t)q, (int32_t)k};
             covered.assign(cand.size(), 0);
             joined.assign(nc, 0);
-            stamp_of.assign(n, 0);
-            stamp_score.assign(n, 0);
+            stamped.assign(n, 0);
         }
         uint32_t stamp = 0;
         std::vector<uint32_t> rest;
@@ -320,18 +319,19 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     auto tb = now();
                     joined[F.slot]++;
                     stamp++;
-                    for (uint64_t e = start[y]; e < start[y + 1]; e++) {
-                        stamp_of[adj[e].id()] = stamp;
-                        stamp_score[adj[e].id()] = adj[e].score();
-                    }
+                    const uint64_t hi = (uint64_t)stamp << 32;
+                    for (uint64_t e = start[y]; e < start[y + 1]; e++)
+                        stamped[adj[e].id()] = hi | (uint32_t)adj[e].score();
                     for (uint32_t u = sub_start[F.slot]; u < sub_start[F.slot + 1]; u++) {
                         const Sub sb = subs[u];
                         if ((size_t)sb.q <= q) continue;    // already decided
                         const uint32_t w = leftover[sb.q];
-                        if (stamp_of[w] != stamp) continue; // w is not a neighbour of the new member
+                        const uint64_t sw = stamped[w];
+                        if ((uint32_t)(sw >> 32) != stamp) continue; // w is not a neighbour of the new member
                         covered[sb.k]++;
                         Cand &cw = cand[sb.k];
-                        if (stamp_score[w] < cw.mn) cw.mn = stamp_score[w];
+                        const int32_t sc = (int32_t)(uint32_t)sw;
+                        if (sc < cw.mn) cw.mn = sc;
                     }
                     if (timing) t_push += std::chrono::duration<double, std::milli>(now() - tb).count();
                 }
