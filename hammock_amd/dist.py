@@ -140,15 +140,19 @@ class PipelinedExchange:
         self.capacity = ((int(n * (n - 1) // 2 * 6e-3 / self.n_parts) + (1 << 20)) // N.HMK_EDGE_SHARDS + 1) * N.HMK_EDGE_SHARDS
         self.comp = torch.cuda.Stream(device)
         self.comm = torch.cuda.Stream(device)
-        self.buf = [self._alloc_score() for _ in range(2)]
-        # warm-up pass sizes the exchange block
-        e, c = self.buf[0]
-        ctx.neighbors_shifted_dev(*self.args, self.part, self.n_parts, e.data_ptr(), self.capacity, c.data_ptr(),
-                                  self.comp.cuda_stream)
-        self.comp.synchronize()
-        cnt = c.tolist()
-        if max(cnt) > self.capacity // N.HMK_EDGE_SHARDS:
-            raise BufferError("edge segment overflow in the warm-up pass")
+        # warm-up pass sizes the score buffers (regrown if a segment overflows: denser data than uniform
+        # random peptides) and the exchange block
+        while True:
+            e, c = self._alloc_score()
+            ctx.neighbors_shifted_dev(*self.args, self.part, self.n_parts, e.data_ptr(), self.capacity, c.data_ptr(),
+                                      self.comp.cuda_stream)
+            self.comp.synchronize()
+            cnt = c.tolist()
+            if max(cnt) <= self.capacity // N.HMK_EDGE_SHARDS:
+                break
+            del e, c
+            self.capacity = (max(cnt) + max(cnt) // 8 + 1024) * N.HMK_EDGE_SHARDS
+        self.buf = [(e, c), self._alloc_score()]
         self.local_total = int(sum(cnt))
         mx = torch.tensor([self.local_total], dtype=torch.int64, device=device)
         if self.collectives:

@@ -129,13 +129,15 @@ def test_pipelined_exchange_single_rank_matches_neighbors(fmt):
     res, off = synth_peptides(3, 30000, 12)
     ctx = hammock_amd.Context(M, device=0)
     ctx.set_sequences(residues=res, offsets=off)
-    want, _ = ctx.neighbors_shifted(3, 0, 20)
-    px = hd.PipelinedExchange(ctx, 3, 0, 20, 0, 1, torch.device("cuda", 0), fmt=fmt)
-    for k in range(5):
-        px.step()
-        if k in (0, 3, 4):
-            got = px.last_result().cpu().numpy().view(np.uint64)
-            assert np.array_equal(np.sort(got), np.sort(want)), k
+    for thr in (20, 8):          # thr 8: far denser than the buffers are first sized for -> they are regrown
+        want, _ = ctx.neighbors_shifted(3, 0, thr)
+        px = hd.PipelinedExchange(ctx, 3, 0, thr, 0, 1, torch.device("cuda", 0), fmt=fmt)
+        for k in range(5):
+            px.step()
+            if k in (0, 3, 4):
+                got = px.last_result().cpu().numpy().view(np.uint64)
+                assert np.array_equal(np.sort(got), np.sort(want)), (thr, k)
+        del px
 
 
 @pytest.mark.gpu
