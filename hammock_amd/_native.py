@@ -29,7 +29,7 @@ SYMBOLS = [
     "hmk_score_pairs_shifted", "hmk_score_with_shift", "hmk_score_pairs_local", "hmk_score_block_shifted", "hmk_score_block_local",
     "hmk_neighbors_shifted", "hmk_neighbors_local", "hmk_neighbors_shifted_dev", "hmk_compact_edges_dev", "hmk_pack_rows_dev", "hmk_unpack_rows_dev",
     "hmk_neighbors_last_plan",
-    "hmk_greedy_cluster", "hmk_greedy_from_edges",
+    "hmk_greedy_cluster", "hmk_greedy_from_edges", "hmk_greedy_from_edges_dev",
 ]
 
 
@@ -89,6 +89,7 @@ def _load():
     L.hmk_unpack_rows_dev.argtypes = [vp, vp, vp, i32, vp, u64, vp]
     L.hmk_neighbors_last_plan.argtypes = [vp, C.POINTER(NeighborStats)]
     L.hmk_greedy_cluster.argtypes = [vp, i32, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
+    L.hmk_greedy_from_edges_dev.argtypes = [vp, vp, u64, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
     L.hmk_greedy_from_edges.argtypes = [vp, p_u64, u64, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
     for name in SYMBOLS:
         fn = getattr(L, name)

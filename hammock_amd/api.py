@@ -293,6 +293,19 @@ class Context:
             self._raise(st, stats)
         return cid[:self.n], order[:stats.n_result_clusters], stats
 
+    def greedy_from_edges_dev(self, d_edges_ptr, n_edges, symmetric, max_clusters):
+        """hmk_greedy_from_edges_dev: packed edges in device memory -> clusters (CSR built on the device)."""
+        cid = np.full(max(self.n, 1), -1, dtype=np.int32)
+        order = np.full(max(self.n, 1), -1, dtype=np.int32)
+        stats = N.GreedyStats()
+        self.member_rank = np.zeros(max(self.n, 1), dtype=np.int32)
+        st = N.lib.hmk_greedy_from_edges_dev(self._h, C.c_void_p(d_edges_ptr), int(n_edges), int(bool(symmetric)),
+                                             int(max_clusters), _ptr(cid, C.c_int32), _ptr(order, C.c_int32),
+                                             _ptr(self.member_rank, C.c_int32), C.byref(stats))
+        if st:
+            self._raise(st, stats)
+        return cid[:self.n], order[:stats.n_result_clusters], stats
+
 
 # -----------------------------------------------------------------------------------------
 # mirrors of the reference classes

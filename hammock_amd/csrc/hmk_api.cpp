@@ -1069,26 +1069,15 @@ int hmk_greedy_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges,
     return HMK_OK;
 }
 
-int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters,
-                       int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
-    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    if (ctx->n && !cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
-    hmk_greedy_stats local;
-    if (!stats) stats = &local;
-    std::memset(stats, 0, sizeof(*stats));
-    if (ctx->n == 0) return HMK_OK;  // cluster() of an empty list returns an empty list
-    unsigned long long counts[HMK_EDGE_SHARDS];
-    double ms = 0;
-    auto t0 = std::chrono::steady_clock::now();
-    int st = neighbors_internal(ctx, max_shift, shift_penalty, threshold, 0, 1, 0, counts, &ms);
-    if (st) return st;
-    uint64_t total = 0;
-    for (int s = 0; s < HMK_EDGE_SHARDS; s++) total += counts[s];
+// Tail shared by hmk_greedy_cluster and hmk_greedy_from_edges_dev: packed edges on the device (HMK_EDGE_SHARDS
+// segments of `seg` entries with their counts) -> CSR on the device -> pinned D2H -> host greedy merge.
+static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint64_t seg, const unsigned long long *d_counts,
+                                     uint64_t total, bool symmetric, int max_clusters, int32_t *cluster_id,
+                                     int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats,
+                                     std::chrono::steady_clock::time_point t0) {
     // edge segments -> CSR on the device, then ONE pinned D2H of start[] and adj[]
     const uint32_t n = ctx->n;
-    const uint64_t n_adj = ctx->symmetric ? 2 * total : total;
-    const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
+    const uint64_t n_adj = symmetric ? 2 * total : total;
     uint32_t *d_deg = nullptr, *d_cursor = nullptr;
     uint64_t *d_start = nullptr, *d_tiles = nullptr;
     int *d_range = nullptr;
@@ -1113,18 +1102,22 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, (size_t)n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_start, ((size_t)n + 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_tiles, scan_scratch_bytes(n));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_range, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_range, 3 * sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(d_deg, 0, (size_t)n * 4, nullptr);
     if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)n * 4, nullptr);
-    if (e == hipSuccess) e = launch_csr_degree_scan(ctx->d_edges, seg, ctx->d_counts, n, ctx->symmetric, d_deg, d_start, d_tiles,
+    if (e == hipSuccess) e = launch_csr_degree_scan(d_edges, seg, d_counts, n, symmetric, d_deg, d_start, d_tiles,
                                                    d_range, nullptr);
     // 4-byte adjacency entries (m << 8 | score - lowest score) when the scores span at most 255
-    int range[2] = {0, 0};
+    int range[3] = {0, 0, 0};
     if (e == hipSuccess) e = hipMemcpy(range, d_range, sizeof(range), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && range[2] != 0) {
+        cleanup();
+        return fail(ctx, HMK_ERR_BAD_ARG, "edge list references a sequence outside [0, n) or a self pair");
+    }
     const bool packed = total == 0 || ((long long)range[1] - range[0] <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr);
     const size_t esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
     if (e == hipSuccess) e = hipMalloc(&d_adj, std::max<uint64_t>(n_adj, 1) * esz);
-    if (e == hipSuccess) e = launch_csr_scatter(ctx->d_edges, seg, ctx->d_counts, ctx->symmetric, d_start, d_cursor, d_adj, packed,
+    if (e == hipSuccess) e = launch_csr_scatter(d_edges, seg, d_counts, symmetric, d_start, d_cursor, d_adj, packed,
                                                 range[0], nullptr);
     lap("CSR build on the device");
     if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + n_adj * esz) {
@@ -1148,14 +1141,57 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     const double nb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::string err;
     const int32_t *szs = ctx->has_sizes ? ctx->sizes.data() : nullptr;
-    st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, ctx->symmetric, max_clusters, cluster_id,
+    int st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, symmetric, max_clusters, cluster_id,
                                          result_order, member_rank, stats, &err)
-                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, ctx->symmetric, max_clusters, cluster_id, result_order,
+                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, symmetric, max_clusters, cluster_id, result_order,
                                   member_rank, stats, &err);
     stats->n_edges = total;
     stats->neighbors_ms = nb_ms;
     if (st) return fail(ctx, st, err);
     return HMK_OK;
+}
+
+
+int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters,
+                       int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (ctx->n && !cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
+    hmk_greedy_stats local;
+    if (!stats) stats = &local;
+    std::memset(stats, 0, sizeof(*stats));
+    if (ctx->n == 0) return HMK_OK;  // cluster() of an empty list returns an empty list
+    unsigned long long counts[HMK_EDGE_SHARDS];
+    double ms = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    int st = neighbors_internal(ctx, max_shift, shift_penalty, threshold, 0, 1, 0, counts, &ms);
+    if (st) return st;
+    uint64_t total = 0;
+    for (int s = 0; s < HMK_EDGE_SHARDS; s++) total += counts[s];
+    return cluster_from_device_edges(ctx, ctx->d_edges, ctx->d_edges_cap / HMK_EDGE_SHARDS, ctx->d_counts, total, ctx->symmetric,
+                                     max_clusters, cluster_id, result_order, member_rank, stats, t0);
+}
+
+int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edges, int symmetric, int max_clusters,
+                              int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    int st = need_device(ctx);
+    if (st) return st;
+    if (ctx->n && !cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
+    if (n_edges && !d_edges) return fail(ctx, HMK_ERR_BAD_ARG, "null edge buffer");
+    hmk_greedy_stats local;
+    if (!stats) stats = &local;
+    std::memset(stats, 0, sizeof(*stats));
+    if (ctx->n == 0) return HMK_OK;
+    auto t0 = std::chrono::steady_clock::now();
+    // one contiguous block = segment 0 of HMK_EDGE_SHARDS, the other segments empty
+    if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
+    unsigned long long counts[HMK_EDGE_SHARDS] = {0};
+    counts[0] = n_edges;
+    HIPCHK(ctx, hipMemcpy(ctx->d_counts, counts, sizeof(counts), hipMemcpyHostToDevice));
+    return cluster_from_device_edges(ctx, (const uint64_t *)d_edges, std::max<uint64_t>(n_edges, 1), ctx->d_counts, n_edges,
+                                     symmetric != 0, max_clusters, cluster_id, result_order, member_rank, stats, t0);
 }
 
 }  // extern "C"

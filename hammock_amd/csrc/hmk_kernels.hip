@@ -1218,10 +1218,11 @@ __device__ __forceinline__ WaveGroup wave_groups(uint32_t key, bool valid) {
     return g;
 }
 
-// score_range[0] / [1]: smallest / largest edge score (decides whether the 4-byte adjacency fits)
+// score_range[0] / [1]: smallest / largest edge score (decides whether the 4-byte adjacency fits);
+// score_range[2]: edges that name a sequence outside [0, n) or a self pair (not counted; the caller gives up)
 __global__ void __launch_bounds__(256)
 k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
-              uint32_t *__restrict__ deg, int symmetric, int *__restrict__ score_range) {
+              uint32_t *__restrict__ deg, int symmetric, int *__restrict__ score_range, uint32_t n) {
     const uint32_t shard = blockIdx.y;
     const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
     const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
@@ -1229,8 +1230,12 @@ k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const 
     // wave-uniform loop: the x side of a wave's 64 consecutive edges has a handful of distinct values
     for (uint64_t k0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); k0 < cnt; k0 += (uint64_t)gridDim.x * 256) {
         const uint64_t k = k0 + (threadIdx.x & 63);
-        const bool valid = k < cnt;
+        bool valid = k < cnt;
         const uint64_t e = valid ? seg[k] : 0;
+        if (valid && (HMK_EDGE_X(e) >= n || HMK_EDGE_M(e) >= n || HMK_EDGE_X(e) == HMK_EDGE_M(e))) {
+            atomicAdd(&score_range[2], 1);
+            valid = false;
+        }
         const WaveGroup g = wave_groups(HMK_EDGE_X(e), valid);
         if (valid && g.rank == 0) atomicAdd(&deg[HMK_EDGE_X(e)], g.size);
         if (valid && symmetric) atomicAdd(&deg[HMK_EDGE_M(e)], 1u);
@@ -1564,11 +1569,11 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
 hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
                                   bool symmetric, uint32_t *deg, uint64_t *start, uint64_t *tile_scratch, int *score_range,
                                   hipStream_t s) {
-    const int init[2] = {INT_MAX, INT_MIN};
+    const int init[3] = {INT_MAX, INT_MIN, 0};
     hipError_t e = hipMemcpyAsync(score_range, init, sizeof(init), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_edge_degree, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg,
-                       symmetric ? 1 : 0, score_range);
+                       symmetric ? 1 : 0, score_range, n);
     launch_scan<uint64_t>(deg, start, n, tile_scratch, nullptr, s);
     return hipGetLastError();
 }

@@ -78,9 +78,14 @@ def merge_and_broadcast(ctx: Context, edges_all: torch.Tensor, symmetric: bool, 
     err = None
     if rank == 0:
         from .api import ReferenceWouldCrash
-        edges = edges_all.cpu().numpy().view(np.uint64)
         try:
-            c, o, st = ctx.greedy_from_edges(edges, symmetric, threshold, max_clusters)
+            if edges_all.is_cuda and ctx.device >= 0:
+                # the gathered graph is already on this GPU: adjacency built there, one pinned copy, host merge
+                torch.cuda.current_stream(edges_all.device).synchronize()
+                c, o, st = ctx.greedy_from_edges_dev(edges_all.data_ptr(), edges_all.numel(), symmetric, max_clusters)
+            else:
+                edges = edges_all.cpu().numpy().view(np.uint64)
+                c, o, st = ctx.greedy_from_edges(edges, symmetric, threshold, max_clusters)
             header[1] = len(o)
             cid[:n] = torch.from_numpy(c).to(dev)
             order[:len(o)] = torch.from_numpy(o).to(dev)

@@ -207,6 +207,14 @@ int hmk_greedy_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges,
                           int threshold, int max_clusters, int32_t *cluster_id,
                           int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats);
 
+/* The same with the edges in device memory (one contiguous block of packed edges, e.g. what the ranks'
+ * all-gather left on every GPU): adjacency built on the device, one pinned copy to the host, host merge --
+ * the tail of hmk_greedy_cluster without the scoring (LimitedGreedySequenceClusterer.java:39-120 on a
+ * precomputed neighbour graph).  Invalid edges (index >= n, self pairs) give HMK_ERR_BAD_ARG. */
+int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edges, int symmetric,
+                              int max_clusters, int32_t *cluster_id, int32_t *result_order,
+                              int32_t *member_rank, hmk_greedy_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -328,6 +328,27 @@ def test_greedy_antibodies_example_vs_oracle(gpu, blosum62, coracle, tmp_path):
     assert stats.phase1_stop_index == ostats.phase1_stop_index and stats.n_multi == maxc
 
 
+def test_greedy_from_device_edges(gpu, blosum62, coracle):
+    """hmk_greedy_from_edges_dev (the distributed path's merge on rank 0): edges resident on the GPU ->
+    same clusters as hmk_greedy_cluster and as the host-side hmk_greedy_from_edges; invalid edges are refused."""
+    import torch
+    res, off = synth_peptides(12, 9000, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    edges, _ = ctx.neighbors_shifted(3, 0, 19)
+    d = torch.from_numpy(edges.view(np.int64).copy()).to("cuda:0")
+    cid, order, _ = ctx.greedy_from_edges_dev(d.data_ptr(), d.numel(), True, 225)
+    cid1, order1, _ = ctx.greedy_cluster(3, 0, 19, 225)
+    cid2, order2, _ = ctx.greedy_from_edges(edges, True, 19, 225)
+    assert np.array_equal(cid, cid1) and np.array_equal(order, order1)
+    assert np.array_equal(cid, cid2) and np.array_equal(order, order2)
+    bad = edges.copy()
+    bad[5] = hammock_amd.pack_edges(np.array([3]), np.array([9000]), np.array([25]))[0]   # m == n: out of range
+    d = torch.from_numpy(bad.view(np.int64).copy()).to("cuda:0")
+    with pytest.raises(Exception) as ei:
+        ctx.greedy_from_edges_dev(d.data_ptr(), d.numel(), True, 225)
+    assert "outside" in str(ei.value)
+
+
 def test_greedy_crash_parity_on_gpu(gpu, blosum62):
     ctx, _, _ = ctx_for(blosum62, ["WWWWWWWW", "CCCCCCCC", "PPPPPPPP", "GGGGGGGG"])
     with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
