@@ -230,7 +230,7 @@ def main():
         }
         if px is not None:
             line["exchange"] = {"format": px.fmt, "gathered_bytes_per_rank_per_step": px.bytes_per_step,
-                                "collectives_per_step": 2}
+                                "collectives_per_step": 1}
         if world == 1:
             if not args.no_greedy:
                 t = time.perf_counter()

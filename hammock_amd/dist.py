@@ -119,7 +119,7 @@ class PipelinedExchange:
 
     No host round trip inside a step: the neighbour kernel runs on a compute stream; on a
     communication stream small device kernels turn its 16 output segments into one exchange block and
-    fixed-size all_gather_into_tensor calls ship it, double buffered so the exchange of pass k overlaps
+    ONE fixed-size all_gather_into_tensor ships it, double buffered so the exchange of pass k overlaps
     the scoring of pass k + 1.  Two block formats:
 
       "rows"   (default) 4 bytes per edge: hmk_pack_rows_dev groups the edges by x into
@@ -163,20 +163,16 @@ class PipelinedExchange:
         if self.collectives:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
         self.pad = int(mx.item()) + 64
-        if fmt == "rows":
-            # block = adj (uint32 per edge); head = row_start[n + 2]
-            self.block = [torch.zeros(self.pad, dtype=torch.int32, device=device) for _ in range(2)]
-            self.head = [torch.zeros(n + 2, dtype=torch.int32, device=device) for _ in range(2)]
-            self.gathered = [torch.empty(world * self.pad, dtype=torch.int32, device=device) for _ in range(2)]
-            self.heads_all = [torch.zeros(world * (n + 2), dtype=torch.int32, device=device) for _ in range(2)]
-        else:
-            # block = packed edges; head = the valid count
-            self.block = [torch.zeros(self.pad, dtype=torch.int64, device=device) for _ in range(2)]
-            self.head = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(2)]
-            self.gathered = [torch.empty(world * self.pad, dtype=torch.int64, device=device) for _ in range(2)]
-            self.heads_all = [torch.zeros(world, dtype=torch.int64, device=device) for _ in range(2)]
-        self.bytes_per_step = (self.gathered[0].numel() * self.gathered[0].element_size()
-                               + self.heads_all[0].numel() * self.heads_all[0].element_size())
+        # One message per rank and pass: [head | block].  rows: head = row_start[n + 2], block = one uint32 per
+        # edge.  edges: head = the valid count, block = the packed edges.  ONE all-gather ships it.
+        dt = torch.int32 if fmt == "rows" else torch.int64
+        self.head_len = n + 2 if fmt == "rows" else 1
+        self.msg_len = self.head_len + self.pad
+        self.msg = [torch.zeros(self.msg_len, dtype=dt, device=device) for _ in range(2)]
+        self.head = [m[:self.head_len] for m in self.msg]
+        self.block = [m[self.head_len:] for m in self.msg]
+        self.gathered = [torch.empty(world * self.msg_len, dtype=dt, device=device) for _ in range(2)]
+        self.bytes_per_step = self.gathered[0].numel() * self.gathered[0].element_size()
         self.scored = [torch.cuda.Event() for _ in range(2)]
         self.packed = [torch.cuda.Event() for _ in range(2)]
         self.k = 0
@@ -210,11 +206,9 @@ class PipelinedExchange:
                                            self.head[b].data_ptr(), self.comm.cuda_stream)
             self.packed[b].record(self.comm)
             if self.collectives:
-                dist.all_gather_into_tensor(self.gathered[b], self.block[b], group=self.group)
-                dist.all_gather_into_tensor(self.heads_all[b], self.head[b], group=self.group)
+                dist.all_gather_into_tensor(self.gathered[b], self.msg[b], group=self.group)
             else:
-                self.gathered[b][:self.pad].copy_(self.block[b])
-                self.heads_all[b].copy_(self.head[b])
+                self.gathered[b][:self.msg_len].copy_(self.msg[b])
         self.k += 1
 
     def finish(self):
@@ -225,13 +219,14 @@ class PipelinedExchange:
         """every rank's edges of the most recent pass as packed 8-byte edges, concatenated in rank order"""
         self.finish()
         b = (self.k - 1) & 1
+        msgs = self.gathered[b].view(self.world, self.msg_len)
         if self.fmt == "edges":
-            tot = self.heads_all[b].tolist()
+            tot = msgs[:, 0].tolist()
             if max(tot) > self.pad:
                 raise BufferError("exchange block overflow")
-            return torch.cat([self.gathered[b][r * self.pad:r * self.pad + int(tot[r])] for r in range(self.world)])
+            return torch.cat([msgs[r, 1:1 + int(tot[r])] for r in range(self.world)])
         n = self.ctx.n
-        heads = self.heads_all[b].view(self.world, n + 2)
+        heads = msgs[:, :self.head_len]
         tail = heads[:, n:].tolist()   # per rank: [edges, misfits]
         if max(t[0] for t in tail) > self.pad:
             raise BufferError("exchange block overflow")
@@ -242,7 +237,7 @@ class PipelinedExchange:
         stream = torch.cuda.current_stream(self.device)
         for r in range(self.world):
             if tail[r][0]:
-                self.ctx.unpack_rows_dev(heads[r].data_ptr(), self.gathered[b][r * self.pad:].data_ptr(), self.args[2],
+                self.ctx.unpack_rows_dev(msgs[r].data_ptr(), msgs[r, self.head_len:].data_ptr(), self.args[2],
                                          out[o:].data_ptr(), tail[r][0], stream.cuda_stream)
             o += tail[r][0]
         stream.synchronize()
