@@ -29,6 +29,11 @@ def synth_peptides(seed: int, n: int, len_lo: int, len_hi: int | None = None):
     """-> (residues uint8 [sum len], offsets uint32 [n+1])"""
     if len_hi is None:
         len_hi = len_lo
+    if len_lo < 1 or len_hi < len_lo:
+        raise ValueError("need 1 <= len_lo <= len_hi")
+    if n > sum(20 ** L for L in range(len_lo, min(len_hi, 8) + 1)) and len_hi <= 8:
+        raise ValueError(f"only {sum(20 ** L for L in range(len_lo, len_hi + 1))} distinct peptides of length "
+                         f"{len_lo}..{len_hi} exist, {n} requested")   # the draw-until-distinct loop would never end
     if len_lo == len_hi:
         L = len_lo
         rows = np.zeros((0, L), dtype=np.uint8)

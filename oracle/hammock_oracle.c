@@ -618,6 +618,11 @@ static uint64_t pep_hash(const uint8_t *p, int len) {
 int hmo_synth(uint64_t seed, uint32_t n, int len_lo, int len_hi, uint8_t *res,
               uint32_t *off) {
     if (len_lo < 1 || len_hi < len_lo || len_hi > 255) return HMO_ERR_BAD_ARG;
+    if (len_hi <= 8) {  /* more distinct peptides requested than exist: the loop below would never end */
+        uint64_t avail = 0, pw = 1;
+        for (int l = 1; l <= len_hi; l++) { pw *= 20; if (l >= len_lo) avail += pw; }
+        if ((uint64_t)n > avail) return HMO_ERR_BAD_ARG;
+    }
     uint64_t cap = 16;
     while (cap < (uint64_t)n * 2 + 2) cap <<= 1;
     int64_t *table = (int64_t *)malloc(cap * sizeof(int64_t));

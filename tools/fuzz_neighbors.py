@@ -3,7 +3,8 @@
 same generator; this runs as many as asked): matrices (shipped, random symmetric, asymmetric, extreme),
 length ranges up to 32, max shift, shift penalty of either sign, thresholds from the score distribution,
 heavy (tryptophan-rich) peptides that straddle the 8-bit row-bound limit.
-Usage: python tools/fuzz_neighbors.py [trials] [seed]"""
+Usage: python tools/fuzz_neighbors.py [trials] [seed] [first_trial]   (trials before first_trial only advance the
+random stream; HMK_FUZZ_VERBOSE=1 prints every trial's parameters before it runs)"""
 import json
 import os
 import sys
@@ -19,6 +20,8 @@ from oracle import c_oracle  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+verbose = os.environ.get("HMK_FUZZ_VERBOSE") == "1"
 with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
     matrices = {k: np.asarray(v, dtype=np.int32) for k, v in json.load(fh)["matrices"].items()}
 names = sorted(matrices)
@@ -58,6 +61,7 @@ for trial in range(trials):
     lo = int(rng.integers(1, 20))
     hi = int(min(32, lo + rng.integers(0, 20)))
     n = int(rng.integers(150, 700))
+    n = min(n, sum(20 ** L for L in range(lo, min(hi, 8) + 1)) // 2) if hi <= 8 else n   # enough distinct peptides exist
     res, off = synth_peptides(int(rng.integers(1, 10 ** 6)), n, lo, hi)
     peps = [res[off[k]:off[k + 1]].copy() for k in range(n)]
     if kind in (0, 4):   # heavy residues in some peptides: both sides of the row-bound limit
@@ -73,8 +77,14 @@ for trial in range(trials):
     p = int(rng.integers(-6, 3))
     i = rng.integers(0, n, 4000).astype(np.uint32)
     j = rng.integers(0, n, 4000).astype(np.uint32)
+    q = float(rng.choice([0.0, 0.5, 0.9, 0.99, 0.999]))
+    if trial < first:
+        continue
     st, sc = c_oracle.score_pairs(M, res, off, i, j, 0, X, p)
-    thr = int(np.quantile(sc, float(rng.choice([0.0, 0.5, 0.9, 0.99, 0.999]))))
+    thr = int(np.quantile(sc, q))
+    if verbose:
+        print(json.dumps({"trial": trial, "kind": kind, "lo": lo, "hi": hi, "n": n, "X": X, "p": p, "thr": thr,
+                          "Mmin": int(M.min()), "Mmax": int(M.max())}), flush=True)
     ctx = hammock_amd.Context(M, device=0)
     ctx.set_sequences(residues=res, offsets=off)
     edges, stats = ctx.neighbors_shifted(X, p, thr)
