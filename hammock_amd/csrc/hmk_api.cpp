@@ -280,7 +280,13 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     // column runs win (7 workgroups/CU, table build amortised); shrink the runs for small
     // inputs so the grid still has a few thousand workgroups.
     pl.hot_variant = 7;
-    pl.cols_per_tile = 16384;
+    // Column runs: long runs amortise the table build (65,536 columns: 3.55 ms for the whole 10^5 pass against
+    // 3.60 ms with 16,384), short ones keep the tail of a small launch short (a 1/8 shard: 0.478 ms with 16,384,
+    // 0.532 ms with 65,536).  Take the longest run that still leaves ~8 rounds of workgroups (256 CUs x 7).
+    const uint64_t row_groups = (uint64_t)n / 6 / n_parts + 1;
+    pl.cols_per_tile = 65536;
+    while (pl.cols_per_tile > 16384 && row_groups * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 8 * 1792)
+        pl.cols_per_tile /= 2;
     while (pl.cols_per_tile > 1024 && ((uint64_t)n / 6 + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
         pl.cols_per_tile /= 2;
     if (const char *v = getenv("HMK_HOT_VARIANT")) pl.hot_variant = atoi(v);   // tuning knobs
