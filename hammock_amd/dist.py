@@ -175,6 +175,8 @@ class PipelinedExchange:
         self.bytes_per_step = self.gathered[0].numel() * self.gathered[0].element_size()
         self.scored = [torch.cuda.Event() for _ in range(2)]
         self.packed = [torch.cuda.Event() for _ in range(2)]
+        self.work = [None, None]   # the all-gather in flight for each message buffer (async: the pack of the next
+                                   # pass does not queue behind it on the communication stream)
         self.k = 0
 
     def _alloc_score(self):
@@ -197,7 +199,10 @@ class PipelinedExchange:
         self.scored[b].record(self.comp)
         self.comm.wait_event(self.scored[b])
         with torch.cuda.stream(self.comm):
-            # block[b] / head[b] / gathered[b] are only touched on the communication stream (serial)
+            # msg[b] / gathered[b] are free again once the all-gather issued two passes ago has completed
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None
             if self.fmt == "rows":
                 self.ctx.pack_rows_dev(e.data_ptr(), self.capacity, c.data_ptr(), self.args[2], self.head[b].data_ptr(),
                                        self.block[b].data_ptr(), self.pad, self.comm.cuda_stream)
@@ -206,12 +211,17 @@ class PipelinedExchange:
                                            self.head[b].data_ptr(), self.comm.cuda_stream)
             self.packed[b].record(self.comm)
             if self.collectives:
-                dist.all_gather_into_tensor(self.gathered[b], self.msg[b], group=self.group)
+                self.work[b] = dist.all_gather_into_tensor(self.gathered[b], self.msg[b], group=self.group, async_op=True)
             else:
                 self.gathered[b][:self.msg_len].copy_(self.msg[b])
         self.k += 1
 
     def finish(self):
+        with torch.cuda.stream(self.comm):
+            for b in range(2):
+                if self.work[b] is not None:
+                    self.work[b].wait()
+                    self.work[b] = None
         self.comp.synchronize()
         self.comm.synchronize()
 
