@@ -1,6 +1,6 @@
 // hmk_api.cpp -- the C ABI of libhammock_hip.so (include/hammock_hip.h):
 // context, sequence upload, neighbour-kernel planning, launches, host buffers.
-// Host code only; the kernels live in hmk_kernels.hip.
+// Host code only; the kernels live in k_*.hip (launchers declared in hmk_kernels.h).
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
