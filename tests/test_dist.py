@@ -274,3 +274,21 @@ def test_pipelined_exchange_over_rccl_single_rank():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert oks == [True, True], oks
+
+
+@pytest.mark.gpu
+def test_distributed_entry_single_process_device_merge():
+    """greedy_cluster_distributed without a process group (one rank): the gathered graph stays on the GPU and
+    rank 0 merges straight from it (hmk_greedy_from_edges_dev) -- same result as hmk_greedy_cluster."""
+    import json
+    import hammock_amd
+    from hammock_amd import dist as hd
+    from hammock_amd.synth import synth_peptides
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+    res, off = synth_peptides(8, 15000, 12)
+    ctx = hammock_amd.Context(M, device=0)
+    ctx.set_sequences(residues=res, offsets=off)
+    cid, order, info = hd.greedy_cluster_distributed(ctx, 3, 0, 20, 375, torch.device("cuda", 0))
+    cid1, order1, _ = ctx.greedy_cluster(3, 0, 20, 375)
+    assert np.array_equal(cid, cid1) and np.array_equal(order, order1)
