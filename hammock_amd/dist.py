@@ -28,8 +28,10 @@ def compact_shards(d_edges: torch.Tensor, d_counts: torch.Tensor) -> torch.Tenso
     return torch.cat([d_edges[s * seg:s * seg + int(c)] for s, c in enumerate(counts)])
 
 
-def neighbors_local(ctx: Context, max_shift, shift_penalty, threshold, rank, world, device, capacity=None):
-    """This rank's shard of the neighbour graph as a device tensor of packed edges (int64 view of uint64)."""
+def neighbors_local(ctx: Context, max_shift, shift_penalty, threshold, rank, world, device, capacity=None,
+                    segments=False):
+    """This rank's shard of the neighbour graph as a device tensor of packed edges (int64 view of uint64);
+    segments=True returns the raw (d_edges, d_counts, capacity) of the kernel instead."""
     n = ctx.n
     if capacity is None:
         capacity = int(n * (n - 1) // 2 * 6e-3 / world) + (1 << 20)
@@ -42,7 +44,7 @@ def neighbors_local(ctx: Context, max_shift, shift_penalty, threshold, rank, wor
                                   d_counts.data_ptr(), stream.cuda_stream)
         mx = int(d_counts.max().item())
         if mx <= capacity // N.HMK_EDGE_SHARDS:
-            return compact_shards(d_edges, d_counts)
+            return (d_edges, d_counts, capacity) if segments else compact_shards(d_edges, d_counts)
         capacity = (mx + mx // 8 + 1024) * N.HMK_EDGE_SHARDS  # a segment overflowed: rescore with room
 
 
@@ -63,6 +65,41 @@ def all_gather_edges(local: torch.Tensor, group=None) -> torch.Tensor:
     gathered = torch.empty(world * mx, dtype=torch.int64, device=local.device)
     dist.all_gather_into_tensor(gathered, padded, group=group)
     return torch.cat([gathered[r * mx:r * mx + sizes_h[r]] for r in range(world)])
+
+
+def all_gather_rows(ctx: Context, d_edges, d_counts, capacity, threshold, group=None):
+    """The exchange in the 4-byte row-block format (hmk_pack_rows_dev): every rank's edge segments are regrouped
+    by x on the device, ONE padded all-gather ships [row_start | adj] of all ranks, and the received blocks are
+    unpacked to packed 8-byte edges.  Returns None if some score - threshold does not fit 8 bits (the caller
+    falls back to all_gather_edges)."""
+    world = dist.get_world_size(group)
+    dev = d_edges.device
+    n = ctx.n
+    total = int(d_counts.sum().item())
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([total], dtype=torch.int64, device=dev), group=group)
+    sizes_h = sizes.tolist()
+    pad = max(max(sizes_h), 1)
+    head_len = n + 2
+    msg = torch.zeros(head_len + pad, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    ctx.pack_rows_dev(d_edges.data_ptr(), capacity, d_counts.data_ptr(), threshold, msg.data_ptr(),
+                      msg[head_len:].data_ptr(), pad, stream.cuda_stream)
+    gathered = torch.empty(world * (head_len + pad), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gathered, msg, group=group)
+    msgs = gathered.view(world, head_len + pad)
+    tail = msgs[:, n:head_len].tolist()           # per rank: [edges, misfits]
+    if any(t[1] for t in tail):
+        return None
+    out = torch.empty(sum(t[0] for t in tail), dtype=torch.int64, device=dev)
+    o = 0
+    for r in range(world):
+        if tail[r][0]:
+            ctx.unpack_rows_dev(msgs[r].data_ptr(), msgs[r, head_len:].data_ptr(), threshold, out[o:].data_ptr(), tail[r][0],
+                                stream.cuda_stream)
+        o += tail[r][0]
+    stream.synchronize()
+    return out
 
 
 def merge_and_broadcast(ctx: Context, edges_all: torch.Tensor, symmetric: bool, threshold, max_clusters, group=None):
@@ -108,8 +145,16 @@ def greedy_cluster_distributed(ctx: Context, max_shift, shift_penalty, threshold
     identical to the single-GPU hmk_greedy_cluster."""
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    local = neighbors_local(ctx, max_shift, shift_penalty, threshold, rank, world, device)
-    edges_all = all_gather_edges(local, group) if world > 1 else local
+    use_rows = world > 1 and device.type == "cuda" and dist.get_backend(group) == "nccl"
+    if use_rows:   # 4 bytes per edge over xGMI; the 8-byte form if a score does not fit
+        d_edges, d_counts, capacity = neighbors_local(ctx, max_shift, shift_penalty, threshold, rank, world, device,
+                                                      segments=True)
+        edges_all = all_gather_rows(ctx, d_edges, d_counts, capacity, threshold, group)
+        if edges_all is None:
+            edges_all = all_gather_edges(compact_shards(d_edges, d_counts), group)
+    else:
+        local = neighbors_local(ctx, max_shift, shift_penalty, threshold, rank, world, device)
+        edges_all = all_gather_edges(local, group) if world > 1 else local
     symmetric = bool((ctx.matrix == ctx.matrix.T).all())
     return merge_and_broadcast(ctx, edges_all, symmetric, threshold, max_clusters, group)
 

@@ -252,6 +252,11 @@ def _nccl_single_rank_worker(port, q):
     ctx.set_sequences(residues=res, offsets=off)
     want, _ = ctx.neighbors_shifted(3, 0, 20)
     oks = []
+    # the row-block all-gather of the distributed entry point, on the one-rank RCCL group
+    d_edges, d_counts, cap = hd.neighbors_local(ctx, 3, 0, 20, 0, 1, dev, segments=True)
+    got = hd.all_gather_rows(ctx, d_edges, d_counts, cap, 20).cpu().numpy().view(np.uint64)
+    oks.append(bool(np.array_equal(np.sort(got), np.sort(want))))
+    oks.append(hd.all_gather_rows(ctx, d_edges, d_counts, cap, -400) is None)   # scores - threshold > 255: refused
     for fmt in ("rows", "edges"):
         px = hd.PipelinedExchange(ctx, 3, 0, 20, 0, 1, dev, fmt=fmt, use_collectives=True)
         for _ in range(4):
@@ -273,7 +278,7 @@ def test_pipelined_exchange_over_rccl_single_rank():
     oks = q.get(timeout=400)
     p.join(timeout=60)
     assert p.exitcode == 0
-    assert oks == [True, True], oks
+    assert oks == [True, True, True, True], oks
 
 
 @pytest.mark.gpu
