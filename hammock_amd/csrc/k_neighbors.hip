@@ -260,7 +260,12 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
     constexpr int TAB_BYTES = R * ROWBYTES;
     constexpr int STAGE_CAP = 128, REC_DW = 3;
     constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;
-    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * REC_DW * 4;
+    // table build scratch: per (row, residue) the row's cells as one byte string (see below); it shares the
+    // stage area, which is idle while the tables are built
+    constexpr int WIN_DW = (LBMAX - 1 + 4 * NW + 3) / 4 + 1;       // dwords per string, one spare for the funnel shift
+    constexpr int STAGE_BYTES = 4 * STAGE_CAP * REC_DW * 4, WIN_BYTES = R * 24 * WIN_DW * 4;
+    constexpr int AUX_BYTES = STAGE_BYTES > WIN_BYTES ? STAGE_BYTES : WIN_BYTES;
+    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + AUX_BYTES;
     static_assert(TAB_BYTES <= 65536 && LDS_BYTES <= 65536, "LDS budget / DS immediate range");
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
     uint8_t *tab = smem;
@@ -291,29 +296,63 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
     // ---- expand the R row peptides into lookup tables (same cells as k_neighbors_swar) ----
     //   column is the longer/equal one (L): cell = M[row[i]][c], i = j - s   (ShiftedScorer.java:71,75)
     //   column is the shorter one (S):      cell = M[c][row[i]], i = j + s
+    // Entry (r, j, c) holds, lane by lane (t = s + X), the cells of ONE byte string per (r, c):
+    //   S:  win[k] = cell(i = k - X),            entry j = win[j .. j + nd)
+    //   L:  win[k] = cell(i = lb - 1 + X - k),   entry j = win[lb - 1 - j .. lb - 1 - j + nd)
+    // (cell = 0 outside the row).  Pass 1 gathers the strings into LDS, four cells per work item; pass 2 cuts
+    // every entry out of its string with funnel shifts (v_alignbyte) -- a handful of instructions per dword
+    // instead of one bounds-checked double gather per lane.
     {
+        uint32_t *win = stage_all;   // R * 24 strings of WIN_DW dwords (aliases the stage: idle during the build)
+        const int l0 = lb - 1 + X;
+        for (int e = tid; e < R * 24 * WIN_DW; e += 256) {
+            const int rc = e / WIN_DW, kd = e - rc * WIN_DW;
+            const int r = rc / 24, c = rc - r * 24;
+            uint32_t acc = 0;
+            if ((uint32_t)r < T.nrows) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k = kd * 4 + q;
+                    const int i = case_b ? k - X : l0 - k;
+                    if (i >= 0 && i < la) {
+                        const int a = rowres[r * 32 + i];
+                        acc |= (uint32_t)(case_b ? mb[c * 24 + a] : mb[a * 24 + c]) << (q * 8);
+                    }
+                }
+            }
+            win[e] = acc;
+        }
+        __syncthreads();
         const int per_row = lb * 24;
-        const int lanes_per_dw = lane16 ? 2 : 4;
-        const int lane_bits = lane16 ? 16 : 8;
+        // lanes at and beyond nd stay zero
+        uint32_t lane_mask[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const int left = nd - w * (lane16 ? 2 : 4);   // live lanes in dword w
+            if (lane16) lane_mask[w] = left >= 2 ? 0xFFFFFFFFu : left == 1 ? 0x0000FFFFu : 0u;
+            else lane_mask[w] = left >= 4 ? 0xFFFFFFFFu : left <= 0 ? 0u : (1u << (left * 8)) - 1u;
+        }
         for (int e = tid; e < R * per_row; e += 256) {
             const int r = e / per_row;
             const int rem = e - r * per_row;
             const int j = rem / 24;
             const int c = rem - j * 24;
+            const uint32_t *str = win + (r * 24 + c) * WIN_DW;
+            const int s0 = case_b ? j : lb - 1 - j;       // first byte of the entry in its string
             uint32_t dw[NW];
+            if (!lane16) {
+                uint32_t d[NW + 1];
 #pragma unroll
-            for (int w = 0; w < NW; w++) {
-                uint32_t acc = 0;
-                for (int k = 0; k < lanes_per_dw; k++) {
-                    const int t = w * lanes_per_dw + k;
-                    const int i = case_b ? (j + t - X) : (j - t + X);
-                    if (t < nd && i >= 0 && i < la && (uint32_t)r < T.nrows) {
-                        const int a = rowres[r * 32 + i];
-                        const uint32_t v = case_b ? mb[c * 24 + a] : mb[a * 24 + c];
-                        acc |= v << (k * lane_bits);
-                    }
+                for (int w = 0; w <= NW; w++) d[w] = str[(s0 >> 2) + w];
+#pragma unroll
+                for (int w = 0; w < NW; w++) dw[w] = __builtin_amdgcn_alignbyte(d[w + 1], d[w], (uint32_t)(s0 & 3)) & lane_mask[w];
+            } else {
+#pragma unroll
+                for (int w = 0; w < NW; w++) {      // two byte cells widened to two 16-bit lanes
+                    const int o = s0 + 2 * w;
+                    const uint32_t t2 = __builtin_amdgcn_alignbyte(str[(o >> 2) + 1], str[o >> 2], (uint32_t)(o & 3));
+                    dw[w] = ((t2 & 0xFFu) | ((t2 << 8) & 0x00FF0000u)) & lane_mask[w];
                 }
-                dw[w] = acc;
             }
             uint8_t *row = tab + r * ROWBYTES;
 #pragma unroll
