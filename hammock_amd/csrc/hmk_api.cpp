@@ -40,6 +40,7 @@ struct Plan {
     uint32_t cols_per_tile = 16384;
     uint8_t *d_res_sorted = nullptr;
     uint32_t *d_perm = nullptr;
+    bool perm_identity = false;
     uint8_t *d_mb = nullptr;
     TileClass *d_classes = nullptr;
     Tile *d_tiles = nullptr;
@@ -52,6 +53,7 @@ struct PlanLocal {
     uint32_t part = 0, n_parts = 1;
     uint8_t *d_res_sorted = nullptr;
     uint32_t *d_perm = nullptr;
+    bool perm_identity = false;
     TileClass *d_classes = nullptr;
     Tile *d_tiles = nullptr;
     uint32_t n_tiles = 0;
@@ -420,6 +422,8 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     HIPCHK(ctx, hipMemcpy(pl.d_res_sorted, res_sorted.data(), res_sorted.size(), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMalloc((void **)&pl.d_perm, (size_t)n * 4));
     HIPCHK(ctx, hipMemcpy(pl.d_perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    pl.perm_identity = true;
+    for (uint32_t q = 0; q < n && pl.perm_identity; q++) pl.perm_identity = perm[q] == q;
     HIPCHK(ctx, hipMalloc((void **)&pl.d_mb, 576));
     HIPCHK(ctx, hipMemcpy(pl.d_mb, mb, 576, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMalloc((void **)&pl.d_classes, std::max<size_t>(1, classes.size()) * sizeof(TileClass)));
@@ -447,6 +451,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     NeighborParams P{};
     P.res_sorted = pl.d_res_sorted;
     P.perm = pl.d_perm;
+    P.perm_identity = pl.perm_identity ? 1u : 0u;
     P.mb = pl.d_mb;
     P.classes = pl.d_classes;
     P.tiles = pl.d_tiles;
@@ -617,6 +622,8 @@ int build_plan_local(hmk_ctx *ctx, uint32_t part, uint32_t n_parts) {
     HIPCHK(ctx, hipMemcpy(pl.d_res_sorted, res_sorted.data(), res_sorted.size(), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMalloc((void **)&pl.d_perm, (size_t)n * 4));
     HIPCHK(ctx, hipMemcpy(pl.d_perm, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    pl.perm_identity = true;
+    for (uint32_t q = 0; q < n && pl.perm_identity; q++) pl.perm_identity = perm[q] == q;
     HIPCHK(ctx, hipMalloc((void **)&pl.d_classes, std::max<size_t>(1, classes.size()) * sizeof(TileClass)));
     if (!classes.empty())
         HIPCHK(ctx, hipMemcpy(pl.d_classes, classes.data(), classes.size() * sizeof(TileClass), hipMemcpyHostToDevice));
@@ -643,6 +650,7 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
     NeighborParams P{};
     P.res_sorted = pl.d_res_sorted;
     P.perm = pl.d_perm;
+    P.perm_identity = pl.perm_identity ? 1u : 0u;
     P.classes = pl.d_classes;
     P.tiles = pl.d_tiles;
     P.edges = d_edges;

@@ -155,7 +155,8 @@ __device__ __forceinline__ void flush_stage(const uint32_t *stage, uint32_t cnt,
             }
             score = (int)mx - g;
         }
-        uint32_t x = P.perm[T.row0 + r], m = P.perm[col];
+        uint32_t x = T.row0 + r, m = col;
+        if (!P.perm_identity) { x = P.perm[x]; m = P.perm[m]; }   // wave-uniform branch
         if (P.row_is_m || (P.symmetric && x > m)) { const uint32_t t = x; x = m; m = t; }
         const unsigned long long pos = base + k;
         if (pos < P.cap_per_shard)

@@ -52,6 +52,7 @@ struct NeighborParams {
     uint32_t lpad;               // 16 or 32
     uint32_t symmetric;          // 1: emit (min, max) caller indices
     uint32_t row_is_m;           // 1: the tile's ROW is seq1 (= m of the edge), LocalAlignmentScorer tiles
+    uint32_t perm_identity;      // 1: sorted position == caller index (one length bucket, no reordering): skip the perm loads
 };
 
 // one directed neighbour: sequenceScore(seq1 = m, seq2 = x) = s for the row x it is stored under
