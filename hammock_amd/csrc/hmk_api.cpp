@@ -1178,7 +1178,10 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     unsigned long long counts[HMK_EDGE_SHARDS];
     double ms = 0;
     auto t0 = std::chrono::steady_clock::now();
-    int st = neighbors_internal(ctx, max_shift, shift_penalty, threshold, 0, 1, 0, counts, &ms);
+    // first guess of the edge buffer: 0.3 % of the pair space (uniform random 12-mers at the default threshold give
+    // 0.26 %); a segment that overflows makes neighbors_grow() size the buffer exactly and score again
+    const uint64_t guess = (uint64_t)((double)ctx->n * (ctx->n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006)) + (1u << 20);
+    int st = neighbors_internal(ctx, max_shift, shift_penalty, threshold, 0, 1, std::min<uint64_t>(guess, 1ull << 31), counts, &ms);
     if (st) return st;
     uint64_t total = 0;
     for (int s = 0; s < HMK_EDGE_SHARDS; s++) total += counts[s];
