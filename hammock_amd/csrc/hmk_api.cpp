@@ -1092,12 +1092,13 @@ static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint
     // edge segments -> CSR on the device, then ONE pinned D2H of start[] and adj[]
     const uint32_t n = ctx->n;
     const uint64_t n_adj = symmetric ? 2 * total : total;
-    uint32_t *d_deg = nullptr, *d_cursor = nullptr;
+    uint32_t *d_deg = nullptr, *d_cursor = nullptr, *d_up = nullptr;
     uint64_t *d_start = nullptr, *d_tiles = nullptr;
     int *d_range = nullptr;
     void *d_adj = nullptr;
     auto cleanup = [&]() {
         if (d_tiles) (void)hipFree(d_tiles);
+        if (d_up) (void)hipFree(d_up);
         if (d_deg) (void)hipFree(d_deg);
         if (d_cursor) (void)hipFree(d_cursor);
         if (d_start) (void)hipFree(d_start);
@@ -1113,13 +1114,15 @@ static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint
     };
     lap("neighbour pass (plan + kernels + counts)");
     hipError_t e = hipMalloc((void **)&d_deg, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, (size_t)n * 8);   // two cursors per row (upper / lower section)
+    if (e == hipSuccess) e = hipMalloc((void **)&d_up, (size_t)n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_start, ((size_t)n + 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_tiles, scan_scratch_bytes(n));
     if (e == hipSuccess) e = hipMalloc((void **)&d_range, 3 * sizeof(int));
     if (e == hipSuccess) e = hipMemsetAsync(d_deg, 0, (size_t)n * 4, nullptr);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)n * 4, nullptr);
-    if (e == hipSuccess) e = launch_csr_degree_scan(d_edges, seg, d_counts, n, symmetric, d_deg, d_start, d_tiles,
+    if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)n * 8, nullptr);
+    if (e == hipSuccess) e = hipMemsetAsync(d_up, 0, (size_t)n * 4, nullptr);
+    if (e == hipSuccess) e = launch_csr_degree_scan(d_edges, seg, d_counts, n, symmetric, d_deg, d_up, d_start, d_tiles,
                                                    d_range, nullptr);
     // 4-byte adjacency entries (m << 8 | score - lowest score) when the scores span at most 255
     int range[3] = {0, 0, 0};
@@ -1131,20 +1134,23 @@ static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint
     const bool packed = total == 0 || ((long long)range[1] - range[0] <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr);
     const size_t esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
     if (e == hipSuccess) e = hipMalloc(&d_adj, std::max<uint64_t>(n_adj, 1) * esz);
-    if (e == hipSuccess) e = launch_csr_scatter(d_edges, seg, d_counts, symmetric, d_start, d_cursor, d_adj, packed,
-                                                range[0], nullptr);
+    if (e == hipSuccess) e = launch_csr_scatter(d_edges, seg, d_counts, symmetric, d_start, d_up, d_cursor, d_adj, packed,
+                                                range[0], n, nullptr);
     lap("CSR build on the device");
-    if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + n_adj * esz) {
+    const size_t up_bytes = ((size_t)n * 4 + 7) & ~(size_t)7;   // upper-neighbour counts, kept 8-byte aligned
+    if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + up_bytes + n_adj * esz) {
         if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
         ctx->h_csr = nullptr;
         ctx->h_csr_cap = 0;
-        const size_t want = ((size_t)n + 1) * 8 + n_adj * esz + (1 << 20);
+        const size_t want = ((size_t)n + 1) * 8 + up_bytes + n_adj * esz + (1 << 20);
         e = hipHostMalloc(&ctx->h_csr, want, hipHostMallocDefault);
         if (e == hipSuccess) ctx->h_csr_cap = want;
     }
     uint64_t *h_start = (uint64_t *)ctx->h_csr;
-    void *h_adj = (char *)ctx->h_csr + ((size_t)n + 1) * 8;
+    uint32_t *h_up = (uint32_t *)((char *)ctx->h_csr + ((size_t)n + 1) * 8);
+    void *h_adj = (char *)h_up + up_bytes;
     if (e == hipSuccess) e = hipMemcpy(h_start, d_start, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && symmetric) e = hipMemcpy(h_up, d_up, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && n_adj) e = hipMemcpy(h_adj, d_adj, n_adj * esz, hipMemcpyDeviceToHost);
     lap("D2H of the adjacency");
     cleanup();
@@ -1155,10 +1161,11 @@ static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint
     const double nb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::string err;
     const int32_t *szs = ctx->has_sizes ? ctx->sizes.data() : nullptr;
-    int st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, symmetric, max_clusters, cluster_id,
-                                         result_order, member_rank, stats, &err)
-                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, symmetric, max_clusters, cluster_id, result_order,
-                                  member_rank, stats, &err);
+    const uint32_t *upper = symmetric ? h_up : nullptr;   // rows are laid out upper neighbours first
+    int st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, upper, symmetric, max_clusters,
+                                         cluster_id, result_order, member_rank, stats, &err)
+                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, upper, symmetric, max_clusters, cluster_id,
+                                  result_order, member_rank, stats, &err);
     stats->n_edges = total;
     stats->neighbors_ms = nb_ms;
     if (st) return fail(ctx, st, err);

@@ -87,8 +87,8 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
             if (symmetric) adj[fill[m]++] = Nbr{x, s};
         }
     }
-    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), symmetric, max_clusters, cluster_id, result_order,
-                                   member_rank, st, err);
+    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), nullptr, symmetric, max_clusters, cluster_id,
+                                   result_order, member_rank, st, err);
     if (st) {
         st->n_edges = n_edges;
         st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -99,8 +99,8 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
 // The merge proper, on a CSR adjacency: start[n + 1], adj[start[x] .. start[x + 1]) = neighbours of x.
 // NbrT: Nbr (8 bytes) or NbrPacked (4 bytes); only id() and score() are used, scores only in comparisons.
 template <class NbrT>
-static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj, bool symmetric_scores,
-                                int max_clusters,
+static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj,
+                                const uint32_t *upper, bool symmetric_scores, int max_clusters,
                                 int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                                 std::string *err) {
     auto t0 = std::chrono::steady_clock::now();
@@ -224,7 +224,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         //     sequence, filled by the threads in order).
         // (2) Sequential, order-dependent part (:60-62) only for the survivors; with symmetric scores a
         //     survivor does not rescan its neighbours (see "Subscribers" below).
-        struct Cand { int32_t c, mn; };
+        struct Cand { int32_t c, mn, covered; };   // cluster, min score so far, members joined in this loop that are neighbours
         const size_t nl = leftover.size();
         std::vector<uint32_t> cand_start(nl + 1, 0);     // CSR of candidate clusters per leftover
         std::vector<Cand> cand;
@@ -249,7 +249,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     }
                     uint32_t k = 0;
                     for (int32_t c : seen) {
-                        if (c2[c] == clusters[c].usize) { found[t].push_back(Cand{c, m2[c]}); k++; }
+                        if (c2[c] == clusters[c].usize) { found[t].push_back(Cand{c, m2[c], 0}); k++; }
                         c2[c] = 0;
                     }
                     cand_start[q + 1] = k;
@@ -272,10 +272,11 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         // covered member (and folds the score into its min); at its own turn a candidate is still feasible
         // iff covered == members joined since the pre-check.
         const bool use_subs = fast && symmetric_scores;
-        struct Sub { int32_t q; int32_t k; };            // leftover index, index of the candidate in `cand`
+        struct Sub { uint32_t w; int32_t k; };           // the subscriber (sequence id), index of its candidate in `cand`;
+                                                         // per cluster in leftover order = increasing id
         std::vector<uint32_t> sub_start;                 // CSR of subscribers per cluster
         std::vector<Sub> subs;
-        std::vector<int32_t> covered;                    // per (leftover, candidate slot): joined members that are neighbours
+        std::vector<uint32_t> sub_pos;                   // per cluster: first subscriber that may still be undecided
         std::vector<int32_t> joined;                     // members that joined each cluster in this loop
         std::vector<uint64_t> stamped;                   // sequence -> (stamp of the join that last touched it) << 32 | score,
                                                          // one word so that stamping and testing touch one cache line
@@ -287,10 +288,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             subs.resize(sub_start[nc]);
             std::vector<uint32_t> fill(sub_start.begin(), sub_start.end() - 1);
             for (size_t q = 0; q < nl; q++)
-                for (uint32_t k = cand_start[q]; k < cand_start[q + 1]; k++) subs[fill[cand[k].c]++] = Sub{(int32_t)q, (int32_t)k};
-            covered.assign(cand.size(), 0);
+                for (uint32_t k = cand_start[q]; k < cand_start[q + 1]; k++) subs[fill[cand[k].c]++] = Sub{leftover[q], (int32_t)k};
             joined.assign(nc, 0);
             stamped.assign(n, 0);
+            sub_pos.assign(sub_start.begin(), sub_start.end() - 1);
         }
         uint32_t stamp = 0;
         std::vector<uint32_t> rest;
@@ -307,7 +308,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             } else {
                 for (uint32_t k = cand_start[q]; k < cand_start[q + 1]; k++) {
                     const Cand cd = cand[k];
-                    if (covered[k] != joined[cd.c]) continue;            // some new member is not a neighbour of y
+                    if (cd.covered != joined[cd.c]) continue;            // some new member is not a neighbour of y
                     if (F.kind == NEAR_NULL ||
                         better(cd.mn, clusters[cd.c].size, clusters[cd.c].id, F.score, clusters[F.slot].size, clusters[F.slot].id))
                         F = Found{NEAR_REAL, cd.c, cd.mn};
@@ -320,16 +321,20 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     joined[F.slot]++;
                     stamp++;
                     const uint64_t hi = (uint64_t)stamp << 32;
-                    for (uint64_t e = start[y]; e < start[y + 1]; e++)
+                    // only still undecided leftovers matter, and they all have ids above y (the leftover list is in
+                    // increasing id order): with an "upper neighbours first" row that is its leading section
+                    const uint64_t e_end = upper ? start[y] + upper[y] : start[y + 1];
+                    for (uint64_t e = start[y]; e < e_end; e++)
                         stamped[adj[e].id()] = hi | (uint32_t)adj[e].score();
-                    for (uint32_t u = sub_start[F.slot]; u < sub_start[F.slot + 1]; u++) {
+                    uint32_t &first = sub_pos[F.slot];       // subscribers with an id up to y are decided: skip them for good
+                    const uint32_t last = sub_start[F.slot + 1];
+                    while (first < last && subs[first].w <= y) first++;
+                    for (uint32_t u = first; u < last; u++) {
                         const Sub sb = subs[u];
-                        if ((size_t)sb.q <= q) continue;    // already decided
-                        const uint32_t w = leftover[sb.q];
-                        const uint64_t sw = stamped[w];
+                        const uint64_t sw = stamped[sb.w];
                         if ((uint32_t)(sw >> 32) != stamp) continue; // w is not a neighbour of the new member
-                        covered[sb.k]++;
-                        Cand &cw = cand[sb.k];
+                        Cand &cw = cand[sb.k];               // one cache line: counter and min score together
+                        cw.covered++;
                         const int32_t sc = (int32_t)(uint32_t)sw;
                         if (sc < cw.mn) cw.mn = sc;
                     }
@@ -375,17 +380,18 @@ crash:
     return HMK_ERR_REFERENCE_WOULD_CRASH;
 }
 
-int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, bool symmetric_scores, int max_clusters,
-                    int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
-    return greedy_from_csr_impl<Nbr>(n, sizes, start, adj, symmetric_scores, max_clusters, cluster_id, result_order, member_rank,
-                                     st, err);
+int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, const uint32_t *upper,
+                    bool symmetric_scores, int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
+                    hmk_greedy_stats *st, std::string *err) {
+    return greedy_from_csr_impl<Nbr>(n, sizes, start, adj, upper, symmetric_scores, max_clusters, cluster_id, result_order,
+                                     member_rank, st, err);
 }
 
-int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj, bool symmetric_scores,
-                           int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
-                           hmk_greedy_stats *st, std::string *err) {
-    return greedy_from_csr_impl<NbrPacked>(n, sizes, start, adj, symmetric_scores, max_clusters, cluster_id, result_order,
-                                           member_rank, st, err);
+int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj,
+                           const uint32_t *upper, bool symmetric_scores, int max_clusters, int32_t *cluster_id,
+                           int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
+    return greedy_from_csr_impl<NbrPacked>(n, sizes, start, adj, upper, symmetric_scores, max_clusters, cluster_id,
+                                           result_order, member_rank, st, err);
 }
 
 }  // namespace hmk

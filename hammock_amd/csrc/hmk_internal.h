@@ -73,11 +73,14 @@ struct NbrPacked {
 
 // host greedy merge (hmk_greedy.cpp)
 // symmetric_scores: adj holds every edge under both ends with the same score (symmetric matrix)
-int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, bool symmetric_scores, int max_clusters,
+// upper: NULL, or per row the number of leading entries whose id is above the row's own (the row is laid out
+//        "upper neighbours first"); lets the join propagation skip the neighbours that are already decided
+int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, const uint32_t *upper,
+                    bool symmetric_scores, int max_clusters,
                     int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                     std::string *err);
-int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj, bool symmetric_scores,
-                           int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
+int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj,
+                           const uint32_t *upper, bool symmetric_scores, int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
                            hmk_greedy_stats *st, std::string *err);
 int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
                       bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,

@@ -31,14 +31,14 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
 
 // edge segments -> CSR (start[n + 1], adj[]) on the device: deg and cursor are zeroed uint32[n] scratch
 hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
-                                  bool symmetric, uint32_t *deg, uint64_t *start, uint64_t *tile_scratch, int *score_range,
-                                  hipStream_t s);  // score_range: device int[3] = {min score, max score, invalid edges}
+                                  bool symmetric, uint32_t *deg, uint32_t *up, uint64_t *start, uint64_t *tile_scratch,
+                                  int *score_range, hipStream_t s);  // up: zeroed uint32[n], receives the upper-neighbour counts  // score_range: device int[3] = {min score, max score, invalid edges}
 size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
 size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)
 hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
-                              bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj, bool packed, int base,
-                              hipStream_t s);
+                              bool symmetric, const uint64_t *start, const uint32_t *up, uint32_t *cursor, void *adj,
+                              bool packed, int base, uint32_t n, hipStream_t s);  // cursor: zeroed uint32[2 n]
 
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);

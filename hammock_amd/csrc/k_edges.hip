@@ -15,7 +15,7 @@ namespace hmk {
 // score_range[2]: edges that name a sequence outside [0, n) or a self pair (not counted; the caller gives up)
 __global__ void __launch_bounds__(256)
 k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
-              uint32_t *__restrict__ deg, int symmetric, int *__restrict__ score_range, uint32_t n) {
+              uint32_t *__restrict__ deg, uint32_t *__restrict__ up, int symmetric, int *__restrict__ score_range, uint32_t n) {
     const uint32_t shard = blockIdx.y;
     const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
     const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
@@ -29,9 +29,16 @@ k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const 
             atomicAdd(&score_range[2], 1);
             valid = false;
         }
-        const WaveGroup g = wave_groups(HMK_EDGE_X(e), valid);
-        if (valid && g.rank == 0) atomicAdd(&deg[HMK_EDGE_X(e)], g.size);
-        if (valid && symmetric) atomicAdd(&deg[HMK_EDGE_M(e)], 1u);
+        // symmetric: the edge is stored under both ends; under its SMALLER end it is an "upper" neighbour (id above
+        // the row's own), counted in up[] as well -- rows are laid out upper neighbours first (k_edge_scatter)
+        const uint32_t ea = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
+        const uint32_t eb = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
+        const WaveGroup g = wave_groups(ea, valid);
+        if (valid && g.rank == 0) {
+            atomicAdd(&deg[ea], g.size);
+            if (symmetric) atomicAdd(&up[ea], g.size);
+        }
+        if (valid && symmetric) atomicAdd(&deg[eb], 1u);
         if (valid) {
             const int sc = HMK_EDGE_SCORE(e);
             lo = min(lo, sc);
@@ -136,11 +143,13 @@ static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *til
 }
 
 // NbrT = Nbr: {m, score}.  NbrT = NbrPacked: m << 8 | (score - base), the caller has checked the score range.
+// symmetric: row r = [neighbours with id > r (up[r] of them) | neighbours with id < r]; cursor = uint32[2 n],
+// one cursor per section.  The host merge only has to look at the first section when a sequence joins a cluster.
 template <class NbrT>
 __global__ void __launch_bounds__(256)
 k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
-               const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, NbrT *__restrict__ adj, int symmetric,
-               int base) {
+               const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, uint32_t *__restrict__ cursor,
+               NbrT *__restrict__ adj, int symmetric, int base, uint32_t n) {
     const uint32_t shard = blockIdx.y;
     const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
     const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
@@ -148,7 +157,8 @@ k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const
         const uint64_t k = k0 + (threadIdx.x & 63);
         const bool valid = k < cnt;
         const uint64_t e = valid ? seg[k] : 0;
-        const uint32_t x = HMK_EDGE_X(e), m = HMK_EDGE_M(e);
+        const uint32_t x = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
+        const uint32_t m = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
         const int32_t s = HMK_EDGE_SCORE(e);
         const WaveGroup g = wave_groups(x, valid);   // one atomic per distinct x of the wave
         uint32_t basex = 0;
@@ -159,10 +169,10 @@ k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const
         if constexpr (sizeof(NbrT) == 4) {
             const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
             adj[px] = NbrT{(m << 8) | rel};
-            if (symmetric) adj[start[m] + atomicAdd(&cursor[m], 1u)] = NbrT{(x << 8) | rel};
+            if (symmetric) adj[start[m] + up[m] + atomicAdd(&cursor[n + m], 1u)] = NbrT{(x << 8) | rel};
         } else {
             adj[px] = NbrT{m, s};
-            if (symmetric) adj[start[m] + atomicAdd(&cursor[m], 1u)] = NbrT{x, s};
+            if (symmetric) adj[start[m] + up[m] + atomicAdd(&cursor[n + m], 1u)] = NbrT{x, s};
         }
     }
 }
@@ -279,26 +289,26 @@ k_rows_unpack(const uint32_t *__restrict__ start, const uint32_t *__restrict__ a
 // launchers
 // -----------------------------------------------------------------------------
 hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
-                                  bool symmetric, uint32_t *deg, uint64_t *start, uint64_t *tile_scratch, int *score_range,
-                                  hipStream_t s) {
+                                  bool symmetric, uint32_t *deg, uint32_t *up, uint64_t *start, uint64_t *tile_scratch,
+                                  int *score_range, hipStream_t s) {
     const int init[3] = {INT_MAX, INT_MIN, 0};
     hipError_t e = hipMemcpyAsync(score_range, init, sizeof(init), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_edge_degree, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg,
+    hipLaunchKernelGGL(k_edge_degree, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg, up,
                        symmetric ? 1 : 0, score_range, n);
     launch_scan<uint64_t>(deg, start, n, tile_scratch, nullptr, s);
     return hipGetLastError();
 }
 
 hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
-                              bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj, bool packed, int base,
-                              hipStream_t s) {
+                              bool symmetric, const uint64_t *start, const uint32_t *up, uint32_t *cursor, void *adj,
+                              bool packed, int base, uint32_t n, hipStream_t s) {
     if (packed)
         hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard,
-                           counts, start, cursor, (NbrPacked *)adj, symmetric ? 1 : 0, base);
+                           counts, start, up, cursor, (NbrPacked *)adj, symmetric ? 1 : 0, base, n);
     else
         hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts,
-                           start, cursor, (Nbr *)adj, symmetric ? 1 : 0, base);
+                           start, up, cursor, (Nbr *)adj, symmetric ? 1 : 0, base, n);
     return hipGetLastError();
 }
 
