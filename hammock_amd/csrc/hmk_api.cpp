@@ -210,6 +210,13 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                     "Shift too big: " + std::to_string(ctx->min_len - 1) + " is maximum, but " + std::to_string(X) +
                         " found");  // ShiftedScorer.java:59-62
     if (thr < -30000 || thr > 30000) return fail(ctx, HMK_ERR_BAD_ARG, "threshold outside [-30000, 30000]");
+    {   // edge scores travel as int16: the largest score any pair can reach must fit
+        const long long top = (long long)ctx->max_len * std::max(0, ctx->max_m) +
+                              (long long)std::max(0, p) * ((ctx->max_len - ctx->min_len) + 2LL * X);
+        if (top > 32767)
+            return fail(ctx, HMK_ERR_BAD_ARG, "scores up to " + std::to_string(top) + " are possible with this matrix / shift penalty: "
+                                               "they do not fit the int16 score of a packed edge");
+    }
 
     // ---- bucket by length ("sorted order") --------------------------------------
     uint32_t bucket[HMK_MAX_LEN + 2] = {0};

@@ -212,6 +212,17 @@ def test_neighbors_asymmetric_matrix(gpu, blosum62, coracle):
     assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, M, res, off, 3, -1, 18))
 
 
+def test_neighbors_refuses_scores_beyond_int16(gpu, blosum62):
+    """A positive shift penalty large enough to push a score past 32767 is refused (edges carry int16 scores)."""
+    res, off = synth_peptides(2, 300, 8, 20)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    with pytest.raises(Exception) as ei:
+        ctx.neighbors_shifted(3, 2000, 20)
+    assert "int16" in str(ei.value)
+    edges, _ = ctx.neighbors_shifted(3, 2, 20)      # a small positive penalty is fine
+    assert len(edges) > 0
+
+
 def test_neighbors_sharded_union_equals_whole(gpu, blosum62):
     """Row-block sharding (multi-GPU): the shards partition the edge set."""
     res, off = synth_peptides(4, 5000, 12)
