@@ -234,6 +234,11 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             const unsigned T = std::max(1u, std::min(16u, hw ? hw : 1u));
             const size_t nc = clusters.size();
             std::vector<std::vector<Cand>> found(T);     // thread t covers a contiguous run of leftovers
+            // most neighbours are in no cluster at all: a bitmap over the sequences (n / 8 bytes, cache resident)
+            // answers that before the 4-byte-per-sequence cluster_of[] has to be touched
+            std::vector<uint64_t> in_cluster(((size_t)n + 63) / 64, 0);
+            for (uint32_t s2 = 0; s2 < n; s2++)
+                if (cluster_of[s2] >= 0) in_cluster[s2 >> 6] |= 1ull << (s2 & 63);
             auto work = [&](unsigned t) {
                 std::vector<int32_t> c2(nc, 0), m2(nc, 0);
                 std::vector<int32_t> seen;
@@ -242,8 +247,9 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     const uint32_t y = leftover[q];
                     seen.clear();
                     for (uint64_t e = start[y]; e < start[y + 1]; e++) {
-                        const int32_t c = cluster_of[adj[e].id()];
-                        if (c < 0) continue;
+                        const uint32_t id = adj[e].id();
+                        if (!((in_cluster[id >> 6] >> (id & 63)) & 1ull)) continue;
+                        const int32_t c = cluster_of[id];
                         if (c2[c]++ == 0) { seen.push_back(c); m2[c] = adj[e].score(); }
                         else if (adj[e].score() < m2[c]) m2[c] = adj[e].score();
                     }
