@@ -10,6 +10,8 @@
 #include <jni.h>
 #include <stdint.h>
 
+#include <stddef.h>
+
 #include "hammock_hip.h"
 
 static void throw_for(JNIEnv *env, hmk_ctx *ctx, int st) {
