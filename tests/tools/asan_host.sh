@@ -3,10 +3,10 @@
 #  1. host greedy merge (hmk_greedy.cpp) on random thresholded graphs, ASAN+UBSAN
 #  2. the oracle's C restatement under ASAN+UBSAN through tests/test_oracle.py
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 T=$(mktemp -d)
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -Ihammock_amd/csrc -Iinclude \
-    tools/asan_merge_harness.cpp hammock_amd/csrc/hmk_greedy.cpp -lpthread -o "$T/harness"
+    tests/tools/asan_merge_harness.cpp hammock_amd/csrc/hmk_greedy.cpp -lpthread -o "$T/harness"
 "$T/harness" | tail -3
 make -C oracle >/dev/null
 cp oracle/_build/libhammock_oracle.so "$T/orig.so"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs the BASELINE.json configs that fit one GPU (2, 3, 4a, 4b; 5 as a single-GPU shard) and
 prints one JSON line each: kernel time, pairs/s, classes per lane path, sampled oracle parity.
-Usage: python tools/bench_configs.py [--quick]"""
+Usage: python tests/tools/bench_configs.py [--quick]"""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import hammock_amd

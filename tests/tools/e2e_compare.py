@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end figure of SURVEY.md 8(d): wall time of "sort + cluster" (Hammock.java:406-411) on the
 BASELINE workload for the GPU path vs the CPU restatement of the reference algorithm, with identical
-cluster membership asserted.  Usage: python tools/e2e_compare.py [n] [threads]"""
+cluster membership asserted.  Usage: python tests/tools/e2e_compare.py [n] [threads]"""
 import json
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import hammock_amd
 from hammock_amd.synth import synth_peptides
 from bench import load_blosum62

@@ -2,14 +2,14 @@
 """Long randomized sweep of hmk_greedy_cluster against the oracle's literal greedy: random sizes (counts),
 mixed lengths, thresholds around the reference default, cluster limits from tiny to large, shift penalty,
 asymmetric matrices, including the inputs on which the reference throws (crash parity).
-Usage: python tools/fuzz_greedy.py [trials] [seed]"""
+Usage: python tests/tools/fuzz_greedy.py [trials] [seed]"""
 import json
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import hammock_amd  # noqa: E402
 from hammock_amd.synth import synth_peptides  # noqa: E402

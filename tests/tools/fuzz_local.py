@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Long randomized sweep of the LocalAlignmentScorer kernels (packed / tagged / plain / literal tiers are
 chosen by the matrix and penalty ranges) against the oracle: dense blocks and thresholded ordered pairs.
-Usage: python tools/fuzz_local.py [trials] [seed]"""
+Usage: python tests/tools/fuzz_local.py [trials] [seed]"""
 import json
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import hammock_amd  # noqa: E402
 from hammock_amd.synth import synth_peptides  # noqa: E402

@@ -3,7 +3,7 @@
 same generator; this runs as many as asked): matrices (shipped, random symmetric, asymmetric, extreme),
 length ranges up to 32, max shift, shift penalty of either sign, thresholds from the score distribution,
 heavy (tryptophan-rich) peptides that straddle the 8-bit row-bound limit.
-Usage: python tools/fuzz_neighbors.py [trials] [seed] [first_trial]   (trials before first_trial only advance the
+Usage: python tests/tools/fuzz_neighbors.py [trials] [seed] [first_trial]   (trials before first_trial only advance the
 random stream; HMK_FUZZ_VERBOSE=1 prints every trial's parameters before it runs)"""
 import json
 import os
@@ -11,7 +11,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hammock_amd  # noqa: E402
