@@ -1160,19 +1160,71 @@ static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint
     if (e == hipSuccess && symmetric) e = hipMemcpy(h_up, d_up, (size_t)n * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && n_adj) e = hipMemcpy(h_adj, d_adj, n_adj * esz, hipMemcpyDeviceToHost);
     lap("D2H of the adjacency");
-    cleanup();
-    lap("device buffers freed");
-    if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,
-                                     std::string("hmk_greedy_cluster (CSR build): ") + hipGetErrorString(e));
-    if (h_start[n] != n_adj) return fail(ctx, HMK_ERR_DEVICE, "CSR build: adjacency size mismatch");
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(ctx, e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,
+                    std::string("hmk_greedy_cluster (CSR build): ") + hipGetErrorString(e));
+    }
+    if (h_start[n] != n_adj) {
+        cleanup();
+        return fail(ctx, HMK_ERR_DEVICE, "CSR build: adjacency size mismatch");
+    }
+    // The adjacency stays on the device until the merge is through: the pre-check of its second loop (every leftover
+    // against every cluster) runs there, on d_start / d_adj, once the host has finished phase 1.
+    GreedyPrecheck precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize,
+                                  const std::vector<uint32_t> &leftover, std::vector<uint32_t> &cand_start,
+                                  std::vector<GreedyCand> &cand) -> bool {
+        if (getenv("HMK_HOST_PRECHECK")) return false;
+        const uint32_t nl = (uint32_t)leftover.size();
+        int32_t *d_cof = nullptr, *d_usize = nullptr;
+        uint32_t *d_left = nullptr, *d_cnt = nullptr, *d_cstart = nullptr, *d_over = nullptr;
+        uint64_t *d_scan = nullptr;
+        GreedyCand *d_cand = nullptr;
+        auto drop = [&]() {
+            for (void *q : {(void *)d_cof, (void *)d_usize, (void *)d_left, (void *)d_cnt, (void *)d_cstart, (void *)d_over,
+                            (void *)d_scan, (void *)d_cand})
+                if (q) (void)hipFree(q);
+        };
+        hipError_t r = hipMalloc((void **)&d_cof, (size_t)n * 4);
+        if (r == hipSuccess) r = hipMalloc((void **)&d_usize, std::max<size_t>(usize.size(), 1) * 4);
+        if (r == hipSuccess) r = hipMalloc((void **)&d_left, (size_t)nl * 4);
+        if (r == hipSuccess) r = hipMalloc((void **)&d_cnt, (size_t)nl * 4);
+        if (r == hipSuccess) r = hipMalloc((void **)&d_cstart, ((size_t)nl + 1) * 4);
+        if (r == hipSuccess) r = hipMalloc((void **)&d_over, 4);
+        if (r == hipSuccess) r = hipMalloc((void **)&d_scan, scan_scratch_bytes(nl));
+        if (r == hipSuccess) r = hipMemcpy(d_cof, cluster_of, (size_t)n * 4, hipMemcpyHostToDevice);
+        if (r == hipSuccess) r = hipMemcpy(d_usize, usize.data(), usize.size() * 4, hipMemcpyHostToDevice);
+        if (r == hipSuccess) r = hipMemcpy(d_left, leftover.data(), (size_t)nl * 4, hipMemcpyHostToDevice);
+        if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 4, nullptr);
+        if (r == hipSuccess) r = hipMemsetAsync(d_cnt, 0, (size_t)nl * 4, nullptr);
+        if (r == hipSuccess) r = launch_greedy_precheck(false, packed, d_start, d_adj, d_cof, d_usize, d_left, nl, d_cnt, nullptr,
+                                                        nullptr, d_over, nullptr);
+        if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, nullptr);
+        uint32_t over = 0;
+        if (r == hipSuccess) r = hipMemcpy(&over, d_over, 4, hipMemcpyDeviceToHost);
+        cand_start.assign((size_t)nl + 1, 0);
+        if (r == hipSuccess) r = hipMemcpy(cand_start.data(), d_cstart, ((size_t)nl + 1) * 4, hipMemcpyDeviceToHost);
+        if (r != hipSuccess || over != 0) { drop(); return false; }   // a row overflowed its hash table: host pre-check
+        const uint32_t total_c = cand_start[nl];
+        cand.resize(total_c);
+        if (total_c) {
+            r = hipMalloc((void **)&d_cand, (size_t)total_c * sizeof(GreedyCand));
+            if (r == hipSuccess) r = launch_greedy_precheck(true, packed, d_start, d_adj, d_cof, d_usize, d_left, nl, d_cnt, d_cstart,
+                                                            d_cand, d_over, nullptr);
+            if (r == hipSuccess) r = hipMemcpy(cand.data(), d_cand, (size_t)total_c * sizeof(GreedyCand), hipMemcpyDeviceToHost);
+        }
+        drop();
+        return r == hipSuccess;
+    };
     const double nb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     std::string err;
     const int32_t *szs = ctx->has_sizes ? ctx->sizes.data() : nullptr;
     const uint32_t *upper = symmetric ? h_up : nullptr;   // rows are laid out upper neighbours first
-    int st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, upper, symmetric, max_clusters,
+    int st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, upper, &precheck, symmetric, max_clusters,
                                          cluster_id, result_order, member_rank, stats, &err)
-                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, upper, symmetric, max_clusters, cluster_id,
+                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, upper, &precheck, symmetric, max_clusters, cluster_id,
                                   result_order, member_rank, stats, &err);
+    cleanup();
     stats->n_edges = total;
     stats->neighbors_ms = nb_ms;
     if (st) return fail(ctx, st, err);

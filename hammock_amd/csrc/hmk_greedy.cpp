@@ -87,7 +87,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
             if (symmetric) adj[fill[m]++] = Nbr{x, s};
         }
     }
-    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), nullptr, symmetric, max_clusters, cluster_id,
+    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), nullptr, nullptr, symmetric, max_clusters, cluster_id,
                                    result_order, member_rank, st, err);
     if (st) {
         st->n_edges = n_edges;
@@ -100,7 +100,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
 // NbrT: Nbr (8 bytes) or NbrPacked (4 bytes); only id() and score() are used, scores only in comparisons.
 template <class NbrT>
 static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj,
-                                const uint32_t *upper, bool symmetric_scores, int max_clusters,
+                                const uint32_t *upper, const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters,
                                 int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                                 std::string *err) {
     auto t0 = std::chrono::steady_clock::now();
@@ -224,12 +224,19 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         //     sequence, filled by the threads in order).
         // (2) Sequential, order-dependent part (:60-62) only for the survivors; with symmetric scores a
         //     survivor does not rescan its neighbours (see "Subscribers" below).
-        struct Cand { int32_t c, mn, covered; };   // cluster, min score so far, members joined in this loop that are neighbours
+        using Cand = GreedyCand;   // cluster, min score so far, members joined in this loop that are neighbours
         const size_t nl = leftover.size();
         std::vector<uint32_t> cand_start(nl + 1, 0);     // CSR of candidate clusters per leftover
         std::vector<Cand> cand;
         const bool fast = !clusters.empty() && nl > 512;
-        if (fast) {
+        bool have_cand = false;
+        if (fast && precheck && *precheck) {   // the adjacency is still on the GPU: pre-check there
+            std::vector<int32_t> usize(clusters.size());
+            for (size_t c = 0; c < clusters.size(); c++) usize[c] = clusters[c].usize;
+            have_cand = (*precheck)(cluster_of.data(), usize, leftover, cand_start, cand);
+            if (!have_cand) { cand_start.assign(nl + 1, 0); cand.clear(); }
+        }
+        if (fast && !have_cand) {
             const unsigned hw = std::thread::hardware_concurrency();
             const unsigned T = std::max(1u, std::min(16u, hw ? hw : 1u));
             const size_t nc = clusters.size();
@@ -387,16 +394,17 @@ crash:
 }
 
 int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, const uint32_t *upper,
-                    bool symmetric_scores, int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
-                    hmk_greedy_stats *st, std::string *err) {
-    return greedy_from_csr_impl<Nbr>(n, sizes, start, adj, upper, symmetric_scores, max_clusters, cluster_id, result_order,
-                                     member_rank, st, err);
+                    const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters, int32_t *cluster_id,
+                    int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
+    return greedy_from_csr_impl<Nbr>(n, sizes, start, adj, upper, precheck, symmetric_scores, max_clusters, cluster_id,
+                                     result_order, member_rank, st, err);
 }
 
 int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj,
-                           const uint32_t *upper, bool symmetric_scores, int max_clusters, int32_t *cluster_id,
-                           int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
-    return greedy_from_csr_impl<NbrPacked>(n, sizes, start, adj, upper, symmetric_scores, max_clusters, cluster_id,
+                           const uint32_t *upper, const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters,
+                           int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
+                           std::string *err) {
+    return greedy_from_csr_impl<NbrPacked>(n, sizes, start, adj, upper, precheck, symmetric_scores, max_clusters, cluster_id,
                                            result_order, member_rank, st, err);
 }
 

@@ -5,7 +5,9 @@
 
 #include <stdint.h>
 
+#include <functional>
 #include <string>
+#include <vector>
 
 #include "../../include/hammock_hip.h"
 
@@ -71,16 +73,29 @@ struct NbrPacked {
     int32_t score() const { return (int32_t)(v & 0xFFu); }
 };
 
+// A cluster a leftover sequence could still join after phase 1: every member of cluster c is a neighbour of the
+// sequence; mn = the lowest of those scores; covered counts, during the second loop, the members that joined
+// later and are neighbours too (starts at 0).
+struct GreedyCand { int32_t c, mn, covered; };
+
+// Optional device-side pre-check of the second loop (hmk_api.cpp provides it when the adjacency is still resident on
+// the GPU): given cluster_of[n] (-1 = none), the clusters' member counts and the leftover list, fill the candidate
+// CSR (cand_start[nl + 1], cand[]).  Returns false if it could not (the merge then runs its threaded host version).
+using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::vector<int32_t> &usize,
+                                          const std::vector<uint32_t> &leftover, std::vector<uint32_t> &cand_start,
+                                          std::vector<GreedyCand> &cand)>;
+
 // host greedy merge (hmk_greedy.cpp)
 // symmetric_scores: adj holds every edge under both ends with the same score (symmetric matrix)
 // upper: NULL, or per row the number of leading entries whose id is above the row's own (the row is laid out
 //        "upper neighbours first"); lets the join propagation skip the neighbours that are already decided
+// precheck: NULL or the device-side pre-check (see GreedyPrecheck)
 int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, const uint32_t *upper,
-                    bool symmetric_scores, int max_clusters,
+                    const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters,
                     int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                     std::string *err);
 int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj,
-                           const uint32_t *upper, bool symmetric_scores, int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
+                           const uint32_t *upper, const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
                            hmk_greedy_stats *st, std::string *err);
 int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
                       bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,

@@ -51,6 +51,12 @@ hipError_t launch_pack_rows(const uint64_t *edges, uint64_t cap_per_shard, const
 hipError_t launch_unpack_rows(const uint32_t *row_start, const uint32_t *adj, uint32_t n, int threshold, uint64_t *out,
                               uint64_t out_capacity, hipStream_t s);
 
+// pre-check of the greedy merge's second loop on the device-resident adjacency (k_edges.hip)
+hipError_t launch_greedy_precheck(bool fill, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
+                                  const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
+                                  const uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, hipStream_t s);
+hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, uint64_t *tile_scratch, hipStream_t s);
+
 // LocalAlignmentScorer dense block, register-resident DP (needs |M| <= 127, gap penalties <= 0, len <= lbmax)
 // enc: the tagged-max DP (needs |M| <= 31 and -31 <= gap penalties <= 0)
 hipError_t launch_local_block(int lbmax, bool enc, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,

@@ -286,6 +286,76 @@ k_rows_unpack(const uint32_t *__restrict__ start, const uint32_t *__restrict__ a
 }
 
 // -----------------------------------------------------------------------------
+// pre-check of the greedy merge's second loop, on the adjacency while it is still on the device
+// -----------------------------------------------------------------------------
+// For every leftover sequence y (one wave each): which clusters have ALL their members among y's neighbours, and
+// with which lowest score (LimitedGreedySequenceClusterer.java:60 asks that of every cluster; complete linkage is
+// monotone, so clusters that fail now can never be joined later -- DESIGN.md "Exact greedy").  The neighbours'
+// clusters are counted in a per-wave LDS hash table (key = cluster, count, min score).  FILL = false counts the
+// candidates of each leftover, FILL = true writes them at cand_start[q]; a row with more distinct clusters than
+// the table takes raises *overflow (the host then runs its own pre-check).
+constexpr int PRE_SLOTS = 1024;   // per wave; 3 x 4 KB
+
+__device__ __forceinline__ uint32_t nbr_id(const Nbr &a) { return a.m; }
+__device__ __forceinline__ int32_t nbr_score(const Nbr &a) { return a.s; }
+__device__ __forceinline__ uint32_t nbr_id(const NbrPacked &a) { return a.v >> 8; }
+__device__ __forceinline__ int32_t nbr_score(const NbrPacked &a) { return (int32_t)(a.v & 0xFFu); }
+
+template <class NbrT, bool FILL>
+__global__ void __launch_bounds__(256)
+k_greedy_precheck(const uint64_t *__restrict__ start, const NbrT *__restrict__ adj, const int32_t *__restrict__ cluster_of,
+                  const int32_t *__restrict__ usize, const uint32_t *__restrict__ leftover, uint32_t nl,
+                  uint32_t *__restrict__ cand_cnt, const uint32_t *__restrict__ cand_start, GreedyCand *__restrict__ cand,
+                  uint32_t *__restrict__ overflow) {
+    __shared__ int32_t keys_all[4 * PRE_SLOTS];
+    __shared__ uint32_t cnt_all[4 * PRE_SLOTS];
+    __shared__ int32_t mn_all[4 * PRE_SLOTS];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int32_t *keys = keys_all + wv * PRE_SLOTS;
+    uint32_t *cnt = cnt_all + wv * PRE_SLOTS;
+    int32_t *mn = mn_all + wv * PRE_SLOTS;
+    for (uint32_t q = blockIdx.x * 4 + wv; q < nl; q += gridDim.x * 4) {
+        for (uint32_t sl = lane; sl < PRE_SLOTS; sl += 64) { keys[sl] = -1; cnt[sl] = 0; mn[sl] = INT_MAX; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        const uint32_t y = leftover[q];
+        const uint64_t b = start[y], e = start[y + 1];
+        bool full = false;
+        for (uint64_t k = b + lane; k < e; k += 64) {
+            const NbrT nb = adj[k];
+            const int32_t c = cluster_of[nbr_id(nb)];
+            if (c < 0) continue;
+            uint32_t sl = ((uint32_t)c * 2654435761u) >> 22;   // top 10 bits
+            int probes = 0;
+            for (;;) {
+                const int32_t old = atomicCAS(&keys[sl], -1, c);
+                if (old == -1 || old == c) {
+                    atomicAdd(&cnt[sl], 1u);
+                    atomicMin(&mn[sl], nbr_score(nb));
+                    break;
+                }
+                sl = (sl + 1) & (PRE_SLOTS - 1);
+                if (++probes >= PRE_SLOTS) { full = true; break; }
+            }
+        }
+        if (__ballot(full) != 0) {
+            if (lane == 0) atomicAdd(overflow, 1u);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        uint32_t found = 0;
+        for (uint32_t s0 = 0; s0 < PRE_SLOTS; s0 += 64) {
+            const uint32_t sl = s0 + lane;
+            const int32_t c = keys[sl];
+            const bool ok = c >= 0 && (int32_t)cnt[sl] == usize[c];   // every member of c is a neighbour of y
+            const uint64_t mask = __ballot(ok);
+            if (FILL && ok) cand[cand_start[q] + found + mbcnt64(mask)] = GreedyCand{c, mn[sl], 0};
+            found += (uint32_t)__popcll(mask);
+        }
+        if (!FILL && lane == 0) cand_cnt[q] = found;
+    }
+}
+
+// -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------
 hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
@@ -341,6 +411,26 @@ size_t scan_scratch_bytes(uint32_t n) { return ((size_t)(n + SCAN_TILE - 1) / SC
 hipError_t launch_unpack_rows(const uint32_t *row_start, const uint32_t *adj, uint32_t n, int threshold, uint64_t *out,
                               uint64_t out_capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_rows_unpack, dim3(1024), dim3(256), 0, s, row_start, adj, n, threshold, out, out_capacity);
+    return hipGetLastError();
+}
+
+// counts (cand_cnt[nl]) or fills (cand at cand_start[q]) the candidate lists; adj is Nbr[] or NbrPacked[]
+hipError_t launch_greedy_precheck(bool fill, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
+                                  const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
+                                  const uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, hipStream_t s) {
+    if (nl == 0) return hipSuccess;
+    const dim3 grid(std::min<uint32_t>((nl + 3) / 4, 256 * 12)), block(256);
+#define HMK_PRE(T, F) hipLaunchKernelGGL((k_greedy_precheck<T, F>), grid, block, 0, s, start, (const T *)adj, cluster_of, usize, \
+                                         leftover, nl, cand_cnt, cand_start, cand, overflow)
+    if (packed) { if (fill) HMK_PRE(NbrPacked, true); else HMK_PRE(NbrPacked, false); }
+    else { if (fill) HMK_PRE(Nbr, true); else HMK_PRE(Nbr, false); }
+#undef HMK_PRE
+    return hipGetLastError();
+}
+
+// exclusive scan of uint32 counts into uint32 start[n + 1] (tile_scratch: scan_scratch_bytes(n))
+hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, uint64_t *tile_scratch, hipStream_t s) {
+    launch_scan<uint32_t>(counts, start, n, tile_scratch, nullptr, s);
     return hipGetLastError();
 }
 
