@@ -90,6 +90,10 @@ struct hmk_ctx {
     static constexpr int N_SIDE = 3;
     hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr, nullptr, nullptr};
+    // chunked device-to-host copy of the adjacency (hmk_greedy_cluster): stream and events are made once
+    static constexpr int COPY_CHUNKS = 32;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t chunk_done[COPY_CHUNKS] = {nullptr};
     uint32_t *d_rows_scratch = nullptr;  // deg[n], cursor[n], misfit of hmk_pack_rows_dev
     uint32_t d_rows_scratch_n = 0;
 
@@ -847,6 +851,9 @@ void hmk_destroy(hmk_ctx *ctx) {
         if (ctx->d_edges) (void)hipFree(ctx->d_edges);
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
         if (ctx->d_rows_scratch) (void)hipFree(ctx->d_rows_scratch);
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        for (int c = 0; c < hmk_ctx::COPY_CHUNKS; c++)
+            if (ctx->chunk_done[c]) (void)hipEventDestroy(ctx->chunk_done[c]);
         for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
             if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
             if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
@@ -1158,20 +1165,60 @@ static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint
     void *h_adj = (char *)h_up + up_bytes;
     if (e == hipSuccess) e = hipMemcpy(h_start, d_start, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess && symmetric) e = hipMemcpy(h_up, d_up, (size_t)n * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && n_adj) e = hipMemcpy(h_adj, d_adj, n_adj * esz, hipMemcpyDeviceToHost);
-    lap("D2H of the adjacency");
+    // the adjacency itself travels in chunks on a side stream; the merge waits for a chunk only when phase 1 (which
+    // walks the rows in order) or the second loop needs it
+    constexpr int COPY_CHUNKS = hmk_ctx::COPY_CHUNKS;
+    hipStream_t &copy_stream = ctx->copy_stream;
+    hipEvent_t *chunk_done = ctx->chunk_done;
+    uint64_t chunk_end[COPY_CHUNKS] = {0};   // entries [0, chunk_end[c]) have been queued up to chunk c
+    int n_chunks = 0;
+    auto drop_copy = [&]() {};               // stream and events live in the context
+    if (e == hipSuccess && n_adj) {
+        if (!copy_stream) {
+            e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+            for (int c = 0; c < COPY_CHUNKS && e == hipSuccess; c++)
+                e = hipEventCreateWithFlags(&chunk_done[c], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();   // the scatter kernel (null stream) has written d_adj
+        // the first chunks are small (phase 1 starts on them at once), the rest split what remains evenly
+        const uint64_t first = std::min<uint64_t>(n_adj, (8u << 20) / esz);
+        const uint64_t per = std::max<uint64_t>((n_adj - first + COPY_CHUNKS - 2) / (COPY_CHUNKS - 1), (16u << 20) / esz);
+        for (uint64_t o = 0; o < n_adj && e == hipSuccess;) {
+            const uint64_t cnt = std::min(o == 0 ? first : per, n_adj - o);
+            e = hipMemcpyAsync((char *)h_adj + o * esz, (const char *)d_adj + o * esz, cnt * esz, hipMemcpyDeviceToHost, copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(chunk_done[n_chunks], copy_stream);
+            o += cnt;
+            chunk_end[n_chunks++] = o;
+        }
+    }
+    lap("D2H of the adjacency queued");
     if (e != hipSuccess) {
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+        drop_copy();
         cleanup();
         return fail(ctx, e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,
                     std::string("hmk_greedy_cluster (CSR build): ") + hipGetErrorString(e));
     }
     if (h_start[n] != n_adj) {
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+        drop_copy();
         cleanup();
         return fail(ctx, HMK_ERR_DEVICE, "CSR build: adjacency size mismatch");
     }
+    int chunks_waited = 0;
+    hipError_t copy_error = hipSuccess;
+    GreedyHooks hooks;
+    hooks.need_entries = [&](uint64_t upto) -> uint64_t {
+        while (chunks_waited < n_chunks && (chunks_waited == 0 || chunk_end[chunks_waited - 1] < upto)) {
+            const hipError_t r = hipEventSynchronize(chunk_done[chunks_waited]);
+            if (r != hipSuccess) copy_error = r;
+            chunks_waited++;
+        }
+        return chunks_waited ? chunk_end[chunks_waited - 1] : 0;
+    };
     // The adjacency stays on the device until the merge is through: the pre-check of its second loop (every leftover
     // against every cluster) runs there, on d_start / d_adj, once the host has finished phase 1.
-    GreedyPrecheck precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize,
+    hooks.precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize,
                                   const std::vector<uint32_t> &leftover, std::vector<uint32_t> &cand_start,
                                   std::vector<GreedyCand> &cand) -> bool {
         if (getenv("HMK_HOST_PRECHECK")) return false;
@@ -1220,11 +1267,15 @@ static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint
     std::string err;
     const int32_t *szs = ctx->has_sizes ? ctx->sizes.data() : nullptr;
     const uint32_t *upper = symmetric ? h_up : nullptr;   // rows are laid out upper neighbours first
-    int st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, upper, &precheck, symmetric, max_clusters,
+    int st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, upper, &hooks, symmetric, max_clusters,
                                          cluster_id, result_order, member_rank, stats, &err)
-                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, upper, &precheck, symmetric, max_clusters, cluster_id,
+                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, upper, &hooks, symmetric, max_clusters, cluster_id,
                                   result_order, member_rank, stats, &err);
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);   // a crash-parity exit may leave chunks in flight
+    drop_copy();
     cleanup();
+    if (copy_error != hipSuccess)
+        return fail(ctx, HMK_ERR_DEVICE, std::string("hmk_greedy_cluster (adjacency copy): ") + hipGetErrorString(copy_error));
     stats->n_edges = total;
     stats->neighbors_ms = nb_ms;
     if (st) return fail(ctx, st, err);

@@ -100,7 +100,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
 // NbrT: Nbr (8 bytes) or NbrPacked (4 bytes); only id() and score() are used, scores only in comparisons.
 template <class NbrT>
 static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj,
-                                const uint32_t *upper, const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters,
+                                const uint32_t *upper, const GreedyHooks *hooks, bool symmetric_scores, int max_clusters,
                                 int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                                 std::string *err) {
     auto t0 = std::chrono::steady_clock::now();
@@ -156,8 +156,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     int64_t remaining = n;  // elements of initialList at positions >= index
     int64_t index = 0;
     uint32_t k = 0;         // sequence behind initialList.get(index)
+    uint64_t arrived = (hooks && hooks->need_entries) ? 0 : start[n];   // adj[0 .. arrived) is on the host
     for (; k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters; k++) {
         if (state[k] != ST_FREE) continue;  // removed from initialList (:101, :110)
+        if (start[k + 1] > arrived) arrived = hooks->need_entries(start[k + 1]);   // row k must have landed
         Found A = nearest_cluster(k);                       // :92
         Found B;                                            // :93
         if (remaining - 1 == 0) {
@@ -214,6 +216,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
 
     {
         // ---- cluster() second loop, :59-66 ---------------------------------
+        if (start[n] > arrived) arrived = hooks->need_entries(start[n]);   // from here on any row may be read
         std::vector<uint32_t> leftover(orphans);
         for (uint32_t q = k; q < n; q++)
             if (state[q] == ST_FREE) leftover.push_back(q);
@@ -230,10 +233,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         std::vector<Cand> cand;
         const bool fast = !clusters.empty() && nl > 512;
         bool have_cand = false;
-        if (fast && precheck && *precheck) {   // the adjacency is still on the GPU: pre-check there
+        if (fast && hooks && hooks->precheck) {   // the adjacency is still on the GPU: pre-check there
             std::vector<int32_t> usize(clusters.size());
             for (size_t c = 0; c < clusters.size(); c++) usize[c] = clusters[c].usize;
-            have_cand = (*precheck)(cluster_of.data(), usize, leftover, cand_start, cand);
+            have_cand = hooks->precheck(cluster_of.data(), usize, leftover, cand_start, cand);
             if (!have_cand) { cand_start.assign(nl + 1, 0); cand.clear(); }
         }
         if (fast && !have_cand) {
@@ -394,17 +397,17 @@ crash:
 }
 
 int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, const uint32_t *upper,
-                    const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters, int32_t *cluster_id,
+                    const GreedyHooks *hooks, bool symmetric_scores, int max_clusters, int32_t *cluster_id,
                     int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
-    return greedy_from_csr_impl<Nbr>(n, sizes, start, adj, upper, precheck, symmetric_scores, max_clusters, cluster_id,
+    return greedy_from_csr_impl<Nbr>(n, sizes, start, adj, upper, hooks, symmetric_scores, max_clusters, cluster_id,
                                      result_order, member_rank, st, err);
 }
 
 int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj,
-                           const uint32_t *upper, const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters,
+                           const uint32_t *upper, const GreedyHooks *hooks, bool symmetric_scores, int max_clusters,
                            int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                            std::string *err) {
-    return greedy_from_csr_impl<NbrPacked>(n, sizes, start, adj, upper, precheck, symmetric_scores, max_clusters, cluster_id,
+    return greedy_from_csr_impl<NbrPacked>(n, sizes, start, adj, upper, hooks, symmetric_scores, max_clusters, cluster_id,
                                            result_order, member_rank, st, err);
 }
 

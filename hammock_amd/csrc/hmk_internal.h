@@ -85,17 +85,27 @@ using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::
                                           const std::vector<uint32_t> &leftover, std::vector<uint32_t> &cand_start,
                                           std::vector<GreedyCand> &cand)>;
 
+// Hooks of the host merge for a caller that still has the adjacency on the device (hmk_api.cpp):
+//   precheck       see GreedyPrecheck (may be empty)
+//   need_entries   the adjacency may still be in flight to the host: need_entries(e) returns once adj[0 .. e) has
+//                  arrived and reports how far the copy has got (>= e); phase 1 asks row by row, so it overlaps the
+//                  tail of the copy.  Empty = everything is there already.
+struct GreedyHooks {
+    GreedyPrecheck precheck;
+    std::function<uint64_t(uint64_t)> need_entries;
+};
+
 // host greedy merge (hmk_greedy.cpp)
 // symmetric_scores: adj holds every edge under both ends with the same score (symmetric matrix)
 // upper: NULL, or per row the number of leading entries whose id is above the row's own (the row is laid out
 //        "upper neighbours first"); lets the join propagation skip the neighbours that are already decided
-// precheck: NULL or the device-side pre-check (see GreedyPrecheck)
+// hooks: NULL or the caller's device-side helpers (see GreedyHooks)
 int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, const uint32_t *upper,
-                    const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters,
+                    const GreedyHooks *hooks, bool symmetric_scores, int max_clusters,
                     int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                     std::string *err);
 int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj,
-                           const uint32_t *upper, const GreedyPrecheck *precheck, bool symmetric_scores, int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
+                           const uint32_t *upper, const GreedyHooks *hooks, bool symmetric_scores, int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
                            hmk_greedy_stats *st, std::string *err);
 int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
                       bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,
