@@ -241,7 +241,7 @@ int runGreedy(const std::vector<std::string> &args) {
         };
         logger.logAndStderr("Ready. Clustering time: " + std::to_string(ms()));                // :411
         logger.logAndStderr("Resulting clusers: " + std::to_string(clusters.size()));          // :412
-        logger.logAndStderr("GPU scoring + transfer: " + std::to_string(clusterer.stats.neighbors_ms) + " ms, host greedy merge: " +
+        logger.logAndStderr("GPU scoring + adjacency build: " + std::to_string(clusterer.stats.neighbors_ms) + " ms, host greedy merge: " +
                             std::to_string(clusterer.stats.greedy_ms) + " ms, neighbour edges: " +
                             std::to_string(clusterer.stats.n_edges));
         logger.logAndStderr("Building MSAs... (skipped: Clustal Omega is outside the scope of hammock-hip; the alignment "

@@ -52,8 +52,8 @@ assert st == 0
 identical = bool(np.array_equal(cid, ocid) and np.array_equal(order, oorder))
 calls = int(ostats.score_calls_phase1 + ostats.score_calls_phase2)
 print(json.dumps({"workload": f"{n} synthetic 12-mers with counts, BLOSUM62, X=3, p=0, thr=20, maxClusters={maxc}",
-                  "gpu_sort_upload_cluster_s": t_gpu, "gpu_neighbors_csr_d2h_ms": gstats.neighbors_ms,
-                  "gpu_host_merge_ms": gstats.greedy_ms, "cpu_port_sort_cluster_s": t_cpu, "cpu_threads": threads,
+                  "gpu_sort_upload_cluster_s": t_gpu, "gpu_score_and_csr_ms": gstats.neighbors_ms,
+                  "gpu_merge_ms_incl_wait_for_d2h": gstats.greedy_ms, "cpu_port_sort_cluster_s": t_cpu, "cpu_threads": threads,
                   "cpu_sequenceScore_calls": calls, "cpu_calls_per_s": calls / t_cpu,
                   "pair_space": n * (n - 1) // 2, "speedup_end_to_end": t_cpu / t_gpu,
                   "identical_membership": identical, "clusters": int(gstats.n_multi)}))

@@ -31,6 +31,6 @@ assert np.array_equal(cid, cid2) and np.array_equal(order, order2)
 sizes = np.bincount(np.unique(cid, return_inverse=True)[1])
 print(json.dumps({"n": n, "pairs": n * (n - 1) // 2, "edges": int(st.n_edges), "clusters": int(st.n_multi),
                   "result_list": int(st.n_result_clusters), "largest_cluster": int(sizes.max()),
-                  "first_call_s": t1, "second_call_s": t2, "neighbors_csr_d2h_ms": st2.neighbors_ms,
-                  "host_merge_ms": st2.greedy_ms, "phase1_stop_index": int(st.phase1_stop_index),
+                  "first_call_s": t1, "second_call_s": t2, "score_and_csr_ms": st2.neighbors_ms,
+                  "merge_ms_incl_wait_for_d2h": st2.greedy_ms, "phase1_stop_index": int(st.phase1_stop_index),
                   "generate_s": t_gen}))
