@@ -360,6 +360,27 @@ def test_greedy_from_device_edges(gpu, blosum62, coracle):
     assert "outside" in str(ei.value)
 
 
+def test_greedy_device_precheck_table_overflow_falls_back(gpu, blosum62):
+    """The device pre-check counts a leftover's neighbouring clusters in a 1,024-slot table; a hub sequence that
+    touches 1,500 clusters overflows it and the merge must quietly use its host pre-check: same result as the
+    host-only merge on the same edges."""
+    import torch
+    n_pairs, extra = 1500, 700
+    n = 2 * n_pairs + 1 + extra
+    res, off = synth_peptides(21, n, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    hub = 2 * n_pairs
+    xs = np.concatenate([np.arange(0, 2 * n_pairs, 2), np.arange(0, 2 * n_pairs, 2)])
+    ms = np.concatenate([np.arange(1, 2 * n_pairs, 2), np.full(n_pairs, hub)])
+    sc = np.concatenate([np.full(n_pairs, 50), np.full(n_pairs, 21)])
+    edges = hammock_amd.pack_edges(xs, ms, sc)
+    want_cid, want_order, _ = ctx.greedy_from_edges(edges, True, 20, n_pairs)
+    d = torch.from_numpy(edges.view(np.int64).copy()).to("cuda:0")
+    cid, order, st = ctx.greedy_from_edges_dev(d.data_ptr(), d.numel(), True, n_pairs)
+    assert np.array_equal(cid, want_cid) and np.array_equal(order, want_order)
+    assert st.n_multi == n_pairs and cid[hub] == hub          # 1,500 pair clusters; the hub joins none of them
+
+
 def test_greedy_crash_parity_on_gpu(gpu, blosum62):
     ctx, _, _ = ctx_for(blosum62, ["WWWWWWWW", "CCCCCCCC", "PPPPPPPP", "GGGGGGGG"])
     with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
