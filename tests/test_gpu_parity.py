@@ -582,6 +582,25 @@ def test_greedy_full_size_1e5_vs_oracle(gpu, blosum62, coracle):
     assert stats.n_multi == 2500 and stats.phase1_stop_index == ostats.phase1_stop_index
 
 
+def test_greedy_full_size_mixed_lengths_1e5_vs_oracle(gpu, blosum62, coracle):
+    """BASELINE config 4a's input end to end: 10^5 peptides of length 7..20 with counts, shift penalty -1 --
+    identical cluster membership (plane kernels, row-bound split, device pre-check, overlapped copy)."""
+    n = 100000
+    res, off = synth_peptides(1, n, 7, 20)
+    rng = np.random.default_rng(1)
+    sizes = np.ones(n, dtype=np.int32)
+    sizes[::4] = 1 + rng.integers(0, 64, size=len(sizes[::4]))
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [res[off[k]:off[k + 1]] for k in perm]
+    sizes = sizes[perm]
+    res, off = hammock_amd.pack_sequences(peps)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
+    cid, order, stats = ctx.greedy_cluster(3, -1, 23, 2500)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, 3, -1, 23, 2500, 16)
+    assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert stats.phase1_stop_index == ostats.phase1_stop_index
+
+
 def test_million_peptide_shard_properties(gpu, blosum62, coracle):
     """BASELINE config 5 size (10^6 x 12), one of 8 row-block shards: pair count, density, sampled oracle parity."""
     n = 1000000
