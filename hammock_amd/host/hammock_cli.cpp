@@ -353,6 +353,21 @@ int main(int argc, char **argv) {
     try {
         if (args[0] == "greedy") return runGreedy(args);
         if (args[0] == "io-selftest") return ioSelftest(args);
+        if (args[0] == "dump-matrix") {   // the default matrix in the text format FileIOManager.loadScoringMatrix reads
+            std::cout << "# BLOSUM62 substitution matrix (public NCBI table), 24 x 24, order " << AMINO_ACIDS << "\n"
+                      << "# default of hammock-hip greedy (-m), same text format Hammock's -m files use\n  ";
+            for (int c = 0; c < 24; c++) std::cout << "  " << AMINO_ACIDS[c];
+            std::cout << "\n";
+            for (int r = 0; r < 24; r++) {
+                std::cout << AMINO_ACIDS[r];
+                for (int c = 0; c < 24; c++) {
+                    const std::string v = std::to_string(BLOSUM62[r][c]);
+                    std::cout << std::string(3 - v.size(), ' ') << v;
+                }
+                std::cout << "\n";
+            }
+            return 0;
+        }
         if (args[0] == "api-selftest") return apiSelftest(args);
         std::cerr << "hammock-hip implements Hammock's `greedy` mode only (modes full, clinkage, cluster are outside "
                      "the scope of the MI355X hot path); got mode \"" << args[0] << "\"\n";
