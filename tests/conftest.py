@@ -13,6 +13,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The product refuses to import without its in-tree library.  On a checkout that has not been built yet
+    # (the .so files are not in git) build it the way __graft_entry__.build() does, before test modules import it.
+    lib = os.path.join(ROOT, "hammock_amd", "lib", "libhammock_hip.so")
+    cli = os.path.join(ROOT, "hammock_amd", "bin", "hammock-hip")
+    if not (os.path.exists(lib) and os.path.exists(cli)):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "hammock_amd", "csrc"), "-j4"], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
