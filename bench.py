@@ -94,6 +94,14 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if not os.path.exists(os.path.join(ROOT, "hammock_amd", "lib", "libhammock_hip.so")):
+        # a tree without the built library (the .so is not in git): build it once, rank 0 of the node first
+        import subprocess
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "hammock_amd", "csrc"), "-j4"], stdout=subprocess.DEVNULL)
+        else:
+            while not os.path.exists(os.path.join(ROOT, "hammock_amd", "bin", "hammock-hip")):
+                time.sleep(1.0)
     import hammock_amd
     from hammock_amd import _native
     from hammock_amd import dist as hd
