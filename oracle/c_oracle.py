@@ -65,7 +65,7 @@ def lib():
         L.hmo_score_pairs.argtypes = [p32, p8, pu32, pu32, pu32, C.c_uint64, C.c_int, C.c_int, C.c_int, p32]
         L.hmo_score_pairs.restype = C.c_int
         L.hmo_greedy_cluster.argtypes = [p32, p8, pu32, p32, C.c_uint32, C.c_int, C.c_int, C.c_int,
-                                         C.c_int, C.c_int, C.c_int, p32, p32, C.POINTER(GreedyStats)]
+                                         C.c_int, C.c_int, C.c_int, p32, p32, p32, C.POINTER(GreedyStats)]
         L.hmo_greedy_cluster.restype = C.c_int
         L.hmo_sort_order.argtypes = [p8, pu32, p32, C.c_uint32, C.c_int, pu32]
         L.hmo_sort_order.restype = C.c_int
@@ -151,20 +151,23 @@ def score_block(M, res, off, rows, cols, scorer, a, b):
 
 
 def greedy_cluster(M, res, off, size, scorer, a, b, threshold, max_clusters, n_threads=1):
-    """-> (status, cluster_id[n], result_order[n_result], stats)"""
+    """-> (status, cluster_id[n], result_order[n_result], stats); stats.member_rank[n] = position of every
+    sequence inside Cluster.getSequences() of its cluster (insertion order)"""
     L = lib()
     M = as_matrix(M)
     n = len(off) - 1
     cid = np.full(max(n, 1), -1, dtype=np.int32)
     order = np.full(max(n, 1), -1, dtype=np.int32)
     stats = GreedyStats()
-    sp = _p(np.ascontiguousarray(size, dtype=np.int32), C.c_int32) if size is not None else None
+    rank = np.zeros(max(n, 1), dtype=np.int32)
+    sp = None
     if size is not None:
         size = np.ascontiguousarray(size, dtype=np.int32)
         sp = _p(size, C.c_int32)
     st = L.hmo_greedy_cluster(_p(M, C.c_int32), _p(res, C.c_uint8), _p(off, C.c_uint32), sp, n, scorer, a, b,
                               threshold, max_clusters, n_threads, _p(cid, C.c_int32), _p(order, C.c_int32),
-                              C.byref(stats))
+                              _p(rank, C.c_int32), C.byref(stats))
+    stats.member_rank = rank[:n]
     return st, cid[:n], order[:stats.n_result_clusters], stats
 
 

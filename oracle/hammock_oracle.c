@@ -381,7 +381,8 @@ int hmo_greedy_cluster(const int32_t *M, const uint8_t *res,
                        const uint32_t *off, const int32_t *size, uint32_t n,
                        int scorer, int a, int b, int threshold,
                        int max_clusters, int n_threads, int32_t *cluster_id,
-                       int32_t *result_order, hmo_greedy_stats *stats) {
+                       int32_t *result_order, int32_t *member_rank,
+                       hmo_greedy_stats *stats) {
     hmo_greedy_stats local;
     if (!stats) stats = &local;
     memset(stats, 0, sizeof(*stats));
@@ -512,14 +513,19 @@ int hmo_greedy_cluster(const int32_t *M, const uint8_t *res,
     {
         int64_t k_out = 0;
         for (int64_t k = 0; k < nc; k++) {
-            for (int32_t m = 0; m < clusters[k]->n; m++)
+            for (int32_t m = 0; m < clusters[k]->n; m++) {
                 cluster_id[clusters[k]->members[m]] = clusters[k]->id;
+                /* Cluster.getSequences() order = insertion order (Cluster.java:50-74) */
+                if (member_rank) member_rank[clusters[k]->members[m]] = m;
+            }
             if (result_order) result_order[k_out] = clusters[k]->id;
             k_out++;
         }
         for (int64_t k = 0; k < nr; k++) {
-            for (int32_t m = 0; m < remaining[k]->n; m++)
+            for (int32_t m = 0; m < remaining[k]->n; m++) {
                 cluster_id[remaining[k]->members[m]] = remaining[k]->id;
+                if (member_rank) member_rank[remaining[k]->members[m]] = m;
+            }
             if (result_order) result_order[k_out] = remaining[k]->id;
             k_out++;
         }

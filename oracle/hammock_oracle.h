@@ -89,12 +89,18 @@ typedef struct {
  *   cluster_id : out, [n]  id (= seed index) of the cluster holding seq k
  *   result_order: out, [n] ids of the returned clusters in list order
  *                (first stats->n_result_clusters entries are valid)
+ *   member_rank: out, [n] or NULL: position of sequence k inside
+ *                Cluster.getSequences() of its cluster = insertion order
+ *                (Cluster.java:50-74; seed first, then the sequence absorbed
+ *                at LimitedGreedySequenceClusterer.java:99-101/108-110, then
+ *                the insertAll calls of :97, :104 and :62 in time order)
  */
 int hmo_greedy_cluster(const int32_t *M, const uint8_t *res,
                        const uint32_t *off, const int32_t *size, uint32_t n,
                        int scorer, int a, int b, int threshold,
                        int max_clusters, int n_threads, int32_t *cluster_id,
-                       int32_t *result_order, hmo_greedy_stats *stats);
+                       int32_t *result_order, int32_t *member_rank,
+                       hmo_greedy_stats *stats);
 
 /* UniqueSequence.java:176-203 for order "size" / "alphabetic" / "input":
  * writes the permutation (perm[k] = input index of the k-th sequence in

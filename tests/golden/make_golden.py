@@ -142,6 +142,7 @@ def main():
         json.dump({"note": "produced by oracle/hammock_oracle.c, NOT by the Java reference",
                    "threshold": thr, "max_shift": X, "max_clusters": maxc,
                    "order": strings, "cluster_id": cid.tolist(), "result_order": order.tolist(),
+                   "member_rank": stats.member_rank.tolist(),
                    "score_calls_phase1": int(stats.score_calls_phase1),
                    "score_calls_phase2": int(stats.score_calls_phase2),
                    "phase1_stop_index": int(stats.phase1_stop_index)}, fh, separators=(",", ":"))

@@ -266,6 +266,12 @@ def test_greedy_musi_matches_oracle_pin(gpu, blosum62):
             cid[index[id(s)]] = c.getId()
     assert cid.tolist() == pin["cluster_id"]
     assert clusterer.stats.phase1_stop_index == pin["phase1_stop_index"]
+    # Cluster.getSequences() order (insertion order, Cluster.java:50-74): ClustalRunner.java:84 reads get(0)
+    rank = np.empty(len(seqs), dtype=np.int64)
+    for c in clusters:
+        for pos, s in enumerate(c.getSequences()):
+            rank[index[id(s)]] = pos
+    assert rank.tolist() == pin["member_rank"]
 
 
 @pytest.mark.parametrize("cfg", [(1, 10000, 12, 12, 0, 0), (2, 6000, 7, 20, -1, 0), (2, 6000, 7, 20, -1, -7),
@@ -293,6 +299,7 @@ def test_greedy_synthetic_vs_oracle(gpu, blosum62, coracle, cfg):
     assert st == 0
     cid, order, stats = ctx.greedy_cluster(X, p, thr, maxc)
     assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)   # insertion order inside every cluster
     assert stats.phase1_stop_index == ostats.phase1_stop_index and stats.n_multi == ostats.n_multi
 
 
@@ -311,6 +318,7 @@ def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
         assert st == 0
         cid, order, stats = ctx.greedy_cluster(3, 0, thr, 200)
         assert np.array_equal(cid, ocid) and np.array_equal(order, oorder), (thr, env)
+        assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)   # insertion order inside every cluster
         if M is not blosum62:
             edges, _ = ctx.neighbors_shifted(3, 0, thr)
             sc = hammock_amd.edge_fields(edges)[2]
@@ -336,6 +344,7 @@ def test_greedy_antibodies_example_vs_oracle(gpu, blosum62, coracle, tmp_path):
     ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
     cid, order, stats = ctx.greedy_cluster(X, 0, thr, maxc)
     assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)   # insertion order inside every cluster
     assert stats.phase1_stop_index == ostats.phase1_stop_index and stats.n_multi == maxc
 
 
@@ -518,6 +527,7 @@ def test_greedy_asymmetric_matrix_end_to_end(gpu, blosum62, coracle):
     assert st == 0
     cid, order, stats = ctx.greedy_cluster(3, -1, 17, 100)
     assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)   # insertion order inside every cluster
     assert stats.phase1_stop_index == ostats.phase1_stop_index
 
 
@@ -579,6 +589,7 @@ def test_greedy_full_size_1e5_vs_oracle(gpu, blosum62, coracle):
     cid, order, stats = ctx.greedy_cluster(3, 0, 20, 2500)
     st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, 3, 0, 20, 2500, 16)
     assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)   # insertion order inside every cluster
     assert stats.n_multi == 2500 and stats.phase1_stop_index == ostats.phase1_stop_index
 
 
@@ -598,6 +609,7 @@ def test_greedy_full_size_mixed_lengths_1e5_vs_oracle(gpu, blosum62, coracle):
     cid, order, stats = ctx.greedy_cluster(3, -1, 23, 2500)
     st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, 3, -1, 23, 2500, 16)
     assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)   # insertion order inside every cluster
     assert stats.phase1_stop_index == ostats.phase1_stop_index
 
 

@@ -78,6 +78,7 @@ def run_both(coracle, M, peps, sizes, X, p, thr, maxc):
     gcid, gorder, gstats = ctx.greedy_from_edges(edges, symmetric, thr, maxc)
     assert np.array_equal(gcid, cid)
     assert np.array_equal(gorder, order)
+    assert np.array_equal(ctx.member_rank[:len(cid)], stats.member_rank)   # Cluster.getSequences() insertion order
     assert gstats.phase1_stop_index == stats.phase1_stop_index
     assert gstats.phase1_clusters == stats.phase1_clusters
     assert gstats.phase1_orphans == stats.phase1_orphans

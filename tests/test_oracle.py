@@ -155,10 +155,13 @@ def _greedy_both(coracle, M, peps, sizes, X, p, thr, maxc, n_threads=1, scorer=0
     assert st == 0
     index_of = {id(s): k for k, s in enumerate(seqs)}
     py_cid = np.full(len(peps), -1, dtype=np.int32)
+    py_rank = np.full(len(peps), -1, dtype=np.int32)
     for c in result:
-        for s in c.sequences:
+        for pos, s in enumerate(c.sequences):
             py_cid[index_of[id(s)]] = c.id
+            py_rank[index_of[id(s)]] = pos
     assert np.array_equal(py_cid, cid)
+    assert np.array_equal(py_rank, stats.member_rank)   # Cluster.getSequences() insertion order, both restatements
     assert [c.id for c in result] == order.tolist()
     assert cl.stats["score_calls_phase1"] == stats.score_calls_phase1
     assert cl.stats["score_calls_phase2"] == stats.score_calls_phase2
