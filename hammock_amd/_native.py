@@ -29,7 +29,7 @@ SYMBOLS = [
     "hmk_score_pairs_shifted", "hmk_score_with_shift", "hmk_score_pairs_local", "hmk_score_block_shifted", "hmk_score_block_local",
     "hmk_neighbors_shifted", "hmk_neighbors_local", "hmk_neighbors_shifted_dev", "hmk_compact_edges_dev", "hmk_pack_rows_dev", "hmk_unpack_rows_dev",
     "hmk_neighbors_last_plan",
-    "hmk_greedy_cluster", "hmk_greedy_from_edges", "hmk_greedy_from_edges_dev",
+    "hmk_greedy_cluster", "hmk_greedy_from_edges", "hmk_greedy_from_edges_dev", "hmk_greedy_last_phases",
 ]
 
 
@@ -48,6 +48,16 @@ class GreedyStats(C.Structure):
         ("n_result_clusters", C.c_int32), ("n_multi", C.c_int32), ("reserved", C.c_int32),
         ("neighbors_ms", C.c_double), ("greedy_ms", C.c_double),
     ]
+
+
+class GreedyPhases(C.Structure):
+    """hmk_greedy_phases: where the time of the last greedy call went (milliseconds)."""
+    _fields_ = [(k, C.c_double) for k in ("plan_ms", "score_ms", "csr_ms", "wait_rows_ms", "phase1_ms", "precheck_ms", "prop_ms",
+                                          "device_loop_ms", "host_precheck_ms", "sequential_ms", "total_ms")] + \
+               [("cand_entries", C.c_uint64), ("prop_entries", C.c_uint64), ("loop_rounds", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 def _load():
@@ -91,6 +101,7 @@ def _load():
     L.hmk_greedy_cluster.argtypes = [vp, i32, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
     L.hmk_greedy_from_edges_dev.argtypes = [vp, vp, u64, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
     L.hmk_greedy_from_edges.argtypes = [vp, p_u64, u64, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
+    L.hmk_greedy_last_phases.argtypes = [vp, C.POINTER(GreedyPhases)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if name not in ("hmk_destroy", "hmk_last_error", "hmk_last_kernel_ms"):

@@ -209,7 +209,7 @@ class Context:
             buf = np.empty(max(cap, 1), dtype=np.uint64)
             st = N.lib.hmk_neighbors_shifted(self._h, int(max_shift), int(shift_penalty), int(threshold), part, n_parts,
                                              _ptr(buf, C.c_uint64), cap, C.byref(n_edges), C.byref(stats))
-            if st == N.HMK_ERR_CAPACITY and capacity is None:
+            if st == N.HMK_ERR_CAPACITY and capacity is None and int(n_edges.value) > cap:
                 cap = int(n_edges.value)
                 continue
             if st:
@@ -225,7 +225,7 @@ class Context:
             buf = np.empty(max(cap, 1), dtype=np.uint64)
             st = N.lib.hmk_neighbors_local(self._h, int(gap_open), int(gap_extend), int(threshold), part, n_parts,
                                            _ptr(buf, C.c_uint64), cap, C.byref(n_edges), C.byref(stats))
-            if st == N.HMK_ERR_CAPACITY and capacity is None:
+            if st == N.HMK_ERR_CAPACITY and capacity is None and int(n_edges.value) > cap:
                 cap = int(n_edges.value)
                 continue
             if st:
@@ -279,6 +279,14 @@ class Context:
         if st:
             self._raise(st, stats)
         return cid[:self.n], order[:stats.n_result_clusters], stats
+
+    def greedy_phases(self):
+        """hmk_greedy_last_phases: per-phase milliseconds of the last greedy_cluster / greedy_from_edges_dev call."""
+        ph = N.GreedyPhases()
+        st = N.lib.hmk_greedy_last_phases(self._h, C.byref(ph))
+        if st:
+            self._raise(st)
+        return ph.as_dict()
 
     def greedy_from_edges(self, edges, symmetric, threshold, max_clusters):
         edges = np.ascontiguousarray(edges, dtype=np.uint64)

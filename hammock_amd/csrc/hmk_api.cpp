@@ -28,12 +28,27 @@ struct Group {
     int nw;
     int lbk;  // column-length capacity of the kernel instantiation
     uint32_t base, count;
+    uint32_t band;  // the first `band` tiles of the group touch a "band" row (caller index < Plan::band_rows)
+};
+
+// grow-only device scratch of the greedy tail (one hipMalloc per buffer and context, not per call)
+struct DevBuf { void *p = nullptr; size_t cap = 0; };
+enum {
+    SB_DEG, SB_UP, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ,                       // full CSR
+    SB_BDEG, SB_BUP, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
+    SB_COF, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
+    SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
+    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
+    SB_PEER, SB_PEERCNT,                                                                  // edge blocks gathered from other devices
+    SB_N
 };
 
 struct Plan {
     bool valid = false;
     int X = 0, p = 0, thr = 0;
     uint32_t part = 0, n_parts = 1;
+    uint32_t band_rows = 0;   // tiles touching caller indices below this come first in every group (0: no band)
+    int64_t band_req = 0;     // what the caller asked for (the plan may have had to drop the band)
     int lbmax = 12, lpad = 16;
     bool exact = false;
     int hot_variant = 7;
@@ -90,17 +105,22 @@ struct hmk_ctx {
     static constexpr int N_SIDE = 3;
     hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr, nullptr, nullptr};
-    // chunked device-to-host copy of the adjacency (hmk_greedy_cluster): stream and events are made once
-    static constexpr int COPY_CHUNKS = 32;
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t chunk_done[COPY_CHUNKS] = {nullptr};
+    hipStream_t copy_stream = nullptr;   // band CSR + device-to-host copies of adjacency rows (hmk_greedy_cluster)
     uint32_t *d_rows_scratch = nullptr;  // deg[n], cursor[n], misfit of hmk_pack_rows_dev
     uint32_t d_rows_scratch_n = 0;
 
     double last_kernel_ms = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    void *h_csr = nullptr;  // pinned staging of the CSR adjacency (hmk_greedy_cluster)
-    size_t h_csr_cap = 0;
+    // greedy tail: own stream + events, grow-only device scratch, pinned host staging (all made once per context)
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_band = nullptr, ev_edges = nullptr, ev_csr = nullptr, ev_bandcsr = nullptr;
+    DevBuf sb[SB_N];
+    void *h_start = nullptr;  // pinned: uint64 start[n + 1], then uint32 up[n]
+    size_t h_start_cap = 0;
+    void *h_adj = nullptr;    // pinned: adjacency rows fetched so far
+    size_t h_adj_cap = 0;
+    unsigned long long *h_counts = nullptr;  // pinned: final segment counts [16], band snapshot [16], misc [8]
+    hmk_greedy_phases phases{};
 
     std::string err;
     std::mutex mu;
@@ -193,11 +213,17 @@ void classify(const hmk_ctx *ctx, int la, int lb, int X, int p, int thr, TileCla
     *out = c;
 }
 
-int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts) {
+// band_rows: tiles that touch a sequence with caller index < band_rows are put first in every launch group, so that a
+// first launch of only those tiles completes the adjacency rows phase 1 of the greedy merge reads first
+// (hmk_greedy_cluster); -1 = the caller does not care (any cached plan with the other parameters will do).
+int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, int64_t band_rows = -1) {
     Plan &pl = ctx->plan;
-    if (pl.valid && pl.X == X && pl.p == p && pl.thr == thr && pl.part == part && pl.n_parts == n_parts)
+    if (pl.valid && pl.X == X && pl.p == p && pl.thr == thr && pl.part == part && pl.n_parts == n_parts &&
+        (band_rows < 0 || pl.band_req == band_rows))
         return HMK_OK;
     free_plan(pl);
+    if (band_rows < 0) band_rows = 0;
+    const int64_t band_req = band_rows;
     const bool plan_timing = getenv("HMK_PLAN_TIMING") != nullptr;
     const auto plan_t0 = std::chrono::steady_clock::now();
     auto plan_lap = [&](const char *what) {
@@ -278,6 +304,17 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         bound_sorted.resize(n);
         for (uint32_t q = 0; q < n; q++) bound_sorted[q] = bound[perm[q]];
     }
+    // band members of a length bucket are its leading sorted positions (the counting sort keeps caller order); a
+    // bucket reordered by score bound has no such prefix, so the band is dropped there (phase 1 then waits for the pass)
+    uint32_t band_end[HMK_MAX_LEN + 2];
+    if (refine || n_parts != 1) band_rows = 0;
+    for (int l = 0; l <= HMK_MAX_LEN; l++) {
+        band_end[l] = bucket[l];
+        if (band_rows > 0)
+            while (band_end[l] < bucket[l + 1] && perm[band_end[l]] < (uint64_t)band_rows) band_end[l]++;
+    }
+    pl.band_rows = (uint32_t)band_rows;
+    pl.band_req = band_req;
     plan_lap("buckets and score bounds");
     pl.lbmax = swar_lbmax_for(ctx->max_len);
     pl.lpad = ctx->max_len <= 16 ? 16 : 32;
@@ -394,6 +431,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                         }
                         if (pairs == 0) continue;
                         S.pairs_scored += pairs;
+                        t.pad0 = (r0 < band_end[la] || c0 < band_end[lb]) ? 1u : 0u;   // band tile (host-side flag)
                         dst.push_back(t);
                     }
                 }
@@ -405,12 +443,18 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     for (auto &kv : grouped) {
         if (kv.second.empty()) continue;
         // workgroups are dispatched in tile order: biggest tiles first keeps the tail of the launch short
+        // (band tiles first: they are launched on their own by hmk_greedy_cluster)
         if (getenv("HMK_NO_LPT") == nullptr)
             std::stable_sort(kv.second.begin(), kv.second.end(), [](const Tile &a, const Tile &b) {
+                if (a.pad0 != b.pad0) return a.pad0 > b.pad0;
                 return (uint64_t)a.nrows * a.ncols > (uint64_t)b.nrows * b.ncols;
             });
+        else
+            std::stable_sort(kv.second.begin(), kv.second.end(), [](const Tile &a, const Tile &b) { return a.pad0 > b.pad0; });
+        uint32_t n_band = 0;
+        for (const Tile &t : kv.second) n_band += t.pad0;
         pl.groups.push_back(Group{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),
-                                  (uint32_t)tiles.size(), (uint32_t)kv.second.size()});
+                                  (uint32_t)tiles.size(), (uint32_t)kv.second.size(), n_band});
         tiles.insert(tiles.end(), kv.second.begin(), kv.second.end());
     }
     S.n_tiles = (uint32_t)tiles.size();
@@ -449,16 +493,21 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     return HMK_OK;
 }
 
+// which: LAUNCH_ALL, or only the band tiles of the plan (LAUNCH_BAND: also zeroes the counts) / only the others
+// (LAUNCH_REST: appends to the counts of the band launch)
+enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2 };
 int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
-                         uint64_t capacity, void *d_counts, hipStream_t stream) {
+                         uint64_t capacity, void *d_counts, hipStream_t stream, int which = LAUNCH_ALL,
+                         int64_t band_rows = -1) {
     int st = need_device(ctx);
     if (st) return st;
     if (!d_edges || !d_counts || capacity < HMK_EDGE_SHARDS)
         return fail(ctx, HMK_ERR_BAD_ARG, "d_edges/d_counts must be device buffers, capacity >= HMK_EDGE_SHARDS");
-    st = build_plan(ctx, X, p, thr, part, n_parts);
+    st = build_plan(ctx, X, p, thr, part, n_parts, band_rows);
     if (st) return st;
     Plan &pl = ctx->plan;
-    HIPCHK(ctx, hipMemsetAsync(d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), stream));
+    if (which != LAUNCH_REST)
+        HIPCHK(ctx, hipMemsetAsync(d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), stream));
     NeighborParams P{};
     P.res_sorted = pl.d_res_sorted;
     P.perm = pl.d_perm;
@@ -495,10 +544,12 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     for (const Group *gp : order) {
         const Group &g = *gp;
         hipStream_t s = fork ? ctx->side[q++ % hmk_ctx::N_SIDE] : stream;
+        const uint32_t t0 = which == LAUNCH_REST ? g.base + g.band : g.base;
+        const uint32_t cnt = which == LAUNCH_ALL ? g.count : which == LAUNCH_BAND ? g.band : g.count - g.band;
         if (g.path == PATH_DIRECT)
-            HIPCHK(ctx, launch_neighbors_direct(P, g.base, g.count, ctx->d_M, X, p, thr, s));
+            HIPCHK(ctx, launch_neighbors_direct(P, t0, cnt, ctx->d_M, X, p, thr, s));
         else
-            HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, g.base, g.count, s));
+            HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, t0, cnt, s));
     }
     if (fork)
         for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
@@ -555,7 +606,7 @@ int neighbors_grow(hmk_ctx *ctx, uint64_t want_cap, unsigned long long counts[HM
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (st == HMK_ERR_CAPACITY) return fail(ctx, st, "internal edge buffer kept overflowing");
+    if (st == HMK_ERR_CAPACITY) return fail(ctx, HMK_ERR_DEVICE, "internal edge buffer kept overflowing");
     return st;
 }
 
@@ -852,14 +903,19 @@ void hmk_destroy(hmk_ctx *ctx) {
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
         if (ctx->d_rows_scratch) (void)hipFree(ctx->d_rows_scratch);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-        for (int c = 0; c < hmk_ctx::COPY_CHUNKS; c++)
-            if (ctx->chunk_done[c]) (void)hipEventDestroy(ctx->chunk_done[c]);
         for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
             if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
             if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
         }
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-        if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
+        if (ctx->h_start) (void)hipHostFree(ctx->h_start);
+        if (ctx->h_adj) (void)hipHostFree(ctx->h_adj);
+        if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+        for (int b = 0; b < SB_N; b++)
+            if (ctx->sb[b].p) (void)hipFree(ctx->sb[b].p);
+        if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
+        for (hipEvent_t ev : {ctx->ev_t0, ctx->ev_band, ctx->ev_edges, ctx->ev_csr, ctx->ev_bandcsr})
+            if (ev) (void)hipEventDestroy(ev);
         if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
         if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     }
@@ -1097,191 +1153,470 @@ int hmk_greedy_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges,
     return HMK_OK;
 }
 
-// Tail shared by hmk_greedy_cluster and hmk_greedy_from_edges_dev: packed edges on the device (HMK_EDGE_SHARDS
-// segments of `seg` entries with their counts) -> CSR on the device -> pinned D2H -> host greedy merge.
-static int cluster_from_device_edges(hmk_ctx *ctx, const uint64_t *d_edges, uint64_t seg, const unsigned long long *d_counts,
-                                     uint64_t total, bool symmetric, int max_clusters, int32_t *cluster_id,
-                                     int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats,
-                                     std::chrono::steady_clock::time_point t0) {
-    // edge segments -> CSR on the device, then ONE pinned D2H of start[] and adj[]
+// =============================================================================
+// greedy clustering on a device-resident neighbour graph
+// =============================================================================
+}  // extern "C"
+
+namespace {
+
+constexpr int ST_RETRY_OVERFLOW = 1000;   // internal: an edge segment overflowed, grow the buffer and score again
+
+hipError_t ensure_buf(hmk_ctx *ctx, int which, size_t bytes) {
+    DevBuf &b = ctx->sb[which];
+    if (b.cap >= bytes) return hipSuccess;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 8 + 256;
+    const hipError_t e = hipMalloc(&b.p, want);
+    if (e == hipSuccess) b.cap = want;
+    return e;
+}
+template <class T> T *buf(hmk_ctx *ctx, int which) { return (T *)ctx->sb[which].p; }
+
+// pinned host buffer, grow-only; the first `keep` bytes survive a reallocation
+hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes, size_t keep) {
+    if (*cap >= bytes) return hipSuccess;
+    void *q = nullptr;
+    const size_t want = bytes + bytes / 4 + (1 << 20);
+    const hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
+    if (e != hipSuccess) return e;
+    if (*p) {
+        if (keep) std::memcpy(q, *p, keep);
+        (void)hipHostFree(*p);
+    }
+    *p = q;
+    *cap = want;
+    return hipSuccess;
+}
+
+int greedy_streams(hmk_ctx *ctx) {
+    if (ctx->gstream) return HMK_OK;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking));
+    // the band hand-over runs while the rest of the pair space is being scored: its small kernels must not queue behind
+    // the thousands of workgroups of that launch, so its stream gets the highest priority
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_hi));
+    for (hipEvent_t *ev : {&ctx->ev_t0, &ctx->ev_band, &ctx->ev_edges, &ctx->ev_csr, &ctx->ev_bandcsr}) HIPCHK(ctx, hipEventCreate(ev));
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+    return HMK_OK;
+}
+
+// Where the edges of one greedy call are, and what is already known about them.  Everything the caller enqueued
+// (scoring, snapshots) is on ctx->gstream; ev_edges has been recorded there after the last edge was written.
+struct EdgeSource {
+    EdgeSegs segs{};
+    bool symmetric = true;
+    bool check_overflow = false;       // segs are the HMK_EDGE_SHARDS segments of a neighbour pass: h_counts[0..16) receives
+    uint64_t seg_cap = 0;              // their counts (copied on gstream before ev_edges); a count above seg_cap = overflow
+    bool format_known = false;         // adjacency entry format decided without looking at the edges
+    bool packed = false;
+    int base = 0;
+    uint64_t adj_bound = 0;            // upper bound of the adjacency entries (format_known only)
+    uint64_t total_known = 0;          // exact number of edges, if known (else 0)
+    uint32_t band_rows = 0;            // rows [0, band_rows) are complete in band_segs once ev_band has passed
+    EdgeSegs band_segs{};
+};
+
+// Builds the CSR adjacency on the device, hands rows to the host merge on demand, runs the merge.
+int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int32_t *cluster_id, int32_t *result_order,
+                      int32_t *member_rank, hmk_greedy_stats *stats, std::chrono::steady_clock::time_point t0) {
     const uint32_t n = ctx->n;
-    const uint64_t n_adj = symmetric ? 2 * total : total;
-    uint32_t *d_deg = nullptr, *d_cursor = nullptr, *d_up = nullptr;
-    uint64_t *d_start = nullptr, *d_tiles = nullptr;
-    int *d_range = nullptr;
-    void *d_adj = nullptr;
-    auto cleanup = [&]() {
-        if (d_tiles) (void)hipFree(d_tiles);
-        if (d_up) (void)hipFree(d_up);
-        if (d_deg) (void)hipFree(d_deg);
-        if (d_cursor) (void)hipFree(d_cursor);
-        if (d_start) (void)hipFree(d_start);
-        if (d_range) (void)hipFree(d_range);
-        if (d_adj) (void)hipFree(d_adj);
+    hipStream_t S = ctx->gstream, C = ctx->copy_stream;
+    hmk_greedy_phases &ph = ctx->phases;
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
     };
     const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;
     auto lap = [&](const char *what) {
-        if (!timing) return;
-        (void)hipDeviceSynchronize();
-        fprintf(stderr, "[hmk greedy] %s at %.2f ms\n", what,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        if (timing) fprintf(stderr, "[hmk greedy] %s at %.2f ms\n", what, ms_since(t0));
     };
-    lap("neighbour pass (plan + kernels + counts)");
-    hipError_t e = hipMalloc((void **)&d_deg, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, (size_t)n * 8);   // two cursors per row (upper / lower section)
-    if (e == hipSuccess) e = hipMalloc((void **)&d_up, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_start, ((size_t)n + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_tiles, scan_scratch_bytes(n));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_range, 3 * sizeof(int));
-    if (e == hipSuccess) e = hipMemsetAsync(d_deg, 0, (size_t)n * 4, nullptr);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, (size_t)n * 8, nullptr);
-    if (e == hipSuccess) e = hipMemsetAsync(d_up, 0, (size_t)n * 4, nullptr);
-    if (e == hipSuccess) e = launch_csr_degree_scan(d_edges, seg, d_counts, n, symmetric, d_deg, d_up, d_start, d_tiles,
-                                                   d_range, nullptr);
-    // 4-byte adjacency entries (m << 8 | score - lowest score) when the scores span at most 255
-    int range[3] = {0, 0, 0};
-    if (e == hipSuccess) e = hipMemcpy(range, d_range, sizeof(range), hipMemcpyDeviceToHost);
-    if (e == hipSuccess && range[2] != 0) {
-        cleanup();
-        return fail(ctx, HMK_ERR_BAD_ARG, "edge list references a sequence outside [0, n) or a self pair");
+    bool packed = src.packed;
+    int base = src.base;
+    size_t esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
+    const bool symmetric = src.symmetric;
+
+    // ---- full CSR on the device, enqueued behind the scoring on S ---------------------------------------
+    HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_UP, (size_t)n * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
+    HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
+    HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
+    HIPCHK(ctx, ensure_buf(ctx, SB_RANGE, 64));
+    if (src.format_known) HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(src.adj_bound, 1) * esz));
+    HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, ((size_t)n + 1) * 8 + (size_t)n * 4 + 64, 0));
+    uint64_t *h_start = (uint64_t *)ctx->h_start;
+    uint32_t *h_up = (uint32_t *)((char *)ctx->h_start + ((size_t)n + 1) * 8);
+    int *h_range = (int *)(ctx->h_counts + 40);
+
+    HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_DEG), 0, (size_t)n * 4, S));
+    HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_UP), 0, (size_t)n * 4, S));
+    HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S));
+    HIPCHK(ctx, launch_csr_degree_scan(src.segs, n, n, symmetric, buf<uint32_t>(ctx, SB_DEG), buf<uint32_t>(ctx, SB_UP),
+                                       buf<uint64_t>(ctx, SB_START), buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S));
+    HIPCHK(ctx, hipMemcpyAsync(h_range, buf<int>(ctx, SB_RANGE), 3 * sizeof(int), hipMemcpyDeviceToHost, S));
+    HIPCHK(ctx, hipMemcpyAsync(&h_start[n], buf<uint64_t>(ctx, SB_START) + n, 8, hipMemcpyDeviceToHost, S));
+    bool scatter_enqueued = false;
+    auto enqueue_scatter = [&]() -> hipError_t {
+        scatter_enqueued = true;
+        hipError_t e = launch_csr_scatter(src.segs, symmetric, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_UP),
+                                          buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ), packed, base, n, S);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
+        return e;
+    };
+    if (src.format_known) HIPCHK(ctx, enqueue_scatter());
+
+    // ---- band: the first rows' adjacency from the edges of the band launch, on the copy stream --------------
+    uint32_t rows_here = 0;          // rows [0, rows_here) are valid in h_start / h_adj
+    bool band_pending = false, band_used = false;
+    const uint32_t R1 = src.band_rows;
+    if (R1 > 0 && src.format_known) {
+        HIPCHK(ctx, ensure_buf(ctx, SB_BDEG, (size_t)R1 * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BUP, (size_t)R1 * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BCURSOR, (size_t)R1 * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BSTART, ((size_t)R1 + 1) * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(R1)));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
+        HIPCHK(ctx, hipStreamWaitEvent(C, ctx->ev_band, 0));
+        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BDEG), 0, (size_t)R1 * 4, C));
+        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BUP), 0, (size_t)R1 * 4, C));
+        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BCURSOR), 0, (size_t)R1 * 8, C));
+        HIPCHK(ctx, launch_csr_degree_scan(src.band_segs, n, R1, symmetric, buf<uint32_t>(ctx, SB_BDEG), buf<uint32_t>(ctx, SB_BUP),
+                                           buf<uint64_t>(ctx, SB_BSTART), buf<uint64_t>(ctx, SB_BSCAN), buf<int>(ctx, SB_BRANGE), C));
+        HIPCHK(ctx, hipMemcpyAsync(h_start, buf<uint64_t>(ctx, SB_BSTART), ((size_t)R1 + 1) * 8, hipMemcpyDeviceToHost, C));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + 16, src.band_segs.s[0].count, HMK_EDGE_SHARDS * sizeof(unsigned long long),
+                                   hipMemcpyDeviceToHost, C));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_bandcsr, C));
+        band_pending = true;
     }
-    const bool packed = total == 0 || ((long long)range[1] - range[0] <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr);
-    const size_t esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
-    if (e == hipSuccess) e = hipMalloc(&d_adj, std::max<uint64_t>(n_adj, 1) * esz);
-    if (e == hipSuccess) e = launch_csr_scatter(d_edges, seg, d_counts, symmetric, d_start, d_up, d_cursor, d_adj, packed,
-                                                range[0], n, nullptr);
-    lap("CSR build on the device");
-    const size_t up_bytes = ((size_t)n * 4 + 7) & ~(size_t)7;   // upper-neighbour counts, kept 8-byte aligned
-    if (e == hipSuccess && ctx->h_csr_cap < ((size_t)n + 1) * 8 + up_bytes + n_adj * esz) {
-        if (ctx->h_csr) (void)hipHostFree(ctx->h_csr);
-        ctx->h_csr = nullptr;
-        ctx->h_csr_cap = 0;
-        const size_t want = ((size_t)n + 1) * 8 + up_bytes + n_adj * esz + (1 << 20);
-        e = hipHostMalloc(&ctx->h_csr, want, hipHostMallocDefault);
-        if (e == hipSuccess) ctx->h_csr_cap = want;
-    }
-    uint64_t *h_start = (uint64_t *)ctx->h_csr;
-    uint32_t *h_up = (uint32_t *)((char *)ctx->h_csr + ((size_t)n + 1) * 8);
-    void *h_adj = (char *)h_up + up_bytes;
-    if (e == hipSuccess) e = hipMemcpy(h_start, d_start, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && symmetric) e = hipMemcpy(h_up, d_up, (size_t)n * 4, hipMemcpyDeviceToHost);
-    // the adjacency itself travels in chunks on a side stream; the merge waits for a chunk only when phase 1 (which
-    // walks the rows in order) or the second loop needs it
-    constexpr int COPY_CHUNKS = hmk_ctx::COPY_CHUNKS;
-    hipStream_t &copy_stream = ctx->copy_stream;
-    hipEvent_t *chunk_done = ctx->chunk_done;
-    uint64_t chunk_end[COPY_CHUNKS] = {0};   // entries [0, chunk_end[c]) have been queued up to chunk c
-    int n_chunks = 0;
-    auto drop_copy = [&]() {};               // stream and events live in the context
-    if (e == hipSuccess && n_adj) {
-        if (!copy_stream) {
-            e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
-            for (int c = 0; c < COPY_CHUNKS && e == hipSuccess; c++)
-                e = hipEventCreateWithFlags(&chunk_done[c], hipEventDisableTiming);
+    lap("scoring, CSR and band hand-over enqueued");
+
+    int status_inside = HMK_OK;   // failure inside a hook (the merge then stops with its own error)
+    std::string hook_err;
+    auto hook_fail = [&](int code, const std::string &msg) { status_inside = code; hook_err = msg; };
+
+    // the full CSR is complete (and trustworthy: no segment overflowed)
+    bool full_ready = false;
+    auto wait_full = [&]() -> bool {
+        if (full_ready) return true;
+        hipError_t e = hipEventSynchronize(ctx->ev_edges);
+        if (e == hipSuccess && src.check_overflow) {
+            for (int q = 0; q < HMK_EDGE_SHARDS; q++)
+                if (ctx->h_counts[q] > src.seg_cap) { hook_fail(ST_RETRY_OVERFLOW, "edge segment overflow"); return false; }
         }
-        if (e == hipSuccess) e = hipDeviceSynchronize();   // the scatter kernel (null stream) has written d_adj
-        // the first chunks are small (phase 1 starts on them at once), the rest split what remains evenly
-        const uint64_t first = std::min<uint64_t>(n_adj, (8u << 20) / esz);
-        const uint64_t per = std::max<uint64_t>((n_adj - first + COPY_CHUNKS - 2) / (COPY_CHUNKS - 1), (16u << 20) / esz);
-        for (uint64_t o = 0; o < n_adj && e == hipSuccess;) {
-            const uint64_t cnt = std::min(o == 0 ? first : per, n_adj - o);
-            e = hipMemcpyAsync((char *)h_adj + o * esz, (const char *)d_adj + o * esz, cnt * esz, hipMemcpyDeviceToHost, copy_stream);
-            if (e == hipSuccess) e = hipEventRecord(chunk_done[n_chunks], copy_stream);
-            o += cnt;
-            chunk_end[n_chunks++] = o;
+        if (e == hipSuccess && !scatter_enqueued) {
+            // the adjacency format depends on the scores found: 4-byte entries when they span at most 255
+            e = hipStreamSynchronize(S);
+            if (e == hipSuccess && h_range[2] != 0) {
+                hook_fail(HMK_ERR_BAD_ARG, "edge list references a sequence outside [0, n) or a self pair");
+                return false;
+            }
+            if (e == hipSuccess) {
+                packed = h_start[n] == 0 || ((long long)h_range[1] - h_range[0] <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr);
+                base = h_range[0];
+                esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
+                e = ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(h_start[n], 1) * esz);
+            }
+            if (e == hipSuccess) e = enqueue_scatter();
         }
-    }
-    lap("D2H of the adjacency queued");
-    if (e != hipSuccess) {
-        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
-        drop_copy();
-        cleanup();
-        return fail(ctx, e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,
-                    std::string("hmk_greedy_cluster (CSR build): ") + hipGetErrorString(e));
-    }
-    if (h_start[n] != n_adj) {
-        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
-        drop_copy();
-        cleanup();
-        return fail(ctx, HMK_ERR_DEVICE, "CSR build: adjacency size mismatch");
-    }
-    int chunks_waited = 0;
-    hipError_t copy_error = hipSuccess;
+        if (e == hipSuccess) e = hipEventSynchronize(ctx->ev_csr);
+        if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("CSR build: ") + hipGetErrorString(e)); return false; }
+        if (h_range[2] != 0) { hook_fail(HMK_ERR_BAD_ARG, "edge list references a sequence outside [0, n) or a self pair"); return false; }
+        const uint64_t want = src.total_known ? (symmetric ? 2 * src.total_known : src.total_known) : h_start[n];
+        if (h_start[n] != want) { hook_fail(HMK_ERR_DEVICE, "CSR build: adjacency size mismatch"); return false; }
+        full_ready = true;
+        lap("full CSR on the device");
+        return true;
+    };
+
     GreedyHooks hooks;
-    hooks.need_entries = [&](uint64_t upto) -> uint64_t {
-        while (chunks_waited < n_chunks && (chunks_waited == 0 || chunk_end[chunks_waited - 1] < upto)) {
-            const hipError_t r = hipEventSynchronize(chunk_done[chunks_waited]);
-            if (r != hipSuccess) copy_error = r;
-            chunks_waited++;
+    double t_rows = 0;   // host time spent waiting for rows
+    hooks.need_rows = [&](uint32_t k) -> uint32_t {
+        if (k < rows_here) return rows_here;
+        const auto tw = std::chrono::steady_clock::now();
+        hipError_t e = hipSuccess;
+        if (band_pending) {
+            band_pending = false;
+            e = hipEventSynchronize(ctx->ev_bandcsr);
+            bool ok = e == hipSuccess;
+            for (int q = 0; q < HMK_EDGE_SHARDS && ok; q++) ok = ctx->h_counts[16 + q] <= src.seg_cap;
+            if (ok) {
+                const uint64_t entries = h_start[R1];
+                e = ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz);
+                if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(entries, 1) * esz, 0);
+                if (e == hipSuccess)
+                    e = launch_csr_scatter(src.band_segs, symmetric, buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BUP),
+                                           buf<uint32_t>(ctx, SB_BCURSOR), buf<void>(ctx, SB_BADJ), packed, base, R1, C);
+                if (e == hipSuccess && entries)
+                    e = hipMemcpyAsync(ctx->h_adj, buf<void>(ctx, SB_BADJ), entries * esz, hipMemcpyDeviceToHost, C);
+                if (e == hipSuccess) e = hipStreamSynchronize(C);
+                if (e == hipSuccess) {
+                    rows_here = R1;
+                    band_used = true;
+                    lap("band rows on the host");
+                }
+            }
+            if (e != hipSuccess) { hook_fail(HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return 0; }
+            if (k < rows_here) { t_rows += ms_since(tw); return rows_here; }
         }
-        return chunks_waited ? chunk_end[chunks_waited - 1] : 0;
+        // more rows from the full CSR (which must be complete by now)
+        if (!wait_full()) return 0;
+        if (band_used) { rows_here = 0; band_used = false; }   // the band rows come again, in the full CSR's layout
+        uint32_t r_end = n;
+        if (k + 1 < n) r_end = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>({(uint64_t)k + 1, 2ull * rows_here, 8192ull}));
+        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
+        e = hipMemcpyAsync(h_start + rows_here, d_start + rows_here, ((size_t)(r_end - rows_here) + 1) * 8, hipMemcpyDeviceToHost, C);
+        if (e == hipSuccess && symmetric)
+            e = hipMemcpyAsync(h_up + rows_here, buf<uint32_t>(ctx, SB_UP) + rows_here, (size_t)(r_end - rows_here) * 4, hipMemcpyDeviceToHost, C);
+        if (e == hipSuccess) e = hipStreamSynchronize(C);
+        if (e == hipSuccess) {
+            const uint64_t a0 = h_start[rows_here], a1 = h_start[r_end];
+            e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(a1, 1) * esz, a0 * esz);
+            if (e == hipSuccess && a1 > a0)
+                e = hipMemcpyAsync((char *)ctx->h_adj + a0 * esz, (const char *)buf<void>(ctx, SB_ADJ) + a0 * esz, (a1 - a0) * esz,
+                                   hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipStreamSynchronize(C);
+        }
+        if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("adjacency copy: ") + hipGetErrorString(e)); return 0; }
+        rows_here = r_end;
+        t_rows += ms_since(tw);
+        return rows_here;
     };
-    // The adjacency stays on the device until the merge is through: the pre-check of its second loop (every leftover
-    // against every cluster) runs there, on d_start / d_adj, once the host has finished phase 1.
-    hooks.precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize,
-                                  const std::vector<uint32_t> &leftover, std::vector<uint32_t> &cand_start,
-                                  std::vector<GreedyCand> &cand) -> bool {
+
+    // ---- second loop on the device-resident CSR ---------------------------------------------------------------
+    // (1) pre-check (k_greedy_precheck): per leftover the clusters that are feasible after phase 1 -> cand CSR on the device.
+    // Then either (2a) small / medium inputs: join-propagation lists (k_greedy_prop), the sequential loop runs on the
+    // host over those lists; or (2b) large inputs: the loop itself runs on the device level by level (k_greedy_level).
+    bool pre_done = false;
+    uint32_t pre_total_c = 0;
+    auto device_precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<uint32_t> &leftover) -> bool {
+        if (pre_done) return true;
         if (getenv("HMK_HOST_PRECHECK")) return false;
+        if (!wait_full()) return false;
+        const auto tp = std::chrono::steady_clock::now();
         const uint32_t nl = (uint32_t)leftover.size();
-        int32_t *d_cof = nullptr, *d_usize = nullptr;
-        uint32_t *d_left = nullptr, *d_cnt = nullptr, *d_cstart = nullptr, *d_over = nullptr;
-        uint64_t *d_scan = nullptr;
-        GreedyCand *d_cand = nullptr;
-        auto drop = [&]() {
-            for (void *q : {(void *)d_cof, (void *)d_usize, (void *)d_left, (void *)d_cnt, (void *)d_cstart, (void *)d_over,
-                            (void *)d_scan, (void *)d_cand})
-                if (q) (void)hipFree(q);
-        };
-        hipError_t r = hipMalloc((void **)&d_cof, (size_t)n * 4);
-        if (r == hipSuccess) r = hipMalloc((void **)&d_usize, std::max<size_t>(usize.size(), 1) * 4);
-        if (r == hipSuccess) r = hipMalloc((void **)&d_left, (size_t)nl * 4);
-        if (r == hipSuccess) r = hipMalloc((void **)&d_cnt, (size_t)nl * 4);
-        if (r == hipSuccess) r = hipMalloc((void **)&d_cstart, ((size_t)nl + 1) * 4);
-        if (r == hipSuccess) r = hipMalloc((void **)&d_over, 4);
-        if (r == hipSuccess) r = hipMalloc((void **)&d_scan, scan_scratch_bytes(nl));
-        if (r == hipSuccess) r = hipMemcpy(d_cof, cluster_of, (size_t)n * 4, hipMemcpyHostToDevice);
-        if (r == hipSuccess) r = hipMemcpy(d_usize, usize.data(), usize.size() * 4, hipMemcpyHostToDevice);
-        if (r == hipSuccess) r = hipMemcpy(d_left, leftover.data(), (size_t)nl * 4, hipMemcpyHostToDevice);
-        if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 4, nullptr);
-        if (r == hipSuccess) r = hipMemsetAsync(d_cnt, 0, (size_t)nl * 4, nullptr);
+        hipError_t r = ensure_buf(ctx, SB_COF, (size_t)n * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_USIZE, std::max<size_t>(usize.size(), 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_LEFT, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CNT, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CSTART, ((size_t)nl + 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_OVER, 64);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>(nl, n)));
+        if (r != hipSuccess) return false;
+        int32_t *d_cof = buf<int32_t>(ctx, SB_COF), *d_usize = buf<int32_t>(ctx, SB_USIZE);
+        uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cnt = buf<uint32_t>(ctx, SB_CNT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
+        uint32_t *d_over = buf<uint32_t>(ctx, SB_OVER);
+        uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
+        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
+        const void *d_adj = buf<void>(ctx, SB_ADJ);
+        r = hipMemcpyAsync(d_cof, cluster_of, (size_t)n * 4, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(d_usize, usize.data(), usize.size() * 4, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(d_left, leftover.data(), (size_t)nl * 4, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 4, S);
+        if (r == hipSuccess) r = hipMemsetAsync(d_cnt, 0, (size_t)nl * 4, S);
         if (r == hipSuccess) r = launch_greedy_precheck(false, packed, d_start, d_adj, d_cof, d_usize, d_left, nl, d_cnt, nullptr,
-                                                        nullptr, d_over, nullptr);
-        if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, nullptr);
-        uint32_t over = 0;
-        if (r == hipSuccess) r = hipMemcpy(&over, d_over, 4, hipMemcpyDeviceToHost);
-        cand_start.assign((size_t)nl + 1, 0);
-        if (r == hipSuccess) r = hipMemcpy(cand_start.data(), d_cstart, ((size_t)nl + 1) * 4, hipMemcpyDeviceToHost);
-        if (r != hipSuccess || over != 0) { drop(); return false; }   // a row overflowed its hash table: host pre-check
-        const uint32_t total_c = cand_start[nl];
-        cand.resize(total_c);
-        if (total_c) {
-            r = hipMalloc((void **)&d_cand, (size_t)total_c * sizeof(GreedyCand));
+                                                        nullptr, d_over, S);
+        if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, S);
+        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + 48);
+        if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[1], d_cstart + nl, 4, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess) r = hipStreamSynchronize(S);
+        if (r != hipSuccess || h_misc[0] != 0) return false;   // a row overflowed its hash table: host pre-check
+        pre_total_c = h_misc[1];
+        if (pre_total_c) {
+            r = ensure_buf(ctx, SB_CAND, (size_t)pre_total_c * sizeof(GreedyCand));
             if (r == hipSuccess) r = launch_greedy_precheck(true, packed, d_start, d_adj, d_cof, d_usize, d_left, nl, d_cnt, d_cstart,
-                                                            d_cand, d_over, nullptr);
-            if (r == hipSuccess) r = hipMemcpy(cand.data(), d_cand, (size_t)total_c * sizeof(GreedyCand), hipMemcpyDeviceToHost);
+                                                            buf<GreedyCand>(ctx, SB_CAND), d_over, S);
+            if (r != hipSuccess) return false;
         }
-        drop();
+        pre_done = true;
+        ph.cand_entries = pre_total_c;
+        ph.precheck_ms = ms_since(tp);   // enqueue + count pass; the fill pass completes under the consumer's first wait
+        return true;
+    };
+    auto fetch_cand = [&](uint32_t nl, std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand) -> bool {
+        cand_start.assign((size_t)nl + 1, 0);
+        cand.resize(pre_total_c);
+        hipError_t r = hipMemcpyAsync(cand_start.data(), buf<uint32_t>(ctx, SB_CSTART), ((size_t)nl + 1) * 4, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess && pre_total_c)
+            r = hipMemcpyAsync(cand.data(), buf<GreedyCand>(ctx, SB_CAND), (size_t)pre_total_c * sizeof(GreedyCand), hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess) r = hipStreamSynchronize(S);
         return r == hipSuccess;
     };
-    const double nb_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const char *loop_mode = getenv("HMK_SECOND_LOOP");   // "device" / "lists" / "host": force one implementation (tests)
+    const bool force_device = loop_mode && std::strcmp(loop_mode, "device") == 0;
+    const bool forbid_device = loop_mode && !force_device;
+    const bool forbid_lists = loop_mode && std::strcmp(loop_mode, "lists") != 0;
+
+    hooks.device_loop = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<int64_t> &csize,
+                            const std::vector<int32_t> &cids, const std::vector<uint32_t> &leftover,
+                            std::vector<int32_t> &join_slot) -> bool {
+        if (forbid_device || !symmetric) return false;
+        if (!device_precheck(cluster_of, usize, leftover)) return false;
+        // the host loop over the lists is quicker while they are small (a few round trips less); beyond that
+        // the device runs the loop itself and nothing but the result crosses PCIe
+        if (!force_device && pre_total_c < (1u << 19)) return false;
+        const auto tl = std::chrono::steady_clock::now();
+        const uint32_t nl = (uint32_t)leftover.size();
+        const uint32_t ncl = (uint32_t)usize.size();
+        hipError_t r = ensure_buf(ctx, SB_JOINED, std::max<size_t>(ncl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBSTART, ((size_t)ncl + 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBS, std::max<size_t>(pre_total_c, 1) * 8);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, ncl})));
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CSIZE, std::max<size_t>(ncl, 1) * 8);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CID, std::max<size_t>(ncl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_FIRST, std::max<size_t>(ncl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_STATUS, std::max<size_t>(nl, 1));
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CHOICE, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_ACCEPTED, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_JSLOT, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_LCOUNT, 64);
+        if (r == hipSuccess && ctx->has_sizes) r = ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4);
+        if (r != hipSuccess) return false;
+        // subscriber lists (count into FIRST as scratch, scan, fill)
+        r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
+        if (r == hipSuccess) r = launch_loop_subscribers(false, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
+                                                         buf<uint32_t>(ctx, SB_FIRST), nullptr, nullptr, S);
+        if (r == hipSuccess) r = launch_scan_u32(buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), ncl, buf<uint64_t>(ctx, SB_SCAN2), S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
+        if (r == hipSuccess) r = launch_loop_subscribers(true, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
+                                                         buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JOINED), 0, (size_t)ncl * 4, S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_STATUS), 0, nl, S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JSLOT), 0xFF, (size_t)nl * 4, S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_LCOUNT), 0, 64, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CSIZE), csize.data(), (size_t)ncl * 8, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CID), cids.data(), (size_t)ncl * 4, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess && ctx->has_sizes)
+            r = hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, S);
+        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + 48);
+        uint32_t rounds = 0;
+        bool done = false;
+        // every round accepts at least the earliest tentative joiner, so nl + 1 rounds always suffice; the host looks at
+        // the device's counter once per batch of rounds (rounds after the end find nothing to do)
+        for (uint32_t batch = 8; r == hipSuccess && !done && rounds <= nl + 8; batch = std::min<uint32_t>(batch * 2, 64)) {
+            for (uint32_t b = 0; b < batch && r == hipSuccess; b++, rounds++)
+                r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_UP), buf<void>(ctx, SB_ADJ),
+                                      buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART),
+                                      buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
+                                      buf<uint32_t>(ctx, SB_FIRST), ncl, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
+                                      buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), buf<int32_t>(ctx, SB_JOINED), buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID),
+                                      ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), S);
+            if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[3], buf<uint32_t>(ctx, SB_LCOUNT) + 3, 4, hipMemcpyDeviceToHost, S);
+            if (r == hipSuccess) r = hipStreamSynchronize(S);
+            done = r == hipSuccess && h_misc[3] == 0;
+        }
+        if (r != hipSuccess || !done) return false;
+        join_slot.resize(nl);
+        if (nl) r = hipMemcpy(join_slot.data(), buf<void>(ctx, SB_JSLOT), (size_t)nl * 4, hipMemcpyDeviceToHost);
+        if (r != hipSuccess) return false;
+        ph.device_loop_ms = ms_since(tl);
+        ph.loop_rounds = rounds;
+        lap("device second loop (rounds)");
+        return true;
+    };
+
+    hooks.precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<uint32_t> &leftover,
+                         bool want_prop, std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand,
+                         std::vector<uint32_t> &prop_start, std::vector<GreedyProp> &prop, bool *have_prop) -> bool {
+        *have_prop = false;
+        if (!device_precheck(cluster_of, usize, leftover)) return false;
+        const uint32_t nl = (uint32_t)leftover.size();
+        const uint32_t total_c = pre_total_c;
+        if (!fetch_cand(nl, cand_start, cand)) return false;
+        lap("device pre-check");
+        if (!want_prop || !symmetric || forbid_lists || getenv("HMK_HOST_PROPAGATION")) return true;
+        // ---- join-propagation lists -------------------------------------------------------------------------
+        const auto tq = std::chrono::steady_clock::now();
+        prop_start.assign((size_t)total_c + 1, 0);
+        prop.clear();
+        if (total_c == 0) { *have_prop = true; return true; }
+        hipError_t r = ensure_buf(ctx, SB_LIDX, (size_t)n * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_PCNT, (size_t)total_c * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_PSTART, ((size_t)total_c + 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, total_c})));
+        if (r != hipSuccess) return true;   // candidates are fine; the merge falls back to stamping rows
+        uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
+        int32_t *d_lidx = buf<int32_t>(ctx, SB_LIDX);
+        uint32_t *d_pcnt = buf<uint32_t>(ctx, SB_PCNT), *d_pstart = buf<uint32_t>(ctx, SB_PSTART);
+        const uint32_t *d_up = buf<uint32_t>(ctx, SB_UP);
+        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
+        const void *d_adj = buf<void>(ctx, SB_ADJ);
+        const uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
+        r = launch_fill_lidx(d_left, nl, d_lidx, n, S);
+        if (r == hipSuccess) r = hipMemsetAsync(d_pcnt, 0, (size_t)total_c * 4, S);
+        if (r == hipSuccess) r = launch_greedy_prop(false, packed, d_start, d_up, d_adj, d_lidx, d_left, nl, d_cstart,
+                                                    buf<GreedyCand>(ctx, SB_CAND), d_pcnt, nullptr, nullptr, S);
+        if (r == hipSuccess) r = launch_scan_u32(d_pcnt, d_pstart, total_c, d_scan, S);
+        unsigned long long *h_total = ctx->h_counts + 56;   // the scan's 64-bit grand total (its uint32 start[] may wrap)
+        if (r == hipSuccess) r = hipMemcpyAsync(h_total, d_scan + scan_total_index(total_c), 8, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess) r = hipStreamSynchronize(S);
+        if (r != hipSuccess) return true;
+        if (*h_total > (1ull << 28)) return true;   // very dense families: let the host stamp rows instead (2 GB of lists)
+        const uint32_t total_p = (uint32_t)*h_total;
+        prop.resize(total_p);
+        r = hipMemcpyAsync(prop_start.data(), d_pstart, ((size_t)total_c + 1) * 4, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess && total_p) {
+            r = ensure_buf(ctx, SB_PROP, (size_t)total_p * sizeof(GreedyProp));
+            if (r == hipSuccess) r = hipMemsetAsync(d_pcnt, 0, (size_t)total_c * 4, S);
+            if (r == hipSuccess) r = launch_greedy_prop(true, packed, d_start, d_up, d_adj, d_lidx, d_left, nl, d_cstart,
+                                                        buf<GreedyCand>(ctx, SB_CAND), d_pcnt, d_pstart, buf<GreedyProp>(ctx, SB_PROP), S);
+            if (r == hipSuccess) r = hipMemcpyAsync(prop.data(), buf<GreedyProp>(ctx, SB_PROP), (size_t)total_p * sizeof(GreedyProp),
+                                                    hipMemcpyDeviceToHost, S);
+        }
+        if (r == hipSuccess) r = hipStreamSynchronize(S);
+        if (r != hipSuccess) { prop.clear(); return true; }
+        *have_prop = true;
+        ph.prop_ms = ms_since(tq);
+        ph.prop_entries = total_p;
+        lap("device join-propagation lists");
+        return true;
+    };
+
+    hooks.adj_base = [&]() -> const void * { return ctx->h_adj; };
+    GreedyTimes times{};
+    hooks.times = &times;
     std::string err;
     const int32_t *szs = ctx->has_sizes ? ctx->sizes.data() : nullptr;
-    const uint32_t *upper = symmetric ? h_up : nullptr;   // rows are laid out upper neighbours first
-    int st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)h_adj, upper, &hooks, symmetric, max_clusters,
-                                         cluster_id, result_order, member_rank, stats, &err)
-                : greedy_from_csr(n, szs, h_start, (const Nbr *)h_adj, upper, &hooks, symmetric, max_clusters, cluster_id,
-                                  result_order, member_rank, stats, &err);
-    if (copy_stream) (void)hipStreamSynchronize(copy_stream);   // a crash-parity exit may leave chunks in flight
-    drop_copy();
-    cleanup();
-    if (copy_error != hipSuccess)
-        return fail(ctx, HMK_ERR_DEVICE, std::string("hmk_greedy_cluster (adjacency copy): ") + hipGetErrorString(copy_error));
-    stats->n_edges = total;
-    stats->neighbors_ms = nb_ms;
+    // the entry format is fixed before the merge starts unless it depends on the scores (then the first need_rows
+    // call settles it through wait_full(), before any row is read): dispatch on a flag the row provider may update
+    int st;
+    if (!src.format_known) {
+        if (!wait_full()) {
+            (void)hipStreamSynchronize(S);
+            (void)hipStreamSynchronize(C);
+            return status_inside == ST_RETRY_OVERFLOW ? ST_RETRY_OVERFLOW : fail(ctx, status_inside, hook_err);
+        }
+    }
+    st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)ctx->h_adj, symmetric ? h_up : nullptr, &hooks, symmetric,
+                                         max_clusters, cluster_id, result_order, member_rank, stats, &err)
+                : greedy_from_csr(n, szs, h_start, (const Nbr *)ctx->h_adj, symmetric ? h_up : nullptr, &hooks, symmetric, max_clusters,
+                                  cluster_id, result_order, member_rank, stats, &err);
+    // nothing of this call may still be running when the buffers are reused (a crash-parity exit leaves the pass in flight)
+    (void)hipStreamSynchronize(S);
+    (void)hipStreamSynchronize(C);
+    if (status_inside == ST_RETRY_OVERFLOW) return ST_RETRY_OVERFLOW;
+    if (status_inside != HMK_OK) return fail(ctx, status_inside, hook_err);
+    if (st == HMK_OK || st == HMK_ERR_REFERENCE_WOULD_CRASH) {
+        // a crash-parity exit during phase 1 never looked at the final counts: an overflow must still be noticed
+        if (src.check_overflow)
+            for (int q = 0; q < HMK_EDGE_SHARDS; q++)
+                if (ctx->h_counts[q] > src.seg_cap) return ST_RETRY_OVERFLOW;
+    }
+    ph.phase1_ms = times.phase1_ms;
+    ph.sequential_ms = times.sequential_ms;
+    ph.wait_rows_ms = t_rows;
+    ph.host_precheck_ms = times.host_precheck_ms;
+    stats->n_edges = src.total_known ? src.total_known : (symmetric ? h_start[n] / 2 : h_start[n]);
     if (st) return fail(ctx, st, err);
     return HMK_OK;
 }
 
+}  // namespace
+
+extern "C" {
 
 int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters,
                        int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
@@ -1291,19 +1626,84 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     hmk_greedy_stats local;
     if (!stats) stats = &local;
     std::memset(stats, 0, sizeof(*stats));
+    ctx->phases = hmk_greedy_phases{};
     if (ctx->n == 0) return HMK_OK;  // cluster() of an empty list returns an empty list
-    unsigned long long counts[HMK_EDGE_SHARDS];
-    double ms = 0;
-    auto t0 = std::chrono::steady_clock::now();
-    // first guess of the edge buffer: 0.3 % of the pair space (uniform random 12-mers at the default threshold give
-    // 0.26 %); a segment that overflows makes neighbors_grow() size the buffer exactly and score again
-    const uint64_t guess = (uint64_t)((double)ctx->n * (ctx->n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006)) + (1u << 20);
-    int st = neighbors_internal(ctx, max_shift, shift_penalty, threshold, 0, 1, std::min<uint64_t>(guess, 1ull << 31), counts, &ms);
+    int st = need_device(ctx);
     if (st) return st;
-    uint64_t total = 0;
-    for (int s = 0; s < HMK_EDGE_SHARDS; s++) total += counts[s];
-    return cluster_from_device_edges(ctx, ctx->d_edges, ctx->d_edges_cap / HMK_EDGE_SHARDS, ctx->d_counts, total, ctx->symmetric,
-                                     max_clusters, cluster_id, result_order, member_rank, stats, t0);
+    st = greedy_streams(ctx);
+    if (st) return st;
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = ctx->n;
+    hipStream_t S = ctx->gstream;
+    // Band: phase 1 of the merge (LimitedGreedySequenceClusterer.java:77-120) reads the adjacency rows in order and
+    // stops once maxClusters clusters exist, normally a little after row maxClusters.  The tiles that complete the first
+    // band_rows rows are launched first, their rows are handed to the host while the rest of the pair space is being scored.
+    int64_t band_rows = 0;
+    if (max_clusters > 0 && n >= 16384 && getenv("HMK_NO_BAND") == nullptr)
+        band_rows = std::min<int64_t>(n, 2LL * max_clusters + 1024);
+    if (band_rows * 2 > (int64_t)n) band_rows = 0;   // no point: the band would be most of the pass
+    const int64_t band_req = band_rows;
+    st = build_plan(ctx, max_shift, shift_penalty, threshold, 0, 1, band_req);
+    if (st) return st;
+    band_rows = ctx->plan.band_rows;   // 0 if the plan could not order its tiles by band
+    ctx->phases.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // adjacency entries are 4 bytes (m << 8 | score - threshold) when no score can exceed threshold + 255
+    const long long top = (long long)ctx->max_len * std::max(0, ctx->max_m) +
+                          (long long)std::max(0, shift_penalty) * ((ctx->max_len - ctx->min_len) + 2LL * max_shift);
+    EdgeSource src;
+    src.symmetric = ctx->symmetric;
+    src.format_known = true;
+    src.packed = top - threshold <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr;
+    src.base = threshold;
+    src.check_overflow = true;
+    if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
+    HIPCHK(ctx, ensure_buf(ctx, SB_BCOUNTS, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
+    // first guess of the edge buffer: 0.3 % of the pair space (uniform random 12-mers at the default threshold give
+    // 0.26 %); a segment that overflows makes the loop below size the buffer to the counts and score again
+    const uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006)) + (1u << 20);
+    uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)HMK_EDGE_SHARDS * 65536, ctx->d_edges_cap});
+    cap = (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (ctx->d_edges_cap < cap) {
+            if (ctx->d_edges) (void)hipFree(ctx->d_edges);
+            ctx->d_edges = nullptr;
+            ctx->d_edges_cap = 0;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t)));
+            ctx->d_edges_cap = cap;
+        }
+        const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
+        src.seg_cap = seg;
+        src.segs = shard_segments(ctx->d_edges, seg, ctx->d_counts);
+        src.adj_bound = (ctx->symmetric ? 2 : 1) * ctx->d_edges_cap;
+        src.band_rows = (uint32_t)band_rows;
+        src.band_segs = shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
+        if (band_rows > 0) {
+            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
+                                      LAUNCH_BAND, band_req);
+            if (st) return st;
+            HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long),
+                                       hipMemcpyDeviceToDevice, S));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_band, S));
+        }
+        st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
+                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req);
+        if (st) { (void)hipStreamSynchronize(S); return st; }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
+        st = cluster_on_device(ctx, src, max_clusters, cluster_id, result_order, member_rank, stats, t0);
+        if (st != ST_RETRY_OVERFLOW) break;
+        unsigned long long mx = 0;
+        for (int q = 0; q < HMK_EDGE_SHARDS; q++) mx = std::max(mx, ctx->h_counts[q]);
+        cap = (uint64_t)HMK_EDGE_SHARDS * (mx + mx / 8 + 1024);  // a segment overflowed: grow and rescore
+    }
+    if (st == ST_RETRY_OVERFLOW) return fail(ctx, HMK_ERR_DEVICE, "internal edge buffer kept overflowing");
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_edges) == hipSuccess) ctx->phases.score_ms = ms;
+    if (hipEventElapsedTime(&ms, ctx->ev_edges, ctx->ev_csr) == hipSuccess) ctx->phases.csr_ms = ms;
+    ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    stats->neighbors_ms = ctx->phases.score_ms;
+    return st;
 }
 
 int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edges, int symmetric, int max_clusters,
@@ -1317,15 +1717,34 @@ int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edge
     hmk_greedy_stats local;
     if (!stats) stats = &local;
     std::memset(stats, 0, sizeof(*stats));
+    ctx->phases = hmk_greedy_phases{};
     if (ctx->n == 0) return HMK_OK;
-    auto t0 = std::chrono::steady_clock::now();
-    // one contiguous block = segment 0 of HMK_EDGE_SHARDS, the other segments empty
-    if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
-    unsigned long long counts[HMK_EDGE_SHARDS] = {0};
-    counts[0] = n_edges;
-    HIPCHK(ctx, hipMemcpy(ctx->d_counts, counts, sizeof(counts), hipMemcpyHostToDevice));
-    return cluster_from_device_edges(ctx, (const uint64_t *)d_edges, std::max<uint64_t>(n_edges, 1), ctx->d_counts, n_edges,
-                                     symmetric != 0, max_clusters, cluster_id, result_order, member_rank, stats, t0);
+    st = greedy_streams(ctx);
+    if (st) return st;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t S = ctx->gstream;
+    // the caller's block may have been written on any stream of its own (an all-gather, a copy): wait for the device
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, ensure_buf(ctx, SB_PEERCNT, HMK_MAX_SEGS * sizeof(unsigned long long)));
+    ctx->h_counts[32] = n_edges;
+    HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_PEERCNT), &ctx->h_counts[32], sizeof(unsigned long long), hipMemcpyHostToDevice, S));
+    EdgeSource src;
+    src.symmetric = symmetric != 0;
+    src.segs.n = 1;
+    src.segs.s[0] = EdgeSeg{(const uint64_t *)d_edges, buf<unsigned long long>(ctx, SB_PEERCNT), n_edges};
+    src.total_known = 0;   // invalid edges are not counted by the degree pass; the adjacency size is checked against it
+    HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
+    st = cluster_on_device(ctx, src, max_clusters, cluster_id, result_order, member_rank, stats, t0);
+    if (st == HMK_OK || st == HMK_ERR_REFERENCE_WOULD_CRASH) stats->n_edges = n_edges;
+    ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+int hmk_greedy_last_phases(const hmk_ctx *ctx, hmk_greedy_phases *out) {
+    if (!ctx || !out) return fail(nullptr, HMK_ERR_BAD_ARG, "null argument");
+    *out = ctx->phases;
+    return HMK_OK;
 }
 
 }  // extern "C"

@@ -99,7 +99,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
 // The merge proper, on a CSR adjacency: start[n + 1], adj[start[x] .. start[x + 1]) = neighbours of x.
 // NbrT: Nbr (8 bytes) or NbrPacked (4 bytes); only id() and score() are used, scores only in comparisons.
 template <class NbrT>
-static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj,
+static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj_in,
                                 const uint32_t *upper, const GreedyHooks *hooks, bool symmetric_scores, int max_clusters,
                                 int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
                                 std::string *err) {
@@ -107,7 +107,9 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     hmk_greedy_stats local;
     if (!st) st = &local;
     std::memset(st, 0, sizeof(*st));
-    st->n_edges = start[n];
+    const bool partial = hooks && hooks->need_rows;   // only a prefix of the rows is on the host so far
+    const NbrT *adj = adj_in;                         // re-read after every need_rows(): the host buffer may have moved
+    if (!partial) st->n_edges = start[n];
     double t_phase1 = 0;
 
     std::vector<uint8_t> state(n, ST_FREE);
@@ -156,10 +158,14 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     int64_t remaining = n;  // elements of initialList at positions >= index
     int64_t index = 0;
     uint32_t k = 0;         // sequence behind initialList.get(index)
-    uint64_t arrived = (hooks && hooks->need_entries) ? 0 : start[n];   // adj[0 .. arrived) is on the host
+    uint32_t rows_here = partial ? 0 : n;   // rows [0, rows_here) of the adjacency are on the host
     for (; k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters; k++) {
         if (state[k] != ST_FREE) continue;  // removed from initialList (:101, :110)
-        if (start[k + 1] > arrived) arrived = hooks->need_entries(start[k + 1]);   // row k must have landed
+        if (k >= rows_here) {                                   // row k must have landed
+            rows_here = hooks->need_rows(k);
+            if (rows_here <= k) return HMK_INTERNAL_ROWS_FAILED;
+            if (hooks->adj_base) adj = (const NbrT *)hooks->adj_base();
+        }
         Found A = nearest_cluster(k);                       // :92
         Found B;                                            // :93
         if (remaining - 1 == 0) {
@@ -216,7 +222,13 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
 
     {
         // ---- cluster() second loop, :59-66 ---------------------------------
-        if (start[n] > arrived) arrived = hooks->need_entries(start[n]);   // from here on any row may be read
+        auto need_all_rows = [&]() -> bool {
+            if (n && rows_here < n) {
+                rows_here = hooks->need_rows(n - 1);
+                if (hooks->adj_base) adj = (const NbrT *)hooks->adj_base();
+            }
+            return rows_here >= n;
+        };
         std::vector<uint32_t> leftover(orphans);
         for (uint32_t q = k; q < n; q++)
             if (state[q] == ST_FREE) leftover.push_back(q);
@@ -232,14 +244,26 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         std::vector<uint32_t> cand_start(nl + 1, 0);     // CSR of candidate clusters per leftover
         std::vector<Cand> cand;
         const bool fast = !clusters.empty() && nl > 512;
-        bool have_cand = false;
-        if (fast && hooks && hooks->precheck) {   // the adjacency is still on the GPU: pre-check there
+        bool have_cand = false, have_prop = false;
+        std::vector<uint32_t> prop_start;                // per candidate entry: the later entries a join must update
+        std::vector<GreedyProp> prop;
+        bool device_done = false;
+        std::vector<int32_t> join_slot;
+        if (fast && symmetric_scores && hooks && hooks->device_loop) {   // large inputs: the whole loop on the GPU, in optimistic rounds
+            std::vector<int32_t> usize(clusters.size()), cids(clusters.size());
+            std::vector<int64_t> csize(clusters.size());
+            for (size_t c = 0; c < clusters.size(); c++) { usize[c] = clusters[c].usize; csize[c] = clusters[c].size; cids[c] = clusters[c].id; }
+            device_done = hooks->device_loop(cluster_of.data(), usize, csize, cids, leftover, join_slot);
+        }
+        if (fast && !device_done && hooks && hooks->precheck) {   // the adjacency is still on the GPU: pre-check there
             std::vector<int32_t> usize(clusters.size());
             for (size_t c = 0; c < clusters.size(); c++) usize[c] = clusters[c].usize;
-            have_cand = hooks->precheck(cluster_of.data(), usize, leftover, cand_start, cand);
-            if (!have_cand) { cand_start.assign(nl + 1, 0); cand.clear(); }
+            have_cand = hooks->precheck(cluster_of.data(), usize, leftover, symmetric_scores, cand_start, cand, prop_start,
+                                        prop, &have_prop);
+            if (!have_cand) { cand_start.assign(nl + 1, 0); cand.clear(); have_prop = false; }
         }
-        if (fast && !have_cand) {
+        if (!device_done && !(have_cand && have_prop) && !need_all_rows()) return HMK_INTERNAL_ROWS_FAILED;   // every other path below reads rows
+        if (fast && !have_cand && !device_done) {
             const unsigned hw = std::thread::hardware_concurrency();
             const unsigned T = std::max(1u, std::min(16u, hw ? hw : 1u));
             const size_t nc = clusters.size();
@@ -280,6 +304,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             for (unsigned t = 0; t < T; t++) cand.insert(cand.end(), found[t].begin(), found[t].end());
         }
         const double t_pre = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (hooks && hooks->times) { hooks->times->phase1_ms = t_phase1; hooks->times->host_precheck_ms = t_pre - t_phase1; }
         if (getenv("HMK_GREEDY_TIMING"))
             fprintf(stderr, "[hmk greedy] phase1 %.2f ms, pre-check %.2f ms (%zu leftovers)\n", t_phase1, t_pre - t_phase1, nl);
         // "Subscribers": per cluster, the leftovers that listed it as a candidate.  When y joins cluster c,
@@ -287,7 +312,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         // only c's later subscribers are visited: a subscriber that is a neighbour of y counts one more
         // covered member (and folds the score into its min); at its own turn a candidate is still feasible
         // iff covered == members joined since the pre-check.
-        const bool use_subs = fast && symmetric_scores;
+        const bool use_subs = fast && symmetric_scores && !have_prop && !device_done;
         struct Sub { uint32_t w; int32_t k; };           // the subscriber (sequence id), index of its candidate in `cand`;
                                                          // per cluster in leftover order = increasing id
         std::vector<uint32_t> sub_start;                 // CSR of subscribers per cluster
@@ -311,12 +336,44 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         }
         uint32_t stamp = 0;
         std::vector<uint32_t> rest;
+        std::vector<int32_t> joined_dev(have_prop ? clusters.size() : 0, 0);   // members that joined each cluster in this loop
         double t_scan = 0, t_push = 0;
         const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;
         auto now = []() { return std::chrono::steady_clock::now(); };
         for (size_t q = 0; q < nl; q++) {
             const uint32_t y = leftover[q];
             Found F{NEAR_NULL, -1, 0};                                              // :60
+            if (device_done) {   // decided on the device (k_loop_*); joins are applied in loop order
+                if (join_slot[q] >= 0) insert_into(join_slot[q], y);                 // :61-62
+                else rest.push_back(y);                                              // :64
+                continue;
+            }
+            if (have_prop) {
+                // device-built propagation lists: the same bookkeeping as "Subscribers" below, but the entries a join
+                // has to update were listed by the GPU (k_greedy_prop), so no adjacency row is read here
+                int32_t kf = -1;
+                for (uint32_t k = cand_start[q]; k < cand_start[q + 1]; k++) {
+                    const Cand cd = cand[k];
+                    if (cd.covered != joined_dev[cd.c]) continue;        // some new member is not a neighbour of y
+                    if (F.kind == NEAR_NULL ||
+                        better(cd.mn, clusters[cd.c].size, clusters[cd.c].id, F.score, clusters[F.slot].size, clusters[F.slot].id)) {
+                        F = Found{NEAR_REAL, cd.c, cd.mn};
+                        kf = (int32_t)k;
+                    }
+                }
+                if (F.kind == NEAR_REAL) {
+                    insert_into(F.slot, y);                                          // :61-62
+                    joined_dev[F.slot]++;
+                    for (uint32_t u = prop_start[kf]; u < prop_start[kf + 1]; u++) {
+                        Cand &cw = cand[prop[u].k];
+                        cw.covered++;
+                        if (prop[u].score < cw.mn) cw.mn = prop[u].score;
+                    }
+                } else {
+                    rest.push_back(y);                                               // :64
+                }
+                continue;
+            }
             if (!use_subs) {
                 auto ta = now();
                 if (!fast || cand_start[q + 1] > cand_start[q]) F = nearest_cluster(y);
@@ -385,6 +442,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         st->n_multi = (int32_t)clusters.size();
     }
     st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (hooks && hooks->times) hooks->times->sequential_ms = st->greedy_ms - hooks->times->phase1_ms - hooks->times->host_precheck_ms;
     if (getenv("HMK_GREEDY_TIMING")) fprintf(stderr, "[hmk greedy] total %.2f ms\n", st->greedy_ms);
     return HMK_OK;
 

@@ -78,22 +78,48 @@ struct NbrPacked {
 // later and are neighbours too (starts at 0).
 struct GreedyCand { int32_t c, mn, covered; };
 
+// One entry of a join-propagation list (k_greedy_prop): candidate entry k (index into the cand array) belongs to a later
+// leftover that is a neighbour of the joining sequence, with that pair's score.
+struct GreedyProp { uint32_t k; int32_t score; };
+
+// A run of packed edges in device memory: min(*count, cap) entries at `edges`.  The CSR kernels take a short list of
+// them: the HMK_EDGE_SHARDS segments of one neighbour pass, or those plus the blocks gathered from other devices.
+struct EdgeSeg { const uint64_t *edges; const unsigned long long *count; uint64_t cap; };
+constexpr uint32_t HMK_MAX_SEGS = 32;
+struct EdgeSegs { EdgeSeg s[HMK_MAX_SEGS]; uint32_t n; };
+
 // Optional device-side pre-check of the second loop (hmk_api.cpp provides it when the adjacency is still resident on
 // the GPU): given cluster_of[n] (-1 = none), the clusters' member counts and the leftover list, fill the candidate
-// CSR (cand_start[nl + 1], cand[]).  Returns false if it could not (the merge then runs its threaded host version).
+// CSR (cand_start[nl + 1], cand[]) and, if want_prop, the join-propagation lists (prop_start[cand.size() + 1], prop[];
+// *have_prop says whether they were produced).  Returns false if it could not (the merge then fetches the whole
+// adjacency and runs its threaded host version).
 using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::vector<int32_t> &usize,
-                                          const std::vector<uint32_t> &leftover, std::vector<uint32_t> &cand_start,
-                                          std::vector<GreedyCand> &cand)>;
+                                          const std::vector<uint32_t> &leftover, bool want_prop,
+                                          std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand,
+                                          std::vector<uint32_t> &prop_start, std::vector<GreedyProp> &prop, bool *have_prop)>;
 
 // Hooks of the host merge for a caller that still has the adjacency on the device (hmk_api.cpp):
-//   precheck       see GreedyPrecheck (may be empty)
-//   need_entries   the adjacency may still be in flight to the host: need_entries(e) returns once adj[0 .. e) has
-//                  arrived and reports how far the copy has got (>= e); phase 1 asks row by row, so it overlaps the
-//                  tail of the copy.  Empty = everything is there already.
+//   precheck    see GreedyPrecheck (may be empty)
+//   need_rows   only a prefix of the rows may be in host memory yet: need_rows(k) returns R > k once start[0 .. R] and
+//               adj[0 .. start[R]) are valid on the host (it fetches more rows from the device if it has to).  Phase 1
+//               asks row by row; with the device pre-check and propagation lists the second loop needs no rows at all.
+//               Empty = everything is there already.
+// Optional device-side run of the whole second loop (hmk_api.cpp, k_loop_*): given the state after phase 1 --
+// cluster_of[n], per cluster slot its member count, Cluster.size() and id, the leftover list -- fill join_slot[q] =
+// the slot leftover q joins or -1.  Returns false if it did not run (the merge then uses precheck / its host loop).
+using GreedyDeviceLoop = std::function<bool(const int32_t *cluster_of, const std::vector<int32_t> &usize,
+                                            const std::vector<int64_t> &csize, const std::vector<int32_t> &cids,
+                                            const std::vector<uint32_t> &leftover, std::vector<int32_t> &join_slot)>;
+
+struct GreedyTimes { double phase1_ms, host_precheck_ms, sequential_ms; };   // host wall time of the merge's parts
 struct GreedyHooks {
     GreedyPrecheck precheck;
-    std::function<uint64_t(uint64_t)> need_entries;
+    GreedyDeviceLoop device_loop;
+    std::function<uint32_t(uint32_t)> need_rows;   // a return value <= k means the rows could not be had: the merge stops
+    std::function<const void *()> adj_base;        // with need_rows: where adj[] is now (the host buffer may move when it grows)
+    GreedyTimes *times = nullptr;
 };
+constexpr int HMK_INTERNAL_ROWS_FAILED = -1;   // greedy_from_csr*: need_rows failed (the caller knows why)
 
 // host greedy merge (hmk_greedy.cpp)
 // symmetric_scores: adj holds every edge under both ends with the same score (symmetric matrix)

@@ -29,16 +29,17 @@ hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, co
 hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
                                   const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s);
 
-// edge segments -> CSR (start[n + 1], adj[]) on the device: deg and cursor are zeroed uint32[n] scratch
-hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
-                                  bool symmetric, uint32_t *deg, uint32_t *up, uint64_t *start, uint64_t *tile_scratch,
-                                  int *score_range, hipStream_t s);  // up: zeroed uint32[n], receives the upper-neighbour counts  // score_range: device int[3] = {min score, max score, invalid edges}
+// edge segments -> CSR (start[row_limit + 1], adj[]) on the device; rows at and beyond row_limit are left out
+// (row_limit = n: the whole graph).  deg / up: zeroed uint32[row_limit]; cursor: zeroed uint32[2 row_limit];
+// score_range: device int[3] = {min score, max score, invalid edges}
+EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts);
+hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
+                                  uint32_t *up, uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s);
 size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
 size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)
-hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
-                              bool symmetric, const uint64_t *start, const uint32_t *up, uint32_t *cursor, void *adj,
-                              bool packed, int base, uint32_t n, hipStream_t s);  // cursor: zeroed uint32[2 n]
+hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, const uint32_t *up,
+                              uint32_t *cursor, void *adj, bool packed, int base, uint32_t row_limit, hipStream_t s);
 
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);
@@ -56,6 +57,24 @@ hipError_t launch_greedy_precheck(bool fill, bool packed, const uint64_t *start,
                                   const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
                                   const uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, hipStream_t s);
 hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, uint64_t *tile_scratch, hipStream_t s);
+// where launch_scan_u32 leaves the 64-bit grand total inside tile_scratch (the uint32 start[n] wraps beyond 2^32 - 1)
+size_t scan_total_index(uint32_t n);
+// device-side second loop (k_loop_*).  Subscriber lists: per cluster the (leftover, candidate entry) pairs listing it,
+// subs = uint32[2 * entries]; pass 0 (fill = false) counts into the zeroed cursor[n_clusters], pass 1 fills.
+hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const GreedyCand *cand, uint32_t *cursor,
+                                   const uint32_t *sub_start, uint32_t *subs, hipStream_t s);
+// one round; counters: device uint32[4] ([3] = tentative joiners the round's eval saw: 0 means the loop is over),
+// first: uint32[n_clusters]
+hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
+                             uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
+                             uint32_t *first, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot, const uint32_t *sub_start,
+                             const uint32_t *subs, int32_t *joined, long long *csize, const int32_t *cid, const int32_t *seq_size,
+                             uint32_t *counters, hipStream_t s);
+// join-propagation lists of the second loop (k_greedy_prop): lidx = sequence -> leftover index or -1
+hipError_t launch_fill_lidx(const uint32_t *leftover, uint32_t nl, int32_t *lidx, uint32_t n, hipStream_t s);
+hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, const uint32_t *up, const void *adj,
+                              const int32_t *lidx, const uint32_t *leftover, uint32_t nl, const uint32_t *cand_start,
+                              const GreedyCand *cand, uint32_t *pcnt, const uint32_t *pstart, GreedyProp *prop, hipStream_t s);
 
 // LocalAlignmentScorer dense block, register-resident DP (needs |M| <= 127, gap penalties <= 0, len <= lbmax)
 // enc: the tagged-max DP (needs |M| <= 31 and -31 <= gap penalties <= 0)

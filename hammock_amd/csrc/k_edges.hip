@@ -14,11 +14,12 @@ namespace hmk {
 // score_range[0] / [1]: smallest / largest edge score (decides whether the 4-byte adjacency fits);
 // score_range[2]: edges that name a sequence outside [0, n) or a self pair (not counted; the caller gives up)
 __global__ void __launch_bounds__(256)
-k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
-              uint32_t *__restrict__ deg, uint32_t *__restrict__ up, int symmetric, int *__restrict__ score_range, uint32_t n) {
-    const uint32_t shard = blockIdx.y;
-    const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
-    const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
+k_edge_degree(const EdgeSegs segs, uint32_t *__restrict__ deg, uint32_t *__restrict__ up, int symmetric,
+              int *__restrict__ score_range, uint32_t n, uint32_t row_limit) {
+    // row_limit: only rows [0, row_limit) are counted (the "band" a first phase-1 hand-over needs); n otherwise
+    const EdgeSeg sg = segs.s[blockIdx.y];
+    const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
+    const uint64_t *seg = sg.edges;
     int lo = INT_MAX, hi = INT_MIN;
     // wave-uniform loop: the x side of a wave's 64 consecutive edges has a handful of distinct values
     for (uint64_t k0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); k0 < cnt; k0 += (uint64_t)gridDim.x * 256) {
@@ -33,12 +34,12 @@ k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const 
         // the row's own), counted in up[] as well -- rows are laid out upper neighbours first (k_edge_scatter)
         const uint32_t ea = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
         const uint32_t eb = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
-        const WaveGroup g = wave_groups(ea, valid);
-        if (valid && g.rank == 0) {
+        const WaveGroup g = wave_groups(ea, valid && ea < row_limit);
+        if (valid && ea < row_limit && g.rank == 0) {
             atomicAdd(&deg[ea], g.size);
             if (symmetric) atomicAdd(&up[ea], g.size);
         }
-        if (valid && symmetric) atomicAdd(&deg[eb], 1u);
+        if (valid && symmetric && eb < row_limit) atomicAdd(&deg[eb], 1u);
         if (valid) {
             const int sc = HMK_EDGE_SCORE(e);
             lo = min(lo, sc);
@@ -53,6 +54,11 @@ k_edge_degree(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const 
         atomicMin(&score_range[0], lo);
         atomicMax(&score_range[1], hi);
     }
+}
+
+// score_range = {INT_MAX, INT_MIN, 0} on the stream (no host buffer whose lifetime an async copy would depend on)
+__global__ void k_init_range(int *__restrict__ score_range) {
+    if (threadIdx.x == 0) { score_range[0] = INT_MAX; score_range[1] = INT_MIN; score_range[2] = 0; }
 }
 
 // Exclusive scan of deg[n] -> start[n + 1] in three coalesced passes over tiles of 2048 counters:
@@ -98,26 +104,26 @@ template <typename T>
 __global__ void __launch_bounds__(256)
 k_scan_tiles(const uint32_t *__restrict__ deg, const uint64_t *__restrict__ tile_off, T *__restrict__ start, uint32_t n,
              uint32_t n_tiles, const uint32_t *__restrict__ tail_word) {
-    __shared__ uint32_t v[SCAN_TILE];
-    __shared__ uint32_t wsum[4];
+    __shared__ T v[SCAN_TILE];   // the tile-local prefix is as wide as the result: 2048 degrees of up to 2^24 pass 2^32
+    __shared__ T wsum[4];
     const uint32_t base = blockIdx.x * SCAN_TILE, tid = threadIdx.x;
     for (uint32_t j = 0; j < SCAN_TILE / 256; j++) {  // coalesced load
         const uint32_t k = base + j * 256 + tid;
         v[j * 256 + tid] = k < n ? deg[k] : 0;
     }
     __syncthreads();
-    uint32_t loc[SCAN_TILE / 256], sum = 0;           // thread tid owns the 8 consecutive counters tid * 8 ..
+    T loc[SCAN_TILE / 256], sum = 0;                  // thread tid owns the 8 consecutive counters tid * 8 ..
     for (uint32_t j = 0; j < SCAN_TILE / 256; j++) { loc[j] = sum; sum += v[tid * (SCAN_TILE / 256) + j]; }
-    uint32_t inc = sum;                               // inclusive scan of the thread sums inside the wave
+    T inc = sum;                                      // inclusive scan of the thread sums inside the wave
     for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, 64);
+        const T t = __shfl_up(inc, o, 64);
         if ((tid & 63) >= (uint32_t)o) inc += t;
     }
     if ((tid & 63) == 63) wsum[tid >> 6] = inc;
     __syncthreads();
-    uint32_t woff = 0;
+    T woff = 0;
     for (uint32_t w = 0; w < (tid >> 6); w++) woff += wsum[w];
-    const uint32_t excl = woff + inc - sum;
+    const T excl = woff + inc - sum;
     __syncthreads();
     for (uint32_t j = 0; j < SCAN_TILE / 256; j++) v[tid * (SCAN_TILE / 256) + j] = excl + loc[j];
     __syncthreads();
@@ -147,12 +153,12 @@ static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *til
 // one cursor per section.  The host merge only has to look at the first section when a sequence joins a cluster.
 template <class NbrT>
 __global__ void __launch_bounds__(256)
-k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const unsigned long long *__restrict__ counts,
-               const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, uint32_t *__restrict__ cursor,
-               NbrT *__restrict__ adj, int symmetric, int base, uint32_t n) {
-    const uint32_t shard = blockIdx.y;
-    const uint64_t cnt = min((uint64_t)counts[shard], cap_per_shard);
-    const uint64_t *seg = edges + (uint64_t)shard * cap_per_shard;
+k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, const uint32_t *__restrict__ up,
+               uint32_t *__restrict__ cursor, NbrT *__restrict__ adj, int symmetric, int base, uint32_t row_limit) {
+    // cursor: uint32[2 * row_limit]; rows at and beyond row_limit are not stored
+    const EdgeSeg sg = segs.s[blockIdx.y];
+    const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
+    const uint64_t *seg = sg.edges;
     for (uint64_t k0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u); k0 < cnt; k0 += (uint64_t)gridDim.x * 256) {
         const uint64_t k = k0 + (threadIdx.x & 63);
         const bool valid = k < cnt;
@@ -160,19 +166,20 @@ k_edge_scatter(const uint64_t *__restrict__ edges, uint64_t cap_per_shard, const
         const uint32_t x = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
         const uint32_t m = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
         const int32_t s = HMK_EDGE_SCORE(e);
-        const WaveGroup g = wave_groups(x, valid);   // one atomic per distinct x of the wave
+        const bool vx = valid && x < row_limit;
+        const WaveGroup g = wave_groups(x, vx);   // one atomic per distinct x of the wave
         uint32_t basex = 0;
-        if (valid && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
+        if (vx && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
         basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
         if (!valid) continue;
-        const uint64_t px = start[x] + basex + g.rank;
+        const bool vm = symmetric && m < row_limit;
         if constexpr (sizeof(NbrT) == 4) {
             const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
-            adj[px] = NbrT{(m << 8) | rel};
-            if (symmetric) adj[start[m] + up[m] + atomicAdd(&cursor[n + m], 1u)] = NbrT{(x << 8) | rel};
+            if (vx) adj[start[x] + basex + g.rank] = NbrT{(m << 8) | rel};
+            if (vm) adj[start[m] + up[m] + atomicAdd(&cursor[row_limit + m], 1u)] = NbrT{(x << 8) | rel};
         } else {
-            adj[px] = NbrT{m, s};
-            if (symmetric) adj[start[m] + up[m] + atomicAdd(&cursor[n + m], 1u)] = NbrT{x, s};
+            if (vx) adj[start[x] + basex + g.rank] = NbrT{m, s};
+            if (vm) adj[start[m] + up[m] + atomicAdd(&cursor[row_limit + m], 1u)] = NbrT{x, s};
         }
     }
 }
@@ -356,29 +363,226 @@ k_greedy_precheck(const uint64_t *__restrict__ start, const NbrT *__restrict__ a
 }
 
 // -----------------------------------------------------------------------------
+// join propagation lists of the second loop, on the device-resident adjacency
+// -----------------------------------------------------------------------------
+// When leftover y joins cluster c (LimitedGreedySequenceClusterer.java:61-62), every LATER leftover w that still lists
+// c as a candidate must learn whether the new member is one of its neighbours (complete linkage: c stays feasible for
+// w only if it is) and with which score.  The host used to find that out by stamping y's whole adjacency row
+// (2,500 entries at 10^6 peptides) per join; here the device lists, for every candidate entry k1 = (y, c), exactly the
+// entries k2 = (w, c) with w > y and w a neighbour of y: prop[prop_start[k1] ..) = {k2, score(y, w)}.  The sequential
+// host loop then touches only these few entries per join and never the adjacency itself.
+// One wave per leftover that has candidates; it walks the row's "upper" section (ids above y: the leftover list is in
+// increasing id order, so later in the loop == larger id).
+__global__ void __launch_bounds__(256) k_fill_lidx(const uint32_t *__restrict__ leftover, uint32_t nl, int32_t *__restrict__ lidx) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q < nl) lidx[leftover[q]] = (int32_t)q;
+}
+
+template <class NbrT, bool FILL>
+__global__ void __launch_bounds__(256)
+k_greedy_prop(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, const NbrT *__restrict__ adj,
+              const int32_t *__restrict__ lidx, const uint32_t *__restrict__ leftover, uint32_t nl,
+              const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand, uint32_t *__restrict__ pcnt,
+              const uint32_t *__restrict__ pstart, GreedyProp *__restrict__ prop) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t q = blockIdx.x * 4 + wv; q < nl; q += gridDim.x * 4) {
+        const uint32_t k1b = cand_start[q], k1e = cand_start[q + 1];
+        if (k1b == k1e) continue;                       // no feasible cluster: y can never join, nothing to propagate
+        const uint32_t y = leftover[q];
+        const uint64_t b = start[y], e = b + up[y];
+        for (uint64_t k = b + lane; k < e; k += 64) {
+            const NbrT nb = adj[k];
+            const int32_t lw = lidx[nbr_id(nb)];
+            if (lw < 0) continue;                       // the neighbour is already in a cluster
+            const uint32_t k2b = cand_start[lw], k2e = cand_start[lw + 1];
+            for (uint32_t k2 = k2b; k2 < k2e; k2++) {
+                const int32_t c2 = cand[k2].c;
+                for (uint32_t k1 = k1b; k1 < k1e; k1++) {
+                    if (cand[k1].c != c2) continue;
+                    const uint32_t pos = atomicAdd(&pcnt[k1], 1u);
+                    if (FILL) prop[pstart[k1] + pos] = GreedyProp{k2, nbr_score(nb)};
+                    break;                              // a leftover lists a cluster once
+                }
+            }
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------
+// the second loop itself on the device, in optimistic rounds
+// -----------------------------------------------------------------------------
+// LimitedGreedySequenceClusterer.java:59-66 is sequential: leftover w joins the best cluster that is feasible given
+// every join made by the leftovers before it.  Complete linkage is monotone in this loop -- clusters only grow, so a
+// cluster that is infeasible for w now is infeasible for good -- and that makes the loop parallel without changing
+// its result.  State per (leftover, candidate cluster) entry: covered = members that joined the cluster in this loop
+// and are neighbours of the leftover; the entry is feasible iff covered == joined[cluster].  One round:
+//   eval    every undecided leftover: F = its feasible entries.  F empty -> it never joins anything (final).  Otherwise
+//           it TENTATIVELY picks the best of F by (score, Cluster.size(), smaller id)
+//           (ClinkageSequenceClusterer.java:163-173,275-289) and atomicMin's its index into first[c] for every c in F.
+//   accept  a tentative joiner is accepted iff first[c] is itself for EVERY c in F: no earlier undecided leftover can
+//           still join any cluster it looked at, so at its turn of the sequential loop those clusters are exactly as
+//           they are now, and its pick is the sequential loop's pick.  (Joins already made by LATER leftovers only
+//           touched clusters that were infeasible for it then, hence now; the earliest tentative joiner always passes.)
+//   apply   every accepted join (at most one per cluster and round) is pushed along the joiner's row: each later,
+//           undecided neighbour that lists the cluster counts one more covered member and folds the pair's score into
+//           its minimum; then joined[c] and Cluster.size() advance, which turns the non-neighbours' entries infeasible.
+// Rounds repeat until no tentative joiner is left.  The host applies the joins in leftover order afterwards.
+enum : uint8_t { LS_UNDECIDED = 0, LS_NEVER = 1, LS_JOINED = 2 };
+
+// subscriber lists: per cluster the (leftover, candidate entry) pairs that list it; pass 0 counts, pass 1 fills
+__global__ void __launch_bounds__(256)
+k_loop_subscribers(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
+                   uint32_t *__restrict__ cursor, const uint32_t *__restrict__ sub_start, uint32_t *__restrict__ subs, int fill) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nl) return;
+    for (uint32_t k = cand_start[q], ke = cand_start[q + 1]; k < ke; k++) {
+        const uint32_t pos = atomicAdd(&cursor[cand[k].c], 1u);
+        if (fill) { subs[2 * (size_t)(sub_start[cand[k].c] + pos)] = q; subs[2 * (size_t)(sub_start[cand[k].c] + pos) + 1] = k; }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_loop_eval(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
+            const int32_t *__restrict__ joined, const long long *__restrict__ csize, const int32_t *__restrict__ cid,
+            uint8_t *__restrict__ status, uint32_t *__restrict__ choice, uint32_t *__restrict__ first,
+            uint32_t *__restrict__ counters) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q == 0) counters[1] = 0;                       // accepted joins of this round (filled by k_loop_accept)
+    if (q >= nl || status[q] != LS_UNDECIDED) return;
+    const uint32_t kb = cand_start[q], ke = cand_start[q + 1];
+    int has = 0, b_mn = 0, b_id = 0;
+    long long b_size = 0;
+    uint32_t b_k = 0;
+    for (uint32_t k = kb; k < ke; k++) {
+        const GreedyCand cd = cand[k];
+        if (cd.covered != joined[cd.c]) continue;      // some new member is not a neighbour: infeasible for good
+        // first[c] = the earliest undecided leftover that could still join c (most threads find a smaller one there)
+        if (q < first[cd.c]) atomicMin(&first[cd.c], q);
+        const int32_t id = cid[cd.c];
+        const long long sz = csize[cd.c];
+        if (!has || cd.mn > b_mn || (cd.mn == b_mn && (sz > b_size || (sz == b_size && id < b_id)))) {
+            has = 1; b_mn = cd.mn; b_size = sz; b_id = id; b_k = k;
+        }
+    }
+    if (!has) { status[q] = LS_NEVER; return; }        // :64, whatever happens later
+    choice[q] = b_k;
+    atomicAdd(&counters[0], 1u);                       // tentative joiners of this round
+}
+
+// Accepted iff no earlier undecided leftover can still join (a) the chosen cluster or (b) a feasible cluster that ties
+// with it on score: those are the only clusters whose change before this leftover's turn could alter its pick -- a
+// candidate with a strictly lower score can never overtake (scores only fall as members join, size and id only break
+// ties), and one that becomes infeasible was not the pick anyway.
+__global__ void __launch_bounds__(256)
+k_loop_accept(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
+              const int32_t *__restrict__ joined, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
+              const uint32_t *__restrict__ first, uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot,
+              uint32_t *__restrict__ counters) {
+    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+    if (q == 0) counters[3] = counters[0];             // what the host polls: tentative joiners seen by the last eval
+    if (q >= nl || status[q] != LS_UNDECIDED) return;
+    const uint32_t kb = cand_start[q], ke = cand_start[q + 1];
+    const GreedyCand pick = cand[choice[q]];
+    if (first[pick.c] != q) return;                    // an earlier leftover may still join the pick: wait
+    for (uint32_t k = kb; k < ke; k++) {
+        const GreedyCand cd = cand[k];
+        if (cd.mn == pick.mn && cd.covered == joined[cd.c] && first[cd.c] != q) return;   // a tie that may still grow
+    }
+    status[q] = LS_JOINED;                             // :61-62
+    join_slot[q] = pick.c;
+    accepted[atomicAdd(&counters[1], 1u)] = q;
+}
+
+// One workgroup per accepted join (y -> c): y's later neighbours go into an LDS hash table, chunk by chunk, and the
+// cluster's subscribers probe it -- a subscriber that is a neighbour counts one more covered member and folds the
+// pair's score into its minimum; the others' entries turn infeasible when joined[c] advances.
+constexpr int APPLY_SLOTS = 8192, APPLY_CHUNK = 4096;   // 64 KB of LDS, load factor <= 1/2
+
+template <class NbrT>
+__global__ void __launch_bounds__(256)
+k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, const NbrT *__restrict__ adj,
+             const uint32_t *__restrict__ leftover, const uint8_t *__restrict__ status, GreedyCand *__restrict__ cand,
+             const uint32_t *__restrict__ choice, const uint32_t *__restrict__ accepted, const uint32_t *__restrict__ sub_start,
+             const uint32_t *__restrict__ subs, int32_t *__restrict__ joined, long long *__restrict__ csize,
+             const int32_t *__restrict__ seq_size, uint32_t *__restrict__ counters) {
+    __shared__ uint32_t keys[APPLY_SLOTS];
+    __shared__ int32_t vals[APPLY_SLOTS];
+    const uint32_t n_acc = counters[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = 0;   // next round's eval counts again (nobody reads it here)
+    for (uint32_t a = blockIdx.x; a < n_acc; a += gridDim.x) {   // workgroup-uniform loop
+        const uint32_t q = accepted[a];
+        const uint32_t y = leftover[q];
+        const int32_t c = cand[choice[q]].c;
+        const uint32_t sb = sub_start[c], se = sub_start[c + 1];
+        const uint64_t b = start[y], e = b + up[y];              // later leftovers have larger ids: the upper section
+        for (uint64_t c0 = b; c0 < e; c0 += APPLY_CHUNK) {
+            for (uint32_t sl = threadIdx.x; sl < (uint32_t)APPLY_SLOTS; sl += 256) keys[sl] = 0xFFFFFFFFu;
+            __syncthreads();
+            const uint64_t c1 = min(e, c0 + (uint64_t)APPLY_CHUNK);
+            for (uint64_t k = c0 + threadIdx.x; k < c1; k += 256) {
+                const NbrT nb = adj[k];
+                const uint32_t id = nbr_id(nb);
+                uint32_t sl = (id * 2654435761u) >> 19;          // top 13 bits
+                for (;;) {
+                    const uint32_t old = atomicCAS(&keys[sl], 0xFFFFFFFFu, id);
+                    if (old == 0xFFFFFFFFu) { vals[sl] = nbr_score(nb); break; }   // (ids inside a row are distinct)
+                    sl = (sl + 1) & (APPLY_SLOTS - 1);
+                }
+            }
+            __syncthreads();
+            for (uint32_t s2 = sb + threadIdx.x; s2 < se; s2 += 256) {
+                const uint32_t q2 = subs[2 * (size_t)s2], k2 = subs[2 * (size_t)s2 + 1];
+                if (q2 <= q || status[q2] != LS_UNDECIDED) continue;
+                const uint32_t id = leftover[q2];
+                uint32_t sl = (id * 2654435761u) >> 19;
+                for (;;) {
+                    const uint32_t kk = keys[sl];
+                    if (kk == id) {                              // this entry belongs to leftover q2 alone; one join per cluster and round
+                        cand[k2].covered += 1;
+                        if (vals[sl] < cand[k2].mn) cand[k2].mn = vals[sl];
+                        break;
+                    }
+                    if (kk == 0xFFFFFFFFu) break;
+                    sl = (sl + 1) & (APPLY_SLOTS - 1);
+                }
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            joined[c] += 1;
+            csize[c] += seq_size ? (long long)seq_size[y] : 1ll;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------
-hipError_t launch_csr_degree_scan(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t n,
-                                  bool symmetric, uint32_t *deg, uint32_t *up, uint64_t *start, uint64_t *tile_scratch,
-                                  int *score_range, hipStream_t s) {
-    const int init[3] = {INT_MAX, INT_MIN, 0};
-    hipError_t e = hipMemcpyAsync(score_range, init, sizeof(init), hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_edge_degree, dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg, up,
-                       symmetric ? 1 : 0, score_range, n);
-    launch_scan<uint64_t>(deg, start, n, tile_scratch, nullptr, s);
+EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts) {
+    EdgeSegs sg{};
+    sg.n = HMK_EDGE_SHARDS;
+    for (uint32_t q = 0; q < HMK_EDGE_SHARDS; q++) sg.s[q] = EdgeSeg{edges + (uint64_t)q * cap_per_shard, counts + q, cap_per_shard};
+    return sg;
+}
+
+hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
+                                  uint32_t *up, uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s) {
+    if (segs.n == 0 || segs.n > HMK_MAX_SEGS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_init_range, dim3(1), dim3(64), 0, s, score_range);
+    hipLaunchKernelGGL(k_edge_degree, dim3(512, segs.n), dim3(256), 0, s, segs, deg, up, symmetric ? 1 : 0, score_range, n,
+                       row_limit);
+    launch_scan<uint64_t>(deg, start, row_limit, tile_scratch, nullptr, s);
     return hipGetLastError();
 }
 
-hipError_t launch_csr_scatter(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
-                              bool symmetric, const uint64_t *start, const uint32_t *up, uint32_t *cursor, void *adj,
-                              bool packed, int base, uint32_t n, hipStream_t s) {
+hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, const uint32_t *up,
+                              uint32_t *cursor, void *adj, bool packed, int base, uint32_t row_limit, hipStream_t s) {
     if (packed)
-        hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard,
-                           counts, start, up, cursor, (NbrPacked *)adj, symmetric ? 1 : 0, base, n);
+        hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(512, segs.n), dim3(256), 0, s, segs, start, up, cursor,
+                           (NbrPacked *)adj, symmetric ? 1 : 0, base, row_limit);
     else
-        hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(512, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts,
-                           start, up, cursor, (Nbr *)adj, symmetric ? 1 : 0, base, n);
+        hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(512, segs.n), dim3(256), 0, s, segs, start, up, cursor, (Nbr *)adj,
+                           symmetric ? 1 : 0, base, row_limit);
     return hipGetLastError();
 }
 
@@ -407,6 +611,7 @@ hipError_t launch_pack_rows(const uint64_t *edges, uint64_t cap_per_shard, const
 
 size_t pack_rows_scratch_bytes(uint32_t n) { return ((size_t)2 * n + 2) * 4 + scan_scratch_bytes(n); }
 size_t scan_scratch_bytes(uint32_t n) { return ((size_t)(n + SCAN_TILE - 1) / SCAN_TILE + 1) * 8; }
+size_t scan_total_index(uint32_t n) { return (size_t)(n + SCAN_TILE - 1) / SCAN_TILE; }
 
 hipError_t launch_unpack_rows(const uint32_t *row_start, const uint32_t *adj, uint32_t n, int threshold, uint64_t *out,
                               uint64_t out_capacity, hipStream_t s) {
@@ -431,6 +636,63 @@ hipError_t launch_greedy_precheck(bool fill, bool packed, const uint64_t *start,
 // exclusive scan of uint32 counts into uint32 start[n + 1] (tile_scratch: scan_scratch_bytes(n))
 hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, uint64_t *tile_scratch, hipStream_t s) {
     launch_scan<uint32_t>(counts, start, n, tile_scratch, nullptr, s);
+    return hipGetLastError();
+}
+
+}  // namespace hmk
+
+namespace hmk {
+
+// subscriber lists of the device-side second loop: cursor = zeroed uint32[n_clusters]; pass 0 leaves the counts in it
+hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const GreedyCand *cand, uint32_t *cursor,
+                                   const uint32_t *sub_start, uint32_t *subs, hipStream_t s) {
+    if (nl == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_loop_subscribers, dim3((nl + 255) / 256), dim3(256), 0, s, nl, cand_start, cand, cursor, sub_start, subs,
+                       fill ? 1 : 0);
+    return hipGetLastError();
+}
+
+// one round of the device-side second loop (see k_loop_eval); counters: device uint32[4], first: uint32[n_clusters]
+hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
+                             uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
+                             uint32_t *first, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot, const uint32_t *sub_start,
+                             const uint32_t *subs, int32_t *joined, long long *csize, const int32_t *cid, const int32_t *seq_size,
+                             uint32_t *counters, hipStream_t s) {
+    if (nl == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(first, 0xFF, (size_t)n_clusters * 4, s);
+    if (e != hipSuccess) return e;
+    const dim3 grid((nl + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_loop_eval, grid, block, 0, s, nl, cand_start, cand, joined, csize, cid, status, choice, first, counters);
+    hipLaunchKernelGGL(k_loop_accept, grid, block, 0, s, nl, cand_start, cand, joined, status, choice, first, accepted, join_slot,
+                       counters);
+    const dim3 agrid(2048);
+    if (packed)
+        hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
+                           choice, accepted, sub_start, subs, joined, csize, seq_size, counters);
+    else
+        hipLaunchKernelGGL((k_loop_apply<Nbr>), agrid, block, 0, s, start, up, (const Nbr *)adj, leftover, status, cand, choice,
+                           accepted, sub_start, subs, joined, csize, seq_size, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_lidx(const uint32_t *leftover, uint32_t nl, int32_t *lidx, uint32_t n, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(lidx, 0xFF, (size_t)n * 4, s);   // -1 everywhere
+    if (e != hipSuccess || nl == 0) return e;
+    hipLaunchKernelGGL(k_fill_lidx, dim3((nl + 255) / 256), dim3(256), 0, s, leftover, nl, lidx);
+    return hipGetLastError();
+}
+
+// counts (fill = false: pcnt[k1] = list length) or fills (pcnt = zeroed cursors) the propagation lists
+hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, const uint32_t *up, const void *adj,
+                              const int32_t *lidx, const uint32_t *leftover, uint32_t nl, const uint32_t *cand_start,
+                              const GreedyCand *cand, uint32_t *pcnt, const uint32_t *pstart, GreedyProp *prop, hipStream_t s) {
+    if (nl == 0) return hipSuccess;
+    const dim3 grid(std::min<uint32_t>((nl + 3) / 4, 256 * 16)), block(256);
+#define HMK_PROP(T, F) hipLaunchKernelGGL((k_greedy_prop<T, F>), grid, block, 0, s, start, up, (const T *)adj, lidx, leftover, nl, \
+                                          cand_start, cand, pcnt, pstart, prop)
+    if (packed) { if (fill) HMK_PROP(NbrPacked, true); else HMK_PROP(NbrPacked, false); }
+    else { if (fill) HMK_PROP(Nbr, true); else HMK_PROP(Nbr, false); }
+#undef HMK_PROP
     return hipGetLastError();
 }
 

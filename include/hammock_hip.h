@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMK_ABI_VERSION 1
+#define HMK_ABI_VERSION 2
 #define HMK_ALPHABET 24
 #define HMK_MAX_LEN 32          /* longest sequence the GPU kernels accept */
 #define HMK_MAX_SEQUENCES (1u << 24)
@@ -214,6 +214,28 @@ int hmk_greedy_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges,
 int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edges, int symmetric,
                               int max_clusters, int32_t *cluster_id, int32_t *result_order,
                               int32_t *member_rank, hmk_greedy_stats *stats);
+
+/* Where the time of the last hmk_greedy_cluster / hmk_greedy_from_edges_dev call of this context went
+ * (milliseconds; the span of Hammock.java:406-411 minus the sort).  score_ms and csr_ms are device times (HIP events on
+ * the call's stream), the others host wall time.  The parts overlap (phase 1 runs while the rest of the pair space is
+ * being scored), so they do not add up to total_ms. */
+typedef struct {
+    double plan_ms;          /* tiling plan (cached between calls with the same parameters) */
+    double score_ms;         /* neighbour kernels, first launch to last edge */
+    double csr_ms;           /* edge segments -> CSR adjacency on the device */
+    double wait_rows_ms;     /* host waiting for adjacency rows (band hand-over, later fetches) */
+    double phase1_ms;        /* firstPhase, LimitedGreedySequenceClusterer.java:77-120 (includes wait_rows_ms) */
+    double precheck_ms;      /* device pre-check of the second loop (:59-66) incl. copies */
+    double prop_ms;          /* device join-propagation lists incl. copies (medium inputs) */
+    double device_loop_ms;   /* the second loop on the device in optimistic rounds (large inputs), incl. copies */
+    double host_precheck_ms; /* host-side part between phase 1 and the sequential loop (includes the two above) */
+    double sequential_ms;    /* the order-dependent loop :59-66 itself */
+    double total_ms;
+    uint64_t cand_entries;   /* (leftover, feasible cluster) pairs after phase 1 */
+    uint64_t prop_entries;   /* entries of the join-propagation lists */
+    uint64_t loop_rounds;    /* rounds of the device-side second loop, 0 if the loop ran on the host */
+} hmk_greedy_phases;
+int hmk_greedy_last_phases(const hmk_ctx *ctx, hmk_greedy_phases *out);
 
 #ifdef __cplusplus
 }

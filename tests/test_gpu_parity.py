@@ -303,6 +303,48 @@ def test_greedy_synthetic_vs_oracle(gpu, blosum62, coracle, cfg):
     assert stats.phase1_stop_index == ostats.phase1_stop_index and stats.n_multi == ostats.n_multi
 
 
+@pytest.mark.parametrize("mode", ["device", "lists", "host"])
+@pytest.mark.parametrize("cfg", [(5, 30000, 12, 12, 0, 0), (6, 12000, 7, 20, -1, -4)])
+def test_greedy_second_loop_implementations(gpu, blosum62, coracle, monkeypatch, mode, cfg):
+    """The second loop of cluster() (LimitedGreedySequenceClusterer.java:59-66) has three implementations behind
+    hmk_greedy_cluster -- on the device in optimistic rounds (large inputs), on the host over device-built
+    join-propagation lists (medium), on the host over the fetched adjacency (small / fallback).  Each one, forced
+    through HMK_SECOND_LOOP, must reproduce the oracle's literal loop: ids, list order and member insertion order."""
+    seed, n, lo, hi, p, dthr = cfg
+    res, off = synth_peptides(seed, n, lo, hi)
+    rng = np.random.default_rng(seed)
+    sizes = np.ones(n, dtype=np.int32)
+    sizes[::3] = 1 + rng.integers(0, 9, size=len(sizes[::3]))   # few distinct counts: many size ties, decided by id
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [res[off[k]:off[k + 1]] for k in perm]
+    sizes = sizes[perm]
+    res, off = hammock_amd.pack_sequences(peps)
+    L = np.diff(off.astype(np.int64))
+    thr, X, maxc = po.java_round(L.mean() * 1.7) + dthr, min(po.java_round(L.mean() / 4), int(L.min()) - 1), po.java_round(n * 0.025)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, X, p, thr, maxc, 8)
+    assert st == 0
+    monkeypatch.setenv("HMK_SECOND_LOOP", mode)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
+    cid, order, stats = ctx.greedy_cluster(X, p, thr, maxc)
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+    ph = ctx.greedy_phases()
+    assert (ph["loop_rounds"] > 0) == (mode == "device") and (ph["prop_entries"] > 0) == (mode == "lists")
+
+
+def test_greedy_3e5_vs_oracle(gpu, blosum62, coracle):
+    """3 x 10^5 peptides (between BASELINE configs 3 and 5): the size at which the device-side second loop takes over
+    by itself; identical membership, list order and member order against the oracle's literal greedy."""
+    n = 300000
+    res, off = synth_peptides(1, n, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    cid, order, stats = ctx.greedy_cluster(3, 0, 20, 7500)
+    assert ctx.greedy_phases()["loop_rounds"] > 0
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 20, 7500, 16)
+    assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+
+
 def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
     """hmk_greedy_cluster ships the adjacency to the host as 4-byte entries when the edge scores span at
     most 255 and as 8-byte entries otherwise; both must give the oracle's clustering.  BLOSUM62 x 12 makes

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Per-phase timing of hmk_greedy_cluster (hmk_greedy_last_phases) on synthetic 12-mers.
+
+    python tools/greedy_phases.py 100000 1000000 > gpurun_out/greedy_phases.jsonl
+
+For every n: a fresh context, three calls (first = buffers being sized, then steady state); prints one JSON line
+per call.  Used for profiles/round2_greedy_phases.jsonl."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hammock_amd  # noqa: E402
+from hammock_amd.synth import synth_peptides  # noqa: E402
+
+with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+    M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+
+for n in [int(a) for a in sys.argv[1:]] or [100000]:
+    lo, hi = (12, 12)
+    res, off = synth_peptides(1, n, lo, hi)
+    maxc = int(np.floor(n * 0.025 + 0.5))
+    ctx = hammock_amd.Context(M, device=0)
+    ctx.set_sequences(residues=res, offsets=off)
+    ref = None
+    for call in range(3):
+        t = time.perf_counter()
+        cid, order, st = ctx.greedy_cluster(3, 0, 20, maxc)
+        wall = time.perf_counter() - t
+        if ref is None:
+            ref = (cid.copy(), order.copy())
+        assert np.array_equal(cid, ref[0]) and np.array_equal(order, ref[1])
+        line = {"n": n, "call": call, "wall_ms": wall * 1e3, "clusters": int(st.n_multi), "result_list": int(st.n_result_clusters),
+                "edges": int(st.n_edges), "phase1_stop_index": int(st.phase1_stop_index)}
+        line.update(ctx.greedy_phases())
+        print(json.dumps(line), flush=True)
+    ctx.close()
