@@ -34,7 +34,9 @@ N_SEQ = 100_000
 SEQ_LEN = 12
 MAX_SHIFT, SHIFT_PENALTY, THRESHOLD = 3, 0, 20
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-LDS_LOOKUP_PEAK = 256 * 32 * 2.4e9   # ds_read_b64: 32 lanes/clk/CU x 256 CUs x 2.4 GHz
+# MI355X_MICROARCH.md, LDS table: ds_read_b64 = 2 LDS cycles per wave-instruction = 256 B/clk/CU; 256 CUs at 2.4 GHz
+LDS_PEAK_GBS = 256 * 256 * 2.4          # 157,286 GB/s ("~150 TB/s aggregate for ds_read_b64/b128")
+LDS_BYTES_PER_PAIR = SEQ_LEN * 8        # one 8-byte table entry (7 shift lanes + 1 pad) per column position
 
 
 def load_blosum62():
@@ -44,17 +46,48 @@ def load_blosum62():
 
 def pmc_traffic(n, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/round1_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
+    (profiles/round2_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
     command, gfx950 x2 read correction applied).  Counters cannot be read from inside the timed
     run, so the value is only reported for the workload it was collected on; otherwise null."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_summary.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "round2_pmc_summary.json")) as fh:
             d = json.load(fh)
         if n == N_SEQ and world == 1:
             return d["hbm_traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, cut by the cgroup CPU quota if there is one
+    (a GPU box hands out a share of a large host; OpenMP teams larger than the share only spin against each other)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    why = "affinity mask"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            q = max(1, int(int(quota) / int(period)))
+            if q < n:
+                n, why = q, f"cgroup cpu.max {quota}/{period}"
+    except (OSError, ValueError):
+        pass
+    return n, why
 
 
 def cpu_baseline(M, res, off, n_sample, threads):
@@ -72,7 +105,8 @@ def cpu_baseline(M, res, off, n_sample, threads):
                                                     int(np.floor(n_sample * 0.025 + 0.5)), threads)
     dt = time.perf_counter() - t0
     calls = int(stats.score_calls_phase1 + stats.score_calls_phase2)
-    return {"value": calls / dt, "unit": "pair scores/s", "cores": threads, "kind": "port",
+    return {"value": calls / dt, "unit": "pair scores/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "nproc": os.cpu_count(),
             "sample": f"oracle greedy (sort + cluster, Hammock.java:406-411) on the first {n_sample} peptides of the "
                       f"workload: {calls} sequenceScore calls in {dt:.2f} s, status {st}",
             "seconds": dt, "score_calls": calls,
@@ -86,7 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=N_SEQ, help="number of synthetic peptides (default: the BASELINE workload)")
     ap.add_argument("--cpu-sample", type=int, default=100000,
-                    help="peptides in the CPU baseline sample (default: the whole workload, about 4 s on 16 threads)")
+                    help="peptides in the CPU baseline sample (default: the whole workload, about 4 s on 16 threads; "
+                         "bounded: the default run stays within a few minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-greedy", action="store_true")
     args = ap.parse_args()
@@ -205,6 +240,20 @@ def main():
     kern_ms = float(kern_ms.item())
     assert int(tot_pairs.item()) == pairs_total, (int(tot_pairs.item()), pairs_total)
 
+    e2e = None
+    if world > 1 and not args.no_greedy:
+        # end to end on N GPUs: one more scored + exchanged pass, then the merge on rank 0 from the gathered graph
+        # (hmk_greedy_from_edges_dev) and the broadcast of the cluster ids
+        dist.barrier()
+        t = time.perf_counter()
+        px.step()
+        gathered = px.last_result()
+        cid, order, info = hd.merge_and_broadcast(ctx, gathered, True, THRESHOLD, int(np.floor(n * 0.025 + 0.5)))
+        torch.cuda.synchronize(dev)
+        e2e = {"wall_s": time.perf_counter() - t, "result_list": int(len(order)),
+               "clusters": int(np.sum(np.bincount(np.unique(cid, return_inverse=True)[1]) > 1)),
+               "phases_ms_rank0": ctx.greedy_phases() if rank == 0 else None,
+               "note": "score (sharded) + RCCL all-gather + unpack + merge on rank 0 + broadcast of the ids"}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total / (elapsed / args.steps)
@@ -214,43 +263,57 @@ def main():
         alg_bytes = 8 * n_edges_rank + 16 * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         lookups = pairs_rank * SEQ_LEN / (kern_ms * 1e-3)
+        lds_gbs = pairs_rank * LDS_BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "pairwise BLOSUM62 ShiftedScorer scores/sec (all-vs-all, thresholded neighbour list)",
             "value": value, "unit": "pair scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8 (8-bit SWAR lanes, host-proven ranges with 16-bit / literal fallbacks; scores are int32-exact)",
+            "data": "synthetic",
             "config": {"workload": f"{n} synthetic length-{SEQ_LEN} peptides (SplitMix64 seed 1), BLOSUM62, max_shift "
                                    f"{MAX_SHIFT}, shift_penalty {SHIFT_PENALTY}, threshold {THRESHOLD}; "
                                    f"{pairs_total} unordered pairs per step",
                        "parallelism": f"row-block sharding over {world} GPU(s)" + (
                            ", per-step RCCL all-gather of the edge blocks (4-byte row-block format) on a second stream "
                            "(overlaps the next pass)" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, world),
+            # the BINDING roofline first (LDS gather, not HBM): bytes the kernel must read from LDS
+            "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                         "frac": lds_gbs / LDS_PEAK_GBS, "traffic": pmc_traffic(n, world),
                          "kernel": "k_neighbors_swar<2, 6, 2, 12, true> (NW=2 dwords/entry, 6 rows/tile, 2 columns/lane, length 12 exact)",
                          "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "HBM does not bind this path (SURVEY.md 8d): the kernel is bound by LDS lookups",
-                         "lds": {"achieved_lookups_per_s": lookups, "peak_lookups_per_s": LDS_LOOKUP_PEAK,
-                                 "frac": lookups / LDS_LOOKUP_PEAK,
-                                 "definition": "12 ds_read_b64 table lookups per pair / (32 lanes/clk/CU x 256 CU x 2.4 GHz)"}},
+                         "definition": f"{LDS_BYTES_PER_PAIR} LDS bytes per pair ({SEQ_LEN} ds_read_b64 table lookups) x pairs per launch / "
+                                       "kernel time, against 256 B/clk/CU x 256 CU x 2.4 GHz (MI355X_MICROARCH.md, LDS table)",
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/round2_pmc_summary.json); "
+                                         "null when the workload differs from the one the counters were collected on",
+                         "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+                                 "note": "8 B per emitted edge + 16 B per peptide read once; HBM does not bind this path"}},
             "edges_per_step": int(tot_edges.item()),
         }
         if px is not None:
             line["exchange"] = {"format": px.fmt, "gathered_bytes_per_rank_per_step": px.bytes_per_step,
                                 "collectives_per_step": 1}
+        maxc = int(np.floor(n * 0.025 + 0.5))
+        if e2e is not None:
+            line["greedy_end_to_end"] = e2e
         if world == 1:
             if not args.no_greedy:
+                ctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, maxc)   # first call sizes the context's buffers
+                first = ctx.greedy_phases()
                 t = time.perf_counter()
-                cid, order, gstats = ctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, int(np.floor(n * 0.025 + 0.5)))
+                cid, order, gstats = ctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, maxc)
+                wall = time.perf_counter() - t
                 line["greedy_end_to_end"] = {
-                    "wall_s": time.perf_counter() - t, "score_and_csr_ms": gstats.neighbors_ms,
-                    "merge_ms_incl_wait_for_d2h": gstats.greedy_ms, "clusters": int(gstats.n_multi),
-                    "result_list": int(gstats.n_result_clusters),
-                    "note": "input order as generated (Hammock -R input); scoring + CSR build on the GPU, then the "
-                            "adjacency copy overlaps the merge (whose pre-check runs on the GPU)"}
+                    "wall_s": wall, "first_call_s": first["total_ms"] * 1e-3, "clusters": int(gstats.n_multi),
+                    "result_list": int(gstats.n_result_clusters), "phases_ms": ctx.greedy_phases(),
+                    "note": "hmk_greedy_cluster = the span of Hammock.java:409 (input order as generated, -R input): scoring, "
+                            "CSR, phase 1 on the host over the band rows while the rest is scored, second loop on the device or "
+                            "over device-built lists; phases overlap (see include/hammock_hip.h hmk_greedy_phases)"}
             if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(M, res, off, min(args.cpu_sample, n), min(16, os.cpu_count() or 1))
+                cores, why = usable_cores()
+                cores = min(cores, int(os.environ.get("HMK_BENCH_CPU_THREADS", "64")))   # the oracle's teams stop scaling well before that
+                line["cpu_baseline"] = cpu_baseline(M, res, off, min(args.cpu_sample, n), cores)
+                line["cpu_baseline"]["cores_chosen_by"] = why
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -125,19 +125,21 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 // record: [0] column (sorted position), [1] row within the tile, [2..] the NW
 // accumulator dwords (SWAR) or the score itself (direct, NW == 0).
 template <int NW>
-__device__ __forceinline__ void flush_stage(const uint32_t *stage, uint32_t cnt, const NeighborParams &P,
+__device__ __forceinline__ void flush_stage(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
                                             const Tile &T, int g, bool lane16, uint32_t shard) {
     constexpr int REC_DW = (NW == 0) ? 3 : NW + 2;
     if (cnt == 0) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
-    const uint32_t lane = lane_id();
+    // threadIdx.x lives in v0 for the whole kernel; an mbcnt-derived lane id is hoisted out of the tile loop by the
+    // compiler and then SPILLED to scratch there (8 bytes per lane and tile: +45 MB of HBM writes on the 10^5 pass)
+    const uint32_t lane = threadIdx.x & 63u;
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(&P.counts[shard], (unsigned long long)cnt);
     const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
     const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
     base = ((unsigned long long)bhi << 32) | blo;
     for (uint32_t k = lane; k < cnt; k += 64) {
-        const uint32_t *rec = stage + k * REC_DW;
+        const HMK_LDS uint32_t *rec = stage + k * REC_DW;
         const uint32_t col = rec[0], r = rec[1];
         int score;
         if (NW == 0) {

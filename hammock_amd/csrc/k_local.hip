@@ -227,7 +227,7 @@ k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_
     const int la = Cp->la, lb = Cp->lb;   // la: row (seq1) length, lb: column (seq2) length
     const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
     const int tid = threadIdx.x;
-    uint32_t *stage = stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
     for (int e = tid; e < 576; e += 256) m8[e] = (int8_t)Mg[e];
     for (int e = tid; e < R * 32; e += 256) {
@@ -279,7 +279,7 @@ k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_
                     cnt = 0;
                 }
                 if (keep) {
-                    uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                    HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
                     rec[0] = col;
                     rec[1] = r;
                     rec[2] = (uint32_t)gmax;
@@ -385,7 +385,7 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
     const int la = Cp->la, lb = Cp->lb;
     const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
     const int tid = threadIdx.x;
-    uint32_t *stage = stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
     for (int e = tid; e < 576; e += 256) m8[e] = (int8_t)Mg[e];
     for (int e = tid; e < R * 32; e += 256) {
@@ -451,7 +451,7 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
                         cnt = 0;
                     }
                     if (keep) {
-                        uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                        HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
                         rec[0] = colv[h];
                         rec[1] = r;
                         rec[2] = (uint32_t)gmax;

@@ -55,7 +55,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
-    uint32_t *stage = stage_all + wave * (STAGE_CAP * REC_DW);
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + wave * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
     // ---- stage the matrix and the row residues ---------------------------------
     for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
@@ -183,7 +183,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
                         }
                         const uint64_t mask = __ballot(keep);
                         if (keep) {
-                            uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                            HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
                             rec[0] = col;
                             rec[1] = (uint32_t)r;
 #pragma unroll
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
     const uint32_t himask = lane16 ? 0x80008000u : 0x80808080u;
     const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
     const int tid = threadIdx.x;
-    uint32_t *stage = stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
     for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
     for (int e = tid; e < R * 32; e += 256) {
@@ -469,7 +469,7 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
                             if (lane16) mx = max(mx, max(dw & 0xFFFFu, dw >> 16));
                             else mx = max(mx, max(max(dw & 0xFFu, (dw >> 8) & 0xFFu), max((dw >> 16) & 0xFFu, dw >> 24)));
                         }
-                        uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                        HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
                         rec[0] = col;
                         rec[1] = (uint32_t)r;
                         rec[2] = (uint32_t)((int)mx - g);
@@ -502,7 +502,7 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
     const int la = Cp->la, lb = Cp->lb;
     const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
     const int tid = threadIdx.x;
-    uint32_t *stage = stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
     for (int e = tid; e < 576; e += 256) M[e] = Mg[e];
     for (int e = tid; e < R * 8; e += 256) {
@@ -542,7 +542,7 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
             const uint64_t mask = __ballot(keep);
             if (mask != 0) {
                 if (keep) {
-                    uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                    HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
                     rec[0] = col;
                     rec[1] = r;
                     rec[2] = (uint32_t)score;

@@ -102,42 +102,62 @@ def all_gather_rows(ctx: Context, d_edges, d_counts, capacity, threshold, group=
     return out
 
 
+class RemoteMergeError(RuntimeError):
+    """The merge on rank 0 failed; raised on every OTHER rank with rank 0's message (rank 0 re-raises its own error)."""
+
+
 def merge_and_broadcast(ctx: Context, edges_all: torch.Tensor, symmetric: bool, threshold, max_clusters, group=None):
-    """Host greedy merge on rank 0 (hmk_greedy_from_edges), result broadcast to every rank.
+    """Host greedy merge on rank 0 (hmk_greedy_from_edges[_dev]), result broadcast to every rank.
     -> (cluster_id int32[n], result_order int32[n_result], status dict).  A reference crash
-    (NullPointerException parity) is raised on every rank."""
+    (NullPointerException parity) is raised on every rank; so is ANY other failure of rank 0 (device error, out of
+    memory, bad edges): rank 0 always reaches the broadcasts and ships its status first, so no rank is left waiting in
+    a collective for the timeout."""
+    from .api import ReferenceWouldCrash
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
     n = ctx.n
     dev = edges_all.device
-    header = torch.zeros(4, dtype=torch.int64, device=dev)  # status, n_result, crash_case, crash_index
+    MSG = 512
+    # status (0 ok, HMK_ERR_REFERENCE_WOULD_CRASH, -1 other failure), n_result, crash_case, crash_index, message length
+    header = torch.zeros(5, dtype=torch.int64, device=dev)
+    message = torch.zeros(MSG, dtype=torch.uint8, device=dev)
     cid = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
     order = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
     err = None
+    stats = None
     if rank == 0:
-        from .api import ReferenceWouldCrash
         try:
             if edges_all.is_cuda and ctx.device >= 0:
-                # the gathered graph is already on this GPU: adjacency built there, one pinned copy, host merge
+                # the gathered graph is already on this GPU: adjacency and the second loop stay there
                 torch.cuda.current_stream(edges_all.device).synchronize()
-                c, o, st = ctx.greedy_from_edges_dev(edges_all.data_ptr(), edges_all.numel(), symmetric, max_clusters)
+                c, o, stats = ctx.greedy_from_edges_dev(edges_all.data_ptr(), edges_all.numel(), symmetric, max_clusters)
             else:
                 edges = edges_all.cpu().numpy().view(np.uint64)
-                c, o, st = ctx.greedy_from_edges(edges, symmetric, threshold, max_clusters)
+                c, o, stats = ctx.greedy_from_edges(edges, symmetric, threshold, max_clusters)
             header[1] = len(o)
             cid[:n] = torch.from_numpy(c).to(dev)
             order[:len(o)] = torch.from_numpy(o).to(dev)
         except ReferenceWouldCrash as e:
             err = e
             header[0], header[2], header[3] = N.HMK_ERR_REFERENCE_WOULD_CRASH, e.case, e.index
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        except Exception as e:  # noqa: BLE001 -- every failure must reach the other ranks before anyone raises
+            err = e
+            text = f"{type(e).__name__}: {e}".encode("utf-8", "replace")[:MSG]
+            header[0], header[4] = -1, len(text)
+            message[:len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(dev)
+    if multi:
         dist.broadcast(header, 0, group=group)
+        dist.broadcast(message, 0, group=group)
         dist.broadcast(cid, 0, group=group)
         dist.broadcast(order, 0, group=group)
     h = header.tolist()
     if h[0] == N.HMK_ERR_REFERENCE_WOULD_CRASH:
-        from .api import ReferenceWouldCrash
         raise err or ReferenceWouldCrash("the reference throws NullPointerException here", h[2], h[3])
-    return cid[:n].cpu().numpy(), order[:h[1]].cpu().numpy(), {"n_result_clusters": h[1]}
+    if h[0] != 0:
+        if err is not None:
+            raise err
+        raise RemoteMergeError("greedy merge failed on rank 0: " + bytes(message[:h[4]].tolist()).decode("utf-8", "replace"))
+    return cid[:n].cpu().numpy(), order[:h[1]].cpu().numpy(), {"n_result_clusters": h[1], "stats": stats}
 
 
 def greedy_cluster_distributed(ctx: Context, max_shift, shift_penalty, threshold, max_clusters, device, group=None):

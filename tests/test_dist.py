@@ -73,6 +73,50 @@ def test_gloo_world2_exchange_and_merge():
     assert out[0][2] == out[1][2] == out[0][3] + out[1][3]  # every rank holds the union
 
 
+def _cpu_worker_rank0_fails(rank, world, port, q):
+    """rank 0's merge fails with something other than the reference-crash parity case (here: an edge that names a
+    sequence outside [0, n)): every rank must come back with an error instead of waiting in a broadcast."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import json
+    import hammock_amd
+    from hammock_amd import dist as hd
+    from oracle import c_oracle
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+    peps = random_peptides(np.random.default_rng(1), 50, 12, 12, alphabet=5)
+    res, off = c_oracle.pack(peps)
+    ctx = hammock_amd.Context(M, device=-1)
+    ctx.set_sequences(residues=res, offsets=off)
+    bad = hammock_amd.pack_edges(np.array([3]), np.array([50]), np.array([25]))   # m == n
+    allv = torch.from_numpy(bad.view(np.int64).copy())
+    try:
+        hd.merge_and_broadcast(ctx, allv, True, 20, 5)
+        q.put((rank, "no error", ""))
+    except hd.RemoteMergeError as e:
+        q.put((rank, "remote", str(e)))
+    except ValueError as e:
+        q.put((rank, "local", str(e)))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_rank0_failure_reaches_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cpu_worker_rank0_fails, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][:2] == (0, "local") and "outside" in out[0][2]
+    assert out[1][:2] == (1, "remote") and "outside" in out[1][2]
+
+
 def _gpu_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
