@@ -25,7 +25,7 @@ HMK_MAX_LEN = 32
 
 # every symbol include/hammock_hip.h declares
 SYMBOLS = [
-    "hmk_abi_version", "hmk_last_kernel_ms", "hmk_create", "hmk_destroy", "hmk_last_error", "hmk_set_sequences",
+    "hmk_abi_version", "hmk_last_kernel_ms", "hmk_create", "hmk_create_multi", "hmk_device_count", "hmk_destroy", "hmk_last_error", "hmk_set_sequences",
     "hmk_score_pairs_shifted", "hmk_score_with_shift", "hmk_score_pairs_local", "hmk_score_block_shifted", "hmk_score_block_local",
     "hmk_neighbors_shifted", "hmk_neighbors_local", "hmk_neighbors_shifted_dev", "hmk_compact_edges_dev", "hmk_pack_rows_dev", "hmk_unpack_rows_dev",
     "hmk_neighbors_last_plan",
@@ -81,6 +81,8 @@ def _load():
     L.hmk_last_kernel_ms.argtypes = [vp]
     L.hmk_last_kernel_ms.restype = C.c_double
     L.hmk_create.argtypes = [p_i32, i32, C.POINTER(vp)]
+    L.hmk_create_multi.argtypes = [p_i32, C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    L.hmk_device_count.argtypes = [vp]
     L.hmk_destroy.argtypes = [vp]
     L.hmk_destroy.restype = None
     L.hmk_last_error.argtypes = [vp]

@@ -94,10 +94,18 @@ def pack_edges(x, m, score) -> np.ndarray:
 class Context:
     """1:1 wrapper of hmk_ctx.  device >= 0: HIP ordinal; -1: host-only."""
 
-    def __init__(self, matrix, device: int = 0):
+    def __init__(self, matrix, device=0):
+        """device: a HIP ordinal, -1 (host only), or a list of ordinals (hmk_create_multi: the first is the root)."""
         self._h = C.c_void_p()
         self.matrix = np.ascontiguousarray(np.asarray(matrix, dtype=np.int32).reshape(24, 24))
-        st = N.lib.hmk_create(_ptr(self.matrix, C.c_int32), int(device), C.byref(self._h))
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*[int(d) for d in device])
+            st = N.lib.hmk_create_multi(_ptr(self.matrix, C.c_int32), devs, len(device), C.byref(self._h))
+            self.devices = [int(d) for d in device]
+            device = self.devices[0] if self.devices else -1
+        else:
+            st = N.lib.hmk_create(_ptr(self.matrix, C.c_int32), int(device), C.byref(self._h))
+            self.devices = [int(device)] if int(device) >= 0 else []
         if st:
             self._h = C.c_void_p()
             self._raise(st, None)

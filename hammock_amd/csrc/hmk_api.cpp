@@ -122,6 +122,10 @@ struct hmk_ctx {
     unsigned long long *h_counts = nullptr;  // pinned: final segment counts [16], band snapshot [16], misc [8]
     hmk_greedy_phases phases{};
 
+    // hmk_create_multi: this context is the root (devices[0]); one sub-context per further device, each with its own
+    // copy of the sequences, its plan (shard d of n) and its edge buffer.  Empty for a single-device context.
+    std::vector<hmk_ctx *> peers;
+
     std::string err;
     std::mutex mu;
 };
@@ -892,6 +896,8 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
 
 void hmk_destroy(hmk_ctx *ctx) {
     if (!ctx) return;
+    for (hmk_ctx *peer : ctx->peers) hmk_destroy(peer);
+    ctx->peers.clear();
     if (ctx->has_device) {
         (void)hipSetDevice(ctx->device);
         free_plan(ctx->plan);
@@ -973,6 +979,10 @@ int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *off
     ctx->len.swap(len);
     ctx->min_len = n ? mn : 0;
     ctx->max_len = mx;
+    for (hmk_ctx *peer : ctx->peers) {   // every device holds all residues (row-block sharding)
+        const int st = hmk_set_sequences(peer, residues, offsets, sizes, n);
+        if (st) return fail(ctx, st, "device " + std::to_string(peer->device) + ": " + peer->err);
+    }
     return HMK_OK;
 }
 
@@ -1161,6 +1171,8 @@ int hmk_greedy_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges,
 namespace {
 
 constexpr int ST_RETRY_OVERFLOW = 1000;   // internal: an edge segment overflowed, grow the buffer and score again
+// layout of the small pinned block hmk_ctx::h_counts (64-bit words)
+enum { HC_COUNTS = 0, HC_BAND = 16, HC_PEER = 32, HC_RANGE = 64, HC_MISC = 72, HC_TOTAL = 80, HC_WORDS = 96 };
 
 hipError_t ensure_buf(hmk_ctx *ctx, int which, size_t bytes) {
     DevBuf &b = ctx->sb[which];
@@ -1200,7 +1212,7 @@ int greedy_streams(hmk_ctx *ctx) {
     HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_hi));
     for (hipEvent_t *ev : {&ctx->ev_t0, &ctx->ev_band, &ctx->ev_edges, &ctx->ev_csr, &ctx->ev_bandcsr}) HIPCHK(ctx, hipEventCreate(ev));
-    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, 64 * sizeof(unsigned long long), hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, HC_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     return HMK_OK;
 }
 
@@ -1249,7 +1261,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, ((size_t)n + 1) * 8 + (size_t)n * 4 + 64, 0));
     uint64_t *h_start = (uint64_t *)ctx->h_start;
     uint32_t *h_up = (uint32_t *)((char *)ctx->h_start + ((size_t)n + 1) * 8);
-    int *h_range = (int *)(ctx->h_counts + 40);
+    int *h_range = (int *)(ctx->h_counts + HC_RANGE);
 
     HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_DEG), 0, (size_t)n * 4, S));
     HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_UP), 0, (size_t)n * 4, S));
@@ -1286,7 +1298,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         HIPCHK(ctx, launch_csr_degree_scan(src.band_segs, n, R1, symmetric, buf<uint32_t>(ctx, SB_BDEG), buf<uint32_t>(ctx, SB_BUP),
                                            buf<uint64_t>(ctx, SB_BSTART), buf<uint64_t>(ctx, SB_BSCAN), buf<int>(ctx, SB_BRANGE), C));
         HIPCHK(ctx, hipMemcpyAsync(h_start, buf<uint64_t>(ctx, SB_BSTART), ((size_t)R1 + 1) * 8, hipMemcpyDeviceToHost, C));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + 16, src.band_segs.s[0].count, HMK_EDGE_SHARDS * sizeof(unsigned long long),
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count, HMK_EDGE_SHARDS * sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, C));
         HIPCHK(ctx, hipEventRecord(ctx->ev_bandcsr, C));
         band_pending = true;
@@ -1341,7 +1353,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             band_pending = false;
             e = hipEventSynchronize(ctx->ev_bandcsr);
             bool ok = e == hipSuccess;
-            for (int q = 0; q < HMK_EDGE_SHARDS && ok; q++) ok = ctx->h_counts[16 + q] <= src.seg_cap;
+            for (int q = 0; q < HMK_EDGE_SHARDS && ok; q++) ok = ctx->h_counts[HC_BAND + q] <= src.seg_cap;
             if (ok) {
                 const uint64_t entries = h_start[R1];
                 e = ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz);
@@ -1419,7 +1431,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = launch_greedy_precheck(false, packed, d_start, d_adj, d_cof, d_usize, d_left, nl, d_cnt, nullptr,
                                                         nullptr, d_over, S);
         if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, S);
-        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + 48);
+        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
         if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, S);
         if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[1], d_cstart + nl, 4, hipMemcpyDeviceToHost, S);
         if (r == hipSuccess) r = hipStreamSynchronize(S);
@@ -1491,7 +1503,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CID), cids.data(), (size_t)ncl * 4, hipMemcpyHostToDevice, S);
         if (r == hipSuccess && ctx->has_sizes)
             r = hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, S);
-        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + 48);
+        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
         uint32_t rounds = 0;
         bool done = false;
         // every round accepts at least the earliest tentative joiner, so nl + 1 rounds always suffice; the host looks at
@@ -1550,7 +1562,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = launch_greedy_prop(false, packed, d_start, d_up, d_adj, d_lidx, d_left, nl, d_cstart,
                                                     buf<GreedyCand>(ctx, SB_CAND), d_pcnt, nullptr, nullptr, S);
         if (r == hipSuccess) r = launch_scan_u32(d_pcnt, d_pstart, total_c, d_scan, S);
-        unsigned long long *h_total = ctx->h_counts + 56;   // the scan's 64-bit grand total (its uint32 start[] may wrap)
+        unsigned long long *h_total = ctx->h_counts + HC_TOTAL;   // the scan's 64-bit grand total (its uint32 start[] may wrap)
         if (r == hipSuccess) r = hipMemcpyAsync(h_total, d_scan + scan_total_index(total_c), 8, hipMemcpyDeviceToHost, S);
         if (r == hipSuccess) r = hipStreamSynchronize(S);
         if (r != hipSuccess) return true;
@@ -1614,6 +1626,9 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     return HMK_OK;
 }
 
+int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters, int32_t *cluster_id,
+                         int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats);
+
 }  // namespace
 
 extern "C" {
@@ -1632,6 +1647,8 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (st) return st;
     st = greedy_streams(ctx);
     if (st) return st;
+    if (!ctx->peers.empty())
+        return greedy_cluster_multi(ctx, max_shift, shift_penalty, threshold, max_clusters, cluster_id, result_order, member_rank, stats);
     const auto t0 = std::chrono::steady_clock::now();
     const uint32_t n = ctx->n;
     hipStream_t S = ctx->gstream;
@@ -1706,6 +1723,162 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     return st;
 }
 
+}  // extern "C"
+
+namespace {
+
+// hmk_greedy_cluster on a multi-device context: every device scores its row-block shard (no collective in the scoring),
+// the peers' edges travel to the root over xGMI as direct peer copies -- one transfer per segment, every peer over its
+// own link to the root -- and the root runs the usual tail on the union (CSR on the device, merge).
+int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters, int32_t *cluster_id,
+                         int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<hmk_ctx *> devs;
+    devs.push_back(ctx);
+    for (hmk_ctx *peer : ctx->peers) devs.push_back(peer);
+    const uint32_t G = (uint32_t)devs.size();
+    const uint32_t n = ctx->n;
+    if (HMK_EDGE_SHARDS + G - 1 > HMK_MAX_SEGS) return fail(ctx, HMK_ERR_BAD_ARG, "too many devices for one context");
+    // ---- launch every shard -----------------------------------------------------------------------------------
+    const uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006) / G * 1.25) + (1u << 20);
+    for (uint32_t d = 0; d < G; d++) {
+        hmk_ctx *c = devs[d];
+        int st = need_device(c);
+        if (st == HMK_OK) st = greedy_streams(c);
+        if (st) return d ? fail(ctx, st, c->err) : st;
+        if (!c->d_counts) HIPCHK(ctx, hipMalloc((void **)&c->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
+    }
+    std::vector<char> pending(G, 1);
+    for (int attempt = 0; attempt < 4; attempt++) {
+        bool any = false;
+        for (uint32_t d = 0; d < G; d++) {
+            if (!pending[d]) continue;
+            any = true;
+            hmk_ctx *c = devs[d];
+            int st = need_device(c);
+            if (st) return fail(ctx, st, c->err);
+            uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)HMK_EDGE_SHARDS * 65536, c->d_edges_cap});
+            if (attempt > 0) {   // a segment overflowed: size to the counts of the last pass
+                unsigned long long mx = 0;
+                for (int q = 0; q < HMK_EDGE_SHARDS; q++) mx = std::max(mx, c->h_counts[q]);
+                cap = std::max<uint64_t>(cap, (uint64_t)HMK_EDGE_SHARDS * (mx + mx / 8 + 1024));
+            }
+            cap = (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
+            if (c->d_edges_cap < cap) {
+                if (c->d_edges) (void)hipFree(c->d_edges);
+                c->d_edges = nullptr;
+                c->d_edges_cap = 0;
+                HIPCHK(ctx, hipMalloc((void **)&c->d_edges, cap * sizeof(uint64_t)));
+                c->d_edges_cap = cap;
+            }
+            if (d == 0) HIPCHK(ctx, hipEventRecord(c->ev_t0, c->gstream));
+            st = neighbors_dev_locked(c, max_shift, shift_penalty, threshold, d, G, c->d_edges, c->d_edges_cap, c->d_counts, c->gstream);
+            if (st) return d ? fail(ctx, st, c->err) : st;
+            HIPCHK(ctx, hipMemcpyAsync(c->h_counts, c->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                       c->gstream));
+            HIPCHK(ctx, hipEventRecord(c->ev_edges, c->gstream));
+        }
+        if (!any) break;
+        for (uint32_t d = 0; d < G; d++) {
+            if (!pending[d]) continue;
+            hmk_ctx *c = devs[d];
+            int st = need_device(c);
+            if (st) return fail(ctx, st, c->err);
+            HIPCHK(ctx, hipEventSynchronize(c->ev_edges));
+            unsigned long long mx = 0;
+            for (int q = 0; q < HMK_EDGE_SHARDS; q++) mx = std::max(mx, c->h_counts[q]);
+            pending[d] = mx > c->d_edges_cap / HMK_EDGE_SHARDS;
+        }
+    }
+    for (uint32_t d = 0; d < G; d++)
+        if (pending[d]) return fail(ctx, HMK_ERR_DEVICE, "internal edge buffer kept overflowing");
+    // ---- gather the peers' segments to the root --------------------------------------------------------------
+    int st = need_device(ctx);
+    if (st) return st;
+    uint64_t total = 0, peer_total = 0;
+    std::vector<uint64_t> shard_total(G, 0);
+    for (uint32_t d = 0; d < G; d++) {
+        for (int q = 0; q < HMK_EDGE_SHARDS; q++) shard_total[d] += devs[d]->h_counts[q];
+        total += shard_total[d];
+        if (d) peer_total += shard_total[d];
+    }
+    HIPCHK(ctx, ensure_buf(ctx, SB_PEER, std::max<uint64_t>(peer_total, 1) * sizeof(uint64_t)));
+    HIPCHK(ctx, ensure_buf(ctx, SB_PEERCNT, HMK_MAX_SEGS * sizeof(unsigned long long)));
+    hipStream_t S = ctx->gstream;
+    EdgeSource src;
+    src.symmetric = ctx->symmetric;
+    src.segs = shard_segments(ctx->d_edges, ctx->d_edges_cap / HMK_EDGE_SHARDS, ctx->d_counts);
+    uint64_t off = 0;
+    for (uint32_t d = 1; d < G; d++) {
+        hmk_ctx *c = devs[d];
+        const uint64_t seg = c->d_edges_cap / HMK_EDGE_SHARDS;
+        uint64_t *dst0 = buf<uint64_t>(ctx, SB_PEER) + off;
+        for (int q = 0; q < HMK_EDGE_SHARDS; q++) {
+            const uint64_t cnt = c->h_counts[q];
+            if (!cnt) continue;
+            HIPCHK(ctx, hipMemcpyPeerAsync(buf<uint64_t>(ctx, SB_PEER) + off, ctx->device, c->d_edges + (uint64_t)q * seg, c->device,
+                                           cnt * sizeof(uint64_t), S));
+            off += cnt;
+        }
+        ctx->h_counts[HC_PEER + d] = shard_total[d];
+        src.segs.s[src.segs.n++] = EdgeSeg{dst0, buf<unsigned long long>(ctx, SB_PEERCNT) + d, shard_total[d]};
+    }
+    HIPCHK(ctx, hipMemcpyAsync(buf<unsigned long long>(ctx, SB_PEERCNT), &ctx->h_counts[HC_PEER], G * sizeof(unsigned long long),
+                               hipMemcpyHostToDevice, S));
+    const long long top = (long long)ctx->max_len * std::max(0, ctx->max_m) +
+                          (long long)std::max(0, shift_penalty) * ((ctx->max_len - ctx->min_len) + 2LL * max_shift);
+    src.format_known = true;
+    src.packed = top - threshold <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr;
+    src.base = threshold;
+    src.total_known = total;
+    src.adj_bound = (ctx->symmetric ? 2 : 1) * total;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
+    st = cluster_on_device(ctx, src, max_clusters, cluster_id, result_order, member_rank, stats, t0);
+    if (st == ST_RETRY_OVERFLOW) return fail(ctx, HMK_ERR_DEVICE, "internal edge buffer overflow");
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_edges) == hipSuccess) ctx->phases.score_ms = ms;   // root shard + gather
+    if (hipEventElapsedTime(&ms, ctx->ev_edges, ctx->ev_csr) == hipSuccess) ctx->phases.csr_ms = ms;
+    ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    stats->neighbors_ms = ctx->phases.score_ms;
+    return st;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hmk_create_multi(const int32_t *matrix, const int *devices, int n_devices, hmk_ctx **out) {
+    if (!matrix || !devices || !out || n_devices < 1) return fail(nullptr, HMK_ERR_BAD_ARG, "hmk_create_multi: null argument or no device");
+    if ((uint32_t)n_devices > HMK_MAX_SEGS - HMK_EDGE_SHARDS + 1)
+        return fail(nullptr, HMK_ERR_BAD_ARG, "hmk_create_multi: at most " + std::to_string(HMK_MAX_SEGS - HMK_EDGE_SHARDS + 1) + " devices");
+    *out = nullptr;
+    hmk_ctx *root = nullptr;
+    int st = hmk_create(matrix, devices[0], &root);
+    if (st) return st;
+    if (!root->has_device) { hmk_destroy(root); return fail(nullptr, HMK_ERR_BAD_ARG, "hmk_create_multi: devices must be HIP ordinals >= 0"); }
+    for (int d = 1; d < n_devices; d++) {
+        hmk_ctx *peer = nullptr;
+        st = devices[d] >= 0 ? hmk_create(matrix, devices[d], &peer) : fail(nullptr, HMK_ERR_BAD_ARG, "hmk_create_multi: devices must be HIP ordinals >= 0");
+        if (st) { hmk_destroy(root); return st; }
+        root->peers.push_back(peer);
+        if (devices[d] != devices[0]) {   // direct xGMI copies peer -> root (a refusal leaves the staged path, still correct)
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[0], devices[d]) == hipSuccess && can) {
+                (void)hipSetDevice(devices[0]);
+                (void)hipDeviceEnablePeerAccess(devices[d], 0);
+                (void)hipSetDevice(devices[d]);
+                (void)hipDeviceEnablePeerAccess(devices[0], 0);
+                (void)hipGetLastError();   // "already enabled" is fine
+            }
+        }
+    }
+    (void)hipSetDevice(devices[0]);
+    *out = root;
+    return HMK_OK;
+}
+
+int hmk_device_count(const hmk_ctx *ctx) { return ctx ? (ctx->has_device ? 1 + (int)ctx->peers.size() : 0) : 0; }
+
 int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edges, int symmetric, int max_clusters,
                               int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
@@ -1726,8 +1899,8 @@ int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edge
     // the caller's block may have been written on any stream of its own (an all-gather, a copy): wait for the device
     HIPCHK(ctx, hipDeviceSynchronize());
     HIPCHK(ctx, ensure_buf(ctx, SB_PEERCNT, HMK_MAX_SEGS * sizeof(unsigned long long)));
-    ctx->h_counts[32] = n_edges;
-    HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_PEERCNT), &ctx->h_counts[32], sizeof(unsigned long long), hipMemcpyHostToDevice, S));
+    ctx->h_counts[HC_PEER] = n_edges;
+    HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_PEERCNT), &ctx->h_counts[HC_PEER], sizeof(unsigned long long), hipMemcpyHostToDevice, S));
     EdgeSource src;
     src.symmetric = symmetric != 0;
     src.segs.n = 1;

@@ -4,7 +4,8 @@
 // reference's greedy mode; everything after initial clustering (Clustal Omega MSAs, HMM stage)
 // is out of scope.
 //
-// Extra flags that the reference does not have: --device <k> (HIP ordinal, default 0).
+// Extra flags that the reference does not have: --device <k> (HIP ordinal, default 0) and --devices a,b,.. (several
+// GPUs of the node behind one context, the first is the root: hmk_create_multi).
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -43,6 +44,7 @@ struct Options {
     bool haveThreshold = false, haveMaxShift = false, haveLimit = false;
     int sequenceClusteringThreshold = 0, shiftPenalty = 0, maxShift = 0, initialClustersLimit = 0;
     int device = 0;
+    std::vector<int> devices;   // --devices 0,1,..: pair space sharded over several GPUs
 };
 
 void parseCommonArgs(const std::vector<std::string> &args, Options &o) {  // Hammock.java:824-908
@@ -61,6 +63,16 @@ void parseCommonArgs(const std::vector<std::string> &args, Options &o) {  // Ham
         if ((a == "-l" || a == "--labels") && more) { o.labelString = args[++i]; o.haveLabels = true; continue; }
         if (a == "--temp" && more) { o.tempDirectory = args[i + 1]; }  // :903-905 (no skip, as in the reference)
         if (a == "--device" && more) { o.device = javaIntegerDecode(args[++i]); continue; }
+        if (a == "--devices" && more) {
+            o.devices.clear();
+            std::string list = args[++i], tok;
+            for (size_t b = 0; b <= list.size(); b++) {
+                if (b == list.size() || list[b] == ',') { if (!tok.empty()) o.devices.push_back(javaIntegerDecode(tok)); tok.clear(); }
+                else tok.push_back(list[b]);
+            }
+            if (o.devices.empty()) throw HammockException("--devices needs a comma separated list of HIP ordinals");
+            continue;
+        }
     }
 }
 
@@ -95,7 +107,8 @@ void printHelp() {  // Hammock.java:295-320 (greedy-relevant part)
               << "-R, --order [size, alphabetic, random, input, <label>]\n\tThe order of sequences during greedy clustering\n\n"
               << "-S, --seed <int>\n\tA seed to make random processes deterministic (if -R random is in use)\n\n"
               << "--initial_clusters_limit <int>\n\tThe max. number of clusters resulting from gredy clustering\n\n"
-              << "--device <int>\n\tHIP device ordinal (default 0)\n\n";
+              << "--device <int>\n\tHIP device ordinal (default 0)\n\n"
+              << "--devices <int,int,...>\n\tShard the pair space over several GPUs of the node (the first one runs the merge)\n\n";
 }
 
 std::string labelsToString(bool have, const std::vector<std::string> &labels) {  // List.toString() / "null"
@@ -229,7 +242,9 @@ int runGreedy(const std::vector<std::string> &args) {
             logger.logAndStderr("Initial greedy clusters limit not set. Setting automatically to: " +
                                 std::to_string(o.initialClustersLimit));
         }
-        auto scorer = std::make_shared<ShiftedScorer>(scoringMatrix, o.shiftPenalty, o.maxShift, o.device);  // :402
+        auto scorer = o.devices.empty()
+                          ? std::make_shared<ShiftedScorer>(scoringMatrix, o.shiftPenalty, o.maxShift, o.device)  // :402
+                          : std::make_shared<ShiftedScorer>(scoringMatrix, o.shiftPenalty, o.maxShift, o.devices);
         HipGreedySequenceClusterer clusterer(scorer, o.sequenceClusteringThreshold, o.initialClustersLimit);  // :403
 
         logger.logAndStderr("Greedy clustering...");

@@ -300,6 +300,17 @@ public:
         const int st = hmk_create(m, device, &ctx_);
         if (st) raise(st, nullptr);
     }
+    // several GPUs of the node behind one context (hmk_create_multi): devices[0] is the root
+    NativeContext(const std::vector<std::vector<int>> &scoringMatrix, const std::vector<int> &devices) {
+        if (scoringMatrix.size() != 24) throw HammockException("scoring matrix must be 24 x 24");
+        int32_t m[576];
+        for (int r = 0; r < 24; r++) {
+            if (scoringMatrix[r].size() != 24) throw HammockException("scoring matrix must be 24 x 24");
+            for (int c = 0; c < 24; c++) m[r * 24 + c] = scoringMatrix[r][c];
+        }
+        const int st = hmk_create_multi(m, devices.data(), (int)devices.size(), &ctx_);
+        if (st) raise(st, nullptr);
+    }
     ~NativeContext() { hmk_destroy(ctx_); }
     NativeContext(const NativeContext &) = delete;
     NativeContext &operator=(const NativeContext &) = delete;
@@ -336,6 +347,9 @@ public:
     // ShiftedScorer(int[][] scoringMatrix, int shiftPenalty, int maxShift), ShiftedScorer.java:28-32
     ShiftedScorer(const std::vector<std::vector<int>> &scoringMatrix, int shiftPenalty, int maxShift, int device = 0)
         : ctx_(std::make_shared<NativeContext>(scoringMatrix, device)), shiftPenalty_(shiftPenalty), maxShift_(maxShift) {}
+    // the same scorer with the pair space sharded over several GPUs (used by HipGreedySequenceClusterer.cluster)
+    ShiftedScorer(const std::vector<std::vector<int>> &scoringMatrix, int shiftPenalty, int maxShift, const std::vector<int> &devices)
+        : ctx_(std::make_shared<NativeContext>(scoringMatrix, devices)), shiftPenalty_(shiftPenalty), maxShift_(maxShift) {}
     AligningScorerResult scoreWithShift(const UniqueSequencePtr &seq1, const UniqueSequencePtr &seq2) override {  // :48-95
         ctx_->setSequences({seq1, seq2}, false);
         const uint32_t i = 0, j = 1;

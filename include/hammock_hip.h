@@ -66,6 +66,15 @@ typedef struct hmk_ctx hmk_ctx;
  * device >= 0: HIP device ordinal.  device == -1: host-only context (only the
  * host-side calls hmk_greedy_from_edges / hmk_set_sequences work). */
 int hmk_create(const int32_t matrix[HMK_ALPHABET * HMK_ALPHABET], int device, hmk_ctx **ctx);
+/* The same on several GPUs of one node (BASELINE config 5: "pair-space sharded 8 x MI355X over xGMI"): devices[0] is the
+ * root.  hmk_set_sequences uploads to every device; hmk_greedy_cluster scores shard d of n_devices on device d (row
+ * blocks dealt cyclically, no collective inside the scoring), gathers the peers' edge segments to the root with direct
+ * xGMI peer copies (every peer over its own link; a gather to the one device whose host runs the merge moves 1/n of an
+ * all-gather's bytes) and runs the merge tail there.  The result is identical to the single-device call.  Every other
+ * entry point works on the root device.  n_devices = 1 is hmk_create.  (One PROCESS per GPU with an RCCL all-gather
+ * -- hammock_amd/dist.py -- is the other multi-GPU form; both end in hmk_greedy_from_edges_dev on rank/device 0.) */
+int hmk_create_multi(const int32_t matrix[HMK_ALPHABET * HMK_ALPHABET], const int *devices, int n_devices, hmk_ctx **ctx);
+int hmk_device_count(const hmk_ctx *ctx); /* devices behind this context (0 for a host-only context) */
 void hmk_destroy(hmk_ctx *ctx);
 const char *hmk_last_error(const hmk_ctx *ctx); /* ctx may be NULL */
 int hmk_abi_version(void);

@@ -345,6 +345,35 @@ def test_greedy_3e5_vs_oracle(gpu, blosum62, coracle):
     assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
 
 
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_greedy_multi_device_context(gpu, blosum62, coracle, devices):
+    """hmk_create_multi: the multi-GPU form below the C ABI.  This box has one GPU, so the device list names it one,
+    two and three times -- every "device" has its own context, plan (shard d of n), edge buffer and stream, the
+    peers' segments reach the root through hipMemcpyPeerAsync, the root builds the CSR over root segments + gathered
+    blocks.  Must equal the single-device call and the oracle."""
+    n = 40000
+    res, off = synth_peptides(21, n, 12)
+    rng = np.random.default_rng(21)
+    sizes = (1 + rng.integers(0, 5, size=n)).astype(np.int32)
+    perm = coracle.sort_order(res, off, sizes, "size")
+    res = np.ascontiguousarray(res.reshape(n, 12)[perm].reshape(-1))
+    sizes = sizes[perm]
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, 3, 0, 20, 1000, 8)
+    assert st == 0
+    ctx = hammock_amd.Context(blosum62, device=devices)
+    from hammock_amd import _native
+    assert _native.lib.hmk_device_count(ctx._h) == len(devices)
+    ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
+    for _ in range(2):   # second call: grown buffers, cached plans
+        cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+        assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+    single = hammock_amd.Context(blosum62, device=0)
+    single.set_sequences(residues=res, offsets=off, sizes=sizes)
+    _, _, sstats = single.greedy_cluster(3, 0, 20, 1000)
+    assert stats.n_edges == sstats.n_edges   # the shards together hold every edge exactly once
+
+
 def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
     """hmk_greedy_cluster ships the adjacency to the host as 4-byte entries when the edge scores span at
     most 255 and as 8-byte entries otherwise; both must give the oracle's clustering.  BLOSUM62 x 12 makes
@@ -479,12 +508,13 @@ def test_score_with_shift_vs_oracle(gpu, blosum62, coracle):
 # --------------------------------------------------------------------------------------
 # the C++ host side + CLI end to end (hammock-hip greedy == `java -jar Hammock.jar greedy`)
 # --------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dataset", ["musi", "manual_counts"])
+@pytest.mark.parametrize("dataset", ["musi", "manual_counts", "musi_two_devices"])
 def test_cli_greedy_writes_reference_files(gpu, blosum62, coracle, tmp_path, dataset):
     import subprocess
     from conftest import ROOT
     cli = os.path.join(ROOT, "hammock_amd", "bin", "hammock-hip")
-    if dataset == "musi":
+    devices = ["--devices", "0,0"] if dataset == "musi_two_devices" else []   # hmk_create_multi behind the CLI
+    if dataset.startswith("musi"):
         fa = os.path.join(GOLDEN, "musi.fa")
         extra = []
     else:  # counts + labels in the headers: size order, size tie-break, label columns
@@ -500,7 +530,7 @@ def test_cli_greedy_writes_reference_files(gpu, blosum62, coracle, tmp_path, dat
                     fh.write(f">{k}\n{s}\n")
         extra = ["-g", "18", "--initial_clusters_limit", "40"]
     out = str(tmp_path / "out")
-    r = subprocess.run([cli, "greedy", "-i", fa, "-d", out] + extra, capture_output=True, text=True)
+    r = subprocess.run([cli, "greedy", "-i", fa, "-d", out] + extra + devices, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     # expected files from the oracle clustering + the writers' restatement
     seqs = po.load_unique_sequences_from_fasta(fa)
