@@ -288,6 +288,21 @@ class Context:
             self._raise(st, stats)
         return cid[:self.n], order[:stats.n_result_clusters], stats
 
+    def clinkage_cluster(self, max_shift, shift_penalty, threshold):
+        """hmk_clinkage_cluster -> (cluster_id int32[n], result_order int32[n_result], ClinkageStats); member_rank in
+        self.member_rank.  Sequences in LOAD order (clinkage mode does not sort)."""
+        cid = np.full(max(self.n, 1), -1, dtype=np.int32)
+        order = np.full(max(self.n, 1), -1, dtype=np.int32)
+        self.member_rank = np.zeros(max(self.n, 1), dtype=np.int32)
+        stats = N.ClinkageStats()
+        st = N.lib.hmk_clinkage_cluster(self._h, int(max_shift), int(shift_penalty), int(threshold), _ptr(cid, C.c_int32),
+                                        _ptr(order, C.c_int32), _ptr(self.member_rank, C.c_int32), C.byref(stats))
+        if st == N.HMK_ERR_REFERENCE_WOULD_CRASH:
+            raise ReferenceWouldCrash(N.lib.hmk_last_error(self._h).decode(), 0, -1)
+        if st:
+            self._raise(st)
+        return cid[:self.n], order[:stats.n_result_clusters], stats
+
     def greedy_phases(self):
         """hmk_greedy_last_phases: per-phase milliseconds of the last greedy_cluster / greedy_from_edges_dev call."""
         ph = N.GreedyPhases()
@@ -433,6 +448,35 @@ class LocalAlignmentScorer(_GpuScorer):
 
     def sequenceScore(self, seq1, seq2):  # :27-29
         return self._score(seq1, seq2)
+
+
+class HipClinkageSequenceClusterer:
+    """Drop-in for ClinkageSequenceClusterer(sequenceScorer, threshold) (ClinkageSequenceClusterer.java:29-33): same
+    ``cluster(List<UniqueSequence>) -> List<Cluster>`` contract (:43-124) -- exact complete linkage, cluster ids as the
+    reference assigns them (singletons index + 1, merged clusters n + 2, ... in merge order), the returned list in the
+    iteration order of the reference's HashSet, members in getSequences() order."""
+
+    def __init__(self, sequenceScorer: "ShiftedScorer", threshold):
+        if not isinstance(sequenceScorer, ShiftedScorer):
+            raise TypeError("the GPU clinkage path takes a ShiftedScorer (Hammock.java:458)")
+        self.sequenceScorer = sequenceScorer
+        self.threshold = int(threshold)
+        self.stats = None
+
+    def cluster(self, sequences):
+        sc = self.sequenceScorer
+        ctx = sc._ctx
+        ctx.set_sequences([s.sequence for s in sequences], sizes=[s.size() for s in sequences])
+        cid, order, stats = ctx.clinkage_cluster(sc.maxShift, sc.shiftPenalty, self.threshold)
+        self.stats = stats
+        members = {}
+        for k, c in enumerate(cid.tolist()):
+            members.setdefault(c, []).append(k)
+        result = []
+        for c in order.tolist():
+            ks = sorted(members[c], key=lambda k: int(ctx.member_rank[k]))
+            result.append(Cluster([sequences[k] for k in ks], c))
+        return result
 
 
 class HipGreedySequenceClusterer:

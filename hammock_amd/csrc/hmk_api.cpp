@@ -1230,6 +1230,7 @@ struct EdgeSource {
     uint64_t total_known = 0;          // exact number of edges, if known (else 0)
     uint32_t band_rows = 0;            // rows [0, band_rows) are complete in band_segs once ev_band has passed
     EdgeSegs band_segs{};
+    hmk_clinkage_stats *clink = nullptr;   // non-null: run the clinkage nearest-neighbour chain instead of the greedy merge
 };
 
 // Builds the CSR adjacency on the device, hands rows to the host merge on demand, runs the merge.
@@ -1592,6 +1593,24 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     hooks.times = &times;
     std::string err;
     const int32_t *szs = ctx->has_sizes ? ctx->sizes.data() : nullptr;
+    if (src.clink) {
+        // clinkage mode: the chain needs every row; fetch the whole adjacency, then run it on the host
+        int cst = HMK_OK;
+        if (!src.format_known && !wait_full()) cst = -1;
+        if (cst == HMK_OK && n && hooks.need_rows(n - 1) < n) cst = -1;
+        if (cst == HMK_OK)
+            cst = packed ? clinkage_from_csr_packed(n, szs, h_start, (const NbrPacked *)ctx->h_adj, cluster_id, result_order, member_rank,
+                                                    src.clink, &err)
+                         : clinkage_from_csr(n, szs, h_start, (const Nbr *)ctx->h_adj, cluster_id, result_order, member_rank, src.clink,
+                                             &err);
+        (void)hipStreamSynchronize(S);
+        (void)hipStreamSynchronize(C);
+        if (status_inside == ST_RETRY_OVERFLOW) return ST_RETRY_OVERFLOW;
+        if (status_inside != HMK_OK) return fail(ctx, status_inside, hook_err);
+        if (cst) return fail(ctx, cst < 0 ? HMK_ERR_DEVICE : cst, err.empty() ? "clinkage: adjacency hand-over failed" : err);
+        src.clink->n_edges = src.total_known ? src.total_known : h_start[n] / 2;
+        return HMK_OK;
+    }
     // the entry format is fixed before the merge starts unless it depends on the scores (then the first need_rows
     // call settles it through wait_full(), before any row is read): dispatch on a flag the row provider may update
     int st;
@@ -1627,7 +1646,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
 }
 
 int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters, int32_t *cluster_id,
-                         int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats);
+                         int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats, hmk_clinkage_stats *clink = nullptr);
 
 }  // namespace
 
@@ -1731,7 +1750,7 @@ namespace {
 // the peers' edges travel to the root over xGMI as direct peer copies -- one transfer per segment, every peer over its
 // own link to the root -- and the root runs the usual tail on the union (CSR on the device, merge).
 int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters, int32_t *cluster_id,
-                         int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
+                         int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats, hmk_clinkage_stats *clink) {
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<hmk_ctx *> devs;
     devs.push_back(ctx);
@@ -1832,6 +1851,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
     src.base = threshold;
     src.total_known = total;
     src.adj_bound = (ctx->symmetric ? 2 : 1) * total;
+    src.clink = clink;
     HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
     st = cluster_on_device(ctx, src, max_clusters, cluster_id, result_order, member_rank, stats, t0);
     if (st == ST_RETRY_OVERFLOW) return fail(ctx, HMK_ERR_DEVICE, "internal edge buffer overflow");
@@ -1839,7 +1859,8 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
     if (hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_edges) == hipSuccess) ctx->phases.score_ms = ms;   // root shard + gather
     if (hipEventElapsedTime(&ms, ctx->ev_edges, ctx->ev_csr) == hipSuccess) ctx->phases.csr_ms = ms;
     ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    stats->neighbors_ms = ctx->phases.score_ms;
+    if (stats) stats->neighbors_ms = ctx->phases.score_ms;
+    if (clink) clink->neighbors_ms = ctx->phases.score_ms;
     return st;
 }
 
@@ -1910,6 +1931,60 @@ int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edge
     HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
     st = cluster_on_device(ctx, src, max_clusters, cluster_id, result_order, member_rank, stats, t0);
     if (st == HMK_OK || st == HMK_ERR_REFERENCE_WOULD_CRASH) stats->n_edges = n_edges;
+    ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return st;
+}
+
+int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int32_t *cluster_id,
+                         int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hmk_clinkage_stats local;
+    if (!stats) stats = &local;
+    std::memset(stats, 0, sizeof(*stats));
+    ctx->phases = hmk_greedy_phases{};
+    if (ctx->n == 0)
+        return fail(ctx, HMK_ERR_REFERENCE_WOULD_CRASH,
+                    "the reference throws NoSuchElementException here (ClinkageSequenceClusterer.java:118): empty input");
+    if (!cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
+    if (!ctx->symmetric)
+        return fail(ctx, HMK_ERR_BAD_ARG, "clinkage needs a symmetric scoring matrix: the reference caches cluster scores by unordered "
+                                          "pair (CachedClusterScorer.java:43-53), so its result depends on the evaluation order otherwise");
+    int st = need_device(ctx);
+    if (st) return st;
+    st = greedy_streams(ctx);
+    if (st) return st;
+    if (!ctx->peers.empty())
+        return greedy_cluster_multi(ctx, max_shift, shift_penalty, threshold, 0, cluster_id, result_order, member_rank, nullptr, stats);
+    const auto t0 = std::chrono::steady_clock::now();
+    const uint32_t n = ctx->n;
+    unsigned long long counts[HMK_EDGE_SHARDS];
+    double ms = 0;
+    // clinkage inputs are small (the reference switches to greedy above 10,000 sequences) but dense: MUSI has 16 % of
+    // its pairs above the default threshold for some rows; neighbors_internal grows the buffer until the pass fits
+    const uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * 0.02) + (1u << 20);
+    st = neighbors_internal(ctx, max_shift, shift_penalty, threshold, 0, 1, std::min<uint64_t>(guess, 1ull << 31), counts, &ms);
+    if (st) return st;
+    uint64_t total = 0;
+    for (int q = 0; q < HMK_EDGE_SHARDS; q++) total += counts[q];
+    hipStream_t S = ctx->gstream;
+    const long long top = (long long)ctx->max_len * std::max(0, ctx->max_m) +
+                          (long long)std::max(0, shift_penalty) * ((ctx->max_len - ctx->min_len) + 2LL * max_shift);
+    EdgeSource src;
+    src.symmetric = true;
+    src.segs = shard_segments(ctx->d_edges, ctx->d_edges_cap / HMK_EDGE_SHARDS, ctx->d_counts);
+    src.format_known = true;
+    src.packed = top - threshold <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr;
+    src.base = threshold;
+    src.total_known = total;
+    src.adj_bound = 2 * total;
+    src.clink = stats;
+    HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
+    st = cluster_on_device(ctx, src, 0, cluster_id, result_order, member_rank, nullptr, t0);
+    if (st == ST_RETRY_OVERFLOW) return fail(ctx, HMK_ERR_DEVICE, "internal edge buffer overflow");
+    stats->neighbors_ms = ms;
+    ctx->phases.score_ms = ms;
     ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return st;
 }

@@ -43,6 +43,7 @@ struct Options {
     std::string inputType = "fasta", order = "size";
     bool haveThreshold = false, haveMaxShift = false, haveLimit = false;
     int sequenceClusteringThreshold = 0, shiftPenalty = 0, maxShift = 0, initialClustersLimit = 0;
+    int cacheSizeLimit = 1;   // clinkage: -L is parsed and logged, never used (Hammock.java:89,1004-1008,459)
     int device = 0;
     std::vector<int> devices;   // --devices 0,1,..: pair space sharded over several GPUs
 };
@@ -92,9 +93,23 @@ void parseGreedyArgs(const std::vector<std::string> &args, Options &o) {  // Ham
     }
 }
 
+void parseClinkageArgs(const std::vector<std::string> &args, Options &o) {  // Hammock.java:972-1011
+    for (size_t i = 1; i < args.size(); i++) {
+        const std::string &a = args[i];
+        const bool more = args.size() > i + 1;
+        if ((a == "-f" || a == "--file_format") && more) { o.inputType = args[++i]; continue; }
+        if ((a == "-x" || a == "--max_shift") && more) { o.maxShift = javaIntegerDecode(args[++i]); o.haveMaxShift = true; continue; }
+        if ((a == "-p" || a == "--gap_penalty") && more) { o.shiftPenalty = javaIntegerDecode(args[++i]); }
+        if ((args[i] == "-g" || args[i] == "--greedy_threshold" || args[i] == "--alignment_threshold") && args.size() > i + 1) {
+            o.sequenceClusteringThreshold = javaIntegerDecode(args[++i]); o.haveThreshold = true;
+        }
+        if ((args[i] == "-L" || args[i] == "--cache_size_limit") && args.size() > i + 1) { o.cacheSizeLimit = javaIntegerDecode(args[++i]); }
+    }
+}
+
 void printHelp() {  // Hammock.java:295-320 (greedy-relevant part)
-    std::cerr << "\nhammock-hip: MI355X-native greedy mode of Hammock version " << VERSION << "\n\n"
-              << "Synopsis: hammock-hip greedy <param1> <param2> ...\n\n"
+    std::cerr << "\nhammock-hip: MI355X-native greedy and clinkage modes of Hammock version " << VERSION << "\n\n"
+              << "Synopsis: hammock-hip <greedy|clinkage> <param1> <param2> ...\n\n"
               << "-i, --input <file>\n\tA path to an input file\n\n"
               << "-d, --output_directory <directory>\n\tA directory to store all output files in\n\n"
               << "-t, --threads <int>\n\tAccepted for compatibility (the GPU path ignores it)\n\n"
@@ -107,6 +122,7 @@ void printHelp() {  // Hammock.java:295-320 (greedy-relevant part)
               << "-R, --order [size, alphabetic, random, input, <label>]\n\tThe order of sequences during greedy clustering\n\n"
               << "-S, --seed <int>\n\tA seed to make random processes deterministic (if -R random is in use)\n\n"
               << "--initial_clusters_limit <int>\n\tThe max. number of clusters resulting from gredy clustering\n\n"
+              << "-L, --cache_size_limit <int>\n\t(clinkage) accepted and logged; has no effect, as in the reference\n\n"
               << "--device <int>\n\tHIP device ordinal (default 0)\n\n"
               << "--devices <int,int,...>\n\tShard the pair space over several GPUs of the node (the first one runs the merge)\n\n";
 }
@@ -130,12 +146,15 @@ int checkMaxShift(const std::vector<UniqueSequencePtr> &seqs, int maxShift) {  /
     return std::min(maxShift, minLength - 1);
 }
 
-int runGreedy(const std::vector<std::string> &args) {
+// greedy mode (Hammock.java:217-234, runGreedyClustering :392-437) and clinkage mode (:236-253, runClinkageClustering
+// :449-489): the two share everything but the clusterer, the ordering step and a few log lines
+int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
     Options o;
     const std::string PARENT_DIR = parentDir();
     o.matrixFile = PARENT_DIR + "/matrices/blosum62.txt";  // Hammock.java:45
     parseCommonArgs(args, o);
-    parseGreedyArgs(args, o);
+    if (clinkage) parseClinkageArgs(args, o);
+    else parseGreedyArgs(args, o);
 
     // ---- checkCommonArgs, Hammock.java:1207-1266 ------------------------------------------------
     if (!o.haveInput) throw CLIException("Error. Parameter input file (-i or --input) missing with no default.");
@@ -167,13 +186,21 @@ int runGreedy(const std::vector<std::string> &args) {
         if (!(o.inputType == "fasta" || o.inputType == "seq" || o.inputType == "tab"))
             throw CLIException("Error. Parameter -f value may be either \"fasta\", \"seq\" or \"tab\". No other values are allowed");
 
-        logger.logWithTime("Program started in mode \"greedy\".");  // :225-229
+        logger.logWithTime(clinkage ? "Program started in mode \"clinkage\"." : "Program started in mode \"greedy\".");  // :225-229, :244-248
         std::string argsString;
         for (auto &a : args) argsString += " " + a;
         logger.logWithoutTime("Command-line arguments: \n" + argsString + "\n");
         logger.logWithoutTime("\nComplete list of input/output parameters: \n-i, --input " + o.inputFileName +
                               "\n-d, --output_directory " + o.workingDirectory + "\n-t, --thread " + std::to_string(o.nThreads) +
                               "\n-l, --labels " + labelsToString(o.haveLabels, labels) + "\n\n");
+        if (clinkage)   // logClinkageParams, :1742-1755 (labels as the reference prints them)
+            logger.logWithoutTime("\nComplete list of clinkage clustering parameters: \n-f, --file_format " + o.inputType +
+                                  "\n-m, --matrix " + o.matrixFile + "\n-g, --alignment_threshold (--greedy_threshold)" +
+                                  (o.haveThreshold ? std::to_string(o.sequenceClusteringThreshold) : std::string("null")) +
+                                  "\n-x, --max_shift " + (o.haveMaxShift ? std::to_string(o.maxShift) : std::string("null")) +
+                                  "\n-p, --gap_penalty " + std::to_string(o.shiftPenalty) + "\n-C, --cache_size_limit " +
+                                  std::to_string(o.cacheSizeLimit) + "\n\n");
+        else
         logger.logWithoutTime("\nComplete list of greedy clustering parameters: \n-f, --file_format " + o.inputType +
                               "\n-m, --matrix " + o.matrixFile + "\n-g, --greedy_threshold " +
                               (o.haveThreshold ? std::to_string(o.sequenceClusteringThreshold) : std::string("null")) +
@@ -232,12 +259,12 @@ int runGreedy(const std::vector<std::string> &args) {
         }
         logger.logAndStderr("Generating input statistics...");
         FileIOManager::saveInputStatistics(sequences, labels, inputStatistics);                 // :814-816
-        if (!o.haveThreshold) {                                                                 // :394-397
+        if (!o.haveThreshold) {                                                                 // :394-397 / :452-455
             o.sequenceClusteringThreshold = (int)javaRound(meanSequenceLength(sequences) * 1.7);
-            logger.logAndStderr("Greedy clustering threshold not set. Setting automatically to: " +
+            logger.logAndStderr(std::string(clinkage ? "Clinkage" : "Greedy") + " clustering threshold not set. Setting automatically to: " +
                                 std::to_string(o.sequenceClusteringThreshold));
         }
-        if (!o.haveLimit) {                                                                     // :398-401
+        if (!clinkage && !o.haveLimit) {                                                                     // :398-401
             o.initialClustersLimit = (int)javaRound((double)sequences.size() * 0.025);
             logger.logAndStderr("Initial greedy clusters limit not set. Setting automatically to: " +
                                 std::to_string(o.initialClustersLimit));
@@ -246,16 +273,23 @@ int runGreedy(const std::vector<std::string> &args) {
                           ? std::make_shared<ShiftedScorer>(scoringMatrix, o.shiftPenalty, o.maxShift, o.device)  // :402
                           : std::make_shared<ShiftedScorer>(scoringMatrix, o.shiftPenalty, o.maxShift, o.devices);
         HipGreedySequenceClusterer clusterer(scorer, o.sequenceClusteringThreshold, o.initialClustersLimit);  // :403
+        HipClinkageSequenceClusterer clinkageClusterer(scorer, o.sequenceClusteringThreshold);                // :459
 
-        logger.logAndStderr("Greedy clustering...");
+        logger.logAndStderr(clinkage ? "Clinkage clustering..." : "Greedy clustering...");
         const auto time0 = std::chrono::steady_clock::now();
-        sortSequences(sequences, o.order, o.seed, labels);                                      // :407
-        std::vector<ClusterPtr> clusters = clusterer.cluster(sequences);                        // :409
+        if (!clinkage) sortSequences(sequences, o.order, o.seed, labels);                       // :407 (clinkage keeps the load order)
+        std::vector<ClusterPtr> clusters = clinkage ? clinkageClusterer.cluster(sequences)      // :462
+                                                    : clusterer.cluster(sequences);             // :409
         auto ms = [&]() {
             return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - time0).count();
         };
-        logger.logAndStderr("Ready. Clustering time: " + std::to_string(ms()));                // :411
-        logger.logAndStderr("Resulting clusers: " + std::to_string(clusters.size()));          // :412
+        logger.logAndStderr("Ready. Clustering time: " + std::to_string(ms()));                // :411 / :463
+        logger.logAndStderr("Resulting clusers: " + std::to_string(clusters.size()));          // :412 / :464
+        if (clinkage)
+            logger.logAndStderr("GPU scoring: " + std::to_string(clinkageClusterer.stats.neighbors_ms) + " ms, host nearest-neighbour chain: " +
+                                std::to_string(clinkageClusterer.stats.chain_ms) + " ms, neighbour edges: " +
+                                std::to_string(clinkageClusterer.stats.n_edges) + ", merges: " + std::to_string(clinkageClusterer.stats.merges));
+        else
         logger.logAndStderr("GPU scoring + adjacency build: " + std::to_string(clusterer.stats.neighbors_ms) + " ms, host greedy merge: " +
                             std::to_string(clusterer.stats.greedy_ms) + " ms, neighbour edges: " +
                             std::to_string(clusterer.stats.n_edges));
@@ -266,7 +300,7 @@ int runGreedy(const std::vector<std::string> &args) {
         FileIOManager::saveClusterSequencesToCsv(clusters, initialClustersSequencesCsv, labels);                              // :429
         FileIOManager::saveClusterSequencesToCsvOrdered(clusters, initialClustersSequencesOrderedCsv, labels, initialSequences);  // :431
         FileIOManager::SaveClustersToCsv(clusters, initialClusters, labels);                                                  // :432
-        logger.logAndStderr("Greedy clustering results in: " + initialClusters);
+        logger.logAndStderr(std::string(clinkage ? "Clinkage" : "Greedy") + " clustering results in: " + initialClusters);
         logger.logAndStderr("and: " + initialClustersSequencesCsv);
         logger.logAndStderr("and: " + initialClustersSequencesOrderedCsv);
         logger.logWithTime("Program successfully ended.");
@@ -366,7 +400,8 @@ int main(int argc, char **argv) {
     std::vector<std::string> args(argv + 1, argv + argc);
     if (args.empty() || args[0] == "--help" || args[0] == "-h") { printHelp(); return args.empty() ? 2 : 0; }
     try {
-        if (args[0] == "greedy") return runGreedy(args);
+        if (args[0] == "greedy") return runSequenceClustering(args, false);
+        if (args[0] == "clinkage") return runSequenceClustering(args, true);
         if (args[0] == "io-selftest") return ioSelftest(args);
         if (args[0] == "dump-matrix") {   // the default matrix in the text format FileIOManager.loadScoringMatrix reads
             std::cout << "# BLOSUM62 substitution matrix (public NCBI table), 24 x 24, order " << AMINO_ACIDS << "\n"
@@ -384,8 +419,8 @@ int main(int argc, char **argv) {
             return 0;
         }
         if (args[0] == "api-selftest") return apiSelftest(args);
-        std::cerr << "hammock-hip implements Hammock's `greedy` mode only (modes full, clinkage, cluster are outside "
-                     "the scope of the MI355X hot path); got mode \"" << args[0] << "\"\n";
+        std::cerr << "hammock-hip implements Hammock's initial-clustering modes `greedy` and `clinkage` (modes full, cluster, "
+                     "compare drive external HMM tools and are outside the scope of the MI355X hot path); got mode \"" << args[0] << "\"\n";
         return 2;
     } catch (const CLIException &e) {  // Hammock.java:146-147
         std::cerr << "Error in command line arguments: " << e.what() << std::endl;

@@ -418,6 +418,39 @@ public:
     }
 };
 
+// ---- HipClinkageSequenceClusterer: ClinkageSequenceClusterer.java:21-124 on the GPU -----------------------------
+class HipClinkageSequenceClusterer : public SequenceClusterer {
+    std::shared_ptr<ShiftedScorer> scorer_;
+    int threshold_;
+public:
+    hmk_clinkage_stats stats{};
+    // same constructor shape as ClinkageSequenceClusterer(sequenceScorer, threshold), :29-33
+    HipClinkageSequenceClusterer(std::shared_ptr<ShiftedScorer> sequenceScorer, int threshold)
+        : scorer_(std::move(sequenceScorer)), threshold_(threshold) {}
+    // cluster(List<UniqueSequence>) -> List<Cluster>, :43-124: ids as the reference assigns them (index + 1 for a sequence
+    // left alone, n + 2, n + 3, ... for merged clusters), the list in the iteration order of the reference's HashSet
+    std::vector<ClusterPtr> cluster(const std::vector<UniqueSequencePtr> &sequences) override {
+        const auto &nc = scorer_->native();
+        nc->setSequences(sequences, true);
+        const size_t n = sequences.size();
+        std::vector<int32_t> cid(std::max<size_t>(n, 1)), order(std::max<size_t>(n, 1)), rank(std::max<size_t>(n, 1));
+        const int st = hmk_clinkage_cluster(nc->get(), scorer_->getMaxShift(), scorer_->getShiftPenalty(), threshold_, cid.data(),
+                                            order.data(), rank.data(), &stats);
+        if (st) nc->raise(st, nullptr);
+        std::unordered_map<int, std::vector<std::pair<int, size_t>>> members;  // id -> (rank, index)
+        for (size_t k = 0; k < n; k++) members[cid[k]].push_back({rank[k], k});
+        std::vector<ClusterPtr> result;
+        for (int q = 0; q < stats.n_result_clusters; q++) {
+            auto &mv = members[order[q]];
+            std::sort(mv.begin(), mv.end());
+            std::vector<UniqueSequencePtr> seqs;
+            for (auto &e : mv) seqs.push_back(sequences[e.second]);
+            result.push_back(std::make_shared<Cluster>(seqs, order[q]));
+        }
+        return result;
+    }
+};
+
 // ---- Logger.java ---------------------------------------------------------------------------------------------
 class Logger {
     std::string filePath_;

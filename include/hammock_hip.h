@@ -224,6 +224,35 @@ int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edge
                               int max_clusters, int32_t *cluster_id, int32_t *result_order,
                               int32_t *member_rank, hmk_greedy_stats *stats);
 
+/* ---- clinkage mode ------------------------------------------------------- */
+
+typedef struct {
+    uint64_t n_edges;            /* neighbour edges consumed */
+    int32_t merges;              /* clusters joined (ClinkageSequenceClusterer.java:96-111) */
+    int32_t searches;            /* nearest-neighbour searches (:77) */
+    int32_t n_result_clusters;   /* size of the returned List<Cluster> */
+    int32_t reserved;
+    double neighbors_ms;         /* GPU scoring */
+    double chain_ms;             /* host nearest-neighbour chain */
+} hmk_clinkage_stats;
+
+/* Replaces ClinkageSequenceClusterer(ShiftedScorer(matrix, shift_penalty, max_shift), threshold).cluster(sequences)
+ * (ClinkageSequenceClusterer.java:29-33,43-124; driver Hammock.java:449-462; the reference's default initial clustering
+ * for up to 10,000 unique sequences, Hammock.java:371-377) on the sequences of hmk_set_sequences, which are in LOAD
+ * order -- clinkage mode does not sort.  The whole pair space is scored on the GPU; the nearest-neighbour chain runs
+ * on the host over the thresholded graph.
+ *   cluster_id[n]   : id of the returned cluster holding sequence k: k + 1 for a sequence left alone, n + 2, n + 3, ...
+ *                     for merged clusters in merge order (:49-55,97)
+ *   result_order[n] : ids of the returned clusters in list order = iteration order of the java.util.HashSet
+ *                     readyClusters (:121-123; Java 8 and later); first n_result_clusters entries valid; may be NULL
+ *   member_rank[n]  : position of sequence k inside Cluster.getSequences() (:105-106); may be NULL
+ * The cacheSizeLimit of -L/--cache_size_limit never reaches the clusterer in the reference (Hammock.java:459 uses the
+ * two-argument constructor), so there is no such parameter.  Needs a symmetric matrix (HMK_ERR_BAD_ARG otherwise: the
+ * reference's score cache is keyed by the unordered pair, so with score(a,b) != score(b,a) its result depends on which
+ * direction happened to be asked first).  An empty input is HMK_ERR_REFERENCE_WOULD_CRASH (NoSuchElementException, :118). */
+int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int32_t *cluster_id,
+                         int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats);
+
 /* Where the time of the last hmk_greedy_cluster / hmk_greedy_from_edges_dev call of this context went
  * (milliseconds; the span of Hammock.java:406-411 minus the sort).  score_ms and csr_ms are device times (HIP events on
  * the call's stream), the others host wall time.  The parts overlap (phase 1 runs while the rest of the pair space is

@@ -38,6 +38,11 @@ class GreedyStats(C.Structure):
     ]
 
 
+class ClinkageStats(C.Structure):
+    _fields_ = [("score_calls", C.c_uint64), ("merges", C.c_int32), ("searches", C.c_int32),
+                ("n_result_clusters", C.c_int32), ("reserved", C.c_int32)]
+
+
 def build(force=False):
     src = os.path.join(_HERE, "hammock_oracle.c")
     hdr = os.path.join(_HERE, "hammock_oracle.h")
@@ -67,6 +72,9 @@ def lib():
         L.hmo_greedy_cluster.argtypes = [p32, p8, pu32, p32, C.c_uint32, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_int, p32, p32, p32, C.POINTER(GreedyStats)]
         L.hmo_greedy_cluster.restype = C.c_int
+        L.hmo_clinkage_cluster.argtypes = [p32, p8, pu32, p32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, p32, p32, p32,
+                                           C.POINTER(ClinkageStats)]
+        L.hmo_clinkage_cluster.restype = C.c_int
         L.hmo_sort_order.argtypes = [p8, pu32, p32, C.c_uint32, C.c_int, pu32]
         L.hmo_sort_order.restype = C.c_int
         L.hmo_synth.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, p8, pu32]
@@ -169,6 +177,25 @@ def greedy_cluster(M, res, off, size, scorer, a, b, threshold, max_clusters, n_t
                               _p(rank, C.c_int32), C.byref(stats))
     stats.member_rank = rank[:n]
     return st, cid[:n], order[:stats.n_result_clusters], stats
+
+
+def clinkage_cluster(M, res, off, size, max_shift, shift_penalty, threshold, n_threads=1):
+    """-> (status, cluster_id[n], result_order[n_result], member_rank[n], stats)"""
+    L = lib()
+    M = as_matrix(M)
+    n = len(off) - 1
+    cid = np.full(max(n, 1), -1, dtype=np.int32)
+    order = np.full(max(n, 1), -1, dtype=np.int32)
+    rank = np.zeros(max(n, 1), dtype=np.int32)
+    stats = ClinkageStats()
+    sp = None
+    if size is not None:
+        size = np.ascontiguousarray(size, dtype=np.int32)
+        sp = _p(size, C.c_int32)
+    st = L.hmo_clinkage_cluster(_p(M, C.c_int32), _p(res, C.c_uint8), _p(off, C.c_uint32), sp, n, max_shift, shift_penalty,
+                                threshold, n_threads, _p(cid, C.c_int32), _p(order, C.c_int32), _p(rank, C.c_int32),
+                                C.byref(stats))
+    return st, cid[:n], order[:stats.n_result_clusters], rank[:n], stats
 
 
 def sort_order(res, off, size, order):

@@ -545,6 +545,241 @@ done:
 }
 
 /* ------------------------------------------------------------------ */
+/* java.util.HashSet<Cluster> iteration order (Java 8+), for the clinkage */
+/* clusterer: Cluster.hashCode() = 79 * 7 + id (Cluster.java:178-183),   */
+/* HashMap.hash = h ^ (h >>> 16), power-of-two table from 16, load 0.75, */
+/* chains in insertion order (tail append, order-preserving resize), no  */
+/* shrink on removal.                                                    */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int32_t *head, *tail; /* per bucket: first / last id of the chain, -1 = empty */
+    int32_t *next;        /* per id */
+    uint32_t cap, size, max_id, lowest;
+} jset_t;
+
+static uint32_t jset_bucket(const jset_t *s, int32_t id) {
+    uint32_t h = (uint32_t)(553 + id);
+    h ^= h >> 16;
+    return h & (s->cap - 1);
+}
+
+static int jset_init(jset_t *s, uint32_t max_id) {
+    s->cap = 16; s->size = 0; s->max_id = max_id; s->lowest = 0;
+    s->head = (int32_t *)malloc(16 * sizeof(int32_t));
+    s->tail = (int32_t *)malloc(16 * sizeof(int32_t));
+    s->next = (int32_t *)malloc(((size_t)max_id + 1) * sizeof(int32_t));
+    if (!s->head || !s->tail || !s->next) return HMO_ERR_OOM;
+    for (uint32_t b = 0; b < 16; b++) s->head[b] = s->tail[b] = -1;
+    return HMO_OK;
+}
+
+static void jset_free(jset_t *s) { free(s->head); free(s->tail); free(s->next); }
+
+static void jset_append(jset_t *s, int32_t id) {
+    uint32_t b = jset_bucket(s, id);
+    s->next[id] = -1;
+    if (s->head[b] < 0) s->head[b] = id; else s->next[s->tail[b]] = id;
+    s->tail[b] = id;
+    if (b < s->lowest) s->lowest = b;
+}
+
+static int jset_add(jset_t *s, int32_t id) {
+    jset_append(s, id);
+    if (++s->size > s->cap / 4 * 3) { /* resize(): every chain is re-appended in order */
+        uint32_t ocap = s->cap;
+        int32_t *ohead = s->head;
+        int32_t *order = (int32_t *)malloc((size_t)s->size * sizeof(int32_t));
+        if (!order) return HMO_ERR_OOM;
+        uint32_t k = 0;
+        for (uint32_t b = 0; b < ocap; b++)
+            for (int32_t id2 = ohead[b]; id2 >= 0; id2 = s->next[id2]) order[k++] = id2;
+        s->cap = ocap * 2;
+        free(s->head); free(s->tail);
+        s->head = (int32_t *)malloc((size_t)s->cap * sizeof(int32_t));
+        s->tail = (int32_t *)malloc((size_t)s->cap * sizeof(int32_t));
+        if (!s->head || !s->tail) { free(order); return HMO_ERR_OOM; }
+        for (uint32_t b = 0; b < s->cap; b++) s->head[b] = s->tail[b] = -1;
+        s->lowest = s->cap;
+        for (uint32_t q = 0; q < k; q++) jset_append(s, order[q]);
+        free(order);
+    }
+    return HMO_OK;
+}
+
+static void jset_remove(jset_t *s, int32_t id) {
+    uint32_t b = jset_bucket(s, id);
+    int32_t prev = -1;
+    for (int32_t cur = s->head[b]; cur >= 0; prev = cur, cur = s->next[cur]) {
+        if (cur != id) continue;
+        if (prev < 0) s->head[b] = s->next[cur]; else s->next[prev] = s->next[cur];
+        if (s->tail[b] == cur) s->tail[b] = prev;
+        s->size--;
+        return;
+    }
+}
+
+static int32_t jset_first(jset_t *s) { /* iterator().next(); -1 if empty */
+    while (s->lowest < s->cap && s->head[s->lowest] < 0) s->lowest++;
+    return s->lowest < s->cap ? s->head[s->lowest] : -1;
+}
+
+/* ------------------------------------------------------------------ */
+/* ClinkageSequenceClusterer.cluster, ClinkageSequenceClusterer.java:43-124 */
+/* ------------------------------------------------------------------ */
+/* The CachedClusterScorer / DynamicMatrix pair (CachedClusterScorer.java:23-280) is NOT restated here: the literal
+ * Python restatement (oracle/hammock_oracle.py) shows by fuzzing over thread counts and with the cache bypassed that
+ * at one pool thread it is a transparent memo of clusterScore.  This C form keeps its own memo of cluster scores
+ * (slots re-used on merge, rows merged by element-wise min as :95-106 does) and is checked against the Python one. */
+int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *off, const int32_t *size, uint32_t n,
+                         int max_shift, int shift_penalty, int threshold, int n_threads, int32_t *cluster_id,
+                         int32_t *result_order, int32_t *member_rank, hmo_clinkage_stats *stats) {
+    hmo_clinkage_stats local;
+    if (!stats) stats = &local;
+    memset(stats, 0, sizeof(*stats));
+    if (!M || !res || !off || !cluster_id) return HMO_ERR_BAD_ARG;
+    if (n == 0) return HMO_ERR_REFERENCE_WOULD_CRASH; /* :118 NoSuchElementException */
+    if (n_threads < 1) n_threads = 1;
+    scorer_t sc = {M, res, off, HMO_SCORER_SHIFTED, max_shift, shift_penalty};
+    const uint32_t max_id = 2 * n + 2;
+    int status = HMO_OK;
+    /* cluster id -> slot (row of the memo), members, sizes */
+    cluster_t *cl = (cluster_t *)calloc((size_t)max_id + 1, sizeof(cluster_t));
+    int32_t *slot_of = (int32_t *)malloc(((size_t)max_id + 1) * sizeof(int32_t));
+    char *alive = (char *)calloc((size_t)max_id + 1, 1);
+    int32_t *stack = (int32_t *)malloc(((size_t)n + 2) * sizeof(int32_t));
+    /* memo[slot a][slot b], a > b: INT_MAX = unknown */
+    int32_t **memo = (int32_t **)calloc(n, sizeof(int32_t *));
+    int32_t *active_ids = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    int32_t *scores = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+    jset_t active, ready;
+    memset(&active, 0, sizeof(active));
+    memset(&ready, 0, sizeof(ready));
+    if (!cl || !slot_of || !alive || !stack || !memo || !active_ids || !scores) { status = HMO_ERR_OOM; goto done; }
+    if ((status = jset_init(&active, max_id)) || (status = jset_init(&ready, max_id))) goto done;
+    for (uint32_t a = 0; a < n; a++) {
+        memo[a] = (int32_t *)malloc(((size_t)a + 1) * sizeof(int32_t));
+        if (!memo[a]) { status = HMO_ERR_OOM; goto done; }
+        for (uint32_t b = 0; b <= a; b++) memo[a][b] = INT_MAX;
+    }
+    int32_t current_id = 1;
+    for (uint32_t k = 0; k < n; k++) { /* :50-55 */
+        cl[current_id].id = current_id;
+        if ((status = cluster_insert(&cl[current_id], k, size ? size[k] : 1))) goto done;
+        slot_of[current_id] = (int32_t)k;
+        alive[current_id] = 1;
+        if ((status = jset_add(&active, current_id))) goto done;
+        current_id++;
+    }
+    uint64_t calls = 0;
+    int64_t sp = 0;
+    while (active.size > 1) { /* :63 */
+        stack[sp++] = jset_first(&active); /* :70-71 */
+        while (sp > 0) {                   /* :72 */
+            const int32_t top = stack[sp - 1];
+            /* findNearestClusterParallel(activeClusters, top, ..) = arg-max over the OTHER active clusters of
+             * (clusterScore, size, -id) among scores >= MIN_VALUE + 42 (:151-176,258-293); null if none */
+            uint32_t na = 0;
+            for (uint32_t b = 0; b < active.cap; b++)
+                for (int32_t id = active.head[b]; id >= 0; id = active.next[id]) active_ids[na++] = id;
+            int st_any = HMO_OK;
+            uint64_t c_any = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads) reduction(+ : c_any) if (n_threads > 1 && na > 256)
+#endif
+            for (int64_t q = 0; q < (int64_t)na; q++) {
+                const int32_t other = active_ids[q];
+                if (other == top) { scores[q] = INT_MIN; continue; }
+                const int32_t sa = slot_of[other], sb = slot_of[top];
+                int32_t *cell = sa > sb ? &memo[sa][sb] : &memo[sb][sa];
+                if (*cell == INT_MAX) {
+                    uint64_t c = 0;
+                    int32_t v;
+                    int st = cluster_score(&sc, threshold, &cl[other], &cl[top], &v, &c); /* clusterScore(i, comparedCluster), :263 */
+                    c_any += c;
+                    if (st) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+                        st_any = st;
+                    }
+                    *cell = v;
+                }
+                scores[q] = *cell;
+            }
+            calls += c_any;
+            stats->searches++;
+            if (st_any) { status = st_any; goto done; }
+            int32_t nearest = -1, max_score = INT_MIN;
+            for (uint32_t q = 0; q < na; q++) {
+                const int32_t other = active_ids[q], s = scores[q];
+                if (other == top || s < INT_MIN + 42) continue;
+                if (nearest < 0 || s > max_score ||
+                    (s == max_score && (cl[other].size > cl[nearest].size ||
+                                        (cl[other].size == cl[nearest].size && other < nearest)))) {
+                    nearest = other;
+                    max_score = s;
+                }
+            }
+            if (nearest < 0 || max_score < threshold) { /* :86-92 */
+                sp--;
+                if ((status = jset_add(&ready, top))) goto done;
+                jset_remove(&active, top);
+                continue;
+            }
+            if (sp > 1 && stack[sp - 2] == nearest) { /* :96 */
+                current_id++;
+                sp -= 2;
+                jset_remove(&active, top);
+                jset_remove(&active, nearest);
+                /* join (:102): the merged cluster's scores are the element-wise min of the two rows where both are
+                 * known; it takes over top's slot, the nearest's slot retires */
+                const int32_t st_ = slot_of[top], sn = slot_of[nearest];
+                for (uint32_t x = 0; x < n; x++) {
+                    if ((int32_t)x == st_ || (int32_t)x == sn) continue;
+                    int32_t *a = (int32_t)x > st_ ? &memo[x][st_] : &memo[st_][x];
+                    const int32_t b = (int32_t)x > sn ? memo[x][sn] : memo[sn][x];
+                    *a = (*a == INT_MAX || b == INT_MAX) ? INT_MAX : (*a < b ? *a : b);
+                }
+                cluster_t *nc = &cl[current_id];
+                nc->id = current_id;
+                if ((status = cluster_insert_all(nc, &cl[top], size))) goto done;     /* :105 top's members first */
+                if ((status = cluster_insert_all(nc, &cl[nearest], size))) goto done; /* :106 */
+                slot_of[current_id] = st_;
+                alive[top] = alive[nearest] = 0;
+                alive[current_id] = 1;
+                if ((status = jset_add(&active, current_id))) goto done;
+                stats->merges++;
+            } else {
+                stack[sp++] = nearest; /* :113 */
+            }
+        }
+    }
+    if ((status = jset_add(&ready, jset_first(&active)))) goto done; /* :118 */
+    {
+        int32_t k_out = 0;
+        for (uint32_t b = 0; b < ready.cap; b++)
+            for (int32_t id = ready.head[b]; id >= 0; id = ready.next[id]) { /* :121-123 HashSet order */
+                for (int32_t m = 0; m < cl[id].n; m++) {
+                    cluster_id[cl[id].members[m]] = id;
+                    if (member_rank) member_rank[cl[id].members[m]] = m;
+                }
+                if (result_order) result_order[k_out] = id;
+                k_out++;
+            }
+        stats->n_result_clusters = k_out;
+    }
+    stats->score_calls = calls;
+done:
+    if (cl)
+        for (uint32_t i = 0; i <= max_id; i++) free(cl[i].members);
+    free(cl); free(slot_of); free(alive); free(stack); free(active_ids); free(scores);
+    if (memo) { for (uint32_t a = 0; a < n; a++) free(memo[a]); free(memo); }
+    if (active.next) jset_free(&active);
+    if (ready.next) jset_free(&ready);
+    return status;
+}
+
+/* ------------------------------------------------------------------ */
 /* UniqueSequence.sortSequences, UniqueSequence.java:176-203,238-261    */
 /* ------------------------------------------------------------------ */
 typedef struct {

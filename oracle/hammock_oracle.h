@@ -102,6 +102,29 @@ int hmo_greedy_cluster(const int32_t *M, const uint8_t *res,
                        int32_t *result_order, int32_t *member_rank,
                        hmo_greedy_stats *stats);
 
+typedef struct {
+    uint64_t score_calls;      /* sequenceScore invocations behind the cluster scores */
+    int32_t merges;            /* clusters joined (ClinkageSequenceClusterer.java:96-111) */
+    int32_t searches;          /* findNearestClusterParallel calls (:77) */
+    int32_t n_result_clusters; /* size of the returned list */
+    int32_t reserved;
+} hmo_clinkage_stats;
+
+/*
+ * ClinkageSequenceClusterer(ShiftedScorer(M, shift_penalty, max_shift), threshold).cluster(sequences)
+ * (ClinkageSequenceClusterer.java:43-124 driven as Hammock.java:458-462 drives it; sequences in LOAD order, clinkage
+ * mode does not sort).  Exact complete linkage by nearest-neighbour chain; the arbitrary start of every chain is
+ * activeClusters.iterator().next() of a java.util.HashSet<Cluster> (Java 8+ iteration order, see hammock_oracle.c).
+ *   cluster_id[n]  : id of the returned cluster holding sequence k (singletons: k + 1; merged clusters: n + 2, n + 3,
+ *                    ... in merge order, ClinkageSequenceClusterer.java:49-55,97)
+ *   result_order[] : ids in the order of the returned list (= iteration order of the HashSet readyClusters)
+ *   member_rank[n] : position of sequence k in its cluster's member list (top's members, then the nearest's, :105-106)
+ * An empty input is HMO_ERR_REFERENCE_WOULD_CRASH (NoSuchElementException at :118).
+ */
+int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *off, const int32_t *size, uint32_t n,
+                         int max_shift, int shift_penalty, int threshold, int n_threads, int32_t *cluster_id,
+                         int32_t *result_order, int32_t *member_rank, hmo_clinkage_stats *stats);
+
 /* UniqueSequence.java:176-203 for order "size" / "alphabetic" / "input":
  * writes the permutation (perm[k] = input index of the k-th sequence in
  * greedy order).  order: 0 size, 1 alphabetic, 2 input. */

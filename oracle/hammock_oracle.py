@@ -360,6 +360,315 @@ def find_nearest_cluster_parallel(input_clusters, compared, scorer, sum_commodit
     return nearest
 
 
+# ---------------------------------------------------------------------------
+# clinkage mode: ClinkageSequenceClusterer.cluster + CachedClusterScorer + DynamicMatrix
+# ---------------------------------------------------------------------------
+class NoSuchElement(Exception):
+    """java.util.NoSuchElementException: activeClusters.iterator().next() on an empty set
+    (ClinkageSequenceClusterer.java:118 with an empty input list)."""
+
+
+def _spread(h):
+    """java.util.HashMap.hash (Java 8+): h ^ (h >>> 16) on the 32-bit hashCode."""
+    h &= 0xFFFFFFFF
+    return h ^ (h >> 16)
+
+
+class JavaHashSet:
+    """Iteration order of java.util.HashSet / HashMap keys, Java 8 and later: power-of-two table starting at 16,
+    load factor 0.75, index = spread(hashCode) & (capacity - 1), a bucket's chain in insertion order (new nodes are
+    appended, a resize splits a chain preserving relative order), no shrinking on removal.  Tree bins (9 nodes in one
+    bucket) never occur for the consecutive integer hash codes used here and are refused.
+    hash_of(element) = the element's Java hashCode(); elements compare by `key_of` (Java equals)."""
+
+    def __init__(self, hash_of, key_of=lambda x: x):
+        self.hash_of, self.key_of = hash_of, key_of
+        self.table = [[] for _ in range(16)]
+        self.size = 0
+
+    def _bucket(self, x):
+        return self.table[_spread(self.hash_of(x)) & (len(self.table) - 1)]
+
+    def add(self, x):
+        b = self._bucket(x)
+        k = self.key_of(x)
+        if any(self.key_of(y) == k for y in b):
+            return False
+        b.append(x)
+        if len(b) >= 9:
+            raise NotImplementedError("HashMap tree bin: iteration order not modelled")
+        self.size += 1
+        if self.size > len(self.table) * 3 // 4:      # ++size > threshold -> resize()
+            old = self.table
+            self.table = [[] for _ in range(2 * len(old))]
+            for chain in old:
+                for y in chain:
+                    self._bucket(y).append(y)
+        return True
+
+    def remove(self, x):
+        b = self._bucket(x)
+        k = self.key_of(x)
+        for i, y in enumerate(b):
+            if self.key_of(y) == k:
+                del b[i]
+                self.size -= 1
+                return True
+        return False
+
+    def __contains__(self, x):
+        k = self.key_of(x)
+        return any(self.key_of(y) == k for y in self._bucket(x))
+
+    def __len__(self):
+        return self.size
+
+    def __iter__(self):
+        for chain in list(self.table):
+            for y in list(chain):
+                yield y
+
+    def first(self):
+        """iterator().next()"""
+        for chain in self.table:
+            if chain:
+                return chain[0]
+        raise NoSuchElement()
+
+
+def _cluster_set():
+    # Cluster.hashCode() = 79 * 7 + id (Cluster.java:178-183); equals compares ids (:185-195)
+    return JavaHashSet(lambda c: 553 + c.id, lambda c: c.id)
+
+
+class DynamicMatrix:
+    """CachedClusterScorer.java:128-280, literally: a lower-triangular List<List<Integer>> with re-used ("dirty") rows."""
+
+    def __init__(self):  # :133-147
+        self.matrix = [[None], [None, None]]
+        self.dirty = JavaHashSet(lambda i: i)
+        self.dirty.add(1)
+
+    def get_row(self, row_index):  # :154-160
+        line = list(self.matrix[row_index])
+        for i in range(row_index + 1, len(self.matrix)):
+            line.append(self.matrix[i][row_index])   # a null row here is a NullPointerException in the reference
+        return line
+
+    def get(self, row_index, column_index):  # :168-175
+        line = self.matrix[max(row_index, column_index)]
+        return line[min(row_index, column_index)] if line is not None else None
+
+    def set(self, row_index, column_index, value):  # :184-196
+        line = self.matrix[max(row_index, column_index)]
+        if line is not None:
+            line[min(row_index, column_index)] = value
+
+    def remove(self, row_index):  # :202-204
+        self.dirty.add(row_index)
+
+    def add_empty(self, matrix_index):  # :213-219
+        self.add_row([None] * (matrix_index + 1), matrix_index)
+
+    def add_value(self, index, row_index, value):  # :230-237
+        line = [None] * len(self.matrix)
+        line[index] = value
+        self.add_row(line, row_index)
+
+    def add_row(self, row, row_index):  # :247-260
+        self.matrix[row_index] = row[:row_index + 1]
+        for i in range(row_index + 1, len(self.matrix)):
+            current = self.matrix[i]
+            if current is not None and i < len(row):
+                current[row_index] = row[i]
+            # else: "Do nothing" -- a stale value of an earlier tenant of this index may stay in column row_index
+
+    def get_matrix_index(self):  # :268-278
+        if len(self.dirty):
+            idx = self.dirty.first()
+            self.dirty.remove(idx)
+        else:
+            idx = len(self.matrix)
+            self.matrix.append(None)
+        return idx
+
+
+class CachedClusterScorer:
+    """CachedClusterScorer.java:23-126 (single-threaded reading of the synchronized collections)."""
+
+    def __init__(self, default_cluster_scorer, size_limit):
+        self.size_limit = size_limit
+        self.default = default_cluster_scorer
+        self.index_map = {}
+        self.matrix = DynamicMatrix()
+        self.default_calls = 0
+
+    def _score(self, cl1, cl2):
+        self.default_calls += 1
+        return self.default.cluster_score(cl1, cl2)
+
+    def cluster_score(self, cl1, cl2):  # :38-79
+        if cl1.get_unique_size() < self.size_limit or cl2.get_unique_size() < self.size_limit:
+            return self._score(cl1, cl2)
+        im, m = self.index_map, self.matrix
+        if cl1.id in im:
+            if cl2.id in im:
+                i1, i2 = im[cl1.id], im[cl2.id]
+                score = m.get(i1, i2)
+                if score is not None:
+                    return score
+                score = self._score(cl1, cl2)
+                m.set(i1, i2, score)
+            else:
+                idx = m.get_matrix_index()
+                score = self._score(cl1, cl2)
+                m.add_value(im[cl1.id], idx, score)
+                im[cl2.id] = idx
+        else:
+            if cl2.id in im:
+                idx = m.get_matrix_index()
+                score = self._score(cl1, cl2)
+                m.add_value(im[cl2.id], idx, score)
+                im[cl1.id] = idx
+            else:
+                first = m.get_matrix_index()
+                second = m.get_matrix_index()
+                score = self._score(cl1, cl2)
+                m.add_empty(first)
+                m.add_empty(second)
+                im[cl1.id] = first
+                im[cl2.id] = second
+        return score
+
+    def join(self, cl1, cl2, new_id):  # :82-125
+        if cl1.get_unique_size() < self.size_limit or cl2.get_unique_size() < self.size_limit:
+            return
+        im, m = self.index_map, self.matrix
+        if cl1.id in im:
+            i1 = im[cl1.id]
+            if cl2.id in im:
+                i2 = im[cl2.id]
+                line1, line2 = m.get_row(i1), m.get_row(i2)
+                new_line = []
+                for a, b in zip(line1, line2):
+                    new_line.append(min(a, b) if a is not None and b is not None else None)
+                m.remove(i1)
+                m.remove(i2)
+                new_index = m.get_matrix_index()
+                m.add_row(new_line, new_index)
+                del im[cl1.id]
+                del im[cl2.id]
+                im[new_id] = new_index
+            else:
+                m.remove(i1)
+                del im[cl1.id]
+        elif cl2.id in im:
+            m.remove(im[cl2.id])
+            del im[cl2.id]
+
+
+def _nearest_over_hash_parts(input_set, compared, scorer, sum_commodity, n_threads):
+    """findNearestClusterParallel (ClinkageSequenceClusterer.java:137-223) with the parts as the HashSets the reference
+    builds (:202-223), evaluated one after the other: the ORDER of the clusterScore calls is what a single pool thread
+    would produce, which matters to the cache's index allocation."""
+    if len(input_set) == 0:
+        return NearestCluster(None, INT_MIN)
+    n_parts = n_threads * 4
+    if len(input_set) < n_threads * 4 + 1:
+        n_parts = max(len(input_set) - 1, 1)
+    parts, current = [], _cluster_set()
+    for_one = sum_commodity // n_parts + 1
+    portion = for_one
+    for cl in input_set:
+        current.add(cl)
+        portion -= cl.get_unique_size()
+        if portion <= 0:
+            parts.append(current)
+            current = _cluster_set()
+            portion = for_one
+    if len(current) > 0:
+        parts.append(current)
+    max_score = INT_MIN + 42
+    nearest = None
+    for part in parts:
+        cur = _nearest_cluster_runner(part, compared, scorer)
+        if cur.score < max_score:
+            continue
+        if cur.score > max_score:
+            nearest = cur
+            max_score = cur.score
+        elif cur.cluster.size() > nearest.cluster.size():
+            nearest = cur
+        elif cur.cluster.size() == nearest.cluster.size() and cur.cluster.id < nearest.cluster.id:
+            nearest = cur
+    return nearest
+
+
+class ClinkageSequenceClusterer:
+    """ClinkageSequenceClusterer.java:21-124: exact complete-linkage clustering by nearest-neighbour chain, at
+    Hammock.nThreads = n_threads with the pool's tasks run one after the other.  size_limit: the constructor's
+    sizeLimit (1 from Hammock.java:459, i.e. every score goes through the cache); a huge value bypasses the cache."""
+
+    def __init__(self, sequence_scorer, threshold, size_limit=1, n_threads=1):
+        self.sequence_scorer = sequence_scorer
+        self.threshold = threshold
+        self.size_limit = size_limit
+        self.n_threads = n_threads
+        self.stats = {}
+
+    def cluster(self, sequences):  # :43-124
+        scorer = CachedClusterScorer(ClinkageClusterScorer(self.sequence_scorer, self.threshold), self.size_limit)
+        stack = []
+        ready = _cluster_set()
+        active = _cluster_set()
+        current_id = 1
+        for seq in sequences:                                   # :50-55
+            active.add(Cluster([seq], current_id))
+            current_id += 1
+        sum_commodity = sum(c.get_unique_size() for c in active)  # :57-59
+        merges = searches = 0
+        while len(active) > 1:                                  # :63
+            stack.append(active.first())                        # :70-71
+            while stack:                                        # :72
+                top = stack[-1]
+                found = _nearest_over_hash_parts(active, top, scorer, sum_commodity, self.n_threads)  # :77
+                searches += 1
+                max_score, nearest = INT_MIN, None
+                if found is not None:                           # :80-83
+                    nearest, max_score = found.cluster, found.score
+                if max_score < self.threshold:                  # :86-92
+                    stack.pop()
+                    ready.add(top)
+                    active.remove(top)
+                    sum_commodity -= top.get_unique_size()
+                    continue
+                if len(stack) > 1 and stack[-2].id == nearest.id:   # :96
+                    current_id += 1
+                    stack.pop()
+                    stack.pop()
+                    active.remove(top)
+                    active.remove(nearest)
+                    scorer.join(top, nearest, current_id)       # :102
+                    sum_commodity -= top.get_unique_size() + nearest.get_unique_size()
+                    merged = top.sequences                      # :105-106: top's own list, then the nearest's members
+                    merged.extend(nearest.sequences)
+                    new_top = Cluster(merged, current_id)
+                    active.add(new_top)
+                    sum_commodity += new_top.get_unique_size()
+                    merges += 1
+                else:
+                    stack.append(nearest)                       # :113
+        ready.add(active.first())                               # :118 (NoSuchElementException for an empty input)
+        self.stats = {"merges": merges, "searches": searches, "default_scorer_calls": scorer.default_calls}
+        return list(ready)                                      # :121-123: the HashSet's iteration order
+
+
+def clinkage_defaults(sequences):
+    """threshold and max shift Hammock derives for `clinkage` (Hammock.java:452-455,1415-1434)."""
+    thr, x, _ = greedy_defaults(sequences)
+    return thr, x
+
+
 class LimitedGreedySequenceClusterer:
     """LimitedGreedySequenceClusterer.java:17-121."""
 

@@ -506,8 +506,119 @@ def test_score_with_shift_vs_oracle(gpu, blosum62, coracle):
 
 
 # --------------------------------------------------------------------------------------
+# clinkage mode (ClinkageSequenceClusterer.cluster) end to end
+# --------------------------------------------------------------------------------------
+def _clinkage_inputs(name):
+    rng = np.random.default_rng(17)
+    if name == "musi":        # the reference's own small example, defaults of Hammock.java:452-455 (thr 20, X 3, p 0)
+        seqs = po.load_unique_sequences_from_fasta(os.path.join(GOLDEN, "musi.fa"))
+        res, off = hammock_amd.pack_sequences([s.get_sequence_string() for s in seqs])
+        return res, off, None, 3, 0, 20
+    if name == "synthetic_1e4":   # the size at which Hammock's `full` mode still picks clinkage (Hammock.java:371-377)
+        res, off = synth_peptides(3, 10000, 12)
+        sizes = np.ones(10000, dtype=np.int32)
+        sizes[::4] = 1 + rng.integers(0, 64, size=2500)   # counts exercise the Cluster.size() tie-break
+        return res, off, sizes, 3, 0, 20
+    if name == "mixed_dense":     # lengths 7..20, shift penalty, a low threshold: long chains and many merges
+        res, off = synth_peptides(4, 3000, 7, 20)
+        return res, off, (1 + rng.integers(0, 3, size=3000)).astype(np.int32), 3, -1, 15
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["musi", "synthetic_1e4", "mixed_dense"])
+def test_clinkage_vs_oracle(gpu, blosum62, coracle, name):
+    """hmk_clinkage_cluster = ClinkageSequenceClusterer.cluster: identical cluster ids (merge order), returned list
+    order (HashSet iteration order) and member order against the oracle."""
+    res, off, sizes, X, p, thr = _clinkage_inputs(name)
+    st, ocid, oorder, orank, ostats = coracle.clinkage_cluster(blosum62, res, off, sizes, X, p, thr, 8)
+    assert st == 0 and ostats.merges > 0
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
+    for _ in range(2):
+        cid, order, stats = ctx.clinkage_cluster(X, p, thr)
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+        assert np.array_equal(ctx.member_rank[:len(cid)], orank)
+        assert (stats.merges, stats.searches, stats.n_result_clusters) == (ostats.merges, ostats.searches, ostats.n_result_clusters)
+    if name == "mixed_dense":   # the same through a two-"device" context (hmk_create_multi)
+        multi = hammock_amd.Context(blosum62, device=[0, 0])
+        multi.set_sequences(residues=res, offsets=off, sizes=sizes)
+        cid, order, _ = multi.clinkage_cluster(X, p, thr)
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(multi.member_rank[:len(cid)], orank)
+
+
+def test_clinkage_edge_cases(gpu, blosum62, coracle):
+    for n in (1, 2, 3):   # one sequence: the loop never runs; two: merged or not
+        res, off = synth_peptides(5, n, 12)
+        for thr in (-40, 200):
+            st, ocid, oorder, orank, _ = coracle.clinkage_cluster(blosum62, res, off, None, 3, 0, thr, 1)
+            ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+            cid, order, _ = ctx.clinkage_cluster(3, 0, thr)
+            assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(ctx.member_rank[:n], orank)
+    ctx = hammock_amd.Context(blosum62, device=0)
+    with pytest.raises(hammock_amd.ReferenceWouldCrash):   # NoSuchElementException, ClinkageSequenceClusterer.java:118
+        ctx.clinkage_cluster(3, 0, 20)
+    M = blosum62.copy()
+    M[0, 1] += 1
+    res, off = synth_peptides(5, 50, 12)
+    actx, _, _ = ctx_for(M, res=res, off=off)
+    with pytest.raises(ValueError) as ei:
+        actx.clinkage_cluster(3, 0, 20)
+    assert "symmetric" in str(ei.value)
+
+
+def test_python_mirror_clinkage_clusterer(gpu, blosum62, coracle):
+    """HipClinkageSequenceClusterer: the ClinkageSequenceClusterer(scorer, threshold).cluster(List) contract."""
+    res, off = synth_peptides(8, 1500, 12)
+    seqs = [hammock_amd.UniqueSequence("".join(hammock_amd.AMINO_ACIDS[int(c)] for c in res[off[k]:off[k + 1]])) for k in range(1500)]
+    clusters = hammock_amd.HipClinkageSequenceClusterer(hammock_amd.ShiftedScorer(blosum62, 0, 3), 18).cluster(seqs)
+    st, ocid, oorder, orank, _ = coracle.clinkage_cluster(blosum62, res, off, None, 3, 0, 18, 4)
+    assert st == 0 and [c.getId() for c in clusters] == oorder.tolist()
+    index = {id(s): k for k, s in enumerate(seqs)}
+    for c in clusters:
+        ks = [index[id(s)] for s in c.getSequences()]
+        assert all(ocid[k] == c.getId() for k in ks) and [int(orank[k]) for k in ks] == list(range(len(ks)))
+
+
+# --------------------------------------------------------------------------------------
 # the C++ host side + CLI end to end (hammock-hip greedy == `java -jar Hammock.jar greedy`)
 # --------------------------------------------------------------------------------------
+def test_cli_clinkage_writes_reference_files(gpu, blosum62, coracle, tmp_path):
+    """`hammock-hip clinkage` = `java -jar Hammock.jar clinkage` (Hammock.java:236-253, :449-489) on the reference's MUSI
+    example with all defaults: the three stage-1 files and input_statistics.tsv byte for byte against the oracle's
+    clustering written by the writers' restatement; -L is accepted and logged (no effect, as in the reference)."""
+    import subprocess
+    from conftest import ROOT
+    cli = os.path.join(ROOT, "hammock_amd", "bin", "hammock-hip")
+    fa = os.path.join(GOLDEN, "musi.fa")
+    out = str(tmp_path / "out")
+    r = subprocess.run([cli, "clinkage", "-i", fa, "-d", out, "-L", "5"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    seqs = po.load_unique_sequences_from_fasta(fa)
+    labels = po.get_sorted_labels(seqs)
+    thr, X = po.clinkage_defaults(seqs)
+    res, off = coracle.pack([s.get_sequence_string() for s in seqs])
+    sizes = np.array([s.size() for s in seqs], dtype=np.int32)
+    st, cid, order, rank, stats = coracle.clinkage_cluster(blosum62, res, off, sizes, X, 0, thr, 4)
+    assert st == 0
+    members = {}
+    for k in np.lexsort((rank, cid)):
+        members.setdefault(int(cid[k]), []).append(seqs[k])
+    cl_list = [po.Cluster(members[c], c) for c in order.tolist()]
+    exp = tmp_path / "exp"
+    exp.mkdir()
+    po.save_input_statistics(seqs, labels, str(exp / "input_statistics.tsv"))
+    po.save_cluster_sequences_csv(cl_list, str(exp / "initial_clusters_sequences.tsv"), labels)
+    po.write_cluster_sequences_csv(seqs, cl_list, str(exp / "initial_clusters_sequences_original_order.tsv"), labels)
+    po.save_clusters_csv(cl_list, str(exp / "initial_clusters.tsv"), labels)
+    for name in ("input_statistics.tsv", "initial_clusters_sequences.tsv",
+                 "initial_clusters_sequences_original_order.tsv", "initial_clusters.tsv"):
+        with open(os.path.join(out, name), "rb") as a, open(exp / name, "rb") as b:
+            assert a.read() == b.read(), name
+    log = open(os.path.join(out, "run.log")).read()
+    assert 'Program started in mode "clinkage".' in log and "-C, --cache_size_limit 5" in log
+    assert f"Clinkage clustering threshold not set. Setting automatically to: {thr}" in log
+    assert f"Resulting clusers: {len(order)}" in log
+
+
 @pytest.mark.parametrize("dataset", ["musi", "manual_counts", "musi_two_devices"])
 def test_cli_greedy_writes_reference_files(gpu, blosum62, coracle, tmp_path, dataset):
     import subprocess

@@ -298,3 +298,70 @@ def test_synth_generator(coracle):
     res2, off2 = coracle.synth(1, 500, 7, 20)
     L = np.diff(off2.astype(np.int64))
     assert L.min() >= 7 and L.max() <= 20 and len(set(L.tolist())) == 14
+
+
+# --------------------------------------------------------------------------------------
+# clinkage mode (ClinkageSequenceClusterer + CachedClusterScorer + DynamicMatrix)
+# --------------------------------------------------------------------------------------
+def _clinkage_python(M, peps, sizes, X, p, thr, n_threads=1, size_limit=1):
+    seqs = [po.UniqueSequence(to_str(q), {"no_label": int(sizes[k]) if sizes is not None else 1}) for k, q in enumerate(peps)]
+    cl = po.ClinkageSequenceClusterer(po.ShiftedScorer(M.tolist(), p, X), thr, size_limit=size_limit, n_threads=n_threads)
+    result = cl.cluster(seqs)
+    index_of = {id(s): k for k, s in enumerate(seqs)}
+    cid = np.full(len(peps), -1, dtype=np.int32)
+    rank = np.full(len(peps), -1, dtype=np.int32)
+    for c in result:
+        for pos, s in enumerate(c.sequences):
+            cid[index_of[id(s)]] = c.id
+            rank[index_of[id(s)]] = pos
+    return cid, [c.id for c in result], rank, cl.stats
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_clinkage_c_vs_literal_python(blosum62, coracle, seed):
+    """The C form (own memo of cluster scores, HashSet order emulated) against the literal Python restatement
+    (CachedClusterScorer + DynamicMatrix + HashSet parts) on random inputs with real merges."""
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(2, 260))
+    peps = random_peptides(rng, n, 8 if seed % 2 else 12, 12, alphabet=3 + seed % 4)
+    sizes = rng.integers(1, 4, size=n).astype(np.int32) if seed % 3 else None
+    res, off = coracle.pack(peps)
+    X, p, thr = seed % 4, -(seed % 2), 10 + 3 * seed
+    st, cid, order, rank, stats = coracle.clinkage_cluster(blosum62, res, off, sizes, X, p, thr, 1 + seed % 3)
+    assert st == 0
+    pcid, porder, prank, pstats = _clinkage_python(blosum62, peps, sizes, X, p, thr)
+    assert np.array_equal(cid, pcid) and order.tolist() == porder and np.array_equal(rank, prank)
+    assert stats.merges == pstats["merges"] and stats.searches == pstats["searches"]
+    if seed < 3:
+        assert stats.merges > 0
+
+
+def test_clinkage_independent_of_threads_and_cache(blosum62):
+    """DESIGN.md (round 1) argued that the reference's clinkage result depends on -t through stale DynamicMatrix
+    entries.  The literal restatement says otherwise for a single pool thread working through the parts in order:
+    only the very first clusterScore call takes the addEmpty path (whose re-used row could keep stale columns), every
+    later row comes from add(index, row, value) or join(), which overwrite the whole column.  So the cache is a
+    transparent memo: same clusters for every part count and with the cache bypassed (sizeLimit = infinity)."""
+    rng = np.random.default_rng(77)
+    for it in range(12):
+        n = int(rng.integers(20, 140))
+        peps = random_peptides(rng, n, 9, 12, alphabet=3 + it % 3)
+        sizes = rng.integers(1, 5, size=n).astype(np.int32)
+        thr = 12 + 2 * (it % 5)
+        ref = _clinkage_python(blosum62, peps, sizes, 2, 0, thr, 1, 1)
+        for t, sl in ((2, 1), (4, 1), (16, 1), (1, 10 ** 9), (4, 10 ** 9)):
+            cur = _clinkage_python(blosum62, peps, sizes, 2, 0, thr, t, sl)
+            assert np.array_equal(cur[0], ref[0]) and cur[1] == ref[1] and np.array_equal(cur[2], ref[2]), (it, t, sl)
+
+
+def test_clinkage_known_small_case(blosum62, coracle):
+    """Hand-checkable: three near-identical peptides and one stranger at a high threshold.  Ids: singletons k + 1,
+    the first merge gets n + 2 (currentId is n + 1 after the initial loop and is incremented BEFORE use, :97)."""
+    peps = ["WVTAPRSLPVLP", "WVTAPRSLPVLA", "WVTAPRSLPVLG", "GSWVVDISNVED"]
+    res, off = coracle.pack(peps)
+    st, cid, order, rank, stats = coracle.clinkage_cluster(blosum62, res, off, None, 3, 0, 40, 1)
+    assert st == 0 and stats.merges == 2
+    assert cid.tolist() == [7, 7, 7, 4] and sorted(order.tolist()) == [4, 7]
+    assert sorted(rank[:3].tolist()) == [0, 1, 2]
+    st, *_ = coracle.clinkage_cluster(blosum62, *coracle.pack([]), None, 0, 0, 10, 1)
+    assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH   # NoSuchElementException, ClinkageSequenceClusterer.java:118
