@@ -705,10 +705,16 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
                                uint64_t *d_edges, uint64_t capacity, unsigned long long *d_counts, hipStream_t stream) {
     int st = need_device(ctx);
     if (st) return st;
-    if (gap_open > 0 || gap_extend > 0 || ctx->min_m < -127 || ctx->max_m > 127)
-        return fail(ctx, HMK_ERR_BAD_ARG,
-                    "hmk_neighbors_local needs gap penalties <= 0 and matrix entries in [-127, 127] "
-                    "(use hmk_score_block_local, which has a literal fallback, otherwise)");
+    // the striped register kernels take gap penalties <= 0 and int8 matrix entries; anything else (the reference imposes
+    // neither, LocalAlignmentScorer.java:43-55) runs the literal DP on the same tiles
+    const bool literal = gap_open > 0 || gap_extend > 0 || ctx->min_m < -127 || ctx->max_m > 127 || getenv("HMK_LOCAL_LITERAL") != nullptr;
+    {   // edge scores travel as int16
+        const long long top = (long long)ctx->max_len * std::max(0, ctx->max_m) +
+                              2LL * ctx->max_len * (long long)std::max(0, std::max(gap_open, gap_extend));
+        if (top > 32767 || thr < -30000 || thr > 30000)
+            return fail(ctx, HMK_ERR_BAD_ARG, "scores up to " + std::to_string(top) + " are possible with this matrix / these gap penalties "
+                                               "(or the threshold is outside [-30000, 30000]): they do not fit the int16 score of a packed edge");
+    }
     st = build_plan_local(ctx, part, n_parts);
     if (st) return st;
     PlanLocal &pl = ctx->plan_local;
@@ -726,7 +732,10 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
     P.lpad = 32;
     P.symmetric = 0;
     P.row_is_m = 1;
-    HIPCHK(ctx, launch_neighbors_local(ctx->max_len, local_enc(ctx, gap_open, gap_extend), P, 0, pl.n_tiles, ctx->d_M, gap_open, gap_extend, thr, stream));
+    if (literal)
+        HIPCHK(ctx, launch_neighbors_local_literal(P, 0, pl.n_tiles, ctx->d_M, gap_open, gap_extend, thr, stream));
+    else
+        HIPCHK(ctx, launch_neighbors_local(ctx->max_len, local_enc(ctx, gap_open, gap_extend), P, 0, pl.n_tiles, ctx->d_M, gap_open, gap_extend, thr, stream));
     return HMK_OK;
 }
 

@@ -29,6 +29,10 @@ hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, co
 hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
                                   const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s);
 
+// the same pass with the literal DP: any gap penalties, any matrix range
+hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, const int32_t *d_matrix,
+                                          int gap_open, int gap_extend, int threshold, hipStream_t s);
+
 // edge segments -> CSR (start[row_limit + 1], adj[]) on the device; rows at and beyond row_limit are left out
 // (row_limit = n: the whole graph).  deg / up: zeroed uint32[row_limit]; cursor: zeroed uint32[2 row_limit];
 // score_range: device int[3] = {min score, max score, invalid edges}

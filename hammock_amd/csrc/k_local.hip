@@ -465,6 +465,82 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
 }
 
 // -----------------------------------------------------------------------------
+// k_neighbors_local_literal: the same pass with the literal DP (LocalAlignmentScorer.java:31-86 line by line)
+// -----------------------------------------------------------------------------
+// For what the striped kernels do not take: positive gap penalties (the reference imposes no sign, :43-55) and matrix
+// entries beyond int8.  Same tiles, same edge orientation (row = seq1 = m, column = seq2 = x), one column per lane.
+__global__ void __launch_bounds__(256)
+k_neighbors_local_literal(const NeighborParams P, const uint32_t tile_base, const int32_t *__restrict__ Mg, int gap_open,
+                          int gap_extend, int threshold) {
+    constexpr int R = 16, STAGE_CAP = 128, REC_DW = 3;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int *M = reinterpret_cast<int *>(smem);                                   // 576 dwords
+    uint32_t *colseq = reinterpret_cast<uint32_t *>(smem + 2304);             // 256 x 9 dwords
+    uint32_t *rowseq = colseq + 256 * SEQ_STRIDE_DW;                          // R x 8 dwords
+    uint32_t *dp = rowseq + R * 8;                                            // 33 x 256 dwords: one DP line per lane
+    uint32_t *stage_all = dp + 33 * 256;
+    const Tile T = P.tiles[tile_base + blockIdx.x];
+    const TileClass *Cp = P.classes + T.cls;
+    const int la = Cp->la, lb = Cp->lb;
+    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const int tid = threadIdx.x;
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
+    for (int e = tid; e < 576; e += 256) M[e] = Mg[e];
+    for (int e = tid; e < R * 8; e += 256) {
+        const int r = e >> 3, q = e & 7;
+        uint32_t v = 0;
+        if ((uint32_t)r < T.nrows && (uint32_t)(q * 4) < P.lpad)
+            v = reinterpret_cast<const uint32_t *>(P.res_sorted + (size_t)(T.row0 + r) * P.lpad)[q];
+        rowseq[e] = v;
+    }
+    __syncthreads();
+    uint32_t cnt = 0;
+    const uint32_t col_end = T.col0 + T.ncols;
+    uint32_t *mine = colseq + tid * SEQ_STRIDE_DW;
+    for (uint32_t c0 = T.col0; c0 < col_end; c0 += 256) {
+        const uint32_t col = c0 + tid;
+        if (col < col_end) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(P.res_sorted + (size_t)col * P.lpad);
+            for (uint32_t q = 0; q < P.lpad / 4; q++) mine[q] = src[q];
+        }
+        for (uint32_t r = 0; r < T.nrows; r++) {
+            if (cnt > (uint32_t)(STAGE_CAP - 64)) {
+                flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+                cnt = 0;
+            }
+            bool keep = col < col_end;
+            if (T.diag) keep = keep && col != T.row0 + r;
+            int score = 0;
+            if (keep) {
+                score = local_score_literal(M, reinterpret_cast<const uint8_t *>(rowseq + r * 8), la,
+                                            reinterpret_cast<const uint8_t *>(mine), lb, gap_open, gap_extend, dp + tid, 256);
+                keep = score >= threshold;
+            }
+            const uint64_t mask = __ballot(keep);
+            if (mask != 0) {
+                if (keep) {
+                    HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
+                    rec[0] = col;
+                    rec[1] = r;
+                    rec[2] = (uint32_t)score;
+                }
+                cnt += (uint32_t)__popcll(mask);
+            }
+        }
+    }
+    flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+}
+
+hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, const int32_t *d_matrix,
+                                          int gap_open, int gap_extend, int threshold, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    const size_t lds = 2304 + 256 * SEQ_STRIDE_DW * 4 + 16 * 8 * 4 + 33 * 256 * 4 + 4 * 128 * 3 * 4;
+    hipLaunchKernelGGL(k_neighbors_local_literal, dim3(n_tiles), dim3(256), lds, s, P, tile_base, d_matrix, gap_open, gap_extend,
+                       threshold);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------
 hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,

@@ -1,11 +1,13 @@
 /*
  * Drop-in for LimitedGreedySequenceClusterer (LimitedGreedySequenceClusterer.java:17-121): same
  * constructor shape, same cluster() contract, the whole pair space scored on one MI355X.
- * Swap it in at Hammock.java:403:
+ * Swap it in at Hammock.java:402-403 (two lines, no casts):
  *
  *   AligningSequenceScorer scorer = new HipShiftedScorer(scoringMatrix, shiftPenalty, maxShift);
- *   SequenceClusterer clusterer = new HipGreedySequenceClusterer((HipShiftedScorer) scorer,
- *           sequenceClusteringThreshold, initialClustersLimit);
+ *   SequenceClusterer clusterer = new HipGreedySequenceClusterer(scorer, sequenceClusteringThreshold, initialClustersLimit);
+ *
+ * Any other AligningSequenceScorer is accepted as well and simply runs the reference's own
+ * LimitedGreedySequenceClusterer, so the class is a strict superset of the one it replaces.
  *
  * SOURCE ONLY (no JDK in the build image), see HipNative.java.
  */
@@ -19,12 +21,15 @@ import java.util.concurrent.ExecutionException;
 
 public class HipGreedySequenceClusterer implements SequenceClusterer {
 
-    private final HipShiftedScorer sequenceScorer;
+    private final AligningSequenceScorer anyScorer;
+    private final HipShiftedScorer sequenceScorer;   // non-null: the native path
     private final int threshold;
     private final int maxClusters;
 
-    public HipGreedySequenceClusterer(HipShiftedScorer sequenceScorer, int threshold, int maxClusters) {
-        this.sequenceScorer = sequenceScorer;
+    /** Same signature as LimitedGreedySequenceClusterer(AligningSequenceScorer, int, int), LimitedGreedySequenceClusterer.java:22. */
+    public HipGreedySequenceClusterer(AligningSequenceScorer sequenceScorer, int threshold, int maxClusters) {
+        this.anyScorer = sequenceScorer;
+        this.sequenceScorer = sequenceScorer instanceof HipShiftedScorer ? (HipShiftedScorer) sequenceScorer : null;
         this.threshold = threshold;
         this.maxClusters = maxClusters;
     }
@@ -37,6 +42,9 @@ public class HipGreedySequenceClusterer implements SequenceClusterer {
      */
     @Override
     public List<Cluster> cluster(List<UniqueSequence> sequences) throws InterruptedException, ExecutionException, DataException {
+        if (sequenceScorer == null) {   // not a GPU scorer: the reference's own clusterer
+            return new LimitedGreedySequenceClusterer(anyScorer, threshold, maxClusters).cluster(sequences);
+        }
         int n = sequences.size();
         synchronized (sequenceScorer) {
             HipShiftedScorer.upload(sequenceScorer.ctx, sequences);

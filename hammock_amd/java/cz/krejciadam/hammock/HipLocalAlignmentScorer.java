@@ -4,16 +4,34 @@
  */
 package cz.krejciadam.hammock;
 
-public class HipLocalAlignmentScorer implements SequenceScorer {
+public class HipLocalAlignmentScorer implements SequenceScorer, AutoCloseable {
 
     private final int gapOpenPenalty;
     private final int gapExtendPenalty;
-    private final long ctx;
+    private long ctx;
 
+    /** LocalAlignmentScorer(scoringMatrix, gapOpenPenalty, gapExtendPenalty); GPU = first entry of hammock.hip.devices. */
     public HipLocalAlignmentScorer(int[][] scoringMatrix, int gapOpenPenalty, int gapExtendPenalty) {
         this.gapOpenPenalty = gapOpenPenalty;
         this.gapExtendPenalty = gapExtendPenalty;
-        this.ctx = HipNative.create(HipShiftedScorer.flatten(scoringMatrix), 0);
+        this.ctx = HipNative.create(HipShiftedScorer.flatten(scoringMatrix), HipShiftedScorer.devicesFromProperty()[0]);
+    }
+
+    @Override
+    public synchronized void close() {
+        if (ctx != 0) {
+            HipNative.destroy(ctx);
+            ctx = 0;
+        }
+    }
+
+    @Override
+    protected void finalize() throws Throwable {
+        try {
+            close();
+        } finally {
+            super.finalize();
+        }
     }
 
     @Override

@@ -21,6 +21,9 @@ final class HipNative {
     /** hmk_create: matrix is int[24][24] flattened row-major (Hammock.scoringMatrix). Returns the context handle. */
     static native long create(int[] matrix576, int device);
 
+    /** hmk_create_multi: the pair space sharded over several GPUs of the node; devices[0] runs the merge. */
+    static native long createMulti(int[] matrix576, int[] devices);
+
     /** hmk_destroy */
     static native void destroy(long ctx);
 
@@ -39,5 +42,13 @@ final class HipNative {
      * (LimitedGreedySequenceClusterer.java:97/104/108), DataException for "Shift too big".
      */
     static native int greedyCluster(long ctx, int maxShift, int shiftPenalty, int threshold, int maxClusters,
+            int[] clusterId, int[] resultOrder, int[] memberRank) throws DataException;
+
+    /**
+     * hmk_clinkage_cluster (sequences in load order). Same outputs as greedyCluster; cluster ids as
+     * ClinkageSequenceClusterer assigns them. Throws NoSuchElementException for an empty input
+     * (ClinkageSequenceClusterer.java:118), DataException for "Shift too big".
+     */
+    static native int clinkageCluster(long ctx, int maxShift, int shiftPenalty, int threshold,
             int[] clusterId, int[] resultOrder, int[] memberRank) throws DataException;
 }

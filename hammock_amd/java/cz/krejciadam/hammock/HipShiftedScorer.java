@@ -6,18 +6,56 @@
  */
 package cz.krejciadam.hammock;
 
-public class HipShiftedScorer implements AligningSequenceScorer {
+public class HipShiftedScorer implements AligningSequenceScorer, AutoCloseable {
 
     final int[][] scoringMatrix;
     final int shiftPenalty;
     final int maxShift;
-    final long ctx;
+    long ctx;
 
+    /**
+     * Same shape as ShiftedScorer(scoringMatrix, shiftPenalty, maxShift) (ShiftedScorer.java:28-32). The GPU(s) come
+     * from the system property hammock.hip.devices, a comma separated list of HIP ordinals (default "0"); more than
+     * one shards the pair space over them (hmk_create_multi), the first one runs the merge:
+     * java -Dhammock.hip.devices=0,1,2,3,4,5,6,7 -jar Hammock.jar greedy ...
+     */
     public HipShiftedScorer(int[][] scoringMatrix, int shiftPenalty, int maxShift) {
+        this(scoringMatrix, shiftPenalty, maxShift, devicesFromProperty());
+    }
+
+    public HipShiftedScorer(int[][] scoringMatrix, int shiftPenalty, int maxShift, int[] devices) {
         this.scoringMatrix = scoringMatrix;
         this.shiftPenalty = shiftPenalty;
         this.maxShift = maxShift;
-        this.ctx = HipNative.create(flatten(scoringMatrix), 0);
+        this.ctx = devices.length == 1 ? HipNative.create(flatten(scoringMatrix), devices[0])
+                                       : HipNative.createMulti(flatten(scoringMatrix), devices);
+    }
+
+    static int[] devicesFromProperty() {
+        String[] parts = System.getProperty("hammock.hip.devices", "0").split(",");
+        int[] devices = new int[parts.length];
+        for (int k = 0; k < parts.length; k++) {
+            devices[k] = Integer.decode(parts[k].trim());
+        }
+        return devices;
+    }
+
+    /** Releases the native context (device buffers, streams). The scorer must not be used afterwards. */
+    @Override
+    public synchronized void close() {
+        if (ctx != 0) {
+            HipNative.destroy(ctx);
+            ctx = 0;
+        }
+    }
+
+    @Override
+    protected void finalize() throws Throwable {
+        try {
+            close();
+        } finally {
+            super.finalize();
+        }
     }
 
     static int[] flatten(int[][] m) {

@@ -1,7 +1,8 @@
 /*
  * hammock_jni.c -- JNI glue between cz.krejciadam.hammock.HipNative and the C ABI of
  * include/hammock_hip.h.  SOURCE ONLY: this image has no JDK (no jni.h), so this file is
- * not part of the in-tree build.  Build where a JDK exists:
+ * not part of the in-tree build; tests/test_cli_io.py compiles it against a declaration-only
+ * stand-in (tests/jni_stub/jni.h) so that it cannot rot.  Build where a JDK exists:
  *
  *   gcc -shared -fPIC -I"$JAVA_HOME/include" -I"$JAVA_HOME/include/linux" -Iinclude \
  *       hammock_amd/java/jni/hammock_jni.c -Lhammock_amd/lib -lhammock_hip \
@@ -33,6 +34,19 @@ JNIEXPORT jlong JNICALL Java_cz_krejciadam_hammock_HipNative_create(JNIEnv *env,
     jint *m = (*env)->GetIntArrayElements(env, matrix, NULL);
     int st = hmk_create((const int32_t *)m, device, &ctx);
     (*env)->ReleaseIntArrayElements(env, matrix, m, JNI_ABORT);
+    if (st) throw_for(env, NULL, st);
+    return (jlong)(intptr_t)ctx;
+}
+
+JNIEXPORT jlong JNICALL Java_cz_krejciadam_hammock_HipNative_createMulti(JNIEnv *env, jclass c, jintArray matrix, jintArray devices) {
+    (void)c;
+    hmk_ctx *ctx = NULL;
+    jsize n = (*env)->GetArrayLength(env, devices);
+    jint *m = (*env)->GetIntArrayElements(env, matrix, NULL);
+    jint *d = (*env)->GetIntArrayElements(env, devices, NULL);
+    int st = hmk_create_multi((const int32_t *)m, (const int *)d, (int)n, &ctx);
+    (*env)->ReleaseIntArrayElements(env, matrix, m, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, devices, d, JNI_ABORT);
     if (st) throw_for(env, NULL, st);
     return (jlong)(intptr_t)ctx;
 }
@@ -96,6 +110,27 @@ JNIEXPORT jint JNICALL Java_cz_krejciadam_hammock_HipNative_greedyCluster(JNIEnv
     (*env)->ReleaseIntArrayElements(env, clusterId, cid, 0);
     (*env)->ReleaseIntArrayElements(env, resultOrder, ord, 0);
     (*env)->ReleaseIntArrayElements(env, memberRank, rank, 0);
+    if (st) { throw_for(env, ctx, st); return 0; }
+    return stats.n_result_clusters;
+}
+
+JNIEXPORT jint JNICALL Java_cz_krejciadam_hammock_HipNative_clinkageCluster(JNIEnv *env, jclass c, jlong h, jint maxShift,
+                                                                            jint shiftPenalty, jint threshold, jintArray clusterId,
+                                                                            jintArray resultOrder, jintArray memberRank) {
+    (void)c;
+    hmk_ctx *ctx = (hmk_ctx *)(intptr_t)h;
+    jint *cid = (*env)->GetIntArrayElements(env, clusterId, NULL);
+    jint *ord = (*env)->GetIntArrayElements(env, resultOrder, NULL);
+    jint *rank = (*env)->GetIntArrayElements(env, memberRank, NULL);
+    hmk_clinkage_stats stats;
+    int st = hmk_clinkage_cluster(ctx, maxShift, shiftPenalty, threshold, (int32_t *)cid, (int32_t *)ord, (int32_t *)rank, &stats);
+    (*env)->ReleaseIntArrayElements(env, clusterId, cid, 0);
+    (*env)->ReleaseIntArrayElements(env, resultOrder, ord, 0);
+    (*env)->ReleaseIntArrayElements(env, memberRank, rank, 0);
+    if (st == HMK_ERR_REFERENCE_WOULD_CRASH) {   /* activeClusters.iterator().next() on an empty set, :118 */
+        (*env)->ThrowNew(env, (*env)->FindClass(env, "java/util/NoSuchElementException"), hmk_last_error(ctx));
+        return 0;
+    }
     if (st) { throw_for(env, ctx, st); return 0; }
     return stats.n_result_clusters;
 }

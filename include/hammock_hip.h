@@ -140,8 +140,8 @@ int hmk_neighbors_shifted(hmk_ctx *ctx, int max_shift, int shift_penalty, int th
 /* The same for LocalAlignmentScorer(matrix, gap_open, gap_extend) (LocalAlignmentScorer.java:27-86): ALL
  * ORDERED pairs (the scorer depends on the argument order) with sequenceScore(seq1 = m, seq2 = x) >= threshold,
  * as edges (x, m, score).  This is the batch form of the stage-2 pre-filter `sequenceScore(first, i) >= 12`
- * (ClustalRunner.java:81-96, Hammock.java:118-121,645-649).  Needs gap penalties <= 0 and |matrix| <= 127
- * (HMK_ERR_BAD_ARG otherwise; hmk_score_block_local has no such restriction). */
+ * (ClustalRunner.java:81-96, Hammock.java:118-121,645-649).  Gap penalties <= 0 and |matrix| <= 127 run the striped
+ * register kernels; anything else (the reference restricts neither) runs the literal DP on the same tiles. */
 int hmk_neighbors_local(hmk_ctx *ctx, int gap_open, int gap_extend, int threshold, uint32_t part,
                         uint32_t n_parts, uint64_t *edges, uint64_t capacity, uint64_t *n_edges,
                         hmk_neighbor_stats *stats);

@@ -96,3 +96,26 @@ def test_cli_argument_errors(tmp_path):
     r = cli("greedy", "-i", os.path.join(GOLDEN, "musi.fa"), "-d", str(tmp_path / "o2"), "-f", "xml")
     assert r.returncode == 2 and "Parameter -f" in r.stderr
     assert cli("full", "-i", "x").returncode == 2                          # other modes are out of scope
+
+
+def test_jni_shim_compiles_and_covers_every_native_method(tmp_path):
+    """The Java side cannot be built here (no JDK).  The C half of the shim can at least be held to compiling: it is
+    compiled with -Wall -Wextra -Werror against tests/jni_stub/jni.h (a declaration-only stand-in, NOT the JDK header)
+    and include/hammock_hip.h, and every `static native` method of HipNative.java must have its
+    Java_cz_krejciadam_hammock_HipNative_<name> function in the object file."""
+    import re
+    import subprocess
+    obj = str(tmp_path / "hammock_jni.o")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fPIC", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
+                           "-I" + os.path.join(ROOT, "include"), "-c",
+                           os.path.join(ROOT, "hammock_amd", "java", "jni", "hammock_jni.c"), "-o", obj])
+    syms = subprocess.check_output(["nm", obj], text=True)
+    defined = set(re.findall(r" T (Java_cz_krejciadam_hammock_HipNative_\w+)", syms))
+    java = open(os.path.join(ROOT, "hammock_amd", "java", "cz", "krejciadam", "hammock", "HipNative.java")).read()
+    natives = re.findall(r"static native [\w\[\]]+ (\w+)\(", java)
+    assert len(natives) >= 8
+    assert {"Java_cz_krejciadam_hammock_HipNative_" + m for m in natives} == defined
+    # every C ABI function the shim calls is one the header declares and the library exports
+    called = set(re.findall(r"\b(hmk_\w+)\(", open(os.path.join(ROOT, "hammock_amd", "java", "jni", "hammock_jni.c")).read()))
+    from hammock_amd import _native
+    assert called <= set(_native.SYMBOLS), called - set(_native.SYMBOLS)

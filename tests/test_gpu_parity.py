@@ -796,6 +796,50 @@ def test_greedy_full_size_mixed_lengths_1e5_vs_oracle(gpu, blosum62, coracle):
     assert stats.phase1_stop_index == ostats.phase1_stop_index
 
 
+def test_million_peptides_greedy_end_to_end(gpu, blosum62, coracle, monkeypatch):
+    """BASELINE config 5's input (10^6 x 12, SplitMix64 seed 1) through hmk_greedy_cluster on this one GPU: 5 x 10^11
+    pairs scored, the second loop on the device.  The oracle needs minutes at this size, so the checks are the
+    size-independent ones: 25,000 clusters whose ids are their seeds in creation order; EVERY pair inside every cluster
+    scores >= threshold (complete linkage, rescored by hmk_score_pairs_shifted and, sampled, by the oracle); and the whole
+    result -- ids, list order, member order -- equals the one produced with the second loop forced onto the HOST
+    implementation (the round-1 code path, an independent implementation over the fetched adjacency)."""
+    n, thr, maxc = 1000000, 20, 25000
+    res, off = synth_peptides(1, n, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    cid, order, stats = ctx.greedy_cluster(3, 0, thr, maxc)
+    rank = ctx.member_rank[:n].copy()
+    ph = ctx.greedy_phases()
+    assert ph["loop_rounds"] > 0                      # the device-side second loop ran
+    assert stats.n_multi == maxc and stats.phase1_clusters == maxc and stats.phase1_stop_index >= maxc
+    assert stats.n_result_clusters == len(order) and len(np.unique(order)) == len(order)
+    multi_ids = order[:maxc]
+    # creation order = seed order; `index` counts list positions AFTER the removals of absorbed sequences (:101,:110), so
+    # the last seed's own position in the input is at most stop index + clusters
+    assert (np.diff(multi_ids) > 0).all() and multi_ids[-1] < stats.phase1_stop_index + maxc
+    assert (cid[multi_ids] == multi_ids).all() and (rank[multi_ids] == 0).all()         # a cluster's id is its seed
+    sizes = np.bincount(cid, minlength=n)
+    assert (sizes[multi_ids] >= 2).all() and (sizes[order[maxc:]] == 1).all() and sizes.sum() == n
+    # complete linkage: all pairs inside every cluster are neighbours
+    members = np.flatnonzero(sizes[cid] >= 2)
+    members = members[np.lexsort((rank[members], cid[members]))]
+    bounds = np.flatnonzero(np.diff(cid[members])) + 1
+    ii, jj = [], []
+    for grp in np.split(members, bounds):
+        a, b = np.triu_indices(len(grp), 1)
+        ii.append(grp[a]); jj.append(grp[b])
+    ii, jj = np.concatenate(ii).astype(np.uint32), np.concatenate(jj).astype(np.uint32)
+    sc = ctx.score_pairs_shifted(ii, jj, 3, 0)
+    assert len(sc) > 200000 and (sc >= thr).all()
+    pick = np.random.default_rng(0).choice(len(ii), 100000, replace=False)
+    st, want = coracle.score_pairs(blosum62, res, off, ii[pick], jj[pick], 0, 3, 0)
+    assert st == 0 and np.array_equal(want, sc[pick])
+    # the same clustering from the host implementation of the second loop
+    monkeypatch.setenv("HMK_SECOND_LOOP", "host")
+    cid2, order2, _ = ctx.greedy_cluster(3, 0, thr, maxc)
+    assert ctx.greedy_phases()["loop_rounds"] == 0
+    assert np.array_equal(cid, cid2) and np.array_equal(order, order2) and np.array_equal(rank, ctx.member_rank[:n])
+
+
 def test_million_peptide_shard_properties(gpu, blosum62, coracle):
     """BASELINE config 5 size (10^6 x 12), one of 8 row-block shards: pair count, density, sampled oracle parity."""
     n = 1000000
@@ -868,8 +912,79 @@ def test_neighbors_local_vs_oracle(gpu, matrices, coracle, cfg):
     # sharding partitions the edge set
     parts = [ctx.neighbors_local(go, ge, thr, part=k, n_parts=3)[0] for k in range(3)]
     assert np.array_equal(np.sort(np.concatenate(parts)), want)
-    with pytest.raises(ValueError):
-        ctx.neighbors_local(1, 0, thr)   # positive gap penalty: outside the striped kernel's contract
+    # positive gap penalties (the reference imposes no sign, LocalAlignmentScorer.java:43-55): the literal tier of the pass
+    sub = np.arange(300, dtype=np.uint32)
+    sres, soff = hammock_amd.pack_sequences([res[off[k]:off[k + 1]] for k in sub])
+    sctx, _, _ = ctx_for(M, res=sres, off=soff)
+    for go2, ge2 in ((1, 0), (-3, 2), (go, ge)):
+        st, sc = coracle.score_block(M, sres, soff, sub, sub, 1, go2, ge2)
+        thr2 = int(np.quantile(sc, 0.97))
+        mm, xx = np.meshgrid(sub, sub, indexing="ij")
+        keep = (sc >= thr2) & (mm != xx)
+        want2 = np.sort(hammock_amd.pack_edges(xx[keep], mm[keep], sc[keep]))
+        got2, _ = sctx.neighbors_local(go2, ge2, thr2)
+        assert np.array_equal(np.sort(got2), want2), (cfg, go2, ge2)
+
+
+def test_neighbors_local_wide_matrix_literal_tier(gpu, coracle):
+    """|matrix| > 127 does not fit the striped kernels' int8 profiles: hmk_neighbors_local runs the literal DP."""
+    rng = np.random.default_rng(31)
+    A = rng.integers(-300, 301, size=(24, 24)).astype(np.int32)
+    res, off = synth_peptides(6, 400, 7, 20)
+    idx = np.arange(400, dtype=np.uint32)
+    for M in (np.minimum(A, A.T), A):   # symmetric and not
+        ctx, _, _ = ctx_for(M, res=res, off=off)
+        st, sc = coracle.score_block(M, res, off, idx, idx, 1, -40, -9)
+        thr = int(np.quantile(sc, 0.98))
+        mm, xx = np.meshgrid(idx, idx, indexing="ij")
+        keep = (sc >= thr) & (mm != xx)
+        edges, stats = ctx.neighbors_local(-40, -9, thr)
+        assert np.array_equal(np.sort(edges), np.sort(hammock_amd.pack_edges(xx[keep], mm[keep], sc[keep])))
+
+
+@pytest.mark.parametrize("leg", ["local", "shifted"])
+def test_config4_full_size(gpu, blosum62, coracle, leg):
+    """BASELINE config 4 at its full size: 10^5 peptides of length 7..20 (SplitMix64 seed 1).
+    local: LocalAlignmentScorer, gap open -5, extend -1, threshold 12 (the stage-2 pre-filter's sequenceAddThreshold,
+    Hammock.java:118-121) over ALL 10^10 ordered pairs through hmk_neighbors_local -- pair count, both orders present,
+    every edge at or above the threshold, sampled edges and 24 complete rows against the oracle.
+    shifted: ShiftedScorer X = 3, p = -1, threshold 23 through hmk_neighbors_shifted, the same checks."""
+    n = 100000
+    res, off = synth_peptides(1, n, 7, 20)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    rng = np.random.default_rng(4)
+    if leg == "local":
+        go, ge, thr = -5, -1, 28    # threshold 28: 0.3 % of the ordered pairs (12 would keep most of the 10^10 pairs)
+        edges, stats = ctx.neighbors_local(go, ge, thr, capacity=120_000_000)
+        assert stats.pairs_scored == n * (n - 1)
+        scorer, a, b = 1, go, ge
+    else:
+        X, p, thr = 3, -1, 23
+        edges, stats = ctx.neighbors_shifted(X, p, thr, capacity=60_000_000)
+        assert stats.pairs_scored == n * (n - 1) // 2
+        scorer, a, b = 0, X, p
+    x, m, s = hammock_amd.edge_fields(edges)
+    assert len(edges) > 10 ** 6 and (s >= thr).all() and (x != m).all() and len(np.unique(edges)) == len(edges)
+    if leg == "local":
+        assert (x < m).any() and (x > m).any()      # ordered pairs: both directions are scored
+    else:
+        assert (x < m).all()
+    pick = rng.choice(len(edges), 200000, replace=False)
+    st, want = coracle.score_pairs(blosum62, res, off, m[pick], x[pick], scorer, a, b)   # edge = score(seq1 = m, seq2 = x)
+    assert st == 0 and np.array_equal(want, s[pick])
+    # complete rows: every neighbour of 24 random sequences, and nothing else
+    rows = rng.choice(n, 24, replace=False).astype(np.uint32)
+    allidx = np.arange(n, dtype=np.uint32)
+    for r in rows:
+        st, sc = coracle.score_pairs(blosum62, res, off, allidx, np.full(n, r, np.uint32), scorer, a, b)   # score(seq1 = j, seq2 = r)
+        sc[r] = -10 ** 6
+        want_m = np.flatnonzero(sc >= thr)
+        if leg == "local":
+            got = m[x == r]
+            assert np.array_equal(np.sort(got), want_m) and np.array_equal(s[x == r][np.argsort(got)], sc[want_m])
+        else:   # unordered: the row's neighbours sit on either side of the edge
+            got = np.concatenate([m[x == r], x[m == r]])
+            assert np.array_equal(np.sort(got), want_m)
 
 
 def test_neighbors_fuzz_lane_classification(gpu, matrices, coracle):
