@@ -102,9 +102,9 @@ struct hmk_ctx {
     uint64_t d_edges_cap = 0;
     unsigned long long *d_counts = nullptr;
     // side streams of the neighbour pass: the per-class launches of a mixed-length plan overlap their tails
-    static constexpr int N_SIDE = 3;
-    hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr, nullptr, nullptr};
+    static constexpr int N_SIDE = 8;     // created; HMK_SIDE_STREAMS (default 3) of them are used
+    hipStream_t side[N_SIDE] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr};
     hipStream_t copy_stream = nullptr;   // band CSR + device-to-host copies of adjacency rows (hmk_greedy_cluster)
     uint32_t *d_rows_scratch = nullptr;  // deg[n], cursor[n], misfit of hmk_pack_rows_dev
     uint32_t d_rows_scratch_n = 0;
@@ -529,6 +529,8 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
     // start, and join back into `stream`.
     const bool fork = pl.groups.size() > 2 && getenv("HMK_NO_SIDE_STREAMS") == nullptr;
+    int n_side = 3;
+    if (const char *v = getenv("HMK_SIDE_STREAMS")) n_side = std::max(1, std::min((int)hmk_ctx::N_SIDE, atoi(v)));
     if (fork) {
         if (!ctx->ev_fork) {
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -538,7 +540,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
             }
         }
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, stream));
-        for (int k = 0; k < hmk_ctx::N_SIDE; k++) HIPCHK(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
+        for (int k = 0; k < n_side; k++) HIPCHK(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     }
     // biggest groups first
     std::vector<const Group *> order;
@@ -547,7 +549,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     size_t q = 0;
     for (const Group *gp : order) {
         const Group &g = *gp;
-        hipStream_t s = fork ? ctx->side[q++ % hmk_ctx::N_SIDE] : stream;
+        hipStream_t s = fork ? ctx->side[q++ % n_side] : stream;
         const uint32_t t0 = which == LAUNCH_REST ? g.base + g.band : g.base;
         const uint32_t cnt = which == LAUNCH_ALL ? g.count : which == LAUNCH_BAND ? g.band : g.count - g.band;
         if (g.path == PATH_DIRECT)
@@ -556,7 +558,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
             HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, t0, cnt, s));
     }
     if (fork)
-        for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
+        for (int k = 0; k < n_side; k++) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_join[k], ctx->side[k]));
             HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[k], 0));
         }

@@ -214,9 +214,15 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
 // Plane strides.  The compiler fuses two ds_reads off the same address register into ds_read2[st64]
 // when their immediates differ by < 2048 B or by a multiple of 512 B (256 B for 4-byte reads); a fused
 // read whose halves are a multiple of 256 B apart hits the same banks with both halves (measured: 43 %
-// conflict cycles with strides of 1536 / 3072 B).  Strides of 8 x odd bytes, >= 2048, rule the fusion out;
-// planes_layout_ok() checks every pair of (row, plane) offsets at compile time.
+// conflict cycles with strides of 1536 / 3072 B).  Strides of 8 x odd bytes, >= 2048, rule the fusion out
+// (static_assert in the kernel).
 constexpr int plane64_bytes(int lbmax) { return lbmax * 24 * 8 + 8; }
+// Odd NW: the last dword of TWO rows shares one 8-byte entry of a "pair plane", so one ds_read_b64 serves both rows
+// (a 4-byte plane per row would cost the same 2 LDS cycles per read as an 8-byte one, MI355X_MICROARCH.md LDS table).
+// Every plane -- NW / 2 per row, then (R + 1) / 2 pair planes -- is plane64_bytes() long, i.e. consecutive planes are
+// 8 x odd >= 2048 bytes apart and no two of a workgroup's (< 64) planes a multiple of 512 B apart: the compiler cannot
+// fuse two table reads off one address register into a same-bank ds_read2[st64] (see "Plane strides" above).
+constexpr int planes_per_tile(int r, int nw) { return r * (nw / 2) + ((r + 1) / 2) * (nw & 1); }
 constexpr int rows_for(int rowbytes, int nw) {  // rows per tile: table bytes and R x NW accumulator registers, tuned on config 4a
 #ifndef HMK_TAB_BUDGET
 #define HMK_TAB_BUDGET 20480
@@ -228,36 +234,19 @@ constexpr int rows_for(int rowbytes, int nw) {  // rows per tile: table bytes an
     if (r > HMK_ACC_CAP / nw) r = HMK_ACC_CAP / nw;
     return r > 16 ? 16 : (r < 1 ? 1 : r);
 }
-constexpr bool planes_layout_ok(int lbmax, int nw, int pad32) {
-    const int np = nw / 2, s64 = plane64_bytes(lbmax);
-    const int rb = np * s64 + (nw & 1) * (lbmax * 24 * 4 + pad32);
-    const int r_rows = rows_for(rb, nw);
-    for (int a = 0; a < r_rows * np; a++)
-        for (int b = a + 1; b < r_rows * np; b++) {
-            const int d = ((b / np) * rb + (b % np) * s64) - ((a / np) * rb + (a % np) * s64);
-            if (d < 2048 || d % 512 == 0) return false;
-        }
-    if (nw & 1)
-        for (int k = 1; k < r_rows; k++)
-            if (k * rb < 1024 || (k * rb) % 256 == 0) return false;
-    return true;
-}
-constexpr int plane32_bytes(int lbmax, int nw) {  // smallest padding of the 4-byte plane that passes the check
-    for (int pad = 8; pad <= 256; pad += 8)
-        if (planes_layout_ok(lbmax, nw, pad)) return lbmax * 24 * 4 + pad;
-    return -1;
-}
-constexpr int planes_rowbytes(int lbmax, int nw) { return (nw / 2) * plane64_bytes(lbmax) + (nw & 1) * plane32_bytes(lbmax, nw); }
+constexpr int planes_rowbytes(int lbmax, int nw) { return (2 * (nw / 2) + (nw & 1)) * plane64_bytes(lbmax) / 2; }   // table bytes per row
 
 template <int NW, int R, int LBMAX>
-__global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P, const uint32_t tile_base) {
+// the narrow-entry instantiations are held to 80 VGPRs = 6 waves/SIMD, which is what their 25 KB of LDS allow per CU
+// (<2, 8, 12> took 85 VGPRs = 5 waves and showed the lowest LDS busy fraction of config 4a)
+__global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const NeighborParams P, const uint32_t tile_base) {
     constexpr int NP = NW / 2, H = NW & 1;
     constexpr int CPL = NW <= 2 ? 2 : 1;
     constexpr int PLANE64 = plane64_bytes(LBMAX);
-    constexpr int ROWBYTES = planes_rowbytes(LBMAX, NW);
-    static_assert(plane32_bytes(LBMAX, NW) > 0 && R == rows_for(ROWBYTES, NW),
-                  "no padding found that keeps table reads from being fused into a same-bank ds_read2");
-    constexpr int TAB_BYTES = R * ROWBYTES;
+    constexpr int NPLANES = planes_per_tile(R, NW);
+    static_assert(R == rows_for(planes_rowbytes(LBMAX, NW), NW) && NPLANES < 64 && PLANE64 >= 2048 && (PLANE64 / 8) % 2 == 1,
+                  "plane stride must keep table reads from being fused into a same-bank ds_read2");
+    constexpr int TAB_BYTES = NPLANES * PLANE64;   // plane (r, q) = r * NP + q; pair plane rp = R * NP + rp
     constexpr int STAGE_CAP = 128, REC_DW = 3;
     constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;
     // table build scratch: per (row, residue) the row's cells as one byte string (see below); it shares the
@@ -265,11 +254,12 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
     constexpr int WIN_DW = (LBMAX - 1 + 4 * NW + 3) / 4 + 1;       // dwords per string, one spare for the funnel shift
     constexpr int STAGE_BYTES = 4 * STAGE_CAP * REC_DW * 4, WIN_BYTES = R * 24 * WIN_DW * 4;
     constexpr int AUX_BYTES = STAGE_BYTES > WIN_BYTES ? STAGE_BYTES : WIN_BYTES;
-    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + AUX_BYTES;
+    constexpr int TAB_PAD = (TAB_BYTES + 15) & ~15;
+    constexpr int LDS_BYTES = TAB_PAD + 576 + R * 32 + AUX_BYTES;
     static_assert(TAB_BYTES <= 65536 && LDS_BYTES <= 65536, "LDS budget / DS immediate range");
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
     uint8_t *tab = smem;
-    uint8_t *mb = smem + TAB_BYTES;
+    uint8_t *mb = smem + TAB_PAD;
     uint8_t *rowres = mb + 576;
     uint32_t *stage_all = reinterpret_cast<uint32_t *>(rowres + R * 32);
 
@@ -354,11 +344,11 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
                     dw[w] = ((t2 & 0xFFu) | ((t2 << 8) & 0x00FF0000u)) & lane_mask[w];
                 }
             }
-            uint8_t *row = tab + r * ROWBYTES;
+            uint8_t *row = tab + (r * NP) * PLANE64;
 #pragma unroll
             for (int q = 0; q < NP; q++)
                 *reinterpret_cast<u32x2 *>(row + q * PLANE64 + (j * 24 + c) * 8) = u32x2{dw[2 * q], dw[2 * q + 1]};
-            if (H) *reinterpret_cast<uint32_t *>(row + NP * PLANE64 + (j * 24 + c) * 4) = dw[NW - 1];
+            if (H) *reinterpret_cast<uint32_t *>(tab + (R * NP + (r >> 1)) * PLANE64 + (j * 24 + c) * 8 + (r & 1) * 4) = dw[NW - 1];
         }
     }
     __syncthreads();
@@ -390,12 +380,11 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
                     words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
                 }
             }
-            uint32_t off64[NP ? LBMAX : 1], off32[H ? LBMAX : 1];
+            uint32_t off64[LBMAX];   // every plane has 8-byte entries: one offset per position serves them all
 #pragma unroll
             for (int j = 0; j < LBMAX; j++) {
                 const uint32_t c = (words[j >> 2] >> ((j & 3) * 8)) & 0xFFu;
-                if (NP) off64[j] = tab_addr + (uint32_t)(j * 24 * 8) + c * 8;
-                if (H) off32[j] = tab_addr + (uint32_t)(NP * PLANE64 + j * 24 * 4) + c * 4;
+                off64[j] = tab_addr + (uint32_t)(j * 24 * 8) + c * 8;
             }
 
             // ---- position-major accumulation: the `j < lb` tests are wave-uniform branches; inside one
@@ -406,28 +395,37 @@ __global__ void __launch_bounds__(256) k_neighbors_planes(const NeighborParams P
             for (int r = 0; r < R; r++)
 #pragma unroll
                 for (int w = 0; w < NW; w++) W[r][w] = cinit[w];
-            auto read_entry = [&](int j, int r, uint32_t (&e)[NW]) {
+            // all R rows' entries of one position: NP reads per row + one read per row PAIR for the odd dword
+            auto read_position = [&](int j, uint32_t (&e)[R][NW]) {
 #pragma unroll
-                for (int q = 0; q < NP; q++) {
-                    const u32x2 v = lds_read<u32x2>(off64[NP ? j : 0] + (uint32_t)(r * ROWBYTES + q * PLANE64));
-                    e[2 * q] = v.x; e[2 * q + 1] = v.y;
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int q = 0; q < NP; q++) {
+                        const u32x2 v = lds_read<u32x2>(off64[j] + (uint32_t)((r * NP + q) * PLANE64));
+                        e[r][2 * q] = v.x; e[r][2 * q + 1] = v.y;
+                    }
+                if (H) {
+#pragma unroll
+                    for (int rp = 0; rp < (R + 1) / 2; rp++) {
+                        const u32x2 v = lds_read<u32x2>(off64[j] + (uint32_t)((R * NP + rp) * PLANE64));
+                        e[2 * rp][NW - 1] = v.x;
+                        if (2 * rp + 1 < R) e[2 * rp + 1 < R ? 2 * rp + 1 : 0][NW - 1] = v.y;
+                    }
                 }
-                if (H) e[NW - 1] = lds_read<uint32_t>(off32[H ? j : 0] + (uint32_t)(r * ROWBYTES));
             };
 #pragma unroll
             for (int j = 0; j < LBMAX; j += 2) {
                 if (j + 1 < lb) {
                     uint32_t e0[R][NW], e1[R][NW];
-#pragma unroll
-                    for (int r = 0; r < R; r++) { read_entry(j, r, e0[r]); read_entry(j + 1, r, e1[r]); }
+                    read_position(j, e0);
+                    read_position(j + 1, e1);
 #pragma unroll
                     for (int r = 0; r < R; r++)
 #pragma unroll
                         for (int w = 0; w < NW; w++) W[r][w] = W[r][w] + e0[r][w] + e1[r][w];
                 } else if (j < lb) {
                     uint32_t e0[R][NW];
-#pragma unroll
-                    for (int r = 0; r < R; r++) read_entry(j, r, e0[r]);
+                    read_position(j, e0);
 #pragma unroll
                     for (int r = 0; r < R; r++)
 #pragma unroll

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""BASELINE config 4a only (1e5 peptides, lengths 7..20, ShiftedScorer X=3 p=-1 thr=23): 4 passes.
-For `rocprofv3 --kernel-trace --stats -- python3 tools/run_config4a.py`."""
+"""BASELINE config 4a only (1e5 peptides, lengths 7..20, ShiftedScorer X=3 p=-1 thr=23): 12 passes, the first two are
+warm-up.  For `rocprofv3 --kernel-trace --stats -- python3 tools/run_config4a.py` and for quick timing."""
+import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
 
 import hammock_amd
@@ -20,7 +22,7 @@ cap = 1 << 24
 d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
 d_counts = torch.zeros(_native.HMK_EDGE_SHARDS, dtype=torch.int64, device=dev)
 ms = []
-for _ in range(4):
+for _ in range(12):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     ctx.neighbors_shifted_dev(3, -1, 23, 0, 1, d_edges.data_ptr(), cap, d_counts.data_ptr(),
@@ -28,4 +30,8 @@ for _ in range(4):
     b.record()
     torch.cuda.synchronize()
     ms.append(a.elapsed_time(b))
-print(int(d_counts.sum().item()), ctx.last_plan().n_tiles, "ms per pass (first includes the plan):", [round(v, 3) for v in ms])
+plan = ctx.last_plan()
+steady = ms[2:]
+print(json.dumps({"config": "4a: 1e5 x 7..20, ShiftedScorer X=3 p=-1 thr=23", "edges": int(d_counts.sum().item()), "tiles": int(plan.n_tiles),
+                  "pairs": int(plan.pairs_scored), "ms_all": [round(v, 3) for v in ms], "ms_median": float(np.median(steady)),
+                  "ms_min": float(min(steady)), "pairs_per_s_median": plan.pairs_scored / (float(np.median(steady)) * 1e-3)}))
