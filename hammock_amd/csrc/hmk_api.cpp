@@ -34,8 +34,8 @@ struct Group {
 // grow-only device scratch of the greedy tail (one hipMalloc per buffer and context, not per call)
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 enum {
-    SB_DEG, SB_UP, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ,                       // full CSR
-    SB_BDEG, SB_BUP, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
+    SB_DEG, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ,                       // full CSR
+    SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
     SB_COF, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
     SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
@@ -502,7 +502,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
 enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2 };
 int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
                          uint64_t capacity, void *d_counts, hipStream_t stream, int which = LAUNCH_ALL,
-                         int64_t band_rows = -1) {
+                         int64_t band_rows = -1, uint32_t *d_deg = nullptr) {
     int st = need_device(ctx);
     if (st) return st;
     if (!d_edges || !d_counts || capacity < HMK_EDGE_SHARDS)
@@ -525,6 +525,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     P.n_tiles = pl.stats.n_tiles;
     P.lpad = (uint32_t)pl.lpad;
     P.symmetric = ctx->symmetric ? 1u : 0u;
+    P.deg = d_deg;
     // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has a dozen of
     // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
     // start, and join back into `stream`.
@@ -1241,6 +1242,7 @@ struct EdgeSource {
     uint64_t total_known = 0;          // exact number of edges, if known (else 0)
     uint32_t band_rows = 0;            // rows [0, band_rows) are complete in band_segs once ev_band has passed
     EdgeSegs band_segs{};
+    bool deg_fused = false;            // SB_DEG / SB_UP were filled by the neighbour kernel itself (zeroed before the pass)
     hmk_clinkage_stats *clink = nullptr;   // non-null: run the clinkage nearest-neighbour chain instead of the greedy merge
 };
 
@@ -1264,7 +1266,6 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
 
     // ---- full CSR on the device, enqueued behind the scoring on S ---------------------------------------
     HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
-    HIPCHK(ctx, ensure_buf(ctx, SB_UP, (size_t)n * 4));
     HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
     HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
     HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
@@ -1275,18 +1276,22 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     uint32_t *h_up = (uint32_t *)((char *)ctx->h_start + ((size_t)n + 1) * 8);
     int *h_range = (int *)(ctx->h_counts + HC_RANGE);
 
-    HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_DEG), 0, (size_t)n * 4, S));
-    HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_UP), 0, (size_t)n * 4, S));
     HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S));
-    HIPCHK(ctx, launch_csr_degree_scan(src.segs, n, n, symmetric, buf<uint32_t>(ctx, SB_DEG), buf<uint32_t>(ctx, SB_UP),
-                                       buf<uint64_t>(ctx, SB_START), buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S));
+    if (src.deg_fused) {
+        HIPCHK(ctx, launch_csr_scan_only(buf<uint32_t>(ctx, SB_DEG), buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN),
+                                         buf<int>(ctx, SB_RANGE), S));
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_DEG), 0, (size_t)n * 4, S));
+        HIPCHK(ctx, launch_csr_degree_scan(src.segs, n, n, symmetric, buf<uint32_t>(ctx, SB_DEG), buf<uint64_t>(ctx, SB_START),
+                                           buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S));
+    }
     HIPCHK(ctx, hipMemcpyAsync(h_range, buf<int>(ctx, SB_RANGE), 3 * sizeof(int), hipMemcpyDeviceToHost, S));
     HIPCHK(ctx, hipMemcpyAsync(&h_start[n], buf<uint64_t>(ctx, SB_START) + n, 8, hipMemcpyDeviceToHost, S));
     bool scatter_enqueued = false;
     auto enqueue_scatter = [&]() -> hipError_t {
         scatter_enqueued = true;
-        hipError_t e = launch_csr_scatter(src.segs, symmetric, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_UP),
-                                          buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ), packed, base, n, S);
+        hipError_t e = launch_csr_scatter(src.segs, symmetric, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR),
+                                          buf<void>(ctx, SB_ADJ), packed, base, n, S);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
         return e;
     };
@@ -1298,17 +1303,15 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     const uint32_t R1 = src.band_rows;
     if (R1 > 0 && src.format_known) {
         HIPCHK(ctx, ensure_buf(ctx, SB_BDEG, (size_t)R1 * 4));
-        HIPCHK(ctx, ensure_buf(ctx, SB_BUP, (size_t)R1 * 4));
         HIPCHK(ctx, ensure_buf(ctx, SB_BCURSOR, (size_t)R1 * 8));
         HIPCHK(ctx, ensure_buf(ctx, SB_BSTART, ((size_t)R1 + 1) * 8));
         HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(R1)));
         HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
         HIPCHK(ctx, hipStreamWaitEvent(C, ctx->ev_band, 0));
         HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BDEG), 0, (size_t)R1 * 4, C));
-        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BUP), 0, (size_t)R1 * 4, C));
         HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BCURSOR), 0, (size_t)R1 * 8, C));
-        HIPCHK(ctx, launch_csr_degree_scan(src.band_segs, n, R1, symmetric, buf<uint32_t>(ctx, SB_BDEG), buf<uint32_t>(ctx, SB_BUP),
-                                           buf<uint64_t>(ctx, SB_BSTART), buf<uint64_t>(ctx, SB_BSCAN), buf<int>(ctx, SB_BRANGE), C));
+        HIPCHK(ctx, launch_csr_degree_scan(src.band_segs, n, R1, symmetric, buf<uint32_t>(ctx, SB_BDEG), buf<uint64_t>(ctx, SB_BSTART),
+                                           buf<uint64_t>(ctx, SB_BSCAN), buf<int>(ctx, SB_BRANGE), C));
         HIPCHK(ctx, hipMemcpyAsync(h_start, buf<uint64_t>(ctx, SB_BSTART), ((size_t)R1 + 1) * 8, hipMemcpyDeviceToHost, C));
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count, HMK_EDGE_SHARDS * sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, C));
@@ -1371,8 +1374,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 e = ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz);
                 if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(entries, 1) * esz, 0);
                 if (e == hipSuccess)
-                    e = launch_csr_scatter(src.band_segs, symmetric, buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BUP),
-                                           buf<uint32_t>(ctx, SB_BCURSOR), buf<void>(ctx, SB_BADJ), packed, base, R1, C);
+                    e = launch_csr_scatter(src.band_segs, symmetric, buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BCURSOR),
+                                           buf<void>(ctx, SB_BADJ), packed, base, R1, C);
                 if (e == hipSuccess && entries)
                     e = hipMemcpyAsync(ctx->h_adj, buf<void>(ctx, SB_BADJ), entries * esz, hipMemcpyDeviceToHost, C);
                 if (e == hipSuccess) e = hipStreamSynchronize(C);
@@ -1393,7 +1396,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
         e = hipMemcpyAsync(h_start + rows_here, d_start + rows_here, ((size_t)(r_end - rows_here) + 1) * 8, hipMemcpyDeviceToHost, C);
         if (e == hipSuccess && symmetric)
-            e = hipMemcpyAsync(h_up + rows_here, buf<uint32_t>(ctx, SB_UP) + rows_here, (size_t)(r_end - rows_here) * 4, hipMemcpyDeviceToHost, C);
+            e = hipMemcpyAsync(h_up + rows_here, buf<uint32_t>(ctx, SB_CURSOR) + rows_here, (size_t)(r_end - rows_here) * 4, hipMemcpyDeviceToHost, C);
         if (e == hipSuccess) e = hipStreamSynchronize(C);
         if (e == hipSuccess) {
             const uint64_t a0 = h_start[rows_here], a1 = h_start[r_end];
@@ -1479,9 +1482,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                             std::vector<int32_t> &join_slot) -> bool {
         if (forbid_device || !symmetric) return false;
         if (!device_precheck(cluster_of, usize, leftover)) return false;
-        // the host loop over the lists is quicker while they are small (a few round trips less); beyond that
-        // the device runs the loop itself and nothing but the result crosses PCIe
-        if (!force_device && pre_total_c < (1u << 19)) return false;
+        // (measured: the device-side loop beats the host loop over device-built lists at every size -- 1e5 uniform 12-mers
+        // 7.5 against 9.5 ms end to end, the antibodies example 14 against 18 ms; the lists stay as the second path)
         const auto tl = std::chrono::steady_clock::now();
         const uint32_t nl = (uint32_t)leftover.size();
         const uint32_t ncl = (uint32_t)usize.size();
@@ -1491,7 +1493,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, ncl})));
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CSIZE, std::max<size_t>(ncl, 1) * 8);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CID, std::max<size_t>(ncl, 1) * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_FIRST, std::max<size_t>(ncl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_FIRST, std::max<size_t>(ncl, 1) * 8);   // two buffers, swapped every round
         if (r == hipSuccess) r = ensure_buf(ctx, SB_STATUS, std::max<size_t>(nl, 1));
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CHOICE, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_ACCEPTED, std::max<size_t>(nl, 1) * 4);
@@ -1507,6 +1509,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
         if (r == hipSuccess) r = launch_loop_subscribers(true, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
                                                          buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0xFF, (size_t)ncl * 8, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JOINED), 0, (size_t)ncl * 4, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_STATUS), 0, nl, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JSLOT), 0xFF, (size_t)nl * 4, S);
@@ -1522,10 +1525,11 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         // the device's counter once per batch of rounds (rounds after the end find nothing to do)
         for (uint32_t batch = 8; r == hipSuccess && !done && rounds <= nl + 8; batch = std::min<uint32_t>(batch * 2, 64)) {
             for (uint32_t b = 0; b < batch && r == hipSuccess; b++, rounds++)
-                r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_UP), buf<void>(ctx, SB_ADJ),
+                r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
                                       buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART),
                                       buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
-                                      buf<uint32_t>(ctx, SB_FIRST), ncl, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
+                                      buf<uint32_t>(ctx, SB_FIRST) + (size_t)(rounds & 1) * ncl, buf<uint32_t>(ctx, SB_FIRST) + (size_t)(~rounds & 1) * ncl,
+                                      ncl, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
                                       buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), buf<int32_t>(ctx, SB_JOINED), buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID),
                                       ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), S);
             if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[3], buf<uint32_t>(ctx, SB_LCOUNT) + 3, 4, hipMemcpyDeviceToHost, S);
@@ -1565,7 +1569,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
         int32_t *d_lidx = buf<int32_t>(ctx, SB_LIDX);
         uint32_t *d_pcnt = buf<uint32_t>(ctx, SB_PCNT), *d_pstart = buf<uint32_t>(ctx, SB_PSTART);
-        const uint32_t *d_up = buf<uint32_t>(ctx, SB_UP);
+        const uint32_t *d_up = buf<uint32_t>(ctx, SB_CURSOR);
         const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
         const void *d_adj = buf<void>(ctx, SB_ADJ);
         const uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
@@ -1724,17 +1728,26 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         src.adj_bound = (ctx->symmetric ? 2 : 1) * ctx->d_edges_cap;
         src.band_rows = (uint32_t)band_rows;
         src.band_segs = shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS));
+        // the CSR's degree counters are filled by the neighbour kernel as it writes the edges
+        const bool fuse = getenv("HMK_NO_FUSED_DEGREE") == nullptr;
+        uint32_t *d_deg = nullptr;
+        if (fuse) {
+            HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
+            d_deg = buf<uint32_t>(ctx, SB_DEG);
+            HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * 4, S));
+        }
+        src.deg_fused = fuse;
         HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
         if (band_rows > 0) {
             st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                      LAUNCH_BAND, band_req);
+                                      LAUNCH_BAND, band_req, d_deg);
             if (st) return st;
             HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long),
                                        hipMemcpyDeviceToDevice, S));
             HIPCHK(ctx, hipEventRecord(ctx->ev_band, S));
         }
         st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req);
+                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, d_deg);
         if (st) { (void)hipStreamSynchronize(S); return st; }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S));
         HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));

@@ -124,7 +124,7 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 // Drains one wave's staged records to its output segment.  REC_DW dwords per
 // record: [0] column (sorted position), [1] row within the tile, [2..] the NW
 // accumulator dwords (SWAR) or the score itself (direct, NW == 0).
-template <int NW>
+template <int NW, bool DEG = true>
 __device__ __forceinline__ void flush_stage(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
                                             const Tile &T, int g, bool lane16, uint32_t shard) {
     constexpr int REC_DW = (NW == 0) ? 3 : NW + 2;
@@ -160,6 +160,10 @@ __device__ __forceinline__ void flush_stage(const HMK_LDS uint32_t *stage, uint3
         uint32_t x = T.row0 + r, m = col;
         if (!P.perm_identity) { x = P.perm[x]; m = P.perm[m]; }   // wave-uniform branch
         if (P.row_is_m || (P.symmetric && x > m)) { const uint32_t t = x; x = m; m = t; }
+        if (DEG && P.deg) {   // wave-uniform; fire-and-forget atomics on the rare path
+            atomicAdd(&P.deg[x], 1u);
+            if (P.symmetric) atomicAdd(&P.deg[m], 1u);
+        }
         const unsigned long long pos = base + k;
         if (pos < P.cap_per_shard)
             P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =

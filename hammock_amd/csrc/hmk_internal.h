@@ -55,6 +55,9 @@ struct NeighborParams {
     uint32_t symmetric;          // 1: emit (min, max) caller indices
     uint32_t row_is_m;           // 1: the tile's ROW is seq1 (= m of the edge), LocalAlignmentScorer tiles
     uint32_t perm_identity;      // 1: sorted position == caller index (one length bucket, no reordering): skip the perm loads
+    // optional (may be null): per-sequence degree counters of the CSR the greedy tail builds from these edges, counted
+    // while the edges are written (zeroed uint32[n]; symmetric: both ends of an edge) -- saves a pass over the edge list
+    uint32_t *deg;
 };
 
 // one directed neighbour: sequenceScore(seq1 = m, seq2 = x) = s for the row x it is stored under

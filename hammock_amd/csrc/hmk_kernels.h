@@ -34,16 +34,19 @@ hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile
                                           int gap_open, int gap_extend, int threshold, hipStream_t s);
 
 // edge segments -> CSR (start[row_limit + 1], adj[]) on the device; rows at and beyond row_limit are left out
-// (row_limit = n: the whole graph).  deg / up: zeroed uint32[row_limit]; cursor: zeroed uint32[2 row_limit];
-// score_range: device int[3] = {min score, max score, invalid edges}
+// (row_limit = n: the whole graph).  deg: zeroed uint32[row_limit]; cursor: zeroed uint32[2 row_limit], whose first half
+// holds the rows' upper-neighbour counts ("up[]") after the scatter; score_range: device int[3] = {min score, max
+// score, invalid edges}
 EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts);
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
-                                  uint32_t *up, uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s);
+                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s);
+hipError_t launch_csr_scan_only(const uint32_t *deg, uint64_t *start, uint32_t n, uint64_t *tile_scratch, int *score_range,
+                                hipStream_t s);   // deg[] already counted by the neighbour kernel (NeighborParams::deg)
 size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
 size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)
-hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, const uint32_t *up,
-                              uint32_t *cursor, void *adj, bool packed, int base, uint32_t row_limit, hipStream_t s);
+hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
+                              bool packed, int base, uint32_t row_limit, hipStream_t s);
 
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);
@@ -68,12 +71,12 @@ size_t scan_total_index(uint32_t n);
 hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const GreedyCand *cand, uint32_t *cursor,
                                    const uint32_t *sub_start, uint32_t *subs, hipStream_t s);
 // one round; counters: device uint32[4] ([3] = tentative joiners the round's eval saw: 0 means the loop is over),
-// first: uint32[n_clusters]
+// first / first_next: uint32[n_clusters] each; first must be all ones, first_next is reset for the next round
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
-                             uint32_t *first, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot, const uint32_t *sub_start,
-                             const uint32_t *subs, int32_t *joined, long long *csize, const int32_t *cid, const int32_t *seq_size,
-                             uint32_t *counters, hipStream_t s);
+                             uint32_t *first, uint32_t *first_next, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot,
+                             const uint32_t *sub_start, const uint32_t *subs, int32_t *joined, long long *csize, const int32_t *cid,
+                             const int32_t *seq_size, uint32_t *counters, hipStream_t s);
 // join-propagation lists of the second loop (k_greedy_prop): lidx = sequence -> leftover index or -1
 hipError_t launch_fill_lidx(const uint32_t *leftover, uint32_t nl, int32_t *lidx, uint32_t n, hipStream_t s);
 hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, const uint32_t *up, const void *adj,

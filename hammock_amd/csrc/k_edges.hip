@@ -14,8 +14,8 @@ namespace hmk {
 // score_range[0] / [1]: smallest / largest edge score (decides whether the 4-byte adjacency fits);
 // score_range[2]: edges that name a sequence outside [0, n) or a self pair (not counted; the caller gives up)
 __global__ void __launch_bounds__(256)
-k_edge_degree(const EdgeSegs segs, uint32_t *__restrict__ deg, uint32_t *__restrict__ up, int symmetric,
-              int *__restrict__ score_range, uint32_t n, uint32_t row_limit) {
+k_edge_degree(const EdgeSegs segs, uint32_t *__restrict__ deg, int symmetric, int *__restrict__ score_range, uint32_t n,
+              uint32_t row_limit) {
     // row_limit: only rows [0, row_limit) are counted (the "band" a first phase-1 hand-over needs); n otherwise
     const EdgeSeg sg = segs.s[blockIdx.y];
     const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
@@ -30,15 +30,11 @@ k_edge_degree(const EdgeSegs segs, uint32_t *__restrict__ deg, uint32_t *__restr
             atomicAdd(&score_range[2], 1);
             valid = false;
         }
-        // symmetric: the edge is stored under both ends; under its SMALLER end it is an "upper" neighbour (id above
-        // the row's own), counted in up[] as well -- rows are laid out upper neighbours first (k_edge_scatter)
+        // symmetric: the edge is stored under both ends
         const uint32_t ea = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
         const uint32_t eb = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
         const WaveGroup g = wave_groups(ea, valid && ea < row_limit);
-        if (valid && ea < row_limit && g.rank == 0) {
-            atomicAdd(&deg[ea], g.size);
-            if (symmetric) atomicAdd(&up[ea], g.size);
-        }
+        if (valid && ea < row_limit && g.rank == 0) atomicAdd(&deg[ea], g.size);
         if (valid && symmetric && eb < row_limit) atomicAdd(&deg[eb], 1u);
         if (valid) {
             const int sc = HMK_EDGE_SCORE(e);
@@ -149,12 +145,14 @@ static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *til
 }
 
 // NbrT = Nbr: {m, score}.  NbrT = NbrPacked: m << 8 | (score - base), the caller has checked the score range.
-// symmetric: row r = [neighbours with id > r (up[r] of them) | neighbours with id < r]; cursor = uint32[2 n],
-// one cursor per section.  The host merge only has to look at the first section when a sequence joins a cluster.
+// symmetric: row r = [neighbours with id > r | neighbours with id < r]; cursor = uint32[2 n], one cursor per section:
+// the upper section grows from the row's start, the lower one backwards from its end, so no per-row split point has
+// to be known beforehand -- afterwards cursor[r] IS the number of upper neighbours ("up[r]").  Consumers that only
+// care about later (larger-id) neighbours walk just the first section.
 template <class NbrT>
 __global__ void __launch_bounds__(256)
-k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, const uint32_t *__restrict__ up,
-               uint32_t *__restrict__ cursor, NbrT *__restrict__ adj, int symmetric, int base, uint32_t row_limit) {
+k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, NbrT *__restrict__ adj,
+               int symmetric, int base, uint32_t row_limit) {
     // cursor: uint32[2 * row_limit]; rows at and beyond row_limit are not stored
     const EdgeSeg sg = segs.s[blockIdx.y];
     const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
@@ -176,10 +174,10 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, const ui
         if constexpr (sizeof(NbrT) == 4) {
             const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
             if (vx) adj[start[x] + basex + g.rank] = NbrT{(m << 8) | rel};
-            if (vm) adj[start[m] + up[m] + atomicAdd(&cursor[row_limit + m], 1u)] = NbrT{(x << 8) | rel};
+            if (vm) adj[start[m + 1] - 1 - atomicAdd(&cursor[row_limit + m], 1u)] = NbrT{(x << 8) | rel};
         } else {
             if (vx) adj[start[x] + basex + g.rank] = NbrT{m, s};
-            if (vm) adj[start[m] + up[m] + atomicAdd(&cursor[row_limit + m], 1u)] = NbrT{x, s};
+            if (vm) adj[start[m + 1] - 1 - atomicAdd(&cursor[row_limit + m], 1u)] = NbrT{x, s};
         }
     }
 }
@@ -476,10 +474,12 @@ k_loop_eval(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCa
 __global__ void __launch_bounds__(256)
 k_loop_accept(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
               const int32_t *__restrict__ joined, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
-              const uint32_t *__restrict__ first, uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot,
-              uint32_t *__restrict__ counters) {
+              const uint32_t *__restrict__ first, uint32_t *__restrict__ first_next, uint32_t n_clusters,
+              uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot, uint32_t *__restrict__ counters) {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q == 0) counters[3] = counters[0];             // what the host polls: tentative joiners seen by the last eval
+    // the next round's first[] (the other of two buffers, idle in this round) is reset here: one launch less per round
+    for (uint32_t c = q; c < n_clusters; c += gridDim.x * 256) first_next[c] = 0xFFFFFFFFu;
     if (q >= nl || status[q] != LS_UNDECIDED) return;
     const uint32_t kb = cand_start[q], ke = cand_start[q + 1];
     const GreedyCand pick = cand[choice[q]];
@@ -566,22 +566,29 @@ EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const uns
 }
 
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
-                                  uint32_t *up, uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s) {
+                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s) {
     if (segs.n == 0 || segs.n > HMK_MAX_SEGS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_init_range, dim3(1), dim3(64), 0, s, score_range);
-    hipLaunchKernelGGL(k_edge_degree, dim3(512, segs.n), dim3(256), 0, s, segs, deg, up, symmetric ? 1 : 0, score_range, n,
-                       row_limit);
+    hipLaunchKernelGGL(k_edge_degree, dim3(512, segs.n), dim3(256), 0, s, segs, deg, symmetric ? 1 : 0, score_range, n, row_limit);
     launch_scan<uint64_t>(deg, start, row_limit, tile_scratch, nullptr, s);
     return hipGetLastError();
 }
 
-hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, const uint32_t *up,
-                              uint32_t *cursor, void *adj, bool packed, int base, uint32_t row_limit, hipStream_t s) {
+// the degrees were counted while the edges were written (NeighborParams::deg): only the scan remains
+hipError_t launch_csr_scan_only(const uint32_t *deg, uint64_t *start, uint32_t n, uint64_t *tile_scratch, int *score_range,
+                                hipStream_t s) {
+    hipLaunchKernelGGL(k_init_range, dim3(1), dim3(64), 0, s, score_range);
+    launch_scan<uint64_t>(deg, start, n, tile_scratch, nullptr, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
+                              bool packed, int base, uint32_t row_limit, hipStream_t s) {
     if (packed)
-        hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(512, segs.n), dim3(256), 0, s, segs, start, up, cursor,
-                           (NbrPacked *)adj, symmetric ? 1 : 0, base, row_limit);
+        hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj,
+                           symmetric ? 1 : 0, base, row_limit);
     else
-        hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(512, segs.n), dim3(256), 0, s, segs, start, up, cursor, (Nbr *)adj,
+        hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (Nbr *)adj,
                            symmetric ? 1 : 0, base, row_limit);
     return hipGetLastError();
 }
@@ -652,20 +659,19 @@ hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_
     return hipGetLastError();
 }
 
-// one round of the device-side second loop (see k_loop_eval); counters: device uint32[4], first: uint32[n_clusters]
+// one round of the device-side second loop (see k_loop_eval); counters: device uint32[4]; first / first_next:
+// uint32[n_clusters] each, `first` all ones on entry (the caller swaps the two between rounds)
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
-                             uint32_t *first, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot, const uint32_t *sub_start,
-                             const uint32_t *subs, int32_t *joined, long long *csize, const int32_t *cid, const int32_t *seq_size,
-                             uint32_t *counters, hipStream_t s) {
+                             uint32_t *first, uint32_t *first_next, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot,
+                             const uint32_t *sub_start, const uint32_t *subs, int32_t *joined, long long *csize, const int32_t *cid,
+                             const int32_t *seq_size, uint32_t *counters, hipStream_t s) {
     if (nl == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(first, 0xFF, (size_t)n_clusters * 4, s);
-    if (e != hipSuccess) return e;
     const dim3 grid((nl + 255) / 256), block(256);
     hipLaunchKernelGGL(k_loop_eval, grid, block, 0, s, nl, cand_start, cand, joined, csize, cid, status, choice, first, counters);
-    hipLaunchKernelGGL(k_loop_accept, grid, block, 0, s, nl, cand_start, cand, joined, status, choice, first, accepted, join_slot,
-                       counters);
-    const dim3 agrid(2048);
+    hipLaunchKernelGGL(k_loop_accept, grid, block, 0, s, nl, cand_start, cand, joined, status, choice, first, first_next, n_clusters,
+                       accepted, join_slot, counters);
+    const dim3 agrid(512);
     if (packed)
         hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
                            choice, accepted, sub_start, subs, joined, csize, seq_size, counters);

@@ -23,7 +23,9 @@ namespace hmk {
 //   mb      576 B                        biased matrix bytes
 //   rowres  R * 32 B                     residues of the tile's rows
 //   stage   4 waves * STAGE_CAP records  hits waiting to be written out
-template <int NW, int R, int CPL, int LBMAX, bool EXACT>
+// DEG: also count the CSR degrees while writing edges (NeighborParams::deg, hmk_greedy_cluster); the plain neighbour pass
+// is its own instantiation so that it keeps its spill-free 72-VGPR allocation.
+template <int NW, int R, int CPL, int LBMAX, bool EXACT, bool DEG>
 // The production tiling (R = 6, CPL = 2) is held to 72 VGPRs = 7 waves/SIMD, which is also what its 22.6 KB of
 // LDS allow per CU (80 VGPRs / 6 waves otherwise): +2.4 % measured.
 __global__ void __launch_bounds__(256, (R == 6 && CPL == 2) ? 7 : 1)
@@ -171,7 +173,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
                     const bool hit = (any & himask) != 0;  // some shift reached score >= threshold
                     if (__ballot(hit) != 0) {              // wave-uniform, rare
                         if (cnt > (uint32_t)(STAGE_CAP - 64)) {  // keep room for one wave of hits
-                            flush_stage<NW>(stage, cnt, P, T, g, lane16, shard);
+                            flush_stage<NW, DEG>(stage, cnt, P, T, g, lane16, shard);
                             cnt = 0;
                         }
                         const uint32_t col = colpos[p];
@@ -195,7 +197,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
             }
         }
     }
-    flush_stage<NW>(stage, cnt, P, T, g, lane16, shard);
+    flush_stage<NW, DEG>(stage, cnt, P, T, g, lane16, shard);
 }
 
 // -----------------------------------------------------------------------------
@@ -557,7 +559,10 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
 // -----------------------------------------------------------------------------
 template <int NW, int R, int CPL, int LBMAX, bool EXACT>
 static hipError_t launch_swar_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
-    hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+    if (P.deg)
+        hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, true>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+    else
+        hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, false>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
     return hipGetLastError();
 }
 
