@@ -36,7 +36,7 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 enum {
     SB_DEG, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ,                       // full CSR
     SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
-    SB_COF, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
+    SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
     SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
     SB_PEER, SB_PEERCNT,                                                                  // edge blocks gathered from other devices
@@ -1425,6 +1425,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         const auto tp = std::chrono::steady_clock::now();
         const uint32_t nl = (uint32_t)leftover.size();
         hipError_t r = ensure_buf(ctx, SB_COF, (size_t)n * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_USIZE, std::max<size_t>(usize.size(), 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_LEFT, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CNT, std::max<size_t>(nl, 1) * 4);
@@ -1439,12 +1440,13 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
         const void *d_adj = buf<void>(ctx, SB_ADJ);
         r = hipMemcpyAsync(d_cof, cluster_of, (size_t)n * 4, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess) r = launch_cluster_bitmap(d_cof, n, buf<uint32_t>(ctx, SB_BITMAP), S);
         if (r == hipSuccess) r = hipMemcpyAsync(d_usize, usize.data(), usize.size() * 4, hipMemcpyHostToDevice, S);
         if (r == hipSuccess) r = hipMemcpyAsync(d_left, leftover.data(), (size_t)nl * 4, hipMemcpyHostToDevice, S);
         if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 4, S);
         if (r == hipSuccess) r = hipMemsetAsync(d_cnt, 0, (size_t)nl * 4, S);
-        if (r == hipSuccess) r = launch_greedy_precheck(false, packed, d_start, d_adj, d_cof, d_usize, d_left, nl, d_cnt, nullptr,
-                                                        nullptr, d_over, S);
+        if (r == hipSuccess) r = launch_greedy_precheck(false, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
+                                                        d_cnt, nullptr, nullptr, d_over, S);
         if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, S);
         uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
         if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, S);
@@ -1454,8 +1456,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         pre_total_c = h_misc[1];
         if (pre_total_c) {
             r = ensure_buf(ctx, SB_CAND, (size_t)pre_total_c * sizeof(GreedyCand));
-            if (r == hipSuccess) r = launch_greedy_precheck(true, packed, d_start, d_adj, d_cof, d_usize, d_left, nl, d_cnt, d_cstart,
-                                                            buf<GreedyCand>(ctx, SB_CAND), d_over, S);
+            if (r == hipSuccess) r = launch_greedy_precheck(true, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
+                                                            d_cnt, d_cstart, buf<GreedyCand>(ctx, SB_CAND), d_over, S);
             if (r != hipSuccess) return false;
         }
         pre_done = true;
@@ -1487,7 +1489,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         const auto tl = std::chrono::steady_clock::now();
         const uint32_t nl = (uint32_t)leftover.size();
         const uint32_t ncl = (uint32_t)usize.size();
-        hipError_t r = ensure_buf(ctx, SB_JOINED, std::max<size_t>(ncl, 1) * 4);
+        hipError_t r = ensure_buf(ctx, SB_JOINED, std::max<size_t>(ncl, 1) * 16);   // {joined, id, size} per cluster
         if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBSTART, ((size_t)ncl + 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBS, std::max<size_t>(pre_total_c, 1) * 8);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, ncl})));
@@ -1510,12 +1512,12 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = launch_loop_subscribers(true, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
                                                          buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0xFF, (size_t)ncl * 8, S);
-        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JOINED), 0, (size_t)ncl * 4, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_STATUS), 0, nl, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JSLOT), 0xFF, (size_t)nl * 4, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_LCOUNT), 0, 64, S);
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CSIZE), csize.data(), (size_t)ncl * 8, hipMemcpyHostToDevice, S);
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CID), cids.data(), (size_t)ncl * 4, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess) r = launch_loop_init_clusters(ncl, buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID), buf<void>(ctx, SB_JOINED), S);
         if (r == hipSuccess && ctx->has_sizes)
             r = hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, S);
         uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
@@ -1530,7 +1532,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                       buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
                                       buf<uint32_t>(ctx, SB_FIRST) + (size_t)(rounds & 1) * ncl, buf<uint32_t>(ctx, SB_FIRST) + (size_t)(~rounds & 1) * ncl,
                                       ncl, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
-                                      buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), buf<int32_t>(ctx, SB_JOINED), buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID),
+                                      buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), buf<void>(ctx, SB_JOINED),
                                       ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), S);
             if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[3], buf<uint32_t>(ctx, SB_LCOUNT) + 3, 4, hipMemcpyDeviceToHost, S);
             if (r == hipSuccess) r = hipStreamSynchronize(S);

@@ -60,8 +60,10 @@ hipError_t launch_unpack_rows(const uint32_t *row_start, const uint32_t *adj, ui
                               uint64_t out_capacity, hipStream_t s);
 
 // pre-check of the greedy merge's second loop on the device-resident adjacency (k_edges.hip)
+// in_cluster: one bit per sequence (launch_cluster_bitmap), bitmap = uint32[(n + 31) / 32]
+hipError_t launch_cluster_bitmap(const int32_t *cluster_of, uint32_t n, uint32_t *bitmap, hipStream_t s);
 hipError_t launch_greedy_precheck(bool fill, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
-                                  const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
+                                  const uint32_t *in_cluster, const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
                                   const uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, hipStream_t s);
 hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, uint64_t *tile_scratch, hipStream_t s);
 // where launch_scan_u32 leaves the 64-bit grand total inside tile_scratch (the uint32 start[n] wraps beyond 2^32 - 1)
@@ -75,8 +77,10 @@ hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
                              uint32_t *first, uint32_t *first_next, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot,
-                             const uint32_t *sub_start, const uint32_t *subs, int32_t *joined, long long *csize, const int32_t *cid,
-                             const int32_t *seq_size, uint32_t *counters, hipStream_t s);
+                             const uint32_t *sub_start, const uint32_t *subs, void *clusters, const int32_t *seq_size,
+                             uint32_t *counters, hipStream_t s);
+// clusters: 16 bytes per cluster {joined = 0, id, size}, built on the device from the uploaded ids and sizes
+hipError_t launch_loop_init_clusters(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *clusters, hipStream_t s);
 // join-propagation lists of the second loop (k_greedy_prop): lidx = sequence -> leftover index or -1
 hipError_t launch_fill_lidx(const uint32_t *leftover, uint32_t nl, int32_t *lidx, uint32_t n, hipStream_t s);
 hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, const uint32_t *up, const void *adj,

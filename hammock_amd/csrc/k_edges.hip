@@ -75,17 +75,19 @@ __global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *__restri
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// one block: exclusive scan of the n_tiles tile sums in place; tile_sum[n_tiles] = grand total
-__global__ void __launch_bounds__(1024) k_scan_tile_offsets(uint64_t *__restrict__ tile_sum, uint32_t n_tiles) {
-    __shared__ uint64_t part[1024];
+// one block: exclusive scan of the n_tiles tile sums in place; tile_sum[n_tiles] = grand total.
+// 256 threads on purpose: this kernel also runs on the band stream WHILE the neighbour kernel saturates every CU, and a
+// 1024-thread workgroup (16 waves on one CU at once) was seen waiting 308 ms for a slot there (rocprofv3 trace, 10^6).
+__global__ void __launch_bounds__(256) k_scan_tile_offsets(uint64_t *__restrict__ tile_sum, uint32_t n_tiles) {
+    __shared__ uint64_t part[256];
     const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = (n_tiles + 1023) / 1024;
+    const uint32_t chunk = (n_tiles + 255) / 256;
     const uint32_t lo = min(n_tiles, tid * chunk), hi = min(n_tiles, lo + chunk);
     uint64_t sum = 0;
     for (uint32_t k = lo; k < hi; k++) sum += tile_sum[k];
     part[tid] = sum;
     __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {  // Hillis-Steele inclusive scan of the 1024 partial sums
+    for (uint32_t o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan of the 256 partial sums
         const uint64_t v = tid >= o ? part[tid - o] : 0;
         __syncthreads();
         part[tid] += v;
@@ -93,7 +95,7 @@ __global__ void __launch_bounds__(1024) k_scan_tile_offsets(uint64_t *__restrict
     }
     uint64_t run = tid ? part[tid - 1] : 0;
     for (uint32_t k = lo; k < hi; k++) { const uint64_t d = tile_sum[k]; tile_sum[k] = run; run += d; }
-    if (tid == 1023) tile_sum[n_tiles] = part[1023];
+    if (tid == 255) tile_sum[n_tiles] = part[255];
 }
 
 template <typename T>
@@ -140,7 +142,7 @@ static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *til
                         hipStream_t s) {
     const uint32_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, deg, tile_scratch, n);
-    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(1024), 0, s, tile_scratch, n_tiles);
+    hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, s, tile_scratch, n_tiles);
     hipLaunchKernelGGL((k_scan_tiles<T>), dim3(n_tiles), dim3(256), 0, s, deg, tile_scratch, start, n, n_tiles, tail_word);
 }
 
@@ -306,9 +308,21 @@ __device__ __forceinline__ int32_t nbr_score(const Nbr &a) { return a.s; }
 __device__ __forceinline__ uint32_t nbr_id(const NbrPacked &a) { return a.v >> 8; }
 __device__ __forceinline__ int32_t nbr_score(const NbrPacked &a) { return (int32_t)(a.v & 0xFFu); }
 
+// one bit per sequence: is it in a cluster?  Most neighbours are not (5 % at 10^6), and the 4-byte cluster_of[] gather
+// per neighbour (a 4 MB table, the size of an XCD's L2, next to 10 GB of streamed adjacency) is what the pre-check
+// waits for; the bitmap is 32 x smaller and answers first.
+__global__ void __launch_bounds__(256) k_cluster_bitmap(const int32_t *__restrict__ cluster_of, uint32_t n, uint32_t *__restrict__ bitmap) {
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w * 32 >= n) return;
+    uint32_t bits = 0;
+    for (uint32_t b = 0; b < 32 && w * 32 + b < n; b++) bits |= (cluster_of[w * 32 + b] >= 0 ? 1u : 0u) << b;
+    bitmap[w] = bits;
+}
+
 template <class NbrT, bool FILL>
 __global__ void __launch_bounds__(256)
 k_greedy_precheck(const uint64_t *__restrict__ start, const NbrT *__restrict__ adj, const int32_t *__restrict__ cluster_of,
+                  const uint32_t *__restrict__ in_cluster,
                   const int32_t *__restrict__ usize, const uint32_t *__restrict__ leftover, uint32_t nl,
                   uint32_t *__restrict__ cand_cnt, const uint32_t *__restrict__ cand_start, GreedyCand *__restrict__ cand,
                   uint32_t *__restrict__ overflow) {
@@ -327,8 +341,9 @@ k_greedy_precheck(const uint64_t *__restrict__ start, const NbrT *__restrict__ a
         bool full = false;
         for (uint64_t k = b + lane; k < e; k += 64) {
             const NbrT nb = adj[k];
-            const int32_t c = cluster_of[nbr_id(nb)];
-            if (c < 0) continue;
+            const uint32_t id = nbr_id(nb);
+            if (!((in_cluster[id >> 5] >> (id & 31)) & 1u)) continue;
+            const int32_t c = cluster_of[id];
             uint32_t sl = ((uint32_t)c * 2654435761u) >> 22;   // top 10 bits
             int probes = 0;
             for (;;) {
@@ -439,11 +454,17 @@ k_loop_subscribers(uint32_t nl, const uint32_t *__restrict__ cand_start, const G
     }
 }
 
+// per-cluster state of the loop in one 16-byte record (one load instead of three gathers per candidate entry)
+struct __attribute__((aligned(16))) LoopCluster {
+    int32_t joined;     // members that joined in this loop
+    int32_t id;         // Cluster.getId()
+    long long size;     // Cluster.size()
+};
+
 __global__ void __launch_bounds__(256)
 k_loop_eval(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
-            const int32_t *__restrict__ joined, const long long *__restrict__ csize, const int32_t *__restrict__ cid,
-            uint8_t *__restrict__ status, uint32_t *__restrict__ choice, uint32_t *__restrict__ first,
-            uint32_t *__restrict__ counters) {
+            const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status, uint32_t *__restrict__ choice,
+            uint32_t *__restrict__ first, uint32_t *__restrict__ counters) {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q == 0) counters[1] = 0;                       // accepted joins of this round (filled by k_loop_accept)
     if (q >= nl || status[q] != LS_UNDECIDED) return;
@@ -453,13 +474,12 @@ k_loop_eval(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCa
     uint32_t b_k = 0;
     for (uint32_t k = kb; k < ke; k++) {
         const GreedyCand cd = cand[k];
-        if (cd.covered != joined[cd.c]) continue;      // some new member is not a neighbour: infeasible for good
+        const LoopCluster c = cl[cd.c];
+        if (cd.covered != c.joined) continue;          // some new member is not a neighbour: infeasible for good
         // first[c] = the earliest undecided leftover that could still join c (most threads find a smaller one there)
         if (q < first[cd.c]) atomicMin(&first[cd.c], q);
-        const int32_t id = cid[cd.c];
-        const long long sz = csize[cd.c];
-        if (!has || cd.mn > b_mn || (cd.mn == b_mn && (sz > b_size || (sz == b_size && id < b_id)))) {
-            has = 1; b_mn = cd.mn; b_size = sz; b_id = id; b_k = k;
+        if (!has || cd.mn > b_mn || (cd.mn == b_mn && (c.size > b_size || (c.size == b_size && c.id < b_id)))) {
+            has = 1; b_mn = cd.mn; b_size = c.size; b_id = c.id; b_k = k;
         }
     }
     if (!has) { status[q] = LS_NEVER; return; }        // :64, whatever happens later
@@ -473,7 +493,7 @@ k_loop_eval(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCa
 // ties), and one that becomes infeasible was not the pick anyway.
 __global__ void __launch_bounds__(256)
 k_loop_accept(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
-              const int32_t *__restrict__ joined, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
+              const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
               const uint32_t *__restrict__ first, uint32_t *__restrict__ first_next, uint32_t n_clusters,
               uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot, uint32_t *__restrict__ counters) {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
@@ -486,7 +506,7 @@ k_loop_accept(uint32_t nl, const uint32_t *__restrict__ cand_start, const Greedy
     if (first[pick.c] != q) return;                    // an earlier leftover may still join the pick: wait
     for (uint32_t k = kb; k < ke; k++) {
         const GreedyCand cd = cand[k];
-        if (cd.mn == pick.mn && cd.covered == joined[cd.c] && first[cd.c] != q) return;   // a tie that may still grow
+        if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && first[cd.c] != q) return;   // a tie that may still grow
     }
     status[q] = LS_JOINED;                             // :61-62
     join_slot[q] = pick.c;
@@ -503,8 +523,8 @@ __global__ void __launch_bounds__(256)
 k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, const NbrT *__restrict__ adj,
              const uint32_t *__restrict__ leftover, const uint8_t *__restrict__ status, GreedyCand *__restrict__ cand,
              const uint32_t *__restrict__ choice, const uint32_t *__restrict__ accepted, const uint32_t *__restrict__ sub_start,
-             const uint32_t *__restrict__ subs, int32_t *__restrict__ joined, long long *__restrict__ csize,
-             const int32_t *__restrict__ seq_size, uint32_t *__restrict__ counters) {
+             const uint32_t *__restrict__ subs, LoopCluster *__restrict__ cl, const int32_t *__restrict__ seq_size,
+             uint32_t *__restrict__ counters) {
     __shared__ uint32_t keys[APPLY_SLOTS];
     __shared__ int32_t vals[APPLY_SLOTS];
     const uint32_t n_acc = counters[1];
@@ -549,8 +569,8 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            joined[c] += 1;
-            csize[c] += seq_size ? (long long)seq_size[y] : 1ll;
+            cl[c].joined += 1;
+            cl[c].size += seq_size ? (long long)seq_size[y] : 1ll;
         }
     }
 }
@@ -627,12 +647,18 @@ hipError_t launch_unpack_rows(const uint32_t *row_start, const uint32_t *adj, ui
 }
 
 // counts (cand_cnt[nl]) or fills (cand at cand_start[q]) the candidate lists; adj is Nbr[] or NbrPacked[]
+hipError_t launch_cluster_bitmap(const int32_t *cluster_of, uint32_t n, uint32_t *bitmap, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cluster_bitmap, dim3(((n + 31) / 32 + 255) / 256), dim3(256), 0, s, cluster_of, n, bitmap);
+    return hipGetLastError();
+}
+
 hipError_t launch_greedy_precheck(bool fill, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
-                                  const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
+                                  const uint32_t *in_cluster, const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
                                   const uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, hipStream_t s) {
     if (nl == 0) return hipSuccess;
     const dim3 grid(std::min<uint32_t>((nl + 3) / 4, 256 * 12)), block(256);
-#define HMK_PRE(T, F) hipLaunchKernelGGL((k_greedy_precheck<T, F>), grid, block, 0, s, start, (const T *)adj, cluster_of, usize, \
+#define HMK_PRE(T, F) hipLaunchKernelGGL((k_greedy_precheck<T, F>), grid, block, 0, s, start, (const T *)adj, cluster_of, in_cluster, usize, \
                                          leftover, nl, cand_cnt, cand_start, cand, overflow)
     if (packed) { if (fill) HMK_PRE(NbrPacked, true); else HMK_PRE(NbrPacked, false); }
     else { if (fill) HMK_PRE(Nbr, true); else HMK_PRE(Nbr, false); }
@@ -650,6 +676,19 @@ hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, 
 
 namespace hmk {
 
+__global__ void __launch_bounds__(256)
+k_loop_init_clusters(uint32_t n_clusters, const long long *__restrict__ csize, const int32_t *__restrict__ cid, LoopCluster *__restrict__ cl) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n_clusters) cl[c] = LoopCluster{0, cid[c], csize[c]};
+}
+
+// per-cluster records of the device-side second loop from the uploaded sizes and ids; cl: 16 bytes per cluster
+hipError_t launch_loop_init_clusters(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *cl, hipStream_t s) {
+    if (n_clusters == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_loop_init_clusters, dim3((n_clusters + 255) / 256), dim3(256), 0, s, n_clusters, csize, cid, (LoopCluster *)cl);
+    return hipGetLastError();
+}
+
 // subscriber lists of the device-side second loop: cursor = zeroed uint32[n_clusters]; pass 0 leaves the counts in it
 hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const GreedyCand *cand, uint32_t *cursor,
                                    const uint32_t *sub_start, uint32_t *subs, hipStream_t s) {
@@ -664,20 +703,21 @@ hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
                              uint32_t *first, uint32_t *first_next, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot,
-                             const uint32_t *sub_start, const uint32_t *subs, int32_t *joined, long long *csize, const int32_t *cid,
-                             const int32_t *seq_size, uint32_t *counters, hipStream_t s) {
+                             const uint32_t *sub_start, const uint32_t *subs, void *clusters, const int32_t *seq_size,
+                             uint32_t *counters, hipStream_t s) {
     if (nl == 0) return hipSuccess;
+    LoopCluster *cl = (LoopCluster *)clusters;
     const dim3 grid((nl + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_loop_eval, grid, block, 0, s, nl, cand_start, cand, joined, csize, cid, status, choice, first, counters);
-    hipLaunchKernelGGL(k_loop_accept, grid, block, 0, s, nl, cand_start, cand, joined, status, choice, first, first_next, n_clusters,
+    hipLaunchKernelGGL(k_loop_eval, grid, block, 0, s, nl, cand_start, cand, cl, status, choice, first, counters);
+    hipLaunchKernelGGL(k_loop_accept, grid, block, 0, s, nl, cand_start, cand, cl, status, choice, first, first_next, n_clusters,
                        accepted, join_slot, counters);
     const dim3 agrid(512);
     if (packed)
         hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
-                           choice, accepted, sub_start, subs, joined, csize, seq_size, counters);
+                           choice, accepted, sub_start, subs, cl, seq_size, counters);
     else
         hipLaunchKernelGGL((k_loop_apply<Nbr>), agrid, block, 0, s, start, up, (const Nbr *)adj, leftover, status, cand, choice,
-                           accepted, sub_start, subs, joined, csize, seq_size, counters);
+                           accepted, sub_start, subs, cl, seq_size, counters);
     return hipGetLastError();
 }
 
