@@ -160,14 +160,18 @@ __device__ __forceinline__ void flush_stage(const HMK_LDS uint32_t *stage, uint3
         uint32_t x = T.row0 + r, m = col;
         if (!P.perm_identity) { x = P.perm[x]; m = P.perm[m]; }   // wave-uniform branch
         if (P.row_is_m || (P.symmetric && x > m)) { const uint32_t t = x; x = m; m = t; }
-        if (DEG && P.deg) {   // wave-uniform; fire-and-forget atomics on the rare path
-            atomicAdd(&P.deg[x], 1u);
-            if (P.symmetric) atomicAdd(&P.deg[m], 1u);
-        }
         const unsigned long long pos = base + k;
-        if (pos < P.cap_per_shard)
+        if (pos < P.cap_per_shard) {
             P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
                 ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
+            // degrees of STORED edges only: an edge dropped by a segment overflow must not be counted, or the CSR built
+            // from the counters (its scatter is enqueued before the host notices the overflow) would be sized for edges that
+            // are not there and overrun the adjacency buffer
+            if (DEG && P.deg) {   // wave-uniform; fire-and-forget atomics on the rare path
+                atomicAdd(&P.deg[x], 1u);
+                if (P.symmetric) atomicAdd(&P.deg[m], 1u);
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
 }

@@ -132,7 +132,8 @@ k_scan_tiles(const uint32_t *__restrict__ deg, const uint64_t *__restrict__ tile
     }
     if (blockIdx.x == 0 && tid == 0) {
         start[n] = (T)tile_off[n_tiles];
-        if (tail_word) start[n + 1] = (T)*tail_word;
+        // tail word (pack_rows: the misfit count): a 32-bit row_start[] that wrapped makes the block unusable as well
+        if (tail_word) start[n + 1] = (T)*tail_word + (T)((sizeof(T) == 4 && tile_off[n_tiles] > 0xFFFFFFFFull) ? 1 : 0);
     }
 }
 

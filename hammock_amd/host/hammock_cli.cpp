@@ -242,6 +242,9 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         }
         logger.logAndStderr("Shortest sequence: " + std::to_string(minLength) + " AA. Longest sequence: " + std::to_string(maxLength) + " AA.");
         if (sequences.empty()) throw FileFormatException("Error. No sequences (with specified labels) to cluster.");
+        if (maxLength > HMK_MAX_LEN)   // the reference has no such limit; say so here instead of failing inside the clusterer
+            throw HammockException("Error. The longest sequence has " + std::to_string(maxLength) + " amino acids; the GPU kernels of hammock-hip "
+                                   "take sequences of up to " + std::to_string(HMK_MAX_LEN) + " (Hammock's domain is 7-20).");
 
         // ---- runGreedyClustering, :392-437 ------------------------------------------------------------
         if (!o.haveLabels) labels = FileIOManager::getSortedLabels(sequences);                 // :796-798

@@ -374,6 +374,29 @@ def test_greedy_multi_device_context(gpu, blosum62, coracle, devices):
     assert stats.n_edges == sstats.n_edges   # the shards together hold every edge exactly once
 
 
+def test_greedy_edge_buffer_overflow_retry(gpu, blosum62, coracle, monkeypatch):
+    """The first guess of the edge buffer is too small (forced: HMK_EDGE_GUESS): segments overflow, edges are dropped, and
+    the CSR / band kernels enqueued behind the pass run on that truncated edge set before the host sees the counters.
+    They must stay inside their buffers (degrees are counted for STORED edges only) and the call must come back with the
+    right clustering after growing the buffer and scoring again -- single device, two devices, both second-loop paths."""
+    n = 50000
+    res, off = synth_peptides(31, n, 12)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 20, 1250, 8)
+    assert st == 0
+    monkeypatch.setenv("HMK_EDGE_GUESS", "1")
+    for devices, mode in ((0, None), (0, "host"), ([0, 0], None)):
+        if mode:
+            monkeypatch.setenv("HMK_SECOND_LOOP", mode)
+        else:
+            monkeypatch.delenv("HMK_SECOND_LOOP", raising=False)
+        ctx = hammock_amd.Context(blosum62, device=devices)   # fresh context: no buffer grown by an earlier call
+        ctx.set_sequences(residues=res, offsets=off)
+        cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1250)
+        assert stats.n_edges > 16 * 65536                     # more edges than the forced first buffer holds
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+        assert np.array_equal(ctx.member_rank[:n], ostats.member_rank)
+
+
 def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
     """hmk_greedy_cluster ships the adjacency to the host as 4-byte entries when the edge scores span at
     most 255 and as 8-byte entries otherwise; both must give the oracle's clustering.  BLOSUM62 x 12 makes

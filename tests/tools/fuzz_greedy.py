@@ -21,13 +21,14 @@ with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
     blosum62 = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
 rng = np.random.default_rng(seed)
 crashes = ok_runs = 0
+paths = {"device": 0, "lists": 0, "host": 0}
 for trial in range(trials):
     M = blosum62.copy()
     if trial % 5 == 4:
         M += rng.integers(-1, 2, size=(24, 24)).astype(np.int32)      # asymmetric
     lo = int(rng.integers(6, 14))
     hi = int(min(32, lo + rng.integers(0, 9)))
-    n = int(rng.integers(300, 5000))
+    n = int(rng.integers(300, 5000)) if trial % 4 else int(rng.integers(5000, 30000))   # every fourth input is big enough for the band + device loop
     alphabet_seed = int(rng.integers(1, 10 ** 6))
     res, off = synth_peptides(alphabet_seed, n, lo, hi)
     if trial % 3 == 0:   # families of near-duplicates: dense neighbourhoods, big clusters
@@ -53,9 +54,14 @@ for trial in range(trials):
     p = int(rng.choice([0, 0, -1, -2]))
     maxc = int(max(1, rng.choice([2, 10, int(n * 0.025) + 1, n // 8 + 1])))
     st, ocid, oorder, ostats = c_oracle.greedy_cluster(M, res, off, sizes, 0, X, p, thr, maxc, 16)
-    ctx = hammock_amd.Context(M, device=0)
+    mode = [None, "device", "lists", "host"][trial % 4 if trial % 8 >= 4 else 0]   # half the trials: the default path
+    if mode:
+        os.environ["HMK_SECOND_LOOP"] = mode
+    else:
+        os.environ.pop("HMK_SECOND_LOOP", None)
+    ctx = hammock_amd.Context(M, device=[0, 0] if trial % 7 == 6 else 0)   # now and then a two-"device" context
     ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
-    info = {"trial": trial, "n": n, "len": [lo, hi], "X": X, "p": p, "thr": thr, "maxc": maxc}
+    info = {"trial": trial, "n": n, "len": [lo, hi], "X": X, "p": p, "thr": thr, "maxc": maxc, "second_loop": mode}
     if st == c_oracle.HMO_ERR_REFERENCE_WOULD_CRASH:
         try:
             ctx.greedy_cluster(X, p, thr, maxc)
@@ -69,10 +75,11 @@ for trial in range(trials):
     else:
         assert st == 0, st
         cid, order, gstats = ctx.greedy_cluster(X, p, thr, maxc)
-        if not (np.array_equal(cid, ocid) and np.array_equal(order, oorder)):
+        if not (np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(ctx.member_rank[:n], ostats.member_rank)):
             print(json.dumps({"FAIL": "clusters differ", **info}))
             sys.exit(1)
         ok_runs += 1
+        paths[("device" if ctx.greedy_phases()["loop_rounds"] else "lists" if ctx.greedy_phases()["prop_entries"] else "host")] += 1
     if trial % 20 == 19:
         print(f"trial {trial + 1}/{trials}: {ok_runs} identical clusterings, {crashes} crash parities", flush=True)
-print(json.dumps({"trials": trials, "seed": seed, "identical": ok_runs, "crash_parity": crashes}))
+print(json.dumps({"trials": trials, "seed": seed, "identical": ok_runs, "crash_parity": crashes, "second_loop_paths": paths}))
