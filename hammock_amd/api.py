@@ -303,6 +303,21 @@ class Context:
             self._raise(st)
         return cid[:self.n], order[:stats.n_result_clusters], stats
 
+    def clinkage_from_edges(self, edges):
+        """hmk_clinkage_from_edges: the nearest-neighbour chain on a given edge list (works on a host-only context)."""
+        edges = np.ascontiguousarray(edges, dtype=np.uint64)
+        cid = np.full(max(self.n, 1), -1, dtype=np.int32)
+        order = np.full(max(self.n, 1), -1, dtype=np.int32)
+        self.member_rank = np.zeros(max(self.n, 1), dtype=np.int32)
+        stats = N.ClinkageStats()
+        st = N.lib.hmk_clinkage_from_edges(self._h, _ptr(edges, C.c_uint64), edges.size, _ptr(cid, C.c_int32),
+                                           _ptr(order, C.c_int32), _ptr(self.member_rank, C.c_int32), C.byref(stats))
+        if st == N.HMK_ERR_REFERENCE_WOULD_CRASH:
+            raise ReferenceWouldCrash(N.lib.hmk_last_error(self._h).decode(), 0, -1)
+        if st:
+            self._raise(st)
+        return cid[:self.n], order[:stats.n_result_clusters], stats
+
     def greedy_phases(self):
         """hmk_greedy_last_phases: per-phase milliseconds of the last greedy_cluster / greedy_from_edges_dev call."""
         ph = N.GreedyPhases()

@@ -2017,6 +2017,46 @@ int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
     return st;
 }
 
+int hmk_clinkage_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges, int32_t *cluster_id, int32_t *result_order,
+                            int32_t *member_rank, hmk_clinkage_stats *stats) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    hmk_clinkage_stats local;
+    if (!stats) stats = &local;
+    std::memset(stats, 0, sizeof(*stats));
+    const uint32_t n = ctx->n;
+    if (n == 0)
+        return fail(ctx, HMK_ERR_REFERENCE_WOULD_CRASH,
+                    "the reference throws NoSuchElementException here (ClinkageSequenceClusterer.java:118): empty input");
+    if (!cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
+    if (n_edges && !edges) return fail(ctx, HMK_ERR_BAD_ARG, "null edge list");
+    // symmetric CSR on the host: every edge under both ends
+    std::vector<uint64_t> start((size_t)n + 1, 0);
+    for (uint64_t e = 0; e < n_edges; e++) {
+        const uint32_t x = HMK_EDGE_X(edges[e]), m = HMK_EDGE_M(edges[e]);
+        if (x >= n || m >= n || x == m) return fail(ctx, HMK_ERR_BAD_ARG, "edge list references a sequence outside [0, n) or a self pair");
+        start[x + 1]++;
+        start[m + 1]++;
+    }
+    for (uint32_t k = 0; k < n; k++) start[k + 1] += start[k];
+    std::vector<Nbr> adj(start[n]);
+    {
+        std::vector<uint64_t> fill(start.begin(), start.end() - 1);
+        for (uint64_t e = 0; e < n_edges; e++) {
+            const uint32_t x = HMK_EDGE_X(edges[e]), m = HMK_EDGE_M(edges[e]);
+            const int32_t sc = HMK_EDGE_SCORE(edges[e]);
+            adj[fill[x]++] = Nbr{m, sc};
+            adj[fill[m]++] = Nbr{x, sc};
+        }
+    }
+    std::string err;
+    const int st = clinkage_from_csr(n, ctx->has_sizes ? ctx->sizes.data() : nullptr, start.data(), adj.data(), cluster_id, result_order,
+                                     member_rank, stats, &err);
+    stats->n_edges = n_edges;
+    if (st) return fail(ctx, st, err);
+    return HMK_OK;
+}
+
 int hmk_greedy_last_phases(const hmk_ctx *ctx, hmk_greedy_phases *out) {
     if (!ctx || !out) return fail(nullptr, HMK_ERR_BAD_ARG, "null argument");
     *out = ctx->phases;

@@ -253,6 +253,11 @@ typedef struct {
 int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int32_t *cluster_id,
                          int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats);
 
+/* The host-side nearest-neighbour chain alone, on the edge list of a symmetric matrix as hmk_neighbors_shifted produces it
+ * (each unordered pair once, any order; all shards concatenated).  Works on a host-only context (device = -1). */
+int hmk_clinkage_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges, int32_t *cluster_id,
+                            int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats);
+
 /* Where the time of the last hmk_greedy_cluster / hmk_greedy_from_edges_dev call of this context went
  * (milliseconds; the span of Hammock.java:406-411 minus the sort).  score_ms and csr_ms are device times (HIP events on
  * the call's stream), the others host wall time.  The parts overlap (phase 1 runs while the rest of the pair space is

@@ -397,6 +397,47 @@ def test_greedy_edge_buffer_overflow_retry(gpu, blosum62, coracle, monkeypatch):
         assert np.array_equal(ctx.member_rank[:n], ostats.member_rank)
 
 
+def test_one_context_many_calls(gpu, blosum62, coracle):
+    """A long-lived context (what a JVM holds): sequence sets of different sizes, greedy with different parameters, clinkage,
+    plain neighbour passes and pair probes interleaved -- grow-only buffers, cached plans (band / no band) and pinned
+    staging must never leak state from one call into the next.  Every result is compared with the oracle."""
+    ctx = hammock_amd.Context(blosum62, device=0)
+    rng = np.random.default_rng(3)
+    for step, (n, lo, hi, what) in enumerate([(6000, 12, 12, "greedy"), (45000, 12, 12, "greedy"), (3000, 9, 14, "clinkage"),
+                                               (20000, 7, 20, "greedy"), (45000, 12, 12, "neighbors"), (2500, 12, 12, "clinkage"),
+                                               (30000, 12, 12, "greedy")]):
+        res, off = synth_peptides(40 + step, n, lo, hi)
+        sizes = (1 + rng.integers(0, 4, size=n)).astype(np.int32)
+        ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
+        L = np.diff(off.astype(np.int64))
+        thr, X = po.java_round(L.mean() * 1.7) - step % 3, min(po.java_round(L.mean() / 4), int(L.min()) - 1)
+        if what == "greedy":
+            maxc = po.java_round(n * 0.025) + 7 * step
+            st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, X, 0, thr, maxc, 8)
+            if st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH:
+                with pytest.raises(hammock_amd.ReferenceWouldCrash):
+                    ctx.greedy_cluster(X, 0, thr, maxc)
+                continue
+            for _ in range(2):
+                cid, order, _ = ctx.greedy_cluster(X, 0, thr, maxc)
+                assert np.array_equal(cid, ocid) and np.array_equal(order, oorder), (step, n)
+                assert np.array_equal(ctx.member_rank[:n], ostats.member_rank)
+        elif what == "clinkage":
+            st, ocid, oorder, orank, _ = coracle.clinkage_cluster(blosum62, res, off, sizes, X, -1, thr - 4, 8)
+            cid, order, _ = ctx.clinkage_cluster(X, -1, thr - 4)
+            assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(ctx.member_rank[:n], orank)
+        else:
+            edges, stats = ctx.neighbors_shifted(X, 0, thr)
+            x, m, s = hammock_amd.edge_fields(edges)
+            pick = rng.choice(len(edges), 50000, replace=False)
+            st, want = coracle.score_pairs(blosum62, res, off, m[pick], x[pick], 0, X, 0)
+            assert st == 0 and np.array_equal(want, s[pick]) and stats.pairs_scored == n * (n - 1) // 2
+        i = rng.integers(0, n, 64).astype(np.uint32)
+        j = rng.integers(0, n, 64).astype(np.uint32)
+        st, want = coracle.score_pairs(blosum62, res, off, i, j, 0, X, 0)
+        assert np.array_equal(ctx.score_pairs_shifted(i, j, X, 0), want)
+
+
 def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
     """hmk_greedy_cluster ships the adjacency to the host as 4-byte entries when the edge scores span at
     most 255 and as 8-byte entries otherwise; both must give the oracle's clustering.  BLOSUM62 x 12 makes

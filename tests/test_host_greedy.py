@@ -145,3 +145,39 @@ def test_greedy_from_edges_large_uses_precheck_and_inbox(blosum62, coracle, asym
     peps = [peps[k] for k in perm]
     cid = run_both(coracle, M, peps, sizes[perm], 3, 0, 24, 60)
     assert cid is not None and int((np.bincount(cid) > 1).sum()) == 60
+
+
+# --------------------------------------------------------------------------------------
+# the product's nearest-neighbour chain (hmk_clinkage.cpp) on the CPU: edges from the oracle scorer
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_clinkage_from_edges_matches_oracle(blosum62, coracle, seed):
+    """hmk_clinkage_from_edges (host-only context, no GPU): the product's chain over the thresholded graph -- candidate
+    lists kept sorted by id, merged by intersection with the smaller score, HashSet order emulated -- against the oracle's
+    ClinkageSequenceClusterer restatement, which scores cluster pairs member by member."""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(2, 500))
+    peps = random_peptides(rng, n, 9 if seed % 2 else 12, 12, alphabet=4 + seed % 3)
+    sizes = rng.integers(1, 5, size=n).astype(np.int32) if seed % 3 else None
+    res, off = coracle.pack(peps)
+    X, p, thr = 2 + seed % 2, -(seed % 2), 12 + 2 * seed
+    st, ocid, oorder, orank, ostats = coracle.clinkage_cluster(blosum62, res, off, sizes, X, p, thr, 2)
+    assert st == 0
+    edges = oracle_edges(coracle, blosum62, res, off, X, p, thr, True)
+    np.random.default_rng(0).shuffle(edges)
+    ctx = hammock_amd.Context(blosum62, device=-1)
+    ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
+    cid, order, stats = ctx.clinkage_from_edges(edges)
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(ctx.member_rank[:n], orank)
+    assert (stats.merges, stats.searches) == (ostats.merges, ostats.searches)
+
+
+def test_clinkage_from_edges_errors(blosum62, coracle):
+    ctx = hammock_amd.Context(blosum62, device=-1)
+    with pytest.raises(hammock_amd.ReferenceWouldCrash):
+        ctx.clinkage_from_edges(np.zeros(0, dtype=np.uint64))                 # empty input: NoSuchElementException parity
+    ctx.set_sequences(["WVTAPRSLPVLP", "WVTAPRSLPVLA"])
+    with pytest.raises(ValueError):
+        ctx.clinkage_from_edges(hammock_amd.pack_edges([0], [2], [50]))       # m == n
+    with pytest.raises(hammock_amd.DeviceError):
+        ctx.clinkage_cluster(3, 0, 20)                                         # no GPU behind this context, no CPU fallback
