@@ -438,6 +438,25 @@ def test_one_context_many_calls(gpu, blosum62, coracle):
         assert np.array_equal(ctx.score_pairs_shifted(i, j, X, 0), want)
 
 
+@pytest.mark.parametrize("n", [700, 20000])
+def test_greedy_extreme_parameters(gpu, blosum62, coracle, n):
+    """Corner settings of -g / --initial_clusters_limit on a small (host second loop) and a larger (band + device loop) input:
+    no cluster allowed, one, as many as sequences; a threshold nothing reaches; a threshold almost everything reaches."""
+    res, off = synth_peptides(77, n, 12)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    for thr, maxc in ((20, 0), (20, 1), (20, n), (200, 50), (-5 if n < 1000 else 14, 40), (17, 3)):
+        st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, thr, maxc, 8)
+        if st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH:
+            with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
+                ctx.greedy_cluster(3, 0, thr, maxc)
+            assert (ei.value.case, ei.value.index) == (ostats.crash_case, ostats.crash_index), (thr, maxc)
+            continue
+        assert st == 0
+        cid, order, stats = ctx.greedy_cluster(3, 0, thr, maxc)
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder), (thr, maxc)
+        assert np.array_equal(ctx.member_rank[:n], ostats.member_rank), (thr, maxc)
+
+
 def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
     """hmk_greedy_cluster ships the adjacency to the host as 4-byte entries when the edge scores span at
     most 255 and as 8-byte entries otherwise; both must give the oracle's clustering.  BLOSUM62 x 12 makes
