@@ -176,6 +176,51 @@ __device__ __forceinline__ void flush_stage(const HMK_LDS uint32_t *stage, uint3
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
 }
 
+// Compact staging (the exact 8-bit lane kernel): one dword per hit, (column - tile's first column) | row << 16 |
+// (score - threshold) << 20.  The lane proof bounds score - threshold to 0..127 (lane = 128 - threshold + score <= 255) and a
+// tile has at most 65,536 columns and 16 rows, so the record is exact; staging it is a ds_write_b32 (2 LDS-array cycles per
+// wave-instruction) where the 16-byte {column, row, accumulators} record was a ds_write_b128 (8): with a hit in ~15 % of the
+// wave iterations that was 5 % of the kernel's LDS cycles (SQ_LDS_IDX_ACTIVE against 2 x the lookups).
+template <bool DEG>
+__device__ __forceinline__ void flush_stage_compact(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
+                                                    const Tile &T, int threshold, uint32_t shard) {
+    if (cnt == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
+    const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage)
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&P.counts[shard], (unsigned long long)cnt);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t rec = stage[k];
+        const int score = (int)(rec >> 20) + threshold;
+        uint32_t x = T.row0 + ((rec >> 16) & 0xFu), m = T.col0 + (rec & 0xFFFFu);
+        if (!P.perm_identity) { x = P.perm[x]; m = P.perm[m]; }   // wave-uniform branch
+        if (P.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
+        const unsigned long long pos = base + k;
+        if (pos < P.cap_per_shard) {
+            P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
+                ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
+            if (DEG && P.deg) {   // stored edges only, see flush_stage
+                atomicAdd(&P.deg[x], 1u);
+                if (P.symmetric) atomicAdd(&P.deg[m], 1u);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
+}
+
+// largest of the eight byte lanes of two accumulator dwords
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t max_byte_lane(uint32_t w0, uint32_t w1) {
+    const uint32_t M = 0x00FF00FFu;
+    u16x2 a = __builtin_bit_cast(u16x2, w0 & M), b = __builtin_bit_cast(u16x2, (w0 >> 8) & M);
+    u16x2 c = __builtin_bit_cast(u16x2, w1 & M), d = __builtin_bit_cast(u16x2, (w1 >> 8) & M);
+    const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+    return max((uint32_t)m.x, (uint32_t)m.y);
+}
+
 // one table entry of NW dwords from LDS byte address `addr`
 template <int NW>
 __device__ __forceinline__ void lds_read_entry(uint32_t addr, uint32_t (&e)[NW]) {

@@ -33,11 +33,11 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
     constexpr int ES = NW * 4;                 // table entry bytes
     constexpr int ROWBYTES = LBMAX * 24 * ES;  // one row's tables
     constexpr int TAB_BYTES = R * ROWBYTES;
-    constexpr int STAGE_CAP = 128;             // records per wave; flushed when fewer than 64 slots are free
-    constexpr int REC_DW = NW + 2;
+    constexpr int STAGE_CAP = 256;             // records per wave; flushed when fewer than 64 slots are free
+    constexpr int REC_DW = 1;                  // compact records, see flush_stage_compact
     constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;  // residue dwords a lane needs (rows are P.lpad bytes apart)
     static_assert(TAB_BYTES <= 65536, "row tables must stay addressable by the DS immediate offset");
-    static_assert(EXACT && NW == 2 && LBMAX == 12, "this kernel is the length 12, max shift 3, 8-bit lane case");
+    static_assert(EXACT && NW == 2 && LBMAX == 12 && R <= 16, "this kernel is the length 12, max shift 3, 8-bit lane case");
     // one STATIC LDS object: its base address is a compile-time constant, so table
     // offsets fold into the ds_read immediate instead of costing a v_add per lookup
     constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * REC_DW * 4;
@@ -50,9 +50,8 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
 
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
-    const bool lane16 = Cp->path == PATH_U16;
-    const int g = Cp->g;
-    const uint32_t himask = lane16 ? 0x80008000u : 0x80808080u;
+    const int threshold = 128 - Cp->g;         // 8-bit lanes: lane value = 128 - threshold + score
+    const uint32_t himask = 0x80808080u;
     const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
 
     const int tid = threadIdx.x;
@@ -173,7 +172,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
                     const bool hit = (any & himask) != 0;  // some shift reached score >= threshold
                     if (__ballot(hit) != 0) {              // wave-uniform, rare
                         if (cnt > (uint32_t)(STAGE_CAP - 64)) {  // keep room for one wave of hits
-                            flush_stage<NW, DEG>(stage, cnt, P, T, g, lane16, shard);
+                            flush_stage_compact<DEG>(stage, cnt, P, T, threshold, shard);
                             cnt = 0;
                         }
                         const uint32_t col = colpos[p];
@@ -184,20 +183,15 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
                             if (T.diag == 2) keep = keep && col != T.row0 + r;  // full square minus the diagonal
                         }
                         const uint64_t mask = __ballot(keep);
-                        if (keep) {
-                            HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
-                            rec[0] = col;
-                            rec[1] = (uint32_t)r;
-#pragma unroll
-                            for (int w = 0; w < NW; w++) rec[2 + w] = W[p][w];
-                        }
+                        if (keep)   // score - threshold = best lane - 128, in 0..127
+                            stage[cnt + mbcnt64(mask)] = (col - T.col0) | ((uint32_t)r << 16) | ((max_byte_lane(W[p][0], W[p][1]) - 128u) << 20);
                         cnt += (uint32_t)__popcll(mask);
                     }
                 }
             }
         }
     }
-    flush_stage<NW, DEG>(stage, cnt, P, T, g, lane16, shard);
+    flush_stage_compact<DEG>(stage, cnt, P, T, threshold, shard);
 }
 
 // -----------------------------------------------------------------------------
