@@ -28,7 +28,7 @@ namespace hmk {
 template <int NW, int R, int CPL, int LBMAX, bool EXACT, bool DEG>
 // The production tiling (R = 6, CPL = 2) is held to 72 VGPRs = 7 waves/SIMD, which is also what its 22.6 KB of
 // LDS allow per CU (80 VGPRs / 6 waves otherwise): +2.4 % measured.
-__global__ void __launch_bounds__(256, (R == 6 && CPL == 2) ? 7 : 1)
+__global__ void __launch_bounds__(256, (R >= 5 && R <= 7 && CPL == 2) ? 7 : 1)
 k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
     constexpr int ES = NW * 4;                 // table entry bytes
     constexpr int ROWBYTES = LBMAX * 24 * ES;  // one row's tables
