@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 N_SEQ = 100_000
 SEQ_LEN = 12
 MAX_SHIFT, SHIFT_PENALTY, THRESHOLD = 3, 0, 20
+E2E_DEADLINE_S = 120          # N > 1: the end-to-end extra after the timed steps may take this long at most
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # MI355X_MICROARCH.md, LDS table: ds_read_b64 = 2 LDS cycles per wave-instruction = 256 B/clk/CU; 256 CUs at 2.4 GHz
 LDS_PEAK_GBS = 256 * 256 * 2.4          # 157,286 GB/s ("~150 TB/s aggregate for ds_read_b64/b128")
@@ -241,19 +242,6 @@ def main():
     assert int(tot_pairs.item()) == pairs_total, (int(tot_pairs.item()), pairs_total)
 
     e2e = None
-    if world > 1 and not args.no_greedy:
-        # end to end on N GPUs: one more scored + exchanged pass, then the merge on rank 0 from the gathered graph
-        # (hmk_greedy_from_edges_dev) and the broadcast of the cluster ids
-        dist.barrier()
-        t = time.perf_counter()
-        px.step()
-        gathered = px.last_result()
-        cid, order, info = hd.merge_and_broadcast(ctx, gathered, True, THRESHOLD, int(np.floor(n * 0.025 + 0.5)))
-        torch.cuda.synchronize(dev)
-        e2e = {"wall_s": time.perf_counter() - t, "result_list": int(len(order)),
-               "clusters": int(np.sum(np.bincount(np.unique(cid, return_inverse=True)[1]) > 1)),
-               "phases_ms_rank0": ctx.greedy_phases() if rank == 0 else None,
-               "note": "score (sharded) + RCCL all-gather + unpack + merge on rank 0 + broadcast of the ids"}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total / (elapsed / args.steps)
@@ -294,8 +282,6 @@ def main():
             line["exchange"] = {"format": px.fmt, "gathered_bytes_per_rank_per_step": px.bytes_per_step,
                                 "collectives_per_step": 1}
         maxc = int(np.floor(n * 0.025 + 0.5))
-        if e2e is not None:
-            line["greedy_end_to_end"] = e2e
         if world == 1:
             if not args.no_greedy:
                 ctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, maxc)   # first call sizes the context's buffers
@@ -314,8 +300,44 @@ def main():
                 cores = min(cores, int(os.environ.get("HMK_BENCH_CPU_THREADS", "64")))   # the oracle's teams stop scaling well before that
                 line["cpu_baseline"] = cpu_baseline(M, res, off, min(args.cpu_sample, n), cores)
                 line["cpu_baseline"]["cores_chosen_by"] = why
-        print(json.dumps(line))
+    else:
+        line = None
+    if world > 1 and not args.no_greedy:
+        # end to end on N GPUs, AFTER the measurement is complete: one more scored + exchanged pass, then the merge on rank 0
+        # from the gathered graph (hmk_greedy_from_edges_dev) and the broadcast of the cluster ids.  The throughput line must
+        # not depend on this extra: a watchdog prints it without the end-to-end figures if the section does not finish.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["greedy_end_to_end"] = {"error": f"not finished within {E2E_DEADLINE_S} s; the timed steps above are complete"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(E2E_DEADLINE_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            dist.barrier()
+            t = time.perf_counter()
+            px.step()
+            gathered = px.last_result()
+            cid, order, info = hd.merge_and_broadcast(ctx, gathered, True, THRESHOLD, int(np.floor(n * 0.025 + 0.5)))
+            torch.cuda.synchronize(dev)
+            e2e = {"wall_s": time.perf_counter() - t, "result_list": int(len(order)),
+                   "clusters": int(np.sum(np.bincount(np.unique(cid, return_inverse=True)[1]) > 1)),
+                   "phases_ms_rank0": ctx.greedy_phases() if rank == 0 else None,
+                   "note": "score (sharded) + RCCL all-gather + unpack + merge on rank 0 + broadcast of the ids"}
+        except Exception as exc:   # reported in the line, never instead of it
+            e2e = {"error": f"{type(exc).__name__}: {exc}"}
+        watchdog.cancel()
+        if rank == 0:
+            line["greedy_end_to_end"] = e2e
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
+        if e2e is not None and "error" in e2e:
+            os._exit(0)   # a rank that failed may have left the others inside a collective: do not wait for them
         dist.destroy_process_group()
 
 

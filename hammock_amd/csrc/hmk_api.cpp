@@ -344,7 +344,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     while (pl.cols_per_tile > 1024 && ((uint64_t)n / 6 + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
         pl.cols_per_tile /= 2;
     if (const char *v = getenv("HMK_HOT_VARIANT")) pl.hot_variant = atoi(v);   // tuning knobs
-    if (const char *v = getenv("HMK_COLS_PER_TILE")) pl.cols_per_tile = (uint32_t)std::max(256, atoi(v));
+    if (const char *v = getenv("HMK_COLS_PER_TILE")) pl.cols_per_tile = (uint32_t)std::min(65536, std::max(256, atoi(v)));   // hit records hold a 16-bit column offset
 
     // ---- classes and tiles --------------------------------------------------------
     std::vector<TileClass> classes;

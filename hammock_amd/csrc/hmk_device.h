@@ -211,6 +211,39 @@ __device__ __forceinline__ void flush_stage_compact(const HMK_LDS uint32_t *stag
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
 }
 
+// The same for the plane kernels, whose lanes may be 16 bits wide: `rec_dw` (wave-uniform) is 1 for the record above with
+// score = (record >> 20) + base_score, or 2 for {(column - first column) | row << 16, score} when score - threshold may
+// not fit 12 bits (16-bit lanes).  The LONGER length bucket supplies a tile's rows, so P.row_is_m may swap the roles.
+template <bool DEG>
+__device__ __forceinline__ void flush_stage_packed(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
+                                                   const Tile &T, int base_score, uint32_t rec_dw, uint32_t shard) {
+    if (cnt == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
+    const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage)
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&P.counts[shard], (unsigned long long)cnt);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t rec = stage[k * rec_dw];
+        const int score = rec_dw == 1 ? (int)(rec >> 20) + base_score : (int)stage[k * 2 + 1];
+        uint32_t x = T.row0 + ((rec >> 16) & 0xFu), m = T.col0 + (rec & 0xFFFFu);
+        if (!P.perm_identity) { x = P.perm[x]; m = P.perm[m]; }   // wave-uniform branch
+        if (P.row_is_m || (P.symmetric && x > m)) { const uint32_t t = x; x = m; m = t; }
+        const unsigned long long pos = base + k;
+        if (pos < P.cap_per_shard) {
+            P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
+                ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
+            if (DEG && P.deg) {   // stored edges only, see flush_stage
+                atomicAdd(&P.deg[x], 1u);
+                if (P.symmetric) atomicAdd(&P.deg[m], 1u);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
+}
+
 // largest of the eight byte lanes of two accumulator dwords
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t max_byte_lane(uint32_t w0, uint32_t w1) {

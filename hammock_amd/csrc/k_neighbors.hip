@@ -206,7 +206,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
 // own instantiation (no rounding of the shift count up to a power of two).
 //
 // LDS map:  tab  R rows x [NP planes x LBMAX x 24 x 8 B | H x LBMAX x 24 x 4 B]
-//           mb 576 B, rowres R x 32 B, stage 4 waves x 128 records x 3 dwords (col, row, score)
+//           mb 576 B, rowres R x 32 B, stage 4 waves x 192 dwords of hit records (one dword each with 8-bit lanes)
 // Plane strides.  The compiler fuses two ds_reads off the same address register into ds_read2[st64]
 // when their immediates differ by < 2048 B or by a multiple of 512 B (256 B for 4-byte reads); a fused
 // read whose halves are a multiple of 256 B apart hits the same banks with both halves (measured: 43 %
@@ -253,12 +253,15 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
     static_assert(R == rows_for(planes_rowbytes(LBMAX, NW), NW) && NPLANES < 64 && PLANE64 >= 2048 && (PLANE64 / 8) % 2 == 1,
                   "plane stride must keep table reads from being fused into a same-bank ds_read2");
     constexpr int TAB_BYTES = NPLANES * PLANE64;   // plane (r, q) = r * NP + q; pair plane rp = R * NP + rp
-    constexpr int STAGE_CAP = 128, REC_DW = 3;
+    constexpr int STAGE_DW = 192;                      // dwords per wave: 192 one-dword hit records (8-bit lanes) or 96 two-dword ones
     constexpr int LPADW = (LBMAX <= 16) ? 4 : 8;
     // table build scratch: per (row, residue) the row's cells as one byte string (see below); it shares the
     // stage area, which is idle while the tables are built
-    constexpr int WIN_DW = (LBMAX - 1 + 4 * NW + 3) / 4 + 1;       // dwords per string, one spare for the funnel shift
-    constexpr int STAGE_BYTES = 4 * STAGE_CAP * REC_DW * 4, WIN_BYTES = R * 24 * WIN_DW * 4;
+    // dwords per string, one spare for the funnel shift; an ODD stride, so that the 64 lanes of pass 2 (consecutive
+    // residues = consecutive strings) spread over all banks: with 8 dwords per string 3.7-6 % of the LDS cycles of the
+    // <4,4,12>, <3,4,16> and <2,5,20> instantiations were bank-conflict cycles (PMC), with 7 or 9 dwords 0.2-0.4 %
+    constexpr int WIN_DW = ((LBMAX - 1 + 4 * NW + 3) / 4 + 1) | 1;
+    constexpr int STAGE_BYTES = 4 * STAGE_DW * 4, WIN_BYTES = R * 24 * WIN_DW * 4;
     constexpr int AUX_BYTES = STAGE_BYTES > WIN_BYTES ? STAGE_BYTES : WIN_BYTES;
     constexpr int TAB_PAD = (TAB_BYTES + 15) & ~15;
     constexpr int LDS_BYTES = TAB_PAD + 576 + R * 32 + AUX_BYTES;
@@ -278,7 +281,11 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
     const uint32_t himask = lane16 ? 0x80008000u : 0x80808080u;
     const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
     const int tid = threadIdx.x;
-    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * STAGE_DW;   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
+    // hit records (hmk_device.h flush_stage_packed): one dword when score - threshold fits 12 bits -- always with 8-bit lanes,
+    // where it is lane - 128 -- else two
+    const uint32_t rec_dw = lane16 ? 2u : 1u;
+    const int base_score = (lane16 ? 32768 : 128) - g;   // the score of a lane that just reaches the threshold
 
     for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
     for (int e = tid; e < R * 32; e += 256) {
@@ -419,9 +426,14 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
                     }
                 }
             };
+            // Positions are taken in pairs (one v_add3 per accumulator dword and pair).  An odd column length puts its
+            // single position FIRST, so that each variant is a chain of nested wave-uniform `if`s around in-place adds --
+            // an `if / else if` per pair made the compiler copy all R x NW accumulators on every skipped pair.
+            auto add_pairs = [&](auto start_tag) {
+                constexpr int J0 = decltype(start_tag)::value;
 #pragma unroll
-            for (int j = 0; j < LBMAX; j += 2) {
-                if (j + 1 < lb) {
+                for (int j = J0; j + 1 < LBMAX; j += 2) {
+                    if (j + 1 >= lb) break;                     // wave-uniform: nothing beyond this position
                     uint32_t e0[R][NW], e1[R][NW];
                     read_position(j, e0);
                     read_position(j + 1, e1);
@@ -429,14 +441,18 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
                     for (int r = 0; r < R; r++)
 #pragma unroll
                         for (int w = 0; w < NW; w++) W[r][w] = W[r][w] + e0[r][w] + e1[r][w];
-                } else if (j < lb) {
-                    uint32_t e0[R][NW];
-                    read_position(j, e0);
-#pragma unroll
-                    for (int r = 0; r < R; r++)
-#pragma unroll
-                        for (int w = 0; w < NW; w++) W[r][w] += e0[r][w];
                 }
+            };
+            if (lb & 1) {
+                uint32_t e0[R][NW];
+                read_position(0, e0);
+#pragma unroll
+                for (int r = 0; r < R; r++)
+#pragma unroll
+                    for (int w = 0; w < NW; w++) W[r][w] += e0[r][w];
+                add_pairs(std::integral_constant<int, 1>{});
+            } else {
+                add_pairs(std::integral_constant<int, 0>{});
             }
 
             // ---- threshold test: some shift lane has its top bit set <=> score >= threshold ----
@@ -454,8 +470,8 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
                 for (int w = 1; w < NW; w++) any |= W[r][w];
                 const bool hit = (any & himask) != 0 && (uint32_t)r < T.nrows;
                 if (__ballot(hit) != 0) {  // wave-uniform, rare
-                    if (cnt > (uint32_t)(STAGE_CAP - 64)) {
-                        flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+                    if ((cnt + 64) * rec_dw > (uint32_t)STAGE_DW) {
+                        flush_stage_packed<true>(stage, cnt, P, T, base_score, rec_dw, shard);
                         cnt = 0;
                     }
                     bool keep = hit;
@@ -473,17 +489,17 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
                             if (lane16) mx = max(mx, max(dw & 0xFFFFu, dw >> 16));
                             else mx = max(mx, max(max(dw & 0xFFu, (dw >> 8) & 0xFFu), max((dw >> 16) & 0xFFu, dw >> 24)));
                         }
-                        HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * REC_DW;
-                        rec[0] = col;
-                        rec[1] = (uint32_t)r;
-                        rec[2] = (uint32_t)((int)mx - g);
+                        HMK_LDS uint32_t *rec = stage + (cnt + mbcnt64(mask)) * rec_dw;
+                        const uint32_t where = (col - T.col0) | ((uint32_t)r << 16);
+                        if (lane16) { rec[0] = where; rec[1] = (uint32_t)((int)mx - g); }
+                        else rec[0] = where | ((mx - 128u) << 20);
                     }
                     cnt += (uint32_t)__popcll(mask);
                 }
             }
         }
     }
-    flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+    flush_stage_packed<true>(stage, cnt, P, T, base_score, rec_dw, shard);
 }
 
 // -----------------------------------------------------------------------------

@@ -1,8 +1,14 @@
 #!/bin/bash
-# Profiles BASELINE config 4a (mixed lengths) on the GPU box: kernel trace + one PMC pass, then all configs.
-#   gpurun -- 'bash tools/profile_config4a.sh'   -> gpurun_out/prof4a, gpurun_out/pmc4a, gpurun_out/configs_new.jsonl
+# BASELINE config 4a (mixed lengths), instantiation by instantiation, on the GPU box: the launches serialised on one stream
+# (HMK_NO_SIDE_STREAMS=1) under rocprofv3 -- kernel trace, then two PMC passes (own runs, --kernel-trace only beside them) --
+# and each instantiation's time against its LDS-cycle ideal (tools/planes_ideal.py).
+#   gpurun -- 'bash tools/profile_config4a.sh'   -> gpurun_out/round2/round2_config4a_lds_ideal.jsonl
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof4a -o c4a -- python3 $R/tools/run_config4a.py > $R/gpurun_out/prof4a.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc4a -o c4a -- python3 $R/tools/run_config4a.py > $R/gpurun_out/pmc4a.log 2>&1
-cd $R && timeout -k 10 600 python tests/tools/bench_configs.py > gpurun_out/configs_new.jsonl 2> gpurun_out/configs_new.err
+O=$R/gpurun_out/round2
+mkdir -p "$O"
+cd /tmp && export TMPDIR=/tmp HMK_NO_SIDE_STREAMS=1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$O/ser4a" -o s -- python3 "$R/tools/run_config4a.py" > "$O/ser4a.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU --output-format csv -d "$O/pmc4a_i" -o s -- python3 "$R/tools/run_config4a.py" > "$O/pmc4a_i.log" 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d "$O/pmc4a_b" -o s -- python3 "$R/tools/run_config4a.py" > "$O/pmc4a_b.log" 2>&1 || exit 1
+cd "$R" && python tools/planes_ideal.py $(find "$O/ser4a" -name "*kernel_trace.csv" | head -1) $(find "$O/pmc4a_i" "$O/pmc4a_b" -name "*counter_collection.csv") > "$O/round2_config4a_lds_ideal.jsonl"
+cat "$O/round2_config4a_lds_ideal.jsonl"
