@@ -38,7 +38,7 @@ enum {
     SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
-    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
+    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
     SB_PEER, SB_PEERCNT,                                                                  // edge blocks gathered from other devices
     SB_N
 };
@@ -1495,8 +1495,9 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, ncl})));
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CSIZE, std::max<size_t>(ncl, 1) * 8);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CID, std::max<size_t>(ncl, 1) * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_FIRST, std::max<size_t>(ncl, 1) * 8);   // two buffers, swapped every round
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_FIRST, std::max<size_t>(ncl, 1) * 16);   // three rotating first[] buffers + taken[]
         if (r == hipSuccess) r = ensure_buf(ctx, SB_STATUS, std::max<size_t>(nl, 1));
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_ACTIVE, std::max<size_t>(nl, 1) * 8);   // two lists of open leftovers
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CHOICE, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_ACCEPTED, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_JSLOT, std::max<size_t>(nl, 1) * 4);
@@ -1511,18 +1512,22 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
         if (r == hipSuccess) r = launch_loop_subscribers(true, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
                                                          buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), S);
-        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0xFF, (size_t)ncl * 8, S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0xFF, (size_t)ncl * 12, S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<uint32_t>(ctx, SB_FIRST) + (size_t)ncl * 3, 0, (size_t)ncl * 4, S);   // taken[]
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_STATUS), 0, nl, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JSLOT), 0xFF, (size_t)nl * 4, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_LCOUNT), 0, 64, S);
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CSIZE), csize.data(), (size_t)ncl * 8, hipMemcpyHostToDevice, S);
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CID), cids.data(), (size_t)ncl * 4, hipMemcpyHostToDevice, S);
-        if (r == hipSuccess) r = launch_loop_init_clusters(ncl, buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID), buf<void>(ctx, SB_JOINED), S);
+        if (r == hipSuccess) r = launch_loop_init(ncl, buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID), buf<void>(ctx, SB_JOINED), nl,
+                                                  buf<uint32_t>(ctx, SB_ACTIVE), buf<uint32_t>(ctx, SB_LCOUNT), S);
         if (r == hipSuccess && ctx->has_sizes)
             r = hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, S);
         uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
-        uint32_t rounds = 0;
+        uint32_t rounds = 0, tick = 0;
         bool done = false;
+        int accept_passes = 2;
+        if (const char *v = getenv("HMK_LOOP_PASSES")) accept_passes = std::min(8, std::max(1, atoi(v)));
         // every round accepts at least the earliest tentative joiner, so nl + 1 rounds always suffice; the host looks at
         // the device's counter once per batch of rounds (rounds after the end find nothing to do)
         for (uint32_t batch = 8; r == hipSuccess && !done && rounds <= nl + 8; batch = std::min<uint32_t>(batch * 2, 64)) {
@@ -1530,8 +1535,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
                                       buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART),
                                       buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
-                                      buf<uint32_t>(ctx, SB_FIRST) + (size_t)(rounds & 1) * ncl, buf<uint32_t>(ctx, SB_FIRST) + (size_t)(~rounds & 1) * ncl,
-                                      ncl, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
+                                      buf<uint32_t>(ctx, SB_ACTIVE), rounds, buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_FIRST) + (size_t)ncl * 3,
+                                      ncl, accept_passes, &tick, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
                                       buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), buf<void>(ctx, SB_JOINED),
                                       ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), S);
             if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[3], buf<uint32_t>(ctx, SB_LCOUNT) + 3, 4, hipMemcpyDeviceToHost, S);

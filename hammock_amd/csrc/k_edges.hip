@@ -433,10 +433,10 @@ k_greedy_prop(const uint64_t *__restrict__ start, const uint32_t *__restrict__ u
 //   eval    every undecided leftover: F = its feasible entries.  F empty -> it never joins anything (final).  Otherwise
 //           it TENTATIVELY picks the best of F by (score, Cluster.size(), smaller id)
 //           (ClinkageSequenceClusterer.java:163-173,275-289) and atomicMin's its index into first[c] for every c in F.
-//   accept  a tentative joiner is accepted iff first[c] is itself for EVERY c in F: no earlier undecided leftover can
-//           still join any cluster it looked at, so at its turn of the sequential loop those clusters are exactly as
-//           they are now, and its pick is the sequential loop's pick.  (Joins already made by LATER leftovers only
-//           touched clusters that were infeasible for it then, hence now; the earliest tentative joiner always passes.)
+//   accept  a tentative joiner is accepted iff no earlier undecided leftover can still join its pick or a feasible cluster
+//           that ties with the pick (k_loop_accept).  Several accept passes run per round: a leftover accepted in one pass
+//           will join exactly its pick, so it stops blocking the other clusters it lists -- the next pass works with
+//           first[] rebuilt from the leftovers that are still open.  (The earliest tentative joiner always passes.)
 //   apply   every accepted join (at most one per cluster and round) is pushed along the joiner's row: each later,
 //           undecided neighbour that lists the cluster counts one more covered member and folds the pair's score into
 //           its minimum; then joined[c] and Cluster.size() advance, which turns the non-neighbours' entries infeasible.
@@ -462,56 +462,126 @@ struct __attribute__((aligned(16))) LoopCluster {
     long long size;     // Cluster.size()
 };
 
+// A leftover's candidate list is walked by LOOP_SUB = 8 lanes (entry k by lane k % 8): one lane per leftover made the
+// kernel as slow as the longest list -- two dependent gathers (entry, then cluster record) of ~1 us per entry, 40 us per
+// round on the antibodies example with under a thousand leftovers still open.  The kernels run over the list of leftovers
+// that are still open (`active`, rebuilt by the last accept pass of every round; counters[4 + which] holds its length) with
+// a fixed grid, so a round costs what the open leftovers cost, not what all of them would.  While more leftovers are open than
+// the grid has 8-lane groups, one lane per leftover is the better use of the lanes (the kernels are then bound by instruction
+// issue, not by latency: 8 lanes per leftover made the early rounds at 10^6 three times slower): loop_lanes_log2().
+constexpr uint32_t LOOP_GRID = 1024;
+__device__ __forceinline__ uint32_t loop_lanes_log2(uint32_t n_active) { return n_active > (gridDim.x * 256u >> 3) ? 0u : 3u; }
+
 __global__ void __launch_bounds__(256)
-k_loop_eval(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
-            const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status, uint32_t *__restrict__ choice,
-            uint32_t *__restrict__ first, uint32_t *__restrict__ counters) {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q == 0) counters[1] = 0;                       // accepted joins of this round (filled by k_loop_accept)
-    if (q >= nl || status[q] != LS_UNDECIDED) return;
-    const uint32_t kb = cand_start[q], ke = cand_start[q + 1];
-    int has = 0, b_mn = 0, b_id = 0;
-    long long b_size = 0;
-    uint32_t b_k = 0;
-    for (uint32_t k = kb; k < ke; k++) {
-        const GreedyCand cd = cand[k];
-        const LoopCluster c = cl[cd.c];
-        if (cd.covered != c.joined) continue;          // some new member is not a neighbour: infeasible for good
-        // first[c] = the earliest undecided leftover that could still join c (most threads find a smaller one there)
-        if (q < first[cd.c]) atomicMin(&first[cd.c], q);
-        if (!has || cd.mn > b_mn || (cd.mn == b_mn && (c.size > b_size || (c.size == b_size && c.id < b_id)))) {
-            has = 1; b_mn = cd.mn; b_size = c.size; b_id = c.id; b_k = k;
+k_loop_eval(const uint32_t *__restrict__ active, uint32_t which, const uint32_t *__restrict__ cand_start,
+            const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
+            uint32_t *__restrict__ choice, uint32_t *__restrict__ first, uint32_t *__restrict__ first_clear, uint32_t n_clusters,
+            uint32_t *__restrict__ counters) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) { counters[1] = 0; counters[4 + (which ^ 1u)] = 0; }   // accepted joins of this round; the next list starts empty
+    // three first[] buffers rotate through the kernels of the loop: each reads one, fills the next, clears the third
+    for (uint32_t c = t; c < n_clusters; c += gridDim.x * 256) first_clear[c] = 0xFFFFFFFFu;
+    const uint32_t n_active = counters[4 + which];
+    const uint32_t lw = loop_lanes_log2(n_active), LOOP_SUB = 1u << lw;   // lanes per leftover: 1 or 8
+    const uint32_t sub = t & (LOOP_SUB - 1), groups = gridDim.x * 256 >> lw;
+    for (uint32_t i = t >> lw; i < n_active; i += groups) {   // (the LOOP_SUB lanes of a leftover stay together)
+        const uint32_t q = active[i];
+        const uint32_t kb = cand_start[q], ke = cand_start[q + 1];
+        int has = 0, b_mn = 0, b_id = 0;
+        long long b_size = 0;
+        uint32_t b_k = 0;
+        for (uint32_t k = kb + sub; k < ke; k += LOOP_SUB) {
+            const GreedyCand cd = cand[k];
+            const LoopCluster c = cl[cd.c];
+            if (cd.covered != c.joined) continue;          // some new member is not a neighbour: infeasible for good
+            // first[c] = the earliest undecided leftover that could still join c (most threads find a smaller one there)
+            if (q < first[cd.c]) atomicMin(&first[cd.c], q);
+            if (!has || cd.mn > b_mn || (cd.mn == b_mn && (c.size > b_size || (c.size == b_size && c.id < b_id)))) {
+                has = 1; b_mn = cd.mn; b_size = c.size; b_id = c.id; b_k = k;
+            }
         }
+        // the best of the LOOP_SUB partial picks: (score, Cluster.size(), smaller id) is a total order over clusters, so
+        // the order in which entries are compared does not matter
+        for (uint32_t m = 1; m < LOOP_SUB; m <<= 1) {
+            const int o_has = __shfl_xor(has, m), o_mn = __shfl_xor(b_mn, m), o_id = __shfl_xor(b_id, m);
+            const long long o_size = ((long long)__shfl_xor((int)(b_size >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)b_size, m);
+            const uint32_t o_k = (uint32_t)__shfl_xor((int)b_k, m);
+            if (o_has && (!has || o_mn > b_mn || (o_mn == b_mn && (o_size > b_size || (o_size == b_size && o_id < b_id))))) {
+                has = 1; b_mn = o_mn; b_size = o_size; b_id = o_id; b_k = o_k;
+            }
+        }
+        if (sub != 0) continue;
+        if (!has) { status[q] = LS_NEVER; continue; }      // :64, whatever happens later
+        choice[q] = b_k;
+        atomicAdd(&counters[0], 1u);                       // tentative joiners of this round
     }
-    if (!has) { status[q] = LS_NEVER; return; }        // :64, whatever happens later
-    choice[q] = b_k;
-    atomicAdd(&counters[0], 1u);                       // tentative joiners of this round
 }
 
 // Accepted iff no earlier undecided leftover can still join (a) the chosen cluster or (b) a feasible cluster that ties
 // with it on score: those are the only clusters whose change before this leftover's turn could alter its pick -- a
 // candidate with a strictly lower score can never overtake (scores only fall as members join, size and id only break
-// ties), and one that becomes infeasible was not the pick anyway.
+// ties), and one that becomes infeasible was not the pick anyway.  "Can still join c" = undecided, not accepted so far in
+// this round, and c feasible for it: first[c] is the earliest such leftover (built by k_loop_eval for the first pass, by
+// the previous pass for the later ones).  A cluster that already took a joiner in this round (taken[c] == stamp) is not
+// what the candidate entries describe any more until k_loop_apply has run: whoever picks it or ties with it waits.  Within
+// one pass the accepted leftovers pick distinct clusters (two leftovers cannot both be first[c]), so a round still brings
+// at most one join per cluster.  The last pass of a round (build_next == 0) writes the next round's list of open leftovers.
 __global__ void __launch_bounds__(256)
-k_loop_accept(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
+k_loop_accept(const uint32_t *__restrict__ active, uint32_t *__restrict__ active_next, uint32_t which,
+              const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
               const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
-              const uint32_t *__restrict__ first, uint32_t *__restrict__ first_next, uint32_t n_clusters,
+              const uint32_t *__restrict__ first, uint32_t *__restrict__ first_next, uint32_t *__restrict__ first_clear,
+              uint32_t n_clusters, uint32_t *__restrict__ taken, uint32_t stamp, int build_next,
               uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot, uint32_t *__restrict__ counters) {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q == 0) counters[3] = counters[0];             // what the host polls: tentative joiners seen by the last eval
-    // the next round's first[] (the other of two buffers, idle in this round) is reset here: one launch less per round
-    for (uint32_t c = q; c < n_clusters; c += gridDim.x * 256) first_next[c] = 0xFFFFFFFFu;
-    if (q >= nl || status[q] != LS_UNDECIDED) return;
-    const uint32_t kb = cand_start[q], ke = cand_start[q + 1];
-    const GreedyCand pick = cand[choice[q]];
-    if (first[pick.c] != q) return;                    // an earlier leftover may still join the pick: wait
-    for (uint32_t k = kb; k < ke; k++) {
-        const GreedyCand cd = cand[k];
-        if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && first[cd.c] != q) return;   // a tie that may still grow
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u;
+    if (t == 0) counters[3] = counters[0];             // what the host polls: tentative joiners seen by the last eval
+    for (uint32_t c = t; c < n_clusters; c += gridDim.x * 256) first_clear[c] = 0xFFFFFFFFu;
+    const uint32_t n_active = counters[4 + which];
+    const uint32_t lw = loop_lanes_log2(n_active), LOOP_SUB = 1u << lw;   // as in k_loop_eval
+    const uint32_t sub = t & (LOOP_SUB - 1), groups = gridDim.x * 256 >> lw;
+    // (wave-uniform trip count: the ballots below need every lane of the wave inside the loop)
+    for (uint32_t i0 = (t - lane) >> lw; i0 < n_active; i0 += groups) {
+        const uint32_t i = i0 + (lane >> lw);
+        const bool live = i < n_active;
+        const uint32_t q = live ? active[i] : 0u;
+        const bool open = live && status[q] == LS_UNDECIDED;   // not LS_NEVER since this round's eval, not accepted by an earlier pass
+        bool bad = true;
+        uint32_t kb = 0, ke = 0;
+        GreedyCand pick{0, 0, 0};
+        if (open) {
+            kb = cand_start[q]; ke = cand_start[q + 1];
+            pick = cand[choice[q]];
+            bad = first[pick.c] != q || taken[pick.c] == stamp;   // an earlier leftover may still join the pick, or one just did
+            if (!bad)
+                for (uint32_t k = kb + sub; k < ke; k += LOOP_SUB) {
+                    const GreedyCand cd = cand[k];
+                    if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && (first[cd.c] != q || taken[cd.c] == stamp)) { bad = true; break; }   // a tie that may still grow
+                }
+        }
+        const bool group_bad = ((__ballot(bad) >> (lane & ~(LOOP_SUB - 1))) & ((1ull << LOOP_SUB) - 1)) != 0;
+        if (open && !group_bad && sub == 0) {
+            status[q] = LS_JOINED;                     // :61-62
+            join_slot[q] = pick.c;
+            taken[pick.c] = stamp;
+            accepted[atomicAdd(&counters[1], 1u)] = q;
+        }
+        const bool stays = open && group_bad;          // still open: it keeps blocking every cluster it could join
+        if (build_next) {
+            if (stays)
+                for (uint32_t k = kb + sub; k < ke; k += LOOP_SUB) {
+                    const GreedyCand cd = cand[k];
+                    if (cd.covered == cl[cd.c].joined && q < first_next[cd.c]) atomicMin(&first_next[cd.c], q);
+                }
+        } else {                                       // next round's list, one atomic per wave
+            const uint64_t keep = __ballot(stays && sub == 0);
+            if (keep) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&counters[4 + (which ^ 1u)], (uint32_t)__popcll(keep));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (stays && sub == 0) active_next[base + (uint32_t)__popcll(keep & ((1ull << lane) - 1ull))] = q;
+            }
+        }
     }
-    status[q] = LS_JOINED;                             // :61-62
-    join_slot[q] = pick.c;
-    accepted[atomicAdd(&counters[1], 1u)] = q;
 }
 
 // One workgroup per accepted join (y -> c): y's later neighbours go into an LDS hash table, chunk by chunk, and the
@@ -678,15 +748,21 @@ hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, 
 namespace hmk {
 
 __global__ void __launch_bounds__(256)
-k_loop_init_clusters(uint32_t n_clusters, const long long *__restrict__ csize, const int32_t *__restrict__ cid, LoopCluster *__restrict__ cl) {
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c < n_clusters) cl[c] = LoopCluster{0, cid[c], csize[c]};
+k_loop_init(uint32_t n_clusters, const long long *__restrict__ csize, const int32_t *__restrict__ cid, LoopCluster *__restrict__ cl,
+            uint32_t nl, uint32_t *__restrict__ active, uint32_t *__restrict__ counters) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n_clusters) cl[t] = LoopCluster{0, cid[t], csize[t]};
+    if (t < nl) active[t] = t;                       // every leftover is open before the first round
+    if (t == 0) counters[4] = nl;
 }
 
-// per-cluster records of the device-side second loop from the uploaded sizes and ids; cl: 16 bytes per cluster
-hipError_t launch_loop_init_clusters(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *cl, hipStream_t s) {
-    if (n_clusters == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_loop_init_clusters, dim3((n_clusters + 255) / 256), dim3(256), 0, s, n_clusters, csize, cid, (LoopCluster *)cl);
+// state of the device-side second loop before its first round: per-cluster records (16 bytes each) from the uploaded sizes
+// and ids, list 0 of open leftovers = all of them (counters: zeroed by the caller beforehand)
+hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *cl, uint32_t nl, uint32_t *active,
+                            uint32_t *counters, hipStream_t s) {
+    const uint32_t m = std::max(n_clusters, nl);
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_loop_init, dim3((m + 255) / 256), dim3(256), 0, s, n_clusters, csize, cid, (LoopCluster *)cl, nl, active, counters);
     return hipGetLastError();
 }
 
@@ -699,19 +775,30 @@ hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_
     return hipGetLastError();
 }
 
-// one round of the device-side second loop (see k_loop_eval); counters: device uint32[4]; first / first_next:
-// uint32[n_clusters] each, `first` all ones on entry (the caller swaps the two between rounds)
+// one round of the device-side second loop (see k_loop_eval): eval, `passes` accept passes, apply.  counters: device
+// uint32[8] (4 + w = length of open-leftover list w); active2: two uint32[nl] lists, list (round & 1) is read and the other
+// written; first3: three uint32[n_clusters] buffers, all ones before the first round; taken: uint32[n_clusters], zeroed;
+// *tick counts the eval / accept kernels launched so far (it selects the buffer each one reads, fills and clears)
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
-                             uint32_t *first, uint32_t *first_next, uint32_t n_clusters, uint32_t *accepted, int32_t *join_slot,
+                             uint32_t *active2, uint32_t round, uint32_t *first3, uint32_t *taken, uint32_t n_clusters, int passes,
+                             uint32_t *tick, uint32_t *accepted, int32_t *join_slot,
                              const uint32_t *sub_start, const uint32_t *subs, void *clusters, const int32_t *seq_size,
                              uint32_t *counters, hipStream_t s) {
     if (nl == 0) return hipSuccess;
     LoopCluster *cl = (LoopCluster *)clusters;
-    const dim3 grid((nl + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_loop_eval, grid, block, 0, s, nl, cand_start, cand, cl, status, choice, first, counters);
-    hipLaunchKernelGGL(k_loop_accept, grid, block, 0, s, nl, cand_start, cand, cl, status, choice, first, first_next, n_clusters,
-                       accepted, join_slot, counters);
+    const dim3 grid((uint32_t)std::min<uint64_t>(LOOP_GRID, ((uint64_t)nl * 8 + 255) / 256)), block(256);
+    auto fb = [&](uint32_t t) { return first3 + (size_t)(t % 3) * n_clusters; };
+    const uint32_t which = round & 1u, stamp = round + 1;
+    const uint32_t *act = active2 + (size_t)which * nl;
+    uint32_t *act_next = active2 + (size_t)(which ^ 1u) * nl;
+    uint32_t t = *tick;
+    hipLaunchKernelGGL(k_loop_eval, grid, block, 0, s, act, which, cand_start, cand, cl, status, choice, fb(t + 1), fb(t + 2), n_clusters, counters);
+    t++;
+    for (int p = 0; p < passes; p++, t++)
+        hipLaunchKernelGGL(k_loop_accept, grid, block, 0, s, act, act_next, which, cand_start, cand, cl, status, choice, fb(t), fb(t + 1),
+                           fb(t + 2), n_clusters, taken, stamp, p + 1 < passes ? 1 : 0, accepted, join_slot, counters);
+    *tick = t;
     const dim3 agrid(512);
     if (packed)
         hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
