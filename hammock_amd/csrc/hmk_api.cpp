@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <tuple>
+#include <thread>
 #include <vector>
 
 #include "hmk_internal.h"
@@ -38,7 +39,7 @@ enum {
     SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
-    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
+    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
     SB_PEER, SB_PEERCNT,                                                                  // edge blocks gathered from other devices
     SB_N
 };
@@ -119,6 +120,7 @@ struct hmk_ctx {
     size_t h_start_cap = 0;
     void *h_adj = nullptr;    // pinned: adjacency rows fetched so far
     size_t h_adj_cap = 0;
+    unsigned long long *h_loop = nullptr;    // pinned, coherent: progress word of the device-side second loop (written by k_loop_apply)
     unsigned long long *h_counts = nullptr;  // pinned: final segment counts [16], band snapshot [16], misc [8]
     hmk_greedy_phases phases{};
 
@@ -929,6 +931,7 @@ void hmk_destroy(hmk_ctx *ctx) {
         if (ctx->h_start) (void)hipHostFree(ctx->h_start);
         if (ctx->h_adj) (void)hipHostFree(ctx->h_adj);
         if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+        if (ctx->h_loop) (void)hipHostFree(ctx->h_loop);
         for (int b = 0; b < SB_N; b++)
             if (ctx->sb[b].p) (void)hipFree(ctx->sb[b].p);
         if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
@@ -1225,6 +1228,8 @@ int greedy_streams(hmk_ctx *ctx) {
     HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_hi));
     for (hipEvent_t *ev : {&ctx->ev_t0, &ctx->ev_band, &ctx->ev_edges, &ctx->ev_csr, &ctx->ev_bandcsr}) HIPCHK(ctx, hipEventCreate(ev));
     HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, HC_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+    // fine-grained, so that a system-scope store of a running kernel is seen by the polling host (no such block: batches + syncs)
+    if (hipHostMalloc((void **)&ctx->h_loop, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { ctx->h_loop = nullptr; (void)hipGetLastError(); }
     return HMK_OK;
 }
 
@@ -1492,56 +1497,92 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         hipError_t r = ensure_buf(ctx, SB_JOINED, std::max<size_t>(ncl, 1) * 16);   // {joined, id, size} per cluster
         if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBSTART, ((size_t)ncl + 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBS, std::max<size_t>(pre_total_c, 1) * 8);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBS2, std::max<size_t>(pre_total_c, 1) * 8);   // merge scratch of the subscriber sort
         if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, ncl})));
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CSIZE, std::max<size_t>(ncl, 1) * 8);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CID, std::max<size_t>(ncl, 1) * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_FIRST, std::max<size_t>(ncl, 1) * 16);   // three rotating first[] buffers + taken[]
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_FIRST, std::max<size_t>(ncl, 1) * 12);   // first[], taken[], list cursor[] per cluster
         if (r == hipSuccess) r = ensure_buf(ctx, SB_STATUS, std::max<size_t>(nl, 1));
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_ACTIVE, std::max<size_t>(nl, 1) * 8);   // two lists of open leftovers
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_ACTIVE, std::max<size_t>(nl, 1) * 8);   // two eval lists
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_DIRTY, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CHOICE, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_ACCEPTED, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_JSLOT, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_LCOUNT, 64);
         if (r == hipSuccess && ctx->has_sizes) r = ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4);
         if (r != hipSuccess) return false;
-        // subscriber lists (count into FIRST as scratch, scan, fill)
+        // subscriber lists (count into FIRST as scratch, scan, fill, sort by leftover)
         r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
         if (r == hipSuccess) r = launch_loop_subscribers(false, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
                                                          buf<uint32_t>(ctx, SB_FIRST), nullptr, nullptr, S);
         if (r == hipSuccess) r = launch_scan_u32(buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), ncl, buf<uint64_t>(ctx, SB_SCAN2), S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
         if (r == hipSuccess) r = launch_loop_subscribers(true, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
-                                                         buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), S);
-        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0xFF, (size_t)ncl * 12, S);
-        if (r == hipSuccess) r = hipMemsetAsync(buf<uint32_t>(ctx, SB_FIRST) + (size_t)ncl * 3, 0, (size_t)ncl * 4, S);   // taken[]
+                                                         buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), S);
+        if (r == hipSuccess) r = launch_loop_sort_subscribers(ncl, buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), buf<uint64_t>(ctx, SB_SUBS2), S);
+        uint32_t *d_first = buf<uint32_t>(ctx, SB_FIRST), *d_taken = d_first + ncl, *d_clcursor = d_first + 2 * (size_t)ncl;
+        if (r == hipSuccess) r = hipMemsetAsync(d_taken, 0, (size_t)ncl * 4, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_STATUS), 0, nl, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JSLOT), 0xFF, (size_t)nl * 4, S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_LCOUNT), 0, 64, S);
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CSIZE), csize.data(), (size_t)ncl * 8, hipMemcpyHostToDevice, S);
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CID), cids.data(), (size_t)ncl * 4, hipMemcpyHostToDevice, S);
-        if (r == hipSuccess) r = launch_loop_init(ncl, buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID), buf<void>(ctx, SB_JOINED), nl,
-                                                  buf<uint32_t>(ctx, SB_ACTIVE), buf<uint32_t>(ctx, SB_LCOUNT), S);
+        if (r == hipSuccess) r = launch_loop_init(ncl, buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID), buf<void>(ctx, SB_JOINED),
+                                                  buf<uint32_t>(ctx, SB_SUBSTART), d_clcursor, nl, buf<uint32_t>(ctx, SB_ACTIVE),
+                                                  buf<uint32_t>(ctx, SB_DIRTY), buf<uint32_t>(ctx, SB_LCOUNT), S);
         if (r == hipSuccess && ctx->has_sizes)
             r = hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, S);
         uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
-        uint32_t rounds = 0, tick = 0;
+        uint32_t rounds = 0;
         bool done = false;
-        int accept_passes = 2;
+        // a second first/accept pass per round saves a third of the rounds; it pays once a round's apply and eval are big enough
+        int accept_passes = ncl >= 8192 ? 2 : 1;
         if (const char *v = getenv("HMK_LOOP_PASSES")) accept_passes = std::min(8, std::max(1, atoi(v)));
-        // every round accepts at least the earliest tentative joiner, so nl + 1 rounds always suffice; the host looks at
-        // the device's counter once per batch of rounds (rounds after the end find nothing to do)
-        for (uint32_t batch = 8; r == hipSuccess && !done && rounds <= nl + 8; batch = std::min<uint32_t>(batch * 2, 64)) {
-            for (uint32_t b = 0; b < batch && r == hipSuccess; b++, rounds++)
-                r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
-                                      buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART),
-                                      buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
-                                      buf<uint32_t>(ctx, SB_ACTIVE), rounds, buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_FIRST) + (size_t)ncl * 3,
-                                      ncl, accept_passes, &tick, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
-                                      buf<uint32_t>(ctx, SB_SUBSTART), buf<uint32_t>(ctx, SB_SUBS), buf<void>(ctx, SB_JOINED),
-                                      ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), S);
-            if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[3], buf<uint32_t>(ctx, SB_LCOUNT) + 3, 4, hipMemcpyDeviceToHost, S);
-            if (r == hipSuccess) r = hipStreamSynchronize(S);
-            done = r == hipSuccess && h_misc[3] == 0;
+        // Every round accepts at least the earliest open leftover that has a feasible cluster, so nl + 1 rounds always suffice
+        // and a round without a join is the end.  The host keeps enqueuing rounds while it watches the progress word that
+        // k_loop_apply stores into pinned host memory (round << 32 | joins of that round), at most LOOKAHEAD rounds ahead of
+        // the device; rounds enqueued after the end find nothing to do.  Without the word: batches of rounds and a sync each.
+        auto one_round = [&]() {
+            r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
+                                  buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART),
+                                  buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
+                                  buf<uint32_t>(ctx, SB_ACTIVE), buf<uint32_t>(ctx, SB_DIRTY), rounds, d_first, d_taken, d_clcursor,
+                                  ncl, accept_passes, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
+                                  buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), buf<void>(ctx, SB_JOINED),
+                                  ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), ctx->h_loop, S);
+            rounds++;
+        };
+        if (nl == 0 || ncl == 0) {
+            done = true;
+        } else if (ctx->h_loop && getenv("HMK_LOOP_BATCHES") == nullptr) {
+            uint32_t LOOKAHEAD = 4;   // a round is 4-6 small dependent kernels: a few rounds in the queue keep the device busy
+            if (const char *v = getenv("HMK_LOOP_LOOKAHEAD")) LOOKAHEAD = (uint32_t)std::max(1, atoi(v));
+            volatile unsigned long long *word = ctx->h_loop;
+            *word = 0;
+            const auto t_poll = std::chrono::steady_clock::now();
+            while (r == hipSuccess && !done && rounds <= nl + 8) {
+                one_round();
+                for (;;) {
+                    const unsigned long long w = *word;
+                    const uint32_t seen = (uint32_t)(w >> 32);      // rounds the device has finished
+                    if (seen && (uint32_t)w == 0) { done = true; break; }
+                    if (rounds - seen < LOOKAHEAD) break;
+                    if ((rounds & 63u) == 0 && ms_since(t_poll) > 60e3) { r = hipErrorNotReady; break; }   // never spin forever
+                    std::this_thread::yield();
+                }
+            }
+            if (r == hipSuccess && !done) {                         // (only when nl + 8 rounds were not enough: impossible)
+                r = hipStreamSynchronize(S);
+                done = r == hipSuccess && (uint32_t)*word == 0;
+            }
+            if (r == hipSuccess) r = hipStreamSynchronize(S);       // drain the rounds enqueued past the end
+        } else {
+            for (uint32_t batch = 8; r == hipSuccess && !done && rounds <= nl + 8; batch = std::min<uint32_t>(batch * 2, 64)) {
+                for (uint32_t b = 0; b < batch && r == hipSuccess; b++) one_round();
+                if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[3], buf<uint32_t>(ctx, SB_LCOUNT) + 3, 4, hipMemcpyDeviceToHost, S);
+                if (r == hipSuccess) r = hipStreamSynchronize(S);
+                done = r == hipSuccess && h_misc[3] == 0;
+            }
         }
         if (r != hipSuccess || !done) return false;
         join_slot.resize(nl);

@@ -71,18 +71,19 @@ size_t scan_total_index(uint32_t n);
 // device-side second loop (k_loop_*).  Subscriber lists: per cluster the (leftover, candidate entry) pairs listing it,
 // subs = uint32[2 * entries]; pass 0 (fill = false) counts into the zeroed cursor[n_clusters], pass 1 fills.
 hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const GreedyCand *cand, uint32_t *cursor,
-                                   const uint32_t *sub_start, uint32_t *subs, hipStream_t s);
+                                   const uint32_t *sub_start, uint64_t *subs, hipStream_t s);
 // one round; counters: device uint32[4] ([3] = tentative joiners the round's eval saw: 0 means the loop is over),
 // first / first_next: uint32[n_clusters] each; first must be all ones, first_next is reset for the next round
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
-                             uint32_t *active2, uint32_t round, uint32_t *first3, uint32_t *taken, uint32_t n_clusters, int passes,
-                             uint32_t *tick, uint32_t *accepted, int32_t *join_slot,
-                             const uint32_t *sub_start, const uint32_t *subs, void *clusters, const int32_t *seq_size,
-                             uint32_t *counters, hipStream_t s);
+                             uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken, uint32_t *cursor,
+                             uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
+                             const uint32_t *sub_start, const uint64_t *subs, void *clusters, const int32_t *seq_size,
+                             uint32_t *counters, unsigned long long *host_word, hipStream_t s);
+hipError_t launch_loop_sort_subscribers(uint32_t n_clusters, const uint32_t *sub_start, uint64_t *subs, uint64_t *tmp, hipStream_t s);
 // clusters: 16 bytes per cluster {joined = 0, id, size}, built on the device from the uploaded ids and sizes
-hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *clusters, uint32_t nl,
-                            uint32_t *active, uint32_t *counters, hipStream_t s);
+hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *clusters, const uint32_t *sub_start,
+                            uint32_t *cursor, uint32_t nl, uint32_t *list, uint32_t *dirty, uint32_t *counters, hipStream_t s);
 // join-propagation lists of the second loop (k_greedy_prop): lidx = sequence -> leftover index or -1
 hipError_t launch_fill_lidx(const uint32_t *leftover, uint32_t nl, int32_t *lidx, uint32_t n, hipStream_t s);
 hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, const uint32_t *up, const void *adj,

@@ -429,29 +429,100 @@ k_greedy_prop(const uint64_t *__restrict__ start, const uint32_t *__restrict__ u
 // every join made by the leftovers before it.  Complete linkage is monotone in this loop -- clusters only grow, so a
 // cluster that is infeasible for w now is infeasible for good -- and that makes the loop parallel without changing
 // its result.  State per (leftover, candidate cluster) entry: covered = members that joined the cluster in this loop
-// and are neighbours of the leftover; the entry is feasible iff covered == joined[cluster].  One round:
-//   eval    every undecided leftover: F = its feasible entries.  F empty -> it never joins anything (final).  Otherwise
-//           it TENTATIVELY picks the best of F by (score, Cluster.size(), smaller id)
-//           (ClinkageSequenceClusterer.java:163-173,275-289) and atomicMin's its index into first[c] for every c in F.
-//   accept  a tentative joiner is accepted iff no earlier undecided leftover can still join its pick or a feasible cluster
-//           that ties with the pick (k_loop_accept).  Several accept passes run per round: a leftover accepted in one pass
-//           will join exactly its pick, so it stops blocking the other clusters it lists -- the next pass works with
-//           first[] rebuilt from the leftovers that are still open.  (The earliest tentative joiner always passes.)
-//   apply   every accepted join (at most one per cluster and round) is pushed along the joiner's row: each later,
-//           undecided neighbour that lists the cluster counts one more covered member and folds the pair's score into
-//           its minimum; then joined[c] and Cluster.size() advance, which turns the non-neighbours' entries infeasible.
-// Rounds repeat until no tentative joiner is left.  The host applies the joins in leftover order afterwards.
+// and are neighbours of the leftover; the entry is feasible iff covered == joined[cluster].  A leftover is OPEN while it
+// is undecided; its pick = the best of its feasible entries by (score, Cluster.size(), smaller id)
+// (ClinkageSequenceClusterer.java:163-173,275-289); without a feasible entry it never joins anything (final).
+//   first[c] = the earliest open leftover for which c is feasible.
+//   An open leftover q is ACCEPTED (its pick is final: it is what the sequential loop does at q's turn) iff first[c] == q
+//   for its pick and for every feasible cluster that ties with the pick on score: no earlier open leftover can still join
+//   any of those, and they are the only clusters whose change before q's turn could alter q's pick -- a candidate with a
+//   strictly lower score can never overtake (scores only fall as members join, size and id only break ties), and one that
+//   becomes infeasible was not the pick anyway.  (Joins already made by LATER leftovers only touched clusters that were
+//   infeasible for q then, hence now.)  The earliest open leftover with a feasible entry always passes.
+// One round:
+//   eval    re-picks the leftovers whose entries changed in the previous round (all of them in the first round)
+//   first   per cluster: first[c] by moving a cursor along the cluster's subscriber list, which is sorted by leftover --
+//           open -> decided and feasible -> infeasible are both one-way, so the cursor only moves forward and the whole
+//           loop walks every list once
+//   accept  per cluster: the leftover at first[c], if c is its pick and the rule above holds; several first/accept passes
+//           run per round, because an accepted leftover stops blocking the other clusters it lists.  A cluster that took a
+//           joiner in this round (taken[c] == stamp) is not what the entries describe until `apply` has run: whoever
+//           picks it or ties with it waits.  At most one join per cluster and round.
+//   apply   every accepted join is pushed along the joiner's row: each later open subscriber of the cluster that is a
+//           neighbour counts one more covered member and folds the pair's score into its minimum; then joined[c] and
+//           Cluster.size() advance, which turns the non-neighbours' entries infeasible.  Every subscriber whose entry was
+//           feasible goes on the next round's eval list.
+// Rounds repeat until one accepts nobody.  The host applies the joins in leftover order afterwards.
 enum : uint8_t { LS_UNDECIDED = 0, LS_NEVER = 1, LS_JOINED = 2 };
 
-// subscriber lists: per cluster the (leftover, candidate entry) pairs that list it; pass 0 counts, pass 1 fills
+// subscriber lists: per cluster the (leftover, candidate entry) pairs that list it, as uint64 = entry << 32 | leftover;
+// pass 0 counts, pass 1 fills (in arbitrary order: k_loop_sort_subs sorts them)
 __global__ void __launch_bounds__(256)
 k_loop_subscribers(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
-                   uint32_t *__restrict__ cursor, const uint32_t *__restrict__ sub_start, uint32_t *__restrict__ subs, int fill) {
+                   uint32_t *__restrict__ cursor, const uint32_t *__restrict__ sub_start, unsigned long long *__restrict__ subs, int fill) {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nl) return;
     for (uint32_t k = cand_start[q], ke = cand_start[q + 1]; k < ke; k++) {
         const uint32_t pos = atomicAdd(&cursor[cand[k].c], 1u);
-        if (fill) { subs[2 * (size_t)(sub_start[cand[k].c] + pos)] = q; subs[2 * (size_t)(sub_start[cand[k].c] + pos) + 1] = k; }
+        if (fill) subs[(size_t)sub_start[cand[k].c] + pos] = ((unsigned long long)k << 32) | q;
+    }
+}
+
+// Sorts every cluster's subscriber list by candidate entry = by leftover (the entries of leftover q are
+// cand[cand_start[q] ..), so entry order is leftover order).  One workgroup per cluster: bitonic sort of runs of SORT_RUN
+// entries in LDS, then -- for the rare longer list -- merges of neighbouring runs through `tmp` (every element finds its
+// place by a binary search in the other run; keys are unique).
+constexpr uint32_t SORT_RUN = 4096;
+
+__global__ void __launch_bounds__(256)
+k_loop_sort_subs(const uint32_t *__restrict__ sub_start, unsigned long long *subs, unsigned long long *tmp) {
+    __shared__ unsigned long long run[SORT_RUN];
+    const uint32_t b = sub_start[blockIdx.x], n = sub_start[blockIdx.x + 1] - b;
+    if (n < 2) return;
+    unsigned long long *list = subs + b, *other = tmp + b;
+    for (uint32_t r0 = 0; r0 < n; r0 += SORT_RUN) {
+        const uint32_t len = min(SORT_RUN, n - r0);
+        uint32_t p2 = 2;
+        while (p2 < len) p2 <<= 1;
+        for (uint32_t e = threadIdx.x; e < p2; e += 256) run[e] = e < len ? list[r0 + e] : ~0ull;
+        __syncthreads();
+        for (uint32_t k = 2; k <= p2; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t e = threadIdx.x; e < p2; e += 256) {
+                    const uint32_t x = e ^ j;
+                    if (x > e) {
+                        const unsigned long long a = run[e], c = run[x];
+                        if ((a > c) == ((e & k) == 0)) { run[e] = c; run[x] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t e = threadIdx.x; e < len; e += 256) list[r0 + e] = run[e];
+        __syncthreads();
+    }
+    if (n <= SORT_RUN) return;
+    __threadfence_block();
+    unsigned long long *src = list, *dst = other;
+    for (uint32_t w = SORT_RUN; w < n; w <<= 1) {
+        for (uint32_t e = threadIdx.x; e < n; e += 256) {
+            const uint32_t pair0 = e / (2 * w) * (2 * w), mid = min(pair0 + w, n), end = min(pair0 + 2 * w, n);
+            const unsigned long long v = src[e];
+            uint32_t lo, hi;                         // number of elements of the OTHER run that come before v
+            if (e < mid) { lo = mid; hi = end; } else { lo = pair0; hi = mid; }
+            const uint32_t base = lo;
+            while (lo < hi) {
+                const uint32_t m = (lo + hi) >> 1;
+                if (src[m] < v) lo = m + 1; else hi = m;
+            }
+            const uint32_t before = lo - base;
+            dst[pair0 + (e < mid ? e - pair0 : e - mid) + before] = v;
+        }
+        __threadfence_block();
+        __syncthreads();
+        unsigned long long *t = src; src = dst; dst = t;
+    }
+    if (src != list) {
+        for (uint32_t e = threadIdx.x; e < n; e += 256) list[e] = src[e];
     }
 }
 
@@ -462,47 +533,40 @@ struct __attribute__((aligned(16))) LoopCluster {
     long long size;     // Cluster.size()
 };
 
-// A leftover's candidate list is walked by LOOP_SUB = 8 lanes (entry k by lane k % 8): one lane per leftover made the
-// kernel as slow as the longest list -- two dependent gathers (entry, then cluster record) of ~1 us per entry, 40 us per
-// round on the antibodies example with under a thousand leftovers still open.  The kernels run over the list of leftovers
-// that are still open (`active`, rebuilt by the last accept pass of every round; counters[4 + which] holds its length) with
-// a fixed grid, so a round costs what the open leftovers cost, not what all of them would.  While more leftovers are open than
-// the grid has 8-lane groups, one lane per leftover is the better use of the lanes (the kernels are then bound by instruction
-// issue, not by latency: 8 lanes per leftover made the early rounds at 10^6 three times slower): loop_lanes_log2().
+// counters (device uint32[8]): 1 = joins accepted in this round, 3 = the same, as the host polls it (written by apply),
+// 4 + w = length of eval list w
+//
+// A leftover's candidate list is walked by 8 lanes (entry k by lane k % 8) while the eval list is short: one lane per
+// leftover makes the kernel as slow as the longest list -- two dependent gathers (entry, then cluster record) of ~1 us per
+// entry.  While the list is longer than the grid has 8-lane groups, one lane per leftover is the better use of the lanes
+// (the kernel is then bound by instruction issue, not by latency).
 constexpr uint32_t LOOP_GRID = 1024;
-__device__ __forceinline__ uint32_t loop_lanes_log2(uint32_t n_active) { return n_active > (gridDim.x * 256u >> 3) ? 0u : 3u; }
-
-__global__ void __launch_bounds__(256)
-k_loop_eval(const uint32_t *__restrict__ active, uint32_t which, const uint32_t *__restrict__ cand_start,
-            const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
-            uint32_t *__restrict__ choice, uint32_t *__restrict__ first, uint32_t *__restrict__ first_clear, uint32_t n_clusters,
-            uint32_t *__restrict__ counters) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t == 0) { counters[1] = 0; counters[4 + (which ^ 1u)] = 0; }   // accepted joins of this round; the next list starts empty
-    // three first[] buffers rotate through the kernels of the loop: each reads one, fills the next, clears the third
-    for (uint32_t c = t; c < n_clusters; c += gridDim.x * 256) first_clear[c] = 0xFFFFFFFFu;
-    const uint32_t n_active = counters[4 + which];
-    const uint32_t lw = loop_lanes_log2(n_active), LOOP_SUB = 1u << lw;   // lanes per leftover: 1 or 8
-    const uint32_t sub = t & (LOOP_SUB - 1), groups = gridDim.x * 256 >> lw;
-    for (uint32_t i = t >> lw; i < n_active; i += groups) {   // (the LOOP_SUB lanes of a leftover stay together)
-        const uint32_t q = active[i];
+__device__ __forceinline__ void
+loop_eval(uint32_t block, uint32_t n_blocks, const uint32_t *__restrict__ list, uint32_t which, const uint32_t *__restrict__ cand_start,
+          const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
+          uint32_t *__restrict__ choice, uint32_t *__restrict__ dirty, uint32_t *__restrict__ counters) {
+    const uint32_t t = block * 256 + threadIdx.x;
+    if (t == 0) { counters[1] = 0; counters[4 + (which ^ 1u)] = 0; }   // accepted joins of this round; the next eval list starts empty
+    const uint32_t n_list = counters[4 + which];
+    const uint32_t lw = n_list > (n_blocks * 256u >> 3) ? 0u : 3u, W = 1u << lw;   // lanes per leftover: 1 or 8
+    const uint32_t sub = t & (W - 1), groups = n_blocks * 256 >> lw;
+    for (uint32_t i = t >> lw; i < n_list; i += groups) {   // (the W lanes of a leftover stay together)
+        const uint32_t q = list[i];
         const uint32_t kb = cand_start[q], ke = cand_start[q + 1];
         int has = 0, b_mn = 0, b_id = 0;
         long long b_size = 0;
         uint32_t b_k = 0;
-        for (uint32_t k = kb + sub; k < ke; k += LOOP_SUB) {
+        for (uint32_t k = kb + sub; k < ke; k += W) {
             const GreedyCand cd = cand[k];
             const LoopCluster c = cl[cd.c];
             if (cd.covered != c.joined) continue;          // some new member is not a neighbour: infeasible for good
-            // first[c] = the earliest undecided leftover that could still join c (most threads find a smaller one there)
-            if (q < first[cd.c]) atomicMin(&first[cd.c], q);
             if (!has || cd.mn > b_mn || (cd.mn == b_mn && (c.size > b_size || (c.size == b_size && c.id < b_id)))) {
                 has = 1; b_mn = cd.mn; b_size = c.size; b_id = c.id; b_k = k;
             }
         }
-        // the best of the LOOP_SUB partial picks: (score, Cluster.size(), smaller id) is a total order over clusters, so
-        // the order in which entries are compared does not matter
-        for (uint32_t m = 1; m < LOOP_SUB; m <<= 1) {
+        // the best of the W partial picks: (score, Cluster.size(), smaller id) is a total order over clusters, so the order
+        // in which entries are compared does not matter
+        for (uint32_t m = 1; m < W; m <<= 1) {
             const int o_has = __shfl_xor(has, m), o_mn = __shfl_xor(b_mn, m), o_id = __shfl_xor(b_id, m);
             const long long o_size = ((long long)__shfl_xor((int)(b_size >> 32), m) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)b_size, m);
             const uint32_t o_k = (uint32_t)__shfl_xor((int)b_k, m);
@@ -511,102 +575,128 @@ k_loop_eval(const uint32_t *__restrict__ active, uint32_t which, const uint32_t 
             }
         }
         if (sub != 0) continue;
-        if (!has) { status[q] = LS_NEVER; continue; }      // :64, whatever happens later
-        choice[q] = b_k;
-        atomicAdd(&counters[0], 1u);                       // tentative joiners of this round
+        dirty[q] = 0;
+        if (status[q] != LS_UNDECIDED) continue;           // (it joined in the round that put it on the list)
+        if (!has) status[q] = LS_NEVER;                    // :64, whatever happens later
+        else choice[q] = b_k;
     }
 }
 
-// Accepted iff no earlier undecided leftover can still join (a) the chosen cluster or (b) a feasible cluster that ties
-// with it on score: those are the only clusters whose change before this leftover's turn could alter its pick -- a
-// candidate with a strictly lower score can never overtake (scores only fall as members join, size and id only break
-// ties), and one that becomes infeasible was not the pick anyway.  "Can still join c" = undecided, not accepted so far in
-// this round, and c feasible for it: first[c] is the earliest such leftover (built by k_loop_eval for the first pass, by
-// the previous pass for the later ones).  A cluster that already took a joiner in this round (taken[c] == stamp) is not
-// what the candidate entries describe any more until k_loop_apply has run: whoever picks it or ties with it waits.  Within
-// one pass the accepted leftovers pick distinct clusters (two leftovers cannot both be first[c]), so a round still brings
-// at most one join per cluster.  The last pass of a round (build_next == 0) writes the next round's list of open leftovers.
-__global__ void __launch_bounds__(256)
-k_loop_accept(const uint32_t *__restrict__ active, uint32_t *__restrict__ active_next, uint32_t which,
-              const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
-              const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
-              const uint32_t *__restrict__ first, uint32_t *__restrict__ first_next, uint32_t *__restrict__ first_clear,
-              uint32_t n_clusters, uint32_t *__restrict__ taken, uint32_t stamp, int build_next,
-              uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot, uint32_t *__restrict__ counters) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u;
-    if (t == 0) counters[3] = counters[0];             // what the host polls: tentative joiners seen by the last eval
-    for (uint32_t c = t; c < n_clusters; c += gridDim.x * 256) first_clear[c] = 0xFFFFFFFFu;
-    const uint32_t n_active = counters[4 + which];
-    const uint32_t lw = loop_lanes_log2(n_active), LOOP_SUB = 1u << lw;   // as in k_loop_eval
-    const uint32_t sub = t & (LOOP_SUB - 1), groups = gridDim.x * 256 >> lw;
-    // (wave-uniform trip count: the ballots below need every lane of the wave inside the loop)
-    for (uint32_t i0 = (t - lane) >> lw; i0 < n_active; i0 += groups) {
-        const uint32_t i = i0 + (lane >> lw);
-        const bool live = i < n_active;
-        const uint32_t q = live ? active[i] : 0u;
-        const bool open = live && status[q] == LS_UNDECIDED;   // not LS_NEVER since this round's eval, not accepted by an earlier pass
-        bool bad = true;
-        uint32_t kb = 0, ke = 0;
-        GreedyCand pick{0, 0, 0};
-        if (open) {
-            kb = cand_start[q]; ke = cand_start[q + 1];
-            pick = cand[choice[q]];
-            bad = first[pick.c] != q || taken[pick.c] == stamp;   // an earlier leftover may still join the pick, or one just did
-            if (!bad)
-                for (uint32_t k = kb + sub; k < ke; k += LOOP_SUB) {
-                    const GreedyCand cd = cand[k];
-                    if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && (first[cd.c] != q || taken[cd.c] == stamp)) { bad = true; break; }   // a tie that may still grow
-                }
+// first[c]: one wave per cluster
+__device__ __forceinline__ void
+loop_first(uint32_t block, uint32_t n_clusters, const uint32_t *__restrict__ sub_start, const unsigned long long *__restrict__ subs,
+           uint32_t *__restrict__ cursor, const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl,
+           const uint8_t *__restrict__ status, const uint32_t *__restrict__ taken, uint32_t stamp, uint32_t *__restrict__ first) {
+    const uint32_t c = block * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (c >= n_clusters) return;
+    // a cluster that took a joiner in this round is closed until `apply` has run (k_loop_accept tests taken[] before
+    // first[]); its cursor must stay on the joiner, which is where `apply` starts from
+    if (taken[c] == stamp) return;
+    const uint32_t end = sub_start[c + 1];
+    uint32_t cu = cursor[c];
+    const int32_t joined = cl[c].joined;
+    auto valid_at = [&](uint32_t idx, uint32_t *q) -> bool {
+        const unsigned long long e = subs[idx];
+        *q = (uint32_t)e;
+        return status[*q] == LS_UNDECIDED && cand[(uint32_t)(e >> 32)].covered == joined;
+    };
+    if (cu < end) {                                       // usually the holder of the previous pass still stands
+        uint32_t q = 0;
+        bool ok = false;
+        if (lane == 0) ok = valid_at(cu, &q);
+        if (__builtin_amdgcn_readfirstlane((int)ok)) {
+            if (lane == 0) first[c] = q;
+            return;
         }
-        const bool group_bad = ((__ballot(bad) >> (lane & ~(LOOP_SUB - 1))) & ((1ull << LOOP_SUB) - 1)) != 0;
-        if (open && !group_bad && sub == 0) {
-            status[q] = LS_JOINED;                     // :61-62
-            join_slot[q] = pick.c;
-            taken[pick.c] = stamp;
-            accepted[atomicAdd(&counters[1], 1u)] = q;
-        }
-        const bool stays = open && group_bad;          // still open: it keeps blocking every cluster it could join
-        if (build_next) {
-            if (stays)
-                for (uint32_t k = kb + sub; k < ke; k += LOOP_SUB) {
-                    const GreedyCand cd = cand[k];
-                    if (cd.covered == cl[cd.c].joined && q < first_next[cd.c]) atomicMin(&first_next[cd.c], q);
-                }
-        } else {                                       // next round's list, one atomic per wave
-            const uint64_t keep = __ballot(stays && sub == 0);
-            if (keep) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&counters[4 + (which ^ 1u)], (uint32_t)__popcll(keep));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (stays && sub == 0) active_next[base + (uint32_t)__popcll(keep & ((1ull << lane) - 1ull))] = q;
-            }
+        cu++;
+    }
+    for (; cu < end; cu += 64) {                          // wave-uniform
+        uint32_t q = 0;
+        const bool ok = cu + lane < end && valid_at(cu + lane, &q);
+        const uint64_t found = __ballot(ok);
+        if (found) {
+            const uint32_t at = (uint32_t)__ffsll((long long)found) - 1;
+            if (lane == at) { first[c] = q; cursor[c] = cu + at; }
+            return;
         }
     }
+    if (lane == 0) { first[c] = 0xFFFFFFFFu; cursor[c] = end; }
+}
+
+// The round's eval and its first `first` pass in one launch (blocks [0, eval_blocks) evaluate): `first` looks at statuses and
+// at entries' covered counts, not at picks, and a leftover that eval is just marking LS_NEVER has no feasible entry, so it is
+// not a valid holder whichever status `first` reads.
+__global__ void __launch_bounds__(256)
+k_loop_eval_first(uint32_t eval_blocks, const uint32_t *__restrict__ list, uint32_t which, const uint32_t *__restrict__ cand_start,
+                  const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
+                  uint32_t *__restrict__ choice, uint32_t *__restrict__ dirty, uint32_t *__restrict__ counters,
+                  uint32_t n_clusters, const uint32_t *__restrict__ sub_start, const unsigned long long *__restrict__ subs,
+                  uint32_t *__restrict__ cursor, const uint32_t *__restrict__ taken, uint32_t stamp, uint32_t *__restrict__ first) {
+    if (blockIdx.x < eval_blocks) loop_eval(blockIdx.x, eval_blocks, list, which, cand_start, cand, cl, status, choice, dirty, counters);
+    else loop_first(blockIdx.x - eval_blocks, n_clusters, sub_start, subs, cursor, cand, cl, status, taken, stamp, first);
+}
+
+__global__ void __launch_bounds__(256)
+k_loop_first(uint32_t n_clusters, const uint32_t *__restrict__ sub_start, const unsigned long long *__restrict__ subs,
+             uint32_t *__restrict__ cursor, const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl,
+             const uint8_t *__restrict__ status, const uint32_t *__restrict__ taken, uint32_t stamp, uint32_t *__restrict__ first) {
+    loop_first(blockIdx.x, n_clusters, sub_start, subs, cursor, cand, cl, status, taken, stamp, first);
+}
+
+// one thread per cluster: the leftover at first[c], if c is its pick
+__global__ void __launch_bounds__(256)
+k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
+              const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
+              const uint32_t *__restrict__ first, uint32_t *__restrict__ taken, uint32_t stamp,
+              uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot, uint32_t *__restrict__ counters) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_clusters) return;
+    const uint32_t q = first[c];
+    if (q == 0xFFFFFFFFu || taken[c] == stamp) return;
+    const GreedyCand pick = cand[choice[q]];
+    if ((uint32_t)pick.c != c) return;                     // q picks another cluster (that cluster's thread looks at it)
+    for (uint32_t k = cand_start[q], ke = cand_start[q + 1]; k < ke; k++) {
+        const GreedyCand cd = cand[k];
+        if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && (first[cd.c] != q || taken[cd.c] == stamp)) return;   // a tie that may still grow
+    }
+    status[q] = LS_JOINED;                                 // :61-62
+    join_slot[q] = pick.c;
+    taken[c] = stamp;
+    accepted[atomicAdd(&counters[1], 1u)] = q;
 }
 
 // One workgroup per accepted join (y -> c): y's later neighbours go into an LDS hash table, chunk by chunk, and the
-// cluster's subscribers probe it -- a subscriber that is a neighbour counts one more covered member and folds the
-// pair's score into its minimum; the others' entries turn infeasible when joined[c] advances.
-constexpr int APPLY_SLOTS = 8192, APPLY_CHUNK = 4096;   // 64 KB of LDS, load factor <= 1/2
+// cluster's subscribers after y probe it -- a subscriber that is a neighbour counts one more covered member and folds
+// the pair's score into its minimum; the others' entries turn infeasible when joined[c] advances.
+constexpr int APPLY_SLOTS = 8192, APPLY_CHUNK = 4096;   // 64 KB of LDS, load factor <= 1/2 (4,096 slots and 1,280 workgroups: no faster)
 
 template <class NbrT>
 __global__ void __launch_bounds__(256)
 k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, const NbrT *__restrict__ adj,
              const uint32_t *__restrict__ leftover, const uint8_t *__restrict__ status, GreedyCand *__restrict__ cand,
              const uint32_t *__restrict__ choice, const uint32_t *__restrict__ accepted, const uint32_t *__restrict__ sub_start,
-             const uint32_t *__restrict__ subs, LoopCluster *__restrict__ cl, const int32_t *__restrict__ seq_size,
-             uint32_t *__restrict__ counters) {
+             const unsigned long long *__restrict__ subs, const uint32_t *__restrict__ cursor, LoopCluster *__restrict__ cl,
+             const int32_t *__restrict__ seq_size, uint32_t *__restrict__ dirty, uint32_t *__restrict__ next_list, uint32_t which,
+             uint32_t *__restrict__ counters, unsigned long long *host_word, uint32_t stamp) {
     __shared__ uint32_t keys[APPLY_SLOTS];
     __shared__ int32_t vals[APPLY_SLOTS];
     const uint32_t n_acc = counters[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = 0;   // next round's eval counts again (nobody reads it here)
+    const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                     // what the host polls: a round without a join is the end
+        counters[3] = n_acc;
+        // (n_acc == 0: this kernel changes nothing, so the word may go out before it ends; otherwise the host only uses the
+        // round number to bound how far ahead it enqueues)
+        if (host_word) __hip_atomic_store(host_word, ((unsigned long long)stamp << 32) | n_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (uint32_t a = blockIdx.x; a < n_acc; a += gridDim.x) {   // workgroup-uniform loop
         const uint32_t q = accepted[a];
         const uint32_t y = leftover[q];
         const int32_t c = cand[choice[q]].c;
-        const uint32_t sb = sub_start[c], se = sub_start[c + 1];
+        const int32_t joined = cl[c].joined;
+        const uint32_t sb = cursor[c] + 1, se = sub_start[c + 1];   // the list is sorted and the cursor stands at q itself
         const uint64_t b = start[y], e = b + up[y];              // later leftovers have larger ids: the upper section
-        for (uint64_t c0 = b; c0 < e; c0 += APPLY_CHUNK) {
+        bool first_chunk = true;
+        for (uint64_t c0 = b; c0 < e || first_chunk; c0 += APPLY_CHUNK) {
             for (uint32_t sl = threadIdx.x; sl < (uint32_t)APPLY_SLOTS; sl += 256) keys[sl] = 0xFFFFFFFFu;
             __syncthreads();
             const uint64_t c1 = min(e, c0 + (uint64_t)APPLY_CHUNK);
@@ -621,23 +711,44 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                 }
             }
             __syncthreads();
-            for (uint32_t s2 = sb + threadIdx.x; s2 < se; s2 += 256) {
-                const uint32_t q2 = subs[2 * (size_t)s2], k2 = subs[2 * (size_t)s2 + 1];
-                if (q2 <= q || status[q2] != LS_UNDECIDED) continue;
-                const uint32_t id = leftover[q2];
-                uint32_t sl = (id * 2654435761u) >> 19;
-                for (;;) {
-                    const uint32_t kk = keys[sl];
-                    if (kk == id) {                              // this entry belongs to leftover q2 alone; one join per cluster and round
-                        cand[k2].covered += 1;
-                        if (vals[sl] < cand[k2].mn) cand[k2].mn = vals[sl];
-                        break;
+            for (uint32_t s0 = sb; s0 < se; s0 += 256) {         // workgroup-uniform: the ballots need whole waves
+                const uint32_t s2 = s0 + threadIdx.x;
+                bool mark = false;
+                uint32_t q2 = 0;
+                if (s2 < se) {
+                    const unsigned long long sub = subs[s2];
+                    q2 = (uint32_t)sub;
+                    const uint32_t k2 = (uint32_t)(sub >> 32);
+                    // only a feasible entry matters (covered == joined; joined + 1 once an earlier chunk has counted y), and it
+                    // changes either way -- one more covered member, or infeasible from now on: its leftover re-picks
+                    if (status[q2] == LS_UNDECIDED && cand[k2].covered == joined) {
+                        const uint32_t id = leftover[q2];
+                        uint32_t sl = (id * 2654435761u) >> 19;
+                        for (;;) {
+                            const uint32_t kk = keys[sl];
+                            if (kk == id) {                      // this entry belongs to leftover q2 alone; one join per cluster and round
+                                cand[k2].covered = joined + 1;
+                                if (vals[sl] < cand[k2].mn) cand[k2].mn = vals[sl];
+                                break;
+                            }
+                            if (kk == 0xFFFFFFFFu) break;
+                            sl = (sl + 1) & (APPLY_SLOTS - 1);
+                        }
+                        if (first_chunk) mark = atomicExch(&dirty[q2], 1u) == 0u;
                     }
-                    if (kk == 0xFFFFFFFFu) break;
-                    sl = (sl + 1) & (APPLY_SLOTS - 1);
+                }
+                if (first_chunk) {                               // next round's eval list, one atomic per wave
+                    const uint64_t m = __ballot(mark);
+                    if (m) {
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(&counters[4 + (which ^ 1u)], (uint32_t)__popcll(m));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (mark) next_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = q2;
+                    }
                 }
             }
             __syncthreads();
+            first_chunk = false;
         }
         if (threadIdx.x == 0) {
             cl[c].joined += 1;
@@ -749,63 +860,73 @@ namespace hmk {
 
 __global__ void __launch_bounds__(256)
 k_loop_init(uint32_t n_clusters, const long long *__restrict__ csize, const int32_t *__restrict__ cid, LoopCluster *__restrict__ cl,
-            uint32_t nl, uint32_t *__restrict__ active, uint32_t *__restrict__ counters) {
+            const uint32_t *__restrict__ sub_start, uint32_t *__restrict__ cursor, uint32_t nl, uint32_t *__restrict__ list,
+            uint32_t *__restrict__ dirty, uint32_t *__restrict__ counters) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n_clusters) cl[t] = LoopCluster{0, cid[t], csize[t]};
-    if (t < nl) active[t] = t;                       // every leftover is open before the first round
+    if (t < n_clusters) { cl[t] = LoopCluster{0, cid[t], csize[t]}; cursor[t] = sub_start[t]; }
+    if (t < nl) { list[t] = t; dirty[t] = 1; }       // the first round evaluates every leftover
     if (t == 0) counters[4] = nl;
 }
 
 // state of the device-side second loop before its first round: per-cluster records (16 bytes each) from the uploaded sizes
-// and ids, list 0 of open leftovers = all of them (counters: zeroed by the caller beforehand)
-hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *cl, uint32_t nl, uint32_t *active,
-                            uint32_t *counters, hipStream_t s) {
+// and ids, the cursors at the heads of the (sorted) subscriber lists, eval list 0 = every leftover (counters: zeroed by
+// the caller beforehand)
+hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *cl, const uint32_t *sub_start,
+                            uint32_t *cursor, uint32_t nl, uint32_t *list, uint32_t *dirty, uint32_t *counters, hipStream_t s) {
     const uint32_t m = std::max(n_clusters, nl);
     if (m == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_loop_init, dim3((m + 255) / 256), dim3(256), 0, s, n_clusters, csize, cid, (LoopCluster *)cl, nl, active, counters);
+    hipLaunchKernelGGL(k_loop_init, dim3((m + 255) / 256), dim3(256), 0, s, n_clusters, csize, cid, (LoopCluster *)cl, sub_start, cursor,
+                       nl, list, dirty, counters);
     return hipGetLastError();
 }
 
 // subscriber lists of the device-side second loop: cursor = zeroed uint32[n_clusters]; pass 0 leaves the counts in it
 hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const GreedyCand *cand, uint32_t *cursor,
-                                   const uint32_t *sub_start, uint32_t *subs, hipStream_t s) {
+                                   const uint32_t *sub_start, uint64_t *subs, hipStream_t s) {
     if (nl == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_loop_subscribers, dim3((nl + 255) / 256), dim3(256), 0, s, nl, cand_start, cand, cursor, sub_start, subs,
-                       fill ? 1 : 0);
+    hipLaunchKernelGGL(k_loop_subscribers, dim3((nl + 255) / 256), dim3(256), 0, s, nl, cand_start, cand, cursor, sub_start,
+                       (unsigned long long *)subs, fill ? 1 : 0);
     return hipGetLastError();
 }
 
-// one round of the device-side second loop (see k_loop_eval): eval, `passes` accept passes, apply.  counters: device
-// uint32[8] (4 + w = length of open-leftover list w); active2: two uint32[nl] lists, list (round & 1) is read and the other
-// written; first3: three uint32[n_clusters] buffers, all ones before the first round; taken: uint32[n_clusters], zeroed;
-// *tick counts the eval / accept kernels launched so far (it selects the buffer each one reads, fills and clears)
+// every cluster's list sorted by leftover; tmp: as large as subs
+hipError_t launch_loop_sort_subscribers(uint32_t n_clusters, const uint32_t *sub_start, uint64_t *subs, uint64_t *tmp, hipStream_t s) {
+    if (n_clusters == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_loop_sort_subs, dim3(n_clusters), dim3(256), 0, s, sub_start, (unsigned long long *)subs, (unsigned long long *)tmp);
+    return hipGetLastError();
+}
+
+// one round of the device-side second loop (see k_loop_eval): eval, `passes` x (first, accept), apply.  counters: device
+// uint32[8]; lists2: two uint32[nl] eval lists, list (round & 1) is read and the other written; first, taken, cursor:
+// uint32[n_clusters] each (taken zeroed before the first round)
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
-                             uint32_t *active2, uint32_t round, uint32_t *first3, uint32_t *taken, uint32_t n_clusters, int passes,
-                             uint32_t *tick, uint32_t *accepted, int32_t *join_slot,
-                             const uint32_t *sub_start, const uint32_t *subs, void *clusters, const int32_t *seq_size,
-                             uint32_t *counters, hipStream_t s) {
-    if (nl == 0) return hipSuccess;
+                             uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken, uint32_t *cursor,
+                             uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
+                             const uint32_t *sub_start, const uint64_t *subs, void *clusters, const int32_t *seq_size,
+                             uint32_t *counters, unsigned long long *host_word, hipStream_t s) {
+    if (nl == 0 || n_clusters == 0) return hipSuccess;
     LoopCluster *cl = (LoopCluster *)clusters;
     const dim3 grid((uint32_t)std::min<uint64_t>(LOOP_GRID, ((uint64_t)nl * 8 + 255) / 256)), block(256);
-    auto fb = [&](uint32_t t) { return first3 + (size_t)(t % 3) * n_clusters; };
     const uint32_t which = round & 1u, stamp = round + 1;
-    const uint32_t *act = active2 + (size_t)which * nl;
-    uint32_t *act_next = active2 + (size_t)(which ^ 1u) * nl;
-    uint32_t t = *tick;
-    hipLaunchKernelGGL(k_loop_eval, grid, block, 0, s, act, which, cand_start, cand, cl, status, choice, fb(t + 1), fb(t + 2), n_clusters, counters);
-    t++;
-    for (int p = 0; p < passes; p++, t++)
-        hipLaunchKernelGGL(k_loop_accept, grid, block, 0, s, act, act_next, which, cand_start, cand, cl, status, choice, fb(t), fb(t + 1),
-                           fb(t + 2), n_clusters, taken, stamp, p + 1 < passes ? 1 : 0, accepted, join_slot, counters);
-    *tick = t;
+    const uint32_t *list = lists2 + (size_t)which * nl;
+    uint32_t *list_next = lists2 + (size_t)(which ^ 1u) * nl;
+    const unsigned long long *sb = (const unsigned long long *)subs;
+    hipLaunchKernelGGL(k_loop_eval_first, dim3(grid.x + (n_clusters + 3) / 4), block, 0, s, grid.x, list, which, cand_start, cand, cl, status,
+                       choice, dirty, counters, n_clusters, sub_start, sb, cursor, taken, stamp, first);
+    for (int p = 0; p < passes; p++) {
+        if (p > 0)
+            hipLaunchKernelGGL(k_loop_first, dim3((n_clusters + 3) / 4), block, 0, s, n_clusters, sub_start, sb, cursor, cand, cl, status, taken, stamp, first);
+        hipLaunchKernelGGL(k_loop_accept, dim3((n_clusters + 255) / 256), block, 0, s, n_clusters, cand_start, cand, cl, status, choice,
+                           first, taken, stamp, accepted, join_slot, counters);
+    }
     const dim3 agrid(512);
     if (packed)
         hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
-                           choice, accepted, sub_start, subs, cl, seq_size, counters);
+                           choice, accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp);
     else
         hipLaunchKernelGGL((k_loop_apply<Nbr>), agrid, block, 0, s, start, up, (const Nbr *)adj, leftover, status, cand, choice,
-                           accepted, sub_start, subs, cl, seq_size, counters);
+                           accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp);
     return hipGetLastError();
 }
 

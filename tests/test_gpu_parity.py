@@ -332,6 +332,29 @@ def test_greedy_second_loop_implementations(gpu, blosum62, coracle, monkeypatch,
     assert (ph["loop_rounds"] > 0) == (mode == "device") and (ph["prop_entries"] > 0) == (mode == "lists")
 
 
+def test_greedy_device_loop_long_subscriber_lists(gpu, blosum62, coracle, monkeypatch):
+    """Three families of 10,000 near-duplicates, three clusters: every cluster is listed by ~10^4 leftovers, so the
+    device loop's subscriber lists are longer than one LDS sort run (4,096) and go through two rounds of merges, its
+    joins come one per cluster and round (thousands of rounds), and the clusters grow to thousands of members."""
+    rng = np.random.default_rng(3)
+    seeds = [rng.integers(0, 20, 12).astype(np.uint8) for _ in range(3)]
+    peps = {}
+    while len(peps) < 30000:
+        q = seeds[int(rng.integers(3))].copy()
+        for _ in range(int(rng.integers(1, 4))):
+            q[int(rng.integers(12))] = rng.integers(0, 20)
+        peps[bytes(q)] = q
+    res, off = hammock_amd.pack_sequences(list(peps.values()))
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 18, 3, 16)
+    assert st == 0 and np.bincount(np.unique(ocid, return_inverse=True)[1]).max() > 5000
+    monkeypatch.setenv("HMK_SECOND_LOOP", "device")
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    cid, order, stats = ctx.greedy_cluster(3, 0, 18, 3)
+    assert ctx.greedy_phases()["loop_rounds"] > 1000
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+
+
 def test_greedy_3e5_vs_oracle(gpu, blosum62, coracle):
     """3 x 10^5 peptides (between BASELINE configs 3 and 5): the size at which the device-side second loop takes over
     by itself; identical membership, list order and member order against the oracle's literal greedy."""
