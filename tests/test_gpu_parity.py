@@ -332,6 +332,25 @@ def test_greedy_second_loop_implementations(gpu, blosum62, coracle, monkeypatch,
     assert (ph["loop_rounds"] > 0) == (mode == "device") and (ph["prop_entries"] > 0) == (mode == "lists")
 
 
+@pytest.mark.parametrize("env", [{"HMK_LOOP_PASSES": "1"}, {"HMK_LOOP_PASSES": "3"}, {"HMK_LOOP_BATCHES": "1"},
+                                 {"HMK_LOOP_LOOKAHEAD": "1"}, {"HMK_LOOP_LOOKAHEAD": "64", "HMK_LOOP_PASSES": "2"}])
+def test_greedy_device_loop_variants(gpu, blosum62, coracle, monkeypatch, env):
+    """The knobs of the device-side second loop -- accept passes per round, how far the host enqueues ahead of the
+    progress word, batches with a sync instead of the word -- change its schedule, never its result."""
+    n = 20000
+    res, off = synth_peptides(11, n, 12)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 19, 500, 16)
+    assert st == 0
+    monkeypatch.setenv("HMK_SECOND_LOOP", "device")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    cid, order, stats = ctx.greedy_cluster(3, 0, 19, 500)
+    assert ctx.greedy_phases()["loop_rounds"] > 0
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+
+
 def test_greedy_device_loop_long_subscriber_lists(gpu, blosum62, coracle, monkeypatch):
     """Three families of 10,000 near-duplicates, three clusters: every cluster is listed by ~10^4 leftovers, so the
     device loop's subscriber lists are longer than one LDS sort run (4,096) and go through two rounds of merges, its

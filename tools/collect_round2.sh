@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything profiles/round2_* is made of, on the GPU box (about 4 minutes):
+# Everything profiles/round2_* is made of (beside tools/collect_profiles.sh), on the GPU box (about 4 minutes):
 #   gpurun --timeout 1200 -- 'bash tools/collect_round2.sh'   -> gpurun_out/round2/
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/round2
@@ -16,4 +16,6 @@ timeout -k 10 200 python tools/run_neighbors_local.py > "$O/round2_neighbors_loc
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof4a" -o c4a -- python3 "$R/tools/run_config4a.py" > "$O/prof4a.log" 2>&1; echo prof4a $?
 cp $(find "$O/prof4a" -name "*kernel_stats.csv" | head -1) "$O/round2_config4a_kernel_stats.csv"
+cd "$R" && timeout -k 10 300 python tools/px_step_time.py > "$O/round2_px_step_time.jsonl" 2> /dev/null; echo px $?
+bash "$R/tools/profile_config4a.sh" > "$O/profile_config4a.log" 2>&1; echo lds_ideal $?
 ls -la "$O"
