@@ -148,6 +148,8 @@ int fail(hmk_ctx *ctx, int code, const std::string &msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                     \
     } while (0)
 
+int greedy_streams(hmk_ctx *ctx);   // streams, events and pinned blocks of the clustering calls (defined with them below)
+
 int need_device(hmk_ctx *ctx) {
     if (!ctx->has_device)
         return fail(ctx, HMK_ERR_DEVICE,
@@ -900,6 +902,13 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
             return fail(nullptr, HMK_ERR_DEVICE, std::string("hmk_create: ") + hipGetErrorString(e));
         }
         ctx->has_device = true;
+        // What a first clustering call would otherwise pay: two HSA queues (streams), events, the pinned blocks (16-17 ms) and
+        // the deferred load of the kernels' code objects (5-10 ms).  The reference constructs its scorer before it starts the
+        // clock of "Clustering time" (Hammock.java:402-406), and a host can create the context while it still reads its input.
+        if (getenv("HMK_LAZY_CONTEXT") == nullptr) {
+            if (greedy_streams(ctx) != HMK_OK || warm_neighbors_module() != hipSuccess || warm_edges_module() != hipSuccess)
+                (void)hipGetLastError();   // not fatal here: the first call tries again and reports
+        }
     } else if (device != -1) {
         delete ctx;
         return fail(nullptr, HMK_ERR_BAD_ARG, "device must be >= 0 or -1 (host-only)");
@@ -1189,9 +1198,18 @@ constexpr int ST_RETRY_OVERFLOW = 1000;   // internal: an edge segment overflowe
 // layout of the small pinned block hmk_ctx::h_counts (64-bit words)
 enum { HC_COUNTS = 0, HC_BAND = 16, HC_PEER = 32, HC_RANGE = 64, HC_MISC = 72, HC_TOTAL = 80, HC_WORDS = 96 };
 
+// (HMK_GREEDY_TIMING: what the grow-only buffers cost a call, i.e. the first call of a context)
+static double g_alloc_ms = 0.0;
+static int g_allocs = 0;
+struct AllocTimer {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    ~AllocTimer() { g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); g_allocs++; }
+};
+
 hipError_t ensure_buf(hmk_ctx *ctx, int which, size_t bytes) {
     DevBuf &b = ctx->sb[which];
     if (b.cap >= bytes) return hipSuccess;
+    AllocTimer at;
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
@@ -1205,6 +1223,7 @@ template <class T> T *buf(hmk_ctx *ctx, int which) { return (T *)ctx->sb[which].
 // pinned host buffer, grow-only; the first `keep` bytes survive a reallocation
 hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes, size_t keep) {
     if (*cap >= bytes) return hipSuccess;
+    AllocTimer at;
     void *q = nullptr;
     const size_t want = bytes + bytes / 4 + (1 << 20);
     const hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
@@ -1230,6 +1249,18 @@ int greedy_streams(hmk_ctx *ctx) {
     HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, HC_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     // fine-grained, so that a system-scope store of a running kernel is seen by the polling host (no such block: batches + syncs)
     if (hipHostMalloc((void **)&ctx->h_loop, 64, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { ctx->h_loop = nullptr; (void)hipGetLastError(); }
+    // The first device-to-host copy of more than a few KB on a stream sets up its DMA path: 8-9 ms, measured in the middle of
+    // a first clustering call (the band's row starts).  One 64 KB copy through each stream now.
+    HIPCHK(ctx, ensure_buf(ctx, SB_DEG, 1 << 20));
+    HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, 2 * 65536, 0));
+    {   // ... and the first blocking upload from pageable memory its staging buffers (hmk_set_sequences: 8 of its 10 ms)
+        std::vector<char> pageable(1 << 20, 0);
+        HIPCHK(ctx, hipMemcpy(buf<void>(ctx, SB_DEG), pageable.data(), pageable.size(), hipMemcpyHostToDevice));
+    }
+    for (hipStream_t q : {ctx->gstream, ctx->copy_stream})
+        HIPCHK(ctx, hipMemcpyAsync((char *)ctx->h_start + (q == ctx->gstream ? 0 : 65536), buf<void>(ctx, SB_DEG), 65536, hipMemcpyDeviceToHost, q));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->gstream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     return HMK_OK;
 }
 
@@ -1318,6 +1349,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         HIPCHK(ctx, launch_csr_degree_scan(src.band_segs, n, R1, symmetric, buf<uint32_t>(ctx, SB_BDEG), buf<uint64_t>(ctx, SB_BSTART),
                                            buf<uint64_t>(ctx, SB_BSCAN), buf<int>(ctx, SB_BRANGE), C));
         HIPCHK(ctx, hipMemcpyAsync(h_start, buf<uint64_t>(ctx, SB_BSTART), ((size_t)R1 + 1) * 8, hipMemcpyDeviceToHost, C));
+
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count, HMK_EDGE_SHARDS * sizeof(unsigned long long),
                                    hipMemcpyDeviceToHost, C));
         HIPCHK(ctx, hipEventRecord(ctx->ev_bandcsr, C));
@@ -1727,11 +1759,18 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (ctx->n == 0) return HMK_OK;  // cluster() of an empty list returns an empty list
     int st = need_device(ctx);
     if (st) return st;
+    const auto t_entry = std::chrono::steady_clock::now();
+    g_alloc_ms = 0.0;
+    g_allocs = 0;
     st = greedy_streams(ctx);
     if (st) return st;
     if (!ctx->peers.empty())
         return greedy_cluster_multi(ctx, max_shift, shift_penalty, threshold, max_clusters, cluster_id, result_order, member_rank, stats);
     const auto t0 = std::chrono::steady_clock::now();
+    const bool call_timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+    auto call_lap = [&](const char *what) {
+        if (call_timing) fprintf(stderr, "[hmk greedy] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     const uint32_t n = ctx->n;
     hipStream_t S = ctx->gstream;
     // Band: phase 1 of the merge (LimitedGreedySequenceClusterer.java:77-120) reads the adjacency rows in order and
@@ -1771,6 +1810,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t)));
             ctx->d_edges_cap = cap;
         }
+        call_lap("edge buffer ready");
         const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
         src.seg_cap = seg;
         src.segs = shard_segments(ctx->d_edges, seg, ctx->d_counts);
@@ -1794,9 +1834,11 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
             HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long),
                                        hipMemcpyDeviceToDevice, S));
             HIPCHK(ctx, hipEventRecord(ctx->ev_band, S));
+            call_lap("band tiles enqueued");
         }
         st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
                                   band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, d_deg);
+        call_lap("all tiles enqueued");
         if (st) { (void)hipStreamSynchronize(S); return st; }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S));
         HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
@@ -1812,6 +1854,10 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (hipEventElapsedTime(&ms, ctx->ev_edges, ctx->ev_csr) == hipSuccess) ctx->phases.csr_ms = ms;
     ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     stats->neighbors_ms = ctx->phases.score_ms;
+    if (getenv("HMK_GREEDY_TIMING"))
+        fprintf(stderr, "[hmk greedy] call %.2f ms: streams/events/pinned block %.2f, plan %.2f, %d buffer (re)allocations %.2f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(),
+                std::chrono::duration<double, std::milli>(t0 - t_entry).count(), ctx->phases.plan_ms, g_allocs, g_alloc_ms);
     return st;
 }
 

@@ -96,5 +96,9 @@ hipError_t launch_local_block(int lbmax, bool enc, const uint8_t *res32, const u
                               uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
                               hipStream_t s);
 
+// force the deferred load of the code objects a clustering call launches from (hmk_create)
+hipError_t warm_neighbors_module();
+hipError_t warm_edges_module();
+
 }  // namespace hmk
 #endif

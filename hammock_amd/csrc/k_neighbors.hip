@@ -645,4 +645,10 @@ hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, 
     return hipGetLastError();
 }
 
+// loads this translation unit's code object (HIP defers that to the first launch: 5-10 ms of the first call otherwise)
+hipError_t warm_neighbors_module() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_neighbors_direct));
+}
+
 }  // namespace hmk

@@ -6,6 +6,7 @@
 //
 // Extra flags that the reference does not have: --device <k> (HIP ordinal, default 0) and --devices a,b,.. (several
 // GPUs of the node behind one context, the first is the root: hmk_create_multi).
+#include <future>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -182,6 +183,11 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         const std::string initialClusters = o.workingDirectory + "/initial_clusters.tsv";
         const std::string inputStatistics = o.workingDirectory + "/input_statistics.tsv";
         const std::vector<std::vector<int>> scoringMatrix = FileIOManager::loadScoringMatrix(o.matrixFile);  // :1264
+        // the GPU context (HIP start-up, queues, code objects: 70-150 ms) is created while the input is read and summarised
+        std::future<std::shared_ptr<NativeContext>> contextReady = std::async(std::launch::async, [&scoringMatrix, &o]() {
+            return o.devices.empty() ? std::make_shared<NativeContext>(scoringMatrix, o.device)
+                                     : std::make_shared<NativeContext>(scoringMatrix, o.devices);
+        });
         // ---- checkGreedyOrClinkageArgs, :1272-1277 ------------------------------------------------
         if (!(o.inputType == "fasta" || o.inputType == "seq" || o.inputType == "tab"))
             throw CLIException("Error. Parameter -f value may be either \"fasta\", \"seq\" or \"tab\". No other values are allowed");
@@ -272,15 +278,15 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
             logger.logAndStderr("Initial greedy clusters limit not set. Setting automatically to: " +
                                 std::to_string(o.initialClustersLimit));
         }
-        auto scorer = o.devices.empty()
-                          ? std::make_shared<ShiftedScorer>(scoringMatrix, o.shiftPenalty, o.maxShift, o.device)  // :402
-                          : std::make_shared<ShiftedScorer>(scoringMatrix, o.shiftPenalty, o.maxShift, o.devices);
+        auto scorer = std::make_shared<ShiftedScorer>(contextReady.get(), o.shiftPenalty, o.maxShift);  // :402 (get() rethrows a device error)
         HipGreedySequenceClusterer clusterer(scorer, o.sequenceClusteringThreshold, o.initialClustersLimit);  // :403
         HipClinkageSequenceClusterer clinkageClusterer(scorer, o.sequenceClusteringThreshold);                // :459
 
         logger.logAndStderr(clinkage ? "Clinkage clustering..." : "Greedy clustering...");
         const auto time0 = std::chrono::steady_clock::now();
         if (!clinkage) sortSequences(sequences, o.order, o.seed, labels);                       // :407 (clinkage keeps the load order)
+        if (std::getenv("HMK_CLI_TIMING"))
+            std::fprintf(stderr, "[hammock-hip] sort: %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - time0).count());
         std::vector<ClusterPtr> clusters = clinkage ? clinkageClusterer.cluster(sequences)      // :462
                                                     : clusterer.cluster(sequences);             // :409
         auto ms = [&]() {

@@ -19,6 +19,7 @@
 #ifndef HAMMOCK_HOST_HPP
 #define HAMMOCK_HOST_HPP
 
+#include <cstdlib>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -166,6 +167,8 @@ public:
 class UniqueSequence {
     std::vector<int> sequence_;
     std::vector<std::pair<std::string, int>> labels_;  // labelsMap, insertion order kept
+    std::string string_;   // getSequenceString(), kept: the comparators ask for it O(n log n) times
+    int size_ = 0;         // size(), kept up to date by the only mutator
 public:
     explicit UniqueSequence(const std::string &sequence) : UniqueSequence(sequence, {{"no_label", 1}}) {}  // :65-74
     UniqueSequence(const std::string &sequence, std::vector<std::pair<std::string, int>> labelsMap)  // :46-57
@@ -177,15 +180,13 @@ public:
                 throw FileFormatException(std::string("Error, character ") + ch +
                                           " is not a valid letter from the amino acid alphabet code.");
             sequence_.push_back((int)(f - AMINO_ACIDS));
+            string_.push_back(AMINO_ACIDS[sequence_.back()]);
         }
+        for (auto &e : labels_) size_ += e.second;
     }
-    int size() const { int s = 0; for (auto &e : labels_) s += e.second; return s; }  // :82-88
+    int size() const { return size_; }  // :82-88 (the sum of the label counts)
     const std::vector<int> &getSequence() const { return sequence_; }
-    std::string getSequenceString() const {  // :103-109
-        std::string s;
-        for (int r : sequence_) s.push_back(AMINO_ACIDS[r]);
-        return s;
-    }
+    const std::string &getSequenceString() const { return string_; }  // :103-109
     const std::vector<std::pair<std::string, int>> &getLabelsMap() const { return labels_; }
     int labelCount(const std::string &label, bool *present = nullptr) const {
         for (auto &e : labels_) if (e.first == label) { if (present) *present = true; return e.second; }
@@ -193,6 +194,7 @@ public:
         return 0;
     }
     void addLabelCount(const std::string &label, int count) {  // FileIOManager.updateLabelsMap :204-216
+        size_ += count;
         for (auto &e : labels_) if (e.first == label) { e.second += count; return; }
         labels_.push_back({label, count});
     }
@@ -245,7 +247,7 @@ class Cluster {
     int id_;
     int size_ = 0;
 public:
-    Cluster(const std::vector<UniqueSequencePtr> &sequences, int id) : sequences_(sequences), id_(id) {  // :31-41
+    Cluster(std::vector<UniqueSequencePtr> sequences, int id) : sequences_(std::move(sequences)), id_(id) {  // :31-41
         for (auto &s : sequences_) size_ += s->size();
     }
     void insert(const UniqueSequencePtr &sequence) {  // :50-63
@@ -350,6 +352,9 @@ public:
     // the same scorer with the pair space sharded over several GPUs (used by HipGreedySequenceClusterer.cluster)
     ShiftedScorer(const std::vector<std::vector<int>> &scoringMatrix, int shiftPenalty, int maxShift, const std::vector<int> &devices)
         : ctx_(std::make_shared<NativeContext>(scoringMatrix, devices)), shiftPenalty_(shiftPenalty), maxShift_(maxShift) {}
+    // over a context that already exists (a host may create it while it is still reading its input)
+    ShiftedScorer(std::shared_ptr<NativeContext> context, int shiftPenalty, int maxShift)
+        : ctx_(std::move(context)), shiftPenalty_(shiftPenalty), maxShift_(maxShift) {}
     AligningScorerResult scoreWithShift(const UniqueSequencePtr &seq1, const UniqueSequencePtr &seq2) override {  // :48-95
         ctx_->setSequences({seq1, seq2}, false);
         const uint32_t i = 0, j = 1;
@@ -398,22 +403,38 @@ public:
     // seed), then the remaining singletons; members in Cluster.getSequences() insertion order.
     std::vector<ClusterPtr> cluster(const std::vector<UniqueSequencePtr> &sequences) override {
         const auto &nc = scorer_->native();
+        const bool timing = std::getenv("HMK_CLI_TIMING") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!timing) return;
+            const auto t1 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[hammock-hip] %s: %.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            t0 = t1;
+        };
         nc->setSequences(sequences, true);
+        lap("upload");
         const size_t n = sequences.size();
         std::vector<int32_t> cid(std::max<size_t>(n, 1)), order(std::max<size_t>(n, 1)), rank(std::max<size_t>(n, 1));
         const int st = hmk_greedy_cluster(nc->get(), scorer_->getMaxShift(), scorer_->getShiftPenalty(), threshold_,
                                           maxClusters_, cid.data(), order.data(), rank.data(), &stats);
         if (st) nc->raise(st, &stats);
-        std::unordered_map<int, std::vector<std::pair<int, size_t>>> members;  // id -> (rank, index)
-        for (size_t k = 0; k < n; k++) members[cid[k]].push_back({rank[k], k});
+        lap("hmk_greedy_cluster");
+        // members of every cluster in insertion order: a cluster's id is the index of its seed (< n), ranks are 0 .. size - 1
+        std::vector<uint32_t> first(n + 1, 0);
+        for (size_t k = 0; k < n; k++) first[(size_t)cid[k] + 1]++;
+        for (size_t c = 0; c < n; c++) first[c + 1] += first[c];
+        std::vector<uint32_t> slot(n);
+        for (size_t k = 0; k < n; k++) slot[first[(size_t)cid[k]] + (size_t)rank[k]] = (uint32_t)k;
         std::vector<ClusterPtr> result;
+        result.reserve((size_t)stats.n_result_clusters);
         for (int q = 0; q < stats.n_result_clusters; q++) {
-            auto &mv = members[order[q]];
-            std::sort(mv.begin(), mv.end());
+            const size_t c = (size_t)order[q];
             std::vector<UniqueSequencePtr> seqs;
-            for (auto &e : mv) seqs.push_back(sequences[e.second]);
-            result.push_back(std::make_shared<Cluster>(seqs, order[q]));
+            seqs.reserve(first[c + 1] - first[c]);
+            for (uint32_t e = first[c]; e < first[c + 1]; e++) seqs.push_back(sequences[slot[e]]);
+            result.push_back(std::make_shared<Cluster>(std::move(seqs), order[q]));
         }
+        lap("Cluster objects");
         return result;
     }
 };
@@ -658,6 +679,36 @@ inline std::string sequenceLine(const UniqueSequence &seq, const std::vector<std
     return out;
 }
 
+// The same columns for many sequences: label -> column once, then every sequence fills its (few) labels' columns --
+// labelCount() is a linear search with string compares, 225 of them per line with 15 labels.
+class LabelColumns {
+    std::unordered_map<std::string, size_t> column_;
+    std::vector<size_t> first_;   // column k prints the count of labels[k]'s FIRST column (a label may be listed twice)
+    size_t n_;
+public:
+    explicit LabelColumns(const std::vector<std::string> &labels) : n_(labels.size()) {
+        for (size_t k = 0; k < labels.size(); k++) first_.push_back(column_.emplace(labels[k], k).first->second);
+    }
+    size_t size() const { return n_; }
+    // adds the sequence's counts to `sums` (n_ entries); labels outside the list are ignored
+    void add(const UniqueSequence &seq, std::vector<long long> &sums) const {
+        for (auto &e : seq.getLabelsMap()) {
+            auto it = column_.find(e.first);
+            if (it != column_.end()) sums[it->second] += e.second;
+        }
+    }
+    // appends "<size>\t<count of label 0>\t..." (sequenceLine) to `out`
+    void appendLine(const UniqueSequence &seq, const std::vector<std::string> &, std::vector<long long> &scratch, std::string &out) const {
+        std::fill(scratch.begin(), scratch.end(), 0);
+        add(seq, scratch);
+        out += std::to_string(seq.size());
+        for (size_t k = 0; k < n_; k++) {
+            out += CSV_SEPARATOR;
+            out += std::to_string(scratch[first_[k]]);   // a label listed twice repeats its column
+        }
+    }
+};
+
 // writeClusterSequencesToCsv, FileIOManager.java:594-638.  The `alignment` column: the reference fills
 // it from Clustal Omega output for multi-member clusters (external process, out of scope) and with the
 // bare sequence for singletons (:770-776); members of multi-member clusters get "NA" (:617-618).
@@ -676,21 +727,29 @@ inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &seq
     }
     std::ofstream w(filePath, std::ios::binary);
     if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
-    w << "cluster_id" << CSV_SEPARATOR << "sequence" << CSV_SEPARATOR << "alignment" << CSV_SEPARATOR << "sum";
-    for (const std::string &label : labels) w << CSV_SEPARATOR << label;
-    w << "\n";
+    std::string out;
+    out.reserve(sequences.size() * (48 + 4 * labels.size()) + 256);
+    out += std::string("cluster_id") + CSV_SEPARATOR + "sequence" + CSV_SEPARATOR + "alignment" + CSV_SEPARATOR + "sum";
+    for (const std::string &label : labels) { out += CSV_SEPARATOR; out += label; }
+    out += "\n";
+    const LabelColumns columns(labels);
+    std::vector<long long> scratch(labels.size());
     for (auto &seq : sequences) {
-        const std::string str = seq->getSequenceString();
+        const std::string &str = seq->getSequenceString();
         auto it = sequenceClusterMap.find(str);
         if (it != sequenceClusterMap.end()) {
-            w << it->second->getId() << CSV_SEPARATOR << str << CSV_SEPARATOR;
+            out += std::to_string(it->second->getId());
+            out += CSV_SEPARATOR; out += str; out += CSV_SEPARATOR;
             auto m = msaMap.find(str);
-            w << (m != msaMap.end() ? m->second : std::string("NA")) << CSV_SEPARATOR;
+            out += m != msaMap.end() ? m->second : std::string("NA");
+            out += CSV_SEPARATOR;
         } else {
-            w << "NA" << CSV_SEPARATOR << str << CSV_SEPARATOR << "NA" << CSV_SEPARATOR;
+            out += "NA"; out += CSV_SEPARATOR; out += str; out += CSV_SEPARATOR; out += "NA"; out += CSV_SEPARATOR;
         }
-        w << sequenceLine(*seq, labels) << "\n";
+        columns.appendLine(*seq, labels, scratch, out);
+        out += "\n";
     }
+    w.write(out.data(), (std::streamsize)out.size());
 }
 
 inline std::vector<ClusterPtr> clustersSortedDescending(const std::vector<ClusterPtr> &clusters) {
@@ -726,9 +785,13 @@ inline void SaveClustersToCsv(const std::vector<ClusterPtr> &clusters, const std
                               const std::vector<std::string> &labels) {
     std::ofstream w(filePath, std::ios::binary);
     if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
-    w << "cluster_id" << CSV_SEPARATOR << "main_sequence" << CSV_SEPARATOR << "sum";
-    for (const std::string &label : labels) w << CSV_SEPARATOR << label;
-    w << "\n";
+    std::string out = std::string("cluster_id") + CSV_SEPARATOR + "main_sequence" + CSV_SEPARATOR + "sum";
+    for (const std::string &label : labels) { out += CSV_SEPARATOR; out += label; }
+    out += "\n";
+    const LabelColumns columns(labels);
+    std::vector<long long> sums(labels.size());
+    std::vector<size_t> first_column(labels.size());   // a label listed twice repeats its column
+    for (size_t k = 0; k < labels.size(); k++) first_column[k] = (size_t)(std::find(labels.begin(), labels.end(), labels[k]) - labels.begin());
     for (auto &cl : clustersSortedDescending(clusters)) {
         auto &seqs = cl->getSequences();  // Collections.sort(sequences, reverseOrder()): UniqueSequence.compareTo :161-171
         std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
@@ -738,14 +801,14 @@ inline void SaveClustersToCsv(const std::vector<ClusterPtr> &clusters, const std
             };
             return cmp(*b, *a) < 0;
         });
-        w << cl->getId() << CSV_SEPARATOR << seqs[0]->getSequenceString() << CSV_SEPARATOR << cl->size();
-        for (const std::string &label : labels) {
-            long long c = 0;
-            for (auto &s : seqs) c += s->labelCount(label);
-            w << CSV_SEPARATOR << c;
-        }
-        w << "\n";
+        out += std::to_string(cl->getId());
+        out += CSV_SEPARATOR; out += seqs[0]->getSequenceString(); out += CSV_SEPARATOR; out += std::to_string(cl->size());
+        std::fill(sums.begin(), sums.end(), 0);
+        for (auto &s : seqs) columns.add(*s, sums);
+        for (size_t k = 0; k < labels.size(); k++) { out += CSV_SEPARATOR; out += std::to_string(sums[first_column[k]]); }
+        out += "\n";
     }
+    w.write(out.data(), (std::streamsize)out.size());
 }
 
 // saveInputStatistics, FileIOManager.java:709-729 (no newline after the last row)

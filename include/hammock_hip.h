@@ -64,7 +64,13 @@ typedef struct hmk_ctx hmk_ctx;
  * construction state (ShiftedScorer.java:28-32, LocalAlignmentScorer.java:20-24):
  * holds the matrix (Hammock.scoringMatrix, Hammock.java:46,1264) on `device`.
  * device >= 0: HIP device ordinal.  device == -1: host-only context (only the
- * host-side calls hmk_greedy_from_edges / hmk_set_sequences work). */
+ * host-side calls hmk_greedy_from_edges / hmk_set_sequences work).
+ * The context comes warm: its streams, events, pinned blocks, the DMA paths of
+ * both directions and the kernels' code objects are set up here (25-35 ms after
+ * HIP itself has started), not inside the first clustering call -- the reference
+ * constructs its scorer before it starts the clock of "Clustering time"
+ * (Hammock.java:402-406), and a host may create the context on another thread
+ * while it reads its input (hammock_cli.cpp does).  HMK_LAZY_CONTEXT=1 defers. */
 int hmk_create(const int32_t matrix[HMK_ALPHABET * HMK_ALPHABET], int device, hmk_ctx **ctx);
 /* The same on several GPUs of one node (BASELINE config 5: "pair-space sharded 8 x MI355X over xGMI"): devices[0] is the
  * root.  hmk_set_sequences uploads to every device; hmk_greedy_cluster scores shard d of n_devices on device d (row
