@@ -267,7 +267,7 @@ def main():
             # the BINDING roofline first (LDS gather, not HBM): bytes the kernel must read from LDS
             "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                          "frac": lds_gbs / LDS_PEAK_GBS, "traffic": pmc_traffic(n, world),
-                         "kernel": "k_neighbors_swar<2, 6, 2, 12, true, false> (NW=2 dwords/entry, 6 rows/tile, 2 columns/lane, length 12 exact)",
+                         "kernel": "k_neighbors_swar<2, 6, 2, 12, true, 0> (NW=2 dwords/entry, 6 rows/tile, 2 columns/lane, length 12 exact)",
                          "kernel_ms": kern_ms,
                          "definition": f"{LDS_BYTES_PER_PAIR} LDS bytes per pair ({SEQ_LEN} ds_read_b64 table lookups) x pairs per launch / "
                                        "kernel time, against 256 B/clk/CU x 256 CU x 2.4 GHz (MI355X_MICROARCH.md, LDS table)",

@@ -39,7 +39,7 @@ enum {
     SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
-    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
+    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RANK, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
     SB_PEER, SB_PEERCNT,                                                                  // edge blocks gathered from other devices
     SB_N
 };
@@ -506,7 +506,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
 enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2 };
 int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
                          uint64_t capacity, void *d_counts, hipStream_t stream, int which = LAUNCH_ALL,
-                         int64_t band_rows = -1, uint32_t *d_deg = nullptr) {
+                         int64_t band_rows = -1, uint32_t *d_deg = nullptr, uint32_t *d_deg_lo = nullptr, uint32_t *d_rank = nullptr) {
     int st = need_device(ctx);
     if (st) return st;
     if (!d_edges || !d_counts || capacity < HMK_EDGE_SHARDS)
@@ -529,7 +529,10 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     P.n_tiles = pl.stats.n_tiles;
     P.lpad = (uint32_t)pl.lpad;
     P.symmetric = ctx->symmetric ? 1u : 0u;
-    P.deg = d_deg;
+    P.deg = d_rank ? nullptr : d_deg;
+    P.deg_up = d_rank ? d_deg : nullptr;
+    P.deg_lo = d_deg_lo;
+    P.rank = d_rank;
     // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has a dozen of
     // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
     // start, and join back into `stream`.
@@ -1278,7 +1281,10 @@ struct EdgeSource {
     uint64_t total_known = 0;          // exact number of edges, if known (else 0)
     uint32_t band_rows = 0;            // rows [0, band_rows) are complete in band_segs once ev_band has passed
     EdgeSegs band_segs{};
-    bool deg_fused = false;            // SB_DEG / SB_UP were filled by the neighbour kernel itself (zeroed before the pass)
+    bool deg_fused = false;            // the neighbour kernel placed the edges itself: SB_CURSOR holds the rows' upper | lower counters
+                                       // (zeroed before the pass), SB_RANK every edge's ranks (parallel to the buffer at edges0)
+    const uint64_t *edges0 = nullptr;
+    bool placed = false;               // deg_fused with ranks (else deg_fused = SB_DEG holds the rows' total degrees, counted by the pass)
     hmk_clinkage_stats *clink = nullptr;   // non-null: run the clinkage nearest-neighbour chain instead of the greedy merge
 };
 
@@ -1312,11 +1318,15 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     uint32_t *h_up = (uint32_t *)((char *)ctx->h_start + ((size_t)n + 1) * 8);
     int *h_range = (int *)(ctx->h_counts + HC_RANGE);
 
-    HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S));
-    if (src.deg_fused) {
-        HIPCHK(ctx, launch_csr_scan_only(buf<uint32_t>(ctx, SB_DEG), buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN),
+    if (src.deg_fused && src.placed) {
+        HIPCHK(ctx, launch_csr_scan_only(buf<uint32_t>(ctx, SB_CURSOR), symmetric ? buf<uint32_t>(ctx, SB_CURSOR) + n : nullptr,
+                                         buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S));
+    } else if (src.deg_fused) {
+        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S));
+        HIPCHK(ctx, launch_csr_scan_only(buf<uint32_t>(ctx, SB_DEG), nullptr, buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN),
                                          buf<int>(ctx, SB_RANGE), S));
     } else {
+        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S));
         HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_DEG), 0, (size_t)n * 4, S));
         HIPCHK(ctx, launch_csr_degree_scan(src.segs, n, n, symmetric, buf<uint32_t>(ctx, SB_DEG), buf<uint64_t>(ctx, SB_START),
                                            buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S));
@@ -1326,8 +1336,11 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     bool scatter_enqueued = false;
     auto enqueue_scatter = [&]() -> hipError_t {
         scatter_enqueued = true;
-        hipError_t e = launch_csr_scatter(src.segs, symmetric, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR),
-                                          buf<void>(ctx, SB_ADJ), packed, base, n, S);
+        hipError_t e = src.deg_fused && src.placed
+                           ? launch_csr_scatter_ranked(src.segs, src.edges0, buf<uint32_t>(ctx, SB_RANK), symmetric, buf<uint64_t>(ctx, SB_START),
+                                                       buf<void>(ctx, SB_ADJ), packed, base, S)
+                           : launch_csr_scatter(src.segs, symmetric, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR),
+                                                buf<void>(ctx, SB_ADJ), packed, base, n, S);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
         return e;
     };
@@ -1817,19 +1830,33 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         src.adj_bound = (ctx->symmetric ? 2 : 1) * ctx->d_edges_cap;
         src.band_rows = (uint32_t)band_rows;
         src.band_segs = shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS));
-        // the CSR's degree counters are filled by the neighbour kernel as it writes the edges
+        // the neighbour kernel places every edge in the CSR as it writes it: per row an upper and a lower counter (they end
+        // up as the sizes of the row's two sections; the upper ones ARE up[]) and, beside the edge, its two ranks
         const bool fuse = getenv("HMK_NO_FUSED_DEGREE") == nullptr;
-        uint32_t *d_deg = nullptr;
-        if (fuse) {
+        // (placing: 10^5 CSR 0.89 -> 0.42 ms, 3 x 10^5 6.0 -> 3.7 ms; at 10^6 the pass loses 35 ms to the returning atomics and
+        // the scatter, bound by its random writes there, gains nothing: then the pass only counts the degrees)
+        bool place = fuse && n <= 500000;
+        if (const char *v = getenv("HMK_PLACE_EDGES")) place = fuse && atoi(v) != 0;
+        uint32_t *d_deg = nullptr, *d_deg_lo = nullptr, *d_rank = nullptr;
+        if (place) {
+            HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
+            HIPCHK(ctx, ensure_buf(ctx, SB_RANK, ctx->d_edges_cap * 8));
+            d_deg = buf<uint32_t>(ctx, SB_CURSOR);
+            d_deg_lo = ctx->symmetric ? d_deg + n : nullptr;
+            d_rank = buf<uint32_t>(ctx, SB_RANK);
+            HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * 8, S));
+        } else if (fuse) {
             HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
             d_deg = buf<uint32_t>(ctx, SB_DEG);
             HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * 4, S));
         }
         src.deg_fused = fuse;
+        src.placed = place;
+        src.edges0 = ctx->d_edges;
         HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
         if (band_rows > 0) {
             st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                      LAUNCH_BAND, band_req, d_deg);
+                                      LAUNCH_BAND, band_req, d_deg, d_deg_lo, d_rank);
             if (st) return st;
             HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long),
                                        hipMemcpyDeviceToDevice, S));
@@ -1837,7 +1864,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
             call_lap("band tiles enqueued");
         }
         st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, d_deg);
+                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, d_deg, d_deg_lo, d_rank);
         call_lap("all tiles enqueued");
         if (st) { (void)hipStreamSynchronize(S); return st; }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S));

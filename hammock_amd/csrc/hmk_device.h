@@ -121,6 +121,24 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// The CSR place of a stored edge (NeighborParams::deg): its rank in row x's upper section and in row m's lower one.  Only
+// STORED edges are placed: an edge dropped by a segment overflow must not be counted, or the CSR sized from the counters
+// (its scatter is enqueued before the host notices the overflow) would expect entries that are not there.
+enum { EDGES_PLAIN = 0, EDGES_RUNTIME = 1, EDGES_COUNT = 2, EDGES_PLACE = 3 };   // what a flush does beside storing the edge
+template <int MODE = EDGES_RUNTIME>
+__device__ __forceinline__ void place_edge(const NeighborParams &P, unsigned long long slot, uint32_t x, uint32_t m) {
+    if (MODE == EDGES_PLACE || (MODE == EDGES_RUNTIME && P.rank)) {   // (run time: wave-uniform)
+        // (deg_up, not deg: with one pointer for both modes the compiler hoists the first atomic out of the branch as a
+        // RETURNING one, and the counting mode then waits for it at the top of the next record -- +10 % on the 10^6 pass)
+        const uint32_t rx = atomicAdd(&P.deg_up[x], 1u);
+        const uint32_t rm = P.symmetric ? atomicAdd(&P.deg_lo[m], 1u) : 0u;
+        reinterpret_cast<uint2 *>(P.rank)[slot] = make_uint2(rx, rm);
+    } else if (MODE == EDGES_COUNT || (MODE == EDGES_RUNTIME && P.deg)) {   // counting only (deg = the rows' total degrees): fire-and-forget atomics
+        atomicAdd(&P.deg[x], 1u);
+        if (P.symmetric) atomicAdd(&P.deg[m], 1u);
+    }
+}
+
 // Drains one wave's staged records to its output segment.  REC_DW dwords per
 // record: [0] column (sorted position), [1] row within the tile, [2..] the NW
 // accumulator dwords (SWAR) or the score itself (direct, NW == 0).
@@ -167,10 +185,7 @@ __device__ __forceinline__ void flush_stage(const HMK_LDS uint32_t *stage, uint3
             // degrees of STORED edges only: an edge dropped by a segment overflow must not be counted, or the CSR built
             // from the counters (its scatter is enqueued before the host notices the overflow) would be sized for edges that
             // are not there and overrun the adjacency buffer
-            if (DEG && P.deg) {   // wave-uniform; fire-and-forget atomics on the rare path
-                atomicAdd(&P.deg[x], 1u);
-                if (P.symmetric) atomicAdd(&P.deg[m], 1u);
-            }
+            if (DEG && (P.deg || P.rank)) place_edge<EDGES_RUNTIME>(P, (unsigned long long)shard * P.cap_per_shard + pos, x, m);   // wave-uniform test; stored edges only
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
@@ -181,7 +196,7 @@ __device__ __forceinline__ void flush_stage(const HMK_LDS uint32_t *stage, uint3
 // tile has at most 65,536 columns and 16 rows, so the record is exact; staging it is a ds_write_b32 (2 LDS-array cycles per
 // wave-instruction) where the 16-byte {column, row, accumulators} record was a ds_write_b128 (8): with a hit in ~15 % of the
 // wave iterations that was 5 % of the kernel's LDS cycles (SQ_LDS_IDX_ACTIVE against 2 x the lookups).
-template <bool DEG>
+template <int MODE>
 __device__ __forceinline__ void flush_stage_compact(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
                                                     const Tile &T, int threshold, uint32_t shard) {
     if (cnt == 0) return;
@@ -202,10 +217,7 @@ __device__ __forceinline__ void flush_stage_compact(const HMK_LDS uint32_t *stag
         if (pos < P.cap_per_shard) {
             P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
                 ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
-            if (DEG && P.deg) {   // stored edges only, see flush_stage
-                atomicAdd(&P.deg[x], 1u);
-                if (P.symmetric) atomicAdd(&P.deg[m], 1u);
-            }
+            if (MODE != EDGES_PLAIN) place_edge<MODE>(P, (unsigned long long)shard * P.cap_per_shard + pos, x, m);   // stored edges only
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
@@ -235,10 +247,7 @@ __device__ __forceinline__ void flush_stage_packed(const HMK_LDS uint32_t *stage
         if (pos < P.cap_per_shard) {
             P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
                 ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
-            if (DEG && P.deg) {   // stored edges only, see flush_stage
-                atomicAdd(&P.deg[x], 1u);
-                if (P.symmetric) atomicAdd(&P.deg[m], 1u);
-            }
+            if (DEG && (P.deg || P.rank)) place_edge<EDGES_RUNTIME>(P, (unsigned long long)shard * P.cap_per_shard + pos, x, m);   // wave-uniform test; stored edges only
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused

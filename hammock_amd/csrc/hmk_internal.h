@@ -55,9 +55,17 @@ struct NeighborParams {
     uint32_t symmetric;          // 1: emit (min, max) caller indices
     uint32_t row_is_m;           // 1: the tile's ROW is seq1 (= m of the edge), LocalAlignmentScorer tiles
     uint32_t perm_identity;      // 1: sorted position == caller index (one length bucket, no reordering): skip the perm loads
-    // optional (may be null): per-sequence degree counters of the CSR the greedy tail builds from these edges, counted
-    // while the edges are written (zeroed uint32[n]; symmetric: both ends of an edge) -- saves a pass over the edge list
-    uint32_t *deg;
+    // optional (may be null): the CSR the greedy tail builds from these edges is PLACED while the edges are written.
+    // deg_up[x] counts row x's "upper" entries (symmetric: the neighbours with a larger index; else all of them), deg_lo[m]
+    // row m's lower ones (symmetric only); both zeroed uint32[n].  The value an edge's atomicAdd returns is its place inside
+    // the row's section: rank[2 * slot] / rank[2 * slot + 1] for the edge stored in slot = segment * cap_per_shard +
+    // position.  The scatter that follows needs no atomics and no pass that counts degrees.  rank == null: deg[] just counts
+    // the rows' total degrees (both ends of a symmetric edge), with fire-and-forget atomics -- at 10^6 the 2.5 x 10^9 returning
+    // atomics cost the pass 10 % and the scatter there is bound by its random writes, not by its atomics.
+    uint32_t *deg;       // counting mode: total degrees
+    uint32_t *deg_up;    // placing mode: the rows' upper counters ...
+    uint32_t *deg_lo;    // ... and lower counters (symmetric only)
+    uint32_t *rank;      // placing mode (else null)
 };
 
 // one directed neighbour: sequenceScore(seq1 = m, seq2 = x) = s for the row x it is stored under

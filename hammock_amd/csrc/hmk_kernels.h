@@ -40,8 +40,10 @@ hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile
 EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts);
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
                                   uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s);
-hipError_t launch_csr_scan_only(const uint32_t *deg, uint64_t *start, uint32_t n, uint64_t *tile_scratch, int *score_range,
-                                hipStream_t s);   // deg[] already counted by the neighbour kernel (NeighborParams::deg)
+hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uint64_t *start, uint32_t n, uint64_t *tile_scratch,
+                                int *score_range, hipStream_t s);
+hipError_t launch_csr_scatter_ranked(const EdgeSegs &segs, const uint64_t *edges0, const uint32_t *rank, bool symmetric,
+                                     const uint64_t *start, void *adj, bool packed, int base, hipStream_t s);   // deg[] already counted by the neighbour kernel (NeighborParams::deg)
 size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
 size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)

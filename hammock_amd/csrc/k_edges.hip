@@ -61,13 +61,14 @@ __global__ void k_init_range(int *__restrict__ score_range) {
 // tile sums, scan of the tile sums (one block), tile-local scan + offset.  T = uint32 or uint64.
 constexpr uint32_t SCAN_TILE = 2048;
 
-__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *__restrict__ deg, uint64_t *__restrict__ tile_sum, uint32_t n) {
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *__restrict__ deg, const uint32_t *__restrict__ deg_b,
+                                                        uint64_t *__restrict__ tile_sum, uint32_t n) {   // deg_b (may be null): a second addend per row
     __shared__ uint64_t red[4];
     const uint32_t base = blockIdx.x * SCAN_TILE;
     uint64_t v = 0;
     for (uint32_t j = 0; j < SCAN_TILE / 256; j++) {
         const uint32_t k = base + j * 256 + threadIdx.x;
-        if (k < n) v += deg[k];
+        if (k < n) v += (uint64_t)deg[k] + (deg_b ? deg_b[k] : 0u);
     }
     for (int o = 32; o; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -100,14 +101,14 @@ __global__ void __launch_bounds__(256) k_scan_tile_offsets(uint64_t *__restrict_
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_scan_tiles(const uint32_t *__restrict__ deg, const uint64_t *__restrict__ tile_off, T *__restrict__ start, uint32_t n,
-             uint32_t n_tiles, const uint32_t *__restrict__ tail_word) {
+k_scan_tiles(const uint32_t *__restrict__ deg, const uint32_t *__restrict__ deg_b, const uint64_t *__restrict__ tile_off,
+             T *__restrict__ start, uint32_t n, uint32_t n_tiles, const uint32_t *__restrict__ tail_word) {
     __shared__ T v[SCAN_TILE];   // the tile-local prefix is as wide as the result: 2048 degrees of up to 2^24 pass 2^32
     __shared__ T wsum[4];
     const uint32_t base = blockIdx.x * SCAN_TILE, tid = threadIdx.x;
     for (uint32_t j = 0; j < SCAN_TILE / 256; j++) {  // coalesced load
         const uint32_t k = base + j * 256 + tid;
-        v[j * 256 + tid] = k < n ? deg[k] : 0;
+        v[j * 256 + tid] = k < n ? (T)deg[k] + (T)(deg_b ? deg_b[k] : 0u) : 0;
     }
     __syncthreads();
     T loc[SCAN_TILE / 256], sum = 0;                  // thread tid owns the 8 consecutive counters tid * 8 ..
@@ -140,11 +141,11 @@ k_scan_tiles(const uint32_t *__restrict__ deg, const uint64_t *__restrict__ tile
 // tile_scratch: uint64[ceil(n / SCAN_TILE) + 1]
 template <typename T>
 static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *tile_scratch, const uint32_t *tail_word,
-                        hipStream_t s) {
+                        hipStream_t s, const uint32_t *deg_b = nullptr) {
     const uint32_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, deg, tile_scratch, n);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(n_tiles), dim3(256), 0, s, deg, deg_b, tile_scratch, n);
     hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(256), 0, s, tile_scratch, n_tiles);
-    hipLaunchKernelGGL((k_scan_tiles<T>), dim3(n_tiles), dim3(256), 0, s, deg, tile_scratch, start, n, n_tiles, tail_word);
+    hipLaunchKernelGGL((k_scan_tiles<T>), dim3(n_tiles), dim3(256), 0, s, deg, deg_b, tile_scratch, start, n, n_tiles, tail_word);
 }
 
 // NbrT = Nbr: {m, score}.  NbrT = NbrPacked: m << 8 | (score - base), the caller has checked the score range.
@@ -181,6 +182,35 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t
         } else {
             if (vx) adj[start[x] + basex + g.rank] = NbrT{m, s};
             if (vm) adj[start[m + 1] - 1 - atomicAdd(&cursor[row_limit + m], 1u)] = NbrT{x, s};
+        }
+    }
+}
+
+// The same CSR from edges that were PLACED while they were written (NeighborParams::rank: every edge's rank inside its
+// two row sections): no atomics -- with one returning atomic per edge the scatter above takes 0.83 ms for the 1.28 x 10^7
+// edges of the 10^5 pass and 63 ms at 10^6.  up[] = the rows' upper counters (NeighborParams::deg), already complete.
+// The score range goes to score_range (the packed format is chosen beforehand here; the range is only checked).
+template <class NbrT>
+__global__ void __launch_bounds__(256)
+k_edge_scatter_ranked(const EdgeSegs segs, const uint64_t *__restrict__ edges0, const uint2 *__restrict__ rank,
+                      const uint64_t *__restrict__ start, NbrT *__restrict__ adj, int symmetric, int base) {
+    const EdgeSeg sg = segs.s[blockIdx.y];
+    const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
+    const uint64_t *seg = sg.edges;
+    const uint2 *rk = rank + (sg.edges - edges0);
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256) {
+        const uint64_t e = seg[k];
+        const uint2 r = rk[k];
+        const uint32_t x = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
+        const uint32_t m = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
+        const int32_t s = HMK_EDGE_SCORE(e);
+        if constexpr (sizeof(NbrT) == 4) {
+            const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
+            adj[start[x] + r.x] = NbrT{(m << 8) | rel};
+            if (symmetric) adj[start[m + 1] - 1 - r.y] = NbrT{(x << 8) | rel};
+        } else {
+            adj[start[x] + r.x] = NbrT{m, s};
+            if (symmetric) adj[start[m + 1] - 1 - r.y] = NbrT{x, s};
         }
     }
 }
@@ -777,10 +807,23 @@ hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row
 }
 
 // the degrees were counted while the edges were written (NeighborParams::deg): only the scan remains
-hipError_t launch_csr_scan_only(const uint32_t *deg, uint64_t *start, uint32_t n, uint64_t *tile_scratch, int *score_range,
-                                hipStream_t s) {
+hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uint64_t *start, uint32_t n, uint64_t *tile_scratch,
+                                int *score_range, hipStream_t s) {
     hipLaunchKernelGGL(k_init_range, dim3(1), dim3(64), 0, s, score_range);
-    launch_scan<uint64_t>(deg, start, n, tile_scratch, nullptr, s);
+    launch_scan<uint64_t>(deg, start, n, tile_scratch, nullptr, s, deg_lo);
+    return hipGetLastError();
+}
+
+// rank: the uint32 pairs the neighbour pass wrote beside the edges at edges0 (all segments lie inside that buffer)
+hipError_t launch_csr_scatter_ranked(const EdgeSegs &segs, const uint64_t *edges0, const uint32_t *rank, bool symmetric,
+                                     const uint64_t *start, void *adj, bool packed, int base, hipStream_t s) {
+    const uint2 *rk = reinterpret_cast<const uint2 *>(rank);
+    if (packed)
+        hipLaunchKernelGGL((k_edge_scatter_ranked<NbrPacked>), dim3(512, segs.n), dim3(256), 0, s, segs, edges0, rk, start, (NbrPacked *)adj,
+                           symmetric ? 1 : 0, base);
+    else
+        hipLaunchKernelGGL((k_edge_scatter_ranked<Nbr>), dim3(512, segs.n), dim3(256), 0, s, segs, edges0, rk, start, (Nbr *)adj,
+                           symmetric ? 1 : 0, base);
     return hipGetLastError();
 }
 

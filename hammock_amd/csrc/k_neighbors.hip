@@ -25,7 +25,7 @@ namespace hmk {
 //   stage   4 waves * STAGE_CAP records  hits waiting to be written out
 // DEG: also count the CSR degrees while writing edges (NeighborParams::deg, hmk_greedy_cluster); the plain neighbour pass
 // is its own instantiation so that it keeps its spill-free 72-VGPR allocation.
-template <int NW, int R, int CPL, int LBMAX, bool EXACT, bool DEG>
+template <int NW, int R, int CPL, int LBMAX, bool EXACT, int DEG>   // DEG: EDGES_PLAIN / EDGES_COUNT / EDGES_PLACE (hmk_device.h)
 // The production tiling (R = 6, CPL = 2) is held to 72 VGPRs = 7 waves/SIMD, which is also what its 22.6 KB of
 // LDS allow per CU (80 VGPRs / 6 waves otherwise): +2.4 % measured.
 __global__ void __launch_bounds__(256, (R >= 5 && R <= 7 && CPL == 2) ? 7 : 1)
@@ -579,10 +579,12 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
 // -----------------------------------------------------------------------------
 template <int NW, int R, int CPL, int LBMAX, bool EXACT>
 static hipError_t launch_swar_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
-    if (P.deg)
-        hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, true>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+    if (P.rank)
+        hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, EDGES_PLACE>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+    else if (P.deg)
+        hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, EDGES_COUNT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
     else
-        hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, false>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+        hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, EDGES_PLAIN>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
     return hipGetLastError();
 }
 

@@ -521,6 +521,31 @@ def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
             assert int(sc.max()) - int(sc.min()) > 255   # the wide form was really needed
 
 
+@pytest.mark.parametrize("env", [{"HMK_PLACE_EDGES": "1"}, {"HMK_PLACE_EDGES": "0"}, {"HMK_NO_FUSED_DEGREE": "1"},
+                                 {"HMK_PLACE_EDGES": "1", "HMK_ADJ_8BYTE": "1"}, {"HMK_PLACE_EDGES": "1", "HMK_NO_BAND": "1"}])
+@pytest.mark.parametrize("cfg", [(21, 24000, 12, 12, 0, True), (22, 9000, 7, 20, -1, True), (23, 6000, 12, 12, 0, False)])
+def test_greedy_csr_construction_modes(gpu, blosum62, coracle, monkeypatch, env, cfg):
+    """Three ways to the same CSR: the neighbour pass places every edge as it writes it (two rank counters per row,
+    ranks stored beside the edges, atomic-free scatter; default up to 5 x 10^5 sequences), it only counts the degrees
+    (fire-and-forget; the scatter takes its places with atomics), or a separate pass counts them.  Uniform and mixed
+    lengths (both flush routines), a symmetric and an asymmetric matrix (one section per row), 4- and 8-byte entries."""
+    seed, n, lo, hi, p, symmetric = cfg
+    M = blosum62.copy()
+    if not symmetric:
+        M[3, 7] += 1
+    res, off = synth_peptides(seed, n, lo, hi)
+    L = np.diff(off.astype(np.int64))
+    thr, X, maxc = po.java_round(L.mean() * 1.7) - 1, min(po.java_round(L.mean() / 4), int(L.min()) - 1), po.java_round(n * 0.025)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(M, res, off, None, 0, X, p, thr, maxc, 16)
+    assert st == 0
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    ctx, _, _ = ctx_for(M, res=res, off=off)
+    cid, order, stats = ctx.greedy_cluster(X, p, thr, maxc)
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+
+
 def test_greedy_antibodies_example_vs_oracle(gpu, blosum62, coracle, tmp_path):
     """The reference's own large example (examples/antibodies: 88,544 FASTA records, 74,041 unique 12-mers,
     counts and 15 labels in the headers; real phage-display data with heavy near-duplicate families, unlike

@@ -15,7 +15,7 @@ import shutil
 import sys
 
 out, rnd = sys.argv[1], sys.argv[2]
-HOT = "k_neighbors_swar<2, 6, 2, 12, true, false>"
+HOT = "k_neighbors_swar<2, 6, 2, 12, true, 0>"
 
 
 def find(pattern):
