@@ -39,7 +39,7 @@ enum {
     SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
-    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RANK, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
+    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RANK, SB_RETRY, SB_PRECNT, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
     SB_PEER, SB_PEERCNT,                                                                  // edge blocks gathered from other devices
     SB_N
 };
@@ -118,6 +118,8 @@ struct hmk_ctx {
     DevBuf sb[SB_N];
     void *h_start = nullptr;  // pinned: uint64 start[n + 1], then uint32 up[n]
     size_t h_start_cap = 0;
+    void *h_stage = nullptr;  // pinned: what the merge uploads after phase 1 (cluster_of, sizes, leftovers, ...)
+    size_t h_stage_cap = 0;
     void *h_adj = nullptr;    // pinned: adjacency rows fetched so far
     size_t h_adj_cap = 0;
     unsigned long long *h_loop = nullptr;    // pinned, coherent: progress word of the device-side second loop (written by k_loop_apply)
@@ -941,6 +943,7 @@ void hmk_destroy(hmk_ctx *ctx) {
         }
         if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
         if (ctx->h_start) (void)hipHostFree(ctx->h_start);
+        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
         if (ctx->h_adj) (void)hipHostFree(ctx->h_adj);
         if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
         if (ctx->h_loop) (void)hipHostFree(ctx->h_loop);
@@ -1466,11 +1469,15 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     // (1) pre-check (k_greedy_precheck): per leftover the clusters that are feasible after phase 1 -> cand CSR on the device.
     // Then either (2a) small / medium inputs: join-propagation lists (k_greedy_prop), the sequential loop runs on the
     // host over those lists; or (2b) large inputs: the loop itself runs on the device level by level (k_greedy_level).
-    bool pre_done = false;
+    // pre_mode: 0 nothing yet, 1 = two passes done (cand_start[] are prefix sums: what the host-side consumers read),
+    // 2 = one pass done (every leftover's block lies where the global counter put it: the device loop takes either)
+    int pre_mode = 0;
     uint32_t pre_total_c = 0;
-    auto device_precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<uint32_t> &leftover) -> bool {
-        if (pre_done) return true;
+    auto device_precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<uint32_t> &leftover,
+                               bool single_pass) -> bool {
+        if (pre_mode == 1 || (pre_mode == 2 && single_pass)) return true;
         if (getenv("HMK_HOST_PRECHECK")) return false;
+        if (getenv("HMK_PRECHECK_TWO_PASSES")) single_pass = false;
         if (!wait_full()) return false;
         const auto tp = std::chrono::steady_clock::now();
         const uint32_t nl = (uint32_t)leftover.size();
@@ -1485,20 +1492,73 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r != hipSuccess) return false;
         int32_t *d_cof = buf<int32_t>(ctx, SB_COF), *d_usize = buf<int32_t>(ctx, SB_USIZE);
         uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cnt = buf<uint32_t>(ctx, SB_CNT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
-        uint32_t *d_over = buf<uint32_t>(ctx, SB_OVER);
+        uint32_t *d_over = buf<uint32_t>(ctx, SB_OVER);                      // [0] table overflows, [2..3] the single pass's entry counter
+        unsigned long long *d_total = (unsigned long long *)(d_over + 2);
         uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
         const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
         const void *d_adj = buf<void>(ctx, SB_ADJ);
-        r = hipMemcpyAsync(d_cof, cluster_of, (size_t)n * 4, hipMemcpyHostToDevice, S);
-        if (r == hipSuccess) r = launch_cluster_bitmap(d_cof, n, buf<uint32_t>(ctx, SB_BITMAP), S);
-        if (r == hipSuccess) r = hipMemcpyAsync(d_usize, usize.data(), usize.size() * 4, hipMemcpyHostToDevice, S);
-        if (r == hipSuccess) r = hipMemcpyAsync(d_left, leftover.data(), (size_t)nl * 4, hipMemcpyHostToDevice, S);
-        if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 4, S);
-        if (r == hipSuccess) r = hipMemsetAsync(d_cnt, 0, (size_t)nl * 4, S);
-        if (r == hipSuccess) r = launch_greedy_precheck(false, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
-                                                        d_cnt, nullptr, nullptr, d_over, S);
-        if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, S);
         uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
+        if (pre_mode == 0) {
+            // through a pinned block: an "async" upload from pageable memory is staged by the runtime chunk by chunk and the
+            // stream waits for it (0.3 ms for these 0.8 MB at 10^5, seen as the pre-check kernel starting late)
+            const size_t b_cof = (size_t)n * 4, b_us = usize.size() * 4, b_left = (size_t)nl * 4;
+            r = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + b_cof + b_us + b_left + 64, 0);
+            if (r != hipSuccess) return false;
+            char *hs = (char *)ctx->h_stage + HMK_PRE_REGIONS * sizeof(unsigned long long);   // (the block starts with the single pass's region counters)
+            std::memcpy(hs, cluster_of, b_cof);
+            std::memcpy(hs + b_cof, usize.data(), b_us);
+            std::memcpy(hs + b_cof + b_us, leftover.data(), b_left);
+            r = hipMemcpyAsync(d_cof, hs, b_cof, hipMemcpyHostToDevice, S);
+            if (r == hipSuccess) r = launch_cluster_bitmap(d_cof, n, buf<uint32_t>(ctx, SB_BITMAP), S);
+            if (r == hipSuccess && b_us) r = hipMemcpyAsync(d_usize, hs + b_cof, b_us, hipMemcpyHostToDevice, S);
+            if (r == hipSuccess && b_left) r = hipMemcpyAsync(d_left, hs + b_cof + b_us, b_left, hipMemcpyHostToDevice, S);
+        }
+        if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 16, S);
+        if (r == hipSuccess && single_pass) {
+            // One pass: every wave takes its block of entries from the counter of its workgroup's region of the buffer.  The
+            // buffer is sized from what previous calls needed (or 24 entries per leftover); a call that overruns a region falls
+            // back to the two passes below.
+            const size_t want = std::max<size_t>({ctx->sb[SB_CAND].cap / sizeof(GreedyCand), (size_t)nl * 24, (size_t)HMK_PRE_REGIONS * 64});
+            const unsigned long long region_cap = std::min<unsigned long long>(want, 0xFFFFFFFFull) / HMK_PRE_REGIONS;
+            r = ensure_buf(ctx, SB_CAND, (size_t)region_cap * HMK_PRE_REGIONS * sizeof(GreedyCand));
+            if (r == hipSuccess) r = ensure_buf(ctx, SB_PRECNT, HMK_PRE_REGIONS * sizeof(unsigned long long));
+            unsigned long long *d_regions = buf<unsigned long long>(ctx, SB_PRECNT);
+            if (r == hipSuccess) r = hipMemsetAsync(d_regions, 0, HMK_PRE_REGIONS * sizeof(unsigned long long), S);
+            // rows with few neighbours inside clusters (the estimate: average degree x the clustered share of the sequences) go
+            // through small tables first
+            size_t in_clusters = 0;
+            for (int32_t u : usize) in_clusters += (size_t)u;
+            const double est = (double)h_start[n] / std::max<uint32_t>(n, 1) * (double)in_clusters / std::max<uint32_t>(n, 1);
+            uint32_t *d_retry = nullptr;
+            const int first_slots = est <= 24.0 ? 128 : 512;   // ~5 x the expected number of distinct clusters in a row
+            if (r == hipSuccess && est <= 100.0 && getenv("HMK_PRECHECK_ONE_STAGE") == nullptr) {
+                r = ensure_buf(ctx, SB_RETRY, std::max<size_t>(nl, 1) * 4);
+                d_retry = buf<uint32_t>(ctx, SB_RETRY);
+            }
+            if (r == hipSuccess) r = launch_greedy_precheck(2, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
+                                                            d_cnt, d_cstart, buf<GreedyCand>(ctx, SB_CAND), d_over, d_regions, region_cap,
+                                                            d_retry, d_over + 1, first_slots, S);
+            unsigned long long *h_regions = (unsigned long long *)ctx->h_stage;   // (sized with the uploads above: pre_mode is 0 here)
+            if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, S);
+            if (r == hipSuccess) r = hipMemcpyAsync(h_regions, d_regions, HMK_PRE_REGIONS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S);
+            if (r == hipSuccess) r = hipStreamSynchronize(S);
+            if (r != hipSuccess || h_misc[0] != 0) return false;   // a row overflowed its hash table: host pre-check
+            unsigned long long total = 0;
+            bool fits = true;
+            for (uint32_t g = 0; g < HMK_PRE_REGIONS; g++) { total += h_regions[g]; fits = fits && h_regions[g] <= region_cap; }
+            if (fits) {
+                pre_total_c = (uint32_t)total;
+                pre_mode = 2;
+                ph.cand_entries = pre_total_c;
+                ph.precheck_ms = ms_since(tp);
+                return true;
+            }
+            if (total > 0xFFFFFFFFull) return false;
+            r = hipMemsetAsync(d_over, 0, 16, S);   // more entries than a region holds: count, size, fill
+        }
+        if (r == hipSuccess) r = launch_greedy_precheck(0, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
+                                                        d_cnt, nullptr, nullptr, d_over, d_total, 0, nullptr, nullptr, 0, S);
+        if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, S);
         if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, S);
         if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[1], d_cstart + nl, 4, hipMemcpyDeviceToHost, S);
         if (r == hipSuccess) r = hipStreamSynchronize(S);
@@ -1506,11 +1566,11 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         pre_total_c = h_misc[1];
         if (pre_total_c) {
             r = ensure_buf(ctx, SB_CAND, (size_t)pre_total_c * sizeof(GreedyCand));
-            if (r == hipSuccess) r = launch_greedy_precheck(true, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
-                                                            d_cnt, d_cstart, buf<GreedyCand>(ctx, SB_CAND), d_over, S);
+            if (r == hipSuccess) r = launch_greedy_precheck(1, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
+                                                            d_cnt, d_cstart, buf<GreedyCand>(ctx, SB_CAND), d_over, d_total, 0, nullptr, nullptr, 0, S);
             if (r != hipSuccess) return false;
         }
-        pre_done = true;
+        pre_mode = 1;
         ph.cand_entries = pre_total_c;
         ph.precheck_ms = ms_since(tp);   // enqueue + count pass; the fill pass completes under the consumer's first wait
         return true;
@@ -1533,7 +1593,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                             const std::vector<int32_t> &cids, const std::vector<uint32_t> &leftover,
                             std::vector<int32_t> &join_slot) -> bool {
         if (forbid_device || !symmetric) return false;
-        if (!device_precheck(cluster_of, usize, leftover)) return false;
+        if (!device_precheck(cluster_of, usize, leftover, true)) return false;
         // (measured: the device-side loop beats the host loop over device-built lists at every size -- 1e5 uniform 12-mers
         // 7.5 against 9.5 ms end to end, the antibodies example 14 against 18 ms; the lists stay as the second path)
         const auto tl = std::chrono::steady_clock::now();
@@ -1558,11 +1618,11 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r != hipSuccess) return false;
         // subscriber lists (count into FIRST as scratch, scan, fill, sort by leftover)
         r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
-        if (r == hipSuccess) r = launch_loop_subscribers(false, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
+        if (r == hipSuccess) r = launch_loop_subscribers(false, nl, buf<uint32_t>(ctx, SB_CSTART), buf<uint32_t>(ctx, SB_CNT), buf<GreedyCand>(ctx, SB_CAND),
                                                          buf<uint32_t>(ctx, SB_FIRST), nullptr, nullptr, S);
         if (r == hipSuccess) r = launch_scan_u32(buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), ncl, buf<uint64_t>(ctx, SB_SCAN2), S);
         if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
-        if (r == hipSuccess) r = launch_loop_subscribers(true, nl, buf<uint32_t>(ctx, SB_CSTART), buf<GreedyCand>(ctx, SB_CAND),
+        if (r == hipSuccess) r = launch_loop_subscribers(true, nl, buf<uint32_t>(ctx, SB_CSTART), buf<uint32_t>(ctx, SB_CNT), buf<GreedyCand>(ctx, SB_CAND),
                                                          buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), S);
         if (r == hipSuccess) r = launch_loop_sort_subscribers(ncl, buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), buf<uint64_t>(ctx, SB_SUBS2), S);
         uint32_t *d_first = buf<uint32_t>(ctx, SB_FIRST), *d_taken = d_first + ncl, *d_clcursor = d_first + 2 * (size_t)ncl;
@@ -1589,7 +1649,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         // the device; rounds enqueued after the end find nothing to do.  Without the word: batches of rounds and a sync each.
         auto one_round = [&]() {
             r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
-                                  buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART),
+                                  buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART), buf<uint32_t>(ctx, SB_CNT),
                                   buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
                                   buf<uint32_t>(ctx, SB_ACTIVE), buf<uint32_t>(ctx, SB_DIRTY), rounds, d_first, d_taken, d_clcursor,
                                   ncl, accept_passes, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
@@ -1643,7 +1703,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                          bool want_prop, std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand,
                          std::vector<uint32_t> &prop_start, std::vector<GreedyProp> &prop, bool *have_prop) -> bool {
         *have_prop = false;
-        if (!device_precheck(cluster_of, usize, leftover)) return false;
+        if (!device_precheck(cluster_of, usize, leftover, false)) return false;
         const uint32_t nl = (uint32_t)leftover.size();
         const uint32_t total_c = pre_total_c;
         if (!fetch_cand(nl, cand_start, cand)) return false;

@@ -64,22 +64,28 @@ hipError_t launch_unpack_rows(const uint32_t *row_start, const uint32_t *adj, ui
 // pre-check of the greedy merge's second loop on the device-resident adjacency (k_edges.hip)
 // in_cluster: one bit per sequence (launch_cluster_bitmap), bitmap = uint32[(n + 31) / 32]
 hipError_t launch_cluster_bitmap(const int32_t *cluster_of, uint32_t n, uint32_t *bitmap, hipStream_t s);
-hipError_t launch_greedy_precheck(bool fill, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
+// mode: 0 count (cand_cnt), 1 fill at the prefix sums cand_start, 2 single pass (blocks of entries taken from the
+// HMK_PRE_REGIONS counters total[], which the caller zeroes, one per region of `capacity` entries of cand[]; cand_start[q] /
+// cand_cnt[q] describe leftover q's block; a counter above capacity: nothing usable was written;
+// retry != null: a first stage with small tables, retry[nl] / *retry_count (zeroed) take the rows that need the large ones)
+constexpr uint32_t HMK_PRE_REGIONS = 256;
+hipError_t launch_greedy_precheck(int mode, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
                                   const uint32_t *in_cluster, const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
-                                  const uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, hipStream_t s);
+                                  uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, unsigned long long *total,
+                                  unsigned long long capacity, uint32_t *retry, uint32_t *retry_count, int first_stage_slots, hipStream_t s);
 hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, uint64_t *tile_scratch, hipStream_t s);
 // where launch_scan_u32 leaves the 64-bit grand total inside tile_scratch (the uint32 start[n] wraps beyond 2^32 - 1)
 size_t scan_total_index(uint32_t n);
 // device-side second loop (k_loop_*).  Subscriber lists: per cluster the (leftover, candidate entry) pairs listing it,
 // subs = uint32[2 * entries]; pass 0 (fill = false) counts into the zeroed cursor[n_clusters], pass 1 fills.
-hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const GreedyCand *cand, uint32_t *cursor,
-                                   const uint32_t *sub_start, uint64_t *subs, hipStream_t s);
+hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const uint32_t *cand_cnt, const GreedyCand *cand,
+                                   uint32_t *cursor, const uint32_t *sub_start, uint64_t *subs, hipStream_t s);
 // one round; counters: device uint32[4] ([3] = tentative joiners the round's eval saw: 0 means the loop is over),
 // first / first_next: uint32[n_clusters] each; first must be all ones, first_next is reset for the next round
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
-                             uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
-                             uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken, uint32_t *cursor,
-                             uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
+                             uint32_t nl, const uint32_t *cand_start, const uint32_t *cand_cnt, GreedyCand *cand, uint8_t *status,
+                             uint32_t *choice, uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken,
+                             uint32_t *cursor, uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
                              const uint32_t *sub_start, const uint64_t *subs, void *clusters, const int32_t *seq_size,
                              uint32_t *counters, unsigned long long *host_word, hipStream_t s);
 hipError_t launch_loop_sort_subscribers(uint32_t n_clusters, const uint32_t *sub_start, uint64_t *subs, uint64_t *tmp, hipStream_t s);

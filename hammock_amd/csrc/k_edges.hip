@@ -329,10 +329,10 @@ k_rows_unpack(const uint32_t *__restrict__ start, const uint32_t *__restrict__ a
 // For every leftover sequence y (one wave each): which clusters have ALL their members among y's neighbours, and
 // with which lowest score (LimitedGreedySequenceClusterer.java:60 asks that of every cluster; complete linkage is
 // monotone, so clusters that fail now can never be joined later -- DESIGN.md "Exact greedy").  The neighbours'
-// clusters are counted in a per-wave LDS hash table (key = cluster, count, min score).  FILL = false counts the
-// candidates of each leftover, FILL = true writes them at cand_start[q]; a row with more distinct clusters than
-// the table takes raises *overflow (the host then runs its own pre-check).
-constexpr int PRE_SLOTS = 1024;   // per wave; 3 x 4 KB
+// clusters are counted in a per-wave LDS hash table (key = cluster, count, min score); a row with more distinct clusters
+// than the table takes raises *overflow (the host then runs its own pre-check).
+constexpr int PRE_SLOTS = 1024;   // per wave; 14 KB of tables.  (PRE_SLOTS_SMALL: the first stage of the single pass, see below)
+constexpr int PRE_SLOTS_SMALL = 128, PRE_SLOTS_MEDIUM = 512;
 
 __device__ __forceinline__ uint32_t nbr_id(const Nbr &a) { return a.m; }
 __device__ __forceinline__ int32_t nbr_score(const Nbr &a) { return a.s; }
@@ -350,59 +350,142 @@ __global__ void __launch_bounds__(256) k_cluster_bitmap(const int32_t *__restric
     bitmap[w] = bits;
 }
 
-template <class NbrT, bool FILL>
+// MODE 0 counts the candidates of each leftover (cand_cnt), MODE 1 writes them at cand_start[q] (the prefix sums of those
+// counts), MODE 2 does both in one pass: the wave takes its block of entries from a counter, writes cand_start[q] = the
+// block's first entry and cand_cnt[q].  ONE counter would be one address for ~10^5..10^6 returning atomics, ~25 ns each
+// (0.5 ms of the 10^5 call, 20 ms at 10^6): the buffer is cut into PRE_REGIONS regions of `capacity` entries with a counter each
+// (total[PRE_REGIONS]), a workgroup uses region blockIdx % PRE_REGIONS; entries beyond a region's end are not written (the
+// caller sees the counter above `capacity` and falls back to the two passes).  The table's occupied slots are kept in a list, so a leftover costs what its
+// row and its few distinct clusters cost -- clearing and scanning all 1,024 slots per leftover was three quarters of the
+// kernel at 10^5, where a row has 250 entries.
+// SLOTS: the table size.  With 1,024 slots per wave a CU holds two workgroups, and a leftover is a chain of dependent gathers
+// (row start, row, bitmap, cluster_of): the kernel is bound by latency at 8 waves per CU.  When rows have few neighbours
+// inside clusters, a first stage runs with 128 slots (8 workgroups per CU); a row that overflows them goes on `retry`
+// (retry_count of them) and the 1,024-slot kernel takes just those (work / work_count; null = all leftovers).
+enum { PRE_COUNT = 0, PRE_FILL = 1, PRE_SINGLE = 2 };
+constexpr uint32_t PRE_REGIONS = 256;
+
+template <class NbrT, int MODE, int SLOTS>
 __global__ void __launch_bounds__(256)
-k_greedy_precheck(const uint64_t *__restrict__ start, const NbrT *__restrict__ adj, const int32_t *__restrict__ cluster_of,
+k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict__ work_count, uint32_t *__restrict__ retry,
+                  uint32_t *__restrict__ retry_count,
+                  const uint64_t *__restrict__ start, const NbrT *__restrict__ adj, const int32_t *__restrict__ cluster_of,
                   const uint32_t *__restrict__ in_cluster,
                   const int32_t *__restrict__ usize, const uint32_t *__restrict__ leftover, uint32_t nl,
-                  uint32_t *__restrict__ cand_cnt, const uint32_t *__restrict__ cand_start, GreedyCand *__restrict__ cand,
-                  uint32_t *__restrict__ overflow) {
-    __shared__ int32_t keys_all[4 * PRE_SLOTS];
-    __shared__ uint32_t cnt_all[4 * PRE_SLOTS];
-    __shared__ int32_t mn_all[4 * PRE_SLOTS];
+                  uint32_t *__restrict__ cand_cnt, uint32_t *__restrict__ cand_start, GreedyCand *__restrict__ cand,
+                  uint32_t *__restrict__ overflow, unsigned long long *__restrict__ total, unsigned long long capacity) {
+    __shared__ int32_t keys_all[4 * SLOTS];
+    __shared__ uint32_t cnt_all[4 * SLOTS];
+    __shared__ int32_t mn_all[4 * SLOTS];
+    __shared__ uint16_t used_all[4 * SLOTS];
+    __shared__ uint32_t n_used_all[4];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int32_t *keys = keys_all + wv * PRE_SLOTS;
-    uint32_t *cnt = cnt_all + wv * PRE_SLOTS;
-    int32_t *mn = mn_all + wv * PRE_SLOTS;
-    for (uint32_t q = blockIdx.x * 4 + wv; q < nl; q += gridDim.x * 4) {
-        for (uint32_t sl = lane; sl < PRE_SLOTS; sl += 64) { keys[sl] = -1; cnt[sl] = 0; mn[sl] = INT_MAX; }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    int32_t *keys = keys_all + wv * SLOTS;
+    uint32_t *cnt = cnt_all + wv * SLOTS;
+    int32_t *mn = mn_all + wv * SLOTS;
+    uint16_t *used = used_all + wv * SLOTS;
+    uint32_t *n_used = n_used_all + wv;
+    for (uint32_t sl = lane; sl < (uint32_t)SLOTS; sl += 64) { keys[sl] = -1; cnt[sl] = 0; mn[sl] = INT_MAX; }
+    if (lane == 0) *n_used = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const uint32_t n_work = work ? *work_count : nl;
+    constexpr uint32_t HASH_SHIFT = SLOTS == 1024 ? 22 : SLOTS == 512 ? 23 : SLOTS == 256 ? 24 : 25;
+    static_assert(SLOTS == 1024 || SLOTS == 512 || SLOTS == 256 || SLOTS == 128, "table sizes");
+    for (uint32_t w = blockIdx.x * 4 + wv; w < n_work; w += gridDim.x * 4) {
+        const uint32_t q = work ? work[w] : w;
         const uint32_t y = leftover[q];
         const uint64_t b = start[y], e = start[y + 1];
         bool full = false;
-        for (uint64_t k = b + lane; k < e; k += 64) {
-            const NbrT nb = adj[k];
-            const uint32_t id = nbr_id(nb);
-            if (!((in_cluster[id >> 5] >> (id & 31)) & 1u)) continue;
-            const int32_t c = cluster_of[id];
-            uint32_t sl = ((uint32_t)c * 2654435761u) >> 22;   // top 10 bits
+        auto insert = [&](const NbrT nb, int32_t c) {
+            uint32_t sl = ((uint32_t)c * 2654435761u) >> HASH_SHIFT;
             int probes = 0;
             for (;;) {
                 const int32_t old = atomicCAS(&keys[sl], -1, c);
+                if (old == -1) used[atomicAdd(n_used, 1u)] = (uint16_t)sl;   // (at most SLOTS slots can be taken)
                 if (old == -1 || old == c) {
                     atomicAdd(&cnt[sl], 1u);
                     atomicMin(&mn[sl], nbr_score(nb));
                     break;
                 }
-                sl = (sl + 1) & (PRE_SLOTS - 1);
-                if (++probes >= PRE_SLOTS) { full = true; break; }
+                sl = (sl + 1) & (SLOTS - 1);
+                if (++probes >= SLOTS) { full = true; break; }
             }
-        }
-        if (__ballot(full) != 0) {
-            if (lane == 0) atomicAdd(overflow, 1u);
-            continue;
+        };
+        // four entries per lane and step: the row is a chain of dependent gathers (entry -> bitmap word -> cluster_of), and
+        // with one entry in flight per lane the kernel waits for memory at every link
+        constexpr int PRE_UNROLL = 4;
+        for (uint64_t k0 = b; k0 < e; k0 += 64 * PRE_UNROLL) {   // wave-uniform
+            NbrT nb[PRE_UNROLL];
+            bool in[PRE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PRE_UNROLL; u++) {
+                const uint64_t k = k0 + (uint64_t)u * 64 + lane;
+                in[u] = k < e;
+                nb[u] = in[u] ? adj[k] : adj[b];
+            }
+#pragma unroll
+            for (int u = 0; u < PRE_UNROLL; u++) {
+                const uint32_t id = nbr_id(nb[u]);
+                in[u] = in[u] && ((in_cluster[id >> 5] >> (id & 31)) & 1u);
+            }
+            int32_t cs[PRE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PRE_UNROLL; u++) cs[u] = in[u] ? cluster_of[nbr_id(nb[u])] : -1;
+#pragma unroll
+            for (int u = 0; u < PRE_UNROLL; u++)
+                if (in[u]) insert(nb[u], cs[u]);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        uint32_t found = 0;
-        for (uint32_t s0 = 0; s0 < PRE_SLOTS; s0 += 64) {
-            const uint32_t sl = s0 + lane;
-            const int32_t c = keys[sl];
-            const bool ok = c >= 0 && (int32_t)cnt[sl] == usize[c];   // every member of c is a neighbour of y
-            const uint64_t mask = __ballot(ok);
-            if (FILL && ok) cand[cand_start[q] + found + mbcnt64(mask)] = GreedyCand{c, mn[sl], 0};
-            found += (uint32_t)__popcll(mask);
+        const uint32_t nu = *n_used;
+        // (a table more than 3/4 full counts as overflowed too: probing it is slow, and the next stage has room)
+        const bool overflowed = __ballot(full) != 0 || (retry && nu > (uint32_t)SLOTS * 3 / 4);
+        if (overflowed && lane == 0) {
+            if (retry) retry[atomicAdd(retry_count, 1u)] = q;   // the larger table's turn
+            else atomicAdd(overflow, 1u);
         }
-        if (!FILL && lane == 0) cand_cnt[q] = found;
+        uint32_t found = 0;
+        if (!overflowed) {
+            if (MODE == PRE_SINGLE) {   // how many, then where
+                for (uint32_t i0 = 0; i0 < nu; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    bool ok = false;
+                    if (i < nu) { const uint32_t sl = used[i]; ok = (int32_t)cnt[sl] == usize[keys[sl]]; }
+                    found += (uint32_t)__popcll(__ballot(ok));
+                }
+            }
+            unsigned long long base = 0;
+            unsigned long long region_end = 0;
+            if (MODE == PRE_SINGLE) {
+                const uint32_t region = blockIdx.x % PRE_REGIONS;
+                if (lane == 0 && found) base = atomicAdd(&total[region], (unsigned long long)found);
+                base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+                region_end = (unsigned long long)(region + 1) * capacity;
+                base += (unsigned long long)region * capacity;
+                if (lane == 0) { cand_start[q] = (uint32_t)base; cand_cnt[q] = found; }
+            } else if (MODE == PRE_FILL) {
+                base = cand_start[q];
+            }
+            uint32_t at = 0;
+            for (uint32_t i0 = 0; i0 < nu; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                bool ok = false;
+                uint32_t sl = 0;
+                int32_t c = -1;
+                if (i < nu) { sl = used[i]; c = keys[sl]; ok = (int32_t)cnt[sl] == usize[c]; }   // every member of c is a neighbour of y
+                const uint64_t mask = __ballot(ok);
+                if (MODE != PRE_COUNT && ok) {
+                    const unsigned long long pos = base + at + mbcnt64(mask);
+                    if (MODE == PRE_FILL || pos < region_end) cand[pos] = GreedyCand{c, mn[sl], 0};
+                }
+                at += (uint32_t)__popcll(mask);
+            }
+            if (MODE == PRE_COUNT && lane == 0) cand_cnt[q] = at;
+        } else if (MODE == PRE_SINGLE && lane == 0 && !retry) {
+            cand_start[q] = 0; cand_cnt[q] = 0;
+        }
+        for (uint32_t i = lane; i < nu; i += 64) { const uint32_t sl = used[i]; keys[sl] = -1; cnt[sl] = 0; mn[sl] = INT_MAX; }   // the table is clean again
+        if (lane == 0) *n_used = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
 }
 
@@ -485,21 +568,22 @@ k_greedy_prop(const uint64_t *__restrict__ start, const uint32_t *__restrict__ u
 // Rounds repeat until one accepts nobody.  The host applies the joins in leftover order afterwards.
 enum : uint8_t { LS_UNDECIDED = 0, LS_NEVER = 1, LS_JOINED = 2 };
 
-// subscriber lists: per cluster the (leftover, candidate entry) pairs that list it, as uint64 = entry << 32 | leftover;
-// pass 0 counts, pass 1 fills (in arbitrary order: k_loop_sort_subs sorts them)
+// subscriber lists: per cluster the (leftover, candidate entry) pairs that list it, as uint64 = leftover << 32 | entry;
+// pass 0 counts, pass 1 fills (in arbitrary order: k_loop_sort_subs sorts them).  Leftover q's entries are
+// cand[cand_start[q] .. cand_start[q] + cand_cnt[q]) -- the blocks need not be in leftover order (single-pass pre-check).
 __global__ void __launch_bounds__(256)
-k_loop_subscribers(uint32_t nl, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
-                   uint32_t *__restrict__ cursor, const uint32_t *__restrict__ sub_start, unsigned long long *__restrict__ subs, int fill) {
+k_loop_subscribers(uint32_t nl, const uint32_t *__restrict__ cand_start, const uint32_t *__restrict__ cand_cnt,
+                   const GreedyCand *__restrict__ cand, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ sub_start,
+                   unsigned long long *__restrict__ subs, int fill) {
     const uint32_t q = blockIdx.x * 256 + threadIdx.x;
     if (q >= nl) return;
-    for (uint32_t k = cand_start[q], ke = cand_start[q + 1]; k < ke; k++) {
+    for (uint32_t k = cand_start[q], ke = k + cand_cnt[q]; k < ke; k++) {
         const uint32_t pos = atomicAdd(&cursor[cand[k].c], 1u);
-        if (fill) subs[(size_t)sub_start[cand[k].c] + pos] = ((unsigned long long)k << 32) | q;
+        if (fill) subs[(size_t)sub_start[cand[k].c] + pos] = ((unsigned long long)q << 32) | k;
     }
 }
 
-// Sorts every cluster's subscriber list by candidate entry = by leftover (the entries of leftover q are
-// cand[cand_start[q] ..), so entry order is leftover order).  One workgroup per cluster: bitonic sort of runs of SORT_RUN
+// Sorts every cluster's subscriber list by leftover (the high word).  One workgroup per cluster: bitonic sort of runs of SORT_RUN
 // entries in LDS, then -- for the rare longer list -- merges of neighbouring runs through `tmp` (every element finds its
 // place by a binary search in the other run; keys are unique).
 constexpr uint32_t SORT_RUN = 4096;
@@ -573,7 +657,7 @@ struct __attribute__((aligned(16))) LoopCluster {
 constexpr uint32_t LOOP_GRID = 1024;
 __device__ __forceinline__ void
 loop_eval(uint32_t block, uint32_t n_blocks, const uint32_t *__restrict__ list, uint32_t which, const uint32_t *__restrict__ cand_start,
-          const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
+          const uint32_t *__restrict__ cand_cnt, const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
           uint32_t *__restrict__ choice, uint32_t *__restrict__ dirty, uint32_t *__restrict__ counters) {
     const uint32_t t = block * 256 + threadIdx.x;
     if (t == 0) { counters[1] = 0; counters[4 + (which ^ 1u)] = 0; }   // accepted joins of this round; the next eval list starts empty
@@ -582,7 +666,7 @@ loop_eval(uint32_t block, uint32_t n_blocks, const uint32_t *__restrict__ list, 
     const uint32_t sub = t & (W - 1), groups = n_blocks * 256 >> lw;
     for (uint32_t i = t >> lw; i < n_list; i += groups) {   // (the W lanes of a leftover stay together)
         const uint32_t q = list[i];
-        const uint32_t kb = cand_start[q], ke = cand_start[q + 1];
+        const uint32_t kb = cand_start[q], ke = kb + cand_cnt[q];
         int has = 0, b_mn = 0, b_id = 0;
         long long b_size = 0;
         uint32_t b_k = 0;
@@ -627,8 +711,8 @@ loop_first(uint32_t block, uint32_t n_clusters, const uint32_t *__restrict__ sub
     const int32_t joined = cl[c].joined;
     auto valid_at = [&](uint32_t idx, uint32_t *q) -> bool {
         const unsigned long long e = subs[idx];
-        *q = (uint32_t)e;
-        return status[*q] == LS_UNDECIDED && cand[(uint32_t)(e >> 32)].covered == joined;
+        *q = (uint32_t)(e >> 32);
+        return status[*q] == LS_UNDECIDED && cand[(uint32_t)e].covered == joined;
     };
     if (cu < end) {                                       // usually the holder of the previous pass still stands
         uint32_t q = 0;
@@ -658,11 +742,11 @@ loop_first(uint32_t block, uint32_t n_clusters, const uint32_t *__restrict__ sub
 // not a valid holder whichever status `first` reads.
 __global__ void __launch_bounds__(256)
 k_loop_eval_first(uint32_t eval_blocks, const uint32_t *__restrict__ list, uint32_t which, const uint32_t *__restrict__ cand_start,
-                  const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
+                  const uint32_t *__restrict__ cand_cnt, const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
                   uint32_t *__restrict__ choice, uint32_t *__restrict__ dirty, uint32_t *__restrict__ counters,
                   uint32_t n_clusters, const uint32_t *__restrict__ sub_start, const unsigned long long *__restrict__ subs,
                   uint32_t *__restrict__ cursor, const uint32_t *__restrict__ taken, uint32_t stamp, uint32_t *__restrict__ first) {
-    if (blockIdx.x < eval_blocks) loop_eval(blockIdx.x, eval_blocks, list, which, cand_start, cand, cl, status, choice, dirty, counters);
+    if (blockIdx.x < eval_blocks) loop_eval(blockIdx.x, eval_blocks, list, which, cand_start, cand_cnt, cand, cl, status, choice, dirty, counters);
     else loop_first(blockIdx.x - eval_blocks, n_clusters, sub_start, subs, cursor, cand, cl, status, taken, stamp, first);
 }
 
@@ -675,7 +759,8 @@ k_loop_first(uint32_t n_clusters, const uint32_t *__restrict__ sub_start, const 
 
 // one thread per cluster: the leftover at first[c], if c is its pick
 __global__ void __launch_bounds__(256)
-k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand,
+k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, const uint32_t *__restrict__ cand_cnt,
+              const GreedyCand *__restrict__ cand,
               const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
               const uint32_t *__restrict__ first, uint32_t *__restrict__ taken, uint32_t stamp,
               uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot, uint32_t *__restrict__ counters) {
@@ -685,7 +770,7 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
     if (q == 0xFFFFFFFFu || taken[c] == stamp) return;
     const GreedyCand pick = cand[choice[q]];
     if ((uint32_t)pick.c != c) return;                     // q picks another cluster (that cluster's thread looks at it)
-    for (uint32_t k = cand_start[q], ke = cand_start[q + 1]; k < ke; k++) {
+    for (uint32_t k = cand_start[q], ke = k + cand_cnt[q]; k < ke; k++) {
         const GreedyCand cd = cand[k];
         if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && (first[cd.c] != q || taken[cd.c] == stamp)) return;   // a tie that may still grow
     }
@@ -747,8 +832,8 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                 uint32_t q2 = 0;
                 if (s2 < se) {
                     const unsigned long long sub = subs[s2];
-                    q2 = (uint32_t)sub;
-                    const uint32_t k2 = (uint32_t)(sub >> 32);
+                    q2 = (uint32_t)(sub >> 32);
+                    const uint32_t k2 = (uint32_t)sub;
                     // only a feasible entry matters (covered == joined; joined + 1 once an earlier chunk has counted y), and it
                     // changes either way -- one more covered member, or infeasible from now on: its leftover re-picks
                     if (status[q2] == LS_UNDECIDED && cand[k2].covered == joined) {
@@ -878,15 +963,37 @@ hipError_t launch_cluster_bitmap(const int32_t *cluster_of, uint32_t n, uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_greedy_precheck(bool fill, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
+hipError_t launch_greedy_precheck(int mode, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
                                   const uint32_t *in_cluster, const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
-                                  const uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, hipStream_t s) {
+                                  uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, unsigned long long *total,
+                                  unsigned long long capacity, uint32_t *retry, uint32_t *retry_count, int first_stage_slots, hipStream_t s) {
     if (nl == 0) return hipSuccess;
-    const dim3 grid(std::min<uint32_t>((nl + 3) / 4, 256 * 12)), block(256);
-#define HMK_PRE(T, F) hipLaunchKernelGGL((k_greedy_precheck<T, F>), grid, block, 0, s, start, (const T *)adj, cluster_of, in_cluster, usize, \
-                                         leftover, nl, cand_cnt, cand_start, cand, overflow)
-    if (packed) { if (fill) HMK_PRE(NbrPacked, true); else HMK_PRE(NbrPacked, false); }
-    else { if (fill) HMK_PRE(Nbr, true); else HMK_PRE(Nbr, false); }
+    const dim3 block(256);
+#define HMK_PRE(T, F, SL, GRID, WORK, WCNT, RETRY, RCNT)                                                                              \
+    hipLaunchKernelGGL((k_greedy_precheck<T, F, SL>), dim3(GRID), block, 0, s, WORK, WCNT, RETRY, RCNT, start, (const T *)adj, cluster_of, \
+                       in_cluster, usize, leftover, nl, cand_cnt, cand_start, cand, overflow, total, capacity)
+    const uint32_t grid_big = std::min<uint32_t>((nl + 3) / 4, 256 * 12), grid_small = std::min<uint32_t>((nl + 3) / 4, 256 * 32);
+    if (mode == PRE_SINGLE && retry) {
+        // two stages: small tables for every leftover, the full-size ones for the rows that did not fit (their number is only
+        // known on the device: the second launch is sized for all of them and reads the count)
+        if (first_stage_slots <= PRE_SLOTS_SMALL) {
+            if (packed) HMK_PRE(NbrPacked, PRE_SINGLE, PRE_SLOTS_SMALL, grid_small, nullptr, nullptr, retry, retry_count);
+            else HMK_PRE(Nbr, PRE_SINGLE, PRE_SLOTS_SMALL, grid_small, nullptr, nullptr, retry, retry_count);
+        } else {
+            if (packed) HMK_PRE(NbrPacked, PRE_SINGLE, PRE_SLOTS_MEDIUM, grid_small, nullptr, nullptr, retry, retry_count);
+            else HMK_PRE(Nbr, PRE_SINGLE, PRE_SLOTS_MEDIUM, grid_small, nullptr, nullptr, retry, retry_count);
+        }
+        if (packed) HMK_PRE(NbrPacked, PRE_SINGLE, PRE_SLOTS, grid_big, retry, retry_count, nullptr, nullptr);
+        else HMK_PRE(Nbr, PRE_SINGLE, PRE_SLOTS, grid_big, retry, retry_count, nullptr, nullptr);
+    } else if (packed) {
+        if (mode == PRE_SINGLE) HMK_PRE(NbrPacked, PRE_SINGLE, PRE_SLOTS, grid_big, nullptr, nullptr, nullptr, nullptr);
+        else if (mode == PRE_FILL) HMK_PRE(NbrPacked, PRE_FILL, PRE_SLOTS, grid_big, nullptr, nullptr, nullptr, nullptr);
+        else HMK_PRE(NbrPacked, PRE_COUNT, PRE_SLOTS, grid_big, nullptr, nullptr, nullptr, nullptr);
+    } else {
+        if (mode == PRE_SINGLE) HMK_PRE(Nbr, PRE_SINGLE, PRE_SLOTS, grid_big, nullptr, nullptr, nullptr, nullptr);
+        else if (mode == PRE_FILL) HMK_PRE(Nbr, PRE_FILL, PRE_SLOTS, grid_big, nullptr, nullptr, nullptr, nullptr);
+        else HMK_PRE(Nbr, PRE_COUNT, PRE_SLOTS, grid_big, nullptr, nullptr, nullptr, nullptr);
+    }
 #undef HMK_PRE
     return hipGetLastError();
 }
@@ -924,10 +1031,10 @@ hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const i
 }
 
 // subscriber lists of the device-side second loop: cursor = zeroed uint32[n_clusters]; pass 0 leaves the counts in it
-hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const GreedyCand *cand, uint32_t *cursor,
-                                   const uint32_t *sub_start, uint64_t *subs, hipStream_t s) {
+hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_start, const uint32_t *cand_cnt, const GreedyCand *cand,
+                                   uint32_t *cursor, const uint32_t *sub_start, uint64_t *subs, hipStream_t s) {
     if (nl == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_loop_subscribers, dim3((nl + 255) / 256), dim3(256), 0, s, nl, cand_start, cand, cursor, sub_start,
+    hipLaunchKernelGGL(k_loop_subscribers, dim3((nl + 255) / 256), dim3(256), 0, s, nl, cand_start, cand_cnt, cand, cursor, sub_start,
                        (unsigned long long *)subs, fill ? 1 : 0);
     return hipGetLastError();
 }
@@ -943,9 +1050,9 @@ hipError_t launch_loop_sort_subscribers(uint32_t n_clusters, const uint32_t *sub
 // uint32[8]; lists2: two uint32[nl] eval lists, list (round & 1) is read and the other written; first, taken, cursor:
 // uint32[n_clusters] each (taken zeroed before the first round)
 hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
-                             uint32_t nl, const uint32_t *cand_start, GreedyCand *cand, uint8_t *status, uint32_t *choice,
-                             uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken, uint32_t *cursor,
-                             uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
+                             uint32_t nl, const uint32_t *cand_start, const uint32_t *cand_cnt, GreedyCand *cand, uint8_t *status,
+                             uint32_t *choice, uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken,
+                             uint32_t *cursor, uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
                              const uint32_t *sub_start, const uint64_t *subs, void *clusters, const int32_t *seq_size,
                              uint32_t *counters, unsigned long long *host_word, hipStream_t s) {
     if (nl == 0 || n_clusters == 0) return hipSuccess;
@@ -955,12 +1062,12 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
     const uint32_t *list = lists2 + (size_t)which * nl;
     uint32_t *list_next = lists2 + (size_t)(which ^ 1u) * nl;
     const unsigned long long *sb = (const unsigned long long *)subs;
-    hipLaunchKernelGGL(k_loop_eval_first, dim3(grid.x + (n_clusters + 3) / 4), block, 0, s, grid.x, list, which, cand_start, cand, cl, status,
+    hipLaunchKernelGGL(k_loop_eval_first, dim3(grid.x + (n_clusters + 3) / 4), block, 0, s, grid.x, list, which, cand_start, cand_cnt, cand, cl, status,
                        choice, dirty, counters, n_clusters, sub_start, sb, cursor, taken, stamp, first);
     for (int p = 0; p < passes; p++) {
         if (p > 0)
             hipLaunchKernelGGL(k_loop_first, dim3((n_clusters + 3) / 4), block, 0, s, n_clusters, sub_start, sb, cursor, cand, cl, status, taken, stamp, first);
-        hipLaunchKernelGGL(k_loop_accept, dim3((n_clusters + 255) / 256), block, 0, s, n_clusters, cand_start, cand, cl, status, choice,
+        hipLaunchKernelGGL(k_loop_accept, dim3((n_clusters + 255) / 256), block, 0, s, n_clusters, cand_start, cand_cnt, cand, cl, status, choice,
                            first, taken, stamp, accepted, join_slot, counters);
     }
     const dim3 agrid(512);
@@ -1000,7 +1107,7 @@ hipError_t warm_edges_module() {
     const void *kernels[] = {
         (const void *)&k_init_range, (const void *)&k_edge_degree, (const void *)&k_scan_tile_sums, (const void *)&k_scan_tile_offsets,
         (const void *)&k_scan_tiles<uint64_t>, (const void *)&k_scan_tiles<uint32_t>, (const void *)&k_edge_scatter<NbrPacked>,
-        (const void *)&k_cluster_bitmap, (const void *)&k_greedy_precheck<NbrPacked, false>, (const void *)&k_greedy_precheck<NbrPacked, true>,
+        (const void *)&k_cluster_bitmap, (const void *)&k_greedy_precheck<NbrPacked, PRE_SINGLE, PRE_SLOTS>, (const void *)&k_greedy_precheck<NbrPacked, PRE_SINGLE, PRE_SLOTS_SMALL>,
         (const void *)&k_loop_subscribers, (const void *)&k_loop_sort_subs, (const void *)&k_loop_init, (const void *)&k_loop_eval_first,
         (const void *)&k_loop_first, (const void *)&k_loop_accept, (const void *)&k_loop_apply<NbrPacked>};
     hipError_t e = hipSuccess;

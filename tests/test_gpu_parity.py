@@ -333,10 +333,12 @@ def test_greedy_second_loop_implementations(gpu, blosum62, coracle, monkeypatch,
 
 
 @pytest.mark.parametrize("env", [{"HMK_LOOP_PASSES": "1"}, {"HMK_LOOP_PASSES": "3"}, {"HMK_LOOP_BATCHES": "1"},
-                                 {"HMK_LOOP_LOOKAHEAD": "1"}, {"HMK_LOOP_LOOKAHEAD": "64", "HMK_LOOP_PASSES": "2"}])
+                                 {"HMK_LOOP_LOOKAHEAD": "1"}, {"HMK_LOOP_LOOKAHEAD": "64", "HMK_LOOP_PASSES": "2"},
+                                 {"HMK_PRECHECK_TWO_PASSES": "1"}, {"HMK_PRECHECK_ONE_STAGE": "1"}])
 def test_greedy_device_loop_variants(gpu, blosum62, coracle, monkeypatch, env):
     """The knobs of the device-side second loop -- accept passes per round, how far the host enqueues ahead of the
-    progress word, batches with a sync instead of the word -- change its schedule, never its result."""
+    progress word, batches with a sync instead of the word -- and of the pre-check in front of it (one pass with region
+    counters or count + fill; small tables first or the full-size ones at once) change the schedule, never the result."""
     n = 20000
     res, off = synth_peptides(11, n, 12)
     st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 19, 500, 16)
@@ -590,12 +592,14 @@ def test_greedy_from_device_edges(gpu, blosum62, coracle):
     assert "outside" in str(ei.value)
 
 
-def test_greedy_device_precheck_table_overflow_falls_back(gpu, blosum62):
-    """The device pre-check counts a leftover's neighbouring clusters in a 1,024-slot table; a hub sequence that
-    touches 1,500 clusters overflows it and the merge must quietly use its host pre-check: same result as the
-    host-only merge on the same edges."""
+@pytest.mark.parametrize("n_pairs", [1500, 300])
+def test_greedy_device_precheck_table_overflow_falls_back(gpu, blosum62, n_pairs):
+    """The device pre-check counts a leftover's neighbouring clusters in a per-wave hash table: 128 slots in the first
+    stage when rows have few neighbours inside clusters, 1,024 for the rows that do not fit.  A hub sequence that touches
+    300 clusters goes through the second stage; one that touches 1,500 overflows that too and the merge must quietly use
+    its host pre-check.  Same result as the host-only merge on the same edges."""
     import torch
-    n_pairs, extra = 1500, 700
+    extra = 700
     n = 2 * n_pairs + 1 + extra
     res, off = synth_peptides(21, n, 12)
     ctx, _, _ = ctx_for(blosum62, res=res, off=off)
@@ -608,7 +612,7 @@ def test_greedy_device_precheck_table_overflow_falls_back(gpu, blosum62):
     d = torch.from_numpy(edges.view(np.int64).copy()).to("cuda:0")
     cid, order, st = ctx.greedy_from_edges_dev(d.data_ptr(), d.numel(), True, n_pairs)
     assert np.array_equal(cid, want_cid) and np.array_equal(order, want_order)
-    assert st.n_multi == n_pairs and cid[hub] == hub          # 1,500 pair clusters; the hub joins none of them
+    assert st.n_multi == n_pairs and cid[hub] == hub          # n_pairs pair clusters; the hub joins none of them
 
 
 def test_greedy_crash_parity_on_gpu(gpu, blosum62):
