@@ -541,16 +541,31 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     const bool fork = pl.groups.size() > 2 && getenv("HMK_NO_SIDE_STREAMS") == nullptr;
     int n_side = 3;
     if (const char *v = getenv("HMK_SIDE_STREAMS")) n_side = std::max(1, std::min((int)hmk_ctx::N_SIDE, atoi(v)));
+    // The streams the launches are dealt to: the pass's own stream and n_side - 1 others.  A process gets few hardware queues
+    // (4 by default), and streams beyond them share one and serialise: with the clustering calls' two streams created first
+    // (hmk_create), three more side streams cost this pass 5 % (5.36 -> 5.65 ms on BASELINE config 4a).  So a pass that does
+    // not run on the clustering stream borrows those two (idle: calls on a context are serialised); a clustering call without
+    // a band borrows the copy stream and creates one side stream; one with a band, whose hand-over needs the copy stream for
+    // itself, creates two.
+    hipStream_t sides[hmk_ctx::N_SIDE] = {nullptr};
     if (fork) {
-        if (!ctx->ev_fork) {
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
-                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
-                HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
-            }
+        if (!ctx->ev_fork) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        std::vector<hipStream_t> lend;
+        if (getenv("HMK_OWN_SIDE_STREAMS") == nullptr && ctx->gstream && ctx->copy_stream) {
+            if (stream != ctx->gstream && stream != ctx->copy_stream) lend = {ctx->gstream, ctx->copy_stream};
+            else if (stream == ctx->gstream && which == LAUNCH_ALL) lend = {ctx->copy_stream};
         }
+        int own = 0;
+        sides[0] = stream;
+        for (int k = 1; k < n_side; k++) {
+            if ((size_t)(k - 1) < lend.size()) { sides[k] = lend[k - 1]; continue; }
+            if (!ctx->side[own]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[own], hipStreamNonBlocking));
+            sides[k] = ctx->side[own++];
+        }
+        for (int k = 1; k < n_side; k++)
+            if (!ctx->ev_join[k]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, stream));
-        for (int k = 0; k < n_side; k++) HIPCHK(ctx, hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
+        for (int k = 1; k < n_side; k++) HIPCHK(ctx, hipStreamWaitEvent(sides[k], ctx->ev_fork, 0));
     }
     // biggest groups first
     std::vector<const Group *> order;
@@ -559,7 +574,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     size_t q = 0;
     for (const Group *gp : order) {
         const Group &g = *gp;
-        hipStream_t s = fork ? ctx->side[q++ % n_side] : stream;
+        hipStream_t s = fork ? sides[q++ % n_side] : stream;
         const uint32_t t0 = which == LAUNCH_REST ? g.base + g.band : g.base;
         const uint32_t cnt = which == LAUNCH_ALL ? g.count : which == LAUNCH_BAND ? g.band : g.count - g.band;
         if (g.path == PATH_DIRECT)
@@ -568,8 +583,8 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
             HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, t0, cnt, s));
     }
     if (fork)
-        for (int k = 0; k < n_side; k++) {
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join[k], ctx->side[k]));
+        for (int k = 1; k < n_side; k++) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join[k], sides[k]));
             HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[k], 0));
         }
     return HMK_OK;
