@@ -1220,8 +1220,8 @@ constexpr int ST_RETRY_OVERFLOW = 1000;   // internal: an edge segment overflowe
 enum { HC_COUNTS = 0, HC_BAND = 16, HC_PEER = 32, HC_RANGE = 64, HC_MISC = 72, HC_TOTAL = 80, HC_WORDS = 96 };
 
 // (HMK_GREEDY_TIMING: what the grow-only buffers cost a call, i.e. the first call of a context)
-static double g_alloc_ms = 0.0;
-static int g_allocs = 0;
+static thread_local double g_alloc_ms = 0.0;
+static thread_local int g_allocs = 0;
 struct AllocTimer {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     ~AllocTimer() { g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); g_allocs++; }
