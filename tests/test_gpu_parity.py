@@ -548,6 +548,52 @@ def test_greedy_csr_construction_modes(gpu, blosum62, coracle, monkeypatch, env,
     assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
 
 
+def test_concurrent_callers(gpu, blosum62, coracle):
+    """The reference calls its scorer from the workers of Hammock.threadPool (ClinkageSequenceClusterer.java:144-149) and
+    a JVM may hold several scorers: four threads share ONE context for pair probes (its calls serialise inside), while two
+    more contexts run hmk_greedy_cluster side by side on the same GPU.  Every result equals the single-threaded one."""
+    import threading
+    res, off = synth_peptides(31, 20000, 12)
+    shared, _, _ = ctx_for(blosum62, res=res, off=off)
+    rng = np.random.default_rng(5)
+    pairs = [(rng.integers(0, 20000, 50000, dtype=np.uint32), rng.integers(0, 20000, 50000, dtype=np.uint32)) for _ in range(4)]
+    want_pairs = [shared.score_pairs_shifted(i, j, 3, 0) for i, j in pairs]
+    inputs = [synth_peptides(32 + k, 30000 + 5000 * k, 12) for k in range(2)]
+    want_greedy = []
+    for r2, o2 in inputs:
+        st, ocid, oorder, _ = coracle.greedy_cluster(blosum62, r2, o2, None, 0, 3, 0, 20, 700, 16)
+        assert st == 0
+        want_greedy.append((ocid, oorder))
+    got_pairs, got_greedy, errors = [None] * 4, [None] * 2, []
+
+    def probe(k):
+        try:
+            for _ in range(5):
+                got_pairs[k] = shared.score_pairs_shifted(pairs[k][0], pairs[k][1], 3, 0)
+        except Exception as exc:   # noqa: BLE001 -- reported below
+            errors.append(exc)
+
+    def cluster(k):
+        try:
+            ctx, _, _ = ctx_for(blosum62, res=inputs[k][0], off=inputs[k][1])
+            for _ in range(3):
+                cid, order, _ = ctx.greedy_cluster(3, 0, 20, 700)
+            got_greedy[k] = (cid, order)
+        except Exception as exc:   # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=probe, args=(k,)) for k in range(4)] + [threading.Thread(target=cluster, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(4):
+        assert np.array_equal(got_pairs[k], want_pairs[k])
+    for k in range(2):
+        assert np.array_equal(got_greedy[k][0], want_greedy[k][0]) and np.array_equal(got_greedy[k][1], want_greedy[k][1])
+
+
 def test_greedy_antibodies_example_vs_oracle(gpu, blosum62, coracle, tmp_path):
     """The reference's own large example (examples/antibodies: 88,544 FASTA records, 74,041 unique 12-mers,
     counts and 15 labels in the headers; real phage-display data with heavy near-duplicate families, unlike
