@@ -26,8 +26,8 @@ namespace hmk {
 // DEG: also count the CSR degrees while writing edges (NeighborParams::deg, hmk_greedy_cluster); the plain neighbour pass
 // is its own instantiation so that it keeps its spill-free 72-VGPR allocation.
 template <int NW, int R, int CPL, int LBMAX, bool EXACT, int DEG>   // DEG: EDGES_PLAIN / EDGES_COUNT / EDGES_PLACE (hmk_device.h)
-// The production tiling (R = 6, CPL = 2) is held to 72 VGPRs = 7 waves/SIMD, which is also what its 22.6 KB of
-// LDS allow per CU (80 VGPRs / 6 waves otherwise): +2.4 % measured.
+// The production tiling (R = 6, CPL = 2) is held to 72 VGPRs = 7 waves/SIMD, which its 18.7 KB of LDS allow as well
+// (80 VGPRs would mean 6 waves): +2.4 % measured.
 __global__ void __launch_bounds__(256, (R >= 5 && R <= 7 && CPL == 2) ? 7 : 1)
 k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
     constexpr int ES = NW * 4;                 // table entry bytes
