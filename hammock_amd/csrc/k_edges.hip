@@ -411,50 +411,64 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
                 if (++probes >= SLOTS) { full = true; break; }
             }
         };
-        // four entries per lane and step: the row is a chain of dependent gathers (entry -> bitmap word -> cluster_of), and
-        // with one entry in flight per lane the kernel waits for memory at every link
-        constexpr int PRE_UNROLL = 4;
-        for (uint64_t k0 = b; k0 < e; k0 += 64 * PRE_UNROLL) {   // wave-uniform
-            NbrT nb[PRE_UNROLL];
-            bool in[PRE_UNROLL];
+        // the row's neighbours inside clusters go into the table -- all of them (parts == 1) or those whose cluster falls
+        // into one of `parts` classes (c mod parts == part), for a row that touches more clusters than the table takes.
+        // Four entries per lane and step: the row is a chain of dependent gathers (entry -> bitmap word -> cluster_of),
+        // and with one entry in flight per lane the kernel waits for memory at every link.
+        auto scan_row = [&](uint32_t part, uint32_t parts) {
+            constexpr int PRE_UNROLL = 4;
+            for (uint64_t k0 = b; k0 < e; k0 += 64 * PRE_UNROLL) {   // wave-uniform
+                NbrT nb[PRE_UNROLL];
+                bool in[PRE_UNROLL];
 #pragma unroll
-            for (int u = 0; u < PRE_UNROLL; u++) {
-                const uint64_t k = k0 + (uint64_t)u * 64 + lane;
-                in[u] = k < e;
-                nb[u] = in[u] ? adj[k] : adj[b];
-            }
-#pragma unroll
-            for (int u = 0; u < PRE_UNROLL; u++) {
-                const uint32_t id = nbr_id(nb[u]);
-                in[u] = in[u] && ((in_cluster[id >> 5] >> (id & 31)) & 1u);
-            }
-            int32_t cs[PRE_UNROLL];
-#pragma unroll
-            for (int u = 0; u < PRE_UNROLL; u++) cs[u] = in[u] ? cluster_of[nbr_id(nb[u])] : -1;
-#pragma unroll
-            for (int u = 0; u < PRE_UNROLL; u++)
-                if (in[u]) insert(nb[u], cs[u]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        const uint32_t nu = *n_used;
-        // (a table more than 3/4 full counts as overflowed too: probing it is slow, and the next stage has room)
-        const bool overflowed = __ballot(full) != 0 || (retry && nu > (uint32_t)SLOTS * 3 / 4);
-        if (overflowed && lane == 0) {
-            if (retry) retry[atomicAdd(retry_count, 1u)] = q;   // the larger table's turn
-            else atomicAdd(overflow, 1u);
-        }
-        uint32_t found = 0;
-        if (!overflowed) {
-            if (MODE == PRE_SINGLE) {   // how many, then where
-                for (uint32_t i0 = 0; i0 < nu; i0 += 64) {
-                    const uint32_t i = i0 + lane;
-                    bool ok = false;
-                    if (i < nu) { const uint32_t sl = used[i]; ok = (int32_t)cnt[sl] == usize[keys[sl]]; }
-                    found += (uint32_t)__popcll(__ballot(ok));
+                for (int u = 0; u < PRE_UNROLL; u++) {
+                    const uint64_t k = k0 + (uint64_t)u * 64 + lane;
+                    in[u] = k < e;
+                    nb[u] = in[u] ? adj[k] : adj[b];
                 }
+#pragma unroll
+                for (int u = 0; u < PRE_UNROLL; u++) {
+                    const uint32_t id = nbr_id(nb[u]);
+                    in[u] = in[u] && ((in_cluster[id >> 5] >> (id & 31)) & 1u);
+                }
+                int32_t cs[PRE_UNROLL];
+#pragma unroll
+                for (int u = 0; u < PRE_UNROLL; u++) cs[u] = in[u] ? cluster_of[nbr_id(nb[u])] : -1;
+#pragma unroll
+                for (int u = 0; u < PRE_UNROLL; u++)
+                    if (in[u] && ((uint32_t)cs[u] & (parts - 1)) == part) insert(nb[u], cs[u]);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        };
+        // the table's clusters of which EVERY member is a neighbour of y: counts them; with `write`, stores them from base + at
+        auto harvest = [&](bool write, unsigned long long base, unsigned long long end, uint32_t at) -> uint32_t {
+            const uint32_t nu = *n_used;
+            uint32_t n_ok = 0;
+            for (uint32_t i0 = 0; i0 < nu; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                bool ok = false;
+                uint32_t sl = 0;
+                int32_t c = -1;
+                if (i < nu) { sl = used[i]; c = keys[sl]; ok = (int32_t)cnt[sl] == usize[c]; }
+                const uint64_t mask = __ballot(ok);
+                if (write && ok) {
+                    const unsigned long long pos = base + at + n_ok + mbcnt64(mask);
+                    if (pos < end) cand[pos] = GreedyCand{c, mn[sl], 0};
+                }
+                n_ok += (uint32_t)__popcll(mask);
+            }
+            return n_ok;
+        };
+        auto clean = [&]() {   // back to an empty table
+            const uint32_t nu = *n_used;
+            for (uint32_t i = lane; i < nu; i += 64) { const uint32_t sl = used[i]; keys[sl] = -1; cnt[sl] = 0; mn[sl] = INT_MAX; }
+            if (lane == 0) *n_used = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        };
+        // where leftover q's `found` entries go (PRE_SINGLE: a block taken from the region's counter; PRE_FILL: the prefix sum)
+        unsigned long long region_end = ~0ull;
+        auto place = [&](uint32_t found) -> unsigned long long {
             unsigned long long base = 0;
-            unsigned long long region_end = 0;
             if (MODE == PRE_SINGLE) {
                 const uint32_t region = blockIdx.x % PRE_REGIONS;
                 if (lane == 0 && found) base = atomicAdd(&total[region], (unsigned long long)found);
@@ -464,28 +478,57 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
                 if (lane == 0) { cand_start[q] = (uint32_t)base; cand_cnt[q] = found; }
             } else if (MODE == PRE_FILL) {
                 base = cand_start[q];
+            } else if (lane == 0) {
+                cand_cnt[q] = found;
             }
-            uint32_t at = 0;
-            for (uint32_t i0 = 0; i0 < nu; i0 += 64) {
-                const uint32_t i = i0 + lane;
-                bool ok = false;
-                uint32_t sl = 0;
-                int32_t c = -1;
-                if (i < nu) { sl = used[i]; c = keys[sl]; ok = (int32_t)cnt[sl] == usize[c]; }   // every member of c is a neighbour of y
-                const uint64_t mask = __ballot(ok);
-                if (MODE != PRE_COUNT && ok) {
-                    const unsigned long long pos = base + at + mbcnt64(mask);
-                    if (MODE == PRE_FILL || pos < region_end) cand[pos] = GreedyCand{c, mn[sl], 0};
-                }
-                at += (uint32_t)__popcll(mask);
-            }
-            if (MODE == PRE_COUNT && lane == 0) cand_cnt[q] = at;
-        } else if (MODE == PRE_SINGLE && lane == 0 && !retry) {
-            cand_start[q] = 0; cand_cnt[q] = 0;
+            return base;
+        };
+
+        scan_row(0, 1);
+        // (a table more than 3/4 full counts as overflowed too in the first stage: probing it is slow, and the next stage has room)
+        bool overflowed = __ballot(full) != 0 || (retry && *n_used > (uint32_t)SLOTS * 3 / 4);
+        if (!overflowed) {
+            const uint32_t found = MODE == PRE_COUNT ? harvest(false, 0, 0, 0) : MODE == PRE_SINGLE ? harvest(false, 0, 0, 0) : 0;
+            const unsigned long long base = place(found);
+            if (MODE != PRE_COUNT) harvest(true, base, region_end, 0);
+            clean();
+            continue;
         }
-        for (uint32_t i = lane; i < nu; i += 64) { const uint32_t sl = used[i]; keys[sl] = -1; cnt[sl] = 0; mn[sl] = INT_MAX; }   // the table is clean again
-        if (lane == 0) *n_used = 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        clean();
+        if (retry) {                                   // the larger table's turn
+            if (lane == 0) retry[atomicAdd(retry_count, 1u)] = q;
+            continue;
+        }
+        // A row that touches more clusters than the table takes (the reference's default order puts 25,000 seeds next to each
+        // other at 10^6, and their neighbours see over a thousand of those clusters): the clusters are taken in 2, 4, ... 64
+        // classes, one table fill per class; one sweep counts, a second one writes.
+        uint32_t parts = 2, found = 0;
+        for (; parts <= 64; parts *= 2) {
+            found = 0;
+            bool fits = true;
+            for (uint32_t part = 0; part < parts && fits; part++) {
+                full = false;
+                scan_row(part, parts);
+                fits = __ballot(full) == 0;
+                if (fits) found += harvest(false, 0, 0, 0);
+                clean();
+            }
+            if (fits) break;
+        }
+        if (parts > 64) {                              // more than ~45,000 clusters next to one sequence: the host's turn
+            if (lane == 0) { atomicAdd(overflow, 1u); if (MODE == PRE_SINGLE) { cand_start[q] = 0; cand_cnt[q] = 0; } }
+            continue;
+        }
+        const unsigned long long base = place(found);
+        if (MODE != PRE_COUNT) {
+            uint32_t at = 0;
+            for (uint32_t part = 0; part < parts; part++) {
+                full = false;
+                scan_row(part, parts);
+                at += harvest(true, base, region_end, at);
+                clean();
+            }
+        }
     }
 }
 

@@ -34,6 +34,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <utility>
 #include <vector>
@@ -216,13 +217,36 @@ inline int sizeAlphabeticCompare(const UniqueSequence &a, const UniqueSequence &
 }
 
 // UniqueSequence.sortSequences, UniqueSequence.java:176-203 (Collections.sort is stable)
+// the "size" order (UniqueSequenceSizeAlphabeticComparator reversed: size descending, then string descending), sorted on
+// keys held beside the pointers -- size and the string's first 8 bytes as one big-endian word decide almost every
+// comparison without touching the sequence objects (10^6 sequences: 0.47 s -> 0.2 s)
+inline void sortBySizeThenStringDescending(std::vector<UniqueSequencePtr> &seqs) {
+    struct Key { int size; uint64_t prefix; uint32_t index; };
+    std::vector<Key> keys(seqs.size());
+    for (size_t k = 0; k < seqs.size(); k++) {
+        const std::string &s = seqs[k]->getSequenceString();
+        uint64_t prefix = 0;
+        for (size_t b = 0; b < 8; b++) prefix = (prefix << 8) | (b < s.size() ? (unsigned char)s[b] : 0u);
+        keys[k] = Key{seqs[k]->size(), prefix, (uint32_t)k};
+    }
+    std::stable_sort(keys.begin(), keys.end(), [&](const Key &a, const Key &b) {
+        if (a.size != b.size) return a.size > b.size;
+        if (a.prefix != b.prefix) return a.prefix > b.prefix;      // (a zero byte pads a string shorter than 8: it sorts first, as in compareTo)
+        return javaStringCompare(seqs[b.index]->getSequenceString(), seqs[a.index]->getSequenceString()) < 0;
+    });
+    std::vector<UniqueSequencePtr> sorted(seqs.size());
+    for (size_t k = 0; k < seqs.size(); k++) sorted[k] = std::move(seqs[keys[k].index]);
+    seqs.swap(sorted);
+}
+
 inline void sortSequences(std::vector<UniqueSequencePtr> &seqs, const std::string &order, int seed,
                           const std::vector<std::string> &labels) {
     auto sizeAlphaDesc = [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
         return sizeAlphabeticCompare(*b, *a) < 0;  // Collections.reverseOrder(cmp)
     };
     if (order == "size") {
-        std::stable_sort(seqs.begin(), seqs.end(), sizeAlphaDesc);
+        if (seqs.size() < (1u << 31)) sortBySizeThenStringDescending(seqs);
+        else std::stable_sort(seqs.begin(), seqs.end(), sizeAlphaDesc);
     } else if (order == "alphabetic") {
         std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
             return javaStringCompare(b->getSequenceString(), a->getSequenceString()) < 0;
@@ -714,17 +738,36 @@ public:
 // bare sequence for singletons (:770-776); members of multi-member clusters get "NA" (:617-618).
 inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &sequences, const std::vector<ClusterPtr> &clusters,
                                        const std::string &filePath, const std::vector<std::string> &labels) {
-    std::unordered_map<std::string, ClusterPtr> sequenceClusterMap;
-    std::unordered_map<std::string, std::string> msaMap;
-    for (auto &cl : clusters) {
-        for (auto &s : cl->getSequences()) sequenceClusterMap[s->getSequenceString()] = cl;
-        if (cl->getUniqueSize() == 1) {
-            const std::string s = cl->getSequences()[0]->getSequenceString();
-            std::string stripped;
-            for (char c : s) if (c != '-') stripped.push_back(c);
-            msaMap[stripped] = s;
+    // sequence -> cluster and (singletons) sequence without gaps -> "alignment", keyed by the sequence STRING as in the
+    // reference (two HashMap<String, ...>, :596-607).  One open-addressing table over views of the strings the sequences own:
+    // with two std::unordered_map<std::string, ...> the two callers of this function took 9 of the 12 s of a 10^6-sequence run.
+    // A sequence has no '-' (not in the alphabet), so the "alignment" key of a singleton IS its string, and as long as no
+    // string occurs in two clusters "found in msaMap" is "its cluster is a singleton"; a repeated string (impossible after the
+    // loaders, which merge duplicates) switches to the two literal maps.
+    struct Slot { std::string_view key; const Cluster *cluster = nullptr; };
+    size_t n_members = 0;
+    for (auto &cl : clusters) n_members += (size_t)cl->getUniqueSize();
+    size_t cap = 16;
+    while (cap < 2 * n_members + 2) cap <<= 1;
+    std::vector<Slot> table(cap);
+    const std::hash<std::string_view> hasher;
+    auto slot_of = [&](std::string_view key) -> Slot & {
+        size_t at = hasher(key) & (cap - 1);
+        while (table[at].cluster && table[at].key != key) at = (at + 1) & (cap - 1);
+        return table[at];
+    };
+    bool repeated = false;
+    for (auto &cl : clusters)
+        for (auto &s : cl->getSequences()) {
+            Slot &sl = slot_of(s->getSequenceString());
+            repeated = repeated || sl.cluster != nullptr;
+            sl.key = s->getSequenceString();
+            sl.cluster = cl.get();               // (the last cluster that holds the string wins, as HashMap.put)
         }
-    }
+    std::unordered_map<std::string_view, std::string_view> msaMap;   // only for the impossible case
+    if (repeated)
+        for (auto &cl : clusters)
+            if (cl->getUniqueSize() == 1) { const std::string &s = cl->getSequences()[0]->getSequenceString(); msaMap[s] = s; }
     std::ofstream w(filePath, std::ios::binary);
     if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
     std::string out;
@@ -736,12 +779,12 @@ inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &seq
     std::vector<long long> scratch(labels.size());
     for (auto &seq : sequences) {
         const std::string &str = seq->getSequenceString();
-        auto it = sequenceClusterMap.find(str);
-        if (it != sequenceClusterMap.end()) {
-            out += std::to_string(it->second->getId());
+        const Slot &sl = slot_of(str);
+        if (sl.cluster) {
+            out += std::to_string(sl.cluster->getId());
             out += CSV_SEPARATOR; out += str; out += CSV_SEPARATOR;
-            auto m = msaMap.find(str);
-            out += m != msaMap.end() ? m->second : std::string("NA");
+            const bool aligned = repeated ? msaMap.find(str) != msaMap.end() : sl.cluster->getUniqueSize() == 1;
+            if (aligned) out += str; else out += "NA";
             out += CSV_SEPARATOR;
         } else {
             out += "NA"; out += CSV_SEPARATOR; out += str; out += CSV_SEPARATOR; out += "NA"; out += CSV_SEPARATOR;
@@ -753,8 +796,16 @@ inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &seq
 }
 
 inline std::vector<ClusterPtr> clustersSortedDescending(const std::vector<ClusterPtr> &clusters) {
-    std::vector<ClusterPtr> sorted(clusters);  // Collections.sort(list, Collections.reverseOrder()): size desc, id desc
-    std::stable_sort(sorted.begin(), sorted.end(), [](const ClusterPtr &a, const ClusterPtr &b) { return b->compareTo(*a) < 0; });
+    // Collections.sort(list, Collections.reverseOrder()): size desc, id desc (Cluster.compareTo :198-204), on keys held
+    // beside the indices so that the sort does not chase 10^6 pointers per pass
+    struct Key { int size, id; uint32_t index; };
+    std::vector<Key> keys(clusters.size());
+    for (size_t k = 0; k < clusters.size(); k++) keys[k] = Key{clusters[k]->size(), clusters[k]->getId(), (uint32_t)k};
+    std::stable_sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {   // b.compareTo(a) < 0, the same int arithmetic
+        return (b.size != a.size ? b.size - a.size : b.id - a.id) < 0;
+    });
+    std::vector<ClusterPtr> sorted(clusters.size());
+    for (size_t k = 0; k < clusters.size(); k++) sorted[k] = clusters[keys[k].index];
     return sorted;
 }
 
@@ -765,9 +816,10 @@ inline void saveClusterSequencesToCsv(const std::vector<ClusterPtr> &clusters, c
     std::vector<UniqueSequencePtr> sortedSequences;
     for (auto &cl : clustersSortedDescending(clusters)) {
         auto &seqs = cl->getSequences();
-        std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
-            return sizeAlphabeticCompare(*b, *a) < 0;
-        });
+        if (seqs.size() > 1)
+            std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+                return sizeAlphabeticCompare(*b, *a) < 0;
+            });
         sortedSequences.insert(sortedSequences.end(), seqs.begin(), seqs.end());
     }
     writeClusterSequencesToCsv(sortedSequences, clusters, filePath, labels);
@@ -794,7 +846,7 @@ inline void SaveClustersToCsv(const std::vector<ClusterPtr> &clusters, const std
     for (size_t k = 0; k < labels.size(); k++) first_column[k] = (size_t)(std::find(labels.begin(), labels.end(), labels[k]) - labels.begin());
     for (auto &cl : clustersSortedDescending(clusters)) {
         auto &seqs = cl->getSequences();  // Collections.sort(sequences, reverseOrder()): UniqueSequence.compareTo :161-171
-        std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+        if (seqs.size() > 1) std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
             auto cmp = [](const UniqueSequence &x, const UniqueSequence &y) {
                 if (x.size() != y.size()) return x.size() - y.size();
                 return -javaStringCompare(x.getSequenceString(), y.getSequenceString());

@@ -642,8 +642,8 @@ def test_greedy_from_device_edges(gpu, blosum62, coracle):
 def test_greedy_device_precheck_table_overflow_falls_back(gpu, blosum62, n_pairs):
     """The device pre-check counts a leftover's neighbouring clusters in a per-wave hash table: 128 slots in the first
     stage when rows have few neighbours inside clusters, 1,024 for the rows that do not fit.  A hub sequence that touches
-    300 clusters goes through the second stage; one that touches 1,500 overflows that too and the merge must quietly use
-    its host pre-check.  Same result as the host-only merge on the same edges."""
+    300 clusters goes through the second stage; one that touches 1,500 does not fit 1,024 slots either and is taken in
+    classes of clusters, one table fill per class.  Same result as the host-only merge on the same edges."""
     import torch
     extra = 700
     n = 2 * n_pairs + 1 + extra
@@ -996,15 +996,22 @@ def test_greedy_full_size_mixed_lengths_1e5_vs_oracle(gpu, blosum62, coracle):
     assert stats.phase1_stop_index == ostats.phase1_stop_index
 
 
-def test_million_peptides_greedy_end_to_end(gpu, blosum62, coracle, monkeypatch):
+@pytest.mark.parametrize("order_by", ["input", "size"])
+def test_million_peptides_greedy_end_to_end(gpu, blosum62, coracle, monkeypatch, order_by):
     """BASELINE config 5's input (10^6 x 12, SplitMix64 seed 1) through hmk_greedy_cluster on this one GPU: 5 x 10^11
     pairs scored, the second loop on the device.  The oracle needs minutes at this size, so the checks are the
     size-independent ones: 25,000 clusters whose ids are their seeds in creation order; EVERY pair inside every cluster
     scores >= threshold (complete linkage, rescored by hmk_score_pairs_shifted and, sampled, by the oracle); and the whole
     result -- ids, list order, member order -- equals the one produced with the second loop forced onto the HOST
-    implementation (the round-1 code path, an independent implementation over the fetched adjacency)."""
+    implementation (the round-1 code path, an independent implementation over the fetched adjacency).
+    order_by = "size": the reference's default order (all counts are 1, so reverse alphabetical) puts the 25,000 seeds next
+    to each other, and their neighbours see more clusters than the pre-check's 1,024-slot tables take -- the rows that the
+    device handles in classes of clusters instead of handing the whole call to the host."""
     n, thr, maxc = 1000000, 20, 25000
     res, off = synth_peptides(1, n, 12)
+    if order_by == "size":
+        letters = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)[res].reshape(n, 12)
+        res = np.ascontiguousarray(res.reshape(n, 12)[np.lexsort(letters.T[::-1])[::-1]]).reshape(-1)
     ctx, _, _ = ctx_for(blosum62, res=res, off=off)
     cid, order, stats = ctx.greedy_cluster(3, 0, thr, maxc)
     rank = ctx.member_rank[:n].copy()

@@ -8,6 +8,7 @@ cd "$R"
 timeout -k 10 300 python tests/tools/bench_configs.py > "$O/round2_configs.jsonl" 2> "$O/configs.err"; echo configs $?
 timeout -k 10 120 python tools/run_config4a.py > "$O/round2_config4a.json" 2> /dev/null; echo 4a $?
 timeout -k 10 300 python tools/greedy_phases.py 100000 300000 1000000 > "$O/round2_greedy_phases.jsonl" 2> /dev/null; echo phases $?
+timeout -k 10 300 python tools/greedy_phases.py --sorted 100000 1000000 > "$O/round2_greedy_phases_default_order.jsonl" 2> /dev/null; echo phases_sorted $?
 timeout -k 10 200 python tests/tools/e2e_compare.py 100000 16 > "$O/round2_end_to_end_1e5.json" 2> /dev/null; echo e2e $?
 timeout -k 10 200 python tests/tools/e2e_antibodies.py 16 > "$O/round2_end_to_end_antibodies.json" 2> /dev/null; echo antibodies $?
 timeout -k 10 200 python tests/tools/e2e_mixed_compare.py > "$O/round2_end_to_end_mixed_1e5.json" 2> /dev/null; echo mixed $?

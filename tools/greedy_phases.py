@@ -20,9 +20,18 @@ from hammock_amd.synth import synth_peptides  # noqa: E402
 with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
     M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
 
-for n in [int(a) for a in sys.argv[1:]] or [100000]:
+# --sorted: the sequences in Hammock's default order ("size": count descending, then the sequence string DESCENDING,
+# UniqueSequence.java:238-248 -- with all counts 1 that is reverse alphabetical, what `hammock-hip greedy` clusters by
+# default); without it the order in which the generator produced them (-R input)
+SORTED = "--sorted" in sys.argv
+LETTERS = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
+for n in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [100000]:
     lo, hi = (12, 12)
     res, off = synth_peptides(1, n, lo, hi)
+    if SORTED:
+        rows = LETTERS[res].reshape(n, 12)
+        order_idx = np.lexsort(rows.T[::-1])[::-1]     # descending by the sequence's letters
+        res = np.ascontiguousarray(res.reshape(n, 12)[order_idx]).reshape(-1)
     maxc = int(np.floor(n * 0.025 + 0.5))
     ctx = hammock_amd.Context(M, device=0)
     ctx.set_sequences(residues=res, offsets=off)
@@ -34,7 +43,7 @@ for n in [int(a) for a in sys.argv[1:]] or [100000]:
         if ref is None:
             ref = (cid.copy(), order.copy())
         assert np.array_equal(cid, ref[0]) and np.array_equal(order, ref[1])
-        line = {"n": n, "call": call, "wall_ms": wall * 1e3, "clusters": int(st.n_multi), "result_list": int(st.n_result_clusters),
+        line = {"n": n, "order": "size" if SORTED else "input", "call": call, "wall_ms": wall * 1e3, "clusters": int(st.n_multi), "result_list": int(st.n_result_clusters),
                 "edges": int(st.n_edges), "phase1_stop_index": int(st.phase1_stop_index)}
         line.update(ctx.greedy_phases())
         print(json.dumps(line), flush=True)
