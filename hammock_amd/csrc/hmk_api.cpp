@@ -1898,6 +1898,33 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t)));
             ctx->d_edges_cap = cap;
         }
+        // Everything cluster_on_device will want, BEFORE the pass is enqueued: a hipMalloc issued while the pass runs returns
+        // when the pass is over (seen at 10^6: the band hand-over of a context's first call was enqueued 340 ms late, i.e.
+        // after the scoring it is meant to overlap).  Grow-only buffers: steady-state calls find them all in place.
+        {
+            const size_t esz0 = src.packed ? sizeof(NbrPacked) : sizeof(Nbr);
+            const uint32_t r1 = (uint32_t)std::max<int64_t>(band_rows, 0);
+            HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, std::max<uint64_t>((ctx->symmetric ? 2 : 1) * ctx->d_edges_cap, 1) * esz0));
+            HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
+            HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
+            HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
+            HIPCHK(ctx, ensure_buf(ctx, SB_RANGE, 64));
+            HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, ((size_t)n + 1) * 8 + (size_t)n * 4 + 64, 0));
+            if (r1) {
+                HIPCHK(ctx, ensure_buf(ctx, SB_BDEG, (size_t)r1 * 4));
+                HIPCHK(ctx, ensure_buf(ctx, SB_BCURSOR, (size_t)r1 * 8));
+                HIPCHK(ctx, ensure_buf(ctx, SB_BSTART, ((size_t)r1 + 1) * 8));
+                HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(r1)));
+                HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
+            }
+            HIPCHK(ctx, ensure_buf(ctx, SB_COF, (size_t)n * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_LEFT, (size_t)n * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_CNT, (size_t)n * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_CSTART, ((size_t)n + 1) * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_CAND, (size_t)n * 24 * sizeof(GreedyCand)));
+        }
         call_lap("edge buffer ready");
         const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
         src.seg_cap = seg;
