@@ -330,7 +330,8 @@ k_rows_unpack(const uint32_t *__restrict__ start, const uint32_t *__restrict__ a
 // with which lowest score (LimitedGreedySequenceClusterer.java:60 asks that of every cluster; complete linkage is
 // monotone, so clusters that fail now can never be joined later -- DESIGN.md "Exact greedy").  The neighbours'
 // clusters are counted in a per-wave LDS hash table (key = cluster, count, min score); a row with more distinct clusters
-// than the table takes raises *overflow (the host then runs its own pre-check).
+// than the table takes is walked once per class of clusters (see the kernel); only beyond 64 classes does it raise
+// *overflow (the host then runs its own pre-check).
 constexpr int PRE_SLOTS = 1024;   // per wave; 14 KB of tables.  (PRE_SLOTS_SMALL: the first stage of the single pass, see below)
 constexpr int PRE_SLOTS_SMALL = 128, PRE_SLOTS_MEDIUM = 512;
 
@@ -355,9 +356,9 @@ __global__ void __launch_bounds__(256) k_cluster_bitmap(const int32_t *__restric
 // block's first entry and cand_cnt[q].  ONE counter would be one address for ~10^5..10^6 returning atomics, ~25 ns each
 // (0.5 ms of the 10^5 call, 20 ms at 10^6): the buffer is cut into PRE_REGIONS regions of `capacity` entries with a counter each
 // (total[PRE_REGIONS]), a workgroup uses region blockIdx % PRE_REGIONS; entries beyond a region's end are not written (the
-// caller sees the counter above `capacity` and falls back to the two passes).  The table's occupied slots are kept in a list, so a leftover costs what its
-// row and its few distinct clusters cost -- clearing and scanning all 1,024 slots per leftover was three quarters of the
-// kernel at 10^5, where a row has 250 entries.
+// caller sees the counter above `capacity` and falls back to the two passes).  The table's occupied slots are kept in a
+// list, so a leftover costs what its row and its few distinct clusters cost -- clearing and scanning all 1,024 slots per
+// leftover was three quarters of the kernel at 10^5, where a row has 250 entries.
 // SLOTS: the table size.  With 1,024 slots per wave a CU holds two workgroups, and a leftover is a chain of dependent gathers
 // (row start, row, bitmap, cluster_of): the kernel is bound by latency at 8 waves per CU.  When rows have few neighbours
 // inside clusters, a first stage runs with 128 slots (8 workgroups per CU); a row that overflows them goes on `retry`
