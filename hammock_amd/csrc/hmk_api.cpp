@@ -1706,7 +1706,12 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         }
         if (r != hipSuccess || !done) return false;
         join_slot.resize(nl);
-        if (nl) r = hipMemcpy(join_slot.data(), buf<void>(ctx, SB_JSLOT), (size_t)nl * 4, hipMemcpyDeviceToHost);
+        if (nl) {   // through the pinned block (a copy into pageable memory is staged chunk by chunk)
+            r = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, (size_t)nl * 4 + 64, 0);
+            if (r == hipSuccess) r = hipMemcpyAsync(ctx->h_stage, buf<void>(ctx, SB_JSLOT), (size_t)nl * 4, hipMemcpyDeviceToHost, S);
+            if (r == hipSuccess) r = hipStreamSynchronize(S);
+            if (r == hipSuccess) std::memcpy(join_slot.data(), ctx->h_stage, (size_t)nl * 4);
+        }
         if (r != hipSuccess) return false;
         ph.device_loop_ms = ms_since(tl);
         ph.loop_rounds = rounds;
