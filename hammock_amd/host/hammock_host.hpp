@@ -561,17 +561,23 @@ inline std::vector<std::string> splitChar(const std::string &line, char sep, boo
 inline std::vector<std::string> readLines(const std::string &path) {  // BufferedReader.readLine semantics
     std::ifstream f(path, std::ios::binary);
     if (!f) throw HammockException("java.io.FileNotFoundException: " + path + " (No such file or directory)");
-    std::stringstream ss;
-    ss << f.rdbuf();
-    const std::string all = ss.str();
+    f.seekg(0, std::ios::end);
+    const std::streamoff size = f.tellg();
+    f.seekg(0, std::ios::beg);
+    std::string all((size_t)std::max<std::streamoff>(size, 0), '\0');
+    if (size > 0) f.read(&all[0], size);
+    all.resize((size_t)f.gcount());
     std::vector<std::string> lines;
-    std::string cur;
+    lines.reserve(all.size() / 12 + 16);
+    size_t start = 0;   // a line ends at \n, \r or \r\n; what follows the last terminator is a line only if it is not empty
     for (size_t k = 0; k < all.size(); k++) {
-        if (all[k] == '\n') { lines.push_back(cur); cur.clear(); }
-        else if (all[k] == '\r') { lines.push_back(cur); cur.clear(); if (k + 1 < all.size() && all[k + 1] == '\n') k++; }
-        else cur.push_back(all[k]);
+        const char c = all[k];
+        if (c != '\n' && c != '\r') continue;
+        lines.emplace_back(all, start, k - start);
+        if (c == '\r' && k + 1 < all.size() && all[k + 1] == '\n') k++;
+        start = k + 1;
     }
-    if (!cur.empty()) lines.push_back(cur);
+    if (start < all.size()) lines.emplace_back(all, start, all.size() - start);
     return lines;
 }
 
@@ -613,6 +619,9 @@ inline std::vector<std::vector<int>> loadScoringMatrix(const std::string &matrix
 inline std::vector<UniqueSequencePtr> loadUniqueSequencesFromFasta(const std::string &fileName) {
     std::vector<std::pair<std::string, std::vector<std::pair<std::string, int>>>> order;  // LinkedHashMap
     std::unordered_map<std::string, size_t> index;
+    const std::vector<std::string> lines = readLines(fileName);
+    index.reserve(lines.size() / 2 + 1);
+    order.reserve(lines.size() / 2 + 1);
     std::string sequence, label;
     int count = 0;
     bool haveLabel = false, haveCount = false;
@@ -628,7 +637,7 @@ inline std::vector<UniqueSequencePtr> loadUniqueSequencesFromFasta(const std::st
             if (!found) lm.push_back({label, count});
         }
     };
-    for (const std::string &line : readLines(fileName)) {
+    for (const std::string &line : lines) {
         if (!line.empty() && line[0] == '>') {
             if (!sequence.empty()) { add(sequence); sequence.clear(); }              // :168-172
             const std::vector<std::string> split = splitChar(trim(line).substr(1), '|', true);  // :173
