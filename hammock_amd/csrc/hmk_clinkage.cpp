@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <string>
 #include <vector>
 
 namespace hmk {
@@ -117,9 +118,11 @@ int clinkage_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const
         active.add(id);
     }
     std::vector<int32_t> stack;
+    std::vector<char> on_stack((size_t)max_id + 1, 0);
     std::vector<CNbr> merged;
     while (active.size() > 1) {                       // :63
         stack.push_back(active.first());              // :70-71
+        on_stack[stack.back()] = 1;
         while (!stack.empty()) {                      // :72
             const int32_t top = stack.back();
             // nearest neighbour: arg-max (score, size, -id) over the live candidates; dead entries are dropped on the way
@@ -140,6 +143,7 @@ int clinkage_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const
             st->searches++;
             if (nearest < 0) {                        // :86-92 (every listed score is >= threshold)
                 stack.pop_back();
+                on_stack[top] = 0;
                 ready.add(top);
                 active.remove(top);
                 continue;
@@ -148,6 +152,7 @@ int clinkage_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const
                 current_id++;
                 stack.pop_back();
                 stack.pop_back();
+                on_stack[top] = on_stack[nearest] = 0;
                 active.remove(top);
                 active.remove(nearest);
                 const int32_t nid = current_id;
@@ -176,7 +181,20 @@ int clinkage_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const
                 active.add(nid);
                 st->merges++;
             } else {
+                if (on_stack[nearest]) {
+                    // A tie (score, then size, then the smaller id) sent the chain back to a cluster that is still on the
+                    // stack, below stack[-2].  The reference pushes it again (:113, no such check), merges or retires the upper
+                    // copy, and later takes the stale Cluster object below as `top`: its members sit in another cluster by
+                    // then, and the run ends in NoSuchElementException (:118, the active set ran empty) or returns a list in
+                    // which a sequence belongs to two clusters -- nothing an int32 cluster_id[n] can reproduce.
+                    if (err)
+                        *err = "the reference's nearest-neighbour chain returns to cluster " + std::to_string(nearest) +
+                               ", which is still on its stack (ClinkageSequenceClusterer.java:96-113 has no check): it goes on with a "
+                               "stale Cluster object and throws NoSuchElementException (:118) or returns a sequence in two clusters";
+                    return HMK_ERR_REFERENCE_WOULD_CRASH;
+                }
                 stack.push_back(nearest);             // :113
+                on_stack[nearest] = 1;
             }
         }
     }

@@ -255,7 +255,11 @@ typedef struct {
  * The cacheSizeLimit of -L/--cache_size_limit never reaches the clusterer in the reference (Hammock.java:459 uses the
  * two-argument constructor), so there is no such parameter.  Needs a symmetric matrix (HMK_ERR_BAD_ARG otherwise: the
  * reference's score cache is keyed by the unordered pair, so with score(a,b) != score(b,a) its result depends on which
- * direction happened to be asked first).  An empty input is HMK_ERR_REFERENCE_WOULD_CRASH (NoSuchElementException, :118). */
+ * direction happened to be asked first).  An empty input is HMK_ERR_REFERENCE_WOULD_CRASH (NoSuchElementException, :118).
+ * So is an input on which the reference's chain returns to a cluster that is still on its stack (a tie of score, size
+ * and id order, :96-113 pushes it again): the reference then works with a stale Cluster object and throws
+ * NoSuchElementException or returns a list in which a sequence belongs to two clusters -- there is no cluster_id[] for
+ * that (hmk_last_error names the cluster; four 6-mers suffice, tests/test_oracle.py). */
 int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int32_t *cluster_id,
                          int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats);
 

@@ -647,6 +647,7 @@ int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *o
     int32_t *slot_of = (int32_t *)malloc(((size_t)max_id + 1) * sizeof(int32_t));
     char *alive = (char *)calloc((size_t)max_id + 1, 1);
     int32_t *stack = (int32_t *)malloc(((size_t)n + 2) * sizeof(int32_t));
+    char *on_stack = (char *)calloc((size_t)max_id + 1, 1);
     /* memo[slot a][slot b], a > b: INT_MAX = unknown */
     int32_t **memo = (int32_t **)calloc(n, sizeof(int32_t *));
     int32_t *active_ids = (int32_t *)malloc((size_t)n * sizeof(int32_t));
@@ -654,7 +655,7 @@ int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *o
     jset_t active, ready;
     memset(&active, 0, sizeof(active));
     memset(&ready, 0, sizeof(ready));
-    if (!cl || !slot_of || !alive || !stack || !memo || !active_ids || !scores) { status = HMO_ERR_OOM; goto done; }
+    if (!cl || !slot_of || !alive || !stack || !on_stack || !memo || !active_ids || !scores) { status = HMO_ERR_OOM; goto done; }
     if ((status = jset_init(&active, max_id)) || (status = jset_init(&ready, max_id))) goto done;
     for (uint32_t a = 0; a < n; a++) {
         memo[a] = (int32_t *)malloc(((size_t)a + 1) * sizeof(int32_t));
@@ -674,6 +675,7 @@ int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *o
     int64_t sp = 0;
     while (active.size > 1) { /* :63 */
         stack[sp++] = jset_first(&active); /* :70-71 */
+        on_stack[stack[sp - 1]] = 1;
         while (sp > 0) {                   /* :72 */
             const int32_t top = stack[sp - 1];
             /* findNearestClusterParallel(activeClusters, top, ..) = arg-max over the OTHER active clusters of
@@ -722,6 +724,7 @@ int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *o
             }
             if (nearest < 0 || max_score < threshold) { /* :86-92 */
                 sp--;
+                on_stack[top] = 0;
                 if ((status = jset_add(&ready, top))) goto done;
                 jset_remove(&active, top);
                 continue;
@@ -729,6 +732,7 @@ int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *o
             if (sp > 1 && stack[sp - 2] == nearest) { /* :96 */
                 current_id++;
                 sp -= 2;
+                on_stack[top] = on_stack[nearest] = 0;
                 jset_remove(&active, top);
                 jset_remove(&active, nearest);
                 /* join (:102): the merged cluster's scores are the element-wise min of the two rows where both are
@@ -750,7 +754,14 @@ int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *o
                 if ((status = jset_add(&active, current_id))) goto done;
                 stats->merges++;
             } else {
+                /* A tie (score, size, smaller id) can send the chain back to a cluster that is still on the stack below
+                 * stack[-2].  The reference pushes it again (:113), merges or retires the upper copy and later takes the
+                 * stale Cluster object below as `top`: the run then ends in NoSuchElementException (:118) or returns a list
+                 * in which a sequence belongs to two clusters (oracle/hammock_oracle.py does exactly that).  Neither fits
+                 * cluster_id[n]: flagged like the other inputs on which the reference does not produce a clustering. */
+                if (on_stack[nearest]) { status = HMO_ERR_REFERENCE_WOULD_CRASH; goto done; }
                 stack[sp++] = nearest; /* :113 */
+                on_stack[nearest] = 1;
             }
         }
     }
@@ -772,7 +783,7 @@ int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *o
 done:
     if (cl)
         for (uint32_t i = 0; i <= max_id; i++) free(cl[i].members);
-    free(cl); free(slot_of); free(alive); free(stack); free(active_ids); free(scores);
+    free(cl); free(slot_of); free(alive); free(stack); free(on_stack); free(active_ids); free(scores);
     if (memo) { for (uint32_t a = 0; a < n; a++) free(memo[a]); free(memo); }
     if (active.next) jset_free(&active);
     if (ready.next) jset_free(&ready);

@@ -765,6 +765,31 @@ def test_clinkage_edge_cases(gpu, blosum62, coracle):
     assert "symmetric" in str(ei.value)
 
 
+def test_clinkage_chain_returns_to_a_stacked_cluster_gpu(gpu, matrices, coracle, tmp_path):
+    """The inputs of tests/test_oracle.py::test_clinkage_chain_returns_to_a_stacked_cluster through hmk_clinkage_cluster and
+    `hammock-hip clinkage`: the reference throws NoSuchElementException or returns sequences in two clusters there; the
+    product refuses with HMK_ERR_REFERENCE_WOULD_CRASH and the CLI ends the way Hammock.main reports an exception."""
+    import subprocess
+    M = matrices["blosum75"]
+    four = ["TTKFVE", "DTKFVE", "QTKFVE", "ETKFVE"]
+    for strings in (four, four + ["WWWWWW", "CCCCCC", "WWWWWC"]):
+        ctx, _, _ = ctx_for(M, strings)
+        with pytest.raises(hammock_amd.ReferenceWouldCrash, match="still on its stack"):
+            ctx.clinkage_cluster(2, -2, 19)
+        cid, order, stats = ctx.clinkage_cluster(2, -2, 25)          # no tie on the way at this threshold
+        res, off = coracle.pack(strings)
+        st, ocid, oorder, orank, ostats = coracle.clinkage_cluster(M, res, off, None, 2, -2, 25, 1)
+        assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+    fasta = tmp_path / "four.fa"
+    fasta.write_text("".join(f">{k}\n{q}\n" for k, q in enumerate(four)))
+    mfile = tmp_path / "blosum75.txt"
+    mfile.write_text("\n".join("X " + " ".join(str(int(v)) for v in row) for row in M) + "\n")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hammock_amd", "bin", "hammock-hip")
+    run = subprocess.run([exe, "clinkage", "-i", str(fasta), "-d", str(tmp_path / "out"), "-m", str(mfile), "-x", "2", "-p", "-2", "-g", "19"],
+                         capture_output=True, text=True)
+    assert run.returncode != 0 and "still on its stack" in run.stderr
+
+
 def test_python_mirror_clinkage_clusterer(gpu, blosum62, coracle):
     """HipClinkageSequenceClusterer: the ClinkageSequenceClusterer(scorer, threshold).cluster(List) contract."""
     res, off = synth_peptides(8, 1500, 12)

@@ -172,6 +172,26 @@ def test_clinkage_from_edges_matches_oracle(blosum62, coracle, seed):
     assert (stats.merges, stats.searches) == (ostats.merges, ostats.searches)
 
 
+def test_clinkage_from_edges_chain_returns_to_a_stacked_cluster(matrices, coracle):
+    """tests/test_oracle.py::test_clinkage_chain_returns_to_a_stacked_cluster through the product's chain: the input on
+    which the reference throws NoSuchElementException and the one on which it returns sequences in two clusters are both
+    refused with HMK_ERR_REFERENCE_WOULD_CRASH; at a threshold without the tie the four peptides cluster as in the oracle."""
+    M = matrices["blosum75"]
+    four = ["TTKFVE", "DTKFVE", "QTKFVE", "ETKFVE"]
+    for strings in (four, four + ["WWWWWW", "CCCCCC", "WWWWWC"]):
+        res, off = coracle.pack(strings)
+        ctx = hammock_amd.Context(M, device=-1)
+        ctx.set_sequences(residues=res, offsets=off)
+        with pytest.raises(hammock_amd.ReferenceWouldCrash, match="still on its stack"):
+            ctx.clinkage_from_edges(oracle_edges(coracle, M, res, off, 2, -2, 19, True))
+    res, off = coracle.pack(four)
+    ctx = hammock_amd.Context(M, device=-1)
+    ctx.set_sequences(residues=res, offsets=off)
+    cid, order, stats = ctx.clinkage_from_edges(oracle_edges(coracle, M, res, off, 2, -2, 25, True))
+    st, ocid, oorder, orank, ostats = coracle.clinkage_cluster(M, res, off, None, 2, -2, 25, 1)
+    assert st == 0 and np.array_equal(cid, ocid) and np.array_equal(order, oorder) and stats.merges == ostats.merges == 1
+
+
 def test_clinkage_from_edges_errors(blosum62, coracle):
     ctx = hammock_amd.Context(blosum62, device=-1)
     with pytest.raises(hammock_amd.ReferenceWouldCrash):

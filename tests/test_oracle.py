@@ -365,3 +365,36 @@ def test_clinkage_known_small_case(blosum62, coracle):
     assert sorted(rank[:3].tolist()) == [0, 1, 2]
     st, *_ = coracle.clinkage_cluster(blosum62, *coracle.pack([]), None, 0, 0, 10, 1)
     assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH   # NoSuchElementException, ClinkageSequenceClusterer.java:118
+
+
+STACKED_AGAIN = ["TTKFVE", "DTKFVE", "QTKFVE", "ETKFVE"]          # BLOSUM75, X = 2, p = -2, thr = 19: found by fuzzing
+STACKED_AGAIN_PLUS = STACKED_AGAIN + ["WWWWWW", "CCCCCC", "WWWWWC"]
+
+
+def test_clinkage_chain_returns_to_a_stacked_cluster(matrices, coracle):
+    """A tie (score, then Cluster.size(), then the smaller id) can send the reference's nearest-neighbour chain back to a
+    cluster that is still on its stack, below stack[-2]; ClinkageSequenceClusterer.java:96-113 pushes it again, merges the
+    upper copy and later takes the stale Cluster object below as `top`.  The literal restatement shows what follows:
+    with nothing else left the active set runs empty and :118 throws NoSuchElementException; with other clusters around
+    the run "succeeds" with sequences that belong to two clusters (mergedSequences aliases top's own list, :105).
+    Neither is a clustering: the C oracle flags the first return to a stacked cluster."""
+    M = matrices["blosum75"]
+    def literal(strings):
+        seqs = [po.UniqueSequence(s, {"no_label": 1}) for s in strings]
+        cl = po.ClinkageSequenceClusterer(po.ShiftedScorer(M.tolist(), -2, 2), 19, size_limit=1, n_threads=1)
+        return seqs, cl.cluster(seqs)
+    with pytest.raises(po.NoSuchElement):
+        literal(STACKED_AGAIN)
+    seqs, result = literal(STACKED_AGAIN_PLUS)
+    memberships = [id(s) for c in result for s in c.sequences]
+    assert len(memberships) > len(seqs) and len(set(memberships)) == len(seqs)     # every sequence is there, three of them twice
+    for strings in (STACKED_AGAIN, STACKED_AGAIN_PLUS):
+        res, off = coracle.pack(strings)
+        for threads in (1, 3):
+            st, *_ = coracle.clinkage_cluster(M, res, off, None, 2, -2, 19, threads)
+            assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH
+    # the same four peptides at a threshold that keeps TTKFVE (24 to all others) out: no tie on the way, an ordinary result
+    # (QTKFVE + ETKFVE at 27; DTKFVE stays alone: 24 to QTKFVE)
+    res, off = coracle.pack(STACKED_AGAIN)
+    st, cid, order, rank, stats = coracle.clinkage_cluster(M, res, off, None, 2, -2, 25, 1)
+    assert st == 0 and stats.merges == 1 and cid.tolist() == [1, 2, 6, 6]
