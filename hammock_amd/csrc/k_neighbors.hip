@@ -429,11 +429,16 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
             // Positions are taken in pairs (one v_add3 per accumulator dword and pair).  An odd column length puts its
             // single position FIRST, so that each variant is a chain of nested wave-uniform `if`s around in-place adds --
             // an `if / else if` per pair made the compiler copy all R x NW accumulators on every skipped pair.
+            // a fresh scalar copy of lb per batch: the length tests below stay s_cmp + s_cbranch_scc.  Hoisted out of the
+            // batch loop they become 64-bit lane masks, more of them than there are SGPRs, and each test then starts with
+            // two v_readlane of a spilled mask (14 % of the VALU instructions of the accumulation, <3,4,12> ISA)
+            int lbs = lb;
+            asm volatile("" : "+s"(lbs));
             auto add_pairs = [&](auto start_tag) {
                 constexpr int J0 = decltype(start_tag)::value;
 #pragma unroll
                 for (int j = J0; j + 1 < LBMAX; j += 2) {
-                    if (j + 1 >= lb) break;                     // wave-uniform: nothing beyond this position
+                    if (j + 1 >= lbs) break;                    // wave-uniform: nothing beyond this position
                     uint32_t e0[R][NW], e1[R][NW];
                     read_position(j, e0);
                     read_position(j + 1, e1);
@@ -443,7 +448,7 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
                         for (int w = 0; w < NW; w++) W[r][w] = W[r][w] + e0[r][w] + e1[r][w];
                 }
             };
-            if (lb & 1) {
+            if (lbs & 1) {
                 uint32_t e0[R][NW];
                 read_position(0, e0);
 #pragma unroll
