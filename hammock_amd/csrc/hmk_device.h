@@ -121,6 +121,31 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Wave priority (s_setprio) in the neighbour kernels.  A wave that is issuing table reads goes ahead of the waves of its SIMD
+// that are testing accumulators or staging hits, so the LDS queue -- the unit that bounds these kernels -- is fed first
+// (length-12 kernel: 3.329 -> 3.297 ms, 0.917 -> 0.926 of the LDS peak with priority 2; 1 and 3 gave 3.304 / 3.309 ms).  A
+// wave that drains its stage goes ahead of everything: the drain is a chain of round trips (segment counter, then -- when the
+// pass also places the edges in the CSR -- two returning atomics per edge), and at the lowest priority its few instructions
+// waited behind every other wave's VALU work.  -DHMK_SETPRIO=0 builds without any of it.
+#ifndef HMK_SETPRIO
+#define HMK_SETPRIO 2
+#endif
+#ifndef HMK_SETPRIO_PLACE
+#define HMK_SETPRIO_PLACE 0
+#endif
+__device__ __forceinline__ void read_phase_begin(bool on) {
+    if (HMK_SETPRIO > 0 && on) __builtin_amdgcn_s_setprio(HMK_SETPRIO);
+}
+__device__ __forceinline__ void read_phase_end(bool on) {
+    if (HMK_SETPRIO > 0 && on) __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void drain_begin() {
+    if (HMK_SETPRIO > 0) __builtin_amdgcn_s_setprio(3);
+}
+__device__ __forceinline__ void drain_end() {
+    if (HMK_SETPRIO > 0) __builtin_amdgcn_s_setprio(0);
+}
+
 // The CSR place of a stored edge (NeighborParams::deg): its rank in row x's upper section and in row m's lower one.  Only
 // STORED edges are placed: an edge dropped by a segment overflow must not be counted, or the CSR sized from the counters
 // (its scatter is enqueued before the host notices the overflow) would expect entries that are not there.
@@ -200,6 +225,7 @@ template <int MODE>
 __device__ __forceinline__ void flush_stage_compact(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
                                                     const Tile &T, int threshold, uint32_t shard) {
     if (cnt == 0) return;
+    drain_begin();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
     const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage)
     unsigned long long base = 0;
@@ -221,6 +247,7 @@ __device__ __forceinline__ void flush_stage_compact(const HMK_LDS uint32_t *stag
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
+    drain_end();
 }
 
 // The same for the plane kernels, whose lanes may be 16 bits wide: `rec_dw` (wave-uniform) is 1 for the record above with
@@ -230,6 +257,7 @@ template <bool DEG>
 __device__ __forceinline__ void flush_stage_packed(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
                                                    const Tile &T, int base_score, uint32_t rec_dw, uint32_t shard) {
     if (cnt == 0) return;
+    drain_begin();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
     const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage)
     unsigned long long base = 0;
@@ -251,6 +279,7 @@ __device__ __forceinline__ void flush_stage_packed(const HMK_LDS uint32_t *stage
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
+    drain_end();
 }
 
 // largest of the eight byte lanes of two accumulator dwords

@@ -140,6 +140,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
             if ((uint32_t)r < T.nrows) {
                 // all CPL accumulations first (CPL * LB independent LDS reads in flight), tests after
                 uint32_t W[CPL][NW];
+                read_phase_begin(DEG != EDGES_PLACE || HMK_SETPRIO_PLACE);
 #pragma unroll
                 for (int p = 0; p < CPL; p++) {
 #pragma unroll
@@ -164,6 +165,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
                         }
                     }
                 }
+                read_phase_end(DEG != EDGES_PLACE || HMK_SETPRIO_PLACE);
 #pragma unroll
                 for (int p = 0; p < CPL; p++) {
                     uint32_t any = W[p][0];
@@ -285,6 +287,7 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
     // hit records (hmk_device.h flush_stage_packed): one dword when score - threshold fits 12 bits -- always with 8-bit lanes,
     // where it is lane - 128 -- else two
     const uint32_t rec_dw = lane16 ? 2u : 1u;
+    const bool prio = P.rank == nullptr || HMK_SETPRIO_PLACE;   // wave priority for the read phase (hmk_device.h), wave-uniform
     const int base_score = (lane16 ? 32768 : 128) - g;   // the score of a lane that just reaches the threshold
 
     for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
@@ -448,6 +451,7 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
                         for (int w = 0; w < NW; w++) W[r][w] = W[r][w] + e0[r][w] + e1[r][w];
                 }
             };
+            read_phase_begin(prio);
             if (lbs & 1) {
                 uint32_t e0[R][NW];
                 read_position(0, e0);
@@ -460,6 +464,7 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
                 add_pairs(std::integral_constant<int, 0>{});
             }
 
+            read_phase_end(prio);
             // ---- threshold test: some shift lane has its top bit set <=> score >= threshold ----
             // one combined test for the R rows first: most batches hold no hit at all
             uint32_t all = 0;
