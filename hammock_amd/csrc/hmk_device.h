@@ -126,7 +126,10 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 // (length-12 kernel: 3.329 -> 3.297 ms, 0.917 -> 0.926 of the LDS peak with priority 2; 1 and 3 gave 3.304 / 3.309 ms).  A
 // wave that drains its stage goes ahead of everything: the drain is a chain of round trips (segment counter, then -- when the
 // pass also places the edges in the CSR -- two returning atomics per edge), and at the lowest priority its few instructions
-// waited behind every other wave's VALU work.  -DHMK_SETPRIO=0 builds without any of it.
+// waited behind every other wave's VALU work (-DHMK_SETPRIO_DRAIN=0: within the noise on the plain pass, 3.296-3.300 against
+// 3.291-3.295 ms).  A priority for the batch's column fetch + unpack changed nothing either.  Passes that place the edges in the
+// CSR keep equal priorities for the read phase: with them the 10^5 call scored in 4.50 instead of 4.40 ms (3 x 10^5: 33.0 against
+// 33.3 ms), -DHMK_SETPRIO_PLACE=1.  -DHMK_SETPRIO=0 builds without any of it (tools/ab_setprio.sh rebuilds and times the variants).
 #ifndef HMK_SETPRIO
 #define HMK_SETPRIO 2
 #endif
@@ -139,11 +142,14 @@ __device__ __forceinline__ void read_phase_begin(bool on) {
 __device__ __forceinline__ void read_phase_end(bool on) {
     if (HMK_SETPRIO > 0 && on) __builtin_amdgcn_s_setprio(0);
 }
+#ifndef HMK_SETPRIO_DRAIN
+#define HMK_SETPRIO_DRAIN 3
+#endif
 __device__ __forceinline__ void drain_begin() {
-    if (HMK_SETPRIO > 0) __builtin_amdgcn_s_setprio(3);
+    if (HMK_SETPRIO > 0 && HMK_SETPRIO_DRAIN > 0) __builtin_amdgcn_s_setprio(HMK_SETPRIO_DRAIN);
 }
 __device__ __forceinline__ void drain_end() {
-    if (HMK_SETPRIO > 0) __builtin_amdgcn_s_setprio(0);
+    if (HMK_SETPRIO > 0 && HMK_SETPRIO_DRAIN > 0) __builtin_amdgcn_s_setprio(0);
 }
 
 // The CSR place of a stored edge (NeighborParams::deg): its rank in row x's upper section and in row m's lower one.  Only

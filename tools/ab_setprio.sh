@@ -1,15 +1,17 @@
 #!/bin/bash
-# A/B on the GPU box: rebuild the library with different wave-priority settings and time the greedy call at 1e5 / 3e5
+# A/B on the GPU box: rebuilds the library with different wave-priority settings (hmk_device.h) and times the plain pass of
+# the BASELINE workload and of config 4a; leaves the LAST variant built (run `make -C hammock_amd/csrc -B` afterwards).
+#   gpurun -- 'bash tools/ab_setprio.sh'
 F="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p gpurun_out/ab
-for v in "0 0" "2 1" "2 0" "0 0" "2 0"; do
-  set -- $v
+B="python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-greedy"
+for v in "" "-DHMK_SETPRIO=0" "-DHMK_SETPRIO_DRAIN=0" "-DHMK_SETPRIO=1" "-DHMK_SETPRIO=3" "" "-DHMK_SETPRIO=0"; do
   touch hammock_amd/csrc/k_neighbors.hip
-  make -C hammock_amd/csrc CXXFLAGS="$F -DHMK_SETPRIO=$1 -DHMK_SETPRIO_PLACE=$2" > gpurun_out/ab/make.log 2>&1 || exit 1
-  timeout -k 10 120 python tools/greedy_phases.py 100000 100000 300000 > gpurun_out/ab/gp_$1_$2.jsonl 2>/dev/null
+  make -C hammock_amd/csrc CXXFLAGS="$F $v" > gpurun_out/ab/make.log 2>&1 || exit 1
+  $B > gpurun_out/ab/b.json 2>/dev/null
+  timeout -k 10 100 python tools/run_config4a.py > gpurun_out/ab/c4a.json 2>/dev/null
   python -c "
-import json,sys
-for l in open('gpurun_out/ab/gp_$1_$2.jsonl'):
-    d=json.loads(l)
-    if d['call']>0: print('prio $1 place $2', d['n'], d['call'], round(d['wall_ms'],2), round(d['score_ms'],2))"
+import json
+d=json.load(open('gpurun_out/ab/b.json')); c=json.load(open('gpurun_out/ab/c4a.json'))
+print('[$v]', round(d['roofline']['kernel_ms'],4), round(d['roofline']['frac'],4), '4a', round(c['ms_median'],3), round(c['ms_min'],3))"
 done
