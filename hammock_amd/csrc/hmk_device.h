@@ -129,7 +129,7 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 // waited behind every other wave's VALU work (-DHMK_SETPRIO_DRAIN=0: within the noise on the plain pass, 3.296-3.300 against
 // 3.291-3.295 ms).  A priority for the batch's column fetch + unpack changed nothing either.  Passes that place the edges in the
 // CSR keep equal priorities for the read phase: with them the 10^5 call scored in 4.50 instead of 4.40 ms (3 x 10^5: 33.0 against
-// 33.3 ms), -DHMK_SETPRIO_PLACE=1.  -DHMK_SETPRIO=0 builds without any of it (tools/ab_setprio.sh rebuilds and times the variants).
+// 33.3 ms), -DHMK_SETPRIO_PLACE=1.  -DHMK_SETPRIO=0 builds without any of it (tools/ab_flags.sh rebuilds and times the variants).
 #ifndef HMK_SETPRIO
 #define HMK_SETPRIO 2
 #endif
