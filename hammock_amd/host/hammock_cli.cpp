@@ -306,9 +306,14 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
                             "column of multi-member clusters is NA)");
         logger.logAndStderr("Ready. Total time: " + std::to_string(ms()));                     // :427
         logger.logAndStderr("Saving results to output files...");
-        FileIOManager::saveClusterSequencesToCsv(clusters, initialClustersSequencesCsv, labels);                              // :429
-        FileIOManager::saveClusterSequencesToCsvOrdered(clusters, initialClustersSequencesOrderedCsv, labels, initialSequences);  // :431
-        FileIOManager::SaveClustersToCsv(clusters, initialClusters, labels);                                                  // :432
+        if (std::getenv("HMK_CLI_SERIAL_WRITERS")) {   // the reference's three calls in a row
+            FileIOManager::saveClusterSequencesToCsv(clusters, initialClustersSequencesCsv, labels);                              // :429
+            FileIOManager::saveClusterSequencesToCsvOrdered(clusters, initialClustersSequencesOrderedCsv, labels, initialSequences);  // :431
+            FileIOManager::SaveClustersToCsv(clusters, initialClusters, labels);                                                  // :432
+        } else {                                       // the same three files written side by side
+            FileIOManager::saveInitialClusters(clusters, initialClustersSequencesCsv, initialClustersSequencesOrderedCsv, initialClusters,
+                                               labels, initialSequences);
+        }
         logger.logAndStderr(std::string(clinkage ? "Clinkage" : "Greedy") + " clustering results in: " + initialClusters);
         logger.logAndStderr("and: " + initialClustersSequencesCsv);
         logger.logAndStderr("and: " + initialClustersSequencesOrderedCsv);
