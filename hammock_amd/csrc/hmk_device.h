@@ -129,7 +129,12 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 // waited behind every other wave's VALU work (-DHMK_SETPRIO_DRAIN=0: within the noise on the plain pass, 3.296-3.300 against
 // 3.291-3.295 ms).  A priority for the batch's column fetch + unpack changed nothing either.  Passes that place the edges in the
 // CSR keep equal priorities for the read phase: with them the 10^5 call scored in 4.50 instead of 4.40 ms (3 x 10^5: 33.0 against
-// 33.3 ms), -DHMK_SETPRIO_PLACE=1.  -DHMK_SETPRIO=0 builds without any of it (tools/ab_flags.sh rebuilds and times the variants).
+// 33.3 ms), -DHMK_SETPRIO_PLACE=1.  A tile's table build runs at
+// priority 3 as well (HMK_SETPRIO_BUILD): until its tables stand a workgroup contributes no table reads at all, and at priority 0
+// its build waited behind the other workgroups' read phases -- mixed lengths (short tiles: a build every 28 batches) 5.29 ->
+// 5.21 ms on one box, the length-12 pass 3.320 -> 3.298 ms; priorities 1 / 2 for the build gave 5.29 / 5.28 ms.  Moving the start
+// of the read phase of the mixed-length kernel up to the batch's column fetch changed nothing.
+// -DHMK_SETPRIO=0 builds without any of it (tools/ab_flags.sh rebuilds and times the variants).
 #ifndef HMK_SETPRIO
 #define HMK_SETPRIO 2
 #endif
@@ -141,6 +146,15 @@ __device__ __forceinline__ void read_phase_begin(bool on) {
 }
 __device__ __forceinline__ void read_phase_end(bool on) {
     if (HMK_SETPRIO > 0 && on) __builtin_amdgcn_s_setprio(0);
+}
+#ifndef HMK_SETPRIO_BUILD
+#define HMK_SETPRIO_BUILD 3
+#endif
+__device__ __forceinline__ void build_begin() {   // a tile's table build
+    if (HMK_SETPRIO > 0 && HMK_SETPRIO_BUILD > 0) __builtin_amdgcn_s_setprio(HMK_SETPRIO_BUILD);
+}
+__device__ __forceinline__ void build_end() {
+    if (HMK_SETPRIO > 0 && HMK_SETPRIO_BUILD > 0) __builtin_amdgcn_s_setprio(0);
 }
 #ifndef HMK_SETPRIO_DRAIN
 #define HMK_SETPRIO_DRAIN 3

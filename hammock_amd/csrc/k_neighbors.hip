@@ -58,6 +58,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
     const int wave = tid >> 6;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + wave * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
+    build_begin();
     // ---- stage the matrix and the row residues ---------------------------------
     for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
     for (int e = tid; e < R * 32; e += 256) {
@@ -97,6 +98,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
         }
     }
     __syncthreads();
+    build_end();
 
     uint32_t cinit[NW];
 #pragma unroll
@@ -290,6 +292,7 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
     const bool prio = P.rank == nullptr || HMK_SETPRIO_PLACE;   // wave priority for the read phase (hmk_device.h), wave-uniform
     const int base_score = (lane16 ? 32768 : 128) - g;   // the score of a lane that just reaches the threshold
 
+    build_begin();
     for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
     for (int e = tid; e < R * 32; e += 256) {
         const int r = e >> 5, k = e & 31;
@@ -368,6 +371,7 @@ __global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const
         }
     }
     __syncthreads();
+    build_end();
 
     uint32_t cinit[NW];
 #pragma unroll
