@@ -35,7 +35,7 @@ struct Group {
 // grow-only device scratch of the greedy tail (one hipMalloc per buffer and context, not per call)
 struct DevBuf { void *p = nullptr; size_t cap = 0; };
 enum {
-    SB_DEG, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ,                       // full CSR
+    SB_DEG, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ, SB_PART, SB_PARTSCR,   // full CSR (+ the bucketed lower sections)
     SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
@@ -1306,6 +1306,15 @@ struct EdgeSource {
     hmk_clinkage_stats *clink = nullptr;   // non-null: run the clinkage nearest-neighbour chain instead of the greedy merge
 };
 
+// The CSR scatter with its lower sections dealt by bucket (k_edges.hip, k_lower_*): for graphs whose scatter is bound by random
+// writes.  Packed symmetric adjacency only; edges that were placed while they were written have their own atomic-free scatter.
+// HMK_CSR_BY_BUCKET=0|1 overrides the size rule (the tests force it at small sizes).
+static bool csr_by_bucket(uint32_t n, bool symmetric, bool packed, bool placed) {
+    if (!symmetric || !packed || placed) return false;
+    if (const char *v = getenv("HMK_CSR_BY_BUCKET")) return atoi(v) != 0;
+    return n > 500000;
+}
+
 // Builds the CSR adjacency on the device, hands rows to the host merge on demand, runs the merge.
 int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int32_t *cluster_id, int32_t *result_order,
                       int32_t *member_rank, hmk_greedy_stats *stats, std::chrono::steady_clock::time_point t0) {
@@ -1354,6 +1363,15 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     bool scatter_enqueued = false;
     auto enqueue_scatter = [&]() -> hipError_t {
         scatter_enqueued = true;
+        if (csr_by_bucket(n, symmetric, packed, src.deg_fused && src.placed)) {   // large graphs: lower sections dealt by bucket
+            hipError_t e = ensure_buf(ctx, SB_PART, std::max<uint64_t>(src.adj_bound / 2, 1) * 8);   // in place already (hmk_greedy_cluster)
+            if (e == hipSuccess) e = ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes());
+            if (e == hipSuccess)
+                e = launch_csr_scatter_partitioned(src.segs, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
+                                                   base, n, buf<uint64_t>(ctx, SB_PART), buf<void>(ctx, SB_PARTSCR), S);
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
+            return e;
+        }
         hipError_t e = src.deg_fused && src.placed
                            ? launch_csr_scatter_ranked(src.segs, src.edges0, buf<uint32_t>(ctx, SB_RANK), symmetric, buf<uint64_t>(ctx, SB_START),
                                                        buf<void>(ctx, SB_ADJ), packed, base, S)
@@ -1922,6 +1940,14 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
                 HIPCHK(ctx, ensure_buf(ctx, SB_BSTART, ((size_t)r1 + 1) * 8));
                 HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(r1)));
                 HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
+            }
+            {
+                bool place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && n <= 500000;
+                if (const char *v = getenv("HMK_PLACE_EDGES")) place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && atoi(v) != 0;
+                if (csr_by_bucket(n, ctx->symmetric, src.packed, place0)) {
+                    HIPCHK(ctx, ensure_buf(ctx, SB_PART, std::max<uint64_t>(ctx->d_edges_cap, 1) * 8));
+                    HIPCHK(ctx, ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes()));
+                }
             }
             HIPCHK(ctx, ensure_buf(ctx, SB_COF, (size_t)n * 4));
             HIPCHK(ctx, ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4));

@@ -153,7 +153,7 @@ static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *til
 // the upper section grows from the row's start, the lower one backwards from its end, so no per-row split point has
 // to be known beforehand -- afterwards cursor[r] IS the number of upper neighbours ("up[r]").  Consumers that only
 // care about later (larger-id) neighbours walk just the first section.
-template <class NbrT>
+template <class NbrT, bool LOWER = true>   // LOWER = false: the upper sections only (the lower ones by bucket, below)
 __global__ void __launch_bounds__(256)
 k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, NbrT *__restrict__ adj,
                int symmetric, int base, uint32_t row_limit) {
@@ -174,7 +174,7 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t
         if (vx && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
         basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
         if (!valid) continue;
-        const bool vm = symmetric && m < row_limit;
+        const bool vm = LOWER && symmetric && m < row_limit;
         if constexpr (sizeof(NbrT) == 4) {
             const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
             if (vx) adj[start[x] + basex + g.rank] = NbrT{(m << 8) | rel};
@@ -184,6 +184,151 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t
             if (vm) adj[start[m + 1] - 1 - atomicAdd(&cursor[row_limit + m], 1u)] = NbrT{x, s};
         }
     }
+}
+
+// ---- the lower sections by bucket ----------------------------------------------------------------------------------------
+// At 10^6 sequences the scatter above is bound by its random 4-byte writes: the lower section of a row receives its 1,300
+// entries one at a time over the whole pass, every write is a partial line in HBM (63-71 ms for 1.28 x 10^9 edges, with or
+// without atomics).  Here the (row m, entry) records are first dealt into buckets of 2^shift consecutive rows -- by a few fat
+// workgroups, so that the lines they have open (one per bucket and workgroup) stay in their XCD's L2 until they are full --
+// and then one workgroup per bucket places its records with LDS counters: all its writes fall into the bucket's own few MB of
+// the adjacency.  Three streaming passes over the edges instead of one pass of random writes.
+constexpr uint32_t LB_MAX_BUCKETS = 4096;   // LDS tables of the partition kernel: 2 x 16 KB
+constexpr uint32_t LB_MAX_ROWS = 4096;      // rows of a bucket (shift <= 12)
+constexpr uint32_t LB_CHUNK = 65536;        // edges a workgroup deals at a time
+
+__global__ void __launch_bounds__(1024)
+k_lower_count(const EdgeSegs segs, uint32_t shift, uint32_t nb, unsigned long long *__restrict__ bucket_cnt) {
+    __shared__ uint32_t hist[LB_MAX_BUCKETS];
+    for (uint32_t b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t sgi = 0; sgi < segs.n; sgi++) {
+        const EdgeSeg sg = segs.s[sgi];
+        const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
+        // four loads in flight per thread: with one, a workgroup moves 8 KB per memory round trip
+        const uint64_t stride = (uint64_t)gridDim.x * 1024;
+        for (uint64_t k = (uint64_t)blockIdx.x * 1024 + threadIdx.x; k < cnt; k += 4 * stride) {
+            uint64_t e[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) e[q] = k + q * stride < cnt ? sg.edges[k + q * stride] : ~0ull;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (e[q] != ~0ull) atomicAdd(&hist[max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q])) >> shift], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += 1024)
+        if (hist[b]) atomicAdd(&bucket_cnt[b], (unsigned long long)hist[b]);
+}
+
+// bucket_off[0 .. nb] = exclusive prefix sums of bucket_cnt; bucket_fill[] = 0
+__global__ void __launch_bounds__(1024)
+k_lower_offsets(const unsigned long long *__restrict__ bucket_cnt, uint32_t nb, unsigned long long *__restrict__ bucket_off,
+                unsigned long long *__restrict__ bucket_fill) {
+    __shared__ unsigned long long part[1024];
+    constexpr uint32_t PER = LB_MAX_BUCKETS / 1024;
+    unsigned long long v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t b = threadIdx.x * PER + q;
+        v[q] = b < nb ? bucket_cnt[b] : 0;
+        sum += v[q];
+    }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        const unsigned long long add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    unsigned long long run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t b = threadIdx.x * PER + q;
+        if (b < nb) { bucket_off[b] = run; bucket_fill[b] = 0; }
+        run += v[q];
+    }
+    if (threadIdx.x == 1023) bucket_off[nb] = part[1023];
+}
+
+// records: row m << 32 | the packed entry (x << 8 | score - base) of m's lower section
+__global__ void __launch_bounds__(1024)
+k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, int base, const unsigned long long *__restrict__ bucket_off,
+                  unsigned long long *__restrict__ bucket_fill, uint64_t *__restrict__ recs) {
+    __shared__ uint32_t hist[LB_MAX_BUCKETS];
+    __shared__ uint32_t first[LB_MAX_BUCKETS];   // where this chunk's records of a bucket start, relative to bucket_off (< 2^32: a bucket holds < 2^12 rows x 2^20)
+    uint32_t g = blockIdx.x;                     // chunk index over the concatenated segments
+    for (uint32_t sgi = 0; sgi < segs.n; sgi++) {
+        const EdgeSeg sg = segs.s[sgi];
+        const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
+        const uint32_t chunks = (uint32_t)((cnt + LB_CHUNK - 1) / LB_CHUNK);
+        while (g < chunks) {
+            const uint64_t k0 = (uint64_t)g * LB_CHUNK;
+            const uint32_t len = (uint32_t)min((uint64_t)LB_CHUNK, cnt - k0);
+            for (uint32_t b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < len; k += 4096) {   // four loads in flight per thread
+                uint64_t e[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) e[q] = k + q * 1024 < len ? sg.edges[k0 + k + q * 1024] : ~0ull;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (e[q] != ~0ull) atomicAdd(&hist[max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q])) >> shift], 1u);
+            }
+            __syncthreads();
+            for (uint32_t b = threadIdx.x; b < nb; b += 1024) {
+                const uint32_t h = hist[b];
+                if (h) first[b] = (uint32_t)atomicAdd(&bucket_fill[b], (unsigned long long)h);
+                hist[b] = 0;
+            }
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < len; k += 4096) {   // the chunk again (512 KB: from the L2)
+                uint64_t ev[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) ev[q] = k + q * 1024 < len ? sg.edges[k0 + k + q * 1024] : ~0ull;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint64_t e = ev[q];
+                    if (e == ~0ull) continue;
+                    const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)), m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
+                    const uint32_t b = m >> shift;
+                    const uint32_t at = first[b] + atomicAdd(&hist[b], 1u);
+                    recs[bucket_off[b] + at] = ((uint64_t)m << 32) | (uint64_t)((x << 8) | ((uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu));
+                }
+            }
+            __syncthreads();
+            g += gridDim.x;
+        }
+        g -= chunks;
+    }
+}
+
+// one workgroup per bucket: the lower section of row m is filled backwards from the row's end, as k_edge_scatter does;
+// cursor[row_limit + m] receives its size
+__global__ void __launch_bounds__(512)
+k_lower_place(const uint64_t *__restrict__ recs, const unsigned long long *__restrict__ bucket_off, uint32_t shift, uint32_t n,
+              const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, uint32_t row_limit, NbrPacked *__restrict__ adj) {
+    __shared__ uint64_t row_end[LB_MAX_ROWS];
+    __shared__ uint32_t filled[LB_MAX_ROWS];
+    const uint32_t row0 = blockIdx.x << shift;
+    const uint32_t rows = min(1u << shift, n - row0);
+    for (uint32_t i = threadIdx.x; i < rows; i += 512) { row_end[i] = start[row0 + i + 1]; filled[i] = 0; }
+    __syncthreads();
+    const unsigned long long k1 = bucket_off[blockIdx.x + 1];
+    for (unsigned long long k = bucket_off[blockIdx.x] + threadIdx.x; k < k1; k += 4 * 512) {   // four loads in flight per thread
+        uint64_t rec[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) rec[q] = k + q * 512 < k1 ? recs[k + q * 512] : ~0ull;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (rec[q] == ~0ull) continue;
+            const uint32_t i = (uint32_t)(rec[q] >> 32) - row0;
+            adj[row_end[i] - 1 - atomicAdd(&filled[i], 1u)] = NbrPacked{(uint32_t)rec[q]};
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < rows; i += 512) cursor[row_limit + row0 + i] = filled[i];
 }
 
 // The same CSR from edges that were PLACED while they were written (NeighborParams::rank: every edge's rank inside its
@@ -964,6 +1109,35 @@ hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64
     else
         hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (Nbr *)adj,
                            symmetric ? 1 : 0, base, row_limit);
+    return hipGetLastError();
+}
+
+// The packed symmetric CSR with the lower sections dealt by bucket (k_lower_*): scratch = 3 x (LB_MAX_BUCKETS + 1) uint64,
+// recs = one uint64 per edge.  n < 2^24 (edge format), so 2^shift rows per bucket with shift <= 12 always give <= 4096 buckets.
+static uint32_t csr_partition_grid() {
+    if (const char *v = getenv("HMK_CSR_PARTITION_GRID")) return (uint32_t)std::max(1, atoi(v));
+    return 256;
+}
+uint32_t csr_partition_shift(uint32_t n) {
+    uint32_t shift = 9;
+    while (((uint64_t)n + (1u << shift) - 1) >> shift > LB_MAX_BUCKETS) shift++;
+    return shift;
+}
+size_t csr_partition_scratch_bytes() { return 3 * ((size_t)LB_MAX_BUCKETS + 1) * sizeof(unsigned long long); }
+hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *start, uint32_t *cursor, void *adj, int base, uint32_t n,
+                                          uint64_t *recs, void *scratch, hipStream_t s) {
+    const uint32_t shift = csr_partition_shift(n);
+    const uint32_t nb = (uint32_t)(((uint64_t)n + (1u << shift) - 1) >> shift);
+    if (shift > 12 || nb > LB_MAX_BUCKETS) return hipErrorInvalidValue;
+    unsigned long long *cnt = (unsigned long long *)scratch, *off = cnt + LB_MAX_BUCKETS + 1, *fill = off + LB_MAX_BUCKETS + 1;
+    hipError_t e = hipMemsetAsync(cnt, 0, (size_t)nb * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lower_count, dim3(512), dim3(1024), 0, s, segs, shift, nb, cnt);
+    hipLaunchKernelGGL(k_lower_offsets, dim3(1), dim3(1024), 0, s, cnt, nb, off, fill);
+    // one 1,024-thread workgroup per CU (10^6 sequences: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms)
+    hipLaunchKernelGGL(k_lower_partition, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, base, off, fill, recs);
+    hipLaunchKernelGGL((k_edge_scatter<NbrPacked, false>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj, 1, base, n);
+    hipLaunchKernelGGL(k_lower_place, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
     return hipGetLastError();
 }
 
