@@ -331,6 +331,68 @@ k_lower_place(const uint64_t *__restrict__ recs, const unsigned long long *__res
     for (uint32_t i = threadIdx.x; i < rows; i += 512) cursor[row_limit + row0 + i] = filled[i];
 }
 
+// The same for buckets of <= 512 rows, with full-line writes: a batch of 8,192 records is counting-sorted by row in LDS first, so a
+// row's entries of the batch (16 on average) leave as one run of consecutive addresses instead of 16 single dwords at 16
+// different times -- 96 buckets share an XCD's 4 MB L2, which therefore cannot collect the lines for them.
+constexpr uint32_t LP_ROWS = 512, LP_BATCH = 8192;
+__global__ void __launch_bounds__(512)
+k_lower_place_sorted(const uint64_t *__restrict__ recs, const unsigned long long *__restrict__ bucket_off, uint32_t shift, uint32_t n,
+                     const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, uint32_t row_limit, NbrPacked *__restrict__ adj) {
+    __shared__ uint64_t row_end[LP_ROWS];
+    __shared__ uint32_t filled[LP_ROWS], hist[LP_ROWS], offs[LP_ROWS], scan[2][LP_ROWS];
+    __shared__ uint32_t sorted[LP_BATCH];
+    __shared__ uint16_t srow[LP_BATCH];
+    constexpr int PER = LP_BATCH / 512;
+    const uint32_t t = threadIdx.x;
+    const uint32_t row0 = blockIdx.x << shift;
+    const uint32_t rows = min(1u << shift, n - row0);   // <= LP_ROWS (the launcher checks the shift)
+    row_end[t] = t < rows ? start[row0 + t + 1] : 0;
+    filled[t] = 0;
+    hist[t] = 0;
+    __syncthreads();
+    const unsigned long long k1 = bucket_off[blockIdx.x + 1];
+    for (unsigned long long k0 = bucket_off[blockIdx.x]; k0 < k1; k0 += LP_BATCH) {
+        const uint32_t len = (uint32_t)min((unsigned long long)LP_BATCH, k1 - k0);
+        uint64_t rec[PER];
+        uint32_t rk[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) rec[q] = t + q * 512 < len ? recs[k0 + t + q * 512] : ~0ull;
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+            if (rec[q] != ~0ull) rk[q] = atomicAdd(&hist[(uint32_t)(rec[q] >> 32) - row0], 1u);
+        __syncthreads();
+        // exclusive scan of hist over the 512 rows (one per thread)
+        uint32_t own = hist[t];
+        scan[0][t] = own;
+        __syncthreads();
+        int src = 0;
+        for (uint32_t d = 1; d < LP_ROWS; d <<= 1) {
+            scan[src ^ 1][t] = scan[src][t] + (t >= d ? scan[src][t - d] : 0u);
+            src ^= 1;
+            __syncthreads();
+        }
+        offs[t] = scan[src][t] - own;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+            if (rec[q] != ~0ull) {
+                const uint32_t i = (uint32_t)(rec[q] >> 32) - row0;
+                sorted[offs[i] + rk[q]] = (uint32_t)rec[q];
+                srow[offs[i] + rk[q]] = (uint16_t)i;
+            }
+        __syncthreads();
+        for (uint32_t p = t; p < len; p += 512) {
+            const uint32_t i = srow[p];
+            adj[row_end[i] - 1 - filled[i] - (p - offs[i])] = NbrPacked{sorted[p]};
+        }
+        __syncthreads();
+        filled[t] += own;
+        hist[t] = 0;
+        __syncthreads();
+    }
+    if (t < rows) cursor[row_limit + row0 + t] = filled[t];
+}
+
 // The same CSR from edges that were PLACED while they were written (NeighborParams::rank: every edge's rank inside its
 // two row sections): no atomics -- with one returning atomic per edge the scatter above takes 0.83 ms for the 1.28 x 10^7
 // edges of the 10^5 pass and 63 ms at 10^6.  up[] = the rows' upper counters (NeighborParams::deg), already complete.
@@ -1137,7 +1199,11 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
     // one 1,024-thread workgroup per CU (10^6 sequences: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms)
     hipLaunchKernelGGL(k_lower_partition, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, base, off, fill, recs);
     hipLaunchKernelGGL((k_edge_scatter<NbrPacked, false>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj, 1, base, n);
-    hipLaunchKernelGGL(k_lower_place, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
+    const bool sorted_place = getenv("HMK_CSR_PLACE_UNSORTED") == nullptr;   // (the tests run both)
+    if (sorted_place && (1u << shift) <= LP_ROWS)
+        hipLaunchKernelGGL(k_lower_place_sorted, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
+    else
+        hipLaunchKernelGGL(k_lower_place, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
     return hipGetLastError();
 }
 
