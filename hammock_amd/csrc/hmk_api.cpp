@@ -1308,11 +1308,12 @@ struct EdgeSource {
 
 // The CSR scatter with its lower sections dealt by bucket (k_edges.hip, k_lower_*): for graphs whose scatter is bound by random
 // writes.  Packed symmetric adjacency only; edges that were placed while they were written have their own atomic-free scatter.
-// HMK_CSR_BY_BUCKET=0|1 overrides the size rule (the tests force it at small sizes).
+// The default at every size (10^5: CSR 0.44 -> 0.31 ms, 10^6: 58 -> 23 ms); HMK_CSR_BY_BUCKET=0 scatters with atomics.
 static bool csr_by_bucket(uint32_t n, bool symmetric, bool packed, bool placed) {
     if (!symmetric || !packed || placed) return false;
     if (const char *v = getenv("HMK_CSR_BY_BUCKET")) return atoi(v) != 0;
-    return n > 500000;
+    (void)n;
+    return true;
 }
 
 // Builds the CSR adjacency on the device, hands rows to the host merge on demand, runs the merge.
@@ -1364,7 +1365,9 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     auto enqueue_scatter = [&]() -> hipError_t {
         scatter_enqueued = true;
         if (csr_by_bucket(n, symmetric, packed, src.deg_fused && src.placed)) {   // large graphs: lower sections dealt by bucket
-            hipError_t e = ensure_buf(ctx, SB_PART, std::max<uint64_t>(src.adj_bound / 2, 1) * 8);   // in place already (hmk_greedy_cluster)
+            uint64_t records = 1;   // one per edge: at most what the segments hold
+            for (uint32_t q = 0; q < src.segs.n; q++) records += src.segs.s[q].cap;
+            hipError_t e = ensure_buf(ctx, SB_PART, records * 8);   // in place already when hmk_greedy_cluster scored the edges itself
             if (e == hipSuccess) e = ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes());
             if (e == hipSuccess)
                 e = launch_csr_scatter_partitioned(src.segs, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
@@ -1942,10 +1945,10 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
                 HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
             }
             {
-                bool place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && n <= 500000;
+                bool place0 = false;
                 if (const char *v = getenv("HMK_PLACE_EDGES")) place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && atoi(v) != 0;
                 if (csr_by_bucket(n, ctx->symmetric, src.packed, place0)) {
-                    HIPCHK(ctx, ensure_buf(ctx, SB_PART, std::max<uint64_t>(ctx->d_edges_cap, 1) * 8));
+                    HIPCHK(ctx, ensure_buf(ctx, SB_PART, (ctx->d_edges_cap + 1) * 8));
                     HIPCHK(ctx, ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes()));
                 }
             }
@@ -1966,9 +1969,10 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         // the neighbour kernel places every edge in the CSR as it writes it: per row an upper and a lower counter (they end
         // up as the sizes of the row's two sections; the upper ones ARE up[]) and, beside the edge, its two ranks
         const bool fuse = getenv("HMK_NO_FUSED_DEGREE") == nullptr;
-        // (placing: 10^5 CSR 0.89 -> 0.42 ms, 3 x 10^5 6.0 -> 3.7 ms; at 10^6 the pass loses 35 ms to the returning atomics and
-        // the scatter, bound by its random writes there, gains nothing: then the pass only counts the degrees)
-        bool place = fuse && n <= 500000;
+        // (placing beat the atomic scatter up to 5 x 10^5 sequences -- 10^5 CSR 0.89 -> 0.42 ms, 3 x 10^5 6.0 -> 3.7 ms -- and lost to
+        // the bucketed one at every size: 10^5 0.31 ms, 3 x 10^5 2.1 ms, 5 x 10^5 5.7 against 12.1 ms, and the pass itself is 1-4 %
+        // faster without the returning atomics.  It stays as HMK_PLACE_EDGES=1.)
+        bool place = false;
         if (const char *v = getenv("HMK_PLACE_EDGES")) place = fuse && atoi(v) != 0;
         uint32_t *d_deg = nullptr, *d_deg_lo = nullptr, *d_rank = nullptr;
         if (place) {

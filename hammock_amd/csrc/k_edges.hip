@@ -197,8 +197,13 @@ constexpr uint32_t LB_MAX_BUCKETS = 4096;   // LDS tables of the partition kerne
 constexpr uint32_t LB_MAX_ROWS = 4096;      // rows of a bucket (shift <= 12)
 constexpr uint32_t LB_CHUNK = 65536;        // edges a workgroup deals at a time
 
+// an edge the degree pass counted (k_edge_degree: both ends in [0, n), no self pair); ~0 marks "no edge" in the unrolled loads
+__device__ __forceinline__ bool lower_record_ok(uint64_t e, uint32_t n) {
+    return e != ~0ull && HMK_EDGE_X(e) < n && HMK_EDGE_M(e) < n && HMK_EDGE_X(e) != HMK_EDGE_M(e);
+}
+
 __global__ void __launch_bounds__(1024)
-k_lower_count(const EdgeSegs segs, uint32_t shift, uint32_t nb, unsigned long long *__restrict__ bucket_cnt) {
+k_lower_count(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, unsigned long long *__restrict__ bucket_cnt) {
     __shared__ uint32_t hist[LB_MAX_BUCKETS];
     for (uint32_t b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
     __syncthreads();
@@ -213,7 +218,7 @@ k_lower_count(const EdgeSegs segs, uint32_t shift, uint32_t nb, unsigned long lo
             for (int q = 0; q < 4; q++) e[q] = k + q * stride < cnt ? sg.edges[k + q * stride] : ~0ull;
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (e[q] != ~0ull) atomicAdd(&hist[max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q])) >> shift], 1u);
+                if (lower_record_ok(e[q], n)) atomicAdd(&hist[max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q])) >> shift], 1u);
         }
     }
     __syncthreads();
@@ -254,7 +259,7 @@ k_lower_offsets(const unsigned long long *__restrict__ bucket_cnt, uint32_t nb, 
 
 // records: row m << 32 | the packed entry (x << 8 | score - base) of m's lower section
 __global__ void __launch_bounds__(1024)
-k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, int base, const unsigned long long *__restrict__ bucket_off,
+k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, int base, const unsigned long long *__restrict__ bucket_off,
                   unsigned long long *__restrict__ bucket_fill, uint64_t *__restrict__ recs) {
     __shared__ uint32_t hist[LB_MAX_BUCKETS];
     __shared__ uint32_t first[LB_MAX_BUCKETS];   // where this chunk's records of a bucket start, relative to bucket_off (< 2^32: a bucket holds < 2^12 rows x 2^20)
@@ -274,7 +279,7 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, int base, co
                 for (int q = 0; q < 4; q++) e[q] = k + q * 1024 < len ? sg.edges[k0 + k + q * 1024] : ~0ull;
 #pragma unroll
                 for (int q = 0; q < 4; q++)
-                    if (e[q] != ~0ull) atomicAdd(&hist[max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q])) >> shift], 1u);
+                    if (lower_record_ok(e[q], n)) atomicAdd(&hist[max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q])) >> shift], 1u);
             }
             __syncthreads();
             for (uint32_t b = threadIdx.x; b < nb; b += 1024) {
@@ -290,7 +295,7 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, int base, co
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint64_t e = ev[q];
-                    if (e == ~0ull) continue;
+                    if (!lower_record_ok(e, n)) continue;
                     const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)), m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
                     const uint32_t b = m >> shift;
                     const uint32_t at = first[b] + atomicAdd(&hist[b], 1u);
@@ -1194,10 +1199,10 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
     unsigned long long *cnt = (unsigned long long *)scratch, *off = cnt + LB_MAX_BUCKETS + 1, *fill = off + LB_MAX_BUCKETS + 1;
     hipError_t e = hipMemsetAsync(cnt, 0, (size_t)nb * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lower_count, dim3(512), dim3(1024), 0, s, segs, shift, nb, cnt);
+    hipLaunchKernelGGL(k_lower_count, dim3(512), dim3(1024), 0, s, segs, shift, nb, n, cnt);
     hipLaunchKernelGGL(k_lower_offsets, dim3(1), dim3(1024), 0, s, cnt, nb, off, fill);
     // one 1,024-thread workgroup per CU (10^6 sequences: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms)
-    hipLaunchKernelGGL(k_lower_partition, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, base, off, fill, recs);
+    hipLaunchKernelGGL(k_lower_partition, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, n, base, off, fill, recs);
     hipLaunchKernelGGL((k_edge_scatter<NbrPacked, false>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj, 1, base, n);
     const bool sorted_place = getenv("HMK_CSR_PLACE_UNSORTED") == nullptr;   // (the tests run both)
     if (sorted_place && (1u << shift) <= LP_ROWS)
