@@ -524,6 +524,7 @@ def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"HMK_PLACE_EDGES": "1"}, {"HMK_PLACE_EDGES": "0"}, {"HMK_NO_FUSED_DEGREE": "1"},
+                                 {"HMK_CSR_BY_BUCKET": "0"}, {"HMK_NO_FUSED_DEGREE": "1", "HMK_CSR_BY_BUCKET": "0"},
                                  {"HMK_PLACE_EDGES": "1", "HMK_ADJ_8BYTE": "1"}, {"HMK_PLACE_EDGES": "1", "HMK_NO_BAND": "1"},
                                  {"HMK_PLACE_EDGES": "0", "HMK_CSR_BY_BUCKET": "1"}, {"HMK_NO_FUSED_DEGREE": "1", "HMK_CSR_BY_BUCKET": "1"},
                                  {"HMK_PLACE_EDGES": "0", "HMK_CSR_BY_BUCKET": "1", "HMK_NO_BAND": "1", "HMK_CSR_PARTITION_GRID": "3"},
@@ -531,9 +532,10 @@ def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
 @pytest.mark.parametrize("cfg", [(21, 24000, 12, 12, 0, True), (22, 9000, 7, 20, -1, True), (23, 6000, 12, 12, 0, False)])
 def test_greedy_csr_construction_modes(gpu, blosum62, coracle, monkeypatch, env, cfg):
     """Three ways to the same CSR: the neighbour pass places every edge as it writes it (two rank counters per row,
-    ranks stored beside the edges, atomic-free scatter; default up to 5 x 10^5 sequences), it only counts the degrees
+    ranks stored beside the edges, atomic-free scatter; HMK_PLACE_EDGES=1), it only counts the degrees
     (fire-and-forget; the scatter takes its places with atomics), or a separate pass counts them -- and, for the two that
-    scatter with atomics, the lower sections dealt by bucket first (the default above 5 x 10^5 sequences).  Uniform and mixed
+    scatter with atomics, the lower sections dealt by bucket first (the default: HMK_CSR_BY_BUCKET=0 is the plain atomic
+    scatter).  Uniform and mixed
     lengths (both flush routines), a symmetric and an asymmetric matrix (one section per row), 4- and 8-byte entries."""
     seed, n, lo, hi, p, symmetric = cfg
     M = blosum62.copy()
