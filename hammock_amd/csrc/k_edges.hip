@@ -1187,6 +1187,7 @@ static uint32_t csr_partition_grid() {
 }
 uint32_t csr_partition_shift(uint32_t n) {
     uint32_t shift = 9;
+    if (const char *v = getenv("HMK_CSR_BUCKET_SHIFT")) shift = (uint32_t)std::min(12, std::max(9, atoi(v)));   // tests: the wide buckets of n > 2^21
     while (((uint64_t)n + (1u << shift) - 1) >> shift > LB_MAX_BUCKETS) shift++;
     return shift;
 }
