@@ -225,7 +225,7 @@ constexpr int plane64_bytes(int lbmax) { return lbmax * 24 * 8 + 8; }
 constexpr int planes_per_tile(int r, int nw) { return r * (nw / 2) + ((r + 1) / 2) * (nw & 1); }
 constexpr int rows_for(int rowbytes, int nw) {  // rows per tile: table bytes and R x NW accumulator registers, tuned on config 4a
 #ifndef HMK_TAB_BUDGET
-#define HMK_TAB_BUDGET 20480
+#define HMK_TAB_BUDGET 24576
 #endif
 #ifndef HMK_ACC_CAP
 #define HMK_ACC_CAP 16
@@ -248,8 +248,9 @@ constexpr int planes_rowbytes(int lbmax, int nw) { return (2 * (nw / 2) + (nw & 
 
 template <int NW, int R, int LBMAX>
 // the narrow-entry instantiations are held to 80 VGPRs = 6 waves/SIMD, which is what their 25 KB of LDS allow per CU
-// (<2, 8, 12> took 85 VGPRs = 5 waves and showed the lowest LDS busy fraction of config 4a)
-__global__ void __launch_bounds__(256, NW == 2 ? 6 : 1) k_neighbors_planes(const NeighborParams P, const uint32_t tile_base) {
+// (<2, 8, 12> took 85 VGPRs = 5 waves and showed the lowest LDS busy fraction of config 4a; <2, 6, 20> -- 12 accumulators and 20
+// offsets -- does not fit 80 and is left alone)
+__global__ void __launch_bounds__(256, (NW == 2 && 2 * R + LBMAX <= 30) ? 6 : 1) k_neighbors_planes(const NeighborParams P, const uint32_t tile_base) {
     constexpr int NP = NW / 2, H = NW & 1;
     constexpr int CPL = NW <= 2 ? 2 : 1;
     constexpr int PLANE64 = plane64_bytes(LBMAX);
