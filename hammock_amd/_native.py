@@ -38,7 +38,7 @@ class NeighborStats(C.Structure):
     _fields_ = [
         ("n_edges", C.c_uint64), ("pairs_scored", C.c_uint64), ("n_tiles", C.c_uint32),
         ("symmetric", C.c_uint32), ("classes_u8", C.c_uint32), ("classes_u16", C.c_uint32),
-        ("classes_direct", C.c_uint32), ("reserved", C.c_uint32), ("kernel_ms", C.c_double),
+        ("classes_direct", C.c_uint32), ("classes_rows", C.c_uint32), ("kernel_ms", C.c_double),
     ]
 
 

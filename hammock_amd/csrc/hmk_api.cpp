@@ -51,7 +51,8 @@ struct Plan {
     uint32_t band_rows = 0;   // tiles touching caller indices below this come first in every group (0: no band)
     int64_t band_req = 0;     // what the caller asked for (the plan may have had to drop the band)
     int lbmax = 12, lpad = 16;
-    bool exact = false;
+    bool exact = false;       // the shift-packed length-12 kernel (k_neighbors_swar; only with HMK_NO_ROWS_KERNEL)
+    bool rows_exact = false;  // one length for all and a row-packed instantiation for exactly that length
     int hot_variant = 7;
     uint32_t cols_per_tile = 16384;
     uint8_t *d_res_sorted = nullptr;
@@ -330,8 +331,18 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     pl.lpad = ctx->max_len <= 16 ? 16 : 32;
     // The exact hot kernel: every sequence has length 12, max shift 3, and the (12, 12) class fits 8-bit
     // lanes in 8-byte entries.  It reads residues pre-multiplied by the entry size (see res_sorted below).
+    // Row-packed kernels (k_neighbors_rows.hip) take every 8-bit-lane class they have an instantiation for; a set of one
+    // length may have one with the length at compile time.  HMK_NO_ROWS_KERNEL=1: the shift-packed kernels of round 1-2.
+    const bool use_rows = getenv("HMK_NO_ROWS_KERNEL") == nullptr;
     pl.exact = false;
-    if (ctx->min_len == 12 && ctx->max_len == 12 && X == 3) {
+    pl.rows_exact = false;
+    if (use_rows && ctx->min_len == ctx->max_len) {
+        TileClass t1;
+        classify(ctx, ctx->min_len, ctx->min_len, X, p, thr, &t1);
+        pl.rows_exact = t1.path == PATH_U8 && rows_kernel_available(X, ctx->min_len, ctx->min_len, true) &&
+                        getenv("HMK_NO_ROWS_EXACT") == nullptr;
+    }
+    if (!use_rows && ctx->min_len == 12 && ctx->max_len == 12 && X == 3) {
         TileClass t12;
         classify(ctx, 12, 12, X, p, thr, &t12);
         pl.exact = t12.path == PATH_U8 && t12.nw == 2;
@@ -343,11 +354,12 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     // Column runs: long runs amortise the table build (65,536 columns: 3.55 ms for the whole 10^5 pass against
     // 3.60 ms with 16,384), short ones keep the tail of a small launch short (a 1/8 shard: 0.478 ms with 16,384,
     // 0.532 ms with 65,536).  Take the longest run that still leaves ~8 rounds of workgroups (256 CUs x 7).
-    const uint64_t row_groups = (uint64_t)n / 6 / n_parts + 1;
+    const uint64_t tile_rows = pl.rows_exact ? (uint64_t)rows_per_tile_rows(X, 0, ctx->min_len, true) : use_rows ? 16 : 6;
+    const uint64_t row_groups = (uint64_t)n / tile_rows / n_parts + 1;
     pl.cols_per_tile = 65536;
     while (pl.cols_per_tile > 16384 && row_groups * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 8 * 1792)
         pl.cols_per_tile /= 2;
-    while (pl.cols_per_tile > 1024 && ((uint64_t)n / 6 + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
+    while (pl.cols_per_tile > 1024 && ((uint64_t)n / tile_rows + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
         pl.cols_per_tile /= 2;
     if (const char *v = getenv("HMK_HOT_VARIANT")) pl.hot_variant = atoi(v);   // tuning knobs
     if (const char *v = getenv("HMK_COLS_PER_TILE")) pl.cols_per_tile = (uint32_t)std::min(65536, std::max(256, atoi(v)));   // hit records hold a 16-bit column offset
@@ -403,10 +415,16 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                 if (tc.path == PATH_U8) S.classes_u8++;
                 else if (tc.path == PATH_U16) S.classes_u16++;
                 else S.classes_direct++;
-                const int lbk = pl.exact ? 12 : swar_lbmax_for(lb);
-                const uint32_t R = tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(lbk, tc.nw, pl.exact, pl.hot_variant);
-                std::vector<Tile> &dst = grouped[std::make_tuple((int)tc.path, tc.path == PATH_DIRECT ? 0 : (int)tc.nw,
-                                                                 tc.path == PATH_DIRECT ? 0 : lbk)];
+                // launch group: (kernel family, entry dwords | length difference, column capacity)
+                const bool rows = use_rows && tc.path == PATH_U8 && la >= lb &&
+                                  (pl.rows_exact || rows_kernel_available(X, la, lb, false));
+                const int lbk = rows ? (pl.rows_exact ? lb : rows_cap_for(lb)) : pl.exact ? 12 : swar_lbmax_for(lb);
+                const uint32_t R = rows ? (uint32_t)rows_per_tile_rows(X, la - lb, lbk, pl.rows_exact)
+                                        : tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(lbk, tc.nw, pl.exact, pl.hot_variant);
+                if (rows) S.classes_rows++;
+                std::vector<Tile> &dst = grouped[rows ? std::make_tuple((int)PATH_ROWS, la - lb, lbk)
+                                                      : std::make_tuple((int)tc.path, tc.path == PATH_DIRECT ? 0 : (int)tc.nw,
+                                                                        tc.path == PATH_DIRECT ? 0 : lbk)];
                 for (uint32_t r0 = rg.lo; r0 < rg.hi; r0 += R) {
                     const bool mine = (row_chunk_counter++ % n_parts) == part;
                     if (!mine) continue;
@@ -471,7 +489,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     plan_lap("tile order");
 
     // ---- device copies ------------------------------------------------------------
-    std::vector<uint8_t> res_sorted((size_t)n * pl.lpad, 0);
+    std::vector<uint8_t> res_sorted((size_t)n * pl.lpad + 16, 0);   // + 16: the row-packed kernel's unaligned tail loads may touch the bytes after the last row
     for (uint32_t s = 0; s < n; s++) {
         const uint32_t k = perm[s];
         for (uint32_t q = 0; q < ctx->len[k]; q++)
@@ -579,6 +597,8 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
         const uint32_t cnt = which == LAUNCH_ALL ? g.count : which == LAUNCH_BAND ? g.band : g.count - g.band;
         if (g.path == PATH_DIRECT)
             HIPCHK(ctx, launch_neighbors_direct(P, t0, cnt, ctx->d_M, X, p, thr, s));
+        else if (g.path == PATH_ROWS)
+            HIPCHK(ctx, launch_neighbors_rows(X, g.nw, g.lbk, pl.rows_exact, P, t0, cnt, s));
         else
             HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, t0, cnt, s));
     }
@@ -926,7 +946,7 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
         // the deferred load of the kernels' code objects (5-10 ms).  The reference constructs its scorer before it starts the
         // clock of "Clustering time" (Hammock.java:402-406), and a host can create the context while it still reads its input.
         if (getenv("HMK_LAZY_CONTEXT") == nullptr) {
-            if (greedy_streams(ctx) != HMK_OK || warm_neighbors_module() != hipSuccess || warm_edges_module() != hipSuccess)
+            if (greedy_streams(ctx) != HMK_OK || warm_neighbors_module() != hipSuccess || warm_neighbors_rows_module() != hipSuccess || warm_edges_module() != hipSuccess)
                 (void)hipGetLastError();   // not fatal here: the first call tries again and reports
         }
     } else if (device != -1) {

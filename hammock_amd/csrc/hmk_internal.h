@@ -18,7 +18,7 @@ namespace hmk {
 // of columns inside ONE (row length, column length) class, so everything that
 // depends on the two lengths is uniform over the workgroup.
 
-enum { PATH_U8 = 0, PATH_U16 = 1, PATH_DIRECT = 2 };
+enum { PATH_U8 = 0, PATH_U16 = 1, PATH_DIRECT = 2, PATH_ROWS = 3 };   // PATH_ROWS: launch groups only (8-bit lanes, k_neighbors_rows.hip)
 
 struct TileClass {
     uint8_t la, lb;    // row / column sequence length

@@ -16,6 +16,14 @@ int swar_lbmax_for(int lb);
 
 hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant, const NeighborParams &P,
                                  uint32_t tile_base, uint32_t n_tiles, hipStream_t s);
+// row-packed kernels (k_neighbors_rows.hip): 8 rows per 8-byte table entry, one accumulator pair per shift.
+// exact: a set of one length lb (its own instantiation); else the capacity form, rows_cap_for(lb) >= lb.
+bool rows_kernel_available(int X, int la, int lb, bool exact);
+int rows_cap_for(int lb);
+int rows_per_tile_rows(int X, int d, int cap, bool exact);   // rows per tile of that instantiation
+hipError_t launch_neighbors_rows(int X, int d, int cap, bool exact, const NeighborParams &P, uint32_t tile_base,
+                                 uint32_t n_tiles, hipStream_t s);
+hipError_t warm_neighbors_rows_module();
 hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
                                    const int32_t *d_matrix, int max_shift, int shift_penalty, int threshold,
                                    hipStream_t s);

@@ -1,0 +1,400 @@
+// k_neighbors_rows.hip -- all-vs-all ShiftedScorer (ShiftedScorer.java:48-95) with threshold -> edge list, "row-packed" form.
+//
+// The reference sums, for every shift s, the cells M[S[i - s]][L[i]] (s <= 0) or M[S[i]][L[i + s]] (s > 0) over the overlap
+// (:67-77).  With the tile's ROW peptides as the longer-or-equal sequence and the lane's COLUMN peptide as the other one this
+// reads: shift plane u (s = u - X) adds, for every column position j, the cell of row position i = j + u - X.  A cell depends
+// on (row, i, column residue) only -- not on the shift -- so the workgroup keeps ONE table per group of 8 rows,
+//
+//     E[i][c] = 8 bytes: byte r = cell(row r, position i, residue c) + bias          (24 x 8 B = 192 B per position i)
+//
+// and a pair of (8 rows, 1 column) is scored by one ds_read_b64 per (u, j) inside the overlap + one v_add3 per two reads and
+// dword: 8 rows advance together, one accumulator pair per shift plane.  Nothing is read that the reference does not add:
+// 72 reads per 8 pairs at length 12 / max shift 3 = 72 B of LDS per pair, where the shift-packed tables of
+// k_neighbors_swar / k_neighbors_planes (k_neighbors.hip: 7 shift lanes + 1 pad lane per 8-byte entry, zero cells of the
+// partial overlaps included) read 96 B.  The binding unit is the LDS byte rate (ds_read_b64: 256 B/clk/CU), so bytes are time.
+//
+// Table placement.  The reads of one column position go to the same address register with immediates 192 x k bytes apart, and
+// the compiler fuses two such ds_read_b64 into one ds_read2_b64 -- which moves 128 B/clk/CU instead of 256
+// (MI355X_MICROARCH.md, LDS table) -- whenever their immediates are < 2048 B or a multiple of 512 B apart.  So the ND row
+// positions one column position can meet are kept SLOT = 2248 bytes apart: position i lives in slot i mod ND, and the
+// 192-byte blocks that share a slot (positions ND apart, the other row groups, the end table) fill its sub-slots.  Two blocks
+// of one group that a column position can meet together are then >= 2248 - 192 bytes and never a multiple of 512 bytes
+// apart (rows_layout_ok below); blocks of different groups are read in different basic blocks.
+//
+// Lanes are 8 bits wide; hmk_api.cpp (classify) proves per length class -- or per row bound -- that every lane stays in
+// [0, 255]: lane = g + penalty(s) - bias * cells(s) + sum of biased cells, g = 128 - threshold, so "score >= threshold" is the
+// lane's top bit.  Classes that do not fit, columns longer than the rows, and (X, D) pairs without an instantiation below run
+// the kernels of k_neighbors.hip.
+//
+// Integer scoring only: no MFMA, no dense contraction.
+#include "hmk_device.h"
+
+namespace hmk {
+
+// Drains one wave's staged one-dword records ((column - tile's first column) | row << 16 | (score - threshold) << 22;
+// a tile has <= 65,536 columns and <= 64 rows, and the lane proof bounds score - threshold to 0..127).
+template <int MODE>
+__device__ __forceinline__ void flush_stage_rows(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
+                                                 const Tile &T, int threshold, uint32_t shard) {
+    if (cnt == 0) return;
+    drain_begin();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
+    const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage, hmk_device.h)
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&P.counts[shard], (unsigned long long)cnt);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    for (uint32_t k = lane; k < cnt; k += 64) {
+        const uint32_t rec = stage[k];
+        const int score = (int)(rec >> 22) + threshold;
+        uint32_t x = T.row0 + ((rec >> 16) & 0x3Fu), m = T.col0 + (rec & 0xFFFFu);
+        if (!P.perm_identity) { x = P.perm[x]; m = P.perm[m]; }   // wave-uniform branch
+        if (P.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
+        const unsigned long long pos = base + k;
+        if (pos < P.cap_per_shard) {
+            P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
+                ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
+            if (MODE != EDGES_PLAIN) place_edge<MODE>(P, (unsigned long long)shard * P.cap_per_shard + pos, x, m);   // stored edges only
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
+    drain_end();
+}
+
+constexpr int rows_slot_bytes() { return 2248; }
+// no two table blocks of one group within a window of nd row positions may be fusable into a ds_read2[st64]_b64:
+// their distance a * SLOT + b * 192 (a slots, b = -1..1 sub-slots) must exceed 2040 bytes and not be a multiple of 512
+constexpr bool rows_layout_ok(int nd) {
+    for (int a = 1; a < nd; a++)
+        for (int b = -1; b <= 1; b++) {
+            const int dist = a * rows_slot_bytes() + b * 192;
+            if (dist <= 2040 || dist % 512 == 0) return false;
+        }
+    return true;
+}
+// waves per SIMD a shape is compiled for: what its LDS footprint lets a CU hold, and no more than its registers (column
+// offsets + 2 accumulators per plane + reads in flight and the rest) allow without spilling
+constexpr int rows_waves(int nd, int cap, int lds_bytes) {
+#ifdef HMK_ROWS_WAVES
+    return HMK_ROWS_WAVES;
+#endif
+    const int v = cap + 2 * nd + 40;
+    const int by_regs = v <= 64 ? 8 : v <= 72 ? 7 : v <= 80 ? 6 : v <= 96 ? 5 : 4;
+    const int by_lds = 163840 / ((lds_bytes + 511) / 512 * 512);
+    return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
+}
+constexpr int rows_lds_bytes(int x, int d, int cap, int g) {   // must match the kernel's LDS map
+    return (2 * x + d + 1) * rows_slot_bytes() + 576 + 8 * g * 32 + 4 * 192 * 4;
+}
+
+// X max shift, D = row length - column length (>= 0), CAP column-length capacity (EXACT_LB: THE column length),
+// G groups of 8 rows per tile, MODE what a flush does beside storing the edge (hmk_device.h)
+template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
+__global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, G)))
+k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
+    constexpr int ND = 2 * X + D + 1;          // shift planes
+    constexpr int NI = CAP + D;                // row positions held per group
+    constexpr int ENT = 192;                   // bytes per row position: 24 residues x 8 rows
+    constexpr int R = 8 * G;
+    constexpr int SLOT = rows_slot_bytes();    // see "Table placement" above
+    constexpr int SUB = (NI + ND - 1) / ND;    // sub-slots a group's positions take
+    constexpr int NEND = EXACT_LB ? 0 : ND - 1;   // end table: the row's last ND - 1 positions again, indexed from the row's end
+    static_assert(G * (SUB + (NEND > 0 ? 1 : 0)) * ENT <= SLOT && rows_layout_ok(ND), "sub-slots must fit the slot; no fusable pair");
+    constexpr int TAB_BYTES = ND * SLOT;
+    // byte address of row position i of group g / of the position e places before the row's end
+    auto pos_addr = [](int g, int i) constexpr { return (i % ND) * SLOT + (g * SUB + i / ND) * ENT; };
+    auto end_addr = [](int g, int e) constexpr { return e * SLOT + (G * SUB + g) * ENT; };
+    constexpr int STAGE_CAP = 192;             // records per wave; flushed when fewer than 64 slots are free
+    constexpr int LPADW = (CAP <= 16) ? 4 : 8; // residue dwords a lane loads (rows are P.lpad bytes apart)
+    constexpr int TW = (X + 3) / 4;            // dwords holding the last X residues of a column
+    static_assert(X >= 0 && D >= 0 && CAP >= 2 * X && CAP >= 1 && CAP <= 32 && G >= 1 && G <= 8, "shape");
+    static_assert(TAB_BYTES <= 65536, "table offsets must fit the DS immediate");
+    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4;
+    static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, G), "rows_lds_bytes must match the LDS map");
+    // one STATIC LDS object: its base address is a compile-time constant, so table offsets fold into the ds_read immediate
+    __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
+    uint8_t *tab = smem;
+    uint8_t *mb = smem + TAB_BYTES;
+    uint8_t *rowres = mb + 576;
+    uint32_t *stage_all = reinterpret_cast<uint32_t *>(rowres + R * 32);
+
+    const Tile T = P.tiles[tile_base + blockIdx.x];
+    const TileClass *Cp = P.classes + T.cls;
+    const int la = Cp->la;
+    int lbs = EXACT_LB ? CAP : (int)Cp->lb;    // column length (wave-uniform)
+    const bool case_b = Cp->case_b != 0;       // the column is the SHORTER sequence: cell = M[c][row[i]], else M[row[i]][c]
+    const int threshold = 128 - Cp->g;
+    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const int tid = threadIdx.x;
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * STAGE_CAP;   // 32-bit LDS pointer
+
+    build_begin();
+    for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
+    for (int e = tid; e < R * 32; e += 256) {
+        const int r = e >> 5, k = e & 31;
+        uint8_t v = 0;
+        if ((uint32_t)r < T.nrows && (uint32_t)k < P.lpad) v = P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k];
+        rowres[e] = v;
+    }
+    __syncthreads();
+    // ---- the cell tables: work item e = ((g * (NI + NEND) + k) * 24 + c) * 2 + h gathers rows 8g + 4h .. + 3 of row position
+    // k (k < NI) or of the position k - NI places before the row's end (end table) ----
+    for (int e = tid; e < G * (NI + NEND) * 24 * 2; e += 256) {
+        const int h = e & 1, ic = e >> 1;
+        const int gi = ic / 24, c = ic - gi * 24;
+        const int g = gi / (NI + NEND), k = gi - g * (NI + NEND);
+        const int i = k < NI ? k : la - 1 - (k - NI);
+        const int dst = k < NI ? (k % ND) * SLOT + (g * SUB + k / ND) * ENT : (k - NI) * SLOT + (G * SUB + g) * ENT;
+        uint32_t v = 0;
+        if (i >= 0 && i < la) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = 8 * g + 4 * h + q;
+                if ((uint32_t)r < T.nrows) {
+                    const int a = rowres[r * 32 + i];
+                    v |= (uint32_t)(case_b ? mb[c * 24 + a] : mb[a * 24 + c]) << (q * 8);
+                }
+            }
+        }
+        *reinterpret_cast<uint32_t *>(tab + dst + c * 8 + h * 4) = v;
+    }
+    __syncthreads();
+    build_end();
+
+    // initial lanes: every byte of plane u starts at g + penalty(s) - bias * cells(s) (TileClass::cinit, one byte per shift)
+    uint32_t ci[ND];
+#pragma unroll
+    for (int u = 0; u < ND; u++) ci[u] = ((Cp->cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
+
+    uint32_t cnt = 0;  // staged records of this wave (wave-uniform)
+    const uint32_t tab_addr = lds_addr(tab);
+    const uint32_t col_end = T.col0 + T.ncols;
+    const uint32_t n_batches = (T.ncols + 255) / 256;
+    const bool interior = T.diag == 0 && T.ncols % 256 == 0;  // every lane's column is a real pair
+    const bool prio = MODE != EDGES_PLACE && (MODE != EDGES_RUNTIME || P.rank == nullptr || HMK_SETPRIO_PLACE);
+
+    for (uint32_t bt = 0; bt < n_batches; bt++) {
+        // ---- this lane's column peptide -> per-position table offsets (residue * 8) ----
+        const uint32_t col = T.col0 + bt * 256 + tid;
+        uint32_t words[LPADW], tw[TW > 0 ? TW : 1];
+#pragma unroll
+        for (int q = 0; q < LPADW; q++) words[q] = 0;
+#pragma unroll
+        for (int q = 0; q < (TW > 0 ? TW : 1); q++) tw[q] = 0;
+        if (col < col_end) {
+            const uint8_t *rowp = P.res_sorted + (size_t)col * P.lpad;
+            const u32x4 v0 = reinterpret_cast<const u32x4 *>(rowp)[0];
+            words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+            if (LPADW == 8) {
+                const u32x4 v1 = reinterpret_cast<const u32x4 *>(rowp)[1];
+                words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
+            }
+            if (!EXACT_LB && TW > 0) {   // the last X residues, wherever the column ends (unaligned dword loads; the array is padded)
+#pragma unroll
+                for (int q = 0; q < TW; q++) __builtin_memcpy(&tw[q], rowp + (lbs - X) + 4 * q, 4);
+            }
+        }
+        // residues are < 32, so byte k of (word << 3) is residue * 8 exactly (the three bits that move in are zero)
+        uint32_t off[CAP];
+#pragma unroll
+        for (int q = 0; q < LPADW; q++) words[q] <<= 3;
+#pragma unroll
+        for (int j = 0; j < CAP; j++) off[j] = tab_addr + ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+        uint32_t toff[X > 0 ? X : 1];   // tail position q = column position lbs - X + q
+        if (EXACT_LB) {
+#pragma unroll
+            for (int q = 0; q < X; q++) toff[q] = off[CAP - X + q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < TW; q++) tw[q] <<= 3;
+#pragma unroll
+            for (int q = 0; q < X; q++) toff[q] = tab_addr + ((tw[q >> 2] >> ((q & 3) * 8)) & 0xFFu);
+        }
+
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if ((uint32_t)(8 * g) >= T.nrows) break;   // wave-uniform
+            uint32_t W0[ND], W1[ND];
+#pragma unroll
+            for (int u = 0; u < ND; u++) { W0[u] = ci[u]; W1[u] = ci[u]; }
+            // column position J, all planes that pair it with a row position >= 0: i = J + u - X
+            auto add_pos = [&](auto jt) {
+                constexpr int J = decltype(jt)::value;
+#pragma unroll
+                for (int u = (X - J > 0 ? X - J : 0); u < ND; u++) {
+                    const u32x2 e = lds_read<u32x2>(off[J] + (uint32_t)pos_addr(g, J + u - X));
+                    W0[u] += e.x; W1[u] += e.y;
+                }
+            };
+            // the main positions j < lbs - X (every plane's row position stays below the row's end), two at a time so that
+            // the adds pair up into v_add3; an odd count takes position 0 on its own first (cf. k_neighbors_planes)
+            auto add_pairs = [&](auto start_tag) {
+                constexpr int J0 = decltype(start_tag)::value;
+                int nmain = lbs - X;
+                if (!EXACT_LB) asm volatile("" : "+s"(nmain));   // keep the tests scalar (s_cmp + s_cbranch), see k_neighbors_planes
+#pragma unroll
+                for (int j = J0; j + 1 < CAP - X; j += 2) {
+                    if (j + 1 >= nmain) break;
+                    // both positions of a plane next to each other: one v_add3 per dword
+#pragma unroll
+                    for (int u = 0; u < ND; u++) {
+                        const bool v0 = u >= X - j, v1 = u >= X - (j + 1);
+                        if (v0 && v1) {
+                            const u32x2 e0 = lds_read<u32x2>(off[j] + (uint32_t)pos_addr(g, j + u - X));
+                            const u32x2 e1 = lds_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(g, j + 1 + u - X));
+                            W0[u] = W0[u] + e0.x + e1.x; W1[u] = W1[u] + e0.y + e1.y;
+                        } else if (v1) {
+                            const u32x2 e1 = lds_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(g, j + 1 + u - X));
+                            W0[u] += e1.x; W1[u] += e1.y;
+                        }
+                    }
+                }
+            };
+            read_phase_begin(prio);
+            if ((lbs - X) & 1) {
+                add_pos(std::integral_constant<int, 0>{});
+                add_pairs(std::integral_constant<int, 1>{});
+            } else {
+                add_pairs(std::integral_constant<int, 0>{});
+            }
+            // the last X column positions: position lbs - X + q pairs with row position lbs - 2X + q + u, which is inside the
+            // row (length lbs + D) for planes u <= ND - 2 - q only; that row position is ND - 2 - q - u places before the row's
+            // end, whatever the column length (end table)
+#pragma unroll
+            for (int u = 0; u < ND; u++) {
+#pragma unroll
+                for (int q = 0; q < X; q++) {
+                    if (u <= ND - 2 - q) {
+                        const u32x2 e = lds_read<u32x2>(toff[q] + (uint32_t)(EXACT_LB ? pos_addr(g, CAP - 2 * X + q + u) : end_addr(g, ND - 2 - q - u)));
+                        W0[u] += e.x; W1[u] += e.y;
+                    }
+                }
+            }
+            read_phase_end(prio);
+
+            // ---- threshold test: some (row, shift) lane has its top bit set <=> score >= threshold ----
+            uint32_t o0 = W0[0], o1 = W1[0];
+#pragma unroll
+            for (int u = 1; u < ND; u++) { o0 |= W0[u]; o1 |= W1[u]; }
+            if (__ballot(((o0 | o1) & 0x80808080u) != 0) == 0) continue;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                if ((uint32_t)(8 * g + r) >= T.nrows) break;   // wave-uniform
+                const bool hit = (((r < 4 ? o0 : o1) >> ((r & 3) * 8 + 7)) & 1u) != 0;
+                if (__ballot(hit) == 0) continue;   // wave-uniform
+                if (cnt > (uint32_t)(STAGE_CAP - 64)) {  // keep room for one wave of hits
+                    flush_stage_rows<MODE>(stage, cnt, P, T, threshold, shard);
+                    cnt = 0;
+                }
+                bool keep = hit;
+                if (!interior) {  // wave-uniform: only edge tiles filter
+                    keep = keep && col < col_end;
+                    if (T.diag == 1) keep = keep && col > T.row0 + 8 * g + r;   // triangle: column after row
+                    if (T.diag == 2) keep = keep && col != T.row0 + 8 * g + r;  // full square minus the diagonal
+                }
+                const uint64_t mask = __ballot(keep);
+                if (keep) {   // score - threshold = best lane - 128, in 0..127
+                    uint32_t mx = 0;
+#pragma unroll
+                    for (int u = 0; u < ND; u++) mx = max(mx, ((r < 4 ? W0[u] : W1[u]) >> ((r & 3) * 8)) & 0xFFu);
+                    stage[cnt + mbcnt64(mask)] = (col - T.col0) | ((uint32_t)(8 * g + r) << 16) | ((mx - 128u) << 22);
+                }
+                cnt += (uint32_t)__popcll(mask);
+            }
+        }
+    }
+    flush_stage_rows<MODE>(stage, cnt, P, T, threshold, shard);
+}
+
+// -----------------------------------------------------------------------------
+// instantiations and launchers
+// -----------------------------------------------------------------------------
+// Uniform-length sets with the reference's default max shift for that length (Hammock.java:1421-1434: round(L / 4)) get
+// their column length at compile time; everything else runs the capacity form (column length <= CAP at run time).
+#ifndef HMK_ROWS_G
+#define HMK_ROWS_G 2
+#endif
+// groups of 8 rows per tile: HMK_ROWS_G, or as many as the sub-slots of a slot hold
+constexpr int rows_groups(int x, int d, int cap, bool exact) {
+    const int nd = 2 * x + d + 1, sub = (cap + d + nd - 1) / nd + (exact ? 0 : 1);
+    const int fit = rows_slot_bytes() / 192 / sub;
+    return fit < 1 ? 0 : fit < HMK_ROWS_G ? fit : HMK_ROWS_G;
+}
+
+struct RowsShape { int x, d, cap; bool exact; };
+
+template <int X, int D, int CAP, bool EXACT_LB>
+static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
+    constexpr int G = rows_groups(X, D, CAP, EXACT_LB);
+    // the flush's mode is a template parameter: with the run-time form the placing branch's registers spill in every mode
+    if (P.rank)
+        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_PLACE>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+    else if (P.deg)
+        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_COUNT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+    else
+        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_PLAIN>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
+    return hipGetLastError();
+}
+
+// the list: HMK_ROWS_EXACT(X, L) uniform length L; HMK_ROWS_CAP(X, D, CAP) column length <= CAP, rows D longer
+#define HMK_ROWS_EXACT_LIST(F) F(3, 12)
+#define HMK_ROWS_CAP_LIST(F) \
+    F(3, 0, 12) F(3, 1, 12) F(3, 2, 12) F(3, 3, 12) F(3, 4, 12) F(3, 5, 12) F(3, 6, 12) F(3, 7, 12) F(3, 8, 12) F(3, 9, 12) \
+    F(3, 10, 12) F(3, 11, 12) F(3, 12, 12) F(3, 13, 12) \
+    F(3, 0, 16) F(3, 1, 16) F(3, 2, 16) F(3, 3, 16) F(3, 4, 16) F(3, 5, 16) F(3, 6, 16) F(3, 7, 16) \
+    F(3, 0, 20) F(3, 1, 20) F(3, 2, 20) F(3, 3, 20)
+
+int rows_cap_for(int lb) { return lb <= 12 ? 12 : lb <= 16 ? 16 : lb <= 20 ? 20 : 0; }
+
+int rows_per_tile_rows(int X, int d, int cap, bool exact) {
+    if (exact) {
+#define HMK_F(XV, L) if (X == XV && d == 0 && cap == L) return 8 * rows_groups(XV, 0, L, true);
+        HMK_ROWS_EXACT_LIST(HMK_F)
+#undef HMK_F
+        return 0;
+    }
+#define HMK_F(XV, DV, CAPV) if (X == XV && d == DV && cap == CAPV) return 8 * rows_groups(XV, DV, CAPV, false);
+    HMK_ROWS_CAP_LIST(HMK_F)
+#undef HMK_F
+    return 0;
+}
+
+// is there a row-packed instantiation for this class?  exact: every sequence of the set has length lb
+bool rows_kernel_available(int X, int la, int lb, bool exact) {
+    if (la < lb || lb < 2 * X || X < 1) return false;
+    const int d = la - lb;
+    if (exact) {
+#define HMK_F(XV, L) if (X == XV && d == 0 && lb == L) return true;
+        HMK_ROWS_EXACT_LIST(HMK_F)
+#undef HMK_F
+        return false;
+    }
+    const int cap = rows_cap_for(lb);
+#define HMK_F(XV, DV, CAPV) if (X == XV && d == DV && cap == CAPV) return true;
+    HMK_ROWS_CAP_LIST(HMK_F)
+#undef HMK_F
+    return false;
+}
+
+hipError_t launch_neighbors_rows(int X, int d, int cap, bool exact, const NeighborParams &P, uint32_t tile_base,
+                                 uint32_t n_tiles, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    if (exact) {
+#define HMK_F(XV, L) if (X == XV && d == 0 && cap == L) return launch_rows_t<XV, 0, L, true>(P, tile_base, n_tiles, s);
+        HMK_ROWS_EXACT_LIST(HMK_F)
+#undef HMK_F
+        return hipErrorInvalidValue;
+    }
+#define HMK_F(XV, DV, CAPV) if (X == XV && d == DV && cap == CAPV) return launch_rows_t<XV, DV, CAPV, false>(P, tile_base, n_tiles, s);
+    HMK_ROWS_CAP_LIST(HMK_F)
+#undef HMK_F
+    return hipErrorInvalidValue;
+}
+
+hipError_t warm_neighbors_rows_module() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_neighbors_rows<3, 0, 12, true, rows_groups(3, 0, 12, true), EDGES_PLAIN>));
+}
+
+}  // namespace hmk

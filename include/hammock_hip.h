@@ -127,7 +127,7 @@ typedef struct {
     uint32_t classes_u8;     /* (row length, column length) classes on the 8-bit lane path */
     uint32_t classes_u16;    /* ... on the 16-bit lane path */
     uint32_t classes_direct; /* ... on the generic one-cell-at-a-time path */
-    uint32_t reserved;
+    uint32_t classes_rows;   /* of the 8-bit lane classes: how many run the row-packed kernels (8 rows per table entry) */
     double kernel_ms;        /* device time of the scoring kernels (HIP events) */
 } hmk_neighbor_stats;
 
