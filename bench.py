@@ -37,7 +37,11 @@ E2E_DEADLINE_S = 120          # N > 1: the end-to-end extra after the timed step
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # MI355X_MICROARCH.md, LDS table: ds_read_b64 = 2 LDS cycles per wave-instruction = 256 B/clk/CU; 256 CUs at 2.4 GHz
 LDS_PEAK_GBS = 256 * 256 * 2.4          # 157,286 GB/s ("~150 TB/s aggregate for ds_read_b64/b128")
-LDS_BYTES_PER_PAIR = SEQ_LEN * 8        # one 8-byte table entry (7 shift lanes + 1 pad) per column position
+# Algorithmic LDS bytes per pair = the cells ShiftedScorer.java:67-77 adds: m (d + 1) + 2 X m - X (X + 1) = 72 at length 12,
+# max shift 3, one byte each: the row-packed kernel (k_neighbors_rows.hip) reads 72 ds_read_b64 per 8 pairs and nothing else.
+# (Rounds 1-2 read 96 B per pair: 12 entries of 7 shift lanes + 1 pad lane, zero cells of the partial overlaps included.)
+CELLS_PER_PAIR = SEQ_LEN * (2 * MAX_SHIFT + 1) - MAX_SHIFT * (MAX_SHIFT + 1)
+LDS_BYTES_PER_PAIR = CELLS_PER_PAIR
 
 
 def load_blosum62():
@@ -250,8 +254,9 @@ def main():
         pairs_rank = int(plan.pairs_scored)
         alg_bytes = 8 * n_edges_rank + 16 * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        lookups = pairs_rank * SEQ_LEN / (kern_ms * 1e-3)
-        lds_gbs = pairs_rank * LDS_BYTES_PER_PAIR / (kern_ms * 1e-3) / 1e9
+        rows_kernel = int(plan.classes_rows) > 0   # the row-packed kernel; HMK_NO_ROWS_KERNEL=1 runs round 2's shift-packed one
+        lds_per_pair = LDS_BYTES_PER_PAIR if rows_kernel else SEQ_LEN * 8
+        lds_gbs = pairs_rank * lds_per_pair / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "pairwise BLOSUM62 ShiftedScorer scores/sec (all-vs-all, thresholded neighbour list)",
             "value": value, "unit": "pair scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -267,10 +272,16 @@ def main():
             # the BINDING roofline first (LDS gather, not HBM): bytes the kernel must read from LDS
             "roofline": {"bound": "lds", "achieved": lds_gbs, "peak": LDS_PEAK_GBS, "unit": "GB/s",
                          "frac": lds_gbs / LDS_PEAK_GBS, "traffic": pmc_traffic(n, world),
-                         "kernel": "k_neighbors_swar<2, 6, 2, 12, true, 0> (NW=2 dwords/entry, 6 rows/tile, 2 columns/lane, length 12 exact)",
+                         "kernel": ("k_neighbors_rows<3, 0, 12, true, 1, 0> (max shift 3, equal lengths, length 12 at compile time, 1 group of 8 "
+                                    "rows per tile, plain edge list)" if rows_kernel else
+                                    "k_neighbors_swar<2, 6, 2, 12, true, 0> (NW=2 dwords/entry, 6 rows/tile, 2 columns/lane, length 12 exact)"),
+                         "lds_bytes_per_pair": lds_per_pair,
                          "kernel_ms": kern_ms,
-                         "definition": f"{LDS_BYTES_PER_PAIR} LDS bytes per pair ({SEQ_LEN} ds_read_b64 table lookups) x pairs per launch / "
-                                       "kernel time, against 256 B/clk/CU x 256 CU x 2.4 GHz (MI355X_MICROARCH.md, LDS table)",
+                         "definition": (f"{lds_per_pair} LDS bytes per pair (= the {CELLS_PER_PAIR} cells the reference adds per pair, one byte each: "
+                                        f"{CELLS_PER_PAIR} ds_read_b64 per 8 pairs) " if rows_kernel else
+                                        f"{lds_per_pair} LDS bytes per pair ({SEQ_LEN} ds_read_b64 table lookups) ") +
+                                       "x pairs per launch / kernel time, against 256 B/clk/CU x 256 CU x 2.4 GHz "
+                                       "(MI355X_MICROARCH.md, LDS table)",
                          "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/round2_pmc_summary.json); "
                                          "null when the workload differs from the one the counters were collected on",
                          "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -31,37 +31,9 @@
 
 namespace hmk {
 
-// Drains one wave's staged one-dword records ((column - tile's first column) | row << 16 | (score - threshold) << 22;
-// a tile has <= 65,536 columns and <= 64 rows, and the lane proof bounds score - threshold to 0..127).
-template <int MODE>
-__device__ __forceinline__ void flush_stage_rows(const HMK_LDS uint32_t *stage, uint32_t cnt, const NeighborParams &P,
-                                                 const Tile &T, int threshold, uint32_t shard) {
-    if (cnt == 0) return;
-    drain_begin();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
-    const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage, hmk_device.h)
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&P.counts[shard], (unsigned long long)cnt);
-    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    base = ((unsigned long long)bhi << 32) | blo;
-    for (uint32_t k = lane; k < cnt; k += 64) {
-        const uint32_t rec = stage[k];
-        const int score = (int)(rec >> 22) + threshold;
-        uint32_t x = T.row0 + ((rec >> 16) & 0x3Fu), m = T.col0 + (rec & 0xFFFFu);
-        if (!P.perm_identity) { x = P.perm[x]; m = P.perm[m]; }   // wave-uniform branch
-        if (P.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
-        const unsigned long long pos = base + k;
-        if (pos < P.cap_per_shard) {
-            P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
-                ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
-            if (MODE != EDGES_PLAIN) place_edge<MODE>(P, (unsigned long long)shard * P.cap_per_shard + pos, x, m);   // stored edges only
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
-    drain_end();
-}
-
+#ifndef HMK_ROWS_STAGE
+#define HMK_ROWS_STAGE 192
+#endif
 constexpr int rows_slot_bytes() { return 2248; }
 // no two table blocks of one group within a window of nd row positions may be fusable into a ds_read2[st64]_b64:
 // their distance a * SLOT + b * 192 (a slots, b = -1..1 sub-slots) must exceed 2040 bytes and not be a multiple of 512
@@ -85,31 +57,258 @@ constexpr int rows_waves(int nd, int cap, int lds_bytes) {
     return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
 }
 constexpr int rows_lds_bytes(int x, int d, int cap, int g) {   // must match the kernel's LDS map
-    return (2 * x + d + 1) * rows_slot_bytes() + 576 + 8 * g * 32 + 4 * 192 * 4;
+    return (2 * x + d + 1) * rows_slot_bytes() + 576 + 8 * g * 32 + 4 * HMK_ROWS_STAGE * 4;
 }
 
-// X max shift, D = row length - column length (>= 0), CAP column-length capacity (EXACT_LB: THE column length),
-// G groups of 8 rows per tile, MODE what a flush does beside storing the edge (hmk_device.h)
+// Everything that depends on the shape only: X max shift, D = row length - column length (>= 0), CAP column-length capacity
+// (EXACT_LB: THE column length), G groups of 8 rows per tile.
+template <int X, int D, int CAP, bool EXACT_LB, int G>
+struct RowsShape {
+    static constexpr int ND = 2 * X + D + 1;          // shift planes
+    static constexpr int NI = CAP + D;                // row positions held per group
+    static constexpr int ENT = 192;                   // bytes per row position: 24 residues x 8 rows
+    static constexpr int SLOT = rows_slot_bytes();    // see "Table placement" above
+    static constexpr int SUB = (NI + ND - 1) / ND;    // sub-slots a group's positions take
+    static constexpr int NEND = EXACT_LB ? 0 : ND - 1;   // end table: the row's last ND - 1 positions again, indexed from the row's end
+    static constexpr int TAB_BYTES = ND * SLOT;
+    static constexpr int LPADW = (CAP <= 16) ? 4 : 8; // residue dwords a lane loads (rows are P.lpad bytes apart)
+    static constexpr int TW = (X + 3) / 4;            // dwords holding the last X residues of a column
+    static constexpr int NT = X > 0 ? X : 1;
+    static_assert(X >= 0 && D >= 0 && CAP >= 2 * X && CAP >= 1 && CAP <= 32 && G >= 1 && G <= 8, "shape");
+    static_assert(G * (SUB + (NEND > 0 ? 1 : 0)) * ENT <= SLOT && rows_layout_ok(ND), "sub-slots must fit the slot; no fusable pair");
+    static_assert(TAB_BYTES <= 65536, "table offsets must fit the DS immediate");
+    // byte address of row position i of group g / of the position e places before the row's end; both are linear in g
+    // (GROUP_STEP / END_STEP bytes per group), which lets the flush add a per-lane group to the offsets instead
+    static constexpr int GROUP_STEP = SUB * ENT, END_STEP = ENT;
+    static constexpr int pos_addr(int g, int i) { return (i % ND) * SLOT + (g * SUB + i / ND) * ENT; }
+    static constexpr int end_addr(int g, int e) { return e * SLOT + (G * SUB + g) * ENT; }
+
+    // A column's residues -> table offsets (residue * 8): off[j] for position j, toff[q] for position lbs - X + q (the last X).
+    // `base` is added to every offset (the table's LDS address + a per-lane group displacement), `tbase` to the tail ones.
+    static __device__ __forceinline__ void offsets(const uint8_t *rowp, bool live, int lbs, uint32_t base, uint32_t tbase,
+                                                   uint32_t (&off)[CAP], uint32_t (&toff)[NT]) {
+        uint32_t words[LPADW], tw[TW > 0 ? TW : 1];
+#pragma unroll
+        for (int q = 0; q < LPADW; q++) words[q] = 0;
+#pragma unroll
+        for (int q = 0; q < (TW > 0 ? TW : 1); q++) tw[q] = 0;
+        if (live) {
+            const u32x4 v0 = reinterpret_cast<const u32x4 *>(rowp)[0];
+            words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+            if constexpr (LPADW == 8) {
+                const u32x4 v1 = reinterpret_cast<const u32x4 *>(rowp)[1];
+                words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
+            }
+            if (!EXACT_LB && TW > 0) {   // the last X residues, wherever the column ends (unaligned dword loads; the array is padded)
+#pragma unroll
+                for (int q = 0; q < TW; q++) __builtin_memcpy(&tw[q], rowp + (lbs - X) + 4 * q, 4);
+            }
+        }
+        // residues are < 32, so byte k of (word << 3) is residue * 8 exactly (the three bits that move in are zero)
+#pragma unroll
+        for (int q = 0; q < LPADW; q++) words[q] <<= 3;
+#pragma unroll
+        for (int j = 0; j < CAP; j++) off[j] = base + ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+        if (EXACT_LB) {
+#pragma unroll
+            for (int q = 0; q < X; q++) toff[q] = off[CAP - X + q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < TW; q++) tw[q] <<= 3;
+#pragma unroll
+            for (int q = 0; q < X; q++) toff[q] = tbase + ((tw[q >> 2] >> ((q & 3) * 8)) & 0xFFu);
+        }
+    }
+
+    // All shift sums of (8 rows of group GI) x (this lane's column): W0 / W1[u] = the 8 byte lanes of plane u.
+    // LOWP (the flush): a scheduling barrier after every position pair, so that the compiler does not put all of a column's
+    // reads in flight at once (2 x 72 registers at length 12) beside the main loop's live state.
+    template <int GI, bool LOWP = false>
+    static __device__ __forceinline__ void accumulate(const uint32_t (&off)[CAP], const uint32_t (&toff)[NT], int lbs,
+                                                      const uint32_t (&ci)[ND], uint32_t (&W0)[ND], uint32_t (&W1)[ND]) {
+        if constexpr (EXACT_LB) {
+            // everything is known at compile time: plane by plane, the plane's reads summed two at a time (one v_add3 per
+            // dword and pair; an odd count starts with a plain add): ceil(reads / 2) VALU instructions per dword, the minimum
+#pragma unroll
+            for (int u = 0; u < ND; u++) {
+                constexpr int NMAIN = CAP - X;
+                const int j0 = X - u > 0 ? X - u : 0;                 // main positions j0 .. NMAIN - 1
+                const int nt = ND - 2 - u >= X ? X : (ND - 2 - u < 0 ? 0 : ND - 1 - u);   // tail positions q = 0 .. nt - 1 (u <= ND - 2 - q)
+                const int n = NMAIN - j0 + nt;
+                uint32_t a0 = ci[u], a1 = ci[u];
+                // read k of the plane: k < NMAIN - j0: main position j0 + k; else tail position k - (NMAIN - j0)
+                auto rd = [&](int k) {
+                    const int j = k < NMAIN - j0 ? j0 + k : NMAIN + (k - (NMAIN - j0));   // column position (tail q = j - NMAIN)
+                    return lds_read<u32x2>(off[j] + (uint32_t)pos_addr(GI, j + u - X));
+                };
+                int k = 0;
+                if (n & 1) { const u32x2 e = rd(0); a0 += e.x; a1 += e.y; k = 1; }
+#pragma unroll
+                for (; k + 1 < n; k += 2) {
+                    const u32x2 e0 = rd(k), e1 = rd(k + 1);
+                    a0 = a0 + e0.x + e1.x; a1 = a1 + e0.y + e1.y;
+                }
+                W0[u] = a0; W1[u] = a1;
+                if (LOWP) __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < ND; u++) { W0[u] = ci[u]; W1[u] = ci[u]; }
+        // column position J, all planes that pair it with a row position >= 0: i = J + u - X
+        auto add_pos = [&](auto jt) {
+            constexpr int J = decltype(jt)::value;
+#pragma unroll
+            for (int u = (X - J > 0 ? X - J : 0); u < ND; u++) {
+                const u32x2 e = lds_read<u32x2>(off[J] + (uint32_t)pos_addr(GI, J + u - X));
+                W0[u] += e.x; W1[u] += e.y;
+            }
+        };
+        // the main positions j < lbs - X (every plane's row position stays below the row's end), two at a time so that
+        // the adds pair up into v_add3; an odd count takes position 0 on its own first (cf. k_neighbors_planes)
+        auto add_pairs = [&](auto start_tag) {
+            constexpr int J0 = decltype(start_tag)::value;
+            int nmain = lbs - X;
+            if (!EXACT_LB) asm volatile("" : "+s"(nmain));   // keep the tests scalar (s_cmp + s_cbranch), see k_neighbors_planes
+#pragma unroll
+            for (int j = J0; j + 1 < CAP - X; j += 2) {
+                if (j + 1 >= nmain) break;
+                // both positions of a plane next to each other: one v_add3 per dword
+#pragma unroll
+                for (int u = 0; u < ND; u++) {
+                    const bool v0 = u >= X - j, v1 = u >= X - (j + 1);
+                    if (v0 && v1) {
+                        const u32x2 e0 = lds_read<u32x2>(off[j] + (uint32_t)pos_addr(GI, j + u - X));
+                        const u32x2 e1 = lds_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(GI, j + 1 + u - X));
+                        W0[u] = W0[u] + e0.x + e1.x; W1[u] = W1[u] + e0.y + e1.y;
+                    } else if (v1) {
+                        const u32x2 e1 = lds_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(GI, j + 1 + u - X));
+                        W0[u] += e1.x; W1[u] += e1.y;
+                    }
+                }
+                if (LOWP) __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if ((lbs - X) & 1) {
+            add_pos(std::integral_constant<int, 0>{});
+            add_pairs(std::integral_constant<int, 1>{});
+        } else {
+            add_pairs(std::integral_constant<int, 0>{});
+        }
+        if (LOWP) __builtin_amdgcn_sched_barrier(0);
+        // the last X column positions: position lbs - X + q pairs with row position lbs - 2X + q + u, which is inside the
+        // row (length lbs + D) for planes u <= ND - 2 - q only; that row position is ND - 2 - q - u places before the row's
+        // end, whatever the column length (end table)
+#pragma unroll
+        for (int u = 0; u < ND; u++) {
+#pragma unroll
+            for (int q = 0; q < X; q++) {
+                if (u <= ND - 2 - q) {
+                    const u32x2 e = lds_read<u32x2>(toff[q] + (uint32_t)(EXACT_LB ? pos_addr(GI, CAP - 2 * X + q + u) : end_addr(GI, ND - 2 - q - u)));
+                    W0[u] += e.x; W1[u] += e.y;
+                }
+            }
+        }
+    }
+};
+
+// What a flush needs, passed BY VALUE to a function that is NOT inlined: inlined, the flush (which scores whole columns again
+// and wants most of the register file) made the compiler keep the append loop's state in scratch memory on every pass.
+struct RowsFlushArgs {
+    const uint8_t *res_sorted;
+    const uint32_t *perm;
+    const TileClass *cls;
+    uint64_t *edges;
+    unsigned long long *counts;
+    uint64_t cap_per_shard;
+    uint32_t *deg, *deg_up, *deg_lo, *rank;
+    uint32_t lpad, symmetric, perm_identity, row0, col0, shard, tab_addr;
+    int lbs, threshold;
+};
+
+// Drains one wave's staged records ((column - tile's first column) | row within the tile << 16).  A record says WHICH pair
+// reached the threshold; its score is worked out here, where every lane has a record of its own: the pair's column is
+// fetched again and scored against its row group's tables (all planes of 8 rows), and the lane's row is cut out of every
+// plane's sums.  In the main loop the same extraction ran for one or two live lanes per wave-instruction and was a fifth of
+// the kernel's VALU work (VALU 99 % busy beside LDS 88 %).
+template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
+__device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_t *stage, uint32_t cnt, const RowsFlushArgs A) {
+    using S = RowsShape<X, D, CAP, EXACT_LB, G>;
+    if (cnt == 0) return;
+    const int lbs = __builtin_amdgcn_readfirstlane(A.lbs);   // arguments arrive in vector registers: the uniform ones the scalar tests need
+    drain_begin();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
+    const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage, hmk_device.h)
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&A.counts[A.shard], (unsigned long long)cnt);
+    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    base = ((unsigned long long)bhi << 32) | blo;
+    const int la = lbs + D;
+    const uint32_t tab = __builtin_amdgcn_readfirstlane(A.tab_addr);
+    const uint8_t *cinit = reinterpret_cast<const uint8_t *>(A.cls->cinit);   // one byte per shift: the lanes' initial value
+    for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {   // wave-uniform trip count: the table reads below run for whole waves
+        const uint32_t k = k0 + lane;
+        const bool live = k < cnt;
+        const uint32_t rec = live ? stage[k] : 0u;
+        const uint32_t rt = rec >> 16, grp = rt >> 3, r = rt & 7u;
+        const uint32_t mcol = A.col0 + (rec & 0xFFFFu);
+        uint32_t off[CAP], toff[S::NT];
+        S::offsets(A.res_sorted + (size_t)mcol * A.lpad, live, lbs, tab + grp * (uint32_t)S::GROUP_STEP, 0u, off, toff);
+        // One plane at a time, in a loop that is NOT unrolled (this path is cold and must stay small in registers): the plane's
+        // cells straight from the position table, row position i = j + u - X wherever it lies inside the row -- the literal
+        // form of ShiftedScorer.java:67-77 on the packed cells, independent of the main loop's unrolled schedule.
+        uint32_t mx = 0;   // best shift = largest lane of this record's row
+        const uint32_t sh = (r & 3u) * 8u;
+#pragma unroll 1
+        for (int u = 0; u < S::ND; u++) {
+            uint32_t a0 = (uint32_t)cinit[u] * 0x01010101u, a1 = a0;
+#pragma unroll
+            for (int j = 0; j < CAP; j++) {
+                const int i = j + u - X;
+                if (j < lbs && i >= 0 && i < la) {   // wave-uniform
+                    const u32x2 e = lds_read<u32x2>(off[j] + (uint32_t)((i % S::ND) * S::SLOT + (i / S::ND) * S::ENT));
+                    a0 += e.x; a1 += e.y;
+                }
+            }
+            mx = max(mx, ((r < 4u ? a0 : a1) >> sh) & 0xFFu);
+        }
+        const int score = (int)mx - 128 + A.threshold;   // lane = 128 - threshold + score
+        uint32_t x = A.row0 + rt, m = mcol;
+        if (!A.perm_identity && live) { x = A.perm[x]; m = A.perm[m]; }
+        if (A.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
+        const unsigned long long pos = base + k;
+        if (live && pos < A.cap_per_shard) {
+            const unsigned long long slot = (unsigned long long)A.shard * A.cap_per_shard + pos;
+            A.edges[slot] = ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
+            // (place_edge of hmk_device.h on the copied fields; stored edges only)
+            if (MODE == EDGES_PLACE) {
+                const uint32_t rx = atomicAdd(&A.deg_up[x], 1u);
+                const uint32_t rm = A.symmetric ? atomicAdd(&A.deg_lo[m], 1u) : 0u;
+                reinterpret_cast<uint2 *>(A.rank)[slot] = make_uint2(rx, rm);
+            } else if (MODE == EDGES_COUNT) {
+                atomicAdd(&A.deg[x], 1u);
+                if (A.symmetric) atomicAdd(&A.deg[m], 1u);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
+    drain_end();
+}
+
+template <class F, int... Is>
+__device__ __forceinline__ void rows_for_each_group(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// MODE: what a flush does beside storing the edge (hmk_device.h)
 template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
 __global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, G)))
 k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
-    constexpr int ND = 2 * X + D + 1;          // shift planes
-    constexpr int NI = CAP + D;                // row positions held per group
-    constexpr int ENT = 192;                   // bytes per row position: 24 residues x 8 rows
+    using S = RowsShape<X, D, CAP, EXACT_LB, G>;
+    constexpr int ND = S::ND, NI = S::NI, ENT = S::ENT, SLOT = S::SLOT, SUB = S::SUB, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
     constexpr int R = 8 * G;
-    constexpr int SLOT = rows_slot_bytes();    // see "Table placement" above
-    constexpr int SUB = (NI + ND - 1) / ND;    // sub-slots a group's positions take
-    constexpr int NEND = EXACT_LB ? 0 : ND - 1;   // end table: the row's last ND - 1 positions again, indexed from the row's end
-    static_assert(G * (SUB + (NEND > 0 ? 1 : 0)) * ENT <= SLOT && rows_layout_ok(ND), "sub-slots must fit the slot; no fusable pair");
-    constexpr int TAB_BYTES = ND * SLOT;
-    // byte address of row position i of group g / of the position e places before the row's end
-    auto pos_addr = [](int g, int i) constexpr { return (i % ND) * SLOT + (g * SUB + i / ND) * ENT; };
-    auto end_addr = [](int g, int e) constexpr { return e * SLOT + (G * SUB + g) * ENT; };
-    constexpr int STAGE_CAP = 192;             // records per wave; flushed when fewer than 64 slots are free
-    constexpr int LPADW = (CAP <= 16) ? 4 : 8; // residue dwords a lane loads (rows are P.lpad bytes apart)
-    constexpr int TW = (X + 3) / 4;            // dwords holding the last X residues of a column
-    static_assert(X >= 0 && D >= 0 && CAP >= 2 * X && CAP >= 1 && CAP <= 32 && G >= 1 && G <= 8, "shape");
-    static_assert(TAB_BYTES <= 65536, "table offsets must fit the DS immediate");
+    constexpr int STAGE_CAP = HMK_ROWS_STAGE;  // records per wave; flushed when fewer than 64 slots are free
     constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4;
     static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, G), "rows_lds_bytes must match the LDS map");
     // one STATIC LDS object: its base address is a compile-time constant, so table offsets fold into the ds_read immediate
@@ -127,7 +326,8 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     const int threshold = 128 - Cp->g;
     const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
     const int tid = threadIdx.x;
-    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * STAGE_CAP;   // 32-bit LDS pointer
+    // 32-bit LDS pointer, wave-uniform (kept in a scalar register: nothing to spill around the flush call)
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_CAP;
 
     build_begin();
     for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
@@ -172,139 +372,79 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     const uint32_t col_end = T.col0 + T.ncols;
     const uint32_t n_batches = (T.ncols + 255) / 256;
     const bool interior = T.diag == 0 && T.ncols % 256 == 0;  // every lane's column is a real pair
-    const bool prio = MODE != EDGES_PLACE && (MODE != EDGES_RUNTIME || P.rank == nullptr || HMK_SETPRIO_PLACE);
+    const bool prio = MODE != EDGES_PLACE || HMK_SETPRIO_PLACE;
+
+    auto flush_args = [&]() {
+        return RowsFlushArgs{P.res_sorted, P.perm, Cp, P.edges, P.counts, P.cap_per_shard, P.deg, P.deg_up, P.deg_lo, P.rank,
+                             P.lpad, P.symmetric, P.perm_identity, T.row0, T.col0, shard, tab_addr, lbs, threshold};
+    };
 
     for (uint32_t bt = 0; bt < n_batches; bt++) {
-        // ---- this lane's column peptide -> per-position table offsets (residue * 8) ----
-        const uint32_t col = T.col0 + bt * 256 + tid;
-        uint32_t words[LPADW], tw[TW > 0 ? TW : 1];
-#pragma unroll
-        for (int q = 0; q < LPADW; q++) words[q] = 0;
-#pragma unroll
-        for (int q = 0; q < (TW > 0 ? TW : 1); q++) tw[q] = 0;
-        if (col < col_end) {
-            const uint8_t *rowp = P.res_sorted + (size_t)col * P.lpad;
-            const u32x4 v0 = reinterpret_cast<const u32x4 *>(rowp)[0];
-            words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
-            if (LPADW == 8) {
-                const u32x4 v1 = reinterpret_cast<const u32x4 *>(rowp)[1];
-                words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
-            }
-            if (!EXACT_LB && TW > 0) {   // the last X residues, wherever the column ends (unaligned dword loads; the array is padded)
-#pragma unroll
-                for (int q = 0; q < TW; q++) __builtin_memcpy(&tw[q], rowp + (lbs - X) + 4 * q, 4);
-            }
-        }
-        // residues are < 32, so byte k of (word << 3) is residue * 8 exactly (the three bits that move in are zero)
-        uint32_t off[CAP];
-#pragma unroll
-        for (int q = 0; q < LPADW; q++) words[q] <<= 3;
-#pragma unroll
-        for (int j = 0; j < CAP; j++) off[j] = tab_addr + ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
-        uint32_t toff[X > 0 ? X : 1];   // tail position q = column position lbs - X + q
-        if (EXACT_LB) {
-#pragma unroll
-            for (int q = 0; q < X; q++) toff[q] = off[CAP - X + q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < TW; q++) tw[q] <<= 3;
-#pragma unroll
-            for (int q = 0; q < X; q++) toff[q] = tab_addr + ((tw[q >> 2] >> ((q & 3) * 8)) & 0xFFu);
-        }
+        const uint32_t colrel = bt * 256 + tid;
+        const uint32_t col = T.col0 + colrel;
+        uint32_t off[CAP], toff[S::NT];
+        S::offsets(P.res_sorted + (size_t)col * P.lpad, col < col_end, lbs, tab_addr, tab_addr, off, toff);
 
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            if ((uint32_t)(8 * g) >= T.nrows) break;   // wave-uniform
+        auto one_group = [&](auto gt) {
+            constexpr int g = decltype(gt)::value;
+            if ((uint32_t)(8 * g) >= T.nrows) return;   // wave-uniform
             uint32_t W0[ND], W1[ND];
-#pragma unroll
-            for (int u = 0; u < ND; u++) { W0[u] = ci[u]; W1[u] = ci[u]; }
-            // column position J, all planes that pair it with a row position >= 0: i = J + u - X
-            auto add_pos = [&](auto jt) {
-                constexpr int J = decltype(jt)::value;
-#pragma unroll
-                for (int u = (X - J > 0 ? X - J : 0); u < ND; u++) {
-                    const u32x2 e = lds_read<u32x2>(off[J] + (uint32_t)pos_addr(g, J + u - X));
-                    W0[u] += e.x; W1[u] += e.y;
-                }
-            };
-            // the main positions j < lbs - X (every plane's row position stays below the row's end), two at a time so that
-            // the adds pair up into v_add3; an odd count takes position 0 on its own first (cf. k_neighbors_planes)
-            auto add_pairs = [&](auto start_tag) {
-                constexpr int J0 = decltype(start_tag)::value;
-                int nmain = lbs - X;
-                if (!EXACT_LB) asm volatile("" : "+s"(nmain));   // keep the tests scalar (s_cmp + s_cbranch), see k_neighbors_planes
-#pragma unroll
-                for (int j = J0; j + 1 < CAP - X; j += 2) {
-                    if (j + 1 >= nmain) break;
-                    // both positions of a plane next to each other: one v_add3 per dword
-#pragma unroll
-                    for (int u = 0; u < ND; u++) {
-                        const bool v0 = u >= X - j, v1 = u >= X - (j + 1);
-                        if (v0 && v1) {
-                            const u32x2 e0 = lds_read<u32x2>(off[j] + (uint32_t)pos_addr(g, j + u - X));
-                            const u32x2 e1 = lds_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(g, j + 1 + u - X));
-                            W0[u] = W0[u] + e0.x + e1.x; W1[u] = W1[u] + e0.y + e1.y;
-                        } else if (v1) {
-                            const u32x2 e1 = lds_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(g, j + 1 + u - X));
-                            W0[u] += e1.x; W1[u] += e1.y;
-                        }
-                    }
-                }
-            };
             read_phase_begin(prio);
-            if ((lbs - X) & 1) {
-                add_pos(std::integral_constant<int, 0>{});
-                add_pairs(std::integral_constant<int, 1>{});
-            } else {
-                add_pairs(std::integral_constant<int, 0>{});
-            }
-            // the last X column positions: position lbs - X + q pairs with row position lbs - 2X + q + u, which is inside the
-            // row (length lbs + D) for planes u <= ND - 2 - q only; that row position is ND - 2 - q - u places before the row's
-            // end, whatever the column length (end table)
-#pragma unroll
-            for (int u = 0; u < ND; u++) {
-#pragma unroll
-                for (int q = 0; q < X; q++) {
-                    if (u <= ND - 2 - q) {
-                        const u32x2 e = lds_read<u32x2>(toff[q] + (uint32_t)(EXACT_LB ? pos_addr(g, CAP - 2 * X + q + u) : end_addr(g, ND - 2 - q - u)));
-                        W0[u] += e.x; W1[u] += e.y;
-                    }
-                }
-            }
+            S::template accumulate<g>(off, toff, lbs, ci, W0, W1);
             read_phase_end(prio);
 
             // ---- threshold test: some (row, shift) lane has its top bit set <=> score >= threshold ----
             uint32_t o0 = W0[0], o1 = W1[0];
 #pragma unroll
             for (int u = 1; u < ND; u++) { o0 |= W0[u]; o1 |= W1[u]; }
-            if (__ballot(((o0 | o1) & 0x80808080u) != 0) == 0) continue;
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                if ((uint32_t)(8 * g + r) >= T.nrows) break;   // wave-uniform
-                const bool hit = (((r < 4 ? o0 : o1) >> ((r & 3) * 8 + 7)) & 1u) != 0;
-                if (__ballot(hit) == 0) continue;   // wave-uniform
-                if (cnt > (uint32_t)(STAGE_CAP - 64)) {  // keep room for one wave of hits
-                    flush_stage_rows<MODE>(stage, cnt, P, T, threshold, shard);
-                    cnt = 0;
-                }
-                bool keep = hit;
-                if (!interior) {  // wave-uniform: only edge tiles filter
-                    keep = keep && col < col_end;
-                    if (T.diag == 1) keep = keep && col > T.row0 + 8 * g + r;   // triangle: column after row
-                    if (T.diag == 2) keep = keep && col != T.row0 + 8 * g + r;  // full square minus the diagonal
-                }
-                const uint64_t mask = __ballot(keep);
-                if (keep) {   // score - threshold = best lane - 128, in 0..127
-                    uint32_t mx = 0;
-#pragma unroll
-                    for (int u = 0; u < ND; u++) mx = max(mx, ((r < 4 ? W0[u] : W1[u]) >> ((r & 3) * 8)) & 0xFFu);
-                    stage[cnt + mbcnt64(mask)] = (col - T.col0) | ((uint32_t)(8 * g + r) << 16) | ((mx - 128u) << 22);
-                }
-                cnt += (uint32_t)__popcll(mask);
+            if (__ballot(((o0 | o1) & 0x80808080u) != 0) == 0) return;
+            // ---- rare path (a hit somewhere in the wave): every lane appends ITS hits, one per turn ----
+            // h0 / h1: bit 8r + 7 set <=> row r / 4 + r of the group reached the threshold for this lane's column
+            uint32_t h0 = o0 & 0x80808080u, h1 = o1 & 0x80808080u;
+            const uint32_t rows_here = T.nrows - 8 * g;   // rows of this group that exist (wave-uniform)
+            if (rows_here < 8) {   // the rows beyond start at the initial lane value, which may itself have the top bit set
+                h0 &= rows_here >= 4 ? 0xFFFFFFFFu : (1u << (8 * rows_here)) - 1u;
+                h1 &= rows_here <= 4 ? 0u : (1u << (8 * (rows_here - 4))) - 1u;
             }
-        }
+            if (!interior) {  // wave-uniform: only edge tiles filter
+                if (col >= col_end) { h0 = 0; h1 = 0; }
+                if (T.diag != 0) {
+                    const int k = (int)col - (int)(T.row0 + 8 * g);   // the row this column IS, relative to the group
+                    if (T.diag == 1) {   // triangle: keep rows r with column > row, i.e. r < k
+                        const int k0 = k < 0 ? 0 : k > 4 ? 4 : k, k1 = k < 4 ? 0 : k > 8 ? 4 : k - 4;
+                        h0 &= k0 >= 4 ? 0xFFFFFFFFu : (1u << (8 * k0)) - 1u;
+                        h1 &= k1 >= 4 ? 0xFFFFFFFFu : (1u << (8 * k1)) - 1u;
+                    } else if (k >= 0 && k < 8) {   // full square minus the diagonal
+                        if (k < 4) h0 &= ~(0x80u << (8 * k)); else h1 &= ~(0x80u << (8 * (k - 4)));
+                    }
+                }
+            }
+            // (the flush sits OUTSIDE the append loop: it scores whole columns again and needs most of the register file; inside the
+            // loop the compiler kept h0 / h1 in scratch memory for every turn of it)
+            for (;;) {
+                bool full = false;
+                for (;;) {
+                    const bool any = (h0 | h1) != 0;
+                    const uint64_t mask = __ballot(any);
+                    if (mask == 0) break;
+                    if (cnt > (uint32_t)(STAGE_CAP - 64)) { full = true; break; }   // keep room for one wave of hits
+                    if (any) {
+                        const bool lo = h0 != 0;
+                        const uint32_t h = lo ? h0 : h1;
+                        const uint32_t row = ((uint32_t)__builtin_ctz(h) >> 3) + (lo ? 0u : 4u);
+                        stage[cnt + mbcnt64(mask)] = (bt * 256 + threadIdx.x) | ((uint32_t)(8 * g) + row) << 16;   // (recomputed: cheaper than keeping it across the flush call)
+                        if (lo) h0 &= h0 - 1u; else h1 &= h1 - 1u;   // clear the lowest set bit
+                    }
+                    cnt += (uint32_t)__popcll(mask);
+                }
+                if (!full) break;
+                flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, flush_args());
+                cnt = 0;
+            }
+        };
+        rows_for_each_group(std::make_integer_sequence<int, G>{}, one_group);
     }
-    flush_stage_rows<MODE>(stage, cnt, P, T, threshold, shard);
+    flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, flush_args());
 }
 
 // -----------------------------------------------------------------------------
@@ -313,7 +453,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
 // Uniform-length sets with the reference's default max shift for that length (Hammock.java:1421-1434: round(L / 4)) get
 // their column length at compile time; everything else runs the capacity form (column length <= CAP at run time).
 #ifndef HMK_ROWS_G
-#define HMK_ROWS_G 2
+#define HMK_ROWS_G 1
 #endif
 // groups of 8 rows per tile: HMK_ROWS_G, or as many as the sub-slots of a slot hold
 constexpr int rows_groups(int x, int d, int cap, bool exact) {
@@ -321,8 +461,6 @@ constexpr int rows_groups(int x, int d, int cap, bool exact) {
     const int fit = rows_slot_bytes() / 192 / sub;
     return fit < 1 ? 0 : fit < HMK_ROWS_G ? fit : HMK_ROWS_G;
 }
-
-struct RowsShape { int x, d, cap; bool exact; };
 
 template <int X, int D, int CAP, bool EXACT_LB>
 static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
@@ -339,11 +477,15 @@ static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uin
 
 // the list: HMK_ROWS_EXACT(X, L) uniform length L; HMK_ROWS_CAP(X, D, CAP) column length <= CAP, rows D longer
 #define HMK_ROWS_EXACT_LIST(F) F(3, 12)
+#ifdef HMK_ROWS_MINIMAL   // tuning builds (tools/ab_flags.sh): the BASELINE shapes only, seconds to compile
+#define HMK_ROWS_CAP_LIST(F) F(3, 0, 12)
+#else
 #define HMK_ROWS_CAP_LIST(F) \
     F(3, 0, 12) F(3, 1, 12) F(3, 2, 12) F(3, 3, 12) F(3, 4, 12) F(3, 5, 12) F(3, 6, 12) F(3, 7, 12) F(3, 8, 12) F(3, 9, 12) \
     F(3, 10, 12) F(3, 11, 12) F(3, 12, 12) F(3, 13, 12) \
     F(3, 0, 16) F(3, 1, 16) F(3, 2, 16) F(3, 3, 16) F(3, 4, 16) F(3, 5, 16) F(3, 6, 16) F(3, 7, 16) \
     F(3, 0, 20) F(3, 1, 20) F(3, 2, 20) F(3, 3, 20)
+#endif
 
 int rows_cap_for(int lb) { return lb <= 12 ? 12 : lb <= 16 ? 16 : lb <= 20 ? 20 : 0; }
 

@@ -8,8 +8,8 @@ mkdir -p gpurun_out/ab
 B="python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-greedy"
 IFS=";" read -ra VARS <<< "${VARIANTS:-;-DHMK_SETPRIO=0;-DHMK_SETPRIO_DRAIN=0;-DHMK_SETPRIO=1;-DHMK_SETPRIO=3;;-DHMK_SETPRIO=0}"
 for v in "${VARS[@]}"; do
-  touch hammock_amd/csrc/k_neighbors.hip
-  make -C hammock_amd/csrc CXXFLAGS="$F $v" > gpurun_out/ab/make.log 2>&1 || exit 1
+  touch hammock_amd/csrc/k_neighbors.hip hammock_amd/csrc/k_neighbors_rows.hip
+  make -C hammock_amd/csrc -j8 CXXFLAGS="$F $v" > gpurun_out/ab/make.log 2>&1 || exit 1
   $B > gpurun_out/ab/b.json 2>/dev/null
   timeout -k 10 100 python tools/run_config4a.py > gpurun_out/ab/c4a.json 2>/dev/null
   python -c "

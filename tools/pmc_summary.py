@@ -15,7 +15,7 @@ import shutil
 import sys
 
 out, rnd = sys.argv[1], sys.argv[2]
-HOT = "k_neighbors_swar<2, 6, 2, 12, true, 0>"
+HOT = os.environ.get("HMK_HOT_KERNEL_NAME", "k_neighbors_rows<3, 0, 12, true, 1, 0>")   # round 2: "k_neighbors_swar<2, 6, 2, 12, true, 0>"
 
 
 def find(pattern):
