@@ -34,7 +34,20 @@ namespace hmk {
 #ifndef HMK_ROWS_STAGE
 #define HMK_ROWS_STAGE 192
 #endif
+// HMK_ROWS_COMPACT=1 (default): the table reads are VOLATILE loads, which the compiler's load/store optimiser leaves alone, and
+// the tables are packed (192 bytes per row position); 0: plain loads and the spread-out placement described above.
+#ifndef HMK_ROWS_COMPACT
+#define HMK_ROWS_COMPACT 1
+#endif
 constexpr int rows_slot_bytes() { return 2248; }
+template <typename T>
+__device__ __forceinline__ T rows_table_read(uint32_t addr) {
+#if HMK_ROWS_COMPACT
+    return *reinterpret_cast<const volatile HMK_LDS T *>((uintptr_t)addr);
+#else
+    return lds_read<T>(addr);
+#endif
+}
 // no two table blocks of one group within a window of nd row positions may be fusable into a ds_read2[st64]_b64:
 // their distance a * SLOT + b * 192 (a slots, b = -1..1 sub-slots) must exceed 2040 bytes and not be a multiple of 512
 constexpr bool rows_layout_ok(int nd) {
@@ -56,8 +69,12 @@ constexpr int rows_waves(int nd, int cap, int lds_bytes) {
     const int by_lds = 163840 / ((lds_bytes + 511) / 512 * 512);
     return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
 }
-constexpr int rows_lds_bytes(int x, int d, int cap, int g) {   // must match the kernel's LDS map
-    return (2 * x + d + 1) * rows_slot_bytes() + 576 + 8 * g * 32 + 4 * HMK_ROWS_STAGE * 4;
+constexpr int rows_tab_bytes(int x, int d, int cap, bool exact, int g) {
+    const int nd = 2 * x + d + 1;
+    return HMK_ROWS_COMPACT ? g * (cap + d + (exact ? 0 : nd - 1)) * 192 : nd * rows_slot_bytes();
+}
+constexpr int rows_lds_bytes(int x, int d, int cap, bool exact, int g) {   // must match the kernel's LDS map
+    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * HMK_ROWS_STAGE * 4;
 }
 
 // Everything that depends on the shape only: X max shift, D = row length - column length (>= 0), CAP column-length capacity
@@ -70,18 +87,18 @@ struct RowsShape {
     static constexpr int SLOT = rows_slot_bytes();    // see "Table placement" above
     static constexpr int SUB = (NI + ND - 1) / ND;    // sub-slots a group's positions take
     static constexpr int NEND = EXACT_LB ? 0 : ND - 1;   // end table: the row's last ND - 1 positions again, indexed from the row's end
-    static constexpr int TAB_BYTES = ND * SLOT;
+    static constexpr int TAB_BYTES = rows_tab_bytes(X, D, CAP, EXACT_LB, G);
     static constexpr int LPADW = (CAP <= 16) ? 4 : 8; // residue dwords a lane loads (rows are P.lpad bytes apart)
     static constexpr int TW = (X + 3) / 4;            // dwords holding the last X residues of a column
     static constexpr int NT = X > 0 ? X : 1;
     static_assert(X >= 0 && D >= 0 && CAP >= 2 * X && CAP >= 1 && CAP <= 32 && G >= 1 && G <= 8, "shape");
-    static_assert(G * (SUB + (NEND > 0 ? 1 : 0)) * ENT <= SLOT && rows_layout_ok(ND), "sub-slots must fit the slot; no fusable pair");
+    static_assert(HMK_ROWS_COMPACT || (G * (SUB + (NEND > 0 ? 1 : 0)) * ENT <= SLOT && rows_layout_ok(ND)), "sub-slots must fit the slot; no fusable pair");
     static_assert(TAB_BYTES <= 65536, "table offsets must fit the DS immediate");
     // byte address of row position i of group g / of the position e places before the row's end; both are linear in g
     // (GROUP_STEP / END_STEP bytes per group), which lets the flush add a per-lane group to the offsets instead
-    static constexpr int GROUP_STEP = SUB * ENT, END_STEP = ENT;
-    static constexpr int pos_addr(int g, int i) { return (i % ND) * SLOT + (g * SUB + i / ND) * ENT; }
-    static constexpr int end_addr(int g, int e) { return e * SLOT + (G * SUB + g) * ENT; }
+    static constexpr int GROUP_STEP = HMK_ROWS_COMPACT ? NI * ENT : SUB * ENT;
+    static constexpr int pos_addr(int g, int i) { return HMK_ROWS_COMPACT ? (g * NI + i) * ENT : (i % ND) * SLOT + (g * SUB + i / ND) * ENT; }
+    static constexpr int end_addr(int g, int e) { return HMK_ROWS_COMPACT ? (G * NI + g * NEND + e) * ENT : e * SLOT + (G * SUB + g) * ENT; }
 
     // A column's residues -> table offsets (residue * 8): off[j] for position j, toff[q] for position lbs - X + q (the last X).
     // `base` is added to every offset (the table's LDS address + a per-lane group displacement), `tbase` to the tail ones.
@@ -139,7 +156,7 @@ struct RowsShape {
                 // read k of the plane: k < NMAIN - j0: main position j0 + k; else tail position k - (NMAIN - j0)
                 auto rd = [&](int k) {
                     const int j = k < NMAIN - j0 ? j0 + k : NMAIN + (k - (NMAIN - j0));   // column position (tail q = j - NMAIN)
-                    return lds_read<u32x2>(off[j] + (uint32_t)pos_addr(GI, j + u - X));
+                    return rows_table_read<u32x2>(off[j] + (uint32_t)pos_addr(GI, j + u - X));
                 };
                 int k = 0;
                 if (n & 1) { const u32x2 e = rd(0); a0 += e.x; a1 += e.y; k = 1; }
@@ -160,7 +177,7 @@ struct RowsShape {
             constexpr int J = decltype(jt)::value;
 #pragma unroll
             for (int u = (X - J > 0 ? X - J : 0); u < ND; u++) {
-                const u32x2 e = lds_read<u32x2>(off[J] + (uint32_t)pos_addr(GI, J + u - X));
+                const u32x2 e = rows_table_read<u32x2>(off[J] + (uint32_t)pos_addr(GI, J + u - X));
                 W0[u] += e.x; W1[u] += e.y;
             }
         };
@@ -178,11 +195,11 @@ struct RowsShape {
                 for (int u = 0; u < ND; u++) {
                     const bool v0 = u >= X - j, v1 = u >= X - (j + 1);
                     if (v0 && v1) {
-                        const u32x2 e0 = lds_read<u32x2>(off[j] + (uint32_t)pos_addr(GI, j + u - X));
-                        const u32x2 e1 = lds_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(GI, j + 1 + u - X));
+                        const u32x2 e0 = rows_table_read<u32x2>(off[j] + (uint32_t)pos_addr(GI, j + u - X));
+                        const u32x2 e1 = rows_table_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(GI, j + 1 + u - X));
                         W0[u] = W0[u] + e0.x + e1.x; W1[u] = W1[u] + e0.y + e1.y;
                     } else if (v1) {
-                        const u32x2 e1 = lds_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(GI, j + 1 + u - X));
+                        const u32x2 e1 = rows_table_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(GI, j + 1 + u - X));
                         W0[u] += e1.x; W1[u] += e1.y;
                     }
                 }
@@ -204,7 +221,7 @@ struct RowsShape {
 #pragma unroll
             for (int q = 0; q < X; q++) {
                 if (u <= ND - 2 - q) {
-                    const u32x2 e = lds_read<u32x2>(toff[q] + (uint32_t)(EXACT_LB ? pos_addr(GI, CAP - 2 * X + q + u) : end_addr(GI, ND - 2 - q - u)));
+                    const u32x2 e = rows_table_read<u32x2>(toff[q] + (uint32_t)(EXACT_LB ? pos_addr(GI, CAP - 2 * X + q + u) : end_addr(GI, ND - 2 - q - u)));
                     W0[u] += e.x; W1[u] += e.y;
                 }
             }
@@ -267,7 +284,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
             for (int j = 0; j < CAP; j++) {
                 const int i = j + u - X;
                 if (j < lbs && i >= 0 && i < la) {   // wave-uniform
-                    const u32x2 e = lds_read<u32x2>(off[j] + (uint32_t)((i % S::ND) * S::SLOT + (i / S::ND) * S::ENT));
+                    const u32x2 e = lds_read<u32x2>(off[j] + (uint32_t)S::pos_addr(0, i));
                     a0 += e.x; a1 += e.y;
                 }
             }
@@ -303,14 +320,14 @@ __device__ __forceinline__ void rows_for_each_group(std::integer_sequence<int, I
 
 // MODE: what a flush does beside storing the edge (hmk_device.h)
 template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
-__global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, G)))
+__global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, EXACT_LB, G)))
 k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     using S = RowsShape<X, D, CAP, EXACT_LB, G>;
-    constexpr int ND = S::ND, NI = S::NI, ENT = S::ENT, SLOT = S::SLOT, SUB = S::SUB, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
+    constexpr int ND = S::ND, NI = S::NI, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
     constexpr int R = 8 * G;
     constexpr int STAGE_CAP = HMK_ROWS_STAGE;  // records per wave; flushed when fewer than 64 slots are free
     constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4;
-    static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, G), "rows_lds_bytes must match the LDS map");
+    static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, EXACT_LB, G), "rows_lds_bytes must match the LDS map");
     // one STATIC LDS object: its base address is a compile-time constant, so table offsets fold into the ds_read immediate
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
     uint8_t *tab = smem;
@@ -345,7 +362,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
         const int gi = ic / 24, c = ic - gi * 24;
         const int g = gi / (NI + NEND), k = gi - g * (NI + NEND);
         const int i = k < NI ? k : la - 1 - (k - NI);
-        const int dst = k < NI ? (k % ND) * SLOT + (g * SUB + k / ND) * ENT : (k - NI) * SLOT + (G * SUB + g) * ENT;
+        const int dst = k < NI ? S::pos_addr(g, k) : S::end_addr(g, k - NI);
         uint32_t v = 0;
         if (i >= 0 && i < la) {
 #pragma unroll
@@ -452,14 +469,18 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
 // -----------------------------------------------------------------------------
 // Uniform-length sets with the reference's default max shift for that length (Hammock.java:1421-1434: round(L / 4)) get
 // their column length at compile time; everything else runs the capacity form (column length <= CAP at run time).
-#ifndef HMK_ROWS_G
-#define HMK_ROWS_G 1
+#ifndef HMK_ROWS_G          // capacity form (mixed lengths: a length bucket's short column runs; 1 / 2 / 3 / 4 groups: 4.87 / 4.48 / 4.58 /
+#define HMK_ROWS_G 2        // 4.74 ms on BASELINE config 4a)
+#endif
+#ifndef HMK_ROWS_G_EXACT    // one length for all: long column runs, the tile's dead time is small either way (2.65-2.67 ms with 1 or 2)
+#define HMK_ROWS_G_EXACT 1
 #endif
 // groups of 8 rows per tile: HMK_ROWS_G, or as many as the sub-slots of a slot hold
 constexpr int rows_groups(int x, int d, int cap, bool exact) {
     const int nd = 2 * x + d + 1, sub = (cap + d + nd - 1) / nd + (exact ? 0 : 1);
-    const int fit = rows_slot_bytes() / 192 / sub;
-    return fit < 1 ? 0 : fit < HMK_ROWS_G ? fit : HMK_ROWS_G;
+    const int fit = HMK_ROWS_COMPACT ? 8 : rows_slot_bytes() / 192 / sub;
+    const int want = exact ? HMK_ROWS_G_EXACT : HMK_ROWS_G;
+    return fit < 1 ? 0 : fit < want ? fit : want;
 }
 
 template <int X, int D, int CAP, bool EXACT_LB>
