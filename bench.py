@@ -51,11 +51,11 @@ def load_blosum62():
 
 def pmc_traffic(n, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/round2_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
+    (profiles/round3_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
     command, gfx950 x2 read correction applied).  Counters cannot be read from inside the timed
     run, so the value is only reported for the workload it was collected on; otherwise null."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round2_pmc_summary.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "round3_pmc_summary.json")) as fh:
             d = json.load(fh)
         if n == N_SEQ and world == 1:
             return d["hbm_traffic_bytes_per_launch"]
@@ -118,6 +118,89 @@ def cpu_baseline(M, res, off, n_sample, threads):
             "pair_space_fraction": calls / (n_sample * (n_sample - 1) / 2)}
 
 
+def cells_per_pair(la, lb, X):
+    """Cells ShiftedScorer.java:67-77 adds for one pair of lengths la >= lb: m (d + 1) + 2 X m - X (X + 1)."""
+    return lb * (2 * X + (la - lb) + 1) - X * (X + 1)
+
+
+def lds_ideal_ms(lengths, X):
+    """Time the LDS byte rate alone allows for one all-vs-all pass over sequences of these lengths: one byte per cell."""
+    cnt = np.bincount(lengths)
+    total = 0.0
+    for la in range(1, len(cnt)):
+        for lb in range(1, la + 1):
+            pairs = cnt[la] * cnt[lb] if la != lb else cnt[la] * (cnt[la] - 1) // 2
+            total += float(pairs) * cells_per_pair(la, lb, X)
+    return total / (LDS_PEAK_GBS * 1e9) * 1e3
+
+
+def other_configs(M, dev, stream):
+    """The other BASELINE configs that fit one GPU, run AFTER the timed region (never inside it): config 2 (1e4 12-mers),
+    4a (1e5 peptides of length 7..20, ShiftedScorer p = -1, thr 23), 4b (the same set, LocalAlignmentScorer -5 / -1, all
+    ordered pairs, thr 28) and one of the 8 shards of config 5 (1e6 12-mers).  Kernel time by HIP events on the launch
+    stream, median of a few passes after a warm-up; each with its own roofline fraction."""
+    import torch
+    import hammock_amd
+    from hammock_amd import _native
+    from hammock_amd.synth import synth_peptides
+    out = []
+    cap = 1 << 25
+    d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
+    d_counts = torch.zeros(_native.HMK_EDGE_SHARDS, dtype=torch.int64, device=dev)
+
+    def shifted(name, n, lo, hi, X, p, thr, part, n_parts, reps, warm):
+        res, off = synth_peptides(1, n, lo, hi)
+        ctx = hammock_amd.Context(M, device=dev.index)
+        ctx.set_sequences(residues=res, offsets=off)
+        ms = []
+        for k in range(warm + reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            ctx.neighbors_shifted_dev(X, p, thr, part, n_parts, d_edges.data_ptr(), cap, d_counts.data_ptr(), stream.cuda_stream)
+            b.record(stream)
+            torch.cuda.synchronize(dev)
+            if k >= warm:
+                ms.append(a.elapsed_time(b))
+        plan = ctx.last_plan()
+        med = float(np.median(ms))
+        ideal = lds_ideal_ms(np.diff(off.astype(np.int64)), X) * (int(plan.pairs_scored) / (n * (n - 1) / 2))
+        out.append({"config": name, "kernel_ms": med, "pairs": int(plan.pairs_scored), "pairs_per_s": int(plan.pairs_scored) / (med * 1e-3),
+                    "edges": int(d_counts.sum().item()), "row_packed_classes": int(plan.classes_rows),
+                    "classes": int(plan.classes_u8 + plan.classes_u16 + plan.classes_direct),
+                    "roofline": {"bound": "lds", "ideal_ms": ideal, "frac": ideal / med,
+                                 "definition": "one LDS byte per cell the reference adds (ShiftedScorer.java:67-77) at 256 B/clk/CU x 256 CU "
+                                               "x 2.4 GHz, over the measured kernel time"}})
+        ctx.close()
+
+    shifted("2: 1e4 x 12, BLOSUM62, X 3, p 0, thr 20", 10000, 12, 12, 3, 0, 20, 0, 1, 10, 5)
+    shifted("4a: 1e5 x 7..20, ShiftedScorer X 3, p -1, thr 23", 100000, 7, 20, 3, -1, 23, 0, 1, 8, 6)
+    shifted("5, one of 8 shards: 1e6 x 12, BLOSUM62, X 3, p 0, thr 20", 1000000, 12, 12, 3, 0, 20, 0, 8, 3, 2)
+    # 4b: LocalAlignmentScorer, all ordered pairs of the 4a set.  The packed tagged-max kernel issues ~7.5 VALU instructions per
+    # DP cell and lane pair (two column sequences per lane; PMC: profiles/round3_neighbors_local_pmc.json), and a wave64
+    # integer VALU instruction holds its SIMD for 4 cycles: peak = 256 CU x 4 SIMD x 2.4 GHz / 4 x 64 lanes.
+    res, off = synth_peptides(1, 100000, 7, 20)
+    ctx = hammock_amd.Context(M, device=dev.index)
+    ctx.set_sequences(residues=res, offsets=off)
+    ms = []
+    for _ in range(3):
+        edges, st = ctx.neighbors_local(-5, -1, 28, capacity=1 << 26)
+        ms.append(float(st.kernel_ms))
+    lens = np.diff(off.astype(np.int64)).astype(np.float64)
+    cells = float(lens.sum()) ** 2 - float((lens * lens).sum())      # sum over ordered pairs i != j of len_i * len_j
+    valu_per_cell = 7.5 / 2          # per sequence pair: the instruction serves two column sequences
+    peak_lane_ops = 256 * 4 * 2.4e9 / 4 * 64
+    med = float(np.median(ms[1:]))
+    out.append({"config": "4b: 1e5 x 7..20, LocalAlignmentScorer open -5, extend -1, all ordered pairs, thr 28", "kernel_ms": med,
+                "pairs": int(st.pairs_scored), "pairs_per_s": int(st.pairs_scored) / (med * 1e-3), "edges": int(len(edges)),
+                "dp_cells_per_s": cells / (med * 1e-3),
+                "roofline": {"bound": "valu-issue", "frac": cells * valu_per_cell / (med * 1e-3) / peak_lane_ops,
+                             "valu_instructions_per_cell_and_pair": valu_per_cell,
+                             "definition": "DP cells x 3.75 VALU lane-instructions per cell (7.5 per cell of a lane that carries two column "
+                                           "sequences) over the kernel time, against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz of integer VALU issue"}})
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +212,7 @@ def main():
                          "bounded: the default run stays within a few minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-greedy", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the block with the other BASELINE configs (2, 4a, 4b, a shard of 5)")
     args = ap.parse_args()
 
     import torch
@@ -282,7 +366,7 @@ def main():
                                         f"{lds_per_pair} LDS bytes per pair ({SEQ_LEN} ds_read_b64 table lookups) ") +
                                        "x pairs per launch / kernel time, against 256 B/clk/CU x 256 CU x 2.4 GHz "
                                        "(MI355X_MICROARCH.md, LDS table)",
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/round2_pmc_summary.json); "
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/round3_pmc_summary.json); "
                                          "null when the workload differs from the one the counters were collected on",
                          "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
@@ -316,6 +400,13 @@ def main():
                             "(-R size; host_sort_s = numpy's sort, the span of :407): scoring, CSR, phase 1 on the host over the "
                             "band rows while the rest is scored, second loop on the device; phases overlap (see "
                             "include/hammock_hip.h hmk_greedy_phases)"}
+            if not args.no_configs and n == N_SEQ:
+                t = time.perf_counter()
+                try:
+                    line["configs"] = other_configs(M, dev, stream)
+                except Exception as exc:   # reported in the line, never instead of it
+                    line["configs"] = {"error": f"{type(exc).__name__}: {exc}"}
+                line["configs_wall_s"] = time.perf_counter() - t
             if not args.no_cpu_baseline:
                 cores, why = usable_cores()
                 cores = min(cores, int(os.environ.get("HMK_BENCH_CPU_THREADS", "64")))   # the oracle's teams stop scaling well before that
@@ -328,12 +419,24 @@ def main():
         # from the gathered graph (hmk_greedy_from_edges_dev) and the broadcast of the cluster ids.  The throughput line must
         # not depend on this extra: a watchdog prints it without the end-to-end figures if the section does not finish.
         import threading
+        emit_lock = threading.Lock()
+        emitted = [False]
+
+        def emit(extra):
+            """Exactly one JSON line per run, whoever gets here first (the main thread or the watchdog)."""
+            with emit_lock:
+                if emitted[0]:
+                    return False
+                emitted[0] = True
+                if rank == 0:
+                    out = dict(line)
+                    out["greedy_end_to_end"] = extra
+                    print(json.dumps(out), flush=True)
+                return True
 
         def give_up():
-            if rank == 0:
-                line["greedy_end_to_end"] = {"error": f"not finished within {E2E_DEADLINE_S} s; the timed steps above are complete"}
-                print(json.dumps(line), flush=True)
-            os._exit(0)
+            emit({"error": f"not finished within {E2E_DEADLINE_S} s; the timed steps above are complete"})
+            os._exit(1)   # the line is out; a hung collective must not read as success
 
         watchdog = threading.Timer(E2E_DEADLINE_S, give_up)
         watchdog.daemon = True
@@ -352,13 +455,14 @@ def main():
         except Exception as exc:   # reported in the line, never instead of it
             e2e = {"error": f"{type(exc).__name__}: {exc}"}
         watchdog.cancel()
-        if rank == 0:
-            line["greedy_end_to_end"] = e2e
+        emit(e2e)
+        if e2e is not None and "error" in e2e:
+            os._exit(1)   # a rank that failed may have left the others inside a collective: do not wait for them, and say so
+        dist.destroy_process_group()
+        return
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
-        if e2e is not None and "error" in e2e:
-            os._exit(0)   # a rank that failed may have left the others inside a collective: do not wait for them
         dist.destroy_process_group()
 
 

@@ -74,7 +74,7 @@ constexpr int rows_tab_bytes(int x, int d, int cap, bool exact, int g) {
     return HMK_ROWS_COMPACT ? g * (cap + d + (exact ? 0 : nd - 1)) * 192 : nd * rows_slot_bytes();
 }
 constexpr int rows_lds_bytes(int x, int d, int cap, bool exact, int g) {   // must match the kernel's LDS map
-    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * HMK_ROWS_STAGE * 4;
+    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * HMK_ROWS_STAGE * 4 + 160;
 }
 
 // Everything that depends on the shape only: X max shift, D = row length - column length (>= 0), CAP column-length capacity
@@ -229,8 +229,10 @@ struct RowsShape {
     }
 };
 
-// What a flush needs, passed BY VALUE to a function that is NOT inlined: inlined, the flush (which scores whole columns again
-// and wants most of the register file) made the compiler keep the append loop's state in scratch memory on every pass.
+// What a flush needs.  The flush is a function that is NOT inlined: inlined, it (it scores whole columns again and wants most
+// of the register file) made the compiler keep the append loop's state in scratch memory on every pass.  Its arguments are
+// written to LDS once per tile and the call passes their address: passed by value they travelled through the stack, 120 bytes
+// per LANE and call -- 1.2 GB of scratch writes per pass of the BASELINE workload (rocprofv3 WRITE_SIZE), 12 x its edge list.
 struct RowsFlushArgs {
     const uint8_t *res_sorted;
     const uint32_t *perm;
@@ -241,7 +243,9 @@ struct RowsFlushArgs {
     uint32_t *deg, *deg_up, *deg_lo, *rank;
     uint32_t lpad, symmetric, perm_identity, row0, col0, shard, tab_addr;
     int lbs, threshold;
+    uint32_t cinit[8];   // TileClass::cinit: one byte per shift, the lanes' initial value
 };
+static_assert(sizeof(RowsFlushArgs) % 8 == 0, "LDS map");
 
 // Drains one wave's staged records ((column - tile's first column) | row within the tile << 16).  A record says WHICH pair
 // reached the threshold; its score is worked out here, where every lane has a record of its own: the pair's column is
@@ -249,10 +253,19 @@ struct RowsFlushArgs {
 // plane's sums.  In the main loop the same extraction ran for one or two live lanes per wave-instruction and was a fifth of
 // the kernel's VALU work (VALU 99 % busy beside LDS 88 %).
 template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
-__device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_t *stage, uint32_t cnt, const RowsFlushArgs A) {
+__device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_t *stage, uint32_t cnt, uint32_t args_addr) {
     using S = RowsShape<X, D, CAP, EXACT_LB, G>;
     if (cnt == 0) return;
-    const int lbs = __builtin_amdgcn_readfirstlane(A.lbs);   // arguments arrive in vector registers: the uniform ones the scalar tests need
+    // (arguments arrive in vector registers: the scalar tests below need the uniform ones as scalars)
+    RowsFlushArgs A;
+    {
+        const uint32_t a0 = __builtin_amdgcn_readfirstlane(args_addr);
+        uint32_t raw[sizeof(RowsFlushArgs) / 4];
+#pragma unroll
+        for (uint32_t q = 0; q < sizeof(RowsFlushArgs) / 4; q++) raw[q] = lds_read<uint32_t>(a0 + 4 * q);
+        __builtin_memcpy(&A, raw, sizeof(RowsFlushArgs));
+    }
+    const int lbs = __builtin_amdgcn_readfirstlane(A.lbs);
     drain_begin();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
     const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage, hmk_device.h)
@@ -263,7 +276,6 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
     base = ((unsigned long long)bhi << 32) | blo;
     const int la = lbs + D;
     const uint32_t tab = __builtin_amdgcn_readfirstlane(A.tab_addr);
-    const uint8_t *cinit = reinterpret_cast<const uint8_t *>(A.cls->cinit);   // one byte per shift: the lanes' initial value
     for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {   // wave-uniform trip count: the table reads below run for whole waves
         const uint32_t k = k0 + lane;
         const bool live = k < cnt;
@@ -272,23 +284,29 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         const uint32_t mcol = A.col0 + (rec & 0xFFFFu);
         uint32_t off[CAP], toff[S::NT];
         S::offsets(A.res_sorted + (size_t)mcol * A.lpad, live, lbs, tab + grp * (uint32_t)S::GROUP_STEP, 0u, off, toff);
-        // One plane at a time, in a loop that is NOT unrolled (this path is cold and must stay small in registers): the plane's
-        // cells straight from the position table, row position i = j + u - X wherever it lies inside the row -- the literal
-        // form of ShiftedScorer.java:67-77 on the packed cells, independent of the main loop's unrolled schedule.
         uint32_t mx = 0;   // best shift = largest lane of this record's row
         const uint32_t sh = (r & 3u) * 8u;
+        {
+            // One plane at a time, in a loop that is NOT unrolled (this path is cold and must stay small in registers; unrolled,
+            // with or without scheduling barriers, the compiler put a column's 72 reads in flight at once and spilled them): the
+            // plane's cells straight from the position table, row position i = j + u - X wherever it lies inside the row -- the
+            // literal form of ShiftedScorer.java:67-77 on the packed cells, independent of the main loop's unrolled schedule.
 #pragma unroll 1
-        for (int u = 0; u < S::ND; u++) {
-            uint32_t a0 = (uint32_t)cinit[u] * 0x01010101u, a1 = a0;
+            for (int u = 0; u < S::ND; u++) {
+                uint32_t cw = A.cinit[0];
 #pragma unroll
-            for (int j = 0; j < CAP; j++) {
-                const int i = j + u - X;
-                if (j < lbs && i >= 0 && i < la) {   // wave-uniform
-                    const u32x2 e = lds_read<u32x2>(off[j] + (uint32_t)S::pos_addr(0, i));
-                    a0 += e.x; a1 += e.y;
+                for (int q = 1; q < 8; q++) cw = (u >> 2) == q ? A.cinit[q] : cw;
+                uint32_t a0 = ((cw >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u, a1 = a0;
+#pragma unroll
+                for (int j = 0; j < CAP; j++) {
+                    const int i = j + u - X;
+                    if (j < lbs && i >= 0 && i < la) {   // wave-uniform
+                        const u32x2 e = lds_read<u32x2>(off[j] + (uint32_t)S::pos_addr(0, i));
+                        a0 += e.x; a1 += e.y;
+                    }
                 }
+                mx = max(mx, ((r < 4u ? a0 : a1) >> sh) & 0xFFu);
             }
-            mx = max(mx, ((r < 4u ? a0 : a1) >> sh) & 0xFFu);
         }
         const int score = (int)mx - 128 + A.threshold;   // lane = 128 - threshold + score
         uint32_t x = A.row0 + rt, m = mcol;
@@ -326,7 +344,8 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     constexpr int ND = S::ND, NI = S::NI, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
     constexpr int R = 8 * G;
     constexpr int STAGE_CAP = HMK_ROWS_STAGE;  // records per wave; flushed when fewer than 64 slots are free
-    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4;
+    static_assert(sizeof(RowsFlushArgs) <= 160, "LDS map");
+    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4 + 160;
     static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, EXACT_LB, G), "rows_lds_bytes must match the LDS map");
     // one STATIC LDS object: its base address is a compile-time constant, so table offsets fold into the ds_read immediate
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
@@ -334,6 +353,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     uint8_t *mb = smem + TAB_BYTES;
     uint8_t *rowres = mb + 576;
     uint32_t *stage_all = reinterpret_cast<uint32_t *>(rowres + R * 32);
+    RowsFlushArgs *fargs = reinterpret_cast<RowsFlushArgs *>(stage_all + 4 * STAGE_CAP);
 
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
@@ -347,6 +367,14 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_CAP;
 
     build_begin();
+    const uint32_t tab_addr = lds_addr(tab);
+    if (tid == 0) {
+        RowsFlushArgs a{P.res_sorted, P.perm, Cp, P.edges, P.counts, P.cap_per_shard, P.deg, P.deg_up, P.deg_lo, P.rank,
+                        P.lpad, P.symmetric, P.perm_identity, T.row0, T.col0, shard, tab_addr, lbs, threshold, {0}};
+#pragma unroll
+        for (int q = 0; q < 8; q++) a.cinit[q] = Cp->cinit[q];
+        *fargs = a;
+    }
     for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
     for (int e = tid; e < R * 32; e += 256) {
         const int r = e >> 5, k = e & 31;
@@ -385,16 +413,12 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     for (int u = 0; u < ND; u++) ci[u] = ((Cp->cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
 
     uint32_t cnt = 0;  // staged records of this wave (wave-uniform)
-    const uint32_t tab_addr = lds_addr(tab);
     const uint32_t col_end = T.col0 + T.ncols;
     const uint32_t n_batches = (T.ncols + 255) / 256;
     const bool interior = T.diag == 0 && T.ncols % 256 == 0;  // every lane's column is a real pair
     const bool prio = MODE != EDGES_PLACE || HMK_SETPRIO_PLACE;
 
-    auto flush_args = [&]() {
-        return RowsFlushArgs{P.res_sorted, P.perm, Cp, P.edges, P.counts, P.cap_per_shard, P.deg, P.deg_up, P.deg_lo, P.rank,
-                             P.lpad, P.symmetric, P.perm_identity, T.row0, T.col0, shard, tab_addr, lbs, threshold};
-    };
+    const uint32_t fargs_addr = lds_addr(fargs);
 
     for (uint32_t bt = 0; bt < n_batches; bt++) {
         const uint32_t colrel = bt * 256 + tid;
@@ -416,52 +440,52 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
             for (int u = 1; u < ND; u++) { o0 |= W0[u]; o1 |= W1[u]; }
             if (__ballot(((o0 | o1) & 0x80808080u) != 0) == 0) return;
             // ---- rare path (a hit somewhere in the wave): every lane appends ITS hits, one per turn ----
-            // h0 / h1: bit 8r + 7 set <=> row r / 4 + r of the group reached the threshold for this lane's column
-            uint32_t h0 = o0 & 0x80808080u, h1 = o1 & 0x80808080u;
-            const uint32_t rows_here = T.nrows - 8 * g;   // rows of this group that exist (wave-uniform)
-            if (rows_here < 8) {   // the rows beyond start at the initial lane value, which may itself have the top bit set
-                h0 &= rows_here >= 4 ? 0xFFFFFFFFu : (1u << (8 * rows_here)) - 1u;
-                h1 &= rows_here <= 4 ? 0u : (1u << (8 * (rows_here - 4))) - 1u;
-            }
+            // hm: bit 8r + 7 set <=> row r of the group (r < 4) reached the threshold for this lane's column, bit 8r + 3 <=> row
+            // 4 + r.  The rows beyond the tile's last start at the initial lane value, which may itself have the top bit set:
+            // rm0 / rm1 (wave-uniform) leave them out.
+            const uint32_t rows_here = T.nrows - 8 * g;
+            const uint32_t rm0 = rows_here >= 4 ? 0x80808080u : 0x80808080u & ((1u << (8 * rows_here)) - 1u);
+            const uint32_t rm1 = rows_here >= 8 ? 0x80808080u : rows_here <= 4 ? 0u : 0x80808080u & ((1u << (8 * (rows_here - 4))) - 1u);
+            uint32_t hm = (o0 & rm0) | ((o1 & rm1) >> 4);
             if (!interior) {  // wave-uniform: only edge tiles filter
-                if (col >= col_end) { h0 = 0; h1 = 0; }
+                if (col >= col_end) hm = 0;
                 if (T.diag != 0) {
                     const int k = (int)col - (int)(T.row0 + 8 * g);   // the row this column IS, relative to the group
                     if (T.diag == 1) {   // triangle: keep rows r with column > row, i.e. r < k
                         const int k0 = k < 0 ? 0 : k > 4 ? 4 : k, k1 = k < 4 ? 0 : k > 8 ? 4 : k - 4;
-                        h0 &= k0 >= 4 ? 0xFFFFFFFFu : (1u << (8 * k0)) - 1u;
-                        h1 &= k1 >= 4 ? 0xFFFFFFFFu : (1u << (8 * k1)) - 1u;
+                        hm &= (k0 >= 4 ? 0x80808080u : 0x80808080u & ((1u << (8 * k0)) - 1u)) |
+                              (k1 >= 4 ? 0x08080808u : 0x08080808u & ((1u << (8 * k1)) - 1u));
                     } else if (k >= 0 && k < 8) {   // full square minus the diagonal
-                        if (k < 4) h0 &= ~(0x80u << (8 * k)); else h1 &= ~(0x80u << (8 * (k - 4)));
+                        hm &= ~(k < 4 ? 0x80u << (8 * k) : 0x08u << (8 * (k - 4)));
                     }
                 }
             }
             // (the flush sits OUTSIDE the append loop: it scores whole columns again and needs most of the register file; inside the
-            // loop the compiler kept h0 / h1 in scratch memory for every turn of it)
+            // loop the compiler kept the loop's state in scratch memory for every turn of it)
             for (;;) {
                 bool full = false;
                 for (;;) {
-                    const bool any = (h0 | h1) != 0;
+                    const bool any = hm != 0;
                     const uint64_t mask = __ballot(any);
                     if (mask == 0) break;
                     if (cnt > (uint32_t)(STAGE_CAP - 64)) { full = true; break; }   // keep room for one wave of hits
                     if (any) {
-                        const bool lo = h0 != 0;
-                        const uint32_t h = lo ? h0 : h1;
-                        const uint32_t row = ((uint32_t)__builtin_ctz(h) >> 3) + (lo ? 0u : 4u);
-                        stage[cnt + mbcnt64(mask)] = (bt * 256 + threadIdx.x) | ((uint32_t)(8 * g) + row) << 16;   // (recomputed: cheaper than keeping it across the flush call)
-                        if (lo) h0 &= h0 - 1u; else h1 &= h1 - 1u;   // clear the lowest set bit
+                        const uint32_t b = (uint32_t)__builtin_ctz(hm);
+                        const uint32_t row = (b >> 3) + 4u - (b & 4u);   // bit 8r + 7: row r; bit 8r + 3: row 4 + r
+                        // (the column is recomputed: cheaper than keeping it across the flush call)
+                        stage[cnt + mbcnt64(mask)] = (bt * 256 + threadIdx.x) | ((uint32_t)(8 * g) + row) << 16;
+                        hm &= hm - 1u;   // clear the lowest set bit
                     }
                     cnt += (uint32_t)__popcll(mask);
                 }
                 if (!full) break;
-                flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, flush_args());
+                flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, fargs_addr);
                 cnt = 0;
             }
         };
         rows_for_each_group(std::make_integer_sequence<int, G>{}, one_group);
     }
-    flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, flush_args());
+    flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, fargs_addr);
 }
 
 // -----------------------------------------------------------------------------

@@ -5,7 +5,7 @@
 #   gpurun -- 'VARIANTS=";-DHMK_ROW_AHEAD=2" bash tools/ab_flags.sh'
 F="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p gpurun_out/ab
-B="python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-greedy"
+B="python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-greedy --no-configs"
 IFS=";" read -ra VARS <<< "${VARIANTS:-;-DHMK_SETPRIO=0;-DHMK_SETPRIO_DRAIN=0;-DHMK_SETPRIO=1;-DHMK_SETPRIO=3;;-DHMK_SETPRIO=0}"
 for v in "${VARS[@]}"; do
   touch hammock_amd/csrc/k_neighbors.hip hammock_amd/csrc/k_neighbors_rows.hip

@@ -5,7 +5,7 @@
 #   gpurun -- 'VARIANTS=";-DHMK_ROWS_G=1;-DHMK_ROWS_G=3" NO4A=1 bash tools/ab_rows.sh'
 F="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p gpurun_out/ab
-B="python bench.py --steps ${STEPS:-40} --warmup 8 --no-cpu-baseline --no-greedy"
+B="python bench.py --steps ${STEPS:-40} --warmup 8 --no-cpu-baseline --no-greedy --no-configs"
 IFS=";" read -ra VARS <<< "${VARIANTS:-;}"
 for v in "${VARS[@]}"; do
   touch hammock_amd/csrc/k_neighbors_rows.hip

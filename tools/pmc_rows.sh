@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS"; do
     tag=$(echo "$c" | cut -d' ' -f1)
     timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$tag" -o pmc -- \
-        python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-greedy > /dev/null 2> "$O/pmc_$tag.log"
+        python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-greedy --no-configs > /dev/null 2> "$O/pmc_$tag.log"
 done
 cd "$R"
 python3 - <<'PY'

@@ -40,8 +40,35 @@ if trace:
                    "steady_state_avg_ns": sum(timed) / max(len(timed), 1), "min_ns": min(timed) if timed else None,
                    "max_ns": max(timed) if timed else None,
                    "all_dispatches_avg_ns": sum(d for _, d in durs) / max(len(durs), 1)}, fh, indent=1)
+# config 4b: k_neighbors_local_pk on this build (VALU instructions per DP cell, VALU busy fraction)
+local_csv = find("pmc_local/**/*counter_collection.csv")
+if local_csv:
+    acc = {}
+    with open(local_csv) as fh:
+        for row in csv.DictReader(fh):
+            if "k_neighbors_local" in row["Kernel_Name"]:
+                acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    loc = {k: sum(v) / len(v) for k, v in acc.items()}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import numpy as np
+    from hammock_amd.synth import synth_peptides
+    _, off = synth_peptides(1, 100000, 7, 20)
+    lens = np.diff(off.astype(np.int64)).astype(np.float64)
+    cells = float(lens.sum()) ** 2 - float((lens * lens).sum())   # ordered pairs i != j
+    if "SQ_INSTS_VALU" in loc:
+        loc["valu_wave_instructions_per_64_cells"] = loc["SQ_INSTS_VALU"] / (cells / 64)
+    if "GRBM_GUI_ACTIVE" in loc and "SQ_ACTIVE_INST_VALU" in loc:
+        loc["valu_busy_frac"] = loc["SQ_ACTIVE_INST_VALU"] / (loc["GRBM_GUI_ACTIVE"] / 8 * 256)
+    loc["dp_cells_per_launch"] = cells
+    loc["_note"] = ("rocprofv3 --pmc pass of tools/run_neighbors_local.py (1e5 peptides of length 7..20, open -5, extend -1, thr 28); per-launch "
+                    "means over the k_neighbors_local* dispatches; a lane carries two column sequences, so one wave instruction serves 128 cells")
+    with open(os.path.join(out, f"{rnd}_neighbors_local_pmc.json"), "w") as fh:
+        json.dump(loc, fh, indent=1)
+    st = find("trace_local/**/*kernel_stats.csv")
+    if st:
+        shutil.copyfile(st, os.path.join(out, f"{rnd}_neighbors_local_kernel_stats.csv"))
 summary = {}
-for path in sorted(glob.glob(os.path.join(out, "pmc_*/**/*counter_collection.csv"), recursive=True)):
+for path in sorted(glob.glob(os.path.join(out, "pmc_[FWS]*/**/*counter_collection.csv"), recursive=True)):
     acc = {}
     with open(path) as fh:
         for row in csv.DictReader(fh):
