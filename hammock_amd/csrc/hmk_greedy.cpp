@@ -24,6 +24,7 @@
 #include "hmk_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdio>
@@ -115,31 +116,31 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     std::vector<uint8_t> state(n, ST_FREE);
     std::vector<int32_t> cluster_of(n, -1);
     std::vector<ClusterRec> clusters;
-    std::vector<int32_t> cnt, mn;          // per-cluster scratch of the feasibility pass
-    std::vector<int32_t> touched;
     std::vector<uint32_t> orphans;
     auto seq_size = [&](uint32_t k) -> int64_t { return sizes ? sizes[k] : 1; };
 
-    // nearest(clusters, x): findNearestClusterParallel over actualClusters
+    // nearest(clusters, x): findNearestClusterParallel over actualClusters (the second loop's plain path, :59-66)
+    std::vector<int32_t> ncnt, nmn, ntouched;          // per-cluster scratch of the feasibility pass
     auto nearest_cluster = [&](uint32_t x) -> Found {
         if (clusters.empty()) return Found{NEAR_DUMMY, -1, INT_MIN};  // :138-140
-        touched.clear();
+        if (ncnt.size() < clusters.size()) { ncnt.resize(clusters.size(), 0); nmn.resize(clusters.size(), 0); }
+        ntouched.clear();
         for (uint64_t q = start[x]; q < start[x + 1]; q++) {
             int32_t c = cluster_of[adj[q].id()];
             if (c < 0) continue;
-            if (cnt[c] == 0) { touched.push_back(c); mn[c] = adj[q].score(); }
-            else if (adj[q].score() < mn[c]) mn[c] = adj[q].score();
-            cnt[c]++;
+            if (ncnt[c] == 0) { ntouched.push_back(c); nmn[c] = adj[q].score(); }
+            else if (adj[q].score() < nmn[c]) nmn[c] = adj[q].score();
+            ncnt[c]++;
         }
         Found best{NEAR_NULL, -1, 0};
-        for (int32_t c : touched) {
-            if (cnt[c] == clusters[c].usize) {  // complete linkage: all members >= threshold
+        for (int32_t c : ntouched) {
+            if (ncnt[c] == clusters[c].usize) {  // complete linkage: all members >= threshold
                 if (best.kind == NEAR_NULL ||
-                    better(mn[c], clusters[c].size, clusters[c].id, best.score,
+                    better(nmn[c], clusters[c].size, clusters[c].id, best.score,
                            clusters[best.slot].size, clusters[best.slot].id))
-                    best = Found{NEAR_REAL, c, mn[c]};
+                    best = Found{NEAR_REAL, c, nmn[c]};
             }
-            cnt[c] = 0;
+            ncnt[c] = 0;
         }
         return best;
     };
@@ -155,65 +156,190 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     };
 
     // ---- firstPhase, LimitedGreedySequenceClusterer.java:77-120 ------------
+    // One pass over the row of x answers both searches of a step: nearest(clusters, x) (:92, findNearestClusterParallel over
+    // actualClusters: per-cluster counters over the neighbours that are members) and nearest(initial[idx+1:], x) (:93: the best
+    // neighbour that is still an untouched singleton; every earlier position has been clustered, orphaned or absorbed).
+    //
+    // The steps are sequential in the reference, but a step reads little: the states of x's neighbours and the clusters they
+    // are in.  So the rows of a WINDOW of upcoming positions are scanned by several threads against the state at the window's
+    // start, and the steps are then committed in order; a commit invalidates exactly the scans it can have changed:
+    //   * k itself changes state (member, seed or orphan): every later row of the window that has k as a neighbour -- known
+    //     from k's own row (symmetric scores) -- is scanned again at its turn;
+    //   * k absorbs B (:99-101, :108-110): B stops being a candidate -- rows whose best candidate was B are scanned again; the
+    //     new cluster {k, B} can only be feasible for rows that have k as a neighbour (above);
+    //   * k joins cluster c (:97, :104): for rows that do not have k as a neighbour c stops being feasible (complete linkage:
+    //     every member must be a neighbour) -- c is struck from their feasible lists.
+    // A row's scan leaves out the window's earlier positions as candidates (they are decided before its turn).  Results are
+    // those of the sequential loop, step by step; with one thread the window is one row.
+    struct RowScan {
+        std::vector<std::pair<int32_t, int32_t>> feas;   // (cluster slot, min score) of the clusters feasible at the scan
+        std::vector<uint32_t> ahead;                     // neighbours at later positions of the window
+        Found B{NEAR_NULL, -1, 0};
+        bool no_clusters = false;                        // the scan saw an empty cluster list (:138-140: the dummy)
+        bool dirty = false;
+    };
+    struct ScanScratch { std::vector<int32_t> cnt, mn, touched; };
+    const size_t slots_max = std::min<size_t>((size_t)std::max(max_clusters, 0), (size_t)n) + 2;   // cluster slots a scan can meet
+    auto scan_row = [&](uint32_t x, uint32_t win_lo, uint32_t win_hi, ScanScratch &sc, RowScan &out) {
+        out.feas.clear();
+        out.ahead.clear();
+        out.dirty = false;
+        out.no_clusters = clusters.empty();
+        Found B{NEAR_NULL, -1, 0};
+        sc.touched.clear();
+        for (uint64_t q = start[x]; q < start[x + 1]; q++) {
+            const uint32_t m = adj[q].id();
+            const int32_t s = adj[q].score();
+            const uint8_t stt = state[m];
+            if (stt == ST_FREE) {                           // only untouched singletons follow x
+                if (m < x) { if (m >= win_lo) continue; }    // an earlier position of this window: decided before x's turn
+                else if (m < win_hi) out.ahead.push_back(m);
+                if (B.kind == NEAR_NULL || s > B.score ||
+                    (s == B.score && better(s, seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot)))
+                    B = Found{NEAR_REAL, (int32_t)m, s};
+            } else if (stt == ST_IN_CLUSTER) {
+                const int32_t c = cluster_of[m];
+                if (sc.cnt[c] == 0) { sc.touched.push_back(c); sc.mn[c] = s; }
+                else if (s < sc.mn[c]) sc.mn[c] = s;
+                sc.cnt[c]++;
+            }
+        }
+        for (int32_t c : sc.touched) {
+            if (sc.cnt[c] == clusters[c].usize) out.feas.emplace_back(c, sc.mn[c]);   // complete linkage: all members >= threshold
+            sc.cnt[c] = 0;
+        }
+        out.B = B;
+    };
+
+    unsigned T = 1;
+    if (symmetric_scores && n >= 65536 && max_clusters >= 256) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        T = std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
+    }
+    if (const char *v = getenv("HMK_PHASE1_THREADS"))   // tests: any input, any thread count
+        if (symmetric_scores) T = (unsigned)std::max(1, std::min(32, atoi(v)));
+    const uint32_t W = T > 1 ? 16 * T : 1;            // positions per window
+    std::vector<RowScan> res(W);
+    std::vector<ScanScratch> scratch(T);
+    for (ScanScratch &sc : scratch) { sc.cnt.assign(slots_max, 0); sc.mn.assign(slots_max, 0); }
+    // a small pool for the window scans: generation counter + work cursor, spinning workers (a window is tens of microseconds)
+    std::vector<uint32_t> win_rows;                    // the window's FREE positions
+    uint32_t win_lo = 0, win_hi = 0;
+    std::atomic<uint32_t> gen{0}, cursor{0}, finished{0};
+    std::atomic<bool> quit{false};
+    auto run_window = [&](unsigned t) {
+        for (;;) {
+            const uint32_t i = cursor.fetch_add(1, std::memory_order_relaxed);
+            if (i >= win_rows.size()) break;
+            const uint32_t x = win_rows[i];
+            scan_row(x, win_lo, win_hi, scratch[t], res[x - win_lo]);
+            finished.fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < T; t++)
+        pool.emplace_back([&, t]() {
+            uint32_t seen = 0;
+            for (;;) {
+                uint32_t g;
+                unsigned spins = 0;
+                while ((g = gen.load(std::memory_order_acquire)) == seen) {
+                    if (quit.load(std::memory_order_acquire)) return;
+                    if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
+                }
+                seen = g;
+                run_window(t);
+            }
+        });
+    struct PoolGuard {   // joins on every way out of the function (crash parity returns early)
+        std::vector<std::thread> &pool; std::atomic<bool> &quit;
+        ~PoolGuard() { quit.store(true, std::memory_order_release); for (std::thread &th : pool) th.join(); }
+    } pool_guard{pool, quit};
+
     int64_t remaining = n;  // elements of initialList at positions >= index
     int64_t index = 0;
     uint32_t k = 0;         // sequence behind initialList.get(index)
     uint32_t rows_here = partial ? 0 : n;   // rows [0, rows_here) of the adjacency are on the host
-    for (; k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters; k++) {
-        if (state[k] != ST_FREE) continue;  // removed from initialList (:101, :110)
+    while (k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters) {
+        if (state[k] != ST_FREE) { k++; continue; }  // removed from initialList (:101, :110)
         if (k >= rows_here) {                                   // row k must have landed
             rows_here = hooks->need_rows(k);
             if (rows_here <= k) return HMK_INTERNAL_ROWS_FAILED;
             if (hooks->adj_base) adj = (const NbrT *)hooks->adj_base();
         }
-        Found A = nearest_cluster(k);                       // :92
-        Found B;                                            // :93
-        if (remaining - 1 == 0) {
-            B = Found{NEAR_DUMMY, -1, INT_MIN};
-        } else {
-            B = Found{NEAR_NULL, -1, 0};
-            for (uint64_t q = start[k]; q < start[k + 1]; q++) {
-                uint32_t m = adj[q].id();
-                if (state[m] != ST_FREE) continue;  // only untouched singletons follow x
-                if (B.kind == NEAR_NULL ||
-                    better(adj[q].score(), seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot))
-                    B = Found{NEAR_REAL, (int32_t)m, adj[q].score()};
-            }
-        }
-        bool absorb = false;
-        if (A.kind != NEAR_NULL) {                          // :94
-            if (B.kind != NEAR_NULL) {                      // :95
-                if (A.score >= B.score) {                   // :96
-                    if (A.kind == NEAR_DUMMY) { st->crash_case = 2; st->crash_index = (int32_t)index; goto crash; }
-                    insert_into(A.slot, k);                 // :97
+        // ---- scan a window of positions against the current state ----
+        win_lo = k;
+        win_hi = (uint32_t)std::min<uint64_t>({(uint64_t)k + W, (uint64_t)rows_here, (uint64_t)n});
+        win_rows.clear();
+        for (uint32_t x = win_lo; x < win_hi; x++)
+            if (state[x] == ST_FREE) win_rows.push_back(x);
+        cursor.store(0, std::memory_order_relaxed);
+        finished.store(0, std::memory_order_relaxed);
+        if (T > 1 && win_rows.size() > 1) gen.fetch_add(1, std::memory_order_release);
+        run_window(0);
+        while (finished.load(std::memory_order_acquire) < win_rows.size()) { }
+        // ---- commit the window's steps in order ----
+        for (; k < win_hi && remaining > 0 && (int64_t)clusters.size() < max_clusters; k++) {
+            if (state[k] != ST_FREE) continue;
+            RowScan &R = res[k - win_lo];
+            if (R.dirty || R.no_clusters != clusters.empty()) scan_row(k, k, win_hi, scratch[0], R);   // as the sequential loop sees it now (its later neighbours inside the window stay listed)
+            Found A{NEAR_NULL, -1, 0};                      // :92
+            if (clusters.empty()) A = Found{NEAR_DUMMY, -1, INT_MIN};  // :138-140
+            else
+                for (const std::pair<int32_t, int32_t> &f : R.feas)
+                    if (A.kind == NEAR_NULL || better(f.second, clusters[f.first].size, clusters[f.first].id, A.score,
+                                                      clusters[A.slot].size, clusters[A.slot].id))
+                        A = Found{NEAR_REAL, f.first, f.second};
+            Found B = remaining - 1 == 0 ? Found{NEAR_DUMMY, -1, INT_MIN} : R.B;   // :93
+            bool absorb = false;
+            int32_t joined = -1;
+            if (A.kind != NEAR_NULL) {                          // :94
+                if (B.kind != NEAR_NULL) {                      // :95
+                    if (A.score >= B.score) {                   // :96
+                        if (A.kind == NEAR_DUMMY) { st->crash_case = 2; st->crash_index = (int32_t)index; goto crash; }
+                        insert_into(A.slot, k);                 // :97
+                        joined = A.slot;
+                    } else {
+                        absorb = true;                          // :99-101
+                    }
                 } else {
-                    absorb = true;                          // :99-101
+                    if (A.kind == NEAR_DUMMY) { st->crash_case = 1; st->crash_index = (int32_t)index; goto crash; }
+                    insert_into(A.slot, k);                     // :104
+                    joined = A.slot;
                 }
             } else {
-                if (A.kind == NEAR_DUMMY) { st->crash_case = 1; st->crash_index = (int32_t)index; goto crash; }
-                insert_into(A.slot, k);                     // :104
+                if (B.kind != NEAR_NULL) {                      // :107
+                    if (B.kind == NEAR_DUMMY) { st->crash_case = 3; st->crash_index = (int32_t)index; goto crash; }
+                    absorb = true;                              // :108-110
+                } else {
+                    state[k] = ST_ORPHAN;                       // :112
+                    orphans.push_back(k);
+                }
             }
-        } else {
-            if (B.kind != NEAR_NULL) {                      // :107
-                if (B.kind == NEAR_DUMMY) { st->crash_case = 3; st->crash_index = (int32_t)index; goto crash; }
-                absorb = true;                              // :108-110
-            } else {
-                state[k] = ST_ORPHAN;                       // :112
-                orphans.push_back(k);
+            if (absorb) {
+                int32_t c = (int32_t)clusters.size();
+                clusters.push_back(ClusterRec{(int32_t)k, 1, seq_size(k)});
+                cluster_of[k] = c;
+                state[k] = ST_IN_CLUSTER;
+                insert_into(c, (uint32_t)B.slot);
+                remaining--;  // initialList.remove(B)
             }
+            remaining--;
+            index++;          // :115
+            // ---- what this step can have changed for the window's later rows ----
+            for (uint32_t m : R.ahead) res[m - win_lo].dirty = true;
+            if (absorb || joined >= 0)
+                for (uint32_t x = k + 1; x < win_hi; x++) {
+                    RowScan &L = res[x - win_lo];
+                    if (L.dirty || state[x] != ST_FREE) continue;
+                    if (absorb) {
+                        if (L.B.kind == NEAR_REAL && L.B.slot == B.slot) L.dirty = true;
+                    } else {
+                        for (size_t f = 0; f < L.feas.size(); f++)
+                            if (L.feas[f].first == joined) { L.feas[f] = L.feas.back(); L.feas.pop_back(); break; }
+                    }
+                }
         }
-        if (absorb) {
-            int32_t c = (int32_t)clusters.size();
-            clusters.push_back(ClusterRec{(int32_t)k, 1, seq_size(k)});
-            cnt.push_back(0);
-            mn.push_back(0);
-            cluster_of[k] = c;
-            state[k] = ST_IN_CLUSTER;
-            insert_into(c, (uint32_t)B.slot);
-            remaining--;  // initialList.remove(B)
-        }
-        remaining--;
-        index++;          // :115
     }
     t_phase1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     st->phase1_stop_index = (int32_t)index;

@@ -32,7 +32,7 @@
 namespace hmk {
 
 #ifndef HMK_ROWS_STAGE
-#define HMK_ROWS_STAGE 192
+#define HMK_ROWS_STAGE 320
 #endif
 // HMK_ROWS_COMPACT=1 (default): the table reads are VOLATILE loads, which the compiler's load/store optimiser leaves alone, and
 // the tables are packed (192 bytes per row position); 0: plain loads and the spread-out placement described above.
@@ -64,7 +64,7 @@ constexpr int rows_waves(int nd, int cap, int lds_bytes) {
 #ifdef HMK_ROWS_WAVES
     return HMK_ROWS_WAVES;
 #endif
-    const int v = cap + 2 * nd + 40;
+    const int v = cap + 2 * nd + 36;
     const int by_regs = v <= 64 ? 8 : v <= 72 ? 7 : v <= 80 ? 6 : v <= 96 ? 5 : 4;
     const int by_lds = 163840 / ((lds_bytes + 511) / 512 * 512);
     return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;

@@ -147,6 +147,26 @@ def test_greedy_from_edges_large_uses_precheck_and_inbox(blosum62, coracle, asym
     assert cid is not None and int((np.bincount(cid) > 1).sum()) == 60
 
 
+@pytest.mark.parametrize("threads", [1, 2, 5, 8])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_greedy_phase1_window_scans_match_oracle(blosum62, coracle, monkeypatch, seed, threads):
+    """Phase 1 scans a window of upcoming positions on several threads and commits the steps in order, invalidating the
+    scans a commit can have changed (hmk_greedy.cpp, firstPhase).  Dense, low-complexity inputs make those conflicts the
+    rule -- most rows of a window are neighbours of each other, absorb each other's candidates and join the same clusters --
+    and the cluster limit is high enough that phase 1 runs over most of the list.  Ids, list order, member order and the
+    phase-1 counters must equal the oracle's literal sequential loop for every thread count."""
+    monkeypatch.setenv("HMK_PHASE1_THREADS", str(threads))
+    rng = np.random.default_rng(4000 + seed)
+    n = [900, 1500, 2500][seed]
+    peps = random_peptides(rng, n, 12, 12, alphabet=[3, 4, 5][seed])
+    sizes = rng.integers(1, 4, size=len(peps)).astype(np.int32) if seed != 1 else None
+    res, off = coracle.pack(peps)
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [peps[k] for k in perm]
+    cid = run_both(coracle, blosum62, peps, None if sizes is None else sizes[perm], 3, 0, [30, 26, 24][seed], [400, 500, 700][seed])
+    assert cid is not None
+
+
 # --------------------------------------------------------------------------------------
 # the product's nearest-neighbour chain (hmk_clinkage.cpp) on the CPU: edges from the oracle scorer
 # --------------------------------------------------------------------------------------
