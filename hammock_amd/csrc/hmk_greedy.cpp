@@ -218,7 +218,8 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     }
     if (const char *v = getenv("HMK_PHASE1_THREADS"))   // tests: any input, any thread count
         if (symmetric_scores) T = (unsigned)std::max(1, std::min(32, atoi(v)));
-    const uint32_t W = T > 1 ? 16 * T : 1;            // positions per window
+    uint32_t W = T > 1 ? 4 * T : 1;                   // positions per window (more positions: more scans a commit invalidates)
+    if (const char *v = getenv("HMK_PHASE1_WINDOW")) W = (uint32_t)std::max(1, std::min(4096, atoi(v)));
     std::vector<RowScan> res(W);
     std::vector<ScanScratch> scratch(T);
     for (ScanScratch &sc : scratch) { sc.cnt.assign(slots_max, 0); sc.mn.assign(slots_max, 0); }

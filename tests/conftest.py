@@ -47,6 +47,30 @@ def coracle():
     return c_oracle
 
 
+def gpu_count():
+    """GPUs visible to this process (counting devices does not initialise HIP)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def multi_device_lists(repeated=((0, 0), (0, 0, 0))):
+    """Device lists for the hmk_create_multi tests: the one GPU named several times (separate contexts, plans, buffers and
+    streams on one card; runs everywhere) AND, on a box with more GPUs, distinct ordinals -- [0, 1], [1, 0] and all of them --
+    which is what exercises hipDeviceEnablePeerAccess and real peer copies.  The distinct lists are always generated and are
+    skipped, visibly, where fewer than two GPUs exist: nobody has to edit a test the day a multi-GPU box runs them."""
+    n = gpu_count()
+    out = [pytest.param(list(d), id="dev" + "".join(map(str, d))) for d in repeated]
+    need2 = pytest.mark.skipif(n < 2, reason="needs two GPUs (distinct ordinals: peer access, peer copies over xGMI)")
+    out.append(pytest.param([0, 1], id="dev01_distinct", marks=need2))
+    out.append(pytest.param([1, 0], id="dev10_distinct", marks=need2))
+    out.append(pytest.param(list(range(max(n, 3))), id="dev_all_distinct",
+                            marks=pytest.mark.skipif(n < 3, reason="needs three or more GPUs")))
+    return out
+
+
 def random_peptides(rng, n, len_lo, len_hi, alphabet=20):
     """n DISTINCT random peptides as a list of uint8 arrays."""
     seen, out = set(), []

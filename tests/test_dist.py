@@ -325,6 +325,63 @@ def test_pipelined_exchange_over_rccl_single_rank():
     assert oks == [True, True, True, True], oks
 
 
+def _nccl_rank_per_gpu_worker(rank, world, port, q):
+    """One rank per GPU over RCCL (what `bench.py --gpus N` launches): the pipelined exchange in both block formats, then the
+    distributed clustering entry point; rank 0 reports against the single-GPU results it computes itself."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+    import json
+    import hammock_amd
+    from hammock_amd import dist as hd
+    from hammock_amd.synth import synth_peptides
+    with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
+        M = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
+    res, off = synth_peptides(6, 30000, 12)
+    ctx = hammock_amd.Context(M, device=rank)
+    ctx.set_sequences(residues=res, offsets=off)
+    want, _ = ctx.neighbors_shifted(3, 0, 20)          # the whole graph, on this rank's own GPU
+    oks = []
+    for fmt in ("rows", "edges"):
+        px = hd.PipelinedExchange(ctx, 3, 0, 20, rank, world, dev, fmt=fmt, use_collectives=True)
+        for _ in range(4):
+            px.step()
+        got = px.last_result().cpu().numpy().view(np.uint64)
+        oks.append(bool(np.array_equal(np.sort(got), np.sort(want))))
+    cid, order, info = hd.greedy_cluster_distributed(ctx, 3, 0, 20, 750, dev)
+    cid1, order1, _ = ctx.greedy_cluster(3, 0, 20, 750)
+    oks.append(bool(np.array_equal(cid, cid1) and np.array_equal(order, order1)))
+    q.put((rank, oks))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rank_per_gpu_over_rccl(world):
+    """The N > 1 path on REAL GPUs: one process per GPU, RCCL over xGMI (all_gather_into_tensor of the edge blocks on the
+    communication stream, broadcast of the ids).  Skipped where the box has fewer GPUs than ranks -- a one-GPU box runs the
+    same code on gloo / one-rank RCCL in the tests around this one; on a multi-GPU box this test needs no editing."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    if world > 6:
+        pytest.skip("more than 6 GPU processes at once are not allowed on the test boxes (process guard)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_rank_per_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, oks in out:
+        assert oks == [True, True, True], (rank, oks)
+
+
 @pytest.mark.gpu
 def test_distributed_entry_single_process_device_merge():
     """greedy_cluster_distributed without a process group (one rank): the gathered graph stays on the GPU and

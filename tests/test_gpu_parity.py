@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, random_peptides
+from conftest import GOLDEN, gpu_count, multi_device_lists, random_peptides
 from oracle import hammock_oracle as po
 
 import hammock_amd
@@ -389,12 +389,14 @@ def test_greedy_3e5_vs_oracle(gpu, blosum62, coracle):
     assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("devices", [pytest.param([0], id="dev0")] + multi_device_lists())
 def test_greedy_multi_device_context(gpu, blosum62, coracle, devices):
-    """hmk_create_multi: the multi-GPU form below the C ABI.  This box has one GPU, so the device list names it one,
-    two and three times -- every "device" has its own context, plan (shard d of n), edge buffer and stream, the
-    peers' segments reach the root through hipMemcpyPeerAsync, the root builds the CSR over root segments + gathered
-    blocks.  Must equal the single-device call and the oracle."""
+    """hmk_create_multi: the multi-GPU form below the C ABI.  On a one-GPU box the device list names it one, two and
+    three times -- every "device" has its own context, worker thread, plan (shard d of n, band tiles first), edge buffer and
+    streams; the peers' band blocks and edge blocks reach the root through hipMemcpyPeerAsync behind the peers' own events,
+    the root builds the band's adjacency and later the CSR over root segments + gathered blocks while phase 1 runs on the
+    host.  With two or more GPUs the same test runs on distinct ordinals (peer access, real xGMI copies).  Must equal the
+    single-device call and the oracle."""
     n = 40000
     res, off = synth_peptides(21, n, 12)
     rng = np.random.default_rng(21)
@@ -428,7 +430,10 @@ def test_greedy_edge_buffer_overflow_retry(gpu, blosum62, coracle, monkeypatch):
     st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 20, 1250, 8)
     assert st == 0
     monkeypatch.setenv("HMK_EDGE_GUESS", "1")
-    for devices, mode in ((0, None), (0, "host"), ([0, 0], None)):
+    cases = [(0, None), (0, "host"), ([0, 0], None)]
+    if gpu_count() >= 2:
+        cases.append(([0, 1], None))   # distinct GPUs when the box has them
+    for devices, mode in cases:
         if mode:
             monkeypatch.setenv("HMK_SECOND_LOOP", mode)
         else:
@@ -746,10 +751,11 @@ def test_clinkage_vs_oracle(gpu, blosum62, coracle, name):
         assert np.array_equal(ctx.member_rank[:len(cid)], orank)
         assert (stats.merges, stats.searches, stats.n_result_clusters) == (ostats.merges, ostats.searches, ostats.n_result_clusters)
     if name == "mixed_dense":   # the same through a two-"device" context (hmk_create_multi)
-        multi = hammock_amd.Context(blosum62, device=[0, 0])
-        multi.set_sequences(residues=res, offsets=off, sizes=sizes)
-        cid, order, _ = multi.clinkage_cluster(X, p, thr)
-        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(multi.member_rank[:len(cid)], orank)
+        for devs in [[0, 0]] + ([[0, 1]] if gpu_count() >= 2 else []):   # distinct GPUs when the box has them
+            multi = hammock_amd.Context(blosum62, device=devs)
+            multi.set_sequences(residues=res, offsets=off, sizes=sizes)
+            cid, order, _ = multi.clinkage_cluster(X, p, thr)
+            assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(multi.member_rank[:len(cid)], orank)
 
 
 def test_clinkage_edge_cases(gpu, blosum62, coracle):
@@ -851,12 +857,15 @@ def test_cli_clinkage_writes_reference_files(gpu, blosum62, coracle, tmp_path):
     assert f"Resulting clusers: {len(order)}" in log
 
 
-@pytest.mark.parametrize("dataset", ["musi", "manual_counts", "musi_two_devices"])
+@pytest.mark.parametrize("dataset", ["musi", "manual_counts", "musi_two_devices",
+                                     pytest.param("musi_two_distinct_devices",
+                                                  marks=pytest.mark.skipif(gpu_count() < 2, reason="needs two GPUs"))])
 def test_cli_greedy_writes_reference_files(gpu, blosum62, coracle, tmp_path, dataset):
     import subprocess
     from conftest import ROOT
     cli = os.path.join(ROOT, "hammock_amd", "bin", "hammock-hip")
-    devices = ["--devices", "0,0"] if dataset == "musi_two_devices" else []   # hmk_create_multi behind the CLI
+    # hmk_create_multi behind the CLI: the one GPU twice, or two GPUs where the box has them
+    devices = ["--devices", "0,0"] if dataset == "musi_two_devices" else ["--devices", "0,1"] if dataset == "musi_two_distinct_devices" else []
     if dataset.startswith("musi"):
         fa = os.path.join(GOLDEN, "musi.fa")
         extra = []

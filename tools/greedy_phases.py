@@ -24,6 +24,10 @@ with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
 # UniqueSequence.java:238-248 -- with all counts 1 that is reverse alphabetical, what `hammock-hip greedy` clusters by
 # default); without it the order in which the generator produced them (-R input)
 SORTED = "--sorted" in sys.argv
+DEVICES = 0          # --devices=0,0: a multi-device context (hmk_create_multi), e.g. the one GPU twice
+for a in sys.argv[1:]:
+    if a.startswith("--devices="):
+        DEVICES = [int(v) for v in a.split("=", 1)[1].split(",")]
 LETTERS = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", dtype=np.uint8)
 for n in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [100000]:
     lo, hi = (12, 12)
@@ -33,7 +37,7 @@ for n in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [100000]:
         order_idx = np.lexsort(rows.T[::-1])[::-1]     # descending by the sequence's letters
         res = np.ascontiguousarray(res.reshape(n, 12)[order_idx]).reshape(-1)
     maxc = int(np.floor(n * 0.025 + 0.5))
-    ctx = hammock_amd.Context(M, device=0)
+    ctx = hammock_amd.Context(M, device=DEVICES)
     ctx.set_sequences(residues=res, offsets=off)
     ref = None
     for call in range(3):
