@@ -43,7 +43,7 @@ enum {
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
     SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RANK, SB_RETRY, SB_PRECNT, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
-    SB_PEER, SB_PEERCNT, SB_PEERBAND,                                                     // edge blocks gathered from other devices (root) / compacted for the root (peers)
+    SB_PEER, SB_PEERCNT, SB_PEERBAND, SB_PEERDEG,                                                     // edge blocks gathered from other devices (root) / compacted for the root (peers)
     SB_N
 };
 
@@ -2120,6 +2120,9 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
     if (const char *v = getenv("HMK_EDGE_GUESS")) guess = std::strtoull(v, nullptr, 10);   // tests: force the overflow / retry path
     const long long top = (long long)ctx->max_len * std::max(0, ctx->max_m) +
                           (long long)std::max(0, shift_penalty) * ((ctx->max_len - ctx->min_len) + 2LL * max_shift);
+    // every device counts the row degrees of the edges it writes (the CSR's first pass, fused into the scoring as in the
+    // single-device call); the peers' counters travel with their blocks and are added to the root's
+    const bool fuse = ctx->symmetric && getenv("HMK_NO_FUSED_DEGREE") == nullptr;
     int st = HMK_OK;
     for (int attempt = 0; attempt < 4; attempt++) {
         // ---- edge buffers (grown to the counts of the last attempt if a segment overflowed) and the root-side regions -----
@@ -2149,6 +2152,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                 HIPCHK(ctx, ensure_buf(c, SB_PEER, c->d_edges_cap * sizeof(uint64_t)));
                 HIPCHK(ctx, ensure_buf(c, SB_PEERBAND, (c->d_edges_cap / 2 + 1) * sizeof(uint64_t)));
                 HIPCHK(ctx, ensure_buf(c, SB_PEERCNT, 64));
+                if (fuse) HIPCHK(ctx, ensure_buf(c, SB_DEG, (size_t)n * 4));
                 jobs.emplace_back(new PeerJob());
                 PeerJob &J = *jobs.back();
                 J.c = c;
@@ -2164,6 +2168,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
         HIPCHK(ctx, ensure_buf(ctx, SB_PEER, std::max<uint64_t>(off, 1) * sizeof(uint64_t)));
         HIPCHK(ctx, ensure_buf(ctx, SB_PEERBAND, std::max<uint64_t>(boff, 1) * sizeof(uint64_t)));
         HIPCHK(ctx, ensure_buf(ctx, SB_PEERCNT, 2 * HMK_MAX_SEGS * sizeof(unsigned long long)));   // [d]: a peer's total, [HMK_MAX_SEGS + d]: its band total
+        if (fuse) HIPCHK(ctx, ensure_buf(ctx, SB_PEERDEG, std::max<size_t>(jobs.size(), 1) * (size_t)n * 4));
         for (auto &jp : jobs) {   // root-side stream and events of the peer's transfers
             hmk_ctx *c = jp->c;
             if (!c->gather_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&c->gather_stream, hipStreamNonBlocking));
@@ -2213,8 +2218,10 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             r = build_plan(c, max_shift, shift_penalty, threshold, J.part, G, band_req);
             if (r) { set_full(-1, r, c->err); return; }
             const bool band = c->plan.band_rows > 0;
+            uint32_t *p_deg = fuse ? buf<uint32_t>(c, SB_DEG) : nullptr;
+            if (p_deg && (e = hipMemsetAsync(p_deg, 0, (size_t)n * 4, Q)) != hipSuccess) { hip_fail("degree counters", e); return; }
             if (band) {
-                r = neighbors_dev_locked(c, max_shift, shift_penalty, threshold, J.part, G, c->d_edges, c->d_edges_cap, c->d_counts, Q, LAUNCH_BAND, band_req);
+                r = neighbors_dev_locked(c, max_shift, shift_penalty, threshold, J.part, G, c->d_edges, c->d_edges_cap, c->d_counts, Q, LAUNCH_BAND, band_req, p_deg);
                 if (r) { set_full(-1, r, c->err); return; }
                 e = hipMemcpyAsync(buf<void>(c, SB_BCOUNTS), c->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, Q);
                 if (e == hipSuccess) e = launch_compact_edges(c->d_edges, seg, buf<unsigned long long>(c, SB_BCOUNTS), buf<uint64_t>(c, SB_PEERBAND), J.band_region, d_tot + 1, Q);
@@ -2223,7 +2230,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                 if (e != hipSuccess) { hip_fail("band launch", e); return; }
             }
             r = neighbors_dev_locked(c, max_shift, shift_penalty, threshold, J.part, G, c->d_edges, c->d_edges_cap, c->d_counts, Q,
-                                     band ? LAUNCH_REST : LAUNCH_ALL, band_req);
+                                     band ? LAUNCH_REST : LAUNCH_ALL, band_req, p_deg);
             if (r) { (void)hipStreamSynchronize(Q); set_full(-1, r, c->err); return; }
             e = hipMemcpyAsync(c->h_counts, c->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, Q);
             if (e == hipSuccess) e = launch_compact_edges(c->d_edges, seg, c->d_counts, buf<uint64_t>(c, SB_PEER), J.region, d_tot, Q);
@@ -2258,6 +2265,8 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             e = hipSetDevice(root_dev);
             if (e == hipSuccess && J.total)
                 e = hipMemcpyPeerAsync(root_peer + J.off, root_dev, buf<uint64_t>(c, SB_PEER), c->device, J.total * sizeof(uint64_t), c->gather_stream);
+            if (e == hipSuccess && p_deg)
+                e = hipMemcpyPeerAsync(buf<uint32_t>(ctx, SB_PEERDEG) + (size_t)(J.part - 1) * n, root_dev, p_deg, c->device, (size_t)n * 4, c->gather_stream);
             if (e == hipSuccess) e = hipMemcpyAsync(root_cnt + J.part, h_tot + 2, 8, hipMemcpyHostToDevice, c->gather_stream);
             if (e == hipSuccess) e = hipEventRecord(c->ev_gather, c->gather_stream);
             (void)hipSetDevice(c->device);
@@ -2276,19 +2285,22 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
         const int64_t band_rows = ctx->plan.band_rows;
         ctx->phases.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         const uint64_t seg0 = ctx->d_edges_cap / HMK_EDGE_SHARDS;
+        uint32_t *r_deg = fuse ? buf<uint32_t>(ctx, SB_DEG) : nullptr;
+        if (r_deg) HIPCHK(ctx, hipMemsetAsync(r_deg, 0, (size_t)n * 4, S));
         HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
         if (band_rows > 0) {
-            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, G, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S, LAUNCH_BAND, band_req);
+            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, G, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S, LAUNCH_BAND, band_req, r_deg);
             if (st) return st;
             HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToDevice, S));
             HIPCHK(ctx, hipEventRecord(ctx->ev_band, S));
         }
         st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, G, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req);
+                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, r_deg);
         if (st) { (void)hipStreamSynchronize(S); return st; }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S));
 
         EdgeSource src;
+        src.deg_fused = fuse;
         src.symmetric = ctx->symmetric;
         src.format_known = true;
         src.packed = packed;
@@ -2327,8 +2339,13 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             }
             if (bad) return bad;
             if (overflow) return ST_RETRY_OVERFLOW;
-            for (auto &jp : jobs)
+            for (auto &jp : jobs) {
                 if (hipStreamWaitEvent(S, jp->c->ev_gather, 0) != hipSuccess) { ctx->err = "hipStreamWaitEvent (peer gather)"; return HMK_ERR_DEVICE; }
+                if (fuse && launch_add_u32(buf<uint32_t>(ctx, SB_DEG), buf<uint32_t>(ctx, SB_PEERDEG) + (size_t)(jp->part - 1) * n, n, S) != hipSuccess) {
+                    ctx->err = "adding a peer's row degrees";
+                    return HMK_ERR_DEVICE;
+                }
+            }
             if (hipEventRecord(ctx->ev_edges, S) != hipSuccess) { ctx->err = "hipEventRecord"; return HMK_ERR_DEVICE; }
             return HMK_OK;
         };

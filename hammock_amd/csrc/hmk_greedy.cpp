@@ -187,7 +187,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         out.no_clusters = clusters.empty();
         Found B{NEAR_NULL, -1, 0};
         sc.touched.clear();
-        for (uint64_t q = start[x]; q < start[x + 1]; q++) {
+        const uint64_t q_end = start[x + 1];
+        for (uint64_t q = start[x]; q < q_end; q++) {
+            // the states are random reads from an n-byte array: ask for the one needed 32 entries from now
+            if (q + 32 < q_end) __builtin_prefetch(&state[adj[q + 32].id()], 0, 1);
             const uint32_t m = adj[q].id();
             const int32_t s = adj[q].score();
             const uint8_t stt = state[m];
@@ -261,13 +264,20 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     int64_t index = 0;
     uint32_t k = 0;         // sequence behind initialList.get(index)
     uint32_t rows_here = partial ? 0 : n;   // rows [0, rows_here) of the adjacency are on the host
+    const bool p1_timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+    double p1_scan = 0, p1_commit = 0, p1_rows = 0;
+    uint64_t p1_windows = 0, p1_scanned = 0, p1_rescans = 0;
+    auto p1_now = []() { return std::chrono::steady_clock::now(); };
     while (k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters) {
         if (state[k] != ST_FREE) { k++; continue; }  // removed from initialList (:101, :110)
         if (k >= rows_here) {                                   // row k must have landed
+            const auto tw = p1_now();
             rows_here = hooks->need_rows(k);
             if (rows_here <= k) return HMK_INTERNAL_ROWS_FAILED;
             if (hooks->adj_base) adj = (const NbrT *)hooks->adj_base();
+            p1_rows += std::chrono::duration<double, std::milli>(p1_now() - tw).count();
         }
+        const auto ts = p1_now();
         // ---- scan a window of positions against the current state ----
         win_lo = k;
         win_hi = (uint32_t)std::min<uint64_t>({(uint64_t)k + W, (uint64_t)rows_here, (uint64_t)n});
@@ -279,10 +289,15 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         if (T > 1 && win_rows.size() > 1) gen.fetch_add(1, std::memory_order_release);
         run_window(0);
         while (finished.load(std::memory_order_acquire) < win_rows.size()) { }
+        const auto tc = p1_now();
+        p1_scan += std::chrono::duration<double, std::milli>(tc - ts).count();
+        p1_windows++;
+        p1_scanned += win_rows.size();
         // ---- commit the window's steps in order ----
         for (; k < win_hi && remaining > 0 && (int64_t)clusters.size() < max_clusters; k++) {
             if (state[k] != ST_FREE) continue;
             RowScan &R = res[k - win_lo];
+            if (R.dirty || R.no_clusters != clusters.empty()) p1_rescans++;
             if (R.dirty || R.no_clusters != clusters.empty()) scan_row(k, k, win_hi, scratch[0], R);   // as the sequential loop sees it now (its later neighbours inside the window stay listed)
             Found A{NEAR_NULL, -1, 0};                      // :92
             if (clusters.empty()) A = Found{NEAR_DUMMY, -1, INT_MIN};  // :138-140
@@ -341,8 +356,13 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     }
                 }
         }
+        p1_commit += std::chrono::duration<double, std::milli>(p1_now() - tc).count();
     }
     t_phase1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (p1_timing)
+        fprintf(stderr, "[hmk greedy] phase 1: %.2f ms = rows %.2f + window scans %.2f + commits %.2f; %llu windows of %u, %llu rows scanned, %llu scanned again, %u threads\n",
+                t_phase1, p1_rows, p1_scan, p1_commit, (unsigned long long)p1_windows, W, (unsigned long long)p1_scanned,
+                (unsigned long long)p1_rescans, T);
     st->phase1_stop_index = (int32_t)index;
     st->phase1_clusters = (int32_t)clusters.size();
     st->phase1_orphans = (int32_t)orphans.size();

@@ -52,6 +52,7 @@ hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uin
                                 int *score_range, hipStream_t s);
 hipError_t launch_csr_scatter_ranked(const EdgeSegs &segs, const uint64_t *edges0, const uint32_t *rank, bool symmetric,
                                      const uint64_t *start, void *adj, bool packed, int base, hipStream_t s);   // deg[] already counted by the neighbour kernel (NeighborParams::deg)
+hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, uint32_t n, hipStream_t s);   // dst[k] += src[k]
 size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
 size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)

@@ -1391,6 +1391,16 @@ hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, con
     return hipGetLastError();
 }
 
+// dst[k] += src[k]: the row degrees the peers of a multi-device call counted while they wrote their edges, added to the root's
+__global__ void __launch_bounds__(256) k_add_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t n) {
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) dst[k] += src[k];
+}
+hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, uint32_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_add_u32, dim3(std::min<uint32_t>((n + 255) / 256, 2048)), dim3(256), 0, s, dst, src, n);
+    return hipGetLastError();
+}
+
 // loads this translation unit's code object (HIP defers that to the first launch: 5-10 ms of the first call otherwise)
 hipError_t warm_edges_module() {
     // ... and resolves the kernels of the default clustering path (4-byte adjacency), each a one-time 0.1-0.3 ms otherwise
