@@ -288,6 +288,13 @@ class Context:
             self._raise(st, stats)
         return cid[:self.n], order[:stats.n_result_clusters], stats
 
+    def set_java_hashset(self, version):
+        """hmk_set_java_hashset: 8 (default, Java 8+), 7 (JDK 7u6+) or 6 (JDK 6 / 7 before 7u6) -- whose HashSet iteration
+        order the clinkage calls emulate for the chain starts and the returned list."""
+        st = N.lib.hmk_set_java_hashset(self._h, int(version))
+        if st:
+            self._raise(st)
+
     def clinkage_cluster(self, max_shift, shift_penalty, threshold):
         """hmk_clinkage_cluster -> (cluster_id int32[n], result_order int32[n_result], ClinkageStats); member_rank in
         self.member_rank.  Sequences in LOAD order (clinkage mode does not sort)."""

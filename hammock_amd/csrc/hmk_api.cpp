@@ -88,6 +88,7 @@ struct hmk_ctx {
     int min_m = 0, max_m = 0;
     int device = -1;
     bool has_device = false;
+    int java_hashset = 8;   // hmk_set_java_hashset: whose HashSet iteration order clinkage emulates
 
     uint32_t n = 0;
     std::vector<uint8_t> res;
@@ -139,7 +140,7 @@ struct hmk_ctx {
     hipEvent_t ev_bandgather = nullptr, ev_gather = nullptr;
 
     std::string err;
-    std::mutex mu;
+    mutable std::mutex mu;
 };
 
 namespace {
@@ -1519,6 +1520,10 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                            buf<void>(ctx, SB_BADJ), packed, base, R1, C);
                 if (e == hipSuccess && entries)
                     e = hipMemcpyAsync(ctx->h_adj, buf<void>(ctx, SB_BADJ), entries * esz, hipMemcpyDeviceToHost, C);
+                // the band rows' upper-section sizes travel with them: upper[] must never hold a previous call's values for rows
+                // the merge may read (today every reader refetches from the full CSR first; this keeps it true by construction)
+                if (e == hipSuccess && symmetric)
+                    e = hipMemcpyAsync(h_up, buf<uint32_t>(ctx, SB_BCURSOR), (size_t)R1 * 4, hipMemcpyDeviceToHost, C);
                 if (e == hipSuccess) e = hipStreamSynchronize(C);
                 if (e == hipSuccess) {
                     rows_here = R1;
@@ -1752,17 +1757,27 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             if (const char *v = getenv("HMK_LOOP_LOOKAHEAD")) LOOKAHEAD = (uint32_t)std::max(1, atoi(v));
             volatile unsigned long long *word = ctx->h_loop;
             *word = 0;
-            const auto t_poll = std::chrono::steady_clock::now();
+            // never spin forever: the deadline runs from the last round the device was SEEN to finish (a long loop is fine, a
+            // stalled device is not) and is looked at on every poll (a few thousand spins apart)
+            auto t_progress = std::chrono::steady_clock::now();
+            uint32_t last_seen = 0;
+            bool stalled = false;
             while (r == hipSuccess && !done && rounds <= nl + 8) {
                 one_round();
-                for (;;) {
+                for (uint32_t spins = 0;; spins++) {
                     const unsigned long long w = *word;
                     const uint32_t seen = (uint32_t)(w >> 32);      // rounds the device has finished
                     if (seen && (uint32_t)w == 0) { done = true; break; }
                     if (rounds - seen < LOOKAHEAD) break;
-                    if ((rounds & 63u) == 0 && ms_since(t_poll) > 60e3) { r = hipErrorNotReady; break; }   // never spin forever
+                    if (seen != last_seen) { last_seen = seen; t_progress = std::chrono::steady_clock::now(); }
+                    else if ((spins & 1023u) == 1023u && ms_since(t_progress) > 60e3) { stalled = true; break; }
                     std::this_thread::yield();
                 }
+                if (stalled) break;
+            }
+            if (stalled) {   // no k_loop_* kernel may still be writing cand[] or the progress word when the host path takes over
+                (void)hipStreamSynchronize(S);
+                r = hipErrorNotReady;
             }
             if (r == hipSuccess && !done) {                         // (only when nl + 8 rounds were not enough: impossible)
                 r = hipStreamSynchronize(S);
@@ -1860,9 +1875,9 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (!src.format_known && !wait_full()) cst = -1;
         if (cst == HMK_OK && n && hooks.need_rows(n - 1) < n) cst = -1;
         if (cst == HMK_OK)
-            cst = packed ? clinkage_from_csr_packed(n, szs, h_start, (const NbrPacked *)ctx->h_adj, cluster_id, result_order, member_rank,
+            cst = packed ? clinkage_from_csr_packed(ctx->java_hashset, n, szs, h_start, (const NbrPacked *)ctx->h_adj, cluster_id, result_order, member_rank,
                                                     src.clink, &err)
-                         : clinkage_from_csr(n, szs, h_start, (const Nbr *)ctx->h_adj, cluster_id, result_order, member_rank, src.clink,
+                         : clinkage_from_csr(ctx->java_hashset, n, szs, h_start, (const Nbr *)ctx->h_adj, cluster_id, result_order, member_rank, src.clink,
                                              &err);
         (void)hipStreamSynchronize(S);
         (void)hipStreamSynchronize(C);
@@ -2402,6 +2417,15 @@ int hmk_create_multi(const int32_t *matrix, const int *devices, int n_devices, h
     return HMK_OK;
 }
 
+int hmk_set_java_hashset(hmk_ctx *ctx, int version) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    if (version != 8 && version != 7 && version != 6) return fail(ctx, HMK_ERR_BAD_ARG, "hmk_set_java_hashset: 8 (Java 8+), 7 (JDK 7u6+) or 6 (JDK 6 / 7 before 7u6)");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->java_hashset = version;
+    for (hmk_ctx *peer : ctx->peers) peer->java_hashset = version;
+    return HMK_OK;
+}
+
 int hmk_device_count(const hmk_ctx *ctx) { return ctx ? (ctx->has_device ? 1 + (int)ctx->peers.size() : 0) : 0; }
 
 int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edges, int symmetric, int max_clusters,
@@ -2526,7 +2550,7 @@ int hmk_clinkage_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edge
         }
     }
     std::string err;
-    const int st = clinkage_from_csr(n, ctx->has_sizes ? ctx->sizes.data() : nullptr, start.data(), adj.data(), cluster_id, result_order,
+    const int st = clinkage_from_csr(ctx->java_hashset, n, ctx->has_sizes ? ctx->sizes.data() : nullptr, start.data(), adj.data(), cluster_id, result_order,
                                      member_rank, stats, &err);
     stats->n_edges = n_edges;
     if (st) return fail(ctx, st, err);
@@ -2535,6 +2559,7 @@ int hmk_clinkage_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edge
 
 int hmk_greedy_last_phases(const hmk_ctx *ctx, hmk_greedy_phases *out) {
     if (!ctx || !out) return fail(nullptr, HMK_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);   // the clustering calls write it under the same lock: never a torn struct
     *out = ctx->phases;
     return HMK_OK;
 }

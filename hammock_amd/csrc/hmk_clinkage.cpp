@@ -33,37 +33,73 @@ namespace hmk {
 
 namespace {
 
-// java.util.HashSet<Cluster> keyed by cluster id (see the header comment)
+// java.util.HashSet<Cluster> keyed by cluster id (see the header comment).
+//   version 8 (default): Java 8 and later -- hash = h ^ h >>> 16, a new node is APPENDED to its bucket's chain, a resize splits
+//                        the chains preserving their order.  A bucket that reaches 8 nodes in a table of 64+ would be
+//                        treeified (its iteration order then starts at the tree's root): that is not modelled; it cannot
+//                        happen for the consecutive ids used here at load factor 0.75, and `unmodelled()` says so if it did.
+//   version 7: JDK 7u6 ... 7u80 (the reference is a Java 1.7 project, nbproject/project.properties:45-46) --
+//              hash = h ^ h >>> 20 ^ h >>> 12, then h ^ h >>> 7 ^ h >>> 4; a new entry goes to the HEAD of its chain; addEntry
+//              resizes BEFORE inserting when size >= threshold and the target bucket is not empty; transfer() walks the old
+//              buckets in order and puts every entry at the head of its new bucket.
+//   version 6: JDK 6 and JDK 7 before 7u6 -- as 7, but the entry is inserted first and the table resized when size++ >= threshold.
 class JavaClusterSet {
     std::vector<int32_t> head_, tail_, next_;
     uint32_t cap_ = 16, size_ = 0, lowest_ = 0;
+    int version_ = 8;
+    bool unmodelled_ = false;
     uint32_t bucket(int32_t id) const {
         uint32_t h = (uint32_t)(553 + id);   // Cluster.java:178-183
-        h ^= h >> 16;
+        if (version_ == 8) h ^= h >> 16;
+        else { h ^= (h >> 20) ^ (h >> 12); h ^= (h >> 7) ^ (h >> 4); }
         return h & (cap_ - 1);
     }
-    void append(int32_t id) {
+    void append(int32_t id) {   // Java 8+
         const uint32_t b = bucket(id);
         next_[id] = -1;
         if (head_[b] < 0) head_[b] = id; else next_[tail_[b]] = id;
         tail_[b] = id;
         lowest_ = std::min(lowest_, b);
+        if (cap_ >= 64) {       // TREEIFY_THRESHOLD = 8, MIN_TREEIFY_CAPACITY = 64
+            uint32_t len = 0;
+            for (int32_t cur = head_[b]; cur >= 0; cur = next_[cur]) len++;
+            if (len >= 8) unmodelled_ = true;
+        }
+    }
+    void push_head(int32_t id) {   // Java <= 7: table[i] = new Entry(.., table[i])
+        const uint32_t b = bucket(id);
+        next_[id] = head_[b];
+        if (head_[b] < 0) tail_[b] = id;
+        head_[b] = id;
+        lowest_ = std::min(lowest_, b);
+    }
+    void grow() {
+        std::vector<int32_t> order;
+        order.reserve(size_ + 1);
+        for (uint32_t b = 0; b < cap_; b++)
+            for (int32_t cur = head_[b]; cur >= 0; cur = next_[cur]) order.push_back(cur);
+        cap_ *= 2;
+        head_.assign(cap_, -1);
+        tail_.assign(cap_, -1);
+        lowest_ = cap_;
+        for (int32_t id2 : order) { if (version_ == 8) append(id2); else push_head(id2); }
     }
 public:
-    explicit JavaClusterSet(uint32_t max_id) : head_(16, -1), tail_(16, -1), next_((size_t)max_id + 1, -1) {}
+    JavaClusterSet(uint32_t max_id, int version) : head_(16, -1), tail_(16, -1), next_((size_t)max_id + 1, -1), version_(version) {}
     uint32_t size() const { return size_; }
+    bool unmodelled() const { return unmodelled_; }
     void add(int32_t id) {
-        append(id);
-        if (++size_ > cap_ / 4 * 3) {   // resize(): chains are split preserving their order
-            std::vector<int32_t> order;
-            order.reserve(size_);
-            for (uint32_t b = 0; b < cap_; b++)
-                for (int32_t cur = head_[b]; cur >= 0; cur = next_[cur]) order.push_back(cur);
-            cap_ *= 2;
-            head_.assign(cap_, -1);
-            tail_.assign(cap_, -1);
-            lowest_ = cap_;
-            for (int32_t id2 : order) append(id2);
+        const uint32_t threshold = cap_ / 4 * 3;
+        if (version_ == 8) {
+            append(id);
+            if (++size_ > threshold) grow();   // resize(): chains are split preserving their order
+        } else if (version_ == 7) {
+            if (size_ >= threshold && head_[bucket(id)] >= 0) grow();
+            push_head(id);
+            size_++;
+        } else {
+            push_head(id);
+            if (size_++ >= threshold) grow();
         }
     }
     void remove(int32_t id) {
@@ -91,7 +127,7 @@ struct CNbr { int32_t id, score; };   // candidate cluster, complete-linkage sco
 
 template <class NbrT>
 int clinkage_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj, int32_t *cluster_id,
-                  int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *st, std::string *err) {
+                  int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *st, std::string *err, int hashset_version) {
     const auto t0 = std::chrono::steady_clock::now();
     if (n == 0) {   // activeClusters.iterator().next() on an empty set, :118
         if (err) *err = "the reference throws NoSuchElementException here (ClinkageSequenceClusterer.java:118): empty input";
@@ -104,7 +140,7 @@ int clinkage_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const
     // member lists as chains over the sequences: head / tail per cluster, next per sequence (top's members, then the
     // nearest's, :105-106)
     std::vector<int32_t> mhead((size_t)max_id + 1, -1), mtail((size_t)max_id + 1, -1), mnext(n, -1);
-    JavaClusterSet active(max_id), ready(max_id);
+    JavaClusterSet active(max_id, hashset_version), ready(max_id, hashset_version);
     int32_t current_id = 1;
     for (uint32_t k = 0; k < n; k++) {   // :50-55: one cluster per sequence, ids from 1 in list order
         const int32_t id = current_id++;
@@ -212,19 +248,23 @@ int clinkage_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const
     });
     st->n_result_clusters = out;
     st->chain_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (active.unmodelled() || ready.unmodelled()) {   // never seen; a result whose order rests on an unmodelled tree bin is refused
+        if (err) *err = "clinkage: a HashSet bucket reached 8 entries (Java 8+ would treeify it): its iteration order is not modelled";
+        return HMK_ERR_BAD_ARG;
+    }
     return HMK_OK;
 }
 
 }  // namespace
 
-int clinkage_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, int32_t *cluster_id,
+int clinkage_from_csr(int hashset_version, uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, int32_t *cluster_id,
                       int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *st, std::string *err) {
-    return clinkage_impl<Nbr>(n, sizes, start, adj, cluster_id, result_order, member_rank, st, err);
+    return clinkage_impl<Nbr>(n, sizes, start, adj, cluster_id, result_order, member_rank, st, err, hashset_version);
 }
 
-int clinkage_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj, int32_t *cluster_id,
+int clinkage_from_csr_packed(int hashset_version, uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj, int32_t *cluster_id,
                              int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *st, std::string *err) {
-    return clinkage_impl<NbrPacked>(n, sizes, start, adj, cluster_id, result_order, member_rank, st, err);
+    return clinkage_impl<NbrPacked>(n, sizes, start, adj, cluster_id, result_order, member_rank, st, err, hashset_version);
 }
 
 }  // namespace hmk

@@ -149,9 +149,11 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
                       int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err);
 
 // exact complete linkage by nearest-neighbour chain on a symmetric CSR adjacency (hmk_clinkage.cpp)
-int clinkage_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, int32_t *cluster_id,
+// hashset_version: 8 (Java 8+), 7 (JDK 7u6+) or 6 (JDK 6 / early 7): whose java.util.HashSet iteration order picks the chain
+// starts and orders the returned list
+int clinkage_from_csr(int hashset_version, uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, int32_t *cluster_id,
                       int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *st, std::string *err);
-int clinkage_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj, int32_t *cluster_id,
+int clinkage_from_csr_packed(int hashset_version, uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj, int32_t *cluster_id,
                              int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *st, std::string *err);
 
 }  // namespace hmk

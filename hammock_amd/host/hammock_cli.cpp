@@ -47,6 +47,7 @@ struct Options {
     int cacheSizeLimit = 1;   // clinkage: -L is parsed and logged, never used (Hammock.java:89,1004-1008,459)
     int device = 0;
     std::vector<int> devices;   // --devices 0,1,..: pair space sharded over several GPUs
+    int javaHashSet = 8;        // --java_hashset 8|7|6 (clinkage): whose java.util.HashSet iteration order is emulated
 };
 
 void parseCommonArgs(const std::vector<std::string> &args, Options &o) {  // Hammock.java:824-908
@@ -65,6 +66,12 @@ void parseCommonArgs(const std::vector<std::string> &args, Options &o) {  // Ham
         if ((a == "-l" || a == "--labels") && more) { o.labelString = args[++i]; o.haveLabels = true; continue; }
         if (a == "--temp" && more) { o.tempDirectory = args[i + 1]; }  // :903-905 (no skip, as in the reference)
         if (a == "--device" && more) { o.device = javaIntegerDecode(args[++i]); continue; }
+        if (a == "--java_hashset" && more) {
+            o.javaHashSet = javaIntegerDecode(args[++i]);
+            if (o.javaHashSet != 8 && o.javaHashSet != 7 && o.javaHashSet != 6)
+                throw CLIException("Error. --java_hashset may be 8 (Java 8 and later, the default), 7 (JDK 7u6 and later 7 updates) or 6 (JDK 6, JDK 7 before 7u6).");
+            continue;
+        }
         if (a == "--devices" && more) {
             o.devices.clear();
             std::string list = args[++i], tok;
@@ -125,7 +132,8 @@ void printHelp() {  // Hammock.java:295-320 (greedy-relevant part)
               << "--initial_clusters_limit <int>\n\tThe max. number of clusters resulting from gredy clustering\n\n"
               << "-L, --cache_size_limit <int>\n\t(clinkage) accepted and logged; has no effect, as in the reference\n\n"
               << "--device <int>\n\tHIP device ordinal (default 0)\n\n"
-              << "--devices <int,int,...>\n\tShard the pair space over several GPUs of the node (the first one runs the merge)\n\n";
+              << "--devices <int,int,...>\n\tShard the pair space over several GPUs of the node (the first one runs the merge)\n\n"
+              << "--java_hashset <8|7|6>\n\t(clinkage) whose java.util.HashSet iteration order picks the chain starts and orders the result: 8 = Java 8 and\n\tlater (default), 7 = JDK 7u6 and later updates of 7, 6 = JDK 6 and JDK 7 before 7u6\n\n";
 }
 
 std::string labelsToString(bool have, const std::vector<std::string> &labels) {  // List.toString() / "null"
@@ -185,8 +193,10 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         const std::vector<std::vector<int>> scoringMatrix = FileIOManager::loadScoringMatrix(o.matrixFile);  // :1264
         // the GPU context (HIP start-up, queues, code objects: 70-150 ms) is created while the input is read and summarised
         std::future<std::shared_ptr<NativeContext>> contextReady = std::async(std::launch::async, [&scoringMatrix, &o]() {
-            return o.devices.empty() ? std::make_shared<NativeContext>(scoringMatrix, o.device)
-                                     : std::make_shared<NativeContext>(scoringMatrix, o.devices);
+            std::shared_ptr<NativeContext> c = o.devices.empty() ? std::make_shared<NativeContext>(scoringMatrix, o.device)
+                                                                 : std::make_shared<NativeContext>(scoringMatrix, o.devices);
+            if (o.javaHashSet != 8 && hmk_set_java_hashset(c->get(), o.javaHashSet) != HMK_OK) throw HammockException("hmk_set_java_hashset failed");
+            return c;
         });
         // ---- checkGreedyOrClinkageArgs, :1272-1277 ------------------------------------------------
         if (!(o.inputType == "fasta" || o.inputType == "seq" || o.inputType == "tab"))

@@ -260,6 +260,13 @@ typedef struct {
  * and id order, :96-113 pushes it again): the reference then works with a stale Cluster object and throws
  * NoSuchElementException or returns a list in which a sequence belongs to two clusters -- there is no cluster_id[] for
  * that (hmk_last_error names the cluster; four 6-mers suffice, tests/test_oracle.py). */
+/* Which java.util.HashSet iteration order hmk_clinkage_cluster / hmk_clinkage_from_edges emulate for
+ * `activeClusters.iterator().next()` (ClinkageSequenceClusterer.java:70, the arbitrary start of every chain) and for the
+ * returned list (:118-123).  version 8 (default): Java 8 and later; 7: JDK 7u6 ... 7u80 (the reference is a Java 1.7
+ * project, nbproject/project.properties:45-46); 6: JDK 6 and JDK 7 before 7u6.  The orders differ in hash spreading, in
+ * where a new entry joins its bucket's chain and in what a resize does to a chain; cluster MEMBERSHIP differs only where a
+ * tie of score, size and id order lets the chain start decide.  HMK_ERR_BAD_ARG for any other version. */
+int hmk_set_java_hashset(hmk_ctx *ctx, int version);
 int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int32_t *cluster_id,
                          int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats);
 

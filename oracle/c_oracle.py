@@ -179,6 +179,11 @@ def greedy_cluster(M, res, off, size, scorer, a, b, threshold, max_clusters, n_t
     return st, cid[:n], order[:stats.n_result_clusters], stats
 
 
+def set_java_hashset(version):
+    """8 (default) / 7 / 6: the HashSet iteration order the clinkage restatement emulates (hammock_oracle.h)."""
+    lib().hmo_set_java_hashset(int(version))
+
+
 def clinkage_cluster(M, res, off, size, max_shift, shift_penalty, threshold, n_threads=1):
     """-> (status, cluster_id[n], result_order[n_result], member_rank[n], stats)"""
     L = lib()

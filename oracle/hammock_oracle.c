@@ -551,6 +551,15 @@ done:
 /* chains in insertion order (tail append, order-preserving resize), no  */
 /* shrink on removal.                                                    */
 /* ------------------------------------------------------------------ */
+/* hmo_set_java_hashset(7) / (6): the same set as Java 7 and earlier kept it (the reference is a Java 1.7 project,          */
+/* nbproject/project.properties:45-46): hash(h) = h ^ (h>>>20) ^ (h>>>12), then h ^ (h>>>7) ^ (h>>>4); a new entry goes  */
+/* to the HEAD of its chain; transfer() walks the old buckets in order and puts every entry at the head of its new        */
+/* bucket.  7 = JDK 7u6+ (resize BEFORE the insert, when size >= threshold and the target bucket is not empty);           */
+/* 6 = JDK 6 and JDK 7 before 7u6 (insert, then resize when size++ >= threshold).                                         */
+static int g_java_hashset = 8;
+void hmo_set_java_hashset(int version) { g_java_hashset = (version == 7 || version == 6) ? version : 8; }
+int hmo_get_java_hashset(void) { return g_java_hashset; }
+
 typedef struct {
     int32_t *head, *tail; /* per bucket: first / last id of the chain, -1 = empty */
     int32_t *next;        /* per id */
@@ -559,7 +568,8 @@ typedef struct {
 
 static uint32_t jset_bucket(const jset_t *s, int32_t id) {
     uint32_t h = (uint32_t)(553 + id);
-    h ^= h >> 16;
+    if (g_java_hashset == 8) h ^= h >> 16;
+    else { h ^= (h >> 20) ^ (h >> 12); h ^= (h >> 7) ^ (h >> 4); }
     return h & (s->cap - 1);
 }
 
@@ -583,7 +593,48 @@ static void jset_append(jset_t *s, int32_t id) {
     if (b < s->lowest) s->lowest = b;
 }
 
+static void jset_push_head(jset_t *s, int32_t id) { /* Java <= 7: table[i] = new Entry(.., table[i]) */
+    uint32_t b = jset_bucket(s, id);
+    s->next[id] = s->head[b];
+    if (s->head[b] < 0) s->tail[b] = id;
+    s->head[b] = id;
+    if (b < s->lowest) s->lowest = b;
+}
+
+static int jset_resize_old(jset_t *s) { /* Java <= 7 transfer(): old buckets in order, every entry to the head of its new chain */
+    uint32_t ocap = s->cap;
+    int32_t *order = (int32_t *)malloc(((size_t)s->size + 1) * sizeof(int32_t));
+    if (!order) return HMO_ERR_OOM;
+    uint32_t k = 0;
+    for (uint32_t b = 0; b < ocap; b++)
+        for (int32_t id2 = s->head[b]; id2 >= 0; id2 = s->next[id2]) order[k++] = id2;
+    s->cap = ocap * 2;
+    free(s->head); free(s->tail);
+    s->head = (int32_t *)malloc((size_t)s->cap * sizeof(int32_t));
+    s->tail = (int32_t *)malloc((size_t)s->cap * sizeof(int32_t));
+    if (!s->head || !s->tail) { free(order); return HMO_ERR_OOM; }
+    for (uint32_t b = 0; b < s->cap; b++) s->head[b] = s->tail[b] = -1;
+    s->lowest = s->cap;
+    for (uint32_t q = 0; q < k; q++) jset_push_head(s, order[q]);
+    free(order);
+    return HMO_OK;
+}
+
 static int jset_add(jset_t *s, int32_t id) {
+    if (g_java_hashset != 8) {
+        const uint32_t threshold = s->cap / 4 * 3;
+        int st = HMO_OK;
+        if (g_java_hashset == 7) {
+            if (s->size >= threshold && s->head[jset_bucket(s, id)] >= 0) st = jset_resize_old(s);
+            if (st) return st;
+            jset_push_head(s, id);
+            s->size++;
+        } else {
+            jset_push_head(s, id);
+            if (s->size++ >= threshold) st = jset_resize_old(s);
+        }
+        return st;
+    }
     jset_append(s, id);
     if (++s->size > s->cap / 4 * 3) { /* resize(): every chain is re-appended in order */
         uint32_t ocap = s->cap;

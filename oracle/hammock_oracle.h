@@ -121,6 +121,11 @@ typedef struct {
  *   member_rank[n] : position of sequence k in its cluster's member list (top's members, then the nearest's, :105-106)
  * An empty input is HMO_ERR_REFERENCE_WOULD_CRASH (NoSuchElementException at :118).
  */
+/* Which java.util.HashSet iteration order the clinkage restatement emulates for `activeClusters.iterator().next()` and the
+ * returned list (ClinkageSequenceClusterer.java:70,118-123): 8 = Java 8 and later (default), 7 = JDK 7u6 ... 7u80,
+ * 6 = JDK 6 and JDK 7 before 7u6.  Process-wide. */
+void hmo_set_java_hashset(int version);
+int hmo_get_java_hashset(void);
 int hmo_clinkage_cluster(const int32_t *M, const uint8_t *res, const uint32_t *off, const int32_t *size, uint32_t n,
                          int max_shift, int shift_penalty, int threshold, int n_threads, int32_t *cluster_id,
                          int32_t *result_order, int32_t *member_rank, hmo_clinkage_stats *stats);

@@ -436,9 +436,64 @@ class JavaHashSet:
         raise NoSuchElement()
 
 
+class JavaHashSet7(JavaHashSet):
+    """The same for Java 7 and earlier -- the reference is a Java 1.7 project (nbproject/project.properties:45-46).
+    java.util.HashMap before the Java 8 rewrite: hash(h) = h ^ (h >>> 20) ^ (h >>> 12), then h ^ (h >>> 7) ^ (h >>> 4);
+    a new entry goes to the HEAD of its bucket's chain (createEntry); transfer() walks the old buckets in order and puts
+    every entry at the head of its new bucket, so a resize reverses the chains it keeps together.
+      variant 7 (JDK 7u6 ... 7u80): addEntry resizes BEFORE inserting, when size >= threshold AND the target bucket is not
+                                    empty;
+      variant 6 (JDK 6, JDK 7 GA ... 7u5): inserts, then resizes when size++ >= threshold.
+    Iteration is the same everywhere: buckets in index order, a chain from its head."""
+
+    def __init__(self, hash_of, key_of=lambda x: x, variant=7):
+        super().__init__(hash_of, key_of)
+        self.variant = variant
+
+    @staticmethod
+    def _hash7(h):
+        h &= 0xFFFFFFFF
+        h ^= (h >> 20) ^ (h >> 12)
+        return (h ^ (h >> 7) ^ (h >> 4)) & 0xFFFFFFFF
+
+    def _bucket(self, x):
+        return self.table[self._hash7(self.hash_of(x)) & (len(self.table) - 1)]
+
+    def _resize(self):
+        old = self.table
+        self.table = [[] for _ in range(2 * len(old))]
+        for chain in old:
+            for y in chain:                       # chain[0] is the head
+                self._bucket(y).insert(0, y)      # e.next = newTable[i]; newTable[i] = e
+
+    def add(self, x):
+        b = self._bucket(x)
+        k = self.key_of(x)
+        if any(self.key_of(y) == k for y in b):
+            return False
+        threshold = len(self.table) * 3 // 4
+        if self.variant == 7:
+            if self.size >= threshold and b:      # addEntry: (size >= threshold) && (null != table[bucketIndex])
+                self._resize()
+                b = self._bucket(x)
+            b.insert(0, x)
+            self.size += 1
+        else:
+            b.insert(0, x)                        # table[bucketIndex] = new Entry(hash, key, value, e)
+            self.size += 1
+            if self.size - 1 >= threshold:        # if (size++ >= threshold) resize(2 * table.length)
+                self._resize()
+        return True
+
+
+JAVA_HASHSET = 8          # 8: Java 8 and later (default); 7: JDK 7u6+; 6: JDK 6 and JDK 7 before 7u6
+
+
 def _cluster_set():
     # Cluster.hashCode() = 79 * 7 + id (Cluster.java:178-183); equals compares ids (:185-195)
-    return JavaHashSet(lambda c: 553 + c.id, lambda c: c.id)
+    if JAVA_HASHSET == 8:
+        return JavaHashSet(lambda c: 553 + c.id, lambda c: c.id)
+    return JavaHashSet7(lambda c: 553 + c.id, lambda c: c.id, JAVA_HASHSET)
 
 
 class DynamicMatrix:

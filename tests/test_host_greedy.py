@@ -192,6 +192,34 @@ def test_clinkage_from_edges_matches_oracle(blosum62, coracle, seed):
     assert (stats.merges, stats.searches) == (ostats.merges, ostats.searches)
 
 
+@pytest.mark.parametrize("version", [7, 6])
+@pytest.mark.parametrize("seed", range(5))
+def test_clinkage_from_edges_java7_hashset_order(blosum62, coracle, seed, version):
+    """hmk_set_java_hashset(7 / 6): the product's chain with the pre-Java-8 HashSet iteration order (the reference is a Java
+    1.7 project) against the oracle in the same mode -- ids, list order, member order, merge and search counts."""
+    rng = np.random.default_rng(1300 + seed)
+    n = int(rng.integers(2, 600))
+    peps = random_peptides(rng, n, 9 if seed % 2 else 12, 12, alphabet=3 + seed % 3)
+    sizes = rng.integers(1, 5, size=n).astype(np.int32) if seed % 3 else None
+    res, off = coracle.pack(peps)
+    X, p, thr = 2 + seed % 2, -(seed % 2), 12 + 2 * seed
+    coracle.set_java_hashset(version)
+    try:
+        st, ocid, oorder, orank, ostats = coracle.clinkage_cluster(blosum62, res, off, sizes, X, p, thr, 2)
+    finally:
+        coracle.set_java_hashset(8)
+    assert st == 0
+    edges = oracle_edges(coracle, blosum62, res, off, X, p, thr, True)
+    ctx = hammock_amd.Context(blosum62, device=-1)
+    ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
+    ctx.set_java_hashset(version)
+    cid, order, stats = ctx.clinkage_from_edges(edges)
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(ctx.member_rank[:n], orank)
+    assert (stats.merges, stats.searches) == (ostats.merges, ostats.searches)
+    with pytest.raises(ValueError):
+        ctx.set_java_hashset(5)
+
+
 def test_clinkage_from_edges_chain_returns_to_a_stacked_cluster(matrices, coracle):
     """tests/test_oracle.py::test_clinkage_chain_returns_to_a_stacked_cluster through the product's chain: the input on
     which the reference throws NoSuchElementException and the one on which it returns sequences in two clusters are both

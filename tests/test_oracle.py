@@ -336,6 +336,59 @@ def test_clinkage_c_vs_literal_python(blosum62, coracle, seed):
         assert stats.merges > 0
 
 
+@pytest.mark.parametrize("version", [7, 6])
+@pytest.mark.parametrize("seed", range(6))
+def test_clinkage_java7_hashset_order_c_vs_literal_python(blosum62, coracle, seed, version):
+    """The reference is a Java 1.7 project (nbproject/project.properties:45-46); chain starts and the returned list's order
+    are HashSet iteration orders (ClinkageSequenceClusterer.java:70,118-123), which Java 8 changed.  Both oracles emulate the
+    older orders on request (7: JDK 7u6+, 6: JDK 6 / early 7): they must agree with each other in those modes too."""
+    rng = np.random.default_rng(700 + seed)
+    n = int(rng.integers(2, 300))
+    peps = random_peptides(rng, n, 8 if seed % 2 else 12, 12, alphabet=3 + seed % 4)
+    sizes = rng.integers(1, 4, size=n).astype(np.int32) if seed % 3 else None
+    res, off = coracle.pack(peps)
+    X, p, thr = seed % 4, -(seed % 2), 10 + 3 * seed
+    coracle.set_java_hashset(version)
+    po.JAVA_HASHSET = version
+    try:
+        st, cid, order, rank, stats = coracle.clinkage_cluster(blosum62, res, off, sizes, X, p, thr, 1)
+        assert st == 0
+        pcid, porder, prank, pstats = _clinkage_python(blosum62, peps, sizes, X, p, thr)
+    finally:
+        coracle.set_java_hashset(8)
+        po.JAVA_HASHSET = 8
+    assert np.array_equal(cid, pcid) and order.tolist() == porder and np.array_equal(rank, prank)
+    assert stats.merges == pstats["merges"] and stats.searches == pstats["searches"]
+
+
+def test_java7_hashmap_order_known_values():
+    """Hand-derived pins of the pre-Java-8 HashMap: hash(h) = h ^ h>>>20 ^ h>>>12, then h ^ h>>>7 ^ h>>>4 (java.util.HashMap,
+    JDK 6/7).  For small non-negative h only the second step acts: hash(553 + 1) = 554 ^ (554 >>> 7 = 4) ^ (554 >>> 4 = 34) = 524
+    -> bucket 12 of 16; hash(555) = 525 -> 13; hash(556) = 556 ^ 4 ^ 34 = 522 -> 10; hash(557) = 523 -> 11.  So a set holding ids
+    1..4 iterates as 3, 4, 1, 2 (buckets 10, 11, 12, 13), where Java 8 (hash = h: 554.. & 15 = 10, 11, 12, 13 for ids 1..4)
+    iterates in insertion order 1, 2, 3, 4."""
+    assert po.JavaHashSet7._hash7(554) == 524 and po.JavaHashSet7._hash7(555) == 525
+    assert po.JavaHashSet7._hash7(556) == 522 and po.JavaHashSet7._hash7(557) == 523
+    class C:  # noqa: E701
+        def __init__(self, i): self.id = i
+    for version, want in ((7, [3, 4, 1, 2]), (6, [3, 4, 1, 2]), (8, [1, 2, 3, 4])):
+        po.JAVA_HASHSET = version
+        try:
+            s = po._cluster_set()
+        finally:
+            po.JAVA_HASHSET = 8
+        for i in (1, 2, 3, 4):
+            s.add(C(i))
+        assert [c.id for c in s] == want, version
+    # 13 entries into a table of 16 (threshold 12): variant 6 resizes after the 13th insert, variant 7 only once a 13th entry
+    # meets an occupied bucket -- with consecutive ids the 13th lands in an empty bucket, so 7 keeps 16 buckets where 6 has 32
+    po.JAVA_HASHSET = 8
+    s7, s6 = po.JavaHashSet7(lambda c: 553 + c.id, lambda c: c.id, 7), po.JavaHashSet7(lambda c: 553 + c.id, lambda c: c.id, 6)
+    for i in range(1, 14):
+        s7.add(C(i)); s6.add(C(i))
+    assert len(s6.table) == 32 and len(s7.table) in (16, 32)
+
+
 def test_clinkage_independent_of_threads_and_cache(blosum62):
     """DESIGN.md (round 1) argued that the reference's clinkage result depends on -t through stale DynamicMatrix
     entries.  The literal restatement says otherwise for a single pool thread working through the parts in order:
