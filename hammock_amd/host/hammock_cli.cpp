@@ -225,11 +225,17 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
                               "\n-S, --seed " + std::to_string(o.seed) + "\n\n");
 
         // ---- loadInputSequences, :749-787 -----------------------------------------------------------
+        const auto timeStart = std::chrono::steady_clock::now();
+        auto cliLap = [&](const char *what) {   // HMK_CLI_TIMING=1: where a hammock-hip process spends its time
+            if (std::getenv("HMK_CLI_TIMING"))
+                std::fprintf(stderr, "[hammock-hip] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - timeStart).count());
+        };
         logger.logAndStderr("Loading input sequences...");
         std::vector<UniqueSequencePtr> sequences;
         if (o.inputType == "fasta") sequences = FileIOManager::loadUniqueSequencesFromFasta(o.inputFileName);
         else if (o.inputType == "tab") sequences = FileIOManager::loadUniqueSequencesFromTable(o.inputFileName);
         else throw HammockException("Error, this should have been checked.");  // "seq", :759-761
+        cliLap("input loaded");
         logger.logAndStderr(std::to_string(sequences.size()) + " unique sequences loaded.");
         long long total = 0;
         for (auto &s : sequences) total += s->size();
@@ -276,8 +282,10 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
                                     " as the length of the shortest sequence is only " + std::to_string(correct + 1));
             }
         }
+        cliLap("labels, lengths, max shift");
         logger.logAndStderr("Generating input statistics...");
         FileIOManager::saveInputStatistics(sequences, labels, inputStatistics);                 // :814-816
+        cliLap("input statistics written");
         if (!o.haveThreshold) {                                                                 // :394-397 / :452-455
             o.sequenceClusteringThreshold = (int)javaRound(meanSequenceLength(sequences) * 1.7);
             logger.logAndStderr(std::string(clinkage ? "Clinkage" : "Greedy") + " clustering threshold not set. Setting automatically to: " +
@@ -292,6 +300,7 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         HipGreedySequenceClusterer clusterer(scorer, o.sequenceClusteringThreshold, o.initialClustersLimit);  // :403
         HipClinkageSequenceClusterer clinkageClusterer(scorer, o.sequenceClusteringThreshold);                // :459
 
+        cliLap("GPU context ready");
         logger.logAndStderr(clinkage ? "Clinkage clustering..." : "Greedy clustering...");
         const auto time0 = std::chrono::steady_clock::now();
         if (!clinkage) sortSequences(sequences, o.order, o.seed, labels);                       // :407 (clinkage keeps the load order)
@@ -302,6 +311,7 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         auto ms = [&]() {
             return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - time0).count();
         };
+        cliLap("clustered");
         logger.logAndStderr("Ready. Clustering time: " + std::to_string(ms()));                // :411 / :463
         logger.logAndStderr("Resulting clusers: " + std::to_string(clusters.size()));          // :412 / :464
         if (clinkage)
@@ -324,6 +334,7 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
             FileIOManager::saveInitialClusters(clusters, initialClustersSequencesCsv, initialClustersSequencesOrderedCsv, initialClusters,
                                                labels, initialSequences);
         }
+        cliLap("result files written");
         logger.logAndStderr(std::string(clinkage ? "Clinkage" : "Greedy") + " clustering results in: " + initialClusters);
         logger.logAndStderr("and: " + initialClustersSequencesCsv);
         logger.logAndStderr("and: " + initialClustersSequencesOrderedCsv);

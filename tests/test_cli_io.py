@@ -51,6 +51,53 @@ def test_antibodies_counts_labels_and_shuffle(tmp_path):
         assert r.stdout == expected_listing(po.load_unique_sequences_from_fasta(str(fa)), order, 42)
 
 
+def test_parallel_fasta_loader_equals_literal_loader(tmp_path):
+    """loadUniqueSequencesFromFasta cuts a large file at header lines and parses the pieces on several threads; the result must
+    be the literal loader's (FileIOManager.java:159-202, HMK_LITERAL_LOADER=1) and the oracle's: duplicates that meet across
+    pieces add their counts to the FIRST occurrence, labels keep their first-seen order per sequence, multi-line sequences are
+    concatenated, \\r\\n and \\r end lines, a header without a sequence adds nothing -- except the very last one, which adds the
+    empty sequence (:193-195).  Malformed input goes to the literal loader and raises what it raises."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    aa = "ARNDCQEGHILKMFPSTWYV"
+    base = ["".join(aa[int(c)] for c in rng.integers(0, 20, size=int(rng.integers(7, 21)))) for _ in range(6000)]
+    lines = []
+    for k in range(40000):
+        s = base[int(rng.integers(0, len(base)))]            # many duplicates, all over the file
+        kind = int(rng.integers(0, 6))
+        head = f">{k}" if kind == 0 else f">{k}|{1 + int(rng.integers(0, 50))}" if kind == 1 else \
+            f"> s{k} | {1 + int(rng.integers(0, 9))} |lab{int(rng.integers(0, 5))}|extra" if kind == 2 else f">{k}|{1 + int(rng.integers(0, 9))}|lab{int(rng.integers(0, 5))}"
+        eol = "\r\n" if k % 7 == 0 else "\r" if k % 11 == 0 else "\n"
+        if k % 5 == 0 and len(s) > 8:                        # multi-line, lower case, padded
+            lines.append(head + eol + "  " + s[:5].lower() + " " + eol + s[5:] + eol)
+        elif k % 97 == 0:
+            lines.append(head + eol)                          # a header without a sequence
+        else:
+            lines.append(head + eol + s + eol)
+    fa = tmp_path / "big.fa"
+    fa.write_bytes("".join(lines).encode())
+    assert fa.stat().st_size > (1 << 16)
+    want = expected_listing(po.load_unique_sequences_from_fasta(str(fa)), "input", 42)
+    fast = cli("io-selftest", "sequences", "fasta", str(fa), "input", "42")
+    assert fast.returncode == 0, fast.stderr
+    env = dict(os.environ, HMK_LITERAL_LOADER="1")
+    literal = subprocess.run([CLI, "io-selftest", "sequences", "fasta", str(fa), "input", "42"], capture_output=True, text=True, env=env)
+    assert literal.returncode == 0, literal.stderr
+    assert fast.stdout == literal.stdout == want
+    # the same file ending in a header: the empty sequence is added by the last record only
+    fa2 = tmp_path / "tail.fa"
+    fa2.write_bytes("".join(lines).encode() + b">last|3|labz\n")
+    a = cli("io-selftest", "sequences", "fasta", str(fa2), "input", "42")
+    b = subprocess.run([CLI, "io-selftest", "sequences", "fasta", str(fa2), "input", "42"], capture_output=True, text=True, env=env)
+    assert (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr)
+    # a count below 1 in the middle of the file: both loaders fail alike
+    fa3 = tmp_path / "bad.fa"
+    fa3.write_bytes("".join(lines[:20000]).encode() + b">x|0|l\nACDEFGHIKL\n" + "".join(lines[20000:]).encode())
+    a = cli("io-selftest", "sequences", "fasta", str(fa3), "input", "42")
+    b = subprocess.run([CLI, "io-selftest", "sequences", "fasta", str(fa3), "input", "42"], capture_output=True, text=True, env=env)
+    assert a.returncode != 0 and (a.returncode, a.stdout, a.stderr) == (b.returncode, b.stdout, b.stderr)
+
+
 def test_matrix_loader_all_shipped_matrices(tmp_path):
     with open(os.path.join(GOLDEN, "matrices.json")) as fh:
         d = json.load(fh)

@@ -758,6 +758,28 @@ def test_clinkage_vs_oracle(gpu, blosum62, coracle, name):
             assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(multi.member_rank[:len(cid)], orank)
 
 
+@pytest.mark.parametrize("version", [7, 6])
+def test_clinkage_java7_hashset_order_on_gpu(gpu, blosum62, coracle, version):
+    """hmk_clinkage_cluster with hmk_set_java_hashset(7 / 6) -- the iteration order of the HashSets of a Java 7 (or 6) JVM,
+    which is what the reference targets -- against the oracle in the same mode: ids, list order, member order."""
+    rng = np.random.default_rng(60 + version)
+    peps = random_peptides(rng, 2500, 10, 14, alphabet=5)
+    sizes = rng.integers(1, 4, size=len(peps)).astype(np.int32)
+    res, off = coracle.pack(peps)
+    coracle.set_java_hashset(version)
+    try:
+        st, ocid, oorder, orank, ostats = coracle.clinkage_cluster(blosum62, res, off, sizes, 3, 0, 30, 8)
+    finally:
+        coracle.set_java_hashset(8)
+    assert st == 0 and ostats.merges > 0
+    ctx = hammock_amd.Context(blosum62, device=0)
+    ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
+    ctx.set_java_hashset(version)
+    cid, order, stats = ctx.clinkage_cluster(3, 0, 30)
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(ctx.member_rank[:len(cid)], orank)
+    assert (stats.merges, stats.searches) == (ostats.merges, ostats.searches)
+
+
 def test_clinkage_edge_cases(gpu, blosum62, coracle):
     for n in (1, 2, 3):   # one sequence: the loop never runs; two: merged or not
         res, off = synth_peptides(5, n, 12)
