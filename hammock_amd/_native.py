@@ -30,7 +30,7 @@ SYMBOLS = [
     "hmk_neighbors_shifted", "hmk_neighbors_local", "hmk_neighbors_shifted_dev", "hmk_compact_edges_dev", "hmk_pack_rows_dev", "hmk_unpack_rows_dev",
     "hmk_neighbors_last_plan",
     "hmk_greedy_cluster", "hmk_greedy_from_edges", "hmk_greedy_from_edges_dev", "hmk_greedy_last_phases",
-    "hmk_clinkage_cluster", "hmk_clinkage_from_edges", "hmk_set_java_hashset",
+    "hmk_clinkage_cluster", "hmk_clinkage_from_edges", "hmk_set_java_hashset", "hmk_reserve",
 ]
 
 
@@ -111,6 +111,7 @@ def _load():
     L.hmk_greedy_from_edges.argtypes = [vp, p_u64, u64, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(GreedyStats)]
     L.hmk_greedy_last_phases.argtypes = [vp, C.POINTER(GreedyPhases)]
     L.hmk_set_java_hashset.argtypes = [vp, i32]
+    L.hmk_reserve.argtypes = [vp, u32]
     L.hmk_clinkage_cluster.argtypes = [vp, i32, i32, i32, p_i32, p_i32, p_i32, C.POINTER(ClinkageStats)]
     L.hmk_clinkage_from_edges.argtypes = [vp, p_u64, u64, p_i32, p_i32, p_i32, C.POINTER(ClinkageStats)]
     for name in SYMBOLS:

@@ -1921,6 +1921,91 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     return HMK_OK;
 }
 
+// The grow-only device and pinned buffers the tail of a clustering call on n sequences asks for (the edge buffer must have
+// its size already): hmk_greedy_cluster before it enqueues the pass, hmk_reserve from a host that knows n early.
+int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, bool full = false) {
+    const size_t esz0 = packed ? sizeof(NbrPacked) : sizeof(Nbr);
+    HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, std::max<uint64_t>((ctx->symmetric ? 2 : 1) * ctx->d_edges_cap, 1) * esz0));
+    HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
+    HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
+    HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
+    HIPCHK(ctx, ensure_buf(ctx, SB_RANGE, 64));
+    HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, ((size_t)n + 1) * 8 + (size_t)n * 4 + 64, 0));
+    if (r1) {
+        HIPCHK(ctx, ensure_buf(ctx, SB_BDEG, (size_t)r1 * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BCURSOR, (size_t)r1 * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BSTART, ((size_t)r1 + 1) * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(r1)));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
+    }
+    {
+        bool place0 = false;
+        if (const char *v = getenv("HMK_PLACE_EDGES")) place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && atoi(v) != 0;
+        if (csr_by_bucket(n, ctx->symmetric, packed, place0)) {
+            HIPCHK(ctx, ensure_buf(ctx, SB_PART, (ctx->d_edges_cap + 1) * 8));
+            HIPCHK(ctx, ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes()));
+        }
+    }
+    HIPCHK(ctx, ensure_buf(ctx, SB_COF, (size_t)n * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_LEFT, (size_t)n * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_CNT, (size_t)n * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_CSTART, ((size_t)n + 1) * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_CAND, (size_t)n * 24 * sizeof(GreedyCand)));
+    if (full) {
+        // (hmk_reserve only: these are sized from data a call learns late -- estimates here, grown by the call if they fall short)
+        const uint64_t avg_deg = n ? (ctx->symmetric ? 2 : 1) * ctx->d_edges_cap / n + 1 : 1;
+        if (r1) {   // the band's adjacency: device + pinned host copy (0.8 GB at 10^6: the pinned allocation alone took 0.1 s of a first call)
+            const uint64_t entries = (uint64_t)r1 * avg_deg;
+            HIPCHK(ctx, ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz0));
+            HIPCHK(ctx, ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(entries, 1) * esz0, 0));
+        }
+        const size_t ncl = (size_t)(n * 0.025 + 2), nl = n, cands = (size_t)n * 16;   // second loop on the device
+        HIPCHK(ctx, ensure_buf(ctx, SB_USIZE, ncl * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_OVER, 64));
+        HIPCHK(ctx, ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>(n, (uint32_t)std::min<size_t>(cands, 0xFFFFFFFFu)))));
+        HIPCHK(ctx, ensure_buf(ctx, SB_PRECNT, HMK_PRE_REGIONS * sizeof(unsigned long long)));
+        HIPCHK(ctx, ensure_buf(ctx, SB_RETRY, nl * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_JOINED, ncl * 16));
+        HIPCHK(ctx, ensure_buf(ctx, SB_SUBSTART, (ncl + 1) * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_SUBS, cands * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_SUBS2, cands * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_CSIZE, ncl * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_CID, ncl * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_FIRST, ncl * 12));
+        HIPCHK(ctx, ensure_buf(ctx, SB_STATUS, nl));
+        HIPCHK(ctx, ensure_buf(ctx, SB_ACTIVE, nl * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_DIRTY, nl * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_CHOICE, nl * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_ACCEPTED, nl * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_JSLOT, nl * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_LCOUNT, 64));
+        HIPCHK(ctx, ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4));
+        HIPCHK(ctx, ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + (size_t)n * 12 + ncl * 4 + 64, 0));
+    }
+    return HMK_OK;
+}
+
+uint64_t first_edge_capacity(const hmk_ctx *ctx, uint32_t n) {
+    // first guess of the edge buffer: 0.3 % of the pair space (uniform random 12-mers at the default threshold give
+    // 0.26 %); a segment that overflows makes the call size the buffer to the counts and score again
+    uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006)) + (1u << 20);
+    if (const char *v = getenv("HMK_EDGE_GUESS")) guess = std::strtoull(v, nullptr, 10);   // tests: force the overflow / retry path
+    uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)HMK_EDGE_SHARDS * 65536, ctx->d_edges_cap});
+    return (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
+}
+
+int grow_edge_buffer(hmk_ctx *ctx, uint64_t cap) {
+    if (ctx->d_edges_cap >= cap) return HMK_OK;
+    if (ctx->d_edges) (void)hipFree(ctx->d_edges);
+    ctx->d_edges = nullptr;
+    ctx->d_edges_cap = 0;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t)));
+    ctx->d_edges_cap = cap;
+    return HMK_OK;
+}
+
 int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters, int32_t *cluster_id,
                          int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats, hmk_clinkage_stats *clink = nullptr);
 
@@ -1977,55 +2062,15 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     src.check_overflow = true;
     if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
     HIPCHK(ctx, ensure_buf(ctx, SB_BCOUNTS, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
-    // first guess of the edge buffer: 0.3 % of the pair space (uniform random 12-mers at the default threshold give
-    // 0.26 %); a segment that overflows makes the loop below size the buffer to the counts and score again
-    uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006)) + (1u << 20);
-    if (const char *v = getenv("HMK_EDGE_GUESS")) guess = std::strtoull(v, nullptr, 10);   // tests: force the overflow / retry path
-    uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)HMK_EDGE_SHARDS * 65536, ctx->d_edges_cap});
-    cap = (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
+    uint64_t cap = first_edge_capacity(ctx, n);
     for (int attempt = 0; attempt < 4; attempt++) {
-        if (ctx->d_edges_cap < cap) {
-            if (ctx->d_edges) (void)hipFree(ctx->d_edges);
-            ctx->d_edges = nullptr;
-            ctx->d_edges_cap = 0;
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t)));
-            ctx->d_edges_cap = cap;
-        }
+        st = grow_edge_buffer(ctx, cap);
+        if (st) return st;
         // Everything cluster_on_device will want, BEFORE the pass is enqueued: a hipMalloc issued while the pass runs returns
         // when the pass is over (seen at 10^6: the band hand-over of a context's first call was enqueued 340 ms late, i.e.
         // after the scoring it is meant to overlap).  Grow-only buffers: steady-state calls find them all in place.
-        {
-            const size_t esz0 = src.packed ? sizeof(NbrPacked) : sizeof(Nbr);
-            const uint32_t r1 = (uint32_t)std::max<int64_t>(band_rows, 0);
-            HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, std::max<uint64_t>((ctx->symmetric ? 2 : 1) * ctx->d_edges_cap, 1) * esz0));
-            HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
-            HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
-            HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
-            HIPCHK(ctx, ensure_buf(ctx, SB_RANGE, 64));
-            HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, ((size_t)n + 1) * 8 + (size_t)n * 4 + 64, 0));
-            if (r1) {
-                HIPCHK(ctx, ensure_buf(ctx, SB_BDEG, (size_t)r1 * 4));
-                HIPCHK(ctx, ensure_buf(ctx, SB_BCURSOR, (size_t)r1 * 8));
-                HIPCHK(ctx, ensure_buf(ctx, SB_BSTART, ((size_t)r1 + 1) * 8));
-                HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(r1)));
-                HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
-            }
-            {
-                bool place0 = false;
-                if (const char *v = getenv("HMK_PLACE_EDGES")) place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && atoi(v) != 0;
-                if (csr_by_bucket(n, ctx->symmetric, src.packed, place0)) {
-                    HIPCHK(ctx, ensure_buf(ctx, SB_PART, (ctx->d_edges_cap + 1) * 8));
-                    HIPCHK(ctx, ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes()));
-                }
-            }
-            HIPCHK(ctx, ensure_buf(ctx, SB_COF, (size_t)n * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_LEFT, (size_t)n * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_CNT, (size_t)n * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_CSTART, ((size_t)n + 1) * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_CAND, (size_t)n * 24 * sizeof(GreedyCand)));
-        }
+        st = reserve_tail_buffers(ctx, n, src.packed, (uint32_t)std::max<int64_t>(band_rows, 0));
+        if (st) return st;
         call_lap("edge buffer ready");
         const uint64_t seg = ctx->d_edges_cap / HMK_EDGE_SHARDS;
         src.seg_cap = seg;
@@ -2415,6 +2460,23 @@ int hmk_create_multi(const int32_t *matrix, const int *devices, int n_devices, h
     (void)hipSetDevice(devices[0]);
     *out = root;
     return HMK_OK;
+}
+
+int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences) {
+    if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    if (!ctx->has_device || n_sequences < 2) return HMK_OK;   // nothing to size
+    int st = need_device(ctx);
+    if (st == HMK_OK) st = greedy_streams(ctx);
+    if (st) return st;
+    if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
+    HIPCHK(ctx, ensure_buf(ctx, SB_BCOUNTS, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
+    st = grow_edge_buffer(ctx, first_edge_capacity(ctx, n_sequences));
+    if (st) return st;
+    const int64_t maxc = (int64_t)(n_sequences * 0.025 + 0.5);      // Hammock.java:398-401, the default cluster limit
+    int64_t band = n_sequences >= 16384 ? std::min<int64_t>(n_sequences, 2 * maxc + 1024) : 0;
+    if (band * 2 > (int64_t)n_sequences) band = 0;
+    return reserve_tail_buffers(ctx, n_sequences, true, (uint32_t)band, true);
 }
 
 int hmk_set_java_hashset(hmk_ctx *ctx, int version) {

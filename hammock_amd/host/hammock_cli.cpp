@@ -192,7 +192,7 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         const std::string inputStatistics = o.workingDirectory + "/input_statistics.tsv";
         const std::vector<std::vector<int>> scoringMatrix = FileIOManager::loadScoringMatrix(o.matrixFile);  // :1264
         // the GPU context (HIP start-up, queues, code objects: 70-150 ms) is created while the input is read and summarised
-        std::future<std::shared_ptr<NativeContext>> contextReady = std::async(std::launch::async, [&scoringMatrix, &o]() {
+        std::shared_future<std::shared_ptr<NativeContext>> contextReady = std::async(std::launch::async, [&scoringMatrix, &o]() {
             std::shared_ptr<NativeContext> c = o.devices.empty() ? std::make_shared<NativeContext>(scoringMatrix, o.device)
                                                                  : std::make_shared<NativeContext>(scoringMatrix, o.devices);
             if (o.javaHashSet != 8 && hmk_set_java_hashset(c->get(), o.javaHashSet) != HMK_OK) throw HammockException("hmk_set_java_hashset failed");
@@ -264,6 +264,11 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         }
         logger.logAndStderr("Shortest sequence: " + std::to_string(minLength) + " AA. Longest sequence: " + std::to_string(maxLength) + " AA.");
         if (sequences.empty()) throw FileFormatException("Error. No sequences (with specified labels) to cluster.");
+        // the sequence count is known: the context's buffers (24 GB at 10^6) are sized on another thread while this one goes on
+        // to the labels, the statistics, the sort and the upload
+        std::future<void> reserved = std::async(std::launch::async, [contextReady, count = (uint32_t)sequences.size()]() {
+            try { (void)hmk_reserve(contextReady.get()->get(), count); } catch (...) { }   // (a device error is reported by the clustering call)
+        });
         if (maxLength > HMK_MAX_LEN)   // the reference has no such limit; say so here instead of failing inside the clusterer
             throw HammockException("Error. The longest sequence has " + std::to_string(maxLength) + " amino acids; the GPU kernels of hammock-hip "
                                    "take sequences of up to " + std::to_string(HMK_MAX_LEN) + " (Hammock's domain is 7-20).");

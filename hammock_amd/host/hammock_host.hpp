@@ -726,40 +726,70 @@ inline std::vector<UniqueSequencePtr> loadUniqueSequencesFromFasta(const std::st
     }
     for (char o : odd) if (o) return loadUniqueSequencesFromFastaLiteral(fileName);
     loaderLap("pieces parsed");
-    // ---- merge in file order (the LinkedHashMap of :160) ----
+    // ---- merge in file order (the LinkedHashMap of :160), partitioned by the sequence's hash: thread t owns the sequences
+    // with hash % threads == t, walks ALL records in file order and merges its own; the first occurrences, marked at their
+    // record's position, are then collected in file order ----
     size_t total = 0;
-    for (auto &v : parsed) total += v.size();
+    std::vector<size_t> piece_base(pieces + 1, 0);
+    for (size_t pc = 0; pc < pieces; pc++) { piece_base[pc + 1] = piece_base[pc] + parsed[pc].size(); }
+    total = piece_base[pieces];
     if (total == 0) return loadUniqueSequencesFromFastaLiteral(fileName);
     struct Entry { std::string seq; std::vector<std::pair<std::string, int>> labels; };
-    std::vector<Entry> order;
-    order.reserve(total);
-    // sequence string -> position in `order`: one open-addressing table of 32-bit slots (a node-based std::unordered_map
-    // spent 0.18 s on its 10^6 allocations)
-    size_t cap = 16;
-    while (cap < 2 * total + 2) cap <<= 1;
-    std::vector<uint32_t> table(cap, 0xFFFFFFFFu);
     const std::hash<std::string_view> hasher;
-    size_t seen = 0;
-    for (auto &v : parsed)
-        for (Record &r : v) {
-            seen++;
-            if (r.seq.empty() && seen != total) continue;   // :168-172 adds a sequence only if it is not empty; :193-195 adds the last one as it is
-            size_t at = hasher(std::string_view(r.seq)) & (cap - 1);
-            while (table[at] != 0xFFFFFFFFu && order[table[at]].seq != r.seq) at = (at + 1) & (cap - 1);
-            if (table[at] == 0xFFFFFFFFu) {
-                table[at] = (uint32_t)order.size();
-                order.push_back(Entry{std::move(r.seq), {{std::move(r.label), r.count}}});
-            } else {
-                auto &lm = order[table[at]].labels;
-                bool found = false;
-                for (auto &e : lm) if (e.first == r.label) { e.second += r.count; found = true; break; }
-                if (!found) lm.push_back({r.label, r.count});
-            }
-        }
+    std::vector<uint64_t> hashes(total);
+    {
+        std::vector<std::thread> pool;
+        for (size_t pc = 0; pc < pieces; pc++)
+            pool.emplace_back([&, pc]() {
+                for (size_t k = 0; k < parsed[pc].size(); k++) hashes[piece_base[pc] + k] = hasher(std::string_view(parsed[pc][k].seq));
+            });
+        for (std::thread &th : pool) th.join();
+    }
+    std::vector<uint64_t> first_at(total, ~0ull);   // thread << 32 | entry, at the record position of a first occurrence
+    std::vector<std::vector<Entry>> owned(T);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < T; t++)
+            pool.emplace_back([&, t]() {
+                std::vector<Entry> &mine = owned[t];
+                size_t share = 0;
+                for (uint64_t h : hashes) share += h % T == t;
+                mine.reserve(share);
+                size_t cap = 16;
+                while (cap < 2 * share + 2) cap <<= 1;
+                std::vector<uint32_t> table(cap, 0xFFFFFFFFu);
+                std::vector<std::pair<size_t, uint32_t>> firsts;         // (record position, entry)
+                for (size_t pc = 0; pc < pieces; pc++)
+                    for (size_t k = 0; k < parsed[pc].size(); k++) {
+                        const size_t g = piece_base[pc] + k;
+                        const uint64_t h = hashes[g];
+                        if (h % T != t) continue;
+                        Record &r = parsed[pc][k];
+                        if (r.seq.empty() && g + 1 != total) continue;   // :168-172 adds a sequence only if it is not empty; :193-195 adds the last one as it is
+                        size_t at = (size_t)(h / T) & (cap - 1);
+                        while (table[at] != 0xFFFFFFFFu && mine[table[at]].seq != r.seq) at = (at + 1) & (cap - 1);
+                        if (table[at] == 0xFFFFFFFFu) {
+                            table[at] = (uint32_t)mine.size();
+                            firsts.push_back({g, (uint32_t)mine.size()});
+                            mine.push_back(Entry{std::move(r.seq), {{std::move(r.label), r.count}}});
+                        } else {
+                            auto &lm = mine[table[at]].labels;
+                            bool found = false;
+                            for (auto &e : lm) if (e.first == r.label) { e.second += r.count; found = true; break; }
+                            if (!found) lm.push_back({r.label, r.count});
+                        }
+                    }
+                for (auto &f : firsts) first_at[f.first] = (uint64_t)t << 32 | f.second;
+            });
+        for (std::thread &th : pool) th.join();
+    }
+    std::vector<Entry *> order;
+    order.reserve(total);
+    for (uint64_t f : first_at) if (f != ~0ull) order.push_back(&owned[f >> 32][(uint32_t)f]);
     loaderLap("records merged");
     std::vector<UniqueSequencePtr> result(order.size());
     parallelRanges(order.size(), T, [&](unsigned, size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; k++) result[k] = std::make_shared<UniqueSequence>(order[k].seq, std::move(order[k].labels));
+        for (size_t k = lo; k < hi; k++) result[k] = std::make_shared<UniqueSequence>(order[k]->seq, std::move(order[k]->labels));
     });
     loaderLap("objects built");
     return result;

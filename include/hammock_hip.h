@@ -260,6 +260,13 @@ typedef struct {
  * and id order, :96-113 pushes it again): the reference then works with a stale Cluster object and throws
  * NoSuchElementException or returns a list in which a sequence belongs to two clusters -- there is no cluster_id[] for
  * that (hmk_last_error names the cluster; four 6-mers suffice, tests/test_oracle.py). */
+/* Optional.  Sizes the context's grow-only device and pinned buffers for a first hmk_greedy_cluster / hmk_clinkage_cluster
+ * call on n_sequences sequences (edge buffer at the first guess of 0.3 % of the pair space, adjacency, CSR and second-loop
+ * scratch: 24 GB at 10^6), so that a host which knows the sequence count early -- hammock-hip after it has read its input --
+ * can have the allocations done on another thread while it is still sorting and packing the sequences.  Calls on a context
+ * are serialised; a later call that needs more grows the buffers as usual.  HMK_OK on a host-only context (nothing to do). */
+int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences);
+
 /* Which java.util.HashSet iteration order hmk_clinkage_cluster / hmk_clinkage_from_edges emulate for
  * `activeClusters.iterator().next()` (ClinkageSequenceClusterer.java:70, the arbitrary start of every chain) and for the
  * returned list (:118-123).  version 8 (default): Java 8 and later; 7: JDK 7u6 ... 7u80 (the reference is a Java 1.7
