@@ -258,9 +258,13 @@ k_lower_offsets(const unsigned long long *__restrict__ bucket_cnt, uint32_t nb, 
 }
 
 // records: row m << 32 | the packed entry (x << 8 | score - base) of m's lower section
+// UPPER: the same pass over the edges also writes the entries of the UPPER sections (row x = the smaller end) straight into the
+// adjacency, as k_edge_scatter<.., false> does -- one read of the edge list less (10 GB at 10^6).
+template <bool UPPER>
 __global__ void __launch_bounds__(1024)
 k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, int base, const unsigned long long *__restrict__ bucket_off,
-                  unsigned long long *__restrict__ bucket_fill, uint64_t *__restrict__ recs) {
+                  unsigned long long *__restrict__ bucket_fill, uint64_t *__restrict__ recs, const uint64_t *__restrict__ start,
+                  uint32_t *__restrict__ cursor, NbrPacked *__restrict__ adj) {
     __shared__ uint32_t hist[LB_MAX_BUCKETS];
     __shared__ uint32_t first[LB_MAX_BUCKETS];   // where this chunk's records of a bucket start, relative to bucket_off (< 2^32: a bucket holds < 2^12 rows x 2^20)
     uint32_t g = blockIdx.x;                     // chunk index over the concatenated segments
@@ -295,11 +299,20 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint64_t e = ev[q];
-                    if (!lower_record_ok(e, n)) continue;
+                    const bool ok = lower_record_ok(e, n);
                     const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)), m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
+                    const uint32_t rel = (uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu;
+                    if (UPPER) {   // (whole waves: wave_groups needs all 64 lanes; a wave's edges come from a handful of rows)
+                        const WaveGroup g = wave_groups(x, ok);   // one atomic per distinct x of the wave
+                        uint32_t basex = 0;
+                        if (ok && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
+                        basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
+                        if (ok) adj[start[x] + basex + g.rank] = NbrPacked{(m << 8) | rel};
+                    }
+                    if (!ok) continue;
                     const uint32_t b = m >> shift;
                     const uint32_t at = first[b] + atomicAdd(&hist[b], 1u);
-                    recs[bucket_off[b] + at] = ((uint64_t)m << 32) | (uint64_t)((x << 8) | ((uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu));
+                    recs[bucket_off[b] + at] = ((uint64_t)m << 32) | (uint64_t)((x << 8) | rel);
                 }
             }
             __syncthreads();
@@ -1203,8 +1216,16 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
     hipLaunchKernelGGL(k_lower_count, dim3(512), dim3(1024), 0, s, segs, shift, nb, n, cnt);
     hipLaunchKernelGGL(k_lower_offsets, dim3(1), dim3(1024), 0, s, cnt, nb, off, fill);
     // one 1,024-thread workgroup per CU (10^6 sequences: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms)
-    hipLaunchKernelGGL(k_lower_partition, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, n, base, off, fill, recs);
-    hipLaunchKernelGGL((k_edge_scatter<NbrPacked, false>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj, 1, base, n);
+    // the upper sections in the same pass over the edges (HMK_CSR_FUSED_UPPER=0: their own kernel, as in round 2)
+    const char *fu = getenv("HMK_CSR_FUSED_UPPER");
+    if (fu == nullptr || atoi(fu) != 0) {
+        hipLaunchKernelGGL(k_lower_partition<true>, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, n, base, off, fill, recs, start,
+                           cursor, (NbrPacked *)adj);
+    } else {
+        hipLaunchKernelGGL(k_lower_partition<false>, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, n, base, off, fill, recs, start,
+                           cursor, (NbrPacked *)adj);
+        hipLaunchKernelGGL((k_edge_scatter<NbrPacked, false>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj, 1, base, n);
+    }
     const bool sorted_place = getenv("HMK_CSR_PLACE_UNSORTED") == nullptr;   // (the tests run both)
     if (sorted_place && (1u << shift) <= LP_ROWS)
         hipLaunchKernelGGL(k_lower_place_sorted, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
