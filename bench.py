@@ -175,9 +175,10 @@ def other_configs(M, dev, stream):
     shifted("2: 1e4 x 12, BLOSUM62, X 3, p 0, thr 20", 10000, 12, 12, 3, 0, 20, 0, 1, 10, 5)
     shifted("4a: 1e5 x 7..20, ShiftedScorer X 3, p -1, thr 23", 100000, 7, 20, 3, -1, 23, 0, 1, 8, 6)
     shifted("5, one of 8 shards: 1e6 x 12, BLOSUM62, X 3, p 0, thr 20", 1000000, 12, 12, 3, 0, 20, 0, 8, 3, 2)
-    # 4b: LocalAlignmentScorer, all ordered pairs of the 4a set.  The packed tagged-max kernel issues ~7.5 VALU instructions per
-    # DP cell and lane pair (two column sequences per lane; PMC: profiles/round3_neighbors_local_pmc.json), and a wave64
-    # integer VALU instruction holds its SIMD for 4 cycles: peak = 256 CU x 4 SIMD x 2.4 GHz / 4 x 64 lanes.
+    # 4b: LocalAlignmentScorer, all ordered pairs of the 4a set.  The packed tagged-max kernel's VALU instruction count per DP
+    # cell comes from the PMC pass of this build (profiles/round3_neighbors_local_pmc.json: SQ_INSTS_VALU per 64 cells =
+    # lane-instructions per cell; a lane carries two column sequences), and a wave64 integer VALU instruction holds its SIMD for
+    # 4 cycles: peak = 256 CU x 4 SIMD x 2.4 GHz / 4 x 64 lanes.
     res, off = synth_peptides(1, 100000, 7, 20)
     ctx = hammock_amd.Context(M, device=dev.index)
     ctx.set_sequences(residues=res, offsets=off)
@@ -187,16 +188,23 @@ def other_configs(M, dev, stream):
         ms.append(float(st.kernel_ms))
     lens = np.diff(off.astype(np.int64)).astype(np.float64)
     cells = float(lens.sum()) ** 2 - float((lens * lens).sum())      # sum over ordered pairs i != j of len_i * len_j
-    valu_per_cell = 7.5 / 2          # per sequence pair: the instruction serves two column sequences
+    valu_per_cell = 8.66             # measured (see above); the file's value if it is there
+    try:
+        with open(os.path.join(ROOT, "profiles", "round3_neighbors_local_pmc.json")) as fh:
+            valu_per_cell = float(json.load(fh)["valu_wave_instructions_per_64_cells"])
+    except (OSError, KeyError, ValueError):
+        pass
     peak_lane_ops = 256 * 4 * 2.4e9 / 4 * 64
     med = float(np.median(ms[1:]))
     out.append({"config": "4b: 1e5 x 7..20, LocalAlignmentScorer open -5, extend -1, all ordered pairs, thr 28", "kernel_ms": med,
                 "pairs": int(st.pairs_scored), "pairs_per_s": int(st.pairs_scored) / (med * 1e-3), "edges": int(len(edges)),
                 "dp_cells_per_s": cells / (med * 1e-3),
                 "roofline": {"bound": "valu-issue", "frac": cells * valu_per_cell / (med * 1e-3) / peak_lane_ops,
-                             "valu_instructions_per_cell_and_pair": valu_per_cell,
-                             "definition": "DP cells x 3.75 VALU lane-instructions per cell (7.5 per cell of a lane that carries two column "
-                                           "sequences) over the kernel time, against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz of integer VALU issue"}})
+                             "valu_lane_instructions_per_cell": valu_per_cell,
+                             "definition": "DP cells x VALU lane-instructions per cell (SQ_INSTS_VALU per 64 cells of the PMC pass in "
+                                           "profiles/round3_neighbors_local_pmc.json) over the kernel time, against 256 CU x 4 SIMD x 16 lanes/clk "
+                                           "x 2.4 GHz of integer VALU issue; ~1.0 = the kernel sits on the VALU-issue roofline (its measured VALU busy "
+                                           "fraction is 1.04 of the nominal 2.4 GHz cycles)"}})
     ctx.close()
     return out
 
