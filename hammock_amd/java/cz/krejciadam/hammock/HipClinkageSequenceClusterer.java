@@ -38,6 +38,7 @@ public class HipClinkageSequenceClusterer implements SequenceClusterer {
         int n = sequences.size();
         synchronized (sequenceScorer) {
             HipShiftedScorer.upload(sequenceScorer.ctx, sequences);
+            HipNative.setJavaHashset(sequenceScorer.ctx, hashSetOrderOfThisJvm());
             int[] clusterId = new int[Math.max(n, 1)];
             int[] resultOrder = new int[Math.max(n, 1)];
             int[] memberRank = new int[Math.max(n, 1)];
@@ -67,5 +68,39 @@ public class HipClinkageSequenceClusterer implements SequenceClusterer {
             }
             return result;
         }
+    }
+
+    /**
+     * The java.util.HashSet iteration order ClinkageSequenceClusterer would see on the JVM this runs in
+     * (activeClusters.iterator().next(), ClinkageSequenceClusterer.java:70): 8 for Java 8 and later,
+     * 7 for 7u6 .. 7u80, 6 for anything older. Overridden by -Dhammock.hip.java_hashset=6|7|8.
+     */
+    static int hashSetOrderOfThisJvm() {
+        String forced = System.getProperty("hammock.hip.java_hashset");
+        if (forced != null) {
+            return Integer.parseInt(forced.trim());
+        }
+        String v = System.getProperty("java.version", "1.8.0");
+        if (!v.startsWith("1.")) {
+            return 8;                       // 9, 10, 11 ... : the Java 8 HashMap
+        }
+        if (v.startsWith("1.8")) {
+            return 8;
+        }
+        if (v.startsWith("1.7")) {
+            int us = v.indexOf('_');
+            int update = 0;
+            if (us >= 0) {
+                int end = us + 1;
+                while (end < v.length() && Character.isDigit(v.charAt(end))) {
+                    end++;
+                }
+                if (end > us + 1) {
+                    update = Integer.parseInt(v.substring(us + 1, end));
+                }
+            }
+            return update >= 6 ? 7 : 6;
+        }
+        return 6;
     }
 }

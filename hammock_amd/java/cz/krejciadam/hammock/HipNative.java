@@ -30,6 +30,15 @@ final class HipNative {
     /** hmk_set_sequences: residues concatenated, offsets[n + 1], sizes[n] = UniqueSequence.size(). */
     static native void setSequences(long ctx, byte[] residues, int[] offsets, int[] sizes);
 
+    /** hmk_reserve: sizes the result buffers for n sequences ahead of the first cluster() call (optional; e.g. while the input is read). */
+    static native void reserve(long ctx, int nSequences);
+
+    /**
+     * hmk_set_java_hashset: which java.util.HashSet iteration order clinkageCluster emulates (8 = Java 8 and later,
+     * 7 = JDK 7u6 .. 7u80, 6 = JDK 6 and JDK 7 before 7u6). HipClinkageSequenceClusterer passes the version of the running JVM.
+     */
+    static native void setJavaHashset(long ctx, int version);
+
     /** hmk_score_with_shift for one pair (i, j): returns {score, shift}. Throws DataException ("Shift too big"). */
     static native int[] scoreWithShift(long ctx, int i, int j, int maxShift, int shiftPenalty) throws DataException;
 

@@ -56,6 +56,18 @@ JNIEXPORT void JNICALL Java_cz_krejciadam_hammock_HipNative_destroy(JNIEnv *env,
     hmk_destroy((hmk_ctx *)(intptr_t)ctx);
 }
 
+JNIEXPORT void JNICALL Java_cz_krejciadam_hammock_HipNative_reserve(JNIEnv *env, jclass c, jlong h, jint n) {
+    (void)c;
+    int st = hmk_reserve((hmk_ctx *)(intptr_t)h, (uint32_t)n);
+    if (st) throw_for(env, (hmk_ctx *)(intptr_t)h, st);
+}
+
+JNIEXPORT void JNICALL Java_cz_krejciadam_hammock_HipNative_setJavaHashset(JNIEnv *env, jclass c, jlong h, jint version) {
+    (void)c;
+    int st = hmk_set_java_hashset((hmk_ctx *)(intptr_t)h, (int)version);
+    if (st) throw_for(env, (hmk_ctx *)(intptr_t)h, st);
+}
+
 JNIEXPORT void JNICALL Java_cz_krejciadam_hammock_HipNative_setSequences(JNIEnv *env, jclass c, jlong h, jbyteArray residues,
                                                                          jintArray offsets, jintArray sizes) {
     (void)c;
