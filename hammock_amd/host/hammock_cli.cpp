@@ -143,17 +143,8 @@ std::string labelsToString(bool have, const std::vector<std::string> &labels) { 
     return s + "]";
 }
 
-double meanSequenceLength(const std::vector<UniqueSequencePtr> &seqs) {  // Hammock.java:1554-1563
-    long long sum = 0;
-    for (auto &s : seqs) sum += (long long)s->getSequence().size();
-    return (double)sum / (double)seqs.size();
-}
-
-int checkMaxShift(const std::vector<UniqueSequencePtr> &seqs, int maxShift) {  // Hammock.java:1421-1427
-    int minLength = INT_MAX;
-    for (auto &s : seqs) minLength = std::min(minLength, (int)s->getSequence().size());
-    return std::min(maxShift, minLength - 1);
-}
+// Hammock.java:1421-1427 (the list's shortest length comes from the one summary pass; the mean length, :1554-1563, too)
+int checkMaxShift(const SequenceListSummary &summary, int maxShift) { return std::min(maxShift, summary.minLength - 1); }
 
 // greedy mode (Hammock.java:217-234, runGreedyClustering :392-437) and clinkage mode (:236-253, runClinkageClustering
 // :449-489): the two share everything but the clusterer, the ordering step and a few log lines
@@ -237,9 +228,8 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         else throw HammockException("Error, this should have been checked.");  // "seq", :759-761
         cliLap("input loaded");
         logger.logAndStderr(std::to_string(sequences.size()) + " unique sequences loaded.");
-        long long total = 0;
-        for (auto &s : sequences) total += s->size();
-        logger.logAndStderr(std::to_string(total) + " total sequences loaded.");
+        SequenceListSummary summary = summariseSequences(sequences);
+        logger.logAndStderr(std::to_string(summary.total) + " total sequences loaded.");
         if (o.haveLabels) {  // filterSequencesForLabels, :1661-1675
             std::vector<UniqueSequencePtr> kept;
             for (auto &s : sequences) {
@@ -252,16 +242,11 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
                 if (!lm.empty()) kept.push_back(std::make_shared<UniqueSequence>(s->getSequenceString(), lm));
             }
             sequences = kept;
+            summary = summariseSequences(sequences);
         }
         logger.logAndStderr(std::to_string(sequences.size()) + " unique sequences after non-specified labels filtered out");
-        total = 0;
-        for (auto &s : sequences) total += s->size();
-        logger.logAndStderr(std::to_string(total) + " total sequences after non-specified labels fileterd out");
-        int minLength = INT_MAX, maxLength = INT_MIN;
-        for (auto &s : sequences) {
-            maxLength = std::max(maxLength, (int)s->getSequence().size());
-            minLength = std::min(minLength, (int)s->getSequence().size());
-        }
+        logger.logAndStderr(std::to_string(summary.total) + " total sequences after non-specified labels fileterd out");
+        const int minLength = summary.minLength, maxLength = summary.maxLength;
         logger.logAndStderr("Shortest sequence: " + std::to_string(minLength) + " AA. Longest sequence: " + std::to_string(maxLength) + " AA.");
         if (sequences.empty()) throw FileFormatException("Error. No sequences (with specified labels) to cluster.");
         // the sequence count is known: the context's buffers (24 GB at 10^6) are sized on another thread while this one goes on
@@ -277,10 +262,10 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         if (!o.haveLabels) labels = FileIOManager::getSortedLabels(sequences);                 // :796-798
         const std::vector<UniqueSequencePtr> initialSequences(sequences);                       // :800-801
         if (!o.haveMaxShift) {                                                                  // :803-811
-            o.maxShift = checkMaxShift(sequences, (int)javaRound(meanSequenceLength(sequences) / 4));
+            o.maxShift = checkMaxShift(summary, (int)javaRound(summary.meanLength() / 4));
             logger.logAndStderr("Max shift not set. Setting automatically to: " + std::to_string(o.maxShift));
         } else {
-            const int correct = checkMaxShift(sequences, o.maxShift);
+            const int correct = checkMaxShift(summary, o.maxShift);
             if (o.maxShift != correct) {
                 o.maxShift = correct;
                 logger.logAndStderr("Setting max shift to " + std::to_string(correct) +
@@ -292,7 +277,7 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         FileIOManager::saveInputStatistics(sequences, labels, inputStatistics);                 // :814-816
         cliLap("input statistics written");
         if (!o.haveThreshold) {                                                                 // :394-397 / :452-455
-            o.sequenceClusteringThreshold = (int)javaRound(meanSequenceLength(sequences) * 1.7);
+            o.sequenceClusteringThreshold = (int)javaRound(summary.meanLength() * 1.7);
             logger.logAndStderr(std::string(clinkage ? "Clinkage" : "Greedy") + " clustering threshold not set. Setting automatically to: " +
                                 std::to_string(o.sequenceClusteringThreshold));
         }
@@ -347,6 +332,7 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         // Everything is on disk (the writers and the logger close their files).  Tearing down 10^6 sequence and cluster
         // objects one by one and handing 30 GB of device buffers back costs 0.3-0.5 s that change nothing: leave at once,
         // the driver reclaims the device memory with the process.  (HMK_CLI_TEARDOWN=1: the ordinary way out.)
+        cliLap("log closed, leaving");
         if (std::getenv("HMK_CLI_TEARDOWN") == nullptr) {
             std::cout.flush();
             std::cerr.flush();
@@ -395,7 +381,38 @@ int ioSelftest(const std::vector<std::string> &args) {
         for (auto &s : seqs) std::cout << s->getSequenceString() << "\t" << FileIOManager::sequenceLine(*s, labels) << "\n";
         return 0;
     }
-    std::cerr << "usage: hammock-hip io-selftest matrix <file> | sequences <fasta|tab> <file> <order> [seed]\n";
+    if (args.size() >= 8 && args[1] == "writers") {  // writers <fasta|tab> <file> <order> <seed> <clusters.tsv> <out dir>
+        // clusters.tsv: one cluster per line, "id<TAB>SEQ,SEQ,..." in list order; the result files are written twice, by the
+        // reference's three calls in a row (<out dir>/serial) and side by side (<out dir>/side)
+        auto seqs = args[2] == "tab" ? FileIOManager::loadUniqueSequencesFromTable(args[3])
+                                     : FileIOManager::loadUniqueSequencesFromFasta(args[3]);
+        const std::vector<std::string> labels = FileIOManager::getSortedLabels(seqs);
+        const std::vector<UniqueSequencePtr> initial(seqs);
+        FileIOManager::saveInputStatistics(seqs, labels, args[7] + "/input_statistics.tsv");
+        sortSequences(seqs, args[4], javaIntegerDecode(args[5]), labels);
+        std::unordered_map<std::string, UniqueSequencePtr> byString;
+        for (auto &q : seqs) byString[q->getSequenceString()] = q;
+        auto build = [&]() {
+            std::vector<ClusterPtr> clusters;
+            for (const std::string &line : FileIOManager::readLines(args[6])) {
+                const std::vector<std::string> f = FileIOManager::splitChar(line, '\t', true);
+                if (f.size() < 2) continue;
+                std::vector<UniqueSequencePtr> members;
+                for (const std::string &m : FileIOManager::splitChar(f[1], ',', true)) members.push_back(byString.at(m));
+                clusters.push_back(std::make_shared<Cluster>(members, javaIntegerDecode(f[0])));
+            }
+            return clusters;
+        };
+        std::vector<ClusterPtr> a = build(), b = build();
+        FileIOManager::saveClusterSequencesToCsv(a, args[7] + "/serial/initial_clusters_sequences.tsv", labels);
+        FileIOManager::saveClusterSequencesToCsvOrdered(a, args[7] + "/serial/initial_clusters_sequences_original_order.tsv", labels, initial);
+        FileIOManager::SaveClustersToCsv(a, args[7] + "/serial/initial_clusters.tsv", labels);
+        FileIOManager::saveInitialClusters(b, args[7] + "/side/initial_clusters_sequences.tsv", args[7] + "/side/initial_clusters_sequences_original_order.tsv",
+                                           args[7] + "/side/initial_clusters.tsv", labels, initial);
+        return 0;
+    }
+    std::cerr << "usage: hammock-hip io-selftest matrix <file> | sequences <fasta|tab> <file> <order> [seed] | "
+                 "writers <fasta|tab> <file> <order> <seed> <clusters.tsv> <out dir>\n";
     return 2;
 }
 

@@ -21,7 +21,10 @@
 
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
+#include <charconv>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -49,7 +52,7 @@ namespace hammock {
 inline unsigned hostThreads() {
     if (const char *v = std::getenv("HMK_HOST_THREADS")) return (unsigned)std::max(1, std::atoi(v));
     const unsigned hw = std::thread::hardware_concurrency();
-    return std::max(1u, std::min(8u, hw ? hw : 1u));
+    return std::max(1u, std::min(16u, hw ? hw : 1u));
 }
 // f(t, lo, hi) over [0, n) cut into one contiguous range per thread; the first exception is rethrown
 template <class F>
@@ -65,7 +68,28 @@ inline void parallelRanges(size_t n, unsigned threads, F f) {
     for (std::thread &th : pool) th.join();
     for (auto &e : failed) if (e) std::rethrow_exception(e);
 }
-
+// f(lo, hi) over [0, n) in chunks of `chunk` items handed out by an atomic cursor (for work whose cost per item is uneven:
+// clusters of 1 .. 10^4 members); the first exception is rethrown
+template <class F>
+inline void parallelChunks(size_t n, size_t chunk, unsigned threads, F f) {
+    threads = (unsigned)std::max<size_t>(1, std::min<size_t>(threads, (n + chunk - 1) / std::max<size_t>(chunk, 1)));
+    if (threads <= 1) { if (n) f((size_t)0, n); return; }
+    std::atomic<size_t> cursor{0};
+    std::vector<std::thread> pool;
+    std::vector<std::exception_ptr> failed(threads);
+    for (unsigned t = 0; t < threads; t++)
+        pool.emplace_back([&, t]() {
+            try {
+                for (;;) {
+                    const size_t lo = cursor.fetch_add(chunk);
+                    if (lo >= n) break;
+                    f(lo, std::min(n, lo + chunk));
+                }
+            } catch (...) { failed[t] = std::current_exception(); }
+        });
+    for (std::thread &th : pool) th.join();
+    for (auto &e : failed) if (e) std::rethrow_exception(e);
+}
 
 // ---- exceptions (HammockException.java and subclasses) ---------------------------------
 struct HammockException : std::runtime_error { using std::runtime_error::runtime_error; };
@@ -248,20 +272,53 @@ inline int sizeAlphabeticCompare(const UniqueSequence &a, const UniqueSequence &
 // comparison without touching the sequence objects (10^6 sequences: 0.47 s -> 0.2 s)
 inline void sortBySizeThenStringDescending(std::vector<UniqueSequencePtr> &seqs) {
     struct Key { int size; uint64_t prefix; uint32_t index; };
-    std::vector<Key> keys(seqs.size());
-    for (size_t k = 0; k < seqs.size(); k++) {
-        const std::string &s = seqs[k]->getSequenceString();
-        uint64_t prefix = 0;
-        for (size_t b = 0; b < 8; b++) prefix = (prefix << 8) | (b < s.size() ? (unsigned char)s[b] : 0u);
-        keys[k] = Key{seqs[k]->size(), prefix, (uint32_t)k};
-    }
-    std::stable_sort(keys.begin(), keys.end(), [&](const Key &a, const Key &b) {
+    const size_t n = seqs.size();
+    std::vector<Key> keys(n);
+    const unsigned T = hostThreads();
+    parallelRanges(n, T, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) {
+            const std::string &s = seqs[k]->getSequenceString();
+            uint64_t prefix = 0;
+            for (size_t b = 0; b < 8; b++) prefix = (prefix << 8) | (b < s.size() ? (unsigned char)s[b] : 0u);
+            keys[k] = Key{seqs[k]->size(), prefix, (uint32_t)k};
+        }
+    });
+    auto before = [&](const Key &a, const Key &b) {
         if (a.size != b.size) return a.size > b.size;
         if (a.prefix != b.prefix) return a.prefix > b.prefix;      // (a zero byte pads a string shorter than 8: it sorts first, as in compareTo)
         return javaStringCompare(seqs[b.index]->getSequenceString(), seqs[a.index]->getSequenceString()) < 0;
+    };
+    // a stable merge sort: contiguous runs sorted on their own threads, then merged pairwise (std::merge takes from the left
+    // run on ties, so the result is the one std::stable_sort of the whole list gives)
+    size_t runs = 1;
+    while (runs < T && n / (2 * runs) >= 16384) runs *= 2;
+    std::vector<size_t> cut(runs + 1);
+    for (size_t r = 0; r <= runs; r++) cut[r] = n * r / runs;
+    {
+        std::vector<std::thread> pool;
+        for (size_t r = 1; r < runs; r++) pool.emplace_back([&, r] { std::stable_sort(keys.begin() + (long)cut[r], keys.begin() + (long)cut[r + 1], before); });
+        std::stable_sort(keys.begin(), keys.begin() + (long)cut[1], before);
+        for (std::thread &th : pool) th.join();
+    }
+    std::vector<Key> other(runs > 1 ? n : 0);
+    std::vector<Key> *from = &keys, *to = &other;
+    for (size_t width = 1; width < runs; width *= 2) {
+        std::vector<std::thread> pool;
+        for (size_t r = 0; r < runs; r += 2 * width) {
+            auto job = [&, r] {
+                std::merge(from->begin() + (long)cut[r], from->begin() + (long)cut[r + width], from->begin() + (long)cut[r + width],
+                           from->begin() + (long)cut[r + 2 * width], to->begin() + (long)cut[r], before);
+            };
+            if (r + 2 * width < runs) pool.emplace_back(job); else job();
+        }
+        for (std::thread &th : pool) th.join();
+        std::swap(from, to);
+    }
+    const std::vector<Key> &order = *from;
+    std::vector<UniqueSequencePtr> sorted(n);
+    parallelRanges(n, T, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) sorted[k] = std::move(seqs[order[k].index]);
     });
-    std::vector<UniqueSequencePtr> sorted(seqs.size());
-    for (size_t k = 0; k < seqs.size(); k++) sorted[k] = std::move(seqs[keys[k].index]);
     seqs.swap(sorted);
 }
 
@@ -561,6 +618,40 @@ public:
 };
 
 // ---- FileIOManager.java (greedy-path subset) ----------------------------------------------------------------------
+// what the driver asks of the whole list before clustering (Hammock.java:763-785 sizes and lengths, :1421-1427 the shortest,
+// :1554-1563 the mean length), gathered in one pass on several threads instead of six walks over 10^6 scattered objects
+struct SequenceListSummary {
+    long long total = 0;        // sum of UniqueSequence.size()
+    long long lengthSum = 0;    // sum of the sequences' lengths
+    int minLength = INT_MAX, maxLength = INT_MIN;
+    size_t count = 0;
+    double meanLength() const { return (double)lengthSum / (double)count; }
+};
+inline SequenceListSummary summariseSequences(const std::vector<UniqueSequencePtr> &sequences) {
+    const unsigned T = hostThreads();
+    std::vector<SequenceListSummary> parts(T);
+    parallelRanges(sequences.size(), T, [&](unsigned t, size_t lo, size_t hi) {
+        SequenceListSummary p;
+        for (size_t q = lo; q < hi; q++) {
+            const int len = (int)sequences[q]->getSequence().size();
+            p.total += sequences[q]->size();
+            p.lengthSum += len;
+            p.minLength = std::min(p.minLength, len);
+            p.maxLength = std::max(p.maxLength, len);
+        }
+        parts[t] = p;
+    });
+    SequenceListSummary all;
+    all.count = sequences.size();
+    for (const SequenceListSummary &p : parts) {
+        all.total += p.total;
+        all.lengthSum += p.lengthSum;
+        all.minLength = std::min(all.minLength, p.minLength);
+        all.maxLength = std::max(all.maxLength, p.maxLength);
+    }
+    return all;
+}
+
 namespace FileIOManager {
 
 // String.split("\\s+"): a leading empty token is kept, trailing empty tokens are dropped
@@ -867,16 +958,38 @@ inline std::vector<UniqueSequencePtr> loadUniqueSequencesFromTable(const std::st
 // Hammock.getSortedLabels, Hammock.java:1586-1605 with ValueComparator (FileIOManager.java:1464-1480):
 // total count descending; among equal totals the label put LATER (in HashMap iteration order) comes first.
 inline std::vector<std::string> getSortedLabels(const std::vector<UniqueSequencePtr> &sequences) {
+    // The reference walks the list once: every sequence's labels in its HashMap's iteration order, a label's first sight
+    // fixing its place in `insertion`, its counts summed.  Here every thread walks one contiguous run of the list the same way;
+    // joining the runs in list order (a label keeps the place of its first sight) gives the same `insertion` and the same sums.
+    struct Part { std::vector<std::string> insertion; std::unordered_map<std::string, long long> total; };
+    const unsigned T = hostThreads();
+    std::vector<Part> parts(T);
+    parallelRanges(sequences.size(), T, [&](unsigned t, size_t lo, size_t hi) {
+        Part &p = parts[t];
+        std::vector<std::string> keys;
+        for (size_t q = lo; q < hi; q++) {
+            const auto &lm = sequences[q]->getLabelsMap();
+            if (lm.size() == 1) {   // one label: its HashMap order is itself
+                auto it = p.total.find(lm[0].first);
+                if (it == p.total.end()) { p.insertion.push_back(lm[0].first); p.total.emplace(lm[0].first, lm[0].second); }
+                else it->second += lm[0].second;
+                continue;
+            }
+            keys.clear();
+            for (auto &e : lm) keys.push_back(e.first);
+            for (const std::string &k : javaHashMapOrder(keys)) {
+                if (!p.total.count(k)) p.insertion.push_back(k);
+                p.total[k] += sequences[q]->labelCount(k);
+            }
+        }
+    });
     std::vector<std::string> insertion;
     std::unordered_map<std::string, long long> total;
-    for (auto &s : sequences) {
-        std::vector<std::string> keys;
-        for (auto &e : s->getLabelsMap()) keys.push_back(e.first);
-        for (const std::string &k : javaHashMapOrder(keys)) {
+    for (const Part &p : parts)
+        for (const std::string &k : p.insertion) {
             if (!total.count(k)) insertion.push_back(k);
-            total[k] += s->labelCount(k);
+            total[k] += p.total.at(k);
         }
-    }
     std::vector<std::string> result;
     for (const std::string &k : javaHashMapOrder(insertion)) {
         size_t pos = 0;
@@ -894,69 +1007,126 @@ inline std::string sequenceLine(const UniqueSequence &seq, const std::vector<std
 
 // The same columns for many sequences: label -> column once, then every sequence fills its (few) labels' columns --
 // labelCount() is a linear search with string compares, 225 of them per line with 15 labels.
+// out += std::to_string(v) without the temporary string
+inline void appendNumber(std::string &out, long long v) {
+    char buf[24];
+    const auto r = std::to_chars(buf, buf + sizeof buf, v);
+    out.append(buf, (size_t)(r.ptr - buf));
+}
+
 class LabelColumns {
     std::unordered_map<std::string, size_t> column_;
+    std::vector<std::string> names_;
     std::vector<size_t> first_;   // column k prints the count of labels[k]'s FIRST column (a label may be listed twice)
     size_t n_;
+    // label -> its first column, or n_: a handful of labels is the rule, and comparing against each beats hashing the string
+    size_t columnOf(const std::string &label) const {
+        if (n_ <= 8) {
+            for (size_t k = 0; k < n_; k++) if (names_[k] == label) return k;
+            return n_;
+        }
+        auto it = column_.find(label);
+        return it == column_.end() ? n_ : it->second;
+    }
 public:
-    explicit LabelColumns(const std::vector<std::string> &labels) : n_(labels.size()) {
+    explicit LabelColumns(const std::vector<std::string> &labels) : names_(labels), n_(labels.size()) {
         for (size_t k = 0; k < labels.size(); k++) first_.push_back(column_.emplace(labels[k], k).first->second);
     }
     size_t size() const { return n_; }
     // adds the sequence's counts to `sums` (n_ entries); labels outside the list are ignored
     void add(const UniqueSequence &seq, std::vector<long long> &sums) const {
         for (auto &e : seq.getLabelsMap()) {
-            auto it = column_.find(e.first);
-            if (it != column_.end()) sums[it->second] += e.second;
+            const size_t c = columnOf(e.first);
+            if (c < n_) sums[c] += e.second;
         }
     }
     // appends "<size>\t<count of label 0>\t..." (sequenceLine) to `out`
     void appendLine(const UniqueSequence &seq, const std::vector<std::string> &, std::vector<long long> &scratch, std::string &out) const {
         std::fill(scratch.begin(), scratch.end(), 0);
         add(seq, scratch);
-        out += std::to_string(seq.size());
+        appendNumber(out, seq.size());
         for (size_t k = 0; k < n_; k++) {
             out += CSV_SEPARATOR;
-            out += std::to_string(scratch[first_[k]]);   // a label listed twice repeats its column
+            appendNumber(out, scratch[first_[k]]);   // a label listed twice repeats its column
         }
+    }
+};
+
+// sequence -> cluster, keyed by the sequence STRING as in the reference (writeClusterSequencesToCsv builds two
+// HashMap<String, ...>, FileIOManager.java:596-607: sequence -> cluster id, and for singletons sequence-without-gaps ->
+// "alignment").  One open-addressing table over the sequence objects the clusters hold, filled on several threads (a slot is
+// claimed with one compare-and-swap of the owner pointer): with two std::unordered_map<std::string, ...> per file the two
+// callers took 9 of the 12 s of a 10^6-sequence run, with one serial table per file 2 x 0.1 s.  A sequence has no '-' (not in
+// the alphabet), so the "alignment" key of a singleton IS its string, and as long as no string occurs in two clusters "found in
+// msaMap" is "its cluster is a singleton"; a repeated string (impossible after the loaders, which merge duplicates) is
+// rebuilt serially with HashMap.put's last-one-wins and the literal msaMap.
+class SequenceClusterIndex {
+    struct Slot { std::atomic<const UniqueSequence *> owner; const Cluster *cluster; };
+    std::unique_ptr<Slot[]> table_;
+    size_t cap_ = 16;
+    bool repeated_ = false;
+    std::unordered_map<std::string_view, std::string_view> msaMap_;   // only for the impossible case
+    static size_t hashOf(std::string_view key) { return std::hash<std::string_view>()(key); }
+public:
+    explicit SequenceClusterIndex(const std::vector<ClusterPtr> &clusters) {
+        size_t n_members = 0;
+        for (auto &cl : clusters) n_members += (size_t)cl->getUniqueSize();
+        while (cap_ < 2 * n_members + 2) cap_ <<= 1;
+        table_.reset(new Slot[cap_]());
+        std::atomic<bool> repeated{false};
+        parallelChunks(clusters.size(), 512, hostThreads(), [&](size_t lo, size_t hi) {
+            for (size_t c = lo; c < hi; c++)
+                for (auto &s : clusters[c]->getSequences()) {
+                    const std::string &key = s->getSequenceString();
+                    size_t at = hashOf(key) & (cap_ - 1);
+                    for (;;) {
+                        const UniqueSequence *cur = table_[at].owner.load(std::memory_order_acquire);
+                        if (cur == nullptr && table_[at].owner.compare_exchange_strong(cur, s.get(), std::memory_order_acq_rel)) {
+                            table_[at].cluster = clusters[c].get();
+                            break;
+                        }
+                        if (cur->getSequenceString() == key) { repeated.store(true, std::memory_order_relaxed); break; }
+                        at = (at + 1) & (cap_ - 1);
+                    }
+                }
+        });
+        repeated_ = repeated.load();
+        if (repeated_) {   // the same string in two clusters (or twice in one): the last put wins, in list order
+            for (size_t k = 0; k < cap_; k++) { table_[k].owner.store(nullptr, std::memory_order_relaxed); table_[k].cluster = nullptr; }
+            for (auto &cl : clusters)
+                for (auto &s : cl->getSequences()) {
+                    const std::string &key = s->getSequenceString();
+                    size_t at = hashOf(key) & (cap_ - 1);
+                    while (table_[at].owner.load(std::memory_order_relaxed) &&
+                           table_[at].owner.load(std::memory_order_relaxed)->getSequenceString() != key) at = (at + 1) & (cap_ - 1);
+                    table_[at].owner.store(s.get(), std::memory_order_relaxed);
+                    table_[at].cluster = cl.get();
+                }
+            for (auto &cl : clusters)
+                if (cl->getUniqueSize() == 1) { const std::string &s = cl->getSequences()[0]->getSequenceString(); msaMap_[s] = s; }
+        }
+    }
+    // the cluster whose member list holds this string, or nullptr
+    const Cluster *clusterOf(std::string_view key) const {
+        size_t at = hashOf(key) & (cap_ - 1);
+        for (;;) {
+            const UniqueSequence *cur = table_[at].owner.load(std::memory_order_relaxed);
+            if (cur == nullptr) return nullptr;
+            if (cur->getSequenceString() == key) return table_[at].cluster;
+            at = (at + 1) & (cap_ - 1);
+        }
+    }
+    // msaMap.containsKey(sequence): the string is the (gap-free) alignment of a single-member cluster
+    bool isSingletonAlignment(std::string_view key, const Cluster *its) const {
+        return repeated_ ? msaMap_.find(key) != msaMap_.end() : its->getUniqueSize() == 1;
     }
 };
 
 // writeClusterSequencesToCsv, FileIOManager.java:594-638.  The `alignment` column: the reference fills
 // it from Clustal Omega output for multi-member clusters (external process, out of scope) and with the
 // bare sequence for singletons (:770-776); members of multi-member clusters get "NA" (:617-618).
-inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &sequences, const std::vector<ClusterPtr> &clusters,
+inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &sequences, const SequenceClusterIndex &index,
                                        const std::string &filePath, const std::vector<std::string> &labels) {
-    // sequence -> cluster and (singletons) sequence without gaps -> "alignment", keyed by the sequence STRING as in the
-    // reference (two HashMap<String, ...>, :596-607).  One open-addressing table over views of the strings the sequences own:
-    // with two std::unordered_map<std::string, ...> the two callers of this function took 9 of the 12 s of a 10^6-sequence run.
-    // A sequence has no '-' (not in the alphabet), so the "alignment" key of a singleton IS its string, and as long as no
-    // string occurs in two clusters "found in msaMap" is "its cluster is a singleton"; a repeated string (impossible after the
-    // loaders, which merge duplicates) switches to the two literal maps.
-    struct Slot { std::string_view key; const Cluster *cluster = nullptr; };
-    size_t n_members = 0;
-    for (auto &cl : clusters) n_members += (size_t)cl->getUniqueSize();
-    size_t cap = 16;
-    while (cap < 2 * n_members + 2) cap <<= 1;
-    std::vector<Slot> table(cap);
-    const std::hash<std::string_view> hasher;
-    auto slot_of = [&](std::string_view key) -> Slot & {
-        size_t at = hasher(key) & (cap - 1);
-        while (table[at].cluster && table[at].key != key) at = (at + 1) & (cap - 1);
-        return table[at];
-    };
-    bool repeated = false;
-    for (auto &cl : clusters)
-        for (auto &s : cl->getSequences()) {
-            Slot &sl = slot_of(s->getSequenceString());
-            repeated = repeated || sl.cluster != nullptr;
-            sl.key = s->getSequenceString();
-            sl.cluster = cl.get();               // (the last cluster that holds the string wins, as HashMap.put)
-        }
-    std::unordered_map<std::string_view, std::string_view> msaMap;   // only for the impossible case
-    if (repeated)
-        for (auto &cl : clusters)
-            if (cl->getUniqueSize() == 1) { const std::string &s = cl->getSequences()[0]->getSequenceString(); msaMap[s] = s; }
     std::ofstream w(filePath, std::ios::binary);
     if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
     std::string head = std::string("cluster_id") + CSV_SEPARATOR + "sequence" + CSV_SEPARATOR + "alignment" + CSV_SEPARATOR + "sum";
@@ -967,21 +1137,18 @@ inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &seq
     // the lines are formatted on several threads, one contiguous run of sequences each, and written in order
     const unsigned T = hostThreads();
     std::vector<std::string> parts(T);
-    unsigned used = 1;
     parallelRanges(sequences.size(), T, [&](unsigned t, size_t lo, size_t hi) {
-      used = std::max(used, t + 1);   // (racy max of small ints: every writer stores a value <= T; read after the join)
       std::string &out = parts[t];
       out.reserve((hi - lo) * (48 + 4 * labels.size()) + 256);
       std::vector<long long> scratch(labels.size());
       for (size_t q = lo; q < hi; q++) {
         const UniqueSequencePtr &seq = sequences[q];
         const std::string &str = seq->getSequenceString();
-        const Slot &sl = slot_of(str);
-        if (sl.cluster) {
-            out += std::to_string(sl.cluster->getId());
+        const Cluster *cluster = index.clusterOf(str);
+        if (cluster) {
+            appendNumber(out, cluster->getId());
             out += CSV_SEPARATOR; out += str; out += CSV_SEPARATOR;
-            const bool aligned = repeated ? msaMap.find(str) != msaMap.end() : sl.cluster->getUniqueSize() == 1;
-            if (aligned) out += str; else out += "NA";
+            if (index.isSingletonAlignment(str, cluster)) out += str; else out += "NA";
             out += CSV_SEPARATOR;
         } else {
             out += "NA"; out += CSV_SEPARATOR; out += str; out += CSV_SEPARATOR; out += "NA"; out += CSV_SEPARATOR;
@@ -991,6 +1158,10 @@ inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &seq
       }
     });
     for (const std::string &part : parts) w.write(part.data(), (std::streamsize)part.size());
+}
+inline void writeClusterSequencesToCsv(const std::vector<UniqueSequencePtr> &sequences, const std::vector<ClusterPtr> &clusters,
+                                       const std::string &filePath, const std::vector<std::string> &labels) {
+    writeClusterSequencesToCsv(sequences, SequenceClusterIndex(clusters), filePath, labels);
 }
 
 inline std::vector<ClusterPtr> clustersSortedDescending(const std::vector<ClusterPtr> &clusters) {
@@ -1007,20 +1178,31 @@ inline std::vector<ClusterPtr> clustersSortedDescending(const std::vector<Cluste
     return sorted;
 }
 
-// saveClusterSequencesToCsv, FileIOManager.java:398-404 + getSortedSequences :530-538 (sorts each
-// cluster's own member list in place, as the reference does)
+// getSortedSequences, FileIOManager.java:530-538: the clusters in descending order, each cluster's own member list sorted in
+// place (size descending, then string descending) as the reference does, the members concatenated.  Clusters are independent:
+// they are sorted on several threads and copied to places known from a prefix sum.
+inline std::vector<UniqueSequencePtr> sortedClusterSequences(const std::vector<ClusterPtr> &clusters) {
+    const std::vector<ClusterPtr> order = clustersSortedDescending(clusters);
+    std::vector<size_t> first(order.size() + 1, 0);
+    for (size_t k = 0; k < order.size(); k++) first[k + 1] = first[k] + order[k]->getSequences().size();
+    std::vector<UniqueSequencePtr> sortedSequences(first[order.size()]);
+    parallelChunks(order.size(), 256, hostThreads(), [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) {
+            auto &seqs = order[k]->getSequences();
+            if (seqs.size() > 1)
+                std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+                    return sizeAlphabeticCompare(*b, *a) < 0;
+                });
+            std::copy(seqs.begin(), seqs.end(), sortedSequences.begin() + (long)first[k]);
+        }
+    });
+    return sortedSequences;
+}
+
+// saveClusterSequencesToCsv, FileIOManager.java:398-404 + getSortedSequences :530-538
 inline void saveClusterSequencesToCsv(const std::vector<ClusterPtr> &clusters, const std::string &filePath,
                                       const std::vector<std::string> &labels) {
-    std::vector<UniqueSequencePtr> sortedSequences;
-    for (auto &cl : clustersSortedDescending(clusters)) {
-        auto &seqs = cl->getSequences();
-        if (seqs.size() > 1)
-            std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
-                return sizeAlphabeticCompare(*b, *a) < 0;
-            });
-        sortedSequences.insert(sortedSequences.end(), seqs.begin(), seqs.end());
-    }
-    writeClusterSequencesToCsv(sortedSequences, clusters, filePath, labels);
+    writeClusterSequencesToCsv(sortedClusterSequences(clusters), clusters, filePath, labels);
 }
 
 // saveClusterSequencesToCsvOrdered, FileIOManager.java:371-374
@@ -1035,61 +1217,72 @@ inline void SaveClustersToCsv(const std::vector<ClusterPtr> &clusters, const std
                               const std::vector<std::string> &labels, bool sortInPlace = true) {
     std::ofstream w(filePath, std::ios::binary);
     if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
-    std::string out = std::string("cluster_id") + CSV_SEPARATOR + "main_sequence" + CSV_SEPARATOR + "sum";
-    for (const std::string &label : labels) { out += CSV_SEPARATOR; out += label; }
-    out += "\n";
+    std::string head = std::string("cluster_id") + CSV_SEPARATOR + "main_sequence" + CSV_SEPARATOR + "sum";
+    for (const std::string &label : labels) { head += CSV_SEPARATOR; head += label; }
+    head += "\n";
     const LabelColumns columns(labels);
-    std::vector<long long> sums(labels.size());
     std::vector<size_t> first_column(labels.size());   // a label listed twice repeats its column
     for (size_t k = 0; k < labels.size(); k++) first_column[k] = (size_t)(std::find(labels.begin(), labels.end(), labels[k]) - labels.begin());
-    std::vector<UniqueSequencePtr> copy;
-    for (auto &cl : clustersSortedDescending(clusters)) {
-        // Collections.sort(sequences, reverseOrder()): UniqueSequence.compareTo :161-171 -- on the cluster's own list as in the
-        // reference, or (sortInPlace = false, saveInitialClusters below) on a copy, so that other writers may read the list
-        if (!sortInPlace) copy = cl->getSequences();
-        auto &seqs = sortInPlace ? cl->getSequences() : copy;
-        if (seqs.size() > 1) std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
-            auto cmp = [](const UniqueSequence &x, const UniqueSequence &y) {
-                if (x.size() != y.size()) return x.size() - y.size();
-                return -javaStringCompare(x.getSequenceString(), y.getSequenceString());
-            };
-            return cmp(*b, *a) < 0;
-        });
-        out += std::to_string(cl->getId());
-        out += CSV_SEPARATOR; out += seqs[0]->getSequenceString(); out += CSV_SEPARATOR; out += std::to_string(cl->size());
-        std::fill(sums.begin(), sums.end(), 0);
-        for (auto &s : seqs) columns.add(*s, sums);
-        for (size_t k = 0; k < labels.size(); k++) { out += CSV_SEPARATOR; out += std::to_string(sums[first_column[k]]); }
-        out += "\n";
-    }
-    w.write(out.data(), (std::streamsize)out.size());
+    auto compareTo = [](const UniqueSequence &x, const UniqueSequence &y) {   // UniqueSequence.compareTo :161-171
+        if (x.size() != y.size()) return x.size() - y.size();
+        return -javaStringCompare(x.getSequenceString(), y.getSequenceString());
+    };
+    const std::vector<ClusterPtr> order = clustersSortedDescending(clusters);
+    // one line per cluster; the clusters are independent, so runs of 1,024 of them are formatted on several threads
+    const size_t RUN = 1024;
+    std::vector<std::string> parts((order.size() + RUN - 1) / RUN);
+    parallelChunks(order.size(), RUN, hostThreads(), [&](size_t lo, size_t hi) {
+        std::string &out = parts[lo / RUN];
+        std::vector<long long> sums(labels.size());
+        for (size_t c = lo; c < hi; c++) {
+            const ClusterPtr &cl = order[c];
+            auto &seqs = cl->getSequences();
+            // Collections.sort(sequences, reverseOrder()) on the cluster's own list as in the reference; the line needs only
+            // the list's new head, so with sortInPlace = false (saveInitialClusters below: other writers are reading the
+            // lists) the head is found without sorting: the first of the greatest elements, which is where a stable sort puts it
+            const UniqueSequence *head_seq = seqs[0].get();
+            if (sortInPlace) {
+                if (seqs.size() > 1) std::stable_sort(seqs.begin(), seqs.end(), [&](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
+                    return compareTo(*b, *a) < 0;
+                });
+                head_seq = seqs[0].get();
+            } else {
+                for (auto &s : seqs) if (compareTo(*s, *head_seq) > 0) head_seq = s.get();
+            }
+            appendNumber(out, cl->getId());
+            out += CSV_SEPARATOR; out += head_seq->getSequenceString(); out += CSV_SEPARATOR; appendNumber(out, cl->size());
+            std::fill(sums.begin(), sums.end(), 0);
+            for (auto &s : seqs) columns.add(*s, sums);
+            for (size_t k = 0; k < labels.size(); k++) { out += CSV_SEPARATOR; appendNumber(out, sums[first_column[k]]); }
+            out += "\n";
+        }
+    });
+    w.write(head.data(), (std::streamsize)head.size());
+    for (const std::string &part : parts) w.write(part.data(), (std::streamsize)part.size());
 }
 
 // The three result files of runGreedyClustering / runClinkageClustering (Hammock.java:429-432, :484-487) written side by side:
-// the member lists are sorted once (what saveClusterSequencesToCsv does first), then the three writers only read the clusters
-// (SaveClustersToCsv sorts copies: its order has no ties, so it does not depend on the order it starts from).  The files are the
-// ones the three calls in a row produce; at 10^6 sequences they take 0.5 s instead of 1.2 s.
+// the member lists are sorted once (what saveClusterSequencesToCsv does first) and the string -> cluster table is built once,
+// then the three writers only read the clusters (SaveClustersToCsv finds each line's main sequence without sorting).  The
+// files are the ones the three calls in a row produce.
 inline void saveInitialClusters(const std::vector<ClusterPtr> &clusters, const std::string &sequencesCsv,
                                 const std::string &sequencesOrderedCsv, const std::string &clustersCsv,
                                 const std::vector<std::string> &labels, const std::vector<UniqueSequencePtr> &orderedSequences) {
-    std::vector<UniqueSequencePtr> sortedSequences;
-    for (auto &cl : clustersSortedDescending(clusters)) {
-        auto &seqs = cl->getSequences();
-        if (seqs.size() > 1)
-            std::stable_sort(seqs.begin(), seqs.end(), [](const UniqueSequencePtr &a, const UniqueSequencePtr &b) {
-                return sizeAlphabeticCompare(*b, *a) < 0;
-            });
-        sortedSequences.insert(sortedSequences.end(), seqs.begin(), seqs.end());
-    }
-    auto ordered = std::async(std::launch::async, [&] { writeClusterSequencesToCsv(orderedSequences, clusters, sequencesOrderedCsv, labels); });
+    const std::vector<UniqueSequencePtr> sortedSequences = sortedClusterSequences(clusters);   // the only step that changes the lists
     auto summary = std::async(std::launch::async, [&] { SaveClustersToCsv(clusters, clustersCsv, labels, false); });
     std::exception_ptr failed;
     try {
-        writeClusterSequencesToCsv(sortedSequences, clusters, sequencesCsv, labels);
+        const SequenceClusterIndex index(clusters);
+        auto ordered = std::async(std::launch::async, [&] { writeClusterSequencesToCsv(orderedSequences, index, sequencesOrderedCsv, labels); });
+        try {
+            writeClusterSequencesToCsv(sortedSequences, index, sequencesCsv, labels);
+        } catch (...) {
+            failed = std::current_exception();
+        }
+        try { ordered.get(); } catch (...) { if (!failed) failed = std::current_exception(); }
     } catch (...) {
-        failed = std::current_exception();
+        if (!failed) failed = std::current_exception();
     }
-    try { ordered.get(); } catch (...) { if (!failed) failed = std::current_exception(); }
     try { summary.get(); } catch (...) { if (!failed) failed = std::current_exception(); }
     if (failed) std::rethrow_exception(failed);
 }
@@ -1100,18 +1293,25 @@ inline void saveInputStatistics(const std::vector<UniqueSequencePtr> &sequences,
     std::ofstream w(filePath, std::ios::binary);
     if (!w) throw HammockException("java.io.IOException: cannot write " + filePath);
     for (const std::string &label : labels) w << CSV_SEPARATOR << label;
+    // per label: the sum of its counts and the number of sequences that carry it -- one pass over the list on several threads
+    const unsigned T = hostThreads();
+    const size_t L = labels.size();
+    std::vector<std::vector<long long>> parts(T, std::vector<long long>(2 * L, 0));
+    parallelRanges(sequences.size(), T, [&](unsigned t, size_t lo, size_t hi) {
+        std::vector<long long> &p = parts[t];
+        for (size_t q = lo; q < hi; q++)
+            for (size_t k = 0; k < L; k++) {
+                bool present = false;
+                p[k] += sequences[q]->labelCount(labels[k], &present);
+                p[L + k] += present;
+            }
+    });
+    std::vector<long long> all(2 * L, 0);
+    for (auto &p : parts) for (size_t k = 0; k < 2 * L; k++) all[k] += p[k];
     w << "\n" << "total_count";
-    for (const std::string &label : labels) {
-        long long c = 0;
-        for (auto &s : sequences) c += s->labelCount(label);
-        w << CSV_SEPARATOR << c;
-    }
+    for (size_t k = 0; k < L; k++) w << CSV_SEPARATOR << all[k];
     w << "\n" << "unique_count";
-    for (const std::string &label : labels) {
-        long long c = 0;
-        for (auto &s : sequences) { bool present = false; s->labelCount(label, &present); c += present; }
-        w << CSV_SEPARATOR << c;
-    }
+    for (size_t k = 0; k < L; k++) w << CSV_SEPARATOR << all[L + k];
 }
 
 }  // namespace FileIOManager
