@@ -7,6 +7,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <future>
 #include <memory>
 #include <cstdio>
 #include <cstdlib>
@@ -138,6 +139,11 @@ struct hmk_ctx {
     // root's streams wait for
     hipStream_t gather_stream = nullptr;
     hipEvent_t ev_bandgather = nullptr, ev_gather = nullptr;
+
+    // hmk_reserve sizes the two buffers a clustering call needs LAST (adjacency, bucket records: 2 x 11 GB at 10^6) on its own
+    // thread: on some hosts a fresh 11 GB of device memory takes 0.3-1.5 s to get, and a call has 0.27 s of scoring to do
+    // before it writes to them.  Whoever touches SB_ADJ / SB_PART joins this first (ensure_buf does).
+    std::future<hipError_t> late_buffers;
 
     std::string err;
     mutable std::mutex mu;
@@ -926,9 +932,18 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
         }
     }
     ctx->device = device;
+    const bool timing = getenv("HMK_CLI_TIMING") != nullptr || getenv("HMK_GREEDY_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[hmk] hmk_create: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     if (device >= 0) {
         int count = 0;
         hipError_t e = hipGetDeviceCount(&count);
+        lap("hipGetDeviceCount (runtime start-up)");
         if (e != hipSuccess || device >= count) {
             delete ctx;
             return fail(nullptr, HMK_ERR_DEVICE,
@@ -950,12 +965,20 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
             return fail(nullptr, HMK_ERR_DEVICE, std::string("hmk_create: ") + hipGetErrorString(e));
         }
         ctx->has_device = true;
+        lap("device properties, first hipMalloc + copy");
         // What a first clustering call would otherwise pay: two HSA queues (streams), events, the pinned blocks (16-17 ms) and
         // the deferred load of the kernels' code objects (5-10 ms).  The reference constructs its scorer before it starts the
         // clock of "Clustering time" (Hammock.java:402-406), and a host can create the context while it still reads its input.
         if (getenv("HMK_LAZY_CONTEXT") == nullptr) {
-            if (greedy_streams(ctx) != HMK_OK || warm_neighbors_module() != hipSuccess || warm_neighbors_rows_module() != hipSuccess || warm_edges_module() != hipSuccess)
-                (void)hipGetLastError();   // not fatal here: the first call tries again and reports
+            bool ok = greedy_streams(ctx) == HMK_OK;
+            lap("streams, events, pinned blocks, first copies");
+            ok = ok && warm_neighbors_module() == hipSuccess;
+            lap("code objects: k_neighbors");
+            ok = ok && warm_neighbors_rows_module() == hipSuccess;
+            lap("code objects: k_neighbors_rows");
+            ok = ok && warm_edges_module() == hipSuccess;
+            lap("code objects: k_edges");
+            if (!ok) (void)hipGetLastError();   // not fatal here: the first call tries again and reports
         }
     } else if (device != -1) {
         delete ctx;
@@ -971,6 +994,7 @@ void hmk_destroy(hmk_ctx *ctx) {
     ctx->peers.clear();
     if (ctx->has_device) {
         (void)hipSetDevice(ctx->device);
+        (void)join_late_buffers(ctx);
         free_plan(ctx->plan);
         free_plan_local(ctx->plan_local);
         if (ctx->d_res32) (void)hipFree(ctx->d_res32);
@@ -1251,28 +1275,50 @@ enum { HC_COUNTS = 0, HC_BAND = 16, HC_PEER = 32, HC_RANGE = 64, HC_MISC = 72, H
 static thread_local double g_alloc_ms = 0.0;
 static thread_local int g_allocs = 0;
 struct AllocTimer {
+    const char *what;
+    size_t bytes;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    ~AllocTimer() { g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); g_allocs++; }
+    AllocTimer(const char *w, size_t b) : what(w), bytes(b) {}
+    ~AllocTimer() {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+        g_alloc_ms += ms;
+        g_allocs++;
+        static const bool timing = getenv("HMK_CLI_TIMING") != nullptr || getenv("HMK_GREEDY_TIMING") != nullptr;
+        if (timing && ms > 5.0) std::fprintf(stderr, "[hmk] %s of %.1f MB took %.1f ms\n", what, (double)bytes / 1048576.0, ms);
+    }
 };
 
-hipError_t ensure_buf(hmk_ctx *ctx, int which, size_t bytes) {
+hipError_t ensure_buf_now(hmk_ctx *ctx, int which, size_t bytes) {
     DevBuf &b = ctx->sb[which];
     if (b.cap >= bytes) return hipSuccess;
-    AllocTimer at;
+    AllocTimer at("hipMalloc", bytes);
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
-    const size_t want = bytes + bytes / 8 + 256;
+    const size_t want = bytes + (bytes < (1ull << 30) ? bytes / 8 : 0) + 256;   // (head room for the small ones only)
     const hipError_t e = hipMalloc(&b.p, want);
     if (e == hipSuccess) b.cap = want;
     return e;
+}
+bool late_buffers_pending(hmk_ctx *ctx) {
+    return ctx->late_buffers.valid() && ctx->late_buffers.wait_for(std::chrono::seconds(0)) != std::future_status::ready;
+}
+hipError_t join_late_buffers(hmk_ctx *ctx) {
+    if (!ctx->late_buffers.valid()) return hipSuccess;
+    const hipError_t e = ctx->late_buffers.get();
+    if (e != hipSuccess) (void)hipGetLastError();   // (the caller's own ensure_buf tries again and reports)
+    return hipSuccess;
+}
+hipError_t ensure_buf(hmk_ctx *ctx, int which, size_t bytes) {
+    if ((which == SB_ADJ || which == SB_PART) && ctx->late_buffers.valid()) (void)join_late_buffers(ctx);
+    return ensure_buf_now(ctx, which, bytes);
 }
 template <class T> T *buf(hmk_ctx *ctx, int which) { return (T *)ctx->sb[which].p; }
 
 // pinned host buffer, grow-only; the first `keep` bytes survive a reallocation
 hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes, size_t keep) {
     if (*cap >= bytes) return hipSuccess;
-    AllocTimer at;
+    AllocTimer at("hipHostMalloc", bytes + bytes / 4 + (1 << 20));
     void *q = nullptr;
     const size_t want = bytes + bytes / 4 + (1 << 20);
     const hipError_t e = hipHostMalloc(&q, want, hipHostMallocDefault);
@@ -1374,7 +1420,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
     HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
     HIPCHK(ctx, ensure_buf(ctx, SB_RANGE, 64));
-    if (src.format_known) HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(src.adj_bound, 1) * esz));
+    const bool late_buffers = late_buffers_pending(ctx);   // hmk_reserve's thread is still getting SB_ADJ / SB_PART: the CSR is enqueued later
+    if (src.format_known && !late_buffers) HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(src.adj_bound, 1) * esz));
     HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, ((size_t)n + 1) * 8 + (size_t)n * 4 + 64, 0));
     uint64_t *h_start = (uint64_t *)ctx->h_start;
     uint32_t *h_up = (uint32_t *)((char *)ctx->h_start + ((size_t)n + 1) * 8);
@@ -1384,6 +1431,10 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     bool scatter_enqueued = false;
     auto enqueue_scatter = [&]() -> hipError_t {
         scatter_enqueued = true;
+        if (late_buffers && src.format_known) {
+            const hipError_t e = ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(src.adj_bound, 1) * esz);   // (joins the thread)
+            if (e != hipSuccess) return e;
+        }
         if (csr_by_bucket(n, symmetric, packed, src.deg_fused && src.placed)) {   // large graphs: lower sections dealt by bucket
             uint64_t records = 1;   // one per edge: at most what the segments hold
             for (uint32_t q = 0; q < src.segs.n; q++) records += src.segs.s[q].cap;
@@ -1429,7 +1480,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (e == hipSuccess && src.format_known) e = enqueue_scatter();
         return e;
     };
-    if (!src.before_full) HIPCHK(ctx, enqueue_full());
+    if (!src.before_full && !late_buffers) HIPCHK(ctx, enqueue_full());
 
     // ---- band: the first rows' adjacency from the edges of the band launch, on the copy stream --------------
     uint32_t rows_here = 0;          // rows [0, rows_here) are valid in h_start / h_adj
@@ -1464,8 +1515,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     bool full_ready = false;
     auto wait_full = [&]() -> bool {
         if (full_ready) return true;
-        if (!full_enqueued) {   // multi-device: the peers' edges first
-            const int r = src.before_full();
+        if (!full_enqueued) {   // multi-device: the peers' edges first; (or: the late buffers are ready only now)
+            const int r = src.before_full ? src.before_full() : HMK_OK;
             if (r != HMK_OK) { hook_fail(r, ctx->err.empty() ? "gathering the peers' edges failed" : ctx->err); return false; }
             const hipError_t e0 = enqueue_full();
             if (e0 != hipSuccess) { hook_fail(e0 == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("CSR build: ") + hipGetErrorString(e0)); return false; }
@@ -1923,9 +1974,17 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
 
 // The grow-only device and pinned buffers the tail of a clustering call on n sequences asks for (the edge buffer must have
 // its size already): hmk_greedy_cluster before it enqueues the pass, hmk_reserve from a host that knows n early.
-int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, bool full = false) {
+int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, bool full = false, bool late_on_a_thread = false) {
     const size_t esz0 = packed ? sizeof(NbrPacked) : sizeof(Nbr);
-    HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, std::max<uint64_t>((ctx->symmetric ? 2 : 1) * ctx->d_edges_cap, 1) * esz0));
+    const size_t adj_bytes = std::max<uint64_t>((ctx->symmetric ? 2 : 1) * ctx->d_edges_cap, 1) * esz0;
+    size_t part_bytes = 0;
+    {
+        bool place0 = false;
+        if (const char *v = getenv("HMK_PLACE_EDGES")) place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && atoi(v) != 0;
+        if (csr_by_bucket(n, ctx->symmetric, packed, place0)) part_bytes = (ctx->d_edges_cap + 1) * 8;
+    }
+    const bool late = late_on_a_thread || late_buffers_pending(ctx);   // (pending: the call's CSR step joins the thread and checks the sizes)
+    if (!late) HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, adj_bytes));
     HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
     HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
     HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
@@ -1939,13 +1998,9 @@ int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, boo
         HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(r1)));
         HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
     }
-    {
-        bool place0 = false;
-        if (const char *v = getenv("HMK_PLACE_EDGES")) place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && atoi(v) != 0;
-        if (csr_by_bucket(n, ctx->symmetric, packed, place0)) {
-            HIPCHK(ctx, ensure_buf(ctx, SB_PART, (ctx->d_edges_cap + 1) * 8));
-            HIPCHK(ctx, ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes()));
-        }
+    if (part_bytes) {
+        if (!late) HIPCHK(ctx, ensure_buf(ctx, SB_PART, part_bytes));
+        HIPCHK(ctx, ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes()));
     }
     HIPCHK(ctx, ensure_buf(ctx, SB_COF, (size_t)n * 4));
     HIPCHK(ctx, ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4));
@@ -1984,6 +2039,16 @@ int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, boo
         HIPCHK(ctx, ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4));
         HIPCHK(ctx, ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + (size_t)n * 12 + ncl * 4 + 64, 0));
     }
+    if (late_on_a_thread && (ctx->sb[SB_ADJ].cap < adj_bytes || ctx->sb[SB_PART].cap < part_bytes)) {
+        (void)join_late_buffers(ctx);
+        const int device = ctx->device;
+        ctx->late_buffers = std::async(std::launch::async, [ctx, device, adj_bytes, part_bytes]() -> hipError_t {
+            hipError_t e = hipSetDevice(device);
+            if (e == hipSuccess) e = ensure_buf_now(ctx, SB_ADJ, adj_bytes);
+            if (e == hipSuccess && part_bytes) e = ensure_buf_now(ctx, SB_PART, part_bytes);
+            return e;
+        });
+    }
     return HMK_OK;
 }
 
@@ -2001,7 +2066,7 @@ int grow_edge_buffer(hmk_ctx *ctx, uint64_t cap) {
     if (ctx->d_edges) (void)hipFree(ctx->d_edges);
     ctx->d_edges = nullptr;
     ctx->d_edges_cap = 0;
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t)));
+    { AllocTimer at("hipMalloc (edges)", cap * sizeof(uint64_t)); HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t))); }
     ctx->d_edges_cap = cap;
     return HMK_OK;
 }
@@ -2464,11 +2529,14 @@ int hmk_create_multi(const int32_t *matrix, const int *devices, int n_devices, h
 
 int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
+    const auto t_call = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> lock(ctx->mu);
     if (!ctx->has_device || n_sequences < 2) return HMK_OK;   // nothing to size
+    const auto t_lock = std::chrono::steady_clock::now();
     int st = need_device(ctx);
     if (st == HMK_OK) st = greedy_streams(ctx);
     if (st) return st;
+    const auto t_streams = std::chrono::steady_clock::now();
     if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
     HIPCHK(ctx, ensure_buf(ctx, SB_BCOUNTS, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
     st = grow_edge_buffer(ctx, first_edge_capacity(ctx, n_sequences));
@@ -2476,7 +2544,13 @@ int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences) {
     const int64_t maxc = (int64_t)(n_sequences * 0.025 + 0.5);      // Hammock.java:398-401, the default cluster limit
     int64_t band = n_sequences >= 16384 ? std::min<int64_t>(n_sequences, 2 * maxc + 1024) : 0;
     if (band * 2 > (int64_t)n_sequences) band = 0;
-    return reserve_tail_buffers(ctx, n_sequences, true, (uint32_t)band, true);
+    st = reserve_tail_buffers(ctx, n_sequences, true, (uint32_t)band, true, getenv("HMK_NO_LATE_BUFFERS") == nullptr);
+    if (getenv("HMK_GREEDY_TIMING") || getenv("HMK_CLI_TIMING")) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[hmk] hmk_reserve(%u): waited for the context %.1f ms, device + streams %.1f ms, buffers %.1f ms\n", n_sequences,
+                     ms(t_call, t_lock), ms(t_lock, t_streams), ms(t_streams, std::chrono::steady_clock::now()));
+    }
+    return st;
 }
 
 int hmk_set_java_hashset(hmk_ctx *ctx, int version) {

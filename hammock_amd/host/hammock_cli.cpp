@@ -13,6 +13,8 @@
 #include <chrono>
 #include <climits>
 
+#include <malloc.h>
+
 #include "hammock_host.hpp"
 
 using namespace hammock;
@@ -251,8 +253,13 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         if (sequences.empty()) throw FileFormatException("Error. No sequences (with specified labels) to cluster.");
         // the sequence count is known: the context's buffers (24 GB at 10^6) are sized on another thread while this one goes on
         // to the labels, the statistics, the sort and the upload
-        std::future<void> reserved = std::async(std::launch::async, [contextReady, count = (uint32_t)sequences.size()]() {
-            try { (void)hmk_reserve(contextReady.get()->get(), count); } catch (...) { }   // (a device error is reported by the clustering call)
+        std::future<void> reserved = std::async(std::launch::async, [contextReady, timeStart, count = (uint32_t)sequences.size()]() {
+            try {   // (a device error is reported by the clustering call)
+                hmk_ctx *c = contextReady.get()->get();
+                if (std::getenv("HMK_CLI_TIMING")) std::fprintf(stderr, "[hammock-hip] hmk_reserve begins at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - timeStart).count());
+                (void)hmk_reserve(c, count);
+                if (std::getenv("HMK_CLI_TIMING")) std::fprintf(stderr, "[hammock-hip] hmk_reserve done at %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - timeStart).count());
+            } catch (...) { }
         });
         if (maxLength > HMK_MAX_LEN)   // the reference has no such limit; say so here instead of failing inside the clusterer
             throw HammockException("Error. The longest sequence has " + std::to_string(maxLength) + " amino acids; the GPU kernels of hammock-hip "
@@ -330,8 +337,10 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         logger.logAndStderr("and: " + initialClustersSequencesOrderedCsv);
         logger.logWithTime("Program successfully ended.");
         // Everything is on disk (the writers and the logger close their files).  Tearing down 10^6 sequence and cluster
-        // objects one by one and handing 30 GB of device buffers back costs 0.3-0.5 s that change nothing: leave at once,
-        // the driver reclaims the device memory with the process.  (HMK_CLI_TEARDOWN=1: the ordinary way out.)
+        // objects one by one and handing 36 GB of device buffers back costs 0.3-0.5 s that change nothing: leave at once,
+        // the driver reclaims the device memory with the process.  (HMK_CLI_TEARDOWN=1: the ordinary way out.  Handing the
+        // context back on another thread while the files are written was measured too: the writers lose 0.1 s to it and the
+        // process still needs 0.17 s to go, 1.42-1.51 s against 1.17-1.45 s.)
         cliLap("log closed, leaving");
         if (std::getenv("HMK_CLI_TEARDOWN") == nullptr) {
             std::cout.flush();
@@ -463,6 +472,13 @@ int apiSelftest(const std::vector<std::string> &args) {
 }  // namespace
 
 int main(int argc, char **argv) {
+    // 10^6 sequences are 4 x 10^6 small allocations made on 16 threads: glibc grows a thread's arena by `top_pad` (128 KB) per
+    // mprotect call, and every such call stops the page faults of all other threads; larger steps, fewer calls
+    {
+        const char *v = std::getenv("HMK_CLI_TOP_PAD_MB");
+        const int mb = v ? std::atoi(v) : 64;
+        if (mb > 0) mallopt(M_TOP_PAD, mb << 20);
+    }
     std::vector<std::string> args(argv + 1, argv + argc);
     if (args.empty() || args[0] == "--help" || args[0] == "-h") { printHelp(); return args.empty() ? 2 : 0; }
     try {
