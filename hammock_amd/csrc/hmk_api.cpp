@@ -166,6 +166,7 @@ int fail(hmk_ctx *ctx, int code, const std::string &msg) {
     } while (0)
 
 int greedy_streams(hmk_ctx *ctx);   // streams, events and pinned blocks of the clustering calls (defined with them below)
+hipError_t join_late_buffers(hmk_ctx *ctx);
 
 int need_device(hmk_ctx *ctx) {
     if (!ctx->has_device)
