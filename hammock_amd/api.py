@@ -288,6 +288,13 @@ class Context:
             self._raise(st, stats)
         return cid[:self.n], order[:stats.n_result_clusters], stats
 
+    def reserve(self, n_sequences):
+        """hmk_reserve: sizes the buffers of a clustering call on n_sequences ahead of time (optional; the two a call needs
+        last are obtained on a thread of their own and the call's CSR step waits for them)."""
+        st = N.lib.hmk_reserve(self._h, int(n_sequences))
+        if st:
+            self._raise(st)
+
     def set_java_hashset(self, version):
         """hmk_set_java_hashset: 8 (default, Java 8+), 7 (JDK 7u6+) or 6 (JDK 6 / 7 before 7u6) -- whose HashSet iteration
         order the clinkage calls emulate for the chain starts and the returned list."""

@@ -2044,6 +2044,8 @@ int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, boo
         (void)join_late_buffers(ctx);
         const int device = ctx->device;
         ctx->late_buffers = std::async(std::launch::async, [ctx, device, adj_bytes, part_bytes]() -> hipError_t {
+            if (const char *v = getenv("HMK_LATE_BUFFERS_DELAY_MS"))   // tests: a host on which device memory is slow to get
+                std::this_thread::sleep_for(std::chrono::milliseconds(std::max(0, atoi(v))));
             hipError_t e = hipSetDevice(device);
             if (e == hipSuccess) e = ensure_buf_now(ctx, SB_ADJ, adj_bytes);
             if (e == hipSuccess && part_bytes) e = ensure_buf_now(ctx, SB_PART, part_bytes);

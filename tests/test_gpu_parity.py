@@ -420,6 +420,29 @@ def test_greedy_multi_device_context(gpu, blosum62, coracle, devices):
     assert stats.n_edges == sstats.n_edges   # the shards together hold every edge exactly once
 
 
+@pytest.mark.parametrize("delay_ms", [0, 150])
+def test_greedy_after_reserve_with_late_buffers(gpu, blosum62, coracle, monkeypatch, delay_ms):
+    """hmk_reserve obtains the adjacency and bucket-record buffers on a thread of its own; a clustering call that starts while
+    that thread is still at it (forced: HMK_LATE_BUFFERS_DELAY_MS) scores, hands the band over and runs phase 1 first and
+    enqueues its CSR step when the buffers are there.  Same result as the oracle, first call and second call (buffers in
+    place), also when the reservation was for fewer sequences than the call brings (the call grows them)."""
+    n = 120000
+    res, off = synth_peptides(17, n, 12)
+    st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 20, 3000, 16)
+    assert st == 0
+    if delay_ms:
+        monkeypatch.setenv("HMK_LATE_BUFFERS_DELAY_MS", str(delay_ms))
+    for reserve_n in (n, n // 3):
+        ctx = hammock_amd.Context(blosum62, device=0)
+        ctx.reserve(reserve_n)
+        ctx.set_sequences(residues=res, offsets=off)
+        for _ in range(2):
+            cid, order, stats = ctx.greedy_cluster(3, 0, 20, 3000)
+            assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+            assert np.array_equal(ctx.member_rank[:n], ostats.member_rank)
+        del ctx
+
+
 def test_greedy_edge_buffer_overflow_retry(gpu, blosum62, coracle, monkeypatch):
     """The first guess of the edge buffer is too small (forced: HMK_EDGE_GUESS): segments overflow, edges are dropped, and
     the CSR / band kernels enqueued behind the pass run on that truncated edge set before the host sees the counters.
