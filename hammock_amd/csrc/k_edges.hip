@@ -195,7 +195,11 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t
 // the adjacency.  Three streaming passes over the edges instead of one pass of random writes.
 constexpr uint32_t LB_MAX_BUCKETS = 4096;   // LDS tables of the partition kernel: 2 x 16 KB
 constexpr uint32_t LB_MAX_ROWS = 4096;      // rows of a bucket (shift <= 12)
-constexpr uint32_t LB_CHUNK = 65536;        // edges a workgroup deals at a time
+#ifndef HMK_LB_LOADS
+#define HMK_LB_LOADS 16
+#endif
+constexpr int LB_LOADS = HMK_LB_LOADS;        // edges a thread of the dealing kernel holds: all of them loads in flight at once
+constexpr uint32_t LB_CHUNK = LB_LOADS * 1024;   // edges a workgroup deals at a time
 
 // an edge the degree pass counted (k_edge_degree: both ends in [0, n), no self pair); ~0 marks "no edge" in the unrolled loads
 __device__ __forceinline__ bool lower_record_ok(uint64_t e, uint32_t n) {
@@ -277,14 +281,14 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
             const uint32_t len = (uint32_t)min((uint64_t)LB_CHUNK, cnt - k0);
             for (uint32_t b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
             __syncthreads();
-            for (uint32_t k = threadIdx.x; k < len; k += 4096) {   // four loads in flight per thread
-                uint64_t e[4];
+            // the chunk is read once and stays in registers for both passes (LB_LOADS edges per thread, all loads in flight)
+            static_assert(LB_CHUNK == LB_LOADS * 1024, "a chunk is one round of loads");
+            uint64_t ev[LB_LOADS];
 #pragma unroll
-                for (int q = 0; q < 4; q++) e[q] = k + q * 1024 < len ? sg.edges[k0 + k + q * 1024] : ~0ull;
+            for (int q = 0; q < LB_LOADS; q++) ev[q] = threadIdx.x + q * 1024 < len ? sg.edges[k0 + threadIdx.x + q * 1024] : ~0ull;
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (lower_record_ok(e[q], n)) atomicAdd(&hist[max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q])) >> shift], 1u);
-            }
+            for (int q = 0; q < LB_LOADS; q++)
+                if (lower_record_ok(ev[q], n)) atomicAdd(&hist[max(HMK_EDGE_X(ev[q]), HMK_EDGE_M(ev[q])) >> shift], 1u);
             __syncthreads();
             for (uint32_t b = threadIdx.x; b < nb; b += 1024) {
                 const uint32_t h = hist[b];
@@ -292,28 +296,23 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
                 hist[b] = 0;
             }
             __syncthreads();
-            for (uint32_t k = threadIdx.x; k < len; k += 4096) {   // the chunk again (512 KB: from the L2)
-                uint64_t ev[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) ev[q] = k + q * 1024 < len ? sg.edges[k0 + k + q * 1024] : ~0ull;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint64_t e = ev[q];
-                    const bool ok = lower_record_ok(e, n);
-                    const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)), m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
-                    const uint32_t rel = (uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu;
-                    if (UPPER) {   // (whole waves: wave_groups needs all 64 lanes; a wave's edges come from a handful of rows)
-                        const WaveGroup g = wave_groups(x, ok);   // one atomic per distinct x of the wave
-                        uint32_t basex = 0;
-                        if (ok && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
-                        basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
-                        if (ok) adj[start[x] + basex + g.rank] = NbrPacked{(m << 8) | rel};
-                    }
-                    if (!ok) continue;
-                    const uint32_t b = m >> shift;
-                    const uint32_t at = first[b] + atomicAdd(&hist[b], 1u);
-                    recs[bucket_off[b] + at] = ((uint64_t)m << 32) | (uint64_t)((x << 8) | rel);
+            for (int q = 0; q < LB_LOADS; q++) {
+                const uint64_t e = ev[q];
+                const bool ok = lower_record_ok(e, n);
+                const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)), m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
+                const uint32_t rel = (uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu;
+                if (UPPER) {   // (whole waves: wave_groups needs all 64 lanes; a wave's edges come from a handful of rows)
+                    const WaveGroup g = wave_groups(x, ok);   // one atomic per distinct x of the wave
+                    uint32_t basex = 0;
+                    if (ok && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
+                    basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
+                    if (ok) adj[start[x] + basex + g.rank] = NbrPacked{(m << 8) | rel};
                 }
+                if (!ok) continue;
+                const uint32_t b = m >> shift;
+                const uint32_t at = first[b] + atomicAdd(&hist[b], 1u);
+                recs[bucket_off[b] + at] = ((uint64_t)m << 32) | (uint64_t)((x << 8) | rel);
             }
             __syncthreads();
             g += gridDim.x;
@@ -1196,7 +1195,7 @@ hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64
 // recs = one uint64 per edge.  n < 2^24 (edge format), so 2^shift rows per bucket with shift <= 12 always give <= 4096 buckets.
 static uint32_t csr_partition_grid() {
     if (const char *v = getenv("HMK_CSR_PARTITION_GRID")) return (uint32_t)std::max(1, atoi(v));
-    return 256;
+    return 512;   // two 1,024-thread workgroups per CU (256 / 512 / 1024: 19.8 / 19.4 / 19.5 ms for the CSR at 10^6)
 }
 uint32_t csr_partition_shift(uint32_t n) {
     uint32_t shift = 9;
@@ -1215,7 +1214,8 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_lower_count, dim3(512), dim3(1024), 0, s, segs, shift, nb, n, cnt);
     hipLaunchKernelGGL(k_lower_offsets, dim3(1), dim3(1024), 0, s, cnt, nb, off, fill);
-    // one 1,024-thread workgroup per CU (10^6 sequences: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms)
+    // (10^6 sequences, round 2: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms with ONE load in flight per thread;
+    // the kernel is bound by memory latency: 4 loads in flight 22.1 ms, 8: 21.5, 16 with the chunk kept in registers: 19.8)
     // the upper sections in the same pass over the edges (HMK_CSR_FUSED_UPPER=0: their own kernel, as in round 2)
     const char *fu = getenv("HMK_CSR_FUSED_UPPER");
     if (fu == nullptr || atoi(fu) != 0) {
