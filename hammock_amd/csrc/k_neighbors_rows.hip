@@ -31,6 +31,12 @@
 
 namespace hmk {
 
+#ifndef HMK_ROWS_DEFER       // 1: a wave looks for hits once per four steps (the history word of the kernel's batch loop)
+#define HMK_ROWS_DEFER 1
+#endif
+#ifndef HMK_ROWS_ARGCOPY     // 1: the batch loop's two kernel arguments are copied out of the argument block (see the kernel)
+#define HMK_ROWS_ARGCOPY 0
+#endif
 #ifndef HMK_ROWS_STAGE
 #define HMK_ROWS_STAGE 320
 #endif
@@ -419,12 +425,38 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     const bool prio = MODE != EDGES_PLACE || HMK_SETPRIO_PLACE;
 
     const uint32_t fargs_addr = lds_addr(fargs);
+    // The batch loop needs two of the kernel's arguments.  As fields of P they keep the WHOLE argument block (16 SGPRs, one
+    // s_load_dwordx16) alive through the loop, and with the flush call's register needs the allocator parks that block in VGPR
+    // lanes and reads all 16 back at every step: 18 v_readlane of a step's 150 VALU instructions.  Copies made by an
+    // instruction of their own (HMK_ROWS_ARGCOPY=1) are values of their own and the v_readlane go away -- and the pass gets
+    // SLOWER, 2.560 against 2.525 ms on the same box, twice: the VALU pipe is not what the kernel waits for (the LDS pipe
+    // is), and the 18 instructions sit where the step's global load is in flight.  Kept as a switch, off.
+#if HMK_ROWS_ARGCOPY
+    uint64_t res_sorted_s;
+    uint32_t lpad_s;
+    asm volatile("s_mov_b64 %0, %1" : "=s"(res_sorted_s) : "s"((uint64_t)(uintptr_t)P.res_sorted));
+    asm volatile("s_mov_b32 %0, %1" : "=s"(lpad_s) : "s"(P.lpad));
+    const uint8_t *const res_sorted = (const uint8_t *)(uintptr_t)res_sorted_s;
+#else
+    const uint8_t *const res_sorted = P.res_sorted;
+    const uint32_t lpad_s = P.lpad;
+#endif
 
+    constexpr bool DEFER = HMK_ROWS_DEFER != 0 && EXACT_LB;   // (mixed lengths: short column runs, two groups -- 1.3 % slower with it)
+    // Hits are rare per pair (0.26 % at the default threshold) but not per step: a wave tests 512 pairs at a time and finds
+    // one in three steps out of four.  So the test's result is only NOTED at every step -- the top bits of the eight rows'
+    // bytes, merged into one word per lane and shifted into a 4-step history (hm uses every 4th bit: step j of a quad lands on
+    // the bits = j mod 4) -- and the wave looks at the history once per quad: one ballot, one append loop whose number of
+    // turns is the largest number of hits any LANE has in the quad (1.1 on average) instead of four of them.
+    uint32_t acc[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) acc[g] = 0;
     for (uint32_t bt = 0; bt < n_batches; bt++) {
         const uint32_t colrel = bt * 256 + tid;
         const uint32_t col = T.col0 + colrel;
         uint32_t off[CAP], toff[S::NT];
-        S::offsets(P.res_sorted + (size_t)col * P.lpad, col < col_end, lbs, tab_addr, tab_addr, off, toff);
+        S::offsets(res_sorted + (size_t)col * lpad_s, col < col_end, lbs, tab_addr, tab_addr, off, toff);
+        const bool look = !DEFER || (bt & 3u) == 3u || bt + 1 == n_batches;   // wave-uniform
 
         auto one_group = [&](auto gt) {
             constexpr int g = decltype(gt)::value;
@@ -438,7 +470,8 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
             uint32_t o0 = W0[0], o1 = W1[0];
 #pragma unroll
             for (int u = 1; u < ND; u++) { o0 |= W0[u]; o1 |= W1[u]; }
-            if (__ballot(((o0 | o1) & 0x80808080u) != 0) == 0) return;
+            if constexpr (!DEFER)
+                if (__ballot(((o0 | o1) & 0x80808080u) != 0) == 0) return;
             // ---- rare path (a hit somewhere in the wave): every lane appends ITS hits, one per turn ----
             // hm: bit 8r + 7 set <=> row r of the group (r < 4) reached the threshold for this lane's column, bit 8r + 3 <=> row
             // 4 + r.  The rows beyond the tile's last start at the initial lane value, which may itself have the top bit set:
@@ -460,6 +493,14 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
                     }
                 }
             }
+            if constexpr (DEFER) {
+                // history: this step's bits stay at 3 mod 4, the earlier steps' move down by one per step
+                acc[g] = (acc[g] >> 1) | hm;
+                if (!look) return;
+                hm = acc[g];
+                acc[g] = 0;
+                if (__ballot(hm != 0) == 0) return;
+            }
             // (the flush sits OUTSIDE the append loop: it scores whole columns again and needs most of the register file; inside the
             // loop the compiler kept the loop's state in scratch memory for every turn of it)
             for (;;) {
@@ -470,10 +511,12 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
                     if (mask == 0) break;
                     if (cnt > (uint32_t)(STAGE_CAP - 64)) { full = true; break; }   // keep room for one wave of hits
                     if (any) {
-                        const uint32_t b = (uint32_t)__builtin_ctz(hm);
-                        const uint32_t row = (b >> 3) + 4u - (b & 4u);   // bit 8r + 7: row r; bit 8r + 3: row 4 + r
+                        const uint32_t q = (uint32_t)__builtin_ctz(hm);
+                        const uint32_t b = DEFER ? q | 3u : q;                // where the bit was when its step noted it
+                        const uint32_t back = DEFER ? 3u - (q & 3u) : 0u;     // ... that many steps ago
+                        const uint32_t row = (b >> 3) + 4u - (b & 4u);        // bit 8r + 7: row r; bit 8r + 3: row 4 + r
                         // (the column is recomputed: cheaper than keeping it across the flush call)
-                        stage[cnt + mbcnt64(mask)] = (bt * 256 + threadIdx.x) | ((uint32_t)(8 * g) + row) << 16;
+                        stage[cnt + mbcnt64(mask)] = ((bt - back) * 256 + threadIdx.x) | ((uint32_t)(8 * g) + row) << 16;
                         hm &= hm - 1u;   // clear the lowest set bit
                     }
                     cnt += (uint32_t)__popcll(mask);
