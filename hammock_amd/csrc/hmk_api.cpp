@@ -1676,7 +1676,12 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             const double est = (double)h_start[n] / std::max<uint32_t>(n, 1) * (double)in_clusters / std::max<uint32_t>(n, 1);
             uint32_t *d_retry = nullptr;
             const int first_slots = est <= 24.0 ? 128 : 512;   // ~5 x the expected number of distinct clusters in a row
-            if (r == hipSuccess && est <= 100.0 && getenv("HMK_PRECHECK_ONE_STAGE") == nullptr) {
+            // (10^6 default-threshold 12-mers give an estimate of 130; small tables first for them too -- 512 slots, five workgroups
+            // per CU instead of two -- was measured and loses: 22.0 against 18.7 ms, 38.9 against 25.8 ms in the reference's
+            // default order, where many rows see far more clusters than the average and are scanned twice)
+            double two_stage_limit = 100.0;
+            if (const char *v = getenv("HMK_PRECHECK_TWO_STAGE_LIMIT")) two_stage_limit = atof(v);
+            if (r == hipSuccess && est <= two_stage_limit && getenv("HMK_PRECHECK_ONE_STAGE") == nullptr) {
                 r = ensure_buf(ctx, SB_RETRY, std::max<size_t>(nl, 1) * 4);
                 d_retry = buf<uint32_t>(ctx, SB_RETRY);
             }

@@ -556,6 +556,9 @@ k_rows_unpack(const uint32_t *__restrict__ start, const uint32_t *__restrict__ a
 // clusters are counted in a per-wave LDS hash table (key = cluster, count, min score); a row with more distinct clusters
 // than the table takes is walked once per class of clusters (see the kernel); only beyond 64 classes does it raise
 // *overflow (the host then runs its own pre-check).
+#ifndef HMK_PRE_UNROLL
+#define HMK_PRE_UNROLL 16
+#endif
 constexpr int PRE_SLOTS = 1024;   // per wave; 14 KB of tables.  (PRE_SLOTS_SMALL: the first stage of the single pass, see below)
 constexpr int PRE_SLOTS_SMALL = 128, PRE_SLOTS_MEDIUM = 512;
 
@@ -638,10 +641,12 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
         };
         // the row's neighbours inside clusters go into the table -- all of them (parts == 1) or those whose cluster falls
         // into one of `parts` classes (c mod parts == part), for a row that touches more clusters than the table takes.
-        // Four entries per lane and step: the row is a chain of dependent gathers (entry -> bitmap word -> cluster_of),
-        // and with one entry in flight per lane the kernel waits for memory at every link.
+        // Sixteen entries per lane and step: the row is a chain of dependent gathers (entry -> bitmap word -> cluster_of), and
+        // the full-size tables leave room for two workgroups per CU only, so the kernel waits for memory at every link unless
+        // a lane has many entries in flight (10^6 sequences, 10 GB of rows: 2 / 4 / 8 / 12 / 16 / 24 entries per lane:
+        // 22.0 / 18.6 / 16.3 / 15.3 / 14.9 / 14.6 ms).
         auto scan_row = [&](uint32_t part, uint32_t parts) {
-            constexpr int PRE_UNROLL = 4;
+            constexpr int PRE_UNROLL = HMK_PRE_UNROLL;
             for (uint64_t k0 = b; k0 < e; k0 += 64 * PRE_UNROLL) {   // wave-uniform
                 NbrT nb[PRE_UNROLL];
                 bool in[PRE_UNROLL];

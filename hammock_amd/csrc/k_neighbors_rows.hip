@@ -37,6 +37,10 @@ namespace hmk {
 #ifndef HMK_ROWS_ARGCOPY     // 1: the batch loop's two kernel arguments are copied out of the argument block (see the kernel)
 #define HMK_ROWS_ARGCOPY 0
 #endif
+#ifndef HMK_ROWS_AHEAD       // 1: a step loads the NEXT step's column while its own table reads run (measured: 2.54 against 2.53 ms, config 4a
+                             // 4.49-4.53 against 4.37-4.44 ms -- eight waves per SIMD hide that load already; off)
+#define HMK_ROWS_AHEAD 0
+#endif
 #ifndef HMK_ROWS_STAGE
 #define HMK_ROWS_STAGE 320
 #endif
@@ -108,13 +112,13 @@ struct RowsShape {
 
     // A column's residues -> table offsets (residue * 8): off[j] for position j, toff[q] for position lbs - X + q (the last X).
     // `base` is added to every offset (the table's LDS address + a per-lane group displacement), `tbase` to the tail ones.
-    static __device__ __forceinline__ void offsets(const uint8_t *rowp, bool live, int lbs, uint32_t base, uint32_t tbase,
-                                                   uint32_t (&off)[CAP], uint32_t (&toff)[NT]) {
-        uint32_t words[LPADW], tw[TW > 0 ? TW : 1];
+    static constexpr int TWN = TW > 0 ? TW : 1;
+    // the column's residue words as they lie in memory (zero for a lane without a column)
+    static __device__ __forceinline__ void load_words(const uint8_t *rowp, bool live, int lbs, uint32_t (&words)[LPADW], uint32_t (&tw)[TWN]) {
 #pragma unroll
         for (int q = 0; q < LPADW; q++) words[q] = 0;
 #pragma unroll
-        for (int q = 0; q < (TW > 0 ? TW : 1); q++) tw[q] = 0;
+        for (int q = 0; q < TWN; q++) tw[q] = 0;
         if (live) {
             const u32x4 v0 = reinterpret_cast<const u32x4 *>(rowp)[0];
             words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
@@ -127,9 +131,13 @@ struct RowsShape {
                 for (int q = 0; q < TW; q++) __builtin_memcpy(&tw[q], rowp + (lbs - X) + 4 * q, 4);
             }
         }
+    }
+    static __device__ __forceinline__ void offsets_of(const uint32_t (&words_in)[LPADW], const uint32_t (&tw_in)[TWN], uint32_t base, uint32_t tbase,
+                                                      uint32_t (&off)[CAP], uint32_t (&toff)[NT]) {
+        uint32_t words[LPADW], tw[TWN];
         // residues are < 32, so byte k of (word << 3) is residue * 8 exactly (the three bits that move in are zero)
 #pragma unroll
-        for (int q = 0; q < LPADW; q++) words[q] <<= 3;
+        for (int q = 0; q < LPADW; q++) words[q] = words_in[q] << 3;
 #pragma unroll
         for (int j = 0; j < CAP; j++) off[j] = base + ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
         if (EXACT_LB) {
@@ -137,10 +145,16 @@ struct RowsShape {
             for (int q = 0; q < X; q++) toff[q] = off[CAP - X + q];
         } else {
 #pragma unroll
-            for (int q = 0; q < TW; q++) tw[q] <<= 3;
+            for (int q = 0; q < TWN; q++) tw[q] = tw_in[q] << 3;
 #pragma unroll
             for (int q = 0; q < X; q++) toff[q] = tbase + ((tw[q >> 2] >> ((q & 3) * 8)) & 0xFFu);
         }
+    }
+    static __device__ __forceinline__ void offsets(const uint8_t *rowp, bool live, int lbs, uint32_t base, uint32_t tbase,
+                                                   uint32_t (&off)[CAP], uint32_t (&toff)[NT]) {
+        uint32_t words[LPADW], tw[TWN];
+        load_words(rowp, live, lbs, words, tw);
+        offsets_of(words, tw, base, tbase, off, toff);
     }
 
     // All shift sums of (8 rows of group GI) x (this lane's column): W0 / W1[u] = the 8 byte lanes of plane u.
@@ -451,11 +465,24 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     uint32_t acc[G];
 #pragma unroll
     for (int g = 0; g < G; g++) acc[g] = 0;
+    // the column of the NEXT step is asked for while this step's table reads run (HMK_ROWS_AHEAD=0: at the step's start)
+    constexpr bool AHEAD = HMK_ROWS_AHEAD != 0;
+    uint32_t nwords[S::LPADW], ntw[S::TWN];
+    if constexpr (AHEAD) {
+        const uint32_t col0 = T.col0 + tid;
+        S::load_words(res_sorted + (size_t)col0 * lpad_s, col0 < col_end, lbs, nwords, ntw);
+    }
     for (uint32_t bt = 0; bt < n_batches; bt++) {
         const uint32_t colrel = bt * 256 + tid;
         const uint32_t col = T.col0 + colrel;
         uint32_t off[CAP], toff[S::NT];
-        S::offsets(res_sorted + (size_t)col * lpad_s, col < col_end, lbs, tab_addr, tab_addr, off, toff);
+        if constexpr (AHEAD) {
+            S::offsets_of(nwords, ntw, tab_addr, tab_addr, off, toff);
+            const uint32_t coln = col + 256;
+            S::load_words(res_sorted + (size_t)coln * lpad_s, bt + 1 < n_batches && coln < col_end, lbs, nwords, ntw);
+        } else {
+            S::offsets(res_sorted + (size_t)col * lpad_s, col < col_end, lbs, tab_addr, tab_addr, off, toff);
+        }
         const bool look = !DEFER || (bt & 3u) == 3u || bt + 1 == n_batches;   // wave-uniform
 
         auto one_group = [&](auto gt) {
