@@ -1814,6 +1814,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             if (const char *v = getenv("HMK_LOOP_LOOKAHEAD")) LOOKAHEAD = (uint32_t)std::max(1, atoi(v));
             volatile unsigned long long *word = ctx->h_loop;
             *word = 0;
+            const bool loop_trace = getenv("HMK_LOOP_TRACE") != nullptr;   // (with HMK_LOOP_LOOKAHEAD=1 every round is seen)
             // never spin forever: the deadline runs from the last round the device was SEEN to finish (a long loop is fine, a
             // stalled device is not) and is looked at on every poll (a few thousand spins apart)
             auto t_progress = std::chrono::steady_clock::now();
@@ -1826,7 +1827,11 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                     const uint32_t seen = (uint32_t)(w >> 32);      // rounds the device has finished
                     if (seen && (uint32_t)w == 0) { done = true; break; }
                     if (rounds - seen < LOOKAHEAD) break;
-                    if (seen != last_seen) { last_seen = seen; t_progress = std::chrono::steady_clock::now(); }
+                    if (seen != last_seen) {
+                        last_seen = seen;
+                        t_progress = std::chrono::steady_clock::now();
+                        if (loop_trace) std::fprintf(stderr, "[hmk greedy] loop round %u: %u joins, %.3f ms since the loop began\n", seen, (uint32_t)w, ms_since(tl));
+                    }
                     else if ((spins & 1023u) == 1023u && ms_since(t_progress) > 60e3) { stalled = true; break; }
                     std::this_thread::yield();
                 }

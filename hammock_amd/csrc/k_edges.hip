@@ -1056,6 +1056,10 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
 // One workgroup per accepted join (y -> c): y's later neighbours go into an LDS hash table, chunk by chunk, and the
 // cluster's subscribers after y probe it -- a subscriber that is a neighbour counts one more covered member and folds
 // the pair's score into its minimum; the others' entries turn infeasible when joined[c] advances.
+#ifndef HMK_APPLY_SUBS
+#define HMK_APPLY_SUBS 4
+#endif
+constexpr int APPLY_SUBS = HMK_APPLY_SUBS;   // subscribers a thread of k_loop_apply has in flight
 constexpr int APPLY_SLOTS = 8192, APPLY_CHUNK = 4096;   // 64 KB of LDS, load factor <= 1/2 (4,096 slots and 1,280 workgroups: no faster)
 
 template <class NbrT>
@@ -1099,18 +1103,32 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                 }
             }
             __syncthreads();
-            for (uint32_t s0 = sb; s0 < se; s0 += 256) {         // workgroup-uniform: the ballots need whole waves
-                const uint32_t s2 = s0 + threadIdx.x;
-                bool mark = false;
-                uint32_t q2 = 0;
-                if (s2 < se) {
-                    const unsigned long long sub = subs[s2];
-                    q2 = (uint32_t)(sub >> 32);
-                    const uint32_t k2 = (uint32_t)sub;
-                    // only a feasible entry matters (covered == joined; joined + 1 once an earlier chunk has counted y), and it
-                    // changes either way -- one more covered member, or infeasible from now on: its leftover re-picks
-                    if (status[q2] == LS_UNDECIDED && cand[k2].covered == joined) {
-                        const uint32_t id = leftover[q2];
+            // the subscribers after the cursor, APPLY_SUBS per thread and step: a subscriber is a chain of dependent gathers (list
+            // entry -> status and candidate entry -> its id -> the table), and with one per thread the workgroup waits for memory
+            // at every link of every 256 subscribers (popular clusters have thousands)
+            for (uint32_t s0 = sb; s0 < se; s0 += 256 * APPLY_SUBS) {   // workgroup-uniform: the ballots need whole waves
+                unsigned long long sub[APPLY_SUBS];
+                bool live[APPLY_SUBS];
+#pragma unroll
+                for (int u = 0; u < APPLY_SUBS; u++) {
+                    const uint32_t s2 = s0 + (uint32_t)u * 256 + threadIdx.x;
+                    live[u] = s2 < se;
+                    sub[u] = live[u] ? subs[s2] : 0ull;
+                }
+                // only a feasible entry matters (covered == joined; joined + 1 once an earlier chunk has counted y), and it
+                // changes either way -- one more covered member, or infeasible from now on: its leftover re-picks
+#pragma unroll
+                for (int u = 0; u < APPLY_SUBS; u++)
+                    live[u] = live[u] && status[(uint32_t)(sub[u] >> 32)] == LS_UNDECIDED && cand[(uint32_t)sub[u]].covered == joined;
+                uint32_t ids[APPLY_SUBS];
+#pragma unroll
+                for (int u = 0; u < APPLY_SUBS; u++) ids[u] = live[u] ? leftover[(uint32_t)(sub[u] >> 32)] : 0u;
+#pragma unroll
+                for (int u = 0; u < APPLY_SUBS; u++) {
+                    bool mark = false;
+                    const uint32_t q2 = (uint32_t)(sub[u] >> 32), k2 = (uint32_t)sub[u];
+                    if (live[u]) {
+                        const uint32_t id = ids[u];
                         uint32_t sl = (id * 2654435761u) >> 19;
                         for (;;) {
                             const uint32_t kk = keys[sl];
@@ -1124,14 +1142,14 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                         }
                         if (first_chunk) mark = atomicExch(&dirty[q2], 1u) == 0u;
                     }
-                }
-                if (first_chunk) {                               // next round's eval list, one atomic per wave
-                    const uint64_t m = __ballot(mark);
-                    if (m) {
-                        uint32_t base = 0;
-                        if (lane == 0) base = atomicAdd(&counters[4 + (which ^ 1u)], (uint32_t)__popcll(m));
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        if (mark) next_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = q2;
+                    if (first_chunk) {                           // next round's eval list, one atomic per wave
+                        const uint64_t m = __ballot(mark);
+                        if (m) {
+                            uint32_t base = 0;
+                            if (lane == 0) base = atomicAdd(&counters[4 + (which ^ 1u)], (uint32_t)__popcll(m));
+                            base = __builtin_amdgcn_readfirstlane(base);
+                            if (mark) next_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = q2;
+                        }
                     }
                 }
             }
