@@ -230,6 +230,13 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     std::vector<uint32_t> win_rows;                    // the window's FREE positions
     uint32_t win_lo = 0, win_hi = 0;
     std::atomic<uint32_t> gen{0}, cursor{0}, finished{0};
+    // A worker that notices a generation late must not walk into the NEXT window's set-up (win_rows, win_lo / win_hi, the
+    // cursor are plain data rewritten by this thread): a generation is open while its scans run; the main thread closes it and
+    // waits until every worker that has entered has left (entered == left) before it touches the window again; a worker that
+    // enters after the close sees that and leaves at once.  (Dekker-style: both sides use sequentially consistent operations,
+    // so either the worker's entry is seen here or the close is seen there.)
+    std::atomic<uint32_t> open_gen{0};
+    std::atomic<uint64_t> entered{0}, left{0};
     std::atomic<bool> quit{false};
     auto run_window = [&](unsigned t) {
         for (;;) {
@@ -252,7 +259,9 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     if (++spins > 2000) { std::this_thread::yield(); spins = 0; }
                 }
                 seen = g;
-                run_window(t);
+                entered.fetch_add(1, std::memory_order_seq_cst);
+                if (open_gen.load(std::memory_order_seq_cst) == g) run_window(t);
+                left.fetch_add(1, std::memory_order_seq_cst);
             }
         });
     struct PoolGuard {   // joins on every way out of the function (crash parity returns early)
@@ -286,9 +295,18 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             if (state[x] == ST_FREE) win_rows.push_back(x);
         cursor.store(0, std::memory_order_relaxed);
         finished.store(0, std::memory_order_relaxed);
-        if (T > 1 && win_rows.size() > 1) gen.fetch_add(1, std::memory_order_release);
+        const bool shared = T > 1 && win_rows.size() > 1;
+        if (shared) {
+            const uint32_t g = gen.load(std::memory_order_relaxed) + 1;
+            open_gen.store(g, std::memory_order_seq_cst);
+            gen.store(g, std::memory_order_release);
+        }
         run_window(0);
         while (finished.load(std::memory_order_acquire) < win_rows.size()) { }
+        if (shared) {   // close the generation and let the workers that are inside leave (their cursor is exhausted)
+            open_gen.store(0, std::memory_order_seq_cst);
+            while (left.load(std::memory_order_seq_cst) != entered.load(std::memory_order_seq_cst)) { }
+        }
         const auto tc = p1_now();
         p1_scan += std::chrono::duration<double, std::milli>(tc - ts).count();
         p1_windows++;
