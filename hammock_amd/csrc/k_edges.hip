@@ -378,17 +378,22 @@ k_lower_place_sorted(const uint64_t *__restrict__ recs, const unsigned long long
         for (int q = 0; q < PER; q++)
             if (rec[q] != ~0ull) rk[q] = atomicAdd(&hist[(uint32_t)(rec[q] >> 32) - row0], 1u);
         __syncthreads();
-        // exclusive scan of hist over the 512 rows (one per thread)
-        uint32_t own = hist[t];
-        scan[0][t] = own;
-        __syncthreads();
-        int src = 0;
-        for (uint32_t d = 1; d < LP_ROWS; d <<= 1) {
-            scan[src ^ 1][t] = scan[src][t] + (t >= d ? scan[src][t - d] : 0u);
-            src ^= 1;
-            __syncthreads();
+        // exclusive scan of hist over the 512 rows (one per thread): inside a wave by shuffles, across the 8 waves through 8
+        // LDS words -- two barriers instead of the ten of a workgroup-wide doubling scan (a batch is a dozen barrier-to-barrier
+        // phases of a microsecond each, and that, not bandwidth, is what this kernel's time is made of)
+        const uint32_t own = hist[t];
+        uint32_t incl = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((int)(t & 63u) >= d) incl += v;
         }
-        offs[t] = scan[src][t] - own;
+        if ((t & 63u) == 63u) scan[0][t >> 6] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < LP_ROWS / 64; w++) before += w < (t >> 6) ? scan[0][w] : 0u;
+        offs[t] = before + incl - own;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PER; q++)
