@@ -177,6 +177,40 @@ int need_device(hmk_ctx *ctx) {
     return HMK_OK;
 }
 
+// std::stable_sort's result on several threads: contiguous runs sorted on their own, then merged pairwise (std::merge takes
+// from the left run on ties)
+template <class T, class Cmp>
+void parallel_stable_sort(std::vector<T> &v, Cmp before) {
+    const size_t n = v.size();
+    const unsigned hw = std::thread::hardware_concurrency();
+    size_t runs = 1;
+    while (runs < 8 && runs < (hw ? hw : 1u) && n / (2 * runs) >= 32768) runs *= 2;
+    if (runs == 1) { std::stable_sort(v.begin(), v.end(), before); return; }
+    std::vector<size_t> cut(runs + 1);
+    for (size_t r = 0; r <= runs; r++) cut[r] = n * r / runs;
+    {
+        std::vector<std::thread> pool;
+        for (size_t r = 1; r < runs; r++) pool.emplace_back([&, r] { std::stable_sort(v.begin() + (long)cut[r], v.begin() + (long)cut[r + 1], before); });
+        std::stable_sort(v.begin(), v.begin() + (long)cut[1], before);
+        for (std::thread &th : pool) th.join();
+    }
+    std::vector<T> other(n);
+    std::vector<T> *from = &v, *to = &other;
+    for (size_t width = 1; width < runs; width *= 2) {
+        std::vector<std::thread> pool;
+        for (size_t r = 0; r < runs; r += 2 * width) {
+            auto job = [&, r] {
+                std::merge(from->begin() + (long)cut[r], from->begin() + (long)cut[r + width], from->begin() + (long)cut[r + width],
+                           from->begin() + (long)cut[r + 2 * width], to->begin() + (long)cut[r], before);
+            };
+            if (r + 2 * width < runs) pool.emplace_back(job); else job();
+        }
+        for (std::thread &th : pool) th.join();
+        std::swap(from, to);
+    }
+    if (from != &v) v.swap(other);
+}
+
 void free_plan(Plan &pl) {
     if (pl.d_res_sorted) (void)hipFree(pl.d_res_sorted);
     if (pl.d_perm) (void)hipFree(pl.d_perm);
@@ -487,13 +521,14 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         if (kv.second.empty()) continue;
         // workgroups are dispatched in tile order: biggest tiles first keeps the tail of the launch short
         // (band tiles first: they are launched on their own by hmk_greedy_cluster)
+        // (10^6 sequences: a million tiles; the stable sort of them was 30 of the plan's 55 ms on one thread)
         if (getenv("HMK_NO_LPT") == nullptr)
-            std::stable_sort(kv.second.begin(), kv.second.end(), [](const Tile &a, const Tile &b) {
+            parallel_stable_sort(kv.second, [](const Tile &a, const Tile &b) {
                 if (a.pad0 != b.pad0) return a.pad0 > b.pad0;
                 return (uint64_t)a.nrows * a.ncols > (uint64_t)b.nrows * b.ncols;
             });
         else
-            std::stable_sort(kv.second.begin(), kv.second.end(), [](const Tile &a, const Tile &b) { return a.pad0 > b.pad0; });
+            parallel_stable_sort(kv.second, [](const Tile &a, const Tile &b) { return a.pad0 > b.pad0; });
         uint32_t n_band = 0;
         for (const Tile &t : kv.second) n_band += t.pad0;
         pl.groups.push_back(Group{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),
@@ -505,10 +540,20 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
 
     // ---- device copies ------------------------------------------------------------
     std::vector<uint8_t> res_sorted((size_t)n * pl.lpad + 16, 0);   // + 16: the row-packed kernel's unaligned tail loads may touch the bytes after the last row
-    for (uint32_t s = 0; s < n; s++) {
-        const uint32_t k = perm[s];
-        for (uint32_t q = 0; q < ctx->len[k]; q++)
-            res_sorted[(size_t)s * pl.lpad + q] = (uint8_t)(ctx->res[ctx->off[k] + q] * (pl.exact ? 8 : 1));
+    {   // (rows are independent: several threads for large sets -- 10 ms on one at 10^6)
+        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned T = n >= (1u << 18) ? std::max(1u, std::min(8u, hw ? hw : 1u)) : 1u;
+        auto fill = [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t s = lo; s < hi; s++) {
+                const uint32_t k = perm[s];
+                for (uint32_t q = 0; q < ctx->len[k]; q++)
+                    res_sorted[(size_t)s * pl.lpad + q] = (uint8_t)(ctx->res[ctx->off[k] + q] * (pl.exact ? 8 : 1));
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; t++) pool.emplace_back(fill, (uint32_t)((uint64_t)n * t / T), (uint32_t)((uint64_t)n * (t + 1) / T));
+        fill(0, (uint32_t)((uint64_t)n / T));
+        for (std::thread &th : pool) th.join();
     }
     const int bias = ctx->min_m < 0 ? -ctx->min_m : 0;
     uint8_t mb[576];
