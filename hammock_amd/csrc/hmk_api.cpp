@@ -177,6 +177,21 @@ int need_device(hmk_ctx *ctx) {
     return HMK_OK;
 }
 
+// The 32-byte-per-sequence copy of the residues (and the lengths) that the one-pair and block scorers index: built and
+// uploaded at their first use -- the neighbour passes and the clustering calls never read it (they use the plan's sorted
+// copy), and at 10^6 sequences it is 32 MB to build and send in every hmk_set_sequences.
+int ensure_res32(hmk_ctx *ctx) {
+    if (ctx->d_res32 || ctx->n == 0) return HMK_OK;
+    const uint32_t n = ctx->n;
+    std::vector<uint8_t> res32((size_t)n * 32, 0);
+    for (uint32_t k = 0; k < n; k++) std::memcpy(&res32[(size_t)k * 32], ctx->res.data() + ctx->off[k], ctx->len[k]);
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_res32, res32.size()));
+    HIPCHK(ctx, hipMemcpy(ctx->d_res32, res32.data(), res32.size(), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_len, n));
+    HIPCHK(ctx, hipMemcpy(ctx->d_len, ctx->len.data(), n, hipMemcpyHostToDevice));
+    return HMK_OK;
+}
+
 // std::stable_sort's result on several threads: contiguous runs sorted on their own, then merged pairwise (std::merge takes
 // from the left run on ties)
 template <class T, class Cmp>
@@ -881,6 +896,8 @@ int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, 
     st = check_pairs(ctx, i, j, n_pairs, scorer == 0, a);
     if (st) return st;
     if (n_pairs && !out) return fail(ctx, HMK_ERR_BAD_ARG, "null output");
+    st = ensure_res32(ctx);
+    if (st) return st;
     const uint64_t CH = 1ull << 24;
     uint32_t *d_i = nullptr, *d_j = nullptr;
     int32_t *d_out = nullptr, *d_shift = nullptr;
@@ -928,6 +945,10 @@ int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0,
         if (a >= mn)
             return fail(ctx, HMK_ERR_SHIFT_TOO_BIG, "Shift too big: " + std::to_string(mn - 1) + " is maximum, but " +
                                                         std::to_string(a) + " found");
+    }
+    {
+        const int st32 = ensure_res32(ctx);
+        if (st32) return st32;
     }
     int32_t *d_out = nullptr;
     HIPCHK(ctx, hipMalloc((void **)&d_out, n_pairs * 4));
@@ -1092,8 +1113,21 @@ int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *off
         if (sizes && sizes[k] < 1) return fail(ctx, HMK_ERR_BAD_ARG, "sizes must be >= 1");
     }
     const uint32_t total = n ? offsets[n] : 0;
-    for (uint32_t q = 0; q < total; q++)
-        if (residues[q] >= HMK_ALPHABET) return fail(ctx, HMK_ERR_BAD_ARG, "residue index >= 24");
+    {   // (12 MB at 10^6 sequences: several threads)
+        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned T = total >= (1u << 22) ? std::max(1u, std::min(8u, hw ? hw : 1u)) : 1u;
+        std::atomic<bool> bad{false};
+        auto check = [&](uint32_t lo, uint32_t hi) {
+            uint8_t worst = 0;
+            for (uint32_t q = lo; q < hi; q++) worst = std::max(worst, residues[q]);
+            if (worst >= HMK_ALPHABET) bad.store(true);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < T; t++) pool.emplace_back(check, (uint32_t)((uint64_t)total * t / T), (uint32_t)((uint64_t)total * (t + 1) / T));
+        check(0, (uint32_t)((uint64_t)total / T));
+        for (std::thread &th : pool) th.join();
+        if (bad.load()) return fail(ctx, HMK_ERR_BAD_ARG, "residue index >= 24");
+    }
     if (ctx->has_device) {
         int st = need_device(ctx);
         if (st) return st;
@@ -1103,14 +1137,7 @@ int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *off
         if (ctx->d_len) (void)hipFree(ctx->d_len);
         ctx->d_res32 = nullptr;
         ctx->d_len = nullptr;
-        if (n) {
-            std::vector<uint8_t> res32((size_t)n * 32, 0);
-            for (uint32_t k = 0; k < n; k++) std::memcpy(&res32[(size_t)k * 32], residues + offsets[k], len[k]);
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_res32, res32.size()));
-            HIPCHK(ctx, hipMemcpy(ctx->d_res32, res32.data(), res32.size(), hipMemcpyHostToDevice));
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_len, n));
-            HIPCHK(ctx, hipMemcpy(ctx->d_len, len.data(), n, hipMemcpyHostToDevice));
-        }
+        // (the padded copy the pair / block scorers read is made at their first use: ensure_res32)
     }
     ctx->n = n;
     ctx->res.assign(residues, residues + total);
