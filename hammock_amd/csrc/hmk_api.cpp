@@ -626,7 +626,9 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     P.symmetric = ctx->symmetric ? 1u : 0u;
     P.deg = d_rank ? nullptr : d_deg;
     P.deg_up = d_rank ? d_deg : nullptr;
-    P.deg_lo = d_deg_lo;
+    P.deg_lo = d_rank ? d_deg_lo : nullptr;
+    P.deg_m_offset = (!d_rank && d_deg && d_deg_lo) ? (uint32_t)(d_deg_lo - d_deg) : 0u;   // counting mode with split counters
+    P.pad_deg = 0;
     P.rank = d_rank;
     // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has a dozen of
     // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
@@ -1449,6 +1451,7 @@ struct EdgeSource {
     bool deg_fused = false;            // the neighbour kernel placed the edges itself: SB_CURSOR holds the rows' upper | lower counters
                                        // (zeroed before the pass), SB_RANK every edge's ranks (parallel to the buffer at edges0)
     const uint64_t *edges0 = nullptr;
+    bool deg_split = false;            // deg_fused without ranks: SB_DEG holds upper counts [0, n) and lower counts [n, 2n) instead of totals
     bool placed = false;               // deg_fused with ranks (else deg_fused = SB_DEG holds the rows' total degrees, counted by the pass)
     hmk_clinkage_stats *clink = nullptr;   // non-null: run the clinkage nearest-neighbour chain instead of the greedy merge
     // multi-device calls: the peers' blocks arrive while the calling thread is already inside cluster_on_device.
@@ -1515,7 +1518,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             if (e == hipSuccess) e = ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes());
             if (e == hipSuccess)
                 e = launch_csr_scatter_partitioned(src.segs, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
-                                                   base, n, buf<uint64_t>(ctx, SB_PART), buf<void>(ctx, SB_PARTSCR), S);
+                                                   base, n, buf<uint64_t>(ctx, SB_PART), buf<void>(ctx, SB_PARTSCR),
+                                                   src.deg_fused && src.deg_split ? buf<uint32_t>(ctx, SB_DEG) + n : nullptr, S);
             if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
             return e;
         }
@@ -1534,8 +1538,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                              buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S))) != hipSuccess) return e_;
         } else if (src.deg_fused) {
             if ((e_ = (hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S))) != hipSuccess) return e_;
-            if ((e_ = (launch_csr_scan_only(buf<uint32_t>(ctx, SB_DEG), nullptr, buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN),
-                                             buf<int>(ctx, SB_RANGE), S))) != hipSuccess) return e_;
+            if ((e_ = (launch_csr_scan_only(buf<uint32_t>(ctx, SB_DEG), src.deg_split ? buf<uint32_t>(ctx, SB_DEG) + n : nullptr,
+                                             buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S))) != hipSuccess) return e_;
         } else {
             if ((e_ = (hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S))) != hipSuccess) return e_;
             if ((e_ = (hipMemsetAsync(buf<void>(ctx, SB_DEG), 0, (size_t)n * 4, S))) != hipSuccess) return e_;
@@ -2068,7 +2072,7 @@ int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, boo
     }
     const bool late = late_on_a_thread || late_buffers_pending(ctx);   // (pending: the call's CSR step joins the thread and checks the sizes)
     if (!late) HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, adj_bytes));
-    HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 8));   // (upper and lower counts of the fused pass)
     HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
     HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
     HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
@@ -2245,9 +2249,15 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
             d_rank = buf<uint32_t>(ctx, SB_RANK);
             HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * 8, S));
         } else if (fuse) {
-            HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
+            // symmetric: the smaller end counts into up[], the larger into lo[] -- the same number of atomics as one total per
+            // row, and the lower counts give the bucket sizes of the CSR's dealing pass without a pass over the edges
+            // (k_lower_count, 2 ms at 10^6).  HMK_NO_SPLIT_DEGREE=1: one counter per row.
+            const bool split = ctx->symmetric && getenv("HMK_NO_SPLIT_DEGREE") == nullptr;
+            HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * (split ? 8 : 4)));
             d_deg = buf<uint32_t>(ctx, SB_DEG);
-            HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * 4, S));
+            d_deg_lo = split ? d_deg + n : nullptr;
+            HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * (split ? 8 : 4), S));
+            src.deg_split = split;
         }
         src.deg_fused = fuse;
         src.placed = place;

@@ -180,7 +180,7 @@ __device__ __forceinline__ void place_edge(const NeighborParams &P, unsigned lon
         reinterpret_cast<uint2 *>(P.rank)[slot] = make_uint2(rx, rm);
     } else if (MODE == EDGES_COUNT || (MODE == EDGES_RUNTIME && P.deg)) {   // counting only (deg = the rows' total degrees): fire-and-forget atomics
         atomicAdd(&P.deg[x], 1u);
-        if (P.symmetric) atomicAdd(&P.deg[m], 1u);
+        if (P.symmetric) atomicAdd(&P.deg[P.deg_m_offset + m], 1u);
     }
 }
 

@@ -62,7 +62,9 @@ struct NeighborParams {
     // position.  The scatter that follows needs no atomics and no pass that counts degrees.  rank == null: deg[] just counts
     // the rows' total degrees (both ends of a symmetric edge), with fire-and-forget atomics -- at 10^6 the 2.5 x 10^9 returning
     // atomics cost the pass 10 % and the scatter there is bound by its random writes, not by its atomics.
-    uint32_t *deg;       // counting mode: total degrees
+    uint32_t *deg;       // counting mode: total degrees -- or, with deg_m_offset = n, upper counts in deg[0, n) and lower counts in deg[n, 2n)
+    uint32_t deg_m_offset;   // counting mode: the larger end m of an edge counts into deg[deg_m_offset + m] (0: one counter per row)
+    uint32_t pad_deg;
     uint32_t *deg_up;    // placing mode: the rows' upper counters ...
     uint32_t *deg_lo;    // ... and lower counters (symmetric only)
     uint32_t *rank;      // placing mode (else null)

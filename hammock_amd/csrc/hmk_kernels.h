@@ -58,7 +58,7 @@ size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scrat
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)
 size_t csr_partition_scratch_bytes();
 hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *start, uint32_t *cursor, void *adj, int base, uint32_t n,
-                                          uint64_t *recs, void *scratch, hipStream_t s);
+                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, hipStream_t s);
 hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
                               bool packed, int base, uint32_t row_limit, hipStream_t s);
 

@@ -261,8 +261,8 @@ struct RowsFlushArgs {
     unsigned long long *counts;
     uint64_t cap_per_shard;
     uint32_t *deg, *deg_up, *deg_lo, *rank;
-    uint32_t lpad, symmetric, perm_identity, row0, col0, shard, tab_addr;
-    int lbs, threshold;
+    uint32_t lpad, symmetric, perm_identity, row0, col0, shard, tab_addr, deg_m_offset;
+    int lbs, threshold, pad_;
     uint32_t cinit[8];   // TileClass::cinit: one byte per shift, the lanes' initial value
 };
 static_assert(sizeof(RowsFlushArgs) % 8 == 0, "LDS map");
@@ -343,7 +343,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
                 reinterpret_cast<uint2 *>(A.rank)[slot] = make_uint2(rx, rm);
             } else if (MODE == EDGES_COUNT) {
                 atomicAdd(&A.deg[x], 1u);
-                if (A.symmetric) atomicAdd(&A.deg[m], 1u);
+                if (A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
             }
         }
     }
@@ -390,7 +390,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     const uint32_t tab_addr = lds_addr(tab);
     if (tid == 0) {
         RowsFlushArgs a{P.res_sorted, P.perm, Cp, P.edges, P.counts, P.cap_per_shard, P.deg, P.deg_up, P.deg_lo, P.rank,
-                        P.lpad, P.symmetric, P.perm_identity, T.row0, T.col0, shard, tab_addr, lbs, threshold, {0}};
+                        P.lpad, P.symmetric, P.perm_identity, T.row0, T.col0, shard, tab_addr, P.deg_m_offset, lbs, threshold, 0, {0}};
 #pragma unroll
         for (int q = 0; q < 8; q++) a.cinit[q] = Cp->cinit[q];
         *fargs = a;

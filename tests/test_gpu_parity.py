@@ -558,7 +558,8 @@ def test_greedy_adjacency_formats(gpu, blosum62, coracle, monkeypatch):
                                  {"HMK_PLACE_EDGES": "0", "HMK_CSR_BY_BUCKET": "1", "HMK_NO_BAND": "1", "HMK_CSR_PARTITION_GRID": "3"},
                                  {"HMK_PLACE_EDGES": "0", "HMK_CSR_BY_BUCKET": "1", "HMK_CSR_PLACE_UNSORTED": "1"},
                                  {"HMK_CSR_BUCKET_SHIFT": "11"}, {"HMK_CSR_BUCKET_SHIFT": "12", "HMK_CSR_PARTITION_GRID": "2"},
-                                 {"HMK_CSR_FUSED_UPPER": "0"}, {"HMK_CSR_FUSED_UPPER": "0", "HMK_NO_FUSED_DEGREE": "1"}])
+                                 {"HMK_CSR_FUSED_UPPER": "0"}, {"HMK_CSR_FUSED_UPPER": "0", "HMK_NO_FUSED_DEGREE": "1"},
+                                 {"HMK_NO_SPLIT_DEGREE": "1"}, {"HMK_NO_SPLIT_DEGREE": "1", "HMK_CSR_BY_BUCKET": "0"}])
 @pytest.mark.parametrize("cfg", [(21, 24000, 12, 12, 0, True), (22, 9000, 7, 20, -1, True), (23, 6000, 12, 12, 0, False)])
 def test_greedy_csr_construction_modes(gpu, blosum62, coracle, monkeypatch, env, cfg):
     """Three ways to the same CSR: the neighbour pass places every edge as it writes it (two rank counters per row,
