@@ -311,23 +311,47 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
                 hist[b] = 0;
             }
             __syncthreads();
+            // LB_WB edges of the thread at a time: first every returning atomic (the upper sections' row cursors, one per distinct x
+            // of the wave) and every start[x] load of the batch is ISSUED, then the entries are written -- one edge after the other
+            // (atomic -> wait -> load -> wait -> store, 16 times) the write phase was 16 dependent memory round trips per chunk
+            constexpr int LB_WB = LB_LOADS < 8 ? LB_LOADS : 8;
+            static_assert(LB_LOADS % LB_WB == 0, "write batches");
 #pragma unroll
-            for (int q = 0; q < LB_LOADS; q++) {
-                const uint64_t e = ev[q];
-                const bool ok = lower_record_ok(e, n);
-                const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)), m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
-                const uint32_t rel = (uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu;
+            for (int q0 = 0; q0 < LB_LOADS; q0 += LB_WB) {
+                uint32_t basex[LB_WB], lr[LB_WB];
+                uint64_t st[LB_WB];
                 if (UPPER) {   // (whole waves: wave_groups needs all 64 lanes; a wave's edges come from a handful of rows)
-                    const WaveGroup g = wave_groups(x, ok);   // one atomic per distinct x of the wave
-                    uint32_t basex = 0;
-                    if (ok && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
-                    basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
-                    if (ok) adj[start[x] + basex + g.rank] = NbrPacked{(m << 8) | rel};
+#pragma unroll
+                    for (int u = 0; u < LB_WB; u++) {
+                        const uint64_t e = ev[q0 + u];
+                        const bool ok = lower_record_ok(e, n);
+                        const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e));
+                        const WaveGroup g = wave_groups(x, ok);   // one atomic per distinct x of the wave
+                        basex[u] = 0;
+                        if (ok && g.rank == 0) basex[u] = atomicAdd(&cursor[x], g.size);
+                        st[u] = ok ? start[x] : 0ull;
+                        lr[u] = g.leader | g.rank << 8;
+                    }
+#pragma unroll
+                    for (int u = 0; u < LB_WB; u++) {
+                        const uint64_t e = ev[q0 + u];
+                        const bool ok = lower_record_ok(e, n);
+                        const uint32_t m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
+                        const uint32_t rel = (uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu;
+                        const uint32_t bx = (uint32_t)__shfl((int)basex[u], (int)(lr[u] & 0xFFu), 64);
+                        if (ok) adj[st[u] + bx + (lr[u] >> 8)] = NbrPacked{(m << 8) | rel};
+                    }
                 }
-                if (!ok) continue;
-                const uint32_t b = m >> shift;
-                const uint32_t at = first[b] + atomicAdd(&hist[b], 1u);
-                recs[bucket_off[b] + at] = ((uint64_t)m << 32) | (uint64_t)((x << 8) | rel);
+#pragma unroll
+                for (int u = 0; u < LB_WB; u++) {
+                    const uint64_t e = ev[q0 + u];
+                    if (!lower_record_ok(e, n)) continue;
+                    const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)), m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
+                    const uint32_t rel = (uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu;
+                    const uint32_t b = m >> shift;
+                    const uint32_t at = first[b] + atomicAdd(&hist[b], 1u);
+                    recs[bucket_off[b] + at] = ((uint64_t)m << 32) | (uint64_t)((x << 8) | rel);
+                }
             }
             __syncthreads();
             g += gridDim.x;
