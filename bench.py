@@ -298,8 +298,9 @@ def main():
     # An idle MI355X needs about 25 ms of load to reach its clocks (tools/probes/warmup.sh: 20 timed steps after 3 / 5 / 10 / 20
     # untimed ones take 2.60 / 2.58 / 2.53 / 2.53 ms each): SETTLE_STEPS untimed passes first, then the W warm-up steps the
     # contract asks for, then exactly K timed steps.  Reported in the line as "settle_steps".
-    for _ in range(SETTLE_STEPS):
-        step()
+    for _ in range(SETTLE_STEPS):   # (this rank's scoring pass alone: the clocks are what settles, the exchange of N > 1 has no part in it)
+        score_pass()
+    torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     if px is not None:
