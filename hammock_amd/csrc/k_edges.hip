@@ -600,6 +600,12 @@ k_rows_unpack(const uint32_t *__restrict__ start, const uint32_t *__restrict__ a
 // clusters are counted in a per-wave LDS hash table (key = cluster, count, min score); a row with more distinct clusters
 // than the table takes is walked once per class of clusters (see the kernel); only beyond 64 classes does it raise
 // *overflow (the host then runs its own pre-check).
+#ifndef HMK_PRE_WAVES
+#define HMK_PRE_WAVES 2
+#endif
+// waves (= leftovers in flight) per workgroup of the pre-check: a wave's tables are 14 KB, so 4 / 2 / 1 waves per workgroup put
+// 8 / 10 / 11 waves on a CU: 14.9 / 12.8 / 12.6 ms at 10^6 (22.3 / 19.4 in the reference's default order), no difference at 10^5
+constexpr int PRE_WAVES = HMK_PRE_WAVES;
 #ifndef HMK_PRE_UNROLL
 #define HMK_PRE_UNROLL 16
 #endif
@@ -638,7 +644,7 @@ enum { PRE_COUNT = 0, PRE_FILL = 1, PRE_SINGLE = 2 };
 constexpr uint32_t PRE_REGIONS = 256;
 
 template <class NbrT, int MODE, int SLOTS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * PRE_WAVES)
 k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict__ work_count, uint32_t *__restrict__ retry,
                   uint32_t *__restrict__ retry_count,
                   const uint64_t *__restrict__ start, const NbrT *__restrict__ adj, const int32_t *__restrict__ cluster_of,
@@ -646,11 +652,11 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
                   const int32_t *__restrict__ usize, const uint32_t *__restrict__ leftover, uint32_t nl,
                   uint32_t *__restrict__ cand_cnt, uint32_t *__restrict__ cand_start, GreedyCand *__restrict__ cand,
                   uint32_t *__restrict__ overflow, unsigned long long *__restrict__ total, unsigned long long capacity) {
-    __shared__ int32_t keys_all[4 * SLOTS];
-    __shared__ uint32_t cnt_all[4 * SLOTS];
-    __shared__ int32_t mn_all[4 * SLOTS];
-    __shared__ uint16_t used_all[4 * SLOTS];
-    __shared__ uint32_t n_used_all[4];
+    __shared__ int32_t keys_all[PRE_WAVES * SLOTS];
+    __shared__ uint32_t cnt_all[PRE_WAVES * SLOTS];
+    __shared__ int32_t mn_all[PRE_WAVES * SLOTS];
+    __shared__ uint16_t used_all[PRE_WAVES * SLOTS];
+    __shared__ uint32_t n_used_all[PRE_WAVES];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int32_t *keys = keys_all + wv * SLOTS;
     uint32_t *cnt = cnt_all + wv * SLOTS;
@@ -663,7 +669,7 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
     const uint32_t n_work = work ? *work_count : nl;
     constexpr uint32_t HASH_SHIFT = SLOTS == 1024 ? 22 : SLOTS == 512 ? 23 : SLOTS == 256 ? 24 : 25;
     static_assert(SLOTS == 1024 || SLOTS == 512 || SLOTS == 256 || SLOTS == 128, "table sizes");
-    for (uint32_t w = blockIdx.x * 4 + wv; w < n_work; w += gridDim.x * 4) {
+    for (uint32_t w = blockIdx.x * PRE_WAVES + wv; w < n_work; w += gridDim.x * PRE_WAVES) {
         const uint32_t q = work ? work[w] : w;
         const uint32_t y = leftover[q];
         const uint64_t b = start[y], e = start[y + 1];
@@ -1350,11 +1356,12 @@ hipError_t launch_greedy_precheck(int mode, bool packed, const uint64_t *start, 
                                   uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, unsigned long long *total,
                                   unsigned long long capacity, uint32_t *retry, uint32_t *retry_count, int first_stage_slots, hipStream_t s) {
     if (nl == 0) return hipSuccess;
-    const dim3 block(256);
+    const dim3 block(64 * PRE_WAVES);
 #define HMK_PRE(T, F, SL, GRID, WORK, WCNT, RETRY, RCNT)                                                                              \
     hipLaunchKernelGGL((k_greedy_precheck<T, F, SL>), dim3(GRID), block, 0, s, WORK, WCNT, RETRY, RCNT, start, (const T *)adj, cluster_of, \
                        in_cluster, usize, leftover, nl, cand_cnt, cand_start, cand, overflow, total, capacity)
-    const uint32_t grid_big = std::min<uint32_t>((nl + 3) / 4, 256 * 12), grid_small = std::min<uint32_t>((nl + 3) / 4, 256 * 32);
+    const uint32_t grid_big = std::min<uint32_t>((nl + PRE_WAVES - 1) / PRE_WAVES, 256 * 12 * 4 / PRE_WAVES),
+                   grid_small = std::min<uint32_t>((nl + PRE_WAVES - 1) / PRE_WAVES, 256 * 32 * 4 / PRE_WAVES);
     if (mode == PRE_SINGLE && retry) {
         // two stages: small tables for every leftover, the full-size ones for the rows that did not fit (their number is only
         // known on the device: the second launch is sized for all of them and reads the count)
