@@ -609,7 +609,10 @@ constexpr int PRE_WAVES = HMK_PRE_WAVES;
 #ifndef HMK_PRE_UNROLL
 #define HMK_PRE_UNROLL 16
 #endif
-constexpr int PRE_SLOTS = 1024;   // per wave; 14 KB of tables.  (PRE_SLOTS_SMALL: the first stage of the single pass, see below)
+#ifndef HMK_PRE_SLOTS
+#define HMK_PRE_SLOTS 1024
+#endif
+constexpr int PRE_SLOTS = HMK_PRE_SLOTS;   // per wave; 14 KB of tables.  (PRE_SLOTS_SMALL: the first stage of the single pass, see below)
 constexpr int PRE_SLOTS_SMALL = 128, PRE_SLOTS_MEDIUM = 512;
 
 __device__ __forceinline__ uint32_t nbr_id(const Nbr &a) { return a.m; }
