@@ -1090,20 +1090,37 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
               const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status, const uint32_t *__restrict__ choice,
               const uint32_t *__restrict__ first, uint32_t *__restrict__ taken, uint32_t stamp,
               uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot, uint32_t *__restrict__ counters) {
+    __shared__ uint32_t n_here, base_here;
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_clusters) return;
-    const uint32_t q = first[c];
-    if (q == 0xFFFFFFFFu || taken[c] == stamp) return;
-    const GreedyCand pick = cand[choice[q]];
-    if ((uint32_t)pick.c != c) return;                     // q picks another cluster (that cluster's thread looks at it)
-    for (uint32_t k = cand_start[q], ke = k + cand_cnt[q]; k < ke; k++) {
-        const GreedyCand cd = cand[k];
-        if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && (first[cd.c] != q || taken[cd.c] == stamp)) return;   // a tie that may still grow
+    if (threadIdx.x == 0) n_here = 0;
+    __syncthreads();
+    uint32_t q = 0xFFFFFFFFu;
+    bool accept = false;
+    GreedyCand pick{0, 0, 0};
+    if (c < n_clusters) {
+        q = first[c];
+        if (q != 0xFFFFFFFFu && taken[c] != stamp) {
+            pick = cand[choice[q]];
+            accept = (uint32_t)pick.c == c;                // (else q picks another cluster: that cluster's thread looks at it)
+            if (accept)
+                for (uint32_t k = cand_start[q], ke = k + cand_cnt[q]; k < ke; k++) {
+                    const GreedyCand cd = cand[k];
+                    if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && (first[cd.c] != q || taken[cd.c] == stamp)) { accept = false; break; }   // a tie that may still grow
+                }
+        }
     }
-    status[q] = LS_JOINED;                                 // :61-62
-    join_slot[q] = pick.c;
-    taken[c] = stamp;
-    accepted[atomicAdd(&counters[1], 1u)] = q;
+    // the round's list of joins: one global atomic per workgroup (one per join was up to 4,000 returning atomics on one address)
+    uint32_t at = 0;
+    if (accept) at = atomicAdd(&n_here, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && n_here) base_here = atomicAdd(&counters[1], n_here);
+    __syncthreads();
+    if (accept) {
+        status[q] = LS_JOINED;                             // :61-62
+        join_slot[q] = pick.c;
+        taken[c] = stamp;
+        accepted[base_here + at] = q;
+    }
 }
 
 // One workgroup per accepted join (y -> c): y's later neighbours go into an LDS hash table, chunk by chunk, and the
@@ -1125,8 +1142,8 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
              uint32_t *__restrict__ counters, unsigned long long *host_word, uint32_t stamp) {
     __shared__ uint32_t keys[APPLY_SLOTS];
     __shared__ int32_t vals[APPLY_SLOTS];
+    __shared__ uint32_t list_count, list_base;
     const uint32_t n_acc = counters[1];
-    const uint32_t lane = threadIdx.x & 63u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {                     // what the host polls: a round without a join is the end
         counters[3] = n_acc;
         // (n_acc == 0: this kernel changes nothing, so the word may go out before it ends; otherwise the host only uses the
@@ -1159,7 +1176,7 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
             // the subscribers after the cursor, APPLY_SUBS per thread and step: a subscriber is a chain of dependent gathers (list
             // entry -> status and candidate entry -> its id -> the table), and with one per thread the workgroup waits for memory
             // at every link of every 256 subscribers (popular clusters have thousands)
-            for (uint32_t s0 = sb; s0 < se; s0 += 256 * APPLY_SUBS) {   // workgroup-uniform: the ballots need whole waves
+            for (uint32_t s0 = sb; s0 < se; s0 += 256 * APPLY_SUBS) {   // workgroup-uniform (barriers inside)
                 unsigned long long sub[APPLY_SUBS];
                 bool live[APPLY_SUBS];
 #pragma unroll
@@ -1176,9 +1193,9 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                 uint32_t ids[APPLY_SUBS];
 #pragma unroll
                 for (int u = 0; u < APPLY_SUBS; u++) ids[u] = live[u] ? leftover[(uint32_t)(sub[u] >> 32)] : 0u;
+                uint32_t n_marks = 0, marks = 0;                 // this lane's new entries of the next eval list (bit u)
 #pragma unroll
                 for (int u = 0; u < APPLY_SUBS; u++) {
-                    bool mark = false;
                     const uint32_t q2 = (uint32_t)(sub[u] >> 32), k2 = (uint32_t)sub[u];
                     if (live[u]) {
                         const uint32_t id = ids[u];
@@ -1193,16 +1210,24 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                             if (kk == 0xFFFFFFFFu) break;
                             sl = (sl + 1) & (APPLY_SLOTS - 1);
                         }
-                        if (first_chunk) mark = atomicExch(&dirty[q2], 1u) == 0u;
+                        if (first_chunk && atomicExch(&dirty[q2], 1u) == 0u) { marks |= 1u << u; n_marks++; }
                     }
-                    if (first_chunk) {                           // next round's eval list, one atomic per wave
-                        const uint64_t m = __ballot(mark);
-                        if (m) {
-                            uint32_t base = 0;
-                            if (lane == 0) base = atomicAdd(&counters[4 + (which ^ 1u)], (uint32_t)__popcll(m));
-                            base = __builtin_amdgcn_readfirstlane(base);
-                            if (mark) next_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = q2;
-                        }
+                }
+                if (first_chunk) {
+                    // next round's eval list: ONE global atomic per workgroup and step.  (One per wave and subscriber slot was
+                    // 4-5,000 returning atomics on a single address per round, ~25 ns each: most of this kernel's 0.14 ms.)
+                    if (threadIdx.x == 0) list_count = 0;
+                    __syncthreads();
+                    uint32_t at = 0;
+                    if (n_marks) at = atomicAdd(&list_count, n_marks);
+                    __syncthreads();
+                    if (threadIdx.x == 0 && list_count) list_base = atomicAdd(&counters[4 + (which ^ 1u)], list_count);
+                    __syncthreads();
+                    if (n_marks) {
+                        uint32_t w = list_base + at;
+#pragma unroll
+                        for (int u = 0; u < APPLY_SUBS; u++)
+                            if (marks >> u & 1u) next_list[w++] = (uint32_t)(sub[u] >> 32);
                     }
                 }
             }
