@@ -1083,7 +1083,8 @@ k_loop_first(uint32_t n_clusters, const uint32_t *__restrict__ sub_start, const 
     loop_first(blockIdx.x, n_clusters, sub_start, subs, cursor, cand, cl, status, taken, stamp, first);
 }
 
-// one thread per cluster: the leftover at first[c], if c is its pick
+// ACCEPT_LANES lanes per cluster: the leftover at first[c], if c is its pick
+constexpr uint32_t ACCEPT_LANES = 8;
 __global__ void __launch_bounds__(256)
 k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, const uint32_t *__restrict__ cand_cnt,
               const GreedyCand *__restrict__ cand,
@@ -1091,7 +1092,9 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
               const uint32_t *__restrict__ first, uint32_t *__restrict__ taken, uint32_t stamp,
               uint32_t *__restrict__ accepted, int32_t *__restrict__ join_slot, uint32_t *__restrict__ counters) {
     __shared__ uint32_t n_here, base_here;
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    // ACCEPT_LANES lanes per cluster: they share the walk over the leftover's candidate entries (two dependent gathers per entry;
+    // with one thread per cluster the longest list of the round set the kernel's time)
+    const uint32_t c = (blockIdx.x * 256 + threadIdx.x) / ACCEPT_LANES, part = threadIdx.x % ACCEPT_LANES;
     if (threadIdx.x == 0) n_here = 0;
     __syncthreads();
     uint32_t q = 0xFFFFFFFFu;
@@ -1101,14 +1104,22 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
         q = first[c];
         if (q != 0xFFFFFFFFu && taken[c] != stamp) {
             pick = cand[choice[q]];
-            accept = (uint32_t)pick.c == c;                // (else q picks another cluster: that cluster's thread looks at it)
-            if (accept)
-                for (uint32_t k = cand_start[q], ke = k + cand_cnt[q]; k < ke; k++) {
-                    const GreedyCand cd = cand[k];
-                    if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && (first[cd.c] != q || taken[cd.c] == stamp)) { accept = false; break; }   // a tie that may still grow
-                }
+            accept = (uint32_t)pick.c == c;                // (else q picks another cluster: that cluster's lanes look at it)
         }
     }
+    bool blocked = false;                                  // a tie that may still grow
+    if (accept)
+        for (uint32_t k = cand_start[q] + part, ke = cand_start[q] + cand_cnt[q]; k < ke; k += ACCEPT_LANES) {
+            const GreedyCand cd = cand[k];
+            if (cd.mn == pick.mn && cd.covered == cl[cd.c].joined && (first[cd.c] != q || taken[cd.c] == stamp)) { blocked = true; break; }
+        }
+    // (the cluster's lanes sit side by side in one wave: fold their verdicts)
+    {
+        const uint64_t bl = __ballot(blocked);
+        const uint32_t lane = threadIdx.x & 63u, g0 = lane & ~(uint32_t)(ACCEPT_LANES - 1);
+        if ((bl >> g0) & ((1ull << ACCEPT_LANES) - 1ull)) accept = false;
+    }
+    accept = accept && part == 0;                          // one lane speaks for the cluster
     // the round's list of joins: one global atomic per workgroup (one per join was up to 4,000 returning atomics on one address)
     uint32_t at = 0;
     if (accept) at = atomicAdd(&n_here, 1u);
@@ -1484,7 +1495,7 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
     for (int p = 0; p < passes; p++) {
         if (p > 0)
             hipLaunchKernelGGL(k_loop_first, dim3((n_clusters + 3) / 4), block, 0, s, n_clusters, sub_start, sb, cursor, cand, cl, status, taken, stamp, first);
-        hipLaunchKernelGGL(k_loop_accept, dim3((n_clusters + 255) / 256), block, 0, s, n_clusters, cand_start, cand_cnt, cand, cl, status, choice,
+        hipLaunchKernelGGL(k_loop_accept, dim3((n_clusters * ACCEPT_LANES + 255) / 256), block, 0, s, n_clusters, cand_start, cand_cnt, cand, cl, status, choice,
                            first, taken, stamp, accepted, join_slot, counters);
     }
     const dim3 agrid(512);
