@@ -976,11 +976,16 @@ struct __attribute__((aligned(16))) LoopCluster {
 // counters (device uint32[8]): 1 = joins accepted in this round, 3 = the same, as the host polls it (written by apply),
 // 4 + w = length of eval list w
 //
-// A leftover's candidate list is walked by 8 lanes (entry k by lane k % 8) while the eval list is short: one lane per
-// leftover makes the kernel as slow as the longest list -- two dependent gathers (entry, then cluster record) of ~1 us per
-// entry.  While the list is longer than the grid has 8-lane groups, one lane per leftover is the better use of the lanes
-// (the kernel is then bound by instruction issue, not by latency).
+// A leftover's candidate list is walked by 8 lanes (entry k by lane k % 8): one lane per leftover makes the kernel as slow as
+// the longest list -- two dependent gathers (entry, then cluster record) of ~1 us per entry.  Round 2 went back to one lane per
+// leftover as soon as the eval list was longer than the grid's 8-lane groups take in one go (32,768); several passes of short
+// chains beat one pass of the longest chain far beyond that: allowing 1 / 4 / 16 / 64 passes, the 10^6 loop takes 27.0 / 26.0 /
+// 23.8 / 23.5 ms (44 / 36 / 35 ms in the reference's default order), no difference at 10^5 and 3 x 10^5.
 constexpr uint32_t LOOP_GRID = 1024;
+#ifndef HMK_LOOP_EVAL_PASSES
+#define HMK_LOOP_EVAL_PASSES 32
+#endif
+constexpr uint32_t LOOP_EVAL_PASSES = HMK_LOOP_EVAL_PASSES;
 __device__ __forceinline__ void
 loop_eval(uint32_t block, uint32_t n_blocks, const uint32_t *__restrict__ list, uint32_t which, const uint32_t *__restrict__ cand_start,
           const uint32_t *__restrict__ cand_cnt, const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
@@ -988,7 +993,9 @@ loop_eval(uint32_t block, uint32_t n_blocks, const uint32_t *__restrict__ list, 
     const uint32_t t = block * 256 + threadIdx.x;
     if (t == 0) { counters[1] = 0; counters[4 + (which ^ 1u)] = 0; }   // accepted joins of this round; the next eval list starts empty
     const uint32_t n_list = counters[4 + which];
-    const uint32_t lw = n_list > (n_blocks * 256u >> 3) ? 0u : 3u, W = 1u << lw;   // lanes per leftover: 1 or 8
+    // lanes per leftover: 8 while the list is at most LOOP_EVAL_PASSES times what the grid's 8-lane groups take in one go
+    // (a second and third pass over short chains beat one pass whose time is the longest chain), else 1
+    const uint32_t lw = n_list > LOOP_EVAL_PASSES * (n_blocks * 256u >> 3) ? 0u : 3u, W = 1u << lw;
     const uint32_t sub = t & (W - 1), groups = n_blocks * 256 >> lw;
     for (uint32_t i = t >> lw; i < n_list; i += groups) {   // (the W lanes of a leftover stay together)
         const uint32_t q = list[i];
