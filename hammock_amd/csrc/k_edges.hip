@@ -1148,7 +1148,19 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
 #define HMK_APPLY_SUBS 4
 #endif
 constexpr int APPLY_SUBS = HMK_APPLY_SUBS;   // subscribers a thread of k_loop_apply has in flight
-constexpr int APPLY_SLOTS = 8192, APPLY_CHUNK = 4096;   // 64 KB of LDS, load factor <= 1/2 (4,096 slots and 1,280 workgroups: no faster)
+#ifndef HMK_APPLY_SLOTS
+#define HMK_APPLY_SLOTS 8192
+#endif
+#ifndef HMK_APPLY_GRID
+#define HMK_APPLY_GRID 1024
+#endif
+#ifndef HMK_APPLY_ROW
+#define HMK_APPLY_ROW 8
+#endif
+constexpr int APPLY_ROW = HMK_APPLY_ROW;   // row entries a thread of k_loop_apply loads before it inserts them
+constexpr int APPLY_SLOTS = HMK_APPLY_SLOTS, APPLY_CHUNK = HMK_APPLY_SLOTS / 2;
+constexpr int APPLY_SHIFT = APPLY_SLOTS == 8192 ? 19 : APPLY_SLOTS == 4096 ? 20 : APPLY_SLOTS == 2048 ? 21 : 22;
+static_assert(APPLY_SLOTS == 8192 || APPLY_SLOTS == 4096 || APPLY_SLOTS == 2048 || APPLY_SLOTS == 1024, "table sizes");   // 64 KB of LDS, load factor <= 1/2 (4,096 slots and 1,280 workgroups: no faster)
 
 template <class NbrT>
 __global__ void __launch_bounds__(256)
@@ -1180,14 +1192,21 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
             for (uint32_t sl = threadIdx.x; sl < (uint32_t)APPLY_SLOTS; sl += 256) keys[sl] = 0xFFFFFFFFu;
             __syncthreads();
             const uint64_t c1 = min(e, c0 + (uint64_t)APPLY_CHUNK);
-            for (uint64_t k = c0 + threadIdx.x; k < c1; k += 256) {
-                const NbrT nb = adj[k];
-                const uint32_t id = nbr_id(nb);
-                uint32_t sl = (id * 2654435761u) >> 19;          // top 13 bits
-                for (;;) {
-                    const uint32_t old = atomicCAS(&keys[sl], 0xFFFFFFFFu, id);
-                    if (old == 0xFFFFFFFFu) { vals[sl] = nbr_score(nb); break; }   // (ids inside a row are distinct)
-                    sl = (sl + 1) & (APPLY_SLOTS - 1);
+            for (uint64_t k0 = c0 + threadIdx.x; k0 < c1; k0 += 256 * APPLY_ROW) {   // APPLY_ROW entries of the row in flight per thread
+                NbrT nbs[APPLY_ROW];
+#pragma unroll
+                for (int u = 0; u < APPLY_ROW; u++) nbs[u] = k0 + (uint64_t)u * 256 < c1 ? adj[k0 + (uint64_t)u * 256] : adj[c0];
+#pragma unroll
+                for (int u = 0; u < APPLY_ROW; u++) {
+                    if (k0 + (uint64_t)u * 256 >= c1) continue;
+                    const NbrT nb = nbs[u];
+                    const uint32_t id = nbr_id(nb);
+                    uint32_t sl = (id * 2654435761u) >> APPLY_SHIFT;   // top bits
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&keys[sl], 0xFFFFFFFFu, id);
+                        if (old == 0xFFFFFFFFu) { vals[sl] = nbr_score(nb); break; }   // (ids inside a row are distinct)
+                        sl = (sl + 1) & (APPLY_SLOTS - 1);
+                    }
                 }
             }
             __syncthreads();
@@ -1217,7 +1236,7 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                     const uint32_t q2 = (uint32_t)(sub[u] >> 32), k2 = (uint32_t)sub[u];
                     if (live[u]) {
                         const uint32_t id = ids[u];
-                        uint32_t sl = (id * 2654435761u) >> 19;
+                        uint32_t sl = (id * 2654435761u) >> APPLY_SHIFT;
                         for (;;) {
                             const uint32_t kk = keys[sl];
                             if (kk == id) {                      // this entry belongs to leftover q2 alone; one join per cluster and round
@@ -1505,7 +1524,7 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
         hipLaunchKernelGGL(k_loop_accept, dim3((n_clusters * ACCEPT_LANES + 255) / 256), block, 0, s, n_clusters, cand_start, cand_cnt, cand, cl, status, choice,
                            first, taken, stamp, accepted, join_slot, counters);
     }
-    const dim3 agrid(512);
+    const dim3 agrid(HMK_APPLY_GRID);
     if (packed)
         hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
                            choice, accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp);
