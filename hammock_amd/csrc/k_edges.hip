@@ -1145,7 +1145,7 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
 // cluster's subscribers after y probe it -- a subscriber that is a neighbour counts one more covered member and folds
 // the pair's score into its minimum; the others' entries turn infeasible when joined[c] advances.
 #ifndef HMK_APPLY_SUBS
-#define HMK_APPLY_SUBS 4
+#define HMK_APPLY_SUBS 8
 #endif
 constexpr int APPLY_SUBS = HMK_APPLY_SUBS;   // subscribers a thread of k_loop_apply has in flight
 #ifndef HMK_APPLY_SLOTS
