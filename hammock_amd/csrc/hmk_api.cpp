@@ -1922,6 +1922,13 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 done = r == hipSuccess && (uint32_t)*word == 0;
             }
             if (r == hipSuccess) r = hipStreamSynchronize(S);       // drain the rounds enqueued past the end
+            if (loop_trace && r == hipSuccess) {   // (a build with -DHMK_APPLY_STATS=1 fills these)
+                uint32_t hc[16] = {0};
+                if (hipMemcpy(hc, buf<uint32_t>(ctx, SB_LCOUNT), 64, hipMemcpyDeviceToHost) == hipSuccess && (hc[8] | hc[10]))
+                    std::fprintf(stderr, "[hmk greedy] apply walked %u subscriber entries (longest list %u) and %u row entries (longest row %u); "
+                                         "joins took %.2f ms in all (longest %.1f us), of which table build %.2f ms, subscribers %.2f ms\n",
+                                 hc[8], hc[9], hc[10], hc[11], hc[12] * 1e-5, hc[13] * 1e-2, hc[14] * 1e-5, hc[15] * 1e-5);
+            }
         } else {
             for (uint32_t batch = 8; r == hipSuccess && !done && rounds <= nl + 8; batch = std::min<uint32_t>(batch * 2, 64)) {
                 for (uint32_t b = 0; b < batch && r == hipSuccess; b++) one_round();

@@ -1148,11 +1148,14 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
 #define HMK_APPLY_SUBS 8
 #endif
 constexpr int APPLY_SUBS = HMK_APPLY_SUBS;   // subscribers a thread of k_loop_apply has in flight
+#ifndef HMK_APPLY_STATS
+#define HMK_APPLY_STATS 0
+#endif
 #ifndef HMK_APPLY_SLOTS
 #define HMK_APPLY_SLOTS 8192
 #endif
 #ifndef HMK_APPLY_GRID
-#define HMK_APPLY_GRID 1024
+#define HMK_APPLY_GRID 2048
 #endif
 #ifndef HMK_APPLY_ROW
 #define HMK_APPLY_ROW 8
@@ -1170,8 +1173,14 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
              const unsigned long long *__restrict__ subs, const uint32_t *__restrict__ cursor, LoopCluster *__restrict__ cl,
              const int32_t *__restrict__ seq_size, uint32_t *__restrict__ dirty, uint32_t *__restrict__ next_list, uint32_t which,
              uint32_t *__restrict__ counters, unsigned long long *host_word, uint32_t stamp) {
+    // Packed adjacency (4-byte entries id << 8 | score): the table holds the entry itself -- 32 KB instead of 64, four workgroups
+    // per CU instead of two, and a join is bound by its chain of dependent gathers (37 us on average at 10^6: 9 table build, 19
+    // subscribers, 9 the loads before them), so the joins in flight are what counts.  Empty slot = 0: an entry of an UPPER section
+    // has an id >= 1.  8-byte entries keep separate key and value arrays (empty = 0xFFFFFFFF).
+    constexpr bool PACKED = sizeof(NbrT) == 4;
+    constexpr uint32_t EMPTY = PACKED ? 0u : 0xFFFFFFFFu;
     __shared__ uint32_t keys[APPLY_SLOTS];
-    __shared__ int32_t vals[APPLY_SLOTS];
+    __shared__ int32_t vals[PACKED ? 1 : APPLY_SLOTS];
     __shared__ uint32_t list_count, list_base;
     const uint32_t n_acc = counters[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) {                     // what the host polls: a round without a join is the end
@@ -1181,16 +1190,29 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
         if (host_word) __hip_atomic_store(host_word, ((unsigned long long)stamp << 32) | n_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (uint32_t a = blockIdx.x; a < n_acc; a += gridDim.x) {   // workgroup-uniform loop
+#if HMK_APPLY_STATS
+        const unsigned long long ts0 = wall_clock64();   // 100 MHz
+        unsigned long long ts_table = 0, ts_subs = 0;
+#endif
         const uint32_t q = accepted[a];
         const uint32_t y = leftover[q];
         const int32_t c = cand[choice[q]].c;
         const int32_t joined = cl[c].joined;
         const uint32_t sb = cursor[c] + 1, se = sub_start[c + 1];   // the list is sorted and the cursor stands at q itself
         const uint64_t b = start[y], e = b + up[y];              // later leftovers have larger ids: the upper section
+#if HMK_APPLY_STATS   // probe build: how long are the lists a join walks? (counters[8..11], printed by HMK_LOOP_TRACE)
+        if (threadIdx.x == 0) {
+            atomicAdd(&counters[8], se - sb); atomicMax(&counters[9], se - sb);
+            atomicAdd(&counters[10], (uint32_t)(e - b)); atomicMax(&counters[11], (uint32_t)(e - b));
+        }
+#endif
         bool first_chunk = true;
         for (uint64_t c0 = b; c0 < e || first_chunk; c0 += APPLY_CHUNK) {
-            for (uint32_t sl = threadIdx.x; sl < (uint32_t)APPLY_SLOTS; sl += 256) keys[sl] = 0xFFFFFFFFu;
+            for (uint32_t sl = threadIdx.x; sl < (uint32_t)APPLY_SLOTS; sl += 256) keys[sl] = EMPTY;
             __syncthreads();
+#if HMK_APPLY_STATS
+            const unsigned long long tc0 = wall_clock64();
+#endif
             const uint64_t c1 = min(e, c0 + (uint64_t)APPLY_CHUNK);
             for (uint64_t k0 = c0 + threadIdx.x; k0 < c1; k0 += 256 * APPLY_ROW) {   // APPLY_ROW entries of the row in flight per thread
                 NbrT nbs[APPLY_ROW];
@@ -1202,14 +1224,20 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                     const NbrT nb = nbs[u];
                     const uint32_t id = nbr_id(nb);
                     uint32_t sl = (id * 2654435761u) >> APPLY_SHIFT;   // top bits
+                    uint32_t word = id;
+                    if constexpr (PACKED) __builtin_memcpy(&word, &nb, 4);
                     for (;;) {
-                        const uint32_t old = atomicCAS(&keys[sl], 0xFFFFFFFFu, id);
-                        if (old == 0xFFFFFFFFu) { vals[sl] = nbr_score(nb); break; }   // (ids inside a row are distinct)
+                        const uint32_t old = atomicCAS(&keys[sl], EMPTY, word);
+                        if (old == EMPTY) { if constexpr (!PACKED) vals[sl] = nbr_score(nb); break; }   // (ids inside a row are distinct)
                         sl = (sl + 1) & (APPLY_SLOTS - 1);
                     }
                 }
             }
             __syncthreads();
+#if HMK_APPLY_STATS
+            const unsigned long long tc1 = wall_clock64();
+            ts_table += tc1 - tc0;
+#endif
             // the subscribers after the cursor, APPLY_SUBS per thread and step: a subscriber is a chain of dependent gathers (list
             // entry -> status and candidate entry -> its id -> the table), and with one per thread the workgroup waits for memory
             // at every link of every 256 subscribers (popular clusters have thousands)
@@ -1227,6 +1255,8 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
 #pragma unroll
                 for (int u = 0; u < APPLY_SUBS; u++)
                     live[u] = live[u] && status[(uint32_t)(sub[u] >> 32)] == LS_UNDECIDED && cand[(uint32_t)sub[u]].covered == joined;
+                // (the ids are asked for AFTER this test on purpose: few subscribers pass it, and with the id gathered for every
+                // subscriber beside its status and entry -- one link less in the chain -- the loop got slower, 19.1 -> 20.1 ms)
                 uint32_t ids[APPLY_SUBS];
 #pragma unroll
                 for (int u = 0; u < APPLY_SUBS; u++) ids[u] = live[u] ? leftover[(uint32_t)(sub[u] >> 32)] : 0u;
@@ -1239,12 +1269,13 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                         uint32_t sl = (id * 2654435761u) >> APPLY_SHIFT;
                         for (;;) {
                             const uint32_t kk = keys[sl];
-                            if (kk == id) {                      // this entry belongs to leftover q2 alone; one join per cluster and round
+                            if (kk == EMPTY) break;
+                            if ((PACKED ? kk >> 8 : kk) == id) { // this entry belongs to leftover q2 alone; one join per cluster and round
+                                const int32_t sc = PACKED ? (int32_t)(kk & 0xFFu) : vals[sl];
                                 cand[k2].covered = joined + 1;
-                                if (vals[sl] < cand[k2].mn) cand[k2].mn = vals[sl];
+                                if (sc < cand[k2].mn) cand[k2].mn = sc;
                                 break;
                             }
-                            if (kk == 0xFFFFFFFFu) break;
                             sl = (sl + 1) & (APPLY_SLOTS - 1);
                         }
                         if (first_chunk && atomicExch(&dirty[q2], 1u) == 0u) { marks |= 1u << u; n_marks++; }
@@ -1269,8 +1300,18 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                 }
             }
             __syncthreads();
+#if HMK_APPLY_STATS
+            ts_subs += wall_clock64() - tc1;
+#endif
             first_chunk = false;
         }
+#if HMK_APPLY_STATS   // (units of 10 ns)
+        if (threadIdx.x == 0) {
+            const unsigned long long ts1 = wall_clock64();
+            atomicAdd(&counters[12], (uint32_t)(ts1 - ts0)); atomicMax(&counters[13], (uint32_t)(ts1 - ts0));
+            atomicAdd(&counters[14], (uint32_t)ts_table); atomicAdd(&counters[15], (uint32_t)ts_subs);
+        }
+#endif
         if (threadIdx.x == 0) {
             cl[c].joined += 1;
             cl[c].size += seq_size ? (long long)seq_size[y] : 1ll;
