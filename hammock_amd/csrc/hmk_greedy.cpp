@@ -173,7 +173,8 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     // those of the sequential loop, step by step; with one thread the window is one row.
     struct RowScan {
         std::vector<std::pair<int32_t, int32_t>> feas;   // (cluster slot, min score) of the clusters feasible at the scan
-        std::vector<uint32_t> ahead;                     // neighbours at later positions of the window
+        std::vector<std::pair<uint32_t, int32_t>> ahead;    // (id, score) of the FREE neighbours at later positions of the window
+        std::vector<std::pair<uint32_t, int32_t>> behind;   // ... and at the window's earlier positions (decided before x's turn)
         Found B{NEAR_NULL, -1, 0};
         bool no_clusters = false;                        // the scan saw an empty cluster list (:138-140: the dummy)
         bool dirty = false;
@@ -183,6 +184,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     auto scan_row = [&](uint32_t x, uint32_t win_lo, uint32_t win_hi, ScanScratch &sc, RowScan &out) {
         out.feas.clear();
         out.ahead.clear();
+        out.behind.clear();
         out.dirty = false;
         out.no_clusters = clusters.empty();
         Found B{NEAR_NULL, -1, 0};
@@ -195,8 +197,8 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             const int32_t s = adj[q].score();
             const uint8_t stt = state[m];
             if (stt == ST_FREE) {                           // only untouched singletons follow x
-                if (m < x) { if (m >= win_lo) continue; }    // an earlier position of this window: decided before x's turn
-                else if (m < win_hi) out.ahead.push_back(m);
+                if (m < x) { if (m >= win_lo) { out.behind.emplace_back(m, s); continue; } }   // an earlier position of this window: decided before x's turn
+                else if (m < win_hi) out.ahead.emplace_back(m, s);
                 if (B.kind == NEAR_NULL || s > B.score ||
                     (s == B.score && better(s, seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot)))
                     B = Found{NEAR_REAL, (int32_t)m, s};
@@ -224,6 +226,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     uint32_t W = T > 1 ? 4 * T : 1;                   // positions per window (more positions: more scans a commit invalidates)
     if (const char *v = getenv("HMK_PHASE1_WINDOW")) W = (uint32_t)std::max(1, std::min(4096, atoi(v)));
     std::vector<RowScan> res(W);
+    std::vector<int32_t> ahead_score(W, INT_MIN);     // commit of k: score(k, x) for the window's later rows x that have k as a neighbour
     std::vector<ScanScratch> scratch(T);
     for (ScanScratch &sc : scratch) { sc.cnt.assign(slots_max, 0); sc.mn.assign(slots_max, 0); }
     // a small pool for the window scans: generation counter + work cursor, spinning workers (a window is tens of microseconds)
@@ -361,13 +364,33 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             remaining--;
             index++;          // :115
             // ---- what this step can have changed for the window's later rows ----
-            for (uint32_t m : R.ahead) res[m - win_lo].dirty = true;
+            // Rows that have k as a neighbour (known from k's own row: symmetric scores) are PATCHED where that is exact:
+            //   * k joined cluster c: for such a row c stays feasible if it was (k is a neighbour too) and its minimum takes the
+            //     pair's score in; for every other row c stops being feasible (struck below);
+            //   * k seeded a cluster with B: the new cluster {k, B} is feasible for such a row iff B is its neighbour as well --
+            //     known from the row's own scan when B lies inside the window (the lists of its free neighbours at window
+            //     positions), else the row is scanned again at its turn, as before;
+            //   * k became an orphan: nothing changes for them.
+            // (In the reference's default order the rows of a window are each other's neighbours: scanning every such row again
+            // -- what this did until the end of round 3 -- took as long as the sequential loop.)
+            const bool b_in_window = absorb && (uint32_t)B.slot >= win_lo && (uint32_t)B.slot < win_hi;
+            for (uint32_t x = k + 1; x < win_hi; x++) ahead_score[x - win_lo] = INT_MIN;
+            for (const std::pair<uint32_t, int32_t> &a : R.ahead) ahead_score[a.first - win_lo] = a.second;
             if (absorb || joined >= 0)
                 for (uint32_t x = k + 1; x < win_hi; x++) {
                     RowScan &L = res[x - win_lo];
                     if (L.dirty || state[x] != ST_FREE) continue;
+                    const int32_t s_kx = ahead_score[x - win_lo];      // INT_MIN: k is not a neighbour of x
                     if (absorb) {
-                        if (L.B.kind == NEAR_REAL && L.B.slot == B.slot) L.dirty = true;
+                        if (L.B.kind == NEAR_REAL && L.B.slot == B.slot) { L.dirty = true; continue; }   // its best candidate is gone
+                        if (s_kx == INT_MIN) continue;                  // the new cluster holds a non-neighbour (k): never feasible
+                        if (!b_in_window) { L.dirty = true; continue; } // is B a neighbour of x? only its whole row says
+                        const std::vector<std::pair<uint32_t, int32_t>> &side = (uint32_t)B.slot > x ? L.ahead : L.behind;
+                        for (const std::pair<uint32_t, int32_t> &nb : side)
+                            if (nb.first == (uint32_t)B.slot) { L.feas.emplace_back((int32_t)clusters.size() - 1, std::min(s_kx, nb.second)); break; }
+                    } else if (s_kx != INT_MIN) {
+                        for (std::pair<int32_t, int32_t> &f : L.feas)
+                            if (f.first == joined) { f.second = std::min(f.second, s_kx); break; }
                     } else {
                         for (size_t f = 0; f < L.feas.size(); f++)
                             if (L.feas[f].first == joined) { L.feas[f] = L.feas.back(); L.feas.pop_back(); break; }
