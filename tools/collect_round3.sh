@@ -17,6 +17,7 @@ timeout -k 10 200 python tests/tools/e2e_mixed_compare.py > "$O/round3_end_to_en
 timeout -k 10 200 python tests/tools/e2e_clinkage.py > "$O/round3_end_to_end_clinkage.jsonl" 2> /dev/null; echo clinkage $?
 timeout -k 10 200 python tools/rows_probe.py 20 60 14 26 > "$O/round3_rows_probe_thresholds.json" 2> /dev/null; echo probe $?
 HMK_GREEDY_TIMING=1 timeout -k 10 200 python tools/greedy_phases.py 1000000 2>&1 >/dev/null | grep "phase 1" > "$O/round3_phase1_breakdown.txt"; echo phase1 $?
+HMK_GREEDY_TIMING=1 timeout -k 10 200 python tools/greedy_phases.py 1000000 --sorted 2>&1 >/dev/null | grep "phase 1" > "$O/round3_phase1_breakdown_default_order.txt"; echo phase1_sorted $?
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof4a" -o c4a -- python3 "$R/tools/run_config4a.py" > "$O/prof4a.log" 2>&1; echo prof4a $?
 cp $(find "$O/prof4a" -name "*kernel_stats.csv" | head -1) "$O/round3_config4a_kernel_stats.csv"
