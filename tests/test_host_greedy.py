@@ -249,3 +249,15 @@ def test_clinkage_from_edges_errors(blosum62, coracle):
         ctx.clinkage_from_edges(hammock_amd.pack_edges([0], [2], [50]))       # m == n
     with pytest.raises(hammock_amd.DeviceError):
         ctx.clinkage_cluster(3, 0, 20)                                         # no GPU behind this context, no CPU fallback
+
+
+def test_greedy_phase1_window_fuzz_small():
+    """tests/tools/fuzz_phase1_windows.py in small: dense inputs in size / alphabetic / input order, random thresholds and cluster
+    limits, 1-8 threads and windows of 1-4,096 positions; every run identical to the oracle's sequential loop (ids, list order,
+    member order, phase-1 counters, crash parity).  The commits of a window patch the later rows' scans (join: minimum updated;
+    new cluster: feasible iff the absorbed sequence is a neighbour too -- from the row's window lists or a search of the row)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "fuzz_phase1_windows.py"), "40", "11"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '"all_identical": true' in r.stdout
