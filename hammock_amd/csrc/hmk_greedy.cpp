@@ -221,8 +221,9 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         const unsigned hw = std::thread::hardware_concurrency();
         T = std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
     }
+    bool pool_decided = false;                        // the threads start with the first window, if the rows are long enough (below)
     if (const char *v = getenv("HMK_PHASE1_THREADS"))   // tests: any input, any thread count
-        if (symmetric_scores) T = (unsigned)std::max(1, std::min(32, atoi(v)));
+        if (symmetric_scores) { T = (unsigned)std::max(1, std::min(32, atoi(v))); pool_decided = true; }
     uint32_t W = T > 1 ? 4 * T : 1;                   // positions per window (more positions: more scans a commit invalidates)
     if (const char *v = getenv("HMK_PHASE1_WINDOW")) W = (uint32_t)std::max(1, std::min(4096, atoi(v)));
     std::vector<RowScan> res(W);
@@ -251,6 +252,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         }
     };
     std::vector<std::thread> pool;
+    auto spawn_pool = [&]() {
     for (unsigned t = 1; t < T; t++)
         pool.emplace_back([&, t]() {
             uint32_t seen = 0;
@@ -267,6 +269,8 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                 left.fetch_add(1, std::memory_order_seq_cst);
             }
         });
+    };
+    if (pool_decided) spawn_pool();
     struct PoolGuard {   // joins on every way out of the function (crash parity returns early)
         std::vector<std::thread> &pool; std::atomic<bool> &quit;
         ~PoolGuard() { quit.store(true, std::memory_order_release); for (std::thread &th : pool) th.join(); }
@@ -288,6 +292,18 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             if (rows_here <= k) return HMK_INTERNAL_ROWS_FAILED;
             if (hooks->adj_base) adj = (const NbrT *)hooks->adj_base();
             p1_rows += std::chrono::duration<double, std::milli>(p1_now() - tw).count();
+        }
+        if (!pool_decided) {
+            // Several threads pay off when a row is long: a window of 32 short rows is less work than handing it out.  Measured
+            // (8 threads against 1, phase 1 in the default / generator order): 10^5 sequences (256 entries per row) 5.3 / 3.2
+            // against 3.2 / 2.7 ms, 3 x 10^5 (770) 21.8 / 14.5 against 17.0 / 14.4, 5 x 10^5 (1,280) 47.6 / 35.1 against
+            // 46.1 / 38.2, 10^6 (2,560) 95 / 60 against 137 / 105.
+            pool_decided = true;
+            double min_row = 1600.0;
+            if (const char *v = getenv("HMK_PHASE1_MIN_ROW")) min_row = atof(v);
+            const double avg_row = rows_here ? (double)start[rows_here] / (double)rows_here : 0.0;
+            if (T > 1 && avg_row >= min_row) spawn_pool();
+            else { T = 1; if (getenv("HMK_PHASE1_WINDOW") == nullptr) W = 1; }
         }
         const auto ts = p1_now();
         // ---- scan a window of positions against the current state ----
