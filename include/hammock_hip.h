@@ -262,9 +262,13 @@ typedef struct {
  * that (hmk_last_error names the cluster; four 6-mers suffice, tests/test_oracle.py). */
 /* Optional.  Sizes the context's grow-only device and pinned buffers for a first hmk_greedy_cluster / hmk_clinkage_cluster
  * call on n_sequences sequences (edge buffer at the first guess of 0.3 % of the pair space, adjacency, CSR and second-loop
- * scratch: 24 GB at 10^6), so that a host which knows the sequence count early -- hammock-hip after it has read its input --
+ * scratch: 36 GB at 10^6), so that a host which knows the sequence count early -- hammock-hip after it has read its input --
  * can have the allocations done on another thread while it is still sorting and packing the sequences.  Calls on a context
- * are serialised; a later call that needs more grows the buffers as usual.  HMK_OK on a host-only context (nothing to do). */
+ * are serialised; a later call that needs more grows the buffers as usual.  HMK_OK on a host-only context (nothing to do).
+ * The two buffers a call needs LAST (the adjacency and the CSR's bucket records, 2 x 11 GB at 10^6) are obtained on a thread
+ * of the library's own after this function has returned -- on some hosts fresh device memory of that size takes 0.3-1.5 s to
+ * get --; a clustering call that starts in the meantime scores, hands the band over and runs phase 1 first and enqueues its
+ * CSR step when they are there (hmk_destroy joins the thread). */
 int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences);
 
 /* Which java.util.HashSet iteration order hmk_clinkage_cluster / hmk_clinkage_from_edges emulate for
