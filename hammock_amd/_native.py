@@ -20,7 +20,7 @@ HMK_ERR_OOM = 4
 HMK_ERR_REFERENCE_WOULD_CRASH = 5
 HMK_ERR_CAPACITY = 6
 HMK_ERR_NO_SEQUENCES = 7
-HMK_EDGE_SHARDS = 16
+HMK_EDGE_SHARDS = 64
 HMK_MAX_LEN = 32
 
 # every symbol include/hammock_hip.h declares

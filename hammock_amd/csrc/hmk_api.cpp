@@ -129,7 +129,7 @@ struct hmk_ctx {
     void *h_adj = nullptr;    // pinned: adjacency rows fetched so far
     size_t h_adj_cap = 0;
     unsigned long long *h_loop = nullptr;    // pinned, coherent: progress word of the device-side second loop (written by k_loop_apply)
-    unsigned long long *h_counts = nullptr;  // pinned: final segment counts [16], band snapshot [16], misc [8]
+    unsigned long long *h_counts = nullptr;  // pinned: final segment counts [HMK_EDGE_SHARDS], band snapshot [HMK_EDGE_SHARDS], misc (HC_* below)
     hmk_greedy_phases phases{};
 
     // hmk_create_multi: this context is the root (devices[0]); one sub-context per further device, each with its own
@@ -701,7 +701,7 @@ int neighbors_grow(hmk_ctx *ctx, uint64_t want_cap, unsigned long long counts[HM
     int st = need_device(ctx);
     if (st) return st;
     if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
-    uint64_t cap = std::max<uint64_t>(want_cap, (uint64_t)HMK_EDGE_SHARDS * 65536);
+    uint64_t cap = std::max<uint64_t>(want_cap, (uint64_t)1 << 20);
     cap = (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
     hipEvent_t e0, e1;
     HIPCHK(ctx, hipEventCreate(&e0));
@@ -1344,7 +1344,7 @@ namespace {
 
 constexpr int ST_RETRY_OVERFLOW = 1000;   // internal: an edge segment overflowed, grow the buffer and score again
 // layout of the small pinned block hmk_ctx::h_counts (64-bit words)
-enum { HC_COUNTS = 0, HC_BAND = 16, HC_PEER = 32, HC_RANGE = 64, HC_MISC = 72, HC_TOTAL = 80, HC_WORDS = 96 };
+enum { HC_COUNTS = 0, HC_BAND = HMK_EDGE_SHARDS, HC_PEER = 2 * HMK_EDGE_SHARDS, HC_RANGE = HC_PEER + 32, HC_MISC = HC_RANGE + 8, HC_TOTAL = HC_MISC + 8, HC_WORDS = HC_TOTAL + 16 };
 
 // (HMK_GREEDY_TIMING: what the grow-only buffers cost a call, i.e. the first call of a context)
 static thread_local double g_alloc_ms = 0.0;
@@ -2153,7 +2153,7 @@ uint64_t first_edge_capacity(const hmk_ctx *ctx, uint32_t n) {
     // 0.26 %); a segment that overflows makes the call size the buffer to the counts and score again
     uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006)) + (1u << 20);
     if (const char *v = getenv("HMK_EDGE_GUESS")) guess = std::strtoull(v, nullptr, 10);   // tests: force the overflow / retry path
-    uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)HMK_EDGE_SHARDS * 65536, ctx->d_edges_cap});
+    uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)1 << 20, ctx->d_edges_cap});
     return (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
 }
 
@@ -2360,7 +2360,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             if (st == HMK_OK) st = greedy_streams(c);
             if (st) return d ? fail(ctx, st, c->err) : st;
             if (!c->d_counts) HIPCHK(ctx, hipMalloc((void **)&c->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
-            uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)HMK_EDGE_SHARDS * 65536, c->d_edges_cap});
+            uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)1 << 20, c->d_edges_cap});
             if (attempt > 0) {
                 unsigned long long mx = 0;
                 for (int q = 0; q < HMK_EDGE_SHARDS; q++) mx = std::max(mx, c->h_counts[q]);

@@ -98,7 +98,7 @@ struct GreedyProp { uint32_t k; int32_t score; };
 // A run of packed edges in device memory: min(*count, cap) entries at `edges`.  The CSR kernels take a short list of
 // them: the HMK_EDGE_SHARDS segments of one neighbour pass, or those plus the blocks gathered from other devices.
 struct EdgeSeg { const uint64_t *edges; const unsigned long long *count; uint64_t cap; };
-constexpr uint32_t HMK_MAX_SEGS = 32;
+constexpr uint32_t HMK_MAX_SEGS = HMK_EDGE_SHARDS + 16;
 struct EdgeSegs { EdgeSeg s[HMK_MAX_SEGS]; uint32_t n; };
 
 // Optional device-side pre-check of the second loop (hmk_api.cpp provides it when the adjacency is still resident on

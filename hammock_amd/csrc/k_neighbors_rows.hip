@@ -1,657 +1,50 @@
-// k_neighbors_rows.hip -- all-vs-all ShiftedScorer (ShiftedScorer.java:48-95) with threshold -> edge list, "row-packed" form.
-//
-// The reference sums, for every shift s, the cells M[S[i - s]][L[i]] (s <= 0) or M[S[i]][L[i + s]] (s > 0) over the overlap
-// (:67-77).  With the tile's ROW peptides as the longer-or-equal sequence and the lane's COLUMN peptide as the other one this
-// reads: shift plane u (s = u - X) adds, for every column position j, the cell of row position i = j + u - X.  A cell depends
-// on (row, i, column residue) only -- not on the shift -- so the workgroup keeps ONE table per group of 8 rows,
-//
-//     E[i][c] = 8 bytes: byte r = cell(row r, position i, residue c) + bias          (24 x 8 B = 192 B per position i)
-//
-// and a pair of (8 rows, 1 column) is scored by one ds_read_b64 per (u, j) inside the overlap + one v_add3 per two reads and
-// dword: 8 rows advance together, one accumulator pair per shift plane.  Nothing is read that the reference does not add:
-// 72 reads per 8 pairs at length 12 / max shift 3 = 72 B of LDS per pair, where the shift-packed tables of
-// k_neighbors_swar / k_neighbors_planes (k_neighbors.hip: 7 shift lanes + 1 pad lane per 8-byte entry, zero cells of the
-// partial overlaps included) read 96 B.  The binding unit is the LDS byte rate (ds_read_b64: 256 B/clk/CU), so bytes are time.
-//
-// Table placement.  The reads of one column position go to the same address register with immediates 192 x k bytes apart, and
-// the compiler fuses two such ds_read_b64 into one ds_read2_b64 -- which moves 128 B/clk/CU instead of 256
-// (MI355X_MICROARCH.md, LDS table) -- whenever their immediates are < 2048 B or a multiple of 512 B apart.  So the ND row
-// positions one column position can meet are kept SLOT = 2248 bytes apart: position i lives in slot i mod ND, and the
-// 192-byte blocks that share a slot (positions ND apart, the other row groups, the end table) fill its sub-slots.  Two blocks
-// of one group that a column position can meet together are then >= 2248 - 192 bytes and never a multiple of 512 bytes
-// apart (rows_layout_ok below); blocks of different groups are read in different basic blocks.
-//
-// Lanes are 8 bits wide; hmk_api.cpp (classify) proves per length class -- or per row bound -- that every lane stays in
-// [0, 255]: lane = g + penalty(s) - bias * cells(s) + sum of biased cells, g = 128 - threshold, so "score >= threshold" is the
-// lane's top bit.  Classes that do not fit, columns longer than the rows, and (X, D) pairs without an instantiation below run
-// the kernels of k_neighbors.hip.
-//
-// Integer scoring only: no MFMA, no dense contraction.
-#include "hmk_device.h"
+// k_neighbors_rows.hip -- which row-packed instantiation (k_neighbors_rows.h) a (max shift, lengths) class runs, and the
+// dispatch to the part (k_rows_part.hip) that holds it.  Host code only.
+#include "k_neighbors_rows.h"
 
 namespace hmk {
 
-#ifndef HMK_ROWS_DEFER       // 1: a wave looks for hits once per four steps (the history word of the kernel's batch loop)
-#define HMK_ROWS_DEFER 1
-#endif
-#ifndef HMK_ROWS_ARGCOPY     // 1: the batch loop's two kernel arguments are copied out of the argument block (see the kernel)
-#define HMK_ROWS_ARGCOPY 0
-#endif
-#ifndef HMK_ROWS_AHEAD       // 1: a step loads the NEXT step's column while its own table reads run (measured: 2.54 against 2.53 ms, config 4a
-                             // 4.49-4.53 against 4.37-4.44 ms -- eight waves per SIMD hide that load already; off)
-#define HMK_ROWS_AHEAD 0
-#endif
-#ifndef HMK_ROWS_STAGE
-#define HMK_ROWS_STAGE 320
-#endif
-// HMK_ROWS_COMPACT=1 (default): the table reads are VOLATILE loads, which the compiler's load/store optimiser leaves alone, and
-// the tables are packed (192 bytes per row position); 0: plain loads and the spread-out placement described above.
-#ifndef HMK_ROWS_COMPACT
-#define HMK_ROWS_COMPACT 1
-#endif
-constexpr int rows_slot_bytes() { return 2248; }
-template <typename T>
-__device__ __forceinline__ T rows_table_read(uint32_t addr) {
-#if HMK_ROWS_COMPACT
-    return *reinterpret_cast<const volatile HMK_LDS T *>((uintptr_t)addr);
-#else
-    return lds_read<T>(addr);
-#endif
-}
-// no two table blocks of one group within a window of nd row positions may be fusable into a ds_read2[st64]_b64:
-// their distance a * SLOT + b * 192 (a slots, b = -1..1 sub-slots) must exceed 2040 bytes and not be a multiple of 512
-constexpr bool rows_layout_ok(int nd) {
-    for (int a = 1; a < nd; a++)
-        for (int b = -1; b <= 1; b++) {
-            const int dist = a * rows_slot_bytes() + b * 192;
-            if (dist <= 2040 || dist % 512 == 0) return false;
-        }
-    return true;
-}
-// waves per SIMD a shape is compiled for: what its LDS footprint lets a CU hold, and no more than its registers (column
-// offsets + 2 accumulators per plane + reads in flight and the rest) allow without spilling
-constexpr int rows_waves(int nd, int cap, int lds_bytes) {
-#ifdef HMK_ROWS_WAVES
-    return HMK_ROWS_WAVES;
-#endif
-    const int v = cap + 2 * nd + 36;
-    const int by_regs = v <= 64 ? 8 : v <= 72 ? 7 : v <= 80 ? 6 : v <= 96 ? 5 : 4;
-    const int by_lds = 163840 / ((lds_bytes + 511) / 512 * 512);
-    return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
-}
-constexpr int rows_tab_bytes(int x, int d, int cap, bool exact, int g) {
-    const int nd = 2 * x + d + 1;
-    return HMK_ROWS_COMPACT ? g * (cap + d + (exact ? 0 : nd - 1)) * 192 : nd * rows_slot_bytes();
-}
-constexpr int rows_lds_bytes(int x, int d, int cap, bool exact, int g) {   // must match the kernel's LDS map
-    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * HMK_ROWS_STAGE * 4 + 160;
-}
-
-// Everything that depends on the shape only: X max shift, D = row length - column length (>= 0), CAP column-length capacity
-// (EXACT_LB: THE column length), G groups of 8 rows per tile.
-template <int X, int D, int CAP, bool EXACT_LB, int G>
-struct RowsShape {
-    static constexpr int ND = 2 * X + D + 1;          // shift planes
-    static constexpr int NI = CAP + D;                // row positions held per group
-    static constexpr int ENT = 192;                   // bytes per row position: 24 residues x 8 rows
-    static constexpr int SLOT = rows_slot_bytes();    // see "Table placement" above
-    static constexpr int SUB = (NI + ND - 1) / ND;    // sub-slots a group's positions take
-    static constexpr int NEND = EXACT_LB ? 0 : ND - 1;   // end table: the row's last ND - 1 positions again, indexed from the row's end
-    static constexpr int TAB_BYTES = rows_tab_bytes(X, D, CAP, EXACT_LB, G);
-    static constexpr int LPADW = (CAP <= 16) ? 4 : 8; // residue dwords a lane loads (rows are P.lpad bytes apart)
-    static constexpr int TW = (X + 3) / 4;            // dwords holding the last X residues of a column
-    static constexpr int NT = X > 0 ? X : 1;
-    static_assert(X >= 0 && D >= 0 && CAP >= 2 * X && CAP >= 1 && CAP <= 32 && G >= 1 && G <= 8, "shape");
-    static_assert(HMK_ROWS_COMPACT || (G * (SUB + (NEND > 0 ? 1 : 0)) * ENT <= SLOT && rows_layout_ok(ND)), "sub-slots must fit the slot; no fusable pair");
-    static_assert(TAB_BYTES <= 65536, "table offsets must fit the DS immediate");
-    // byte address of row position i of group g / of the position e places before the row's end; both are linear in g
-    // (GROUP_STEP / END_STEP bytes per group), which lets the flush add a per-lane group to the offsets instead
-    static constexpr int GROUP_STEP = HMK_ROWS_COMPACT ? NI * ENT : SUB * ENT;
-    static constexpr int pos_addr(int g, int i) { return HMK_ROWS_COMPACT ? (g * NI + i) * ENT : (i % ND) * SLOT + (g * SUB + i / ND) * ENT; }
-    static constexpr int end_addr(int g, int e) { return HMK_ROWS_COMPACT ? (G * NI + g * NEND + e) * ENT : e * SLOT + (G * SUB + g) * ENT; }
-
-    // A column's residues -> table offsets (residue * 8): off[j] for position j, toff[q] for position lbs - X + q (the last X).
-    // `base` is added to every offset (the table's LDS address + a per-lane group displacement), `tbase` to the tail ones.
-    static constexpr int TWN = TW > 0 ? TW : 1;
-    // the column's residue words as they lie in memory (zero for a lane without a column)
-    static __device__ __forceinline__ void load_words(const uint8_t *rowp, bool live, int lbs, uint32_t (&words)[LPADW], uint32_t (&tw)[TWN]) {
-#pragma unroll
-        for (int q = 0; q < LPADW; q++) words[q] = 0;
-#pragma unroll
-        for (int q = 0; q < TWN; q++) tw[q] = 0;
-        if (live) {
-            const u32x4 v0 = reinterpret_cast<const u32x4 *>(rowp)[0];
-            words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
-            if constexpr (LPADW == 8) {
-                const u32x4 v1 = reinterpret_cast<const u32x4 *>(rowp)[1];
-                words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
-            }
-            if (!EXACT_LB && TW > 0) {   // the last X residues, wherever the column ends (unaligned dword loads; the array is padded)
-#pragma unroll
-                for (int q = 0; q < TW; q++) __builtin_memcpy(&tw[q], rowp + (lbs - X) + 4 * q, 4);
-            }
-        }
-    }
-    static __device__ __forceinline__ void offsets_of(const uint32_t (&words_in)[LPADW], const uint32_t (&tw_in)[TWN], uint32_t base, uint32_t tbase,
-                                                      uint32_t (&off)[CAP], uint32_t (&toff)[NT]) {
-        uint32_t words[LPADW], tw[TWN];
-        // residues are < 32, so byte k of (word << 3) is residue * 8 exactly (the three bits that move in are zero)
-#pragma unroll
-        for (int q = 0; q < LPADW; q++) words[q] = words_in[q] << 3;
-#pragma unroll
-        for (int j = 0; j < CAP; j++) off[j] = base + ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
-        if (EXACT_LB) {
-#pragma unroll
-            for (int q = 0; q < X; q++) toff[q] = off[CAP - X + q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < TWN; q++) tw[q] = tw_in[q] << 3;
-#pragma unroll
-            for (int q = 0; q < X; q++) toff[q] = tbase + ((tw[q >> 2] >> ((q & 3) * 8)) & 0xFFu);
-        }
-    }
-    static __device__ __forceinline__ void offsets(const uint8_t *rowp, bool live, int lbs, uint32_t base, uint32_t tbase,
-                                                   uint32_t (&off)[CAP], uint32_t (&toff)[NT]) {
-        uint32_t words[LPADW], tw[TWN];
-        load_words(rowp, live, lbs, words, tw);
-        offsets_of(words, tw, base, tbase, off, toff);
-    }
-
-    // All shift sums of (8 rows of group GI) x (this lane's column): W0 / W1[u] = the 8 byte lanes of plane u.
-    // LOWP (the flush): a scheduling barrier after every position pair, so that the compiler does not put all of a column's
-    // reads in flight at once (2 x 72 registers at length 12) beside the main loop's live state.
-    template <int GI, bool LOWP = false>
-    static __device__ __forceinline__ void accumulate(const uint32_t (&off)[CAP], const uint32_t (&toff)[NT], int lbs,
-                                                      const uint32_t (&ci)[ND], uint32_t (&W0)[ND], uint32_t (&W1)[ND]) {
-        if constexpr (EXACT_LB) {
-            // everything is known at compile time: plane by plane, the plane's reads summed two at a time (one v_add3 per
-            // dword and pair; an odd count starts with a plain add): ceil(reads / 2) VALU instructions per dword, the minimum
-#pragma unroll
-            for (int u = 0; u < ND; u++) {
-                constexpr int NMAIN = CAP - X;
-                const int j0 = X - u > 0 ? X - u : 0;                 // main positions j0 .. NMAIN - 1
-                const int nt = ND - 2 - u >= X ? X : (ND - 2 - u < 0 ? 0 : ND - 1 - u);   // tail positions q = 0 .. nt - 1 (u <= ND - 2 - q)
-                const int n = NMAIN - j0 + nt;
-                uint32_t a0 = ci[u], a1 = ci[u];
-                // read k of the plane: k < NMAIN - j0: main position j0 + k; else tail position k - (NMAIN - j0)
-                auto rd = [&](int k) {
-                    const int j = k < NMAIN - j0 ? j0 + k : NMAIN + (k - (NMAIN - j0));   // column position (tail q = j - NMAIN)
-                    return rows_table_read<u32x2>(off[j] + (uint32_t)pos_addr(GI, j + u - X));
-                };
-                int k = 0;
-                if (n & 1) { const u32x2 e = rd(0); a0 += e.x; a1 += e.y; k = 1; }
-#pragma unroll
-                for (; k + 1 < n; k += 2) {
-                    const u32x2 e0 = rd(k), e1 = rd(k + 1);
-                    a0 = a0 + e0.x + e1.x; a1 = a1 + e0.y + e1.y;
-                }
-                W0[u] = a0; W1[u] = a1;
-                if (LOWP) __builtin_amdgcn_sched_barrier(0);
-            }
-            return;
-        }
-#pragma unroll
-        for (int u = 0; u < ND; u++) { W0[u] = ci[u]; W1[u] = ci[u]; }
-        // column position J, all planes that pair it with a row position >= 0: i = J + u - X
-        auto add_pos = [&](auto jt) {
-            constexpr int J = decltype(jt)::value;
-#pragma unroll
-            for (int u = (X - J > 0 ? X - J : 0); u < ND; u++) {
-                const u32x2 e = rows_table_read<u32x2>(off[J] + (uint32_t)pos_addr(GI, J + u - X));
-                W0[u] += e.x; W1[u] += e.y;
-            }
-        };
-        // the main positions j < lbs - X (every plane's row position stays below the row's end), two at a time so that
-        // the adds pair up into v_add3; an odd count takes position 0 on its own first (cf. k_neighbors_planes)
-        auto add_pairs = [&](auto start_tag) {
-            constexpr int J0 = decltype(start_tag)::value;
-            int nmain = lbs - X;
-            if (!EXACT_LB) asm volatile("" : "+s"(nmain));   // keep the tests scalar (s_cmp + s_cbranch), see k_neighbors_planes
-#pragma unroll
-            for (int j = J0; j + 1 < CAP - X; j += 2) {
-                if (j + 1 >= nmain) break;
-                // both positions of a plane next to each other: one v_add3 per dword
-#pragma unroll
-                for (int u = 0; u < ND; u++) {
-                    const bool v0 = u >= X - j, v1 = u >= X - (j + 1);
-                    if (v0 && v1) {
-                        const u32x2 e0 = rows_table_read<u32x2>(off[j] + (uint32_t)pos_addr(GI, j + u - X));
-                        const u32x2 e1 = rows_table_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(GI, j + 1 + u - X));
-                        W0[u] = W0[u] + e0.x + e1.x; W1[u] = W1[u] + e0.y + e1.y;
-                    } else if (v1) {
-                        const u32x2 e1 = rows_table_read<u32x2>(off[j + 1] + (uint32_t)pos_addr(GI, j + 1 + u - X));
-                        W0[u] += e1.x; W1[u] += e1.y;
-                    }
-                }
-                if (LOWP) __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if ((lbs - X) & 1) {
-            add_pos(std::integral_constant<int, 0>{});
-            add_pairs(std::integral_constant<int, 1>{});
-        } else {
-            add_pairs(std::integral_constant<int, 0>{});
-        }
-        if (LOWP) __builtin_amdgcn_sched_barrier(0);
-        // the last X column positions: position lbs - X + q pairs with row position lbs - 2X + q + u, which is inside the
-        // row (length lbs + D) for planes u <= ND - 2 - q only; that row position is ND - 2 - q - u places before the row's
-        // end, whatever the column length (end table)
-#pragma unroll
-        for (int u = 0; u < ND; u++) {
-#pragma unroll
-            for (int q = 0; q < X; q++) {
-                if (u <= ND - 2 - q) {
-                    const u32x2 e = rows_table_read<u32x2>(toff[q] + (uint32_t)(EXACT_LB ? pos_addr(GI, CAP - 2 * X + q + u) : end_addr(GI, ND - 2 - q - u)));
-                    W0[u] += e.x; W1[u] += e.y;
-                }
-            }
-        }
-    }
-};
-
-// What a flush needs.  The flush is a function that is NOT inlined: inlined, it (it scores whole columns again and wants most
-// of the register file) made the compiler keep the append loop's state in scratch memory on every pass.  Its arguments are
-// written to LDS once per tile and the call passes their address: passed by value they travelled through the stack, 120 bytes
-// per LANE and call -- 1.2 GB of scratch writes per pass of the BASELINE workload (rocprofv3 WRITE_SIZE), 12 x its edge list.
-struct RowsFlushArgs {
-    const uint8_t *res_sorted;
-    const uint32_t *perm;
-    const TileClass *cls;
-    uint64_t *edges;
-    unsigned long long *counts;
-    uint64_t cap_per_shard;
-    uint32_t *deg, *deg_up, *deg_lo, *rank;
-    uint32_t lpad, symmetric, perm_identity, row0, col0, shard, tab_addr, deg_m_offset;
-    int lbs, threshold, pad_;
-    uint32_t cinit[8];   // TileClass::cinit: one byte per shift, the lanes' initial value
-};
-static_assert(sizeof(RowsFlushArgs) % 8 == 0, "LDS map");
-
-// Drains one wave's staged records ((column - tile's first column) | row within the tile << 16).  A record says WHICH pair
-// reached the threshold; its score is worked out here, where every lane has a record of its own: the pair's column is
-// fetched again and scored against its row group's tables (all planes of 8 rows), and the lane's row is cut out of every
-// plane's sums.  In the main loop the same extraction ran for one or two live lanes per wave-instruction and was a fifth of
-// the kernel's VALU work (VALU 99 % busy beside LDS 88 %).
-template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
-__device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_t *stage, uint32_t cnt, uint32_t args_addr) {
-    using S = RowsShape<X, D, CAP, EXACT_LB, G>;
-    if (cnt == 0) return;
-    // (arguments arrive in vector registers: the scalar tests below need the uniform ones as scalars)
-    RowsFlushArgs A;
-    {
-        const uint32_t a0 = __builtin_amdgcn_readfirstlane(args_addr);
-        uint32_t raw[sizeof(RowsFlushArgs) / 4];
-#pragma unroll
-        for (uint32_t q = 0; q < sizeof(RowsFlushArgs) / 4; q++) raw[q] = lds_read<uint32_t>(a0 + 4 * q);
-        __builtin_memcpy(&A, raw, sizeof(RowsFlushArgs));
-    }
-    const int lbs = __builtin_amdgcn_readfirstlane(A.lbs);
-    drain_begin();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // staged ds_writes land before the reads below
-    const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage, hmk_device.h)
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&A.counts[A.shard], (unsigned long long)cnt);
-    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    base = ((unsigned long long)bhi << 32) | blo;
-    const int la = lbs + D;
-    const uint32_t tab = __builtin_amdgcn_readfirstlane(A.tab_addr);
-    for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {   // wave-uniform trip count: the table reads below run for whole waves
-        const uint32_t k = k0 + lane;
-        const bool live = k < cnt;
-        const uint32_t rec = live ? stage[k] : 0u;
-        const uint32_t rt = rec >> 16, grp = rt >> 3, r = rt & 7u;
-        const uint32_t mcol = A.col0 + (rec & 0xFFFFu);
-        uint32_t off[CAP], toff[S::NT];
-        S::offsets(A.res_sorted + (size_t)mcol * A.lpad, live, lbs, tab + grp * (uint32_t)S::GROUP_STEP, 0u, off, toff);
-        uint32_t mx = 0;   // best shift = largest lane of this record's row
-        const uint32_t sh = (r & 3u) * 8u;
-        {
-            // One plane at a time, in a loop that is NOT unrolled (this path is cold and must stay small in registers; unrolled,
-            // with or without scheduling barriers, the compiler put a column's 72 reads in flight at once and spilled them): the
-            // plane's cells straight from the position table, row position i = j + u - X wherever it lies inside the row -- the
-            // literal form of ShiftedScorer.java:67-77 on the packed cells, independent of the main loop's unrolled schedule.
-#pragma unroll 1
-            for (int u = 0; u < S::ND; u++) {
-                uint32_t cw = A.cinit[0];
-#pragma unroll
-                for (int q = 1; q < 8; q++) cw = (u >> 2) == q ? A.cinit[q] : cw;
-                uint32_t a0 = ((cw >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u, a1 = a0;
-#pragma unroll
-                for (int j = 0; j < CAP; j++) {
-                    const int i = j + u - X;
-                    if (j < lbs && i >= 0 && i < la) {   // wave-uniform
-                        const u32x2 e = lds_read<u32x2>(off[j] + (uint32_t)S::pos_addr(0, i));
-                        a0 += e.x; a1 += e.y;
-                    }
-                }
-                mx = max(mx, ((r < 4u ? a0 : a1) >> sh) & 0xFFu);
-            }
-        }
-        const int score = (int)mx - 128 + A.threshold;   // lane = 128 - threshold + score
-        uint32_t x = A.row0 + rt, m = mcol;
-        if (!A.perm_identity && live) { x = A.perm[x]; m = A.perm[m]; }
-        if (A.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
-        const unsigned long long pos = base + k;
-        if (live && pos < A.cap_per_shard) {
-            const unsigned long long slot = (unsigned long long)A.shard * A.cap_per_shard + pos;
-            A.edges[slot] = ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
-            // (place_edge of hmk_device.h on the copied fields; stored edges only)
-            if (MODE == EDGES_PLACE) {
-                const uint32_t rx = atomicAdd(&A.deg_up[x], 1u);
-                const uint32_t rm = A.symmetric ? atomicAdd(&A.deg_lo[m], 1u) : 0u;
-                reinterpret_cast<uint2 *>(A.rank)[slot] = make_uint2(rx, rm);
-            } else if (MODE == EDGES_COUNT) {
-                atomicAdd(&A.deg[x], 1u);
-                if (A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
-    drain_end();
-}
-
-template <class F, int... Is>
-__device__ __forceinline__ void rows_for_each_group(std::integer_sequence<int, Is...>, F &&f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-
-// MODE: what a flush does beside storing the edge (hmk_device.h)
-template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
-__global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, EXACT_LB, G)))
-k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
-    using S = RowsShape<X, D, CAP, EXACT_LB, G>;
-    constexpr int ND = S::ND, NI = S::NI, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
-    constexpr int R = 8 * G;
-    constexpr int STAGE_CAP = HMK_ROWS_STAGE;  // records per wave; flushed when fewer than 64 slots are free
-    static_assert(sizeof(RowsFlushArgs) <= 160, "LDS map");
-    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4 + 160;
-    static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, EXACT_LB, G), "rows_lds_bytes must match the LDS map");
-    // one STATIC LDS object: its base address is a compile-time constant, so table offsets fold into the ds_read immediate
-    __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
-    uint8_t *tab = smem;
-    uint8_t *mb = smem + TAB_BYTES;
-    uint8_t *rowres = mb + 576;
-    uint32_t *stage_all = reinterpret_cast<uint32_t *>(rowres + R * 32);
-    RowsFlushArgs *fargs = reinterpret_cast<RowsFlushArgs *>(stage_all + 4 * STAGE_CAP);
-
-    const Tile T = P.tiles[tile_base + blockIdx.x];
-    const TileClass *Cp = P.classes + T.cls;
-    const int la = Cp->la;
-    int lbs = EXACT_LB ? CAP : (int)Cp->lb;    // column length (wave-uniform)
-    const bool case_b = Cp->case_b != 0;       // the column is the SHORTER sequence: cell = M[c][row[i]], else M[row[i]][c]
-    const int threshold = 128 - Cp->g;
-    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
-    const int tid = threadIdx.x;
-    // 32-bit LDS pointer, wave-uniform (kept in a scalar register: nothing to spill around the flush call)
-    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_CAP;
-
-    build_begin();
-    const uint32_t tab_addr = lds_addr(tab);
-    if (tid == 0) {
-        RowsFlushArgs a{P.res_sorted, P.perm, Cp, P.edges, P.counts, P.cap_per_shard, P.deg, P.deg_up, P.deg_lo, P.rank,
-                        P.lpad, P.symmetric, P.perm_identity, T.row0, T.col0, shard, tab_addr, P.deg_m_offset, lbs, threshold, 0, {0}};
-#pragma unroll
-        for (int q = 0; q < 8; q++) a.cinit[q] = Cp->cinit[q];
-        *fargs = a;
-    }
-    for (int e = tid; e < 576; e += 256) mb[e] = P.mb[e];
-    for (int e = tid; e < R * 32; e += 256) {
-        const int r = e >> 5, k = e & 31;
-        uint8_t v = 0;
-        if ((uint32_t)r < T.nrows && (uint32_t)k < P.lpad) v = P.res_sorted[(size_t)(T.row0 + r) * P.lpad + k];
-        rowres[e] = v;
-    }
-    __syncthreads();
-    // ---- the cell tables: work item e = ((g * (NI + NEND) + k) * 24 + c) * 2 + h gathers rows 8g + 4h .. + 3 of row position
-    // k (k < NI) or of the position k - NI places before the row's end (end table) ----
-    for (int e = tid; e < G * (NI + NEND) * 24 * 2; e += 256) {
-        const int h = e & 1, ic = e >> 1;
-        const int gi = ic / 24, c = ic - gi * 24;
-        const int g = gi / (NI + NEND), k = gi - g * (NI + NEND);
-        const int i = k < NI ? k : la - 1 - (k - NI);
-        const int dst = k < NI ? S::pos_addr(g, k) : S::end_addr(g, k - NI);
-        uint32_t v = 0;
-        if (i >= 0 && i < la) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int r = 8 * g + 4 * h + q;
-                if ((uint32_t)r < T.nrows) {
-                    const int a = rowres[r * 32 + i];
-                    v |= (uint32_t)(case_b ? mb[c * 24 + a] : mb[a * 24 + c]) << (q * 8);
-                }
-            }
-        }
-        *reinterpret_cast<uint32_t *>(tab + dst + c * 8 + h * 4) = v;
-    }
-    __syncthreads();
-    build_end();
-
-    // initial lanes: every byte of plane u starts at g + penalty(s) - bias * cells(s) (TileClass::cinit, one byte per shift)
-    uint32_t ci[ND];
-#pragma unroll
-    for (int u = 0; u < ND; u++) ci[u] = ((Cp->cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
-
-    uint32_t cnt = 0;  // staged records of this wave (wave-uniform)
-    const uint32_t col_end = T.col0 + T.ncols;
-    const uint32_t n_batches = (T.ncols + 255) / 256;
-    const bool interior = T.diag == 0 && T.ncols % 256 == 0;  // every lane's column is a real pair
-    const bool prio = MODE != EDGES_PLACE || HMK_SETPRIO_PLACE;
-
-    const uint32_t fargs_addr = lds_addr(fargs);
-    // The batch loop needs two of the kernel's arguments.  As fields of P they keep the WHOLE argument block (16 SGPRs, one
-    // s_load_dwordx16) alive through the loop, and with the flush call's register needs the allocator parks that block in VGPR
-    // lanes and reads all 16 back at every step: 18 v_readlane of a step's 150 VALU instructions.  Copies made by an
-    // instruction of their own (HMK_ROWS_ARGCOPY=1) are values of their own and the v_readlane go away -- and the pass gets
-    // SLOWER, 2.560 against 2.525 ms on the same box, twice: the VALU pipe is not what the kernel waits for (the LDS pipe
-    // is), and the 18 instructions sit where the step's global load is in flight.  Kept as a switch, off.
-#if HMK_ROWS_ARGCOPY
-    uint64_t res_sorted_s;
-    uint32_t lpad_s;
-    asm volatile("s_mov_b64 %0, %1" : "=s"(res_sorted_s) : "s"((uint64_t)(uintptr_t)P.res_sorted));
-    asm volatile("s_mov_b32 %0, %1" : "=s"(lpad_s) : "s"(P.lpad));
-    const uint8_t *const res_sorted = (const uint8_t *)(uintptr_t)res_sorted_s;
-#else
-    const uint8_t *const res_sorted = P.res_sorted;
-    const uint32_t lpad_s = P.lpad;
-#endif
-
-    constexpr bool DEFER = HMK_ROWS_DEFER != 0 && EXACT_LB;   // (mixed lengths: short column runs, two groups -- 1.3 % slower with it)
-    // Hits are rare per pair (0.26 % at the default threshold) but not per step: a wave tests 512 pairs at a time and finds
-    // one in three steps out of four.  So the test's result is only NOTED at every step -- the top bits of the eight rows'
-    // bytes, merged into one word per lane and shifted into a 4-step history (hm uses every 4th bit: step j of a quad lands on
-    // the bits = j mod 4) -- and the wave looks at the history once per quad: one ballot, one append loop whose number of
-    // turns is the largest number of hits any LANE has in the quad (1.1 on average) instead of four of them.
-    uint32_t acc[G];
-#pragma unroll
-    for (int g = 0; g < G; g++) acc[g] = 0;
-    // the column of the NEXT step is asked for while this step's table reads run (HMK_ROWS_AHEAD=0: at the step's start)
-    constexpr bool AHEAD = HMK_ROWS_AHEAD != 0;
-    uint32_t nwords[S::LPADW], ntw[S::TWN];
-    if constexpr (AHEAD) {
-        const uint32_t col0 = T.col0 + tid;
-        S::load_words(res_sorted + (size_t)col0 * lpad_s, col0 < col_end, lbs, nwords, ntw);
-    }
-    for (uint32_t bt = 0; bt < n_batches; bt++) {
-        const uint32_t colrel = bt * 256 + tid;
-        const uint32_t col = T.col0 + colrel;
-        uint32_t off[CAP], toff[S::NT];
-        if constexpr (AHEAD) {
-            S::offsets_of(nwords, ntw, tab_addr, tab_addr, off, toff);
-            const uint32_t coln = col + 256;
-            S::load_words(res_sorted + (size_t)coln * lpad_s, bt + 1 < n_batches && coln < col_end, lbs, nwords, ntw);
-        } else {
-            S::offsets(res_sorted + (size_t)col * lpad_s, col < col_end, lbs, tab_addr, tab_addr, off, toff);
-        }
-        const bool look = !DEFER || (bt & 3u) == 3u || bt + 1 == n_batches;   // wave-uniform
-
-        auto one_group = [&](auto gt) {
-            constexpr int g = decltype(gt)::value;
-            if ((uint32_t)(8 * g) >= T.nrows) return;   // wave-uniform
-            uint32_t W0[ND], W1[ND];
-            read_phase_begin(prio);
-            S::template accumulate<g>(off, toff, lbs, ci, W0, W1);
-            read_phase_end(prio);
-
-            // ---- threshold test: some (row, shift) lane has its top bit set <=> score >= threshold ----
-            uint32_t o0 = W0[0], o1 = W1[0];
-#pragma unroll
-            for (int u = 1; u < ND; u++) { o0 |= W0[u]; o1 |= W1[u]; }
-            if constexpr (!DEFER)
-                if (__ballot(((o0 | o1) & 0x80808080u) != 0) == 0) return;
-            // ---- rare path (a hit somewhere in the wave): every lane appends ITS hits, one per turn ----
-            // hm: bit 8r + 7 set <=> row r of the group (r < 4) reached the threshold for this lane's column, bit 8r + 3 <=> row
-            // 4 + r.  The rows beyond the tile's last start at the initial lane value, which may itself have the top bit set:
-            // rm0 / rm1 (wave-uniform) leave them out.
-            const uint32_t rows_here = T.nrows - 8 * g;
-            const uint32_t rm0 = rows_here >= 4 ? 0x80808080u : 0x80808080u & ((1u << (8 * rows_here)) - 1u);
-            const uint32_t rm1 = rows_here >= 8 ? 0x80808080u : rows_here <= 4 ? 0u : 0x80808080u & ((1u << (8 * (rows_here - 4))) - 1u);
-            uint32_t hm = (o0 & rm0) | ((o1 & rm1) >> 4);
-            if (!interior) {  // wave-uniform: only edge tiles filter
-                if (col >= col_end) hm = 0;
-                if (T.diag != 0) {
-                    const int k = (int)col - (int)(T.row0 + 8 * g);   // the row this column IS, relative to the group
-                    if (T.diag == 1) {   // triangle: keep rows r with column > row, i.e. r < k
-                        const int k0 = k < 0 ? 0 : k > 4 ? 4 : k, k1 = k < 4 ? 0 : k > 8 ? 4 : k - 4;
-                        hm &= (k0 >= 4 ? 0x80808080u : 0x80808080u & ((1u << (8 * k0)) - 1u)) |
-                              (k1 >= 4 ? 0x08080808u : 0x08080808u & ((1u << (8 * k1)) - 1u));
-                    } else if (k >= 0 && k < 8) {   // full square minus the diagonal
-                        hm &= ~(k < 4 ? 0x80u << (8 * k) : 0x08u << (8 * (k - 4)));
-                    }
-                }
-            }
-            if constexpr (DEFER) {
-                // history: this step's bits stay at 3 mod 4, the earlier steps' move down by one per step
-                acc[g] = (acc[g] >> 1) | hm;
-                if (!look) return;
-                hm = acc[g];
-                acc[g] = 0;
-                if (__ballot(hm != 0) == 0) return;
-            }
-            // (the flush sits OUTSIDE the append loop: it scores whole columns again and needs most of the register file; inside the
-            // loop the compiler kept the loop's state in scratch memory for every turn of it)
-            for (;;) {
-                bool full = false;
-                for (;;) {
-                    const bool any = hm != 0;
-                    const uint64_t mask = __ballot(any);
-                    if (mask == 0) break;
-                    if (cnt > (uint32_t)(STAGE_CAP - 64)) { full = true; break; }   // keep room for one wave of hits
-                    if (any) {
-                        const uint32_t q = (uint32_t)__builtin_ctz(hm);
-                        const uint32_t b = DEFER ? q | 3u : q;                // where the bit was when its step noted it
-                        const uint32_t back = DEFER ? 3u - (q & 3u) : 0u;     // ... that many steps ago
-                        const uint32_t row = (b >> 3) + 4u - (b & 4u);        // bit 8r + 7: row r; bit 8r + 3: row 4 + r
-                        // (the column is recomputed: cheaper than keeping it across the flush call)
-                        stage[cnt + mbcnt64(mask)] = ((bt - back) * 256 + threadIdx.x) | ((uint32_t)(8 * g) + row) << 16;
-                        hm &= hm - 1u;   // clear the lowest set bit
-                    }
-                    cnt += (uint32_t)__popcll(mask);
-                }
-                if (!full) break;
-                flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, fargs_addr);
-                cnt = 0;
-            }
-        };
-        rows_for_each_group(std::make_integer_sequence<int, G>{}, one_group);
-    }
-    flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, fargs_addr);
-}
-
-// -----------------------------------------------------------------------------
-// instantiations and launchers
-// -----------------------------------------------------------------------------
-// Uniform-length sets with the reference's default max shift for that length (Hammock.java:1421-1434: round(L / 4)) get
-// their column length at compile time; everything else runs the capacity form (column length <= CAP at run time).
-#ifndef HMK_ROWS_G          // capacity form (mixed lengths: a length bucket's short column runs; 1 / 2 / 3 / 4 groups: 4.87 / 4.48 / 4.58 /
-#define HMK_ROWS_G 2        // 4.74 ms on BASELINE config 4a)
-#endif
-#ifndef HMK_ROWS_G_EXACT    // one length for all: long column runs, the tile's dead time is small either way (2.65-2.67 ms with 1 or 2)
-#define HMK_ROWS_G_EXACT 1
-#endif
-// groups of 8 rows per tile: HMK_ROWS_G, or as many as the sub-slots of a slot hold
-constexpr int rows_groups(int x, int d, int cap, bool exact) {
-    const int nd = 2 * x + d + 1, sub = (cap + d + nd - 1) / nd + (exact ? 0 : 1);
-    const int fit = HMK_ROWS_COMPACT ? 8 : rows_slot_bytes() / 192 / sub;
-    const int want = exact ? HMK_ROWS_G_EXACT : HMK_ROWS_G;
-    return fit < 1 ? 0 : fit < want ? fit : want;
-}
-
-template <int X, int D, int CAP, bool EXACT_LB>
-static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
-    constexpr int G = rows_groups(X, D, CAP, EXACT_LB);
-    // the flush's mode is a template parameter: with the run-time form the placing branch's registers spill in every mode
-    if (P.rank)
-        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_PLACE>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
-    else if (P.deg)
-        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_COUNT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
-    else
-        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_PLAIN>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
-    return hipGetLastError();
-}
-
-// the list: HMK_ROWS_EXACT(X, L) uniform length L; HMK_ROWS_CAP(X, D, CAP) column length <= CAP, rows D longer
-#define HMK_ROWS_EXACT_LIST(F) F(3, 12)
-#ifdef HMK_ROWS_MINIMAL   // tuning builds (tools/ab_flags.sh): the BASELINE shapes only, seconds to compile
-#define HMK_ROWS_CAP_LIST(F) F(3, 0, 12)
-#else
-#define HMK_ROWS_CAP_LIST(F) \
-    F(3, 0, 12) F(3, 1, 12) F(3, 2, 12) F(3, 3, 12) F(3, 4, 12) F(3, 5, 12) F(3, 6, 12) F(3, 7, 12) F(3, 8, 12) F(3, 9, 12) \
-    F(3, 10, 12) F(3, 11, 12) F(3, 12, 12) F(3, 13, 12) \
-    F(3, 0, 16) F(3, 1, 16) F(3, 2, 16) F(3, 3, 16) F(3, 4, 16) F(3, 5, 16) F(3, 6, 16) F(3, 7, 16) \
-    F(3, 0, 20) F(3, 1, 20) F(3, 2, 20) F(3, 3, 20)
-#endif
-
+// column-length capacities of the capacity form
 int rows_cap_for(int lb) { return lb <= 12 ? 12 : lb <= 16 ? 16 : lb <= 20 ? 20 : 0; }
 
-int rows_per_tile_rows(int X, int d, int cap, bool exact) {
+namespace {
+// part that holds the shape, or -1
+int rows_part_of(int X, int d, int cap, bool exact) {
     if (exact) {
-#define HMK_F(XV, L) if (X == XV && d == 0 && cap == L) return 8 * rows_groups(XV, 0, L, true);
+#define HMK_F(PV, XV, L) if (X == XV && d == 0 && cap == L) return PV;
         HMK_ROWS_EXACT_LIST(HMK_F)
 #undef HMK_F
-        return 0;
+        return -1;
     }
-#define HMK_F(XV, DV, CAPV) if (X == XV && d == DV && cap == CAPV) return 8 * rows_groups(XV, DV, CAPV, false);
-    HMK_ROWS_CAP_LIST(HMK_F)
-#undef HMK_F
-    return 0;
+#define HMK_C(PV, XV, DV, CAPV) if (X == XV && d == DV && cap == CAPV) return PV;
+    HMK_ROWS_CAP_LIST(HMK_C)
+#undef HMK_C
+    return -1;
+}
+}  // namespace
+
+int rows_per_tile_rows(int X, int d, int cap, bool exact) {
+    if (rows_part_of(X, d, cap, exact) < 0) return 0;
+    return 8 * rows_groups(X, d, cap, exact);
 }
 
 // is there a row-packed instantiation for this class?  exact: every sequence of the set has length lb
 bool rows_kernel_available(int X, int la, int lb, bool exact) {
     if (la < lb || lb < 2 * X || X < 1) return false;
-    const int d = la - lb;
-    if (exact) {
-#define HMK_F(XV, L) if (X == XV && d == 0 && lb == L) return true;
-        HMK_ROWS_EXACT_LIST(HMK_F)
-#undef HMK_F
-        return false;
-    }
-    const int cap = rows_cap_for(lb);
-#define HMK_F(XV, DV, CAPV) if (X == XV && d == DV && cap == CAPV) return true;
-    HMK_ROWS_CAP_LIST(HMK_F)
-#undef HMK_F
-    return false;
+    return rows_part_of(X, la - lb, exact ? lb : rows_cap_for(lb), exact) >= 0;
 }
 
 hipError_t launch_neighbors_rows(int X, int d, int cap, bool exact, const NeighborParams &P, uint32_t tile_base,
                                  uint32_t n_tiles, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    if (exact) {
-#define HMK_F(XV, L) if (X == XV && d == 0 && cap == L) return launch_rows_t<XV, 0, L, true>(P, tile_base, n_tiles, s);
-        HMK_ROWS_EXACT_LIST(HMK_F)
-#undef HMK_F
-        return hipErrorInvalidValue;
+    switch (rows_part_of(X, d, cap, exact)) {
+#define HMK_P(p) case p: return launch_rows_part_##p(X, d, cap, exact, P, tile_base, n_tiles, s);
+        HMK_P(0) HMK_P(1) HMK_P(2) HMK_P(3) HMK_P(4) HMK_P(5) HMK_P(6)
+#undef HMK_P
     }
-#define HMK_F(XV, DV, CAPV) if (X == XV && d == DV && cap == CAPV) return launch_rows_t<XV, DV, CAPV, false>(P, tile_base, n_tiles, s);
-    HMK_ROWS_CAP_LIST(HMK_F)
-#undef HMK_F
     return hipErrorInvalidValue;
 }
 
-hipError_t warm_neighbors_rows_module() {
-    hipFuncAttributes a;
-    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_neighbors_rows<3, 0, 12, true, rows_groups(3, 0, 12, true), EDGES_PLAIN>));
-}
+hipError_t warm_neighbors_rows_module() { return warm_rows_part_0(); }
 
 }  // namespace hmk

@@ -27,11 +27,12 @@
 extern "C" {
 #endif
 
-#define HMK_ABI_VERSION 2
+#define HMK_ABI_VERSION 3
 #define HMK_ALPHABET 24
 #define HMK_MAX_LEN 32          /* longest sequence the GPU kernels accept */
 #define HMK_MAX_SEQUENCES (1u << 24)
-#define HMK_EDGE_SHARDS 16      /* output segments of the neighbour kernel */
+#define HMK_EDGE_SHARDS 64      /* output segments of the neighbour kernel (ABI 3: 64, was 16 -- a segment's cursor is ONE address, and a
+                                 * pass whose waves drain 4 x 10^5 stages serialises on 16 of them) */
 
 typedef enum {
     HMK_OK = 0,

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.SYMBOLS)
     for name in declared:
         assert hasattr(N.lib, name), name
-    assert N.lib.hmk_abi_version() == 2
+    assert N.lib.hmk_abi_version() == 3
 
 
 def test_no_gpu_fails_loudly(blosum62):
