@@ -351,6 +351,10 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     if (getenv("HMK_NO_ROW_BOUNDS")) refine = false;
     std::vector<uint32_t> bound_sorted;  // bound of the sequence at each sorted position (refine only)
     constexpr uint32_t BCAP = 4095;      // bounds are only compared with limits < 65536; clamped for the counting sort
+    // refine, but EVERY row of every class that needs its bound has one within the class's limit (uniform 15- or 20-mers at the
+    // reference's default threshold: a 20-mer's bound is ~112 +- 8 against a limit of 161): the buckets keep the caller's order
+    // -- no reordering, so the band of a clustering call survives and a one-length set keeps its compile-time-length kernel
+    bool all_rows_fit = false;
     if (refine) {
         long long best[HMK_ALPHABET];
         for (int a = 0; a < HMK_ALPHABET; a++) {
@@ -365,9 +369,24 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
             for (uint32_t q = ctx->off[k]; q < ctx->off[k + 1]; q++) b += best[ctx->res[q]];
             bound[k] = (uint32_t)std::min<long long>(b, BCAP);
         }
+        {
+            uint32_t bucket_max[HMK_MAX_LEN + 2] = {0};
+            for (uint32_t k = 0; k < n; k++) bucket_max[ctx->len[k]] = std::max(bucket_max[ctx->len[k]], bound[k]);
+            all_rows_fit = getenv("HMK_ALWAYS_SORT_BOUNDS") == nullptr;
+            for (int la = 1; la <= HMK_MAX_LEN && all_rows_fit; la++)
+                for (int lb = 1; lb <= HMK_MAX_LEN && all_rows_fit; lb++) {
+                    if (bucket[la] == bucket[la + 1] || bucket[lb] == bucket[lb + 1]) continue;
+                    if (ctx->symmetric && lb > la) continue;
+                    TileClass tc;
+                    long long limit = -1;
+                    classify(ctx, la, lb, X, p, thr, &tc, -1, &limit);
+                    if (tc.path == PATH_U8) continue;
+                    if (limit < 0 || (long long)bucket_max[la] > std::min<long long>(limit, BCAP - 1)) all_rows_fit = false;
+                }
+        }
         // stable counting sort of every length bucket by bound
         std::vector<uint32_t> sorted(n), cnt(BCAP + 2);
-        for (int l = 1; l <= HMK_MAX_LEN; l++) {
+        for (int l = 1; l <= HMK_MAX_LEN && !all_rows_fit; l++) {
             const uint32_t b0 = bucket[l], b1 = bucket[l + 1];
             if (b0 == b1) continue;
             std::fill(cnt.begin(), cnt.end(), 0u);
@@ -375,14 +394,14 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
             for (uint32_t v = 0; v <= BCAP; v++) cnt[v + 1] += cnt[v];
             for (uint32_t q = b0; q < b1; q++) sorted[b0 + cnt[bound[perm[q]]]++] = perm[q];
         }
-        perm.swap(sorted);
+        if (!all_rows_fit) perm.swap(sorted);
         bound_sorted.resize(n);
         for (uint32_t q = 0; q < n; q++) bound_sorted[q] = bound[perm[q]];
     }
     // band members of a length bucket are its leading sorted positions (the counting sort keeps caller order); a
     // bucket reordered by score bound has no such prefix, so the band is dropped there (phase 1 then waits for the pass)
     uint32_t band_end[HMK_MAX_LEN + 2];
-    if (refine) band_rows = 0;
+    if (refine && !all_rows_fit) band_rows = 0;
     for (int l = 0; l <= HMK_MAX_LEN; l++) {
         band_end[l] = bucket[l];
         if (band_rows > 0)
@@ -403,7 +422,8 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     if (use_rows && ctx->min_len == ctx->max_len) {
         TileClass t1;
         classify(ctx, ctx->min_len, ctx->min_len, X, p, thr, &t1);
-        pl.rows_exact = t1.path == PATH_U8 && rows_kernel_available(X, ctx->min_len, ctx->min_len, true) &&
+        // (8-bit lanes for any pair of the class, or -- by their score bounds -- for every row the set has)
+        pl.rows_exact = (t1.path == PATH_U8 || (refine && all_rows_fit)) && rows_kernel_available(X, ctx->min_len, ctx->min_len, true) &&
                         getenv("HMK_NO_ROWS_EXACT") == nullptr;
     }
     if (!use_rows && ctx->min_len == 12 && ctx->max_len == 12 && X == 3) {
@@ -460,8 +480,9 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                 uint32_t split = rb;  // rows [rb, split) fit 8-bit lanes by their bound
                 if (refine && tc0.path != PATH_U8 && limit >= 0) {
                     const uint32_t lim = (uint32_t)std::min<long long>(limit, BCAP - 1);  // a clamped bound never passes
-                    split = (uint32_t)(std::upper_bound(bound_sorted.begin() + rb, bound_sorted.begin() + re, lim) -
-                                       bound_sorted.begin());
+                    split = all_rows_fit ? re   // (caller order kept: every row of the bucket is within the limit)
+                                         : (uint32_t)(std::upper_bound(bound_sorted.begin() + rb, bound_sorted.begin() + re, lim) -
+                                                      bound_sorted.begin());
                     if (split > rb) {
                         TileClass t8;
                         classify(ctx, la, lb, X, p, thr, &t8, lim);

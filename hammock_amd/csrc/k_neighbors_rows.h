@@ -362,24 +362,29 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
     // Left to the compiler, an iteration of this loop (64 records) is a chain of round trips: the records' columns, (mixed
     // lengths: the permutation,) the placing atomics' return values, and -- because the compiler does not count loads and
     // stores in flight across a loop's back edge and waits with vmcnt(0) wherever it needs one of them -- the edge stores'
-    // completion as well.  So the loop's loads, atomics and stores are issued by inline asm, which the compiler does not
-    // count, in an order that needs ONE wait per iteration:
-    //     atomics of these 64 records (they need the records only)  ->  columns (+ permutation) of the NEXT 64 records  ->
-    //     rescoring of these (table reads, adds: the round trips above run meanwhile)  ->  s_waitcnt vmcnt(0)  ->  stores,
-    // and the stores have the whole next iteration to complete.  Everything is issued by all 64 lanes at valid addresses (a
-    // lane without a record reads the tile's first column and adds 0 to its first row's counter), so no value that is still
-    // in flight ever meets a branch or a copy; what the asm statements define is only used behind `settle`.
+    // completion as well.  Here ONE asm statement per iteration issues the atomics of these 64 records and the loads for the
+    // NEXT 64 (columns, tails, permutation) and waits for all of them (cdna_hip_programming.md, inline asm: "the loads and
+    // their s_waitcnt in ONE statement", early-clobber outputs -- the only form in which no value the compiler can see is
+    // still in flight), and the stores, issued by asm after it, have the next iteration's rescoring to complete: one round
+    // trip per 64 records instead of three or four.  Everything is issued by all 64 lanes at valid addresses (a lane without
+    // a record reads the tile's first column and adds 0 to its first row's counter): no branch inside the statement.
+    // (A first version let the rescoring run between the issue and the wait, each load an asm statement of its own with a
+    // "=v" output: the compiler copied such a register -- v_mov of a loaded word, hoisted above the wait -- before the load
+    // had written it, and 7-mers at a dense threshold got stale columns in one wave of four, now and then.  The rescoring is
+    // a fifth of a round trip: hiding it there was not worth a value in flight.)
     // What it bought ("where a hit's time goes"): the clustering calls' placing pass, whose every iteration used
-    // to wait for two returning atomics (10^5: 3.61 -> 3.41 ms); the plain pass did not move -- there an iteration's time is the
-    // latency of ONE thing, the gather of 64 columns from 30-60 different cache lines, and the rescoring (0.03 ms of the 0.6 ms
-    // that 8 x 10^7 hits cost the 10^5 pass), the stores (nothing) and the append loop (0.07 ms) hide inside it (builds that leave
-    // one part out, HMK_ROWS_DBG).
+    // to wait for two returning atomics on top of the gather (10^5: 3.61 -> 3.41 ms); the plain pass did not move -- there an
+    // iteration's time is the latency of ONE thing, the gather of 64 columns from 30-60 different cache lines, with or without
+    // the rescoring (0.03 ms of the 0.6 ms that 8 x 10^7 hits cost the 10^5 pass), the stores (nothing) and the append loop (0.07 ms;
+    // builds that leave one part out, HMK_ROWS_DBG).
     struct Next {
-        uint32_t rt, mcol;            // row within the tile, column (sorted position)
-        uint32_t w[S::LPADW], tw[S::TWN];   // the column's residue words (in flight until the next settle)
-        uint32_t px, pm;              // perm[row], perm[column] (in flight; unless the sorted order is the caller's)
+        uint32_t rt, mcol;                  // row within the tile, column (sorted position)
+        uint32_t w[S::LPADW], tw[S::TWN];   // the column's residue words
+        uint32_t px, pm;                    // perm[row], perm[column], or the indices themselves
     } nx;
-    auto issue_fetch = [&](uint32_t k0) {
+    uint32_t rx = 0, rm = 0;   // the placing atomics' return values
+    // decode the records of iteration k0 into nx.rt / nx.mcol and return the addresses the statement loads from
+    auto decode = [&](uint32_t k0) {
         const bool live = k0 + lane < cnt;
         const uint32_t rec = live ? stage[k0 + lane] : 0u;
         // the record (see the append loop): bit q of the lane's hit word at the step that looked, noted `back` steps earlier
@@ -389,57 +394,61 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         const uint32_t r = (b >> 3) + 4u - (b & 4u);          // bit 8r + 7: row r; bit 8r + 3: row 4 + r
         nx.rt = live ? grp * 8u + r : 0u;
         nx.mcol = A.col0 + (live ? (rec & 0xFFFFu) - back * 256u : 0u);
+    };
+    // the statement: [atomics of the current records: ux / um += one, old values -> r0 / r1] + loads for the records decoded last
+    // + the wait.  One asm per combination, each with exactly the operands it uses (outputs are early-clobber: a superset of
+    // operands cost 16 registers and a spill).  W_S / W_OUT: the column words' load(s) and destination(s).
+#define HMK_FLUSH_ST_000(W_S, ...) asm volatile(W_S "s_waitcnt vmcnt(0)" : __VA_ARGS__ : [colp] "v"(colp) : "memory")
+#define HMK_FLUSH_ST_001(W_S, ...) asm volatile(W_S "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
+#define HMK_FLUSH_ST_010(W_S, ...) asm volatile(W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [t0] "=&v"(t0), [t1] "=&v"(t1) : [colp] "v"(colp), [tp] "v"(tp) : "memory")
+#define HMK_FLUSH_ST_011(W_S, ...) asm volatile(W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [t0] "=&v"(t0), [t1] "=&v"(t1), [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [tp] "v"(tp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
+#define HMK_FLUSH_ST_100(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2) : "memory")
+#define HMK_FLUSH_ST_101(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1), [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
+#define HMK_FLUSH_ST_110(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0), [t1] "=&v"(t1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2), [tp] "v"(tp) : "memory")
+#define HMK_FLUSH_ST_111(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0), [t1] "=&v"(t1), [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2), [tp] "v"(tp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
+#define HMK_FLUSH_ST(W_S, ...)                                                                          \
+    do {                                                                                                  \
+        if (MODE == EDGES_PLACE && atomics) {                                                             \
+            if constexpr (EXACT_LB || S::TW == 0) { if (A.perm_identity) HMK_FLUSH_ST_100(W_S, __VA_ARGS__); else HMK_FLUSH_ST_101(W_S, __VA_ARGS__); } \
+            else { if (A.perm_identity) HMK_FLUSH_ST_110(W_S, __VA_ARGS__); else HMK_FLUSH_ST_111(W_S, __VA_ARGS__); } \
+        } else {                                                                                          \
+            if constexpr (EXACT_LB || S::TW == 0) { if (A.perm_identity) HMK_FLUSH_ST_000(W_S, __VA_ARGS__); else HMK_FLUSH_ST_001(W_S, __VA_ARGS__); } \
+            else { if (A.perm_identity) HMK_FLUSH_ST_010(W_S, __VA_ARGS__); else HMK_FLUSH_ST_011(W_S, __VA_ARGS__); } \
+        }                                                                                                 \
+    } while (0)
+    // x, m, ok: the CURRENT records' edge ends and whether they are stored (atomics only when `atomics`)
+    auto statement = [&](bool atomics, uint32_t x, uint32_t m, bool ok) {
         const uint8_t *colp = A.res_sorted + (size_t)(HMK_ROWS_DBG == 3 ? A.col0 : nx.mcol) * A.lpad;   // (DBG 3: every lane fetches the tile's first column)
-        if constexpr (S::LPADW == 2) {
-            u32x2 v;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(colp) : "memory");
-            nx.w[0] = v.x; nx.w[1] = v.y;
-        } else {
-            u32x4 v;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(colp) : "memory");
-            nx.w[0] = v.x; nx.w[1] = v.y; nx.w[2] = v.z; nx.w[3] = v.w;
-            if constexpr (S::LPADW == 8) {
-                u32x4 v1;
-                asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(v1) : "v"(colp) : "memory");
-                nx.w[4] = v1.x; nx.w[5] = v1.y; nx.w[6] = v1.z; nx.w[7] = v1.w;
-            }
+        const uint8_t *tp = colp + (lbs - X);
+        const uint32_t *pxp = A.perm + (A.row0 + nx.rt), *pmp = A.perm + nx.mcol;
+        // (an asymmetric matrix has no lower counters: its second atomic adds 0 to the upper one)
+        const uint32_t *ux = A.deg_up + x, *um = A.symmetric ? A.deg_lo + m : A.deg_up + x;
+        const uint32_t one = ok ? 1u : 0u, one2 = A.symmetric ? one : 0u;
+        u32x2 w2 = {0, 0};
+        u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0};
+        uint32_t t0 = 0, t1 = 0, p0 = 0, p1 = 0, r0 = 0, r1 = 0;
+        if constexpr (S::LPADW == 2) HMK_FLUSH_ST("global_load_dwordx2 %[w2], %[colp], off\n\t", [w2] "=&v"(w2));
+        else if constexpr (S::LPADW == 4) HMK_FLUSH_ST("global_load_dwordx4 %[wa], %[colp], off\n\t", [wa] "=&v"(wa));
+        else HMK_FLUSH_ST("global_load_dwordx4 %[wa], %[colp], off\n\tglobal_load_dwordx4 %[wb], %[colp], off offset:16\n\t", [wa] "=&v"(wa), [wb] "=&v"(wb));
+        if constexpr (S::LPADW == 2) { nx.w[0] = w2.x; nx.w[1] = w2.y; }
+        else {
+            nx.w[0] = wa.x; nx.w[1] = wa.y; nx.w[2] = wa.z; nx.w[3] = wa.w;
+            if constexpr (S::LPADW == 8) { nx.w[4] = wb.x; nx.w[5] = wb.y; nx.w[6] = wb.z; nx.w[7] = wb.w; }
         }
 #pragma unroll
         for (int t = 0; t < S::TWN; t++) nx.tw[t] = 0;
-        if constexpr (!EXACT_LB && S::TW > 0) {   // the last X residues, wherever the column ends (unaligned dword loads; the array is padded)
-#pragma unroll
-            for (int t = 0; t < S::TW; t++) {
-                const uint8_t *tp = colp + (lbs - X) + 4 * t;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(nx.tw[t]) : "v"(tp) : "memory");
-            }
-        }
-        nx.px = A.row0 + nx.rt; nx.pm = nx.mcol;
-        if (!A.perm_identity) {   // wave-uniform
-            const uint32_t *pxp = A.perm + nx.px, *pmp = A.perm + nx.pm;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(nx.px) : "v"(pxp) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(nx.pm) : "v"(pmp) : "memory");
-        }
+        if constexpr (!EXACT_LB && S::TW > 0) { nx.tw[0] = t0; if constexpr (S::TW > 1) nx.tw[1] = t1; }
+        nx.px = A.perm_identity ? A.row0 + nx.rt : p0;
+        nx.pm = A.perm_identity ? nx.mcol : p1;
+        if (MODE == EDGES_PLACE && atomics) { rx = r0; rm = A.symmetric ? r1 : 0u; }
     };
-    uint32_t rx = 0, rm = 0;   // the placing atomics' return values (in flight until the settle)
-    auto settle = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // (what was in flight is "modified" here: no use of it can be moved above the wait)
-#pragma unroll
-        for (int t = 0; t < S::LPADW; t++) asm volatile("" : "+v"(nx.w[t]));
-#pragma unroll
-        for (int t = 0; t < S::TWN; t++) asm volatile("" : "+v"(nx.tw[t]));
-        asm volatile("" : "+v"(nx.px));
-        asm volatile("" : "+v"(nx.pm));
-        asm volatile("" : "+v"(rx));
-        asm volatile("" : "+v"(rm));
-    };
-    issue_fetch(0);
+    decode(0);
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(&A.counts[A.shard], (unsigned long long)cnt);
+    statement(false, 0u, 0u, false);
     const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
     const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
     base = ((unsigned long long)bhi << 32) | blo;
-    settle();
     for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {   // wave-uniform trip count: the table reads below run for whole waves
         const uint32_t k = k0 + lane;
         const bool live = k < cnt;
@@ -454,18 +463,12 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         const unsigned long long pos = base + k;
         const bool ok = live && pos < A.cap_per_shard;   // stored edges only (place_edge, hmk_device.h)
         const unsigned long long slot = (unsigned long long)A.shard * A.cap_per_shard + pos;
-        if (MODE == EDGES_PLACE) {
-            const uint32_t one = ok ? 1u : 0u;
-            const uint32_t *ux = A.deg_up + x, *um = A.deg_lo + m;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(rx) : "v"(ux), "v"(one) : "memory");
-            if (A.symmetric) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(rm) : "v"(um), "v"(one) : "memory");   // (wave-uniform; rm stays 0 otherwise)
-        } else if (MODE == EDGES_COUNT) {
+        if (MODE == EDGES_COUNT) {
             if (ok) {   // fire-and-forget: nothing of these is waited for
                 atomicAdd(&A.deg[x], 1u);
                 if (A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
             }
         }
-        issue_fetch(k0 + 64);   // (past the last record: every lane reads the tile's first column -- harmless, and no branch)
         // The record's ROW is byte r of every 8-byte table entry: the lane reads the 4-byte half that holds it (ds_read_b32: 1
         // LDS cycle per wave-instruction where the ds_read_b64 of all eight rows takes 2), sums the halves as they are -- four
         // byte lanes, proven not to carry -- and cuts its byte out of each plane's sum: one v_add3 per two cells + one v_bfe
@@ -525,7 +528,8 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
             }
         }
         const int score = (int)mx - 128 + A.threshold;   // lane = 128 - threshold + score
-        settle();
+        decode(k0 + 64);   // (past the last record: every lane reads the tile's first column -- harmless, and no branch)
+        statement(true, x, m, ok);
         if (ok && (HMK_ROWS_DBG != 4 || score == 0x7fff)) {   // (DBG 4: nothing is stored)
             const unsigned long long e = ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
             const uint64_t *ep = A.edges + slot;
@@ -537,6 +541,15 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
             }
         }
     }
+#undef HMK_FLUSH_ST
+#undef HMK_FLUSH_ST_000
+#undef HMK_FLUSH_ST_001
+#undef HMK_FLUSH_ST_010
+#undef HMK_FLUSH_ST_011
+#undef HMK_FLUSH_ST_100
+#undef HMK_FLUSH_ST_101
+#undef HMK_FLUSH_ST_110
+#undef HMK_FLUSH_ST_111
     asm volatile("" ::: "memory");   // (the stage's reads are done: their values were used)
     drain_end();
 }
@@ -807,6 +820,7 @@ static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uin
     C(4, 4, 8, 12) \
     C(5, 4, 0, 16) C(5, 4, 1, 16) C(5, 4, 2, 16) C(5, 4, 3, 16) C(5, 4, 4, 16) C(5, 4, 5, 16) C(5, 4, 6, 16) C(5, 4, 7, 16) \
     C(5, 4, 0, 20) C(5, 4, 1, 20) C(5, 4, 2, 20) C(5, 4, 3, 20) \
+    C(6, 5, 0, 12) C(6, 5, 1, 12) C(6, 5, 2, 12) \
     C(6, 5, 0, 16) C(6, 5, 1, 16) C(6, 5, 2, 16) C(6, 5, 3, 16) C(6, 5, 4, 16) \
     C(6, 5, 0, 20) C(6, 5, 1, 20) C(6, 5, 2, 20) C(6, 5, 3, 20) C(6, 5, 4, 20)
 #endif

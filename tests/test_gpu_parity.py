@@ -139,6 +139,7 @@ def test_neighbors_len12_blosum62(gpu, blosum62, coracle):
     for thr in (20, 12, 35):
         edges, stats = ctx.neighbors_shifted(3, 0, thr)
         assert stats.symmetric == 1 and stats.classes_u8 == 1 and stats.classes_u16 == stats.classes_direct == 0
+        assert stats.classes_rows == 1                      # the row-packed kernel ran, not the shift-packed tier
         assert stats.pairs_scored == 3000 * 2999 // 2
         assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, blosum62, res, off, 3, 0, thr)), thr
 
@@ -150,6 +151,68 @@ def test_neighbors_dense_all_pairs(gpu, blosum62, coracle):
     edges, stats = ctx.neighbors_shifted(3, 0, -48)
     assert len(edges) == 700 * 699 // 2
     assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, blosum62, res, off, 3, 0, -48))
+
+
+def java_round(v):
+    """Math.round for positive doubles: half up (Hammock.java:1409-1434)."""
+    return int(np.floor(v + 0.5))
+
+
+@pytest.mark.parametrize("L", list(range(6, 21)))
+def test_neighbors_uniform_lengths_at_the_reference_defaults(gpu, blosum62, coracle, L):
+    """Every uniform length 6..20 with the max shift and threshold the reference derives for it (Hammock.java:1409-1434:
+    X = round(L / 4), threshold = round(1.7 L)) and at a low threshold (15 % of the pairs are hits: the flush at work): the
+    row-packed kernel must be the one that runs, and the edge set must equal the oracle's."""
+    X, thr = min(java_round(L / 4), L - 1), java_round(1.7 * L)
+    res, off = synth_peptides(L, 1400, L)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    for t in (thr, java_round(0.4 * L)):
+        edges, stats = ctx.neighbors_shifted(X, 0, t)
+        assert stats.classes_rows == 1 and stats.classes_u8 == 1, (L, X, t, stats.classes_u8, stats.classes_u16, stats.classes_rows)
+        assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, blosum62, res, off, X, 0, t)), (L, X, t)
+    assert len(edges) > 0.05 * 1400 * 1399 / 2          # the low threshold really is dense
+
+
+@pytest.mark.parametrize("case", [(12, 1, 0, 20), (12, 2, -1, 18), (12, 4, 0, 22), (12, 5, -1, 20), (9, 3, 0, 14), (16, 2, 0, 30),
+                                  (20, 3, -2, 40), (7, 1, 0, 10)])
+def test_neighbors_uniform_lengths_other_shifts(gpu, blosum62, coracle, case):
+    """-x is free (Hammock.java:807-811): uniform sets at max shifts other than the derived one run the capacity form."""
+    L, X, p, thr = case
+    res, off = synth_peptides(100 + L, 1300, L)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(X, p, thr)
+    assert stats.classes_rows == 1, case
+    assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, blosum62, res, off, X, p, thr)), case
+
+
+@pytest.mark.parametrize("case", [
+    ("blosum62", 6, 12, 2, -1, 14, 20),    # mean length 9: X = 2
+    ("blosum62", 10, 20, 4, -1, 25, 40),   # mean 15: X = 4
+    ("blosum62", 13, 20, 5, 0, 30, 20),    # mean 16.5 .. X = 5 by -x
+    ("blosum62", 4, 9, 1, 0, 10, 10),
+])
+def test_neighbors_mixed_lengths_other_shifts(gpu, matrices, coracle, case):
+    """Mixed lengths at max shifts 1, 2, 4, 5: most classes run a row-packed capacity form (the rest the shift-packed tier)."""
+    mat, lo, hi, X, p, thr, min_rows = case
+    M = matrices[mat]
+    res, off = synth_peptides(3, 1800, lo, hi)
+    ctx, _, _ = ctx_for(M, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(X, p, thr)
+    assert stats.classes_rows >= min_rows, (case, stats.classes_rows, stats.classes_u8)
+    assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, M, res, off, X, p, thr)), case
+
+
+@pytest.mark.parametrize("case", [(12, 12, 3, 0, 20), (7, 20, 3, -1, 23), (7, 7, 2, 0, 12), (10, 20, 4, -1, 25)])
+def test_neighbors_shift_packed_tier_still_exact(gpu, blosum62, coracle, monkeypatch, case):
+    """HMK_NO_ROWS_KERNEL=1: everything runs the shift-packed kernels of rounds 1-2 (the tier behind the row-packed one for the
+    classes it has no instantiation for) -- still bit-exact, and the stats say which tier ran."""
+    lo, hi, X, p, thr = case
+    monkeypatch.setenv("HMK_NO_ROWS_KERNEL", "1")
+    res, off = synth_peptides(8, 1500, lo, hi)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(X, p, thr)
+    assert stats.classes_rows == 0 and stats.classes_u8 > 0
+    assert np.array_equal(sorted_edges(edges), oracle_edges(coracle, blosum62, res, off, X, p, thr)), case
 
 
 @pytest.mark.parametrize("case", [
@@ -1257,6 +1320,7 @@ def test_config4_full_size(gpu, blosum62, coracle, leg):
         X, p, thr = 3, -1, 23
         edges, stats = ctx.neighbors_shifted(X, p, thr, capacity=60_000_000)
         assert stats.pairs_scored == n * (n - 1) // 2
+        assert stats.classes_u8 + stats.classes_u16 + stats.classes_direct == 106 and stats.classes_rows >= 100   # (105: all but (20, 20), whose lanes need the row bound)
         scorer, a, b = 0, X, p
     x, m, s = hammock_amd.edge_fields(edges)
     assert len(edges) > 10 ** 6 and (s >= thr).all() and (x != m).all() and len(np.unique(edges)) == len(edges)
