@@ -83,3 +83,17 @@ def random_peptides(rng, n, len_lo, len_hi, alphabet=20):
         seen.add(key)
         out.append(p)
     return out
+
+
+def hand_traces():
+    """tests/golden/hand_traces.json + the matrix it describes (int32 [24][24])."""
+    import json
+    import numpy as np
+    with open(os.path.join(GOLDEN, "hand_traces.json")) as fh:
+        ht = json.load(fh)
+    alphabet = "ARNDCQEGHILKMFPSTWYVBZX*"
+    m = ht["matrix"]
+    M = np.full((24, 24), m["off_diagonal"], dtype=np.int32)
+    for k, a in enumerate(alphabet):
+        M[k, k] = m["diagonal"].get(a, m["diagonal_default"])
+    return ht, M

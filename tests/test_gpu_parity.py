@@ -805,6 +805,35 @@ def test_score_with_shift_vs_oracle(gpu, blosum62, coracle):
             assert (score[k], shift[k]) == (s, sh)
 
 
+def test_hand_traced_vectors_on_gpu(gpu):
+    """tests/golden/hand_traces.json (traced by hand through LimitedGreedySequenceClusterer.java:39-120 and
+    ClinkageSequenceClusterer.java:43-124, every step in hand_traces.md) through hmk_greedy_cluster / hmk_clinkage_cluster:
+    ids, list order, member order, the three NullPointerException branches, both HashSet iteration orders."""
+    from conftest import hand_traces
+    ht, M = hand_traces()
+    X, p = ht["max_shift"], ht["shift_penalty"]
+    for case in ht["greedy"]:
+        ctx, _, _ = ctx_for(M, case["sequences"], sizes=np.asarray(case["sizes"], dtype=np.int32))
+        exp = case["expect"]
+        if exp["status"] == "crash":
+            with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
+                ctx.greedy_cluster(X, p, case["threshold"], case["max_clusters"])
+            assert (ei.value.case, ei.value.index) == (exp["crash_case"], exp["crash_index"]), case["name"]
+            continue
+        cid, order, stats = ctx.greedy_cluster(X, p, case["threshold"], case["max_clusters"])
+        n = len(case["sequences"])
+        assert cid.tolist() == exp["cluster_id"] and order.tolist() == exp["result_order"], case["name"]
+        assert ctx.member_rank[:n].tolist() == exp["member_rank"], case["name"]
+    for case in ht["clinkage"]:
+        for version, key in ((8, "expect_java8"), (7, "expect_java7")):
+            ctx, _, _ = ctx_for(M, case["sequences"], sizes=np.asarray(case["sizes"], dtype=np.int32))
+            ctx.set_java_hashset(version)
+            cid, order, stats = ctx.clinkage_cluster(X, p, case["threshold"])
+            exp, n = case[key], len(case["sequences"])
+            assert cid.tolist() == exp["cluster_id"] and order.tolist() == exp["result_order"], (case["name"], version)
+            assert ctx.member_rank[:n].tolist() == exp["member_rank"], (case["name"], version)
+
+
 # --------------------------------------------------------------------------------------
 # clinkage mode (ClinkageSequenceClusterer.cluster) end to end
 # --------------------------------------------------------------------------------------

@@ -451,3 +451,58 @@ def test_clinkage_chain_returns_to_a_stacked_cluster(matrices, coracle):
     res, off = coracle.pack(STACKED_AGAIN)
     st, cid, order, rank, stats = coracle.clinkage_cluster(M, res, off, None, 2, -2, 25, 1)
     assert st == 0 and stats.merges == 1 and cid.tolist() == [1, 2, 6, 6]
+
+
+# --------------------------------------------------------------------------------------
+# hand-traced vectors (tests/golden/hand_traces.md): the only pin a box without a JVM can add
+# --------------------------------------------------------------------------------------
+def test_hand_traced_greedy_vectors_both_oracles(coracle):
+    """Every case of tests/golden/hand_traces.json was traced BY HAND through LimitedGreedySequenceClusterer.java:39-120 (one
+    table row per loop iteration in hand_traces.md); both restatements must reproduce ids, list order and member order,
+    or the reference's NullPointerException with its branch and index."""
+    from conftest import hand_traces
+    ht, M = hand_traces()
+    X, p = ht["max_shift"], ht["shift_penalty"]
+    for case in ht["greedy"]:
+        peps = [coracle.encode(s) for s in case["sequences"]]
+        sizes = np.asarray(case["sizes"], dtype=np.int32)
+        for threads in (1, 3):
+            st, cid, stats = _greedy_both(coracle, M, peps, sizes, X, p, case["threshold"], case["max_clusters"], n_threads=threads)
+            exp = case["expect"]
+            if exp["status"] == "crash":
+                assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH, case["name"]
+                assert (stats.crash_case, stats.crash_index) == (exp["crash_case"], exp["crash_index"]), case["name"]
+                continue
+            assert st == 0, case["name"]
+            res, off = coracle.pack(peps)
+            st, cid, order, stats = coracle.greedy_cluster(M, res, off, sizes, 0, X, p, case["threshold"], case["max_clusters"], threads)
+            assert cid.tolist() == exp["cluster_id"], case["name"]
+            assert order.tolist() == exp["result_order"], case["name"]
+            assert np.asarray(stats.member_rank)[:len(peps)].tolist() == exp["member_rank"], case["name"]
+
+
+def test_hand_traced_clinkage_vectors_both_oracles(coracle):
+    """The clinkage chains of hand_traces.json, traced by hand through ClinkageSequenceClusterer.java:43-124 for the HashSet
+    iteration orders of Java 8 and of JDK 7u6+ (hand_traces.md works the bucket indices out)."""
+    from conftest import hand_traces
+    ht, M = hand_traces()
+    X, p = ht["max_shift"], ht["shift_penalty"]
+    for case in ht["clinkage"]:
+        peps = [coracle.encode(s) for s in case["sequences"]]
+        sizes = np.asarray(case["sizes"], dtype=np.int32)
+        res, off = coracle.pack(peps)
+        for version, key in ((8, "expect_java8"), (7, "expect_java7")):
+            exp = case[key]
+            coracle.set_java_hashset(version)
+            po.JAVA_HASHSET = version
+            try:
+                st, cid, order, rank, stats = coracle.clinkage_cluster(M, res, off, sizes, X, p, case["threshold"], 1)
+                pcid, porder, prank, _ = _clinkage_python(M, peps, sizes, X, p, case["threshold"])
+            finally:
+                coracle.set_java_hashset(8)
+                po.JAVA_HASHSET = 8
+            assert st == 0
+            for got_cid, got_order, got_rank, who in ((cid, order.tolist(), rank, "C"), (pcid, porder, prank, "python")):
+                assert np.asarray(got_cid).tolist() == exp["cluster_id"], (case["name"], version, who)
+                assert list(got_order) == exp["result_order"], (case["name"], version, who)
+                assert np.asarray(got_rank).tolist() == exp["member_rank"], (case["name"], version, who)
