@@ -52,15 +52,20 @@ def load_blosum62():
 
 def pmc_traffic(n, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/round3_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
+    (profiles/round4_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
     command, gfx950 x2 read correction applied).  Counters cannot be read from inside the timed
     run, so the value is only reported for the workload it was collected on; otherwise null."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round3_pmc_summary.json")) as fh:
-            d = json.load(fh)
+        d = None
+        for name in ("round4_pmc_summary.json", "round3_pmc_summary.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                with open(path) as fh:
+                    d = json.load(fh)
+                break
         if n == N_SEQ and world == 1:
             return d["hbm_traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         pass
     return None
 
@@ -135,51 +140,115 @@ def lds_ideal_ms(lengths, X):
     return total / (LDS_PEAK_GBS * 1e9) * 1e3
 
 
+def load_fasta_unique(path):
+    """FileIOManager.loadUniqueSequencesFromFasta (FileIOManager.java:159-202) for `>id|count|label` files: duplicates merged,
+    counts summed, then the reference's default order (-R size: count descending, then the string descending)."""
+    import gzip
+    opener = gzip.open if path.endswith(".gz") else open
+    counts, seen = {}, []
+    with opener(path, "rt") as fh:
+        cnt = 1
+        for line in fh:
+            line = line.strip()
+            if line.startswith(">"):
+                f = line[1:].split("|")
+                cnt = int(f[1]) if len(f) > 1 and f[1] else 1
+            elif line:
+                q = line.upper()
+                if q not in counts:
+                    counts[q] = 0
+                    seen.append(q)
+                counts[q] += cnt
+    seqs = sorted(seen, key=lambda q: (-counts[q], [-ord(c) for c in q]))
+    return seqs, np.array([counts[q] for q in seqs], dtype=np.int32)
+
+
+# LocalAlignmentScorer.java:43-81, one DP cell: 2 selects (:43-48 up gap open/extend, :50-55 left), 3 adds (:57-59), 2 max (:61),
+# 1 clamp at zero (:63-67), 3 direction tests (:73-81), 1 running maximum (:68-72)
+LOCAL_OPS_PER_CELL = 12
+
+
 def other_configs(M, dev, stream):
     """The other BASELINE configs that fit one GPU, run AFTER the timed region (never inside it): config 2 (1e4 12-mers),
     4a (1e5 peptides of length 7..20, ShiftedScorer p = -1, thr 23), 4b (the same set, LocalAlignmentScorer -5 / -1, all
-    ordered pairs, thr 28) and one of the 8 shards of config 5 (1e6 12-mers).  Kernel time by HIP events on the launch
-    stream, median of a few passes after a warm-up; each with its own roofline fraction."""
+    ordered pairs, thr 28), one of the 8 shards of config 5 (1e6 12-mers), and two inputs off the tuned shape: 1e5 7-mers at
+    the reference's defaults (Ph.D.-7 libraries: max shift 2, threshold 12, 2.1 % of the pairs are hits) and the reference's
+    own antibodies example.  Kernel time by HIP events on the launch stream, median of a few passes after a warm-up; each with
+    its own roofline fraction.  The edge buffer is sized from a first pass (a segment that overflows drops edges, and a pass
+    that drops edges has not done its work): `overflowed` says whether the timed passes stored every edge."""
     import torch
     import hammock_amd
     from hammock_amd import _native
     from hammock_amd.synth import synth_peptides
     out = []
-    cap = 1 << 25
-    d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
-    d_counts = torch.zeros(_native.HMK_EDGE_SHARDS, dtype=torch.int64, device=dev)
+    S = _native.HMK_EDGE_SHARDS
+    d_counts = torch.zeros(S, dtype=torch.int64, device=dev)
 
-    def shifted(name, n, lo, hi, X, p, thr, part, n_parts, reps, warm):
-        res, off = synth_peptides(1, n, lo, hi)
+    def shifted(name, res, off, sizes, X, p, thr, part, n_parts, reps, warm, seqs=None):
         ctx = hammock_amd.Context(M, device=dev.index)
-        ctx.set_sequences(residues=res, offsets=off)
-        ms = []
-        for k in range(warm + reps):
+        if seqs is not None:
+            ctx.set_sequences(seqs, sizes=sizes)
+            lengths = np.array([len(q) for q in seqs], dtype=np.int64)
+        else:
+            ctx.set_sequences(residues=res, offsets=off)
+            lengths = np.diff(off.astype(np.int64))
+        n = len(lengths)
+        cap = (1 << 22) // S * S
+        d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
+        ms, sized = [], False
+        k = 0
+        while k < warm + reps:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
             ctx.neighbors_shifted_dev(X, p, thr, part, n_parts, d_edges.data_ptr(), cap, d_counts.data_ptr(), stream.cuda_stream)
             b.record(stream)
             torch.cuda.synchronize(dev)
+            if not sized:   # the counts of a pass are exact even when a segment overflowed: size the buffer from them, once
+                mx = int(d_counts.max().item())
+                if mx > cap // S:
+                    cap = (mx + mx // 8 + 1024) * S
+                    del d_edges
+                    d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
+                    sized = True
+                    continue
+                sized = True
             if k >= warm:
                 ms.append(a.elapsed_time(b))
+            k += 1
         plan = ctx.last_plan()
         med = float(np.median(ms))
-        ideal = lds_ideal_ms(np.diff(off.astype(np.int64)), X) * (int(plan.pairs_scored) / (n * (n - 1) / 2))
+        ideal = lds_ideal_ms(lengths, X) * (int(plan.pairs_scored) / (n * (n - 1) / 2))
         out.append({"config": name, "kernel_ms": med, "pairs": int(plan.pairs_scored), "pairs_per_s": int(plan.pairs_scored) / (med * 1e-3),
-                    "edges": int(d_counts.sum().item()), "row_packed_classes": int(plan.classes_rows),
+                    "edges": int(d_counts.sum().item()), "overflowed": bool(int(d_counts.max().item()) > cap // S),
+                    "row_packed_classes": int(plan.classes_rows),
                     "classes": int(plan.classes_u8 + plan.classes_u16 + plan.classes_direct),
                     "roofline": {"bound": "lds", "ideal_ms": ideal, "frac": ideal / med,
                                  "definition": "one LDS byte per cell the reference adds (ShiftedScorer.java:67-77) at 256 B/clk/CU x 256 CU "
                                                "x 2.4 GHz, over the measured kernel time"}})
         ctx.close()
+        del d_edges
 
-    shifted("2: 1e4 x 12, BLOSUM62, X 3, p 0, thr 20", 10000, 12, 12, 3, 0, 20, 0, 1, 10, 5)
-    shifted("4a: 1e5 x 7..20, ShiftedScorer X 3, p -1, thr 23", 100000, 7, 20, 3, -1, 23, 0, 1, 8, 6)
-    shifted("5, one of 8 shards: 1e6 x 12, BLOSUM62, X 3, p 0, thr 20", 1000000, 12, 12, 3, 0, 20, 0, 8, 3, 2)
-    # 4b: LocalAlignmentScorer, all ordered pairs of the 4a set.  The packed tagged-max kernel's VALU instruction count per DP
-    # cell comes from the PMC pass of this build (profiles/round3_neighbors_local_pmc.json: SQ_INSTS_VALU per 64 cells =
-    # lane-instructions per cell; a lane carries two column sequences), and a wave64 integer VALU instruction holds its SIMD for
-    # 4 cycles: peak = 256 CU x 4 SIMD x 2.4 GHz / 4 x 64 lanes.
+    def synth(name, n, lo, hi, X, p, thr, part, n_parts, reps, warm):
+        res, off = synth_peptides(1, n, lo, hi)
+        shifted(name, res, off, None, X, p, thr, part, n_parts, reps, warm)
+
+    synth("2: 1e4 x 12, BLOSUM62, X 3, p 0, thr 20", 10000, 12, 12, 3, 0, 20, 0, 1, 10, 5)
+    synth("4a: 1e5 x 7..20, ShiftedScorer X 3, p -1, thr 23", 100000, 7, 20, 3, -1, 23, 0, 1, 8, 6)
+    synth("5, one of 8 shards: 1e6 x 12, BLOSUM62, X 3, p 0, thr 20", 1000000, 12, 12, 3, 0, 20, 0, 8, 3, 2)
+    synth("1e5 x 7 (a Ph.D.-7 sized library), BLOSUM62, X 2, p 0, thr 12: the reference's defaults for 7-mers", 100000, 7, 7, 2, 0, 12, 0, 1, 8, 6)
+    fa = os.path.join(ROOT, "tests", "golden", "antibodies.fa.gz")
+    if os.path.exists(fa):
+        seqs, sizes = load_fasta_unique(fa)
+        L = np.array([len(q) for q in seqs])
+        jr = lambda v: int(np.floor(v + 0.5))   # Math.round
+        thr, X = jr(L.mean() * 1.7), min(jr(L.mean() / 4), int(L.min()) - 1)   # Hammock.java:1409-1434
+        shifted(f"antibodies.fa (the reference's example: {len(seqs)} unique sequences, lengths {L.min()}..{L.max()}), BLOSUM62, "
+                f"X {X}, p 0, thr {thr}: the reference's defaults", None, None, sizes, X, 0, thr, 0, 1, 8, 6, seqs=seqs)
+    # 4b: LocalAlignmentScorer, all ordered pairs of the 4a set: VALU-issue roofline from the ALGORITHM's operation count.
+    # One cell of LocalAlignmentScorer.java:43-81 is LOCAL_OPS_PER_CELL = 12 integer operations (counted above the function);
+    # the packed tagged-max kernel (k_local.hip) carries TWO column sequences in the 16-bit halves of a 32-bit lane, so one
+    # lane-operation does two cells' worth: peak = 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz lane-operations/s x 2 cells each.
+    # What the kernel really issues (SQ_INSTS_VALU of the PMC pass) is reported beside it: issued / algorithmic = its overhead.
     res, off = synth_peptides(1, 100000, 7, 20)
     ctx = hammock_amd.Context(M, device=dev.index)
     ctx.set_sequences(residues=res, offsets=off)
@@ -189,23 +258,28 @@ def other_configs(M, dev, stream):
         ms.append(float(st.kernel_ms))
     lens = np.diff(off.astype(np.int64)).astype(np.float64)
     cells = float(lens.sum()) ** 2 - float((lens * lens).sum())      # sum over ordered pairs i != j of len_i * len_j
-    valu_per_cell = 8.66             # measured (see above); the file's value if it is there
-    try:
-        with open(os.path.join(ROOT, "profiles", "round3_neighbors_local_pmc.json")) as fh:
-            valu_per_cell = float(json.load(fh)["valu_wave_instructions_per_64_cells"])
-    except (OSError, KeyError, ValueError):
-        pass
-    peak_lane_ops = 256 * 4 * 2.4e9 / 4 * 64
+    issued_per_cell = None
+    for name in ("round4_neighbors_local_pmc.json", "round3_neighbors_local_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as fh:
+                issued_per_cell = float(json.load(fh)["valu_wave_instructions_per_64_cells"])
+            break
+        except (OSError, KeyError, ValueError):
+            pass
+    peak_lane_ops = 256 * 4 * 16 * 2.4e9
     med = float(np.median(ms[1:]))
+    alg_lane_ops_per_cell = LOCAL_OPS_PER_CELL / 2.0
     out.append({"config": "4b: 1e5 x 7..20, LocalAlignmentScorer open -5, extend -1, all ordered pairs, thr 28", "kernel_ms": med,
                 "pairs": int(st.pairs_scored), "pairs_per_s": int(st.pairs_scored) / (med * 1e-3), "edges": int(len(edges)),
                 "dp_cells_per_s": cells / (med * 1e-3),
-                "roofline": {"bound": "valu-issue", "frac": cells * valu_per_cell / (med * 1e-3) / peak_lane_ops,
-                             "valu_lane_instructions_per_cell": valu_per_cell,
-                             "definition": "DP cells x VALU lane-instructions per cell (SQ_INSTS_VALU per 64 cells of the PMC pass in "
-                                           "profiles/round3_neighbors_local_pmc.json) over the kernel time, against 256 CU x 4 SIMD x 16 lanes/clk "
-                                           "x 2.4 GHz of integer VALU issue; ~1.0 = the kernel sits on the VALU-issue roofline (its measured VALU busy "
-                                           "fraction is 1.04 of the nominal 2.4 GHz cycles)"}})
+                "roofline": {"bound": "valu-issue", "frac": cells * alg_lane_ops_per_cell / (med * 1e-3) / peak_lane_ops,
+                             "algorithmic_ops_per_cell": LOCAL_OPS_PER_CELL, "cells_per_lane_operation": 2,
+                             "issued_valu_lane_instructions_per_cell": issued_per_cell,
+                             "definition": "DP cells x 12 integer operations per cell (LocalAlignmentScorer.java:43-81: 2 selects, 3 adds, 2 max, "
+                                           "1 clamp, 3 direction tests, 1 running max) / 2 cells per lane-operation (two column sequences in the "
+                                           "16-bit halves of a lane) over the kernel time, against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz of "
+                                           "integer VALU issue; issued_valu_lane_instructions_per_cell (rocprofv3 SQ_INSTS_VALU) / 6 = what the "
+                                           "kernel spends beyond the algorithm's count"}})
     ctx.close()
     return out
 
@@ -298,6 +372,28 @@ def main():
     # An idle MI355X needs about 25 ms of load to reach its clocks (tools/probes/warmup.sh: 20 timed steps after 3 / 5 / 10 / 20
     # untimed ones take 2.60 / 2.58 / 2.53 / 2.53 ms each): SETTLE_STEPS untimed passes first, then the W warm-up steps the
     # contract asks for, then exactly K timed steps.  Reported in the line as "settle_steps".
+    # First the contract's sequence taken literally -- W warm-up steps from an idle GPU, then K timed steps -- reported beside
+    # the settled figure as "ms_per_step_no_settle" (it measures the clock ramp as much as the kernel).
+    for _ in range(args.warmup):
+        step()
+    if px is not None:
+        px.finish()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step()
+    if px is not None:
+        px.finish()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    no_settle = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(no_settle, op=dist.ReduceOp.MAX)
+    ms_per_step_no_settle = float(no_settle.item()) / args.steps * 1e3
     for _ in range(SETTLE_STEPS):   # (this rank's scoring pass alone: the clocks are what settles, the exchange of N > 1 has no part in it)
         score_pass()
     torch.cuda.synchronize(dev)
@@ -348,8 +444,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs_total / (elapsed / args.steps)
-        # dominant kernel: k_neighbors_swar<2,6,2,12,true>.  Algorithmic HBM bytes per launch
-        # (DESIGN.md "Roofline"): 8 B per emitted edge + 16 B per peptide read once.
+        # dominant kernel: k_neighbors_rows<3, 0, 12, true, 1, 0> (the shift-packed k_neighbors_swar with HMK_NO_ROWS_KERNEL=1).
+        # Algorithmic HBM bytes per launch (DESIGN.md "Roofline"): 8 B per emitted edge + 16 B per peptide read once.
         pairs_rank = int(plan.pairs_scored)
         alg_bytes = 8 * n_edges_rank + 16 * n
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -359,7 +455,9 @@ def main():
         line = {
             "metric": "pairwise BLOSUM62 ShiftedScorer scores/sec (all-vs-all, thresholded neighbour list)",
             "value": value, "unit": "pair scores/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "settle_steps": SETTLE_STEPS, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "settle_steps": SETTLE_STEPS, "ms_per_step_no_settle": ms_per_step_no_settle,
+            "passes_before_the_timed_region": args.warmup + args.steps + SETTLE_STEPS + args.warmup,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u8 (8-bit SWAR lanes, host-proven ranges with 16-bit / literal fallbacks; scores are int32-exact)",
             "data": "synthetic",
             "config": {"workload": f"{n} synthetic length-{SEQ_LEN} peptides (SplitMix64 seed 1), BLOSUM62, max_shift "
@@ -375,13 +473,14 @@ def main():
                                     "rows per tile, plain edge list)" if rows_kernel else
                                     "k_neighbors_swar<2, 6, 2, 12, true, 0> (NW=2 dwords/entry, 6 rows/tile, 2 columns/lane, length 12 exact)"),
                          "lds_bytes_per_pair": lds_per_pair,
+                         "frac_at_round2_definition_96_bytes_per_pair": pairs_rank * 96 / (kern_ms * 1e-3) / 1e9 / LDS_PEAK_GBS,
                          "kernel_ms": kern_ms,
                          "definition": (f"{lds_per_pair} LDS bytes per pair (= the {CELLS_PER_PAIR} cells the reference adds per pair, one byte each: "
                                         f"{CELLS_PER_PAIR} ds_read_b64 per 8 pairs) " if rows_kernel else
                                         f"{lds_per_pair} LDS bytes per pair ({SEQ_LEN} ds_read_b64 table lookups) ") +
                                        "x pairs per launch / kernel time, against 256 B/clk/CU x 256 CU x 2.4 GHz "
                                        "(MI355X_MICROARCH.md, LDS table)",
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/round3_pmc_summary.json); "
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/round4_pmc_summary.json); "
                                          "null when the workload differs from the one the counters were collected on",
                          "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
@@ -427,6 +526,8 @@ def main():
                 cores = min(cores, int(os.environ.get("HMK_BENCH_CPU_THREADS", "64")))   # the oracle's teams stop scaling well before that
                 line["cpu_baseline"] = cpu_baseline(M, res, off, min(args.cpu_sample, n), cores)
                 line["cpu_baseline"]["cores_chosen_by"] = why
+                # BASELINE.md 3, "C-restate-1": the same restatement on ONE thread, on a sample it finishes in a few seconds
+                line["cpu_baseline_1_thread"] = cpu_baseline(M, res, off, min(20000, n), 1)
     else:
         line = None
     if world > 1 and not args.no_greedy:

@@ -145,6 +145,7 @@ struct hmk_ctx {
     // before it writes to them.  Whoever touches SB_ADJ / SB_PART joins this first (ensure_buf does).
     std::future<hipError_t> late_buffers;
 
+    bool wedged = false;   // a clustering call gave a stalled device up: nothing waits for it any more (calls fail with HMK_ERR_DEVICE)
     std::string err;
     mutable std::mutex mu;
 };
@@ -172,6 +173,7 @@ int need_device(hmk_ctx *ctx) {
     if (!ctx->has_device)
         return fail(ctx, HMK_ERR_DEVICE,
                     "this context has no GPU (created with device = -1); scoring has no CPU fallback");
+    if (ctx->wedged) return fail(ctx, HMK_ERR_DEVICE, "an earlier call on this context gave up on a device that had stopped making progress");
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, HMK_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
     return HMK_OK;
@@ -197,7 +199,7 @@ int ensure_res32(hmk_ctx *ctx) {
 template <class T, class Cmp>
 void parallel_stable_sort(std::vector<T> &v, Cmp before) {
     const size_t n = v.size();
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = usable_cpus();
     size_t runs = 1;
     while (runs < 8 && runs < (hw ? hw : 1u) && n / (2 * runs) >= 32768) runs *= 2;
     if (runs == 1) { std::stable_sort(v.begin(), v.end(), before); return; }
@@ -577,7 +579,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     // ---- device copies ------------------------------------------------------------
     std::vector<uint8_t> res_sorted((size_t)n * pl.lpad + 16, 0);   // + 16: the row-packed kernel's unaligned tail loads may touch the bytes after the last row
     {   // (rows are independent: several threads for large sets -- 10 ms on one at 10^6)
-        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned hw = usable_cpus();
         const unsigned T = n >= (1u << 18) ? std::max(1u, std::min(8u, hw ? hw : 1u)) : 1u;
         auto fill = [&](uint32_t lo, uint32_t hi) {
             for (uint32_t s = lo; s < hi; s++) {
@@ -1137,7 +1139,7 @@ int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *off
     }
     const uint32_t total = n ? offsets[n] : 0;
     {   // (12 MB at 10^6 sequences: several threads)
-        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned hw = usable_cpus();
         const unsigned T = total >= (1u << 22) ? std::max(1u, std::min(8u, hw ? hw : 1u)) : 1u;
         std::atomic<bool> bad{false};
         auto check = [&](uint32_t lo, uint32_t hi) {
@@ -1652,6 +1654,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     GreedyHooks hooks;
     double t_rows = 0;   // host time spent waiting for rows
     hooks.need_rows = [&](uint32_t k) -> uint32_t {
+        if (ctx->wedged) return 0;   // (the second loop gave the device up: the merge stops here instead of waiting for it again)
         if (k < rows_here) return rows_here;
         const auto tw = std::chrono::steady_clock::now();
         hipError_t e = hipSuccess;
@@ -1934,8 +1937,21 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 }
                 if (stalled) break;
             }
-            if (stalled) {   // no k_loop_* kernel may still be writing cand[] or the progress word when the host path takes over
-                (void)hipStreamSynchronize(S);
+            if (stalled) {
+                // No k_loop_* kernel may still be writing cand[] or the progress word when the host path takes over -- but a
+                // device that made no progress for a minute may never drain, and a blocking synchronise would spin forever
+                // after all: poll for ten more seconds, then give the call up (HMK_ERR_DEVICE) instead of falling back.
+                const auto t_drain = std::chrono::steady_clock::now();
+                hipError_t q = hipStreamQuery(S);
+                while (q == hipErrorNotReady && ms_since(t_drain) < 10e3) {
+                    std::this_thread::sleep_for(std::chrono::milliseconds(5));
+                    q = hipStreamQuery(S);
+                }
+                if (q == hipErrorNotReady) {
+                    ctx->wedged = true;
+                    status_inside = HMK_ERR_DEVICE;
+                    hook_err = "the device made no progress for 70 s inside the second loop: call given up (the context is unusable)";
+                }
                 r = hipErrorNotReady;
             }
             if (r == hipSuccess && !done) {                         // (only when nl + 8 rounds were not enough: impossible)
@@ -2068,8 +2084,10 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 : greedy_from_csr(n, szs, h_start, (const Nbr *)ctx->h_adj, symmetric ? h_up : nullptr, &hooks, symmetric, max_clusters,
                                   cluster_id, result_order, member_rank, stats, &err);
     // nothing of this call may still be running when the buffers are reused (a crash-parity exit leaves the pass in flight)
-    (void)hipStreamSynchronize(S);
-    (void)hipStreamSynchronize(C);
+    if (!ctx->wedged) {
+        (void)hipStreamSynchronize(S);
+        (void)hipStreamSynchronize(C);
+    }
     if (status_inside == ST_RETRY_OVERFLOW) return ST_RETRY_OVERFLOW;
     if (status_inside != HMK_OK) return fail(ctx, status_inside, hook_err);
     if (st == HMK_OK || st == HMK_ERR_REFERENCE_WOULD_CRASH) {
@@ -2154,8 +2172,8 @@ int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, boo
         HIPCHK(ctx, ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4));
         HIPCHK(ctx, ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + (size_t)n * 12 + ncl * 4 + 64, 0));
     }
+    if (late_on_a_thread) (void)join_late_buffers(ctx);   // (an earlier hmk_reserve's thread may still be writing the two sizes read next)
     if (late_on_a_thread && (ctx->sb[SB_ADJ].cap < adj_bytes || ctx->sb[SB_PART].cap < part_bytes)) {
-        (void)join_late_buffers(ctx);
         const int device = ctx->device;
         ctx->late_buffers = std::async(std::launch::async, [ctx, device, adj_bytes, part_bytes]() -> hipError_t {
             if (const char *v = getenv("HMK_LATE_BUFFERS_DELAY_MS"))   // tests: a host on which device memory is slow to get
@@ -2662,7 +2680,15 @@ int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences) {
     const auto t_streams = std::chrono::steady_clock::now();
     if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
     HIPCHK(ctx, ensure_buf(ctx, SB_BCOUNTS, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
-    st = grow_edge_buffer(ctx, first_edge_capacity(ctx, n_sequences));
+    {
+        // (a multi-device root scores 1 / devices of the pair space: greedy_cluster_multi takes the larger of its own guess and
+        // what is there, and sizes the root's adjacency from it -- the single-device guess made those twice as large as needed)
+        const uint64_t G = 1 + ctx->peers.size();
+        uint64_t cap = first_edge_capacity(ctx, n_sequences);
+        if (G > 1 && getenv("HMK_EDGE_GUESS") == nullptr)
+            cap = std::max<uint64_t>({(uint64_t)((double)cap / G * 1.25), (uint64_t)1 << 20, ctx->d_edges_cap});
+        st = grow_edge_buffer(ctx, (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS);
+    }
     if (st) return st;
     const int64_t maxc = (int64_t)(n_sequences * 0.025 + 0.5);      // Hammock.java:398-401, the default cluster limit
     int64_t band = n_sequences >= 16384 ? std::min<int64_t>(n_sequences, 2 * maxc + 1024) : 0;

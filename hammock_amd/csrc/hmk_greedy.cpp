@@ -30,10 +30,29 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
 namespace hmk {
+
+unsigned usable_cpus() {
+    unsigned n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    if (n == 0) n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    std::ifstream f("/sys/fs/cgroup/cpu.max");   // cgroup v2: "<quota> <period>" or "max <period>"
+    std::string quota;
+    long long period = 0;
+    if (f && (f >> quota >> period) && quota != "max" && period > 0) {
+        const long long q = std::atoll(quota.c_str()) / period;
+        if (q >= 1 && (unsigned)q < n) n = (unsigned)q;
+    }
+    return n;
+}
 
 namespace {
 
@@ -218,14 +237,15 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
 
     unsigned T = 1;
     if (symmetric_scores && n >= 65536 && max_clusters >= 256) {
-        const unsigned hw = std::thread::hardware_concurrency();
-        T = std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
+        const unsigned hw = usable_cpus();   // (the affinity mask cut by the cgroup quota: a container's share, not the host's 256)
+        T = std::max(1u, std::min(8u, hw / 2));
     }
     bool pool_decided = false;                        // the threads start with the first window, if the rows are long enough (below)
     if (const char *v = getenv("HMK_PHASE1_THREADS"))   // tests: any input, any thread count
         if (symmetric_scores) { T = (unsigned)std::max(1, std::min(32, atoi(v))); pool_decided = true; }
     uint32_t W = T > 1 ? 4 * T : 1;                   // positions per window (more positions: more scans a commit invalidates)
     if (const char *v = getenv("HMK_PHASE1_WINDOW")) W = (uint32_t)std::max(1, std::min(4096, atoi(v)));
+    if (!symmetric_scores) W = 1;   // (a commit patches the later rows' scans with its OWN row's scores: exact for symmetric scores only)
     std::vector<RowScan> res(W);
     std::vector<int32_t> ahead_score(W, INT_MIN);     // commit of k: score(k, x) for the window's later rows x that have k as a neighbour
     std::vector<ScanScratch> scratch(T);
@@ -270,11 +290,11 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             }
         });
     };
-    if (pool_decided) spawn_pool();
-    struct PoolGuard {   // joins on every way out of the function (crash parity returns early)
+    struct PoolGuard {   // joins on every way out of the function (crash parity returns early; a thread that could not be started throws)
         std::vector<std::thread> &pool; std::atomic<bool> &quit;
         ~PoolGuard() { quit.store(true, std::memory_order_release); for (std::thread &th : pool) th.join(); }
     } pool_guard{pool, quit};
+    if (pool_decided) spawn_pool();
 
     int64_t remaining = n;  // elements of initialList at positions >= index
     int64_t index = 0;
@@ -321,10 +341,14 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             gen.store(g, std::memory_order_release);
         }
         run_window(0);
-        while (finished.load(std::memory_order_acquire) < win_rows.size()) { }
+        // (a window is tens of microseconds, so the waits spin -- but not without end: on a host with fewer free cores than
+        // threads a worker may have been descheduled, and a spinning main thread only keeps it off the core longer)
+        for (unsigned spins = 0; finished.load(std::memory_order_acquire) < win_rows.size();)
+            if (++spins > 4000) { std::this_thread::yield(); spins = 0; }
         if (shared) {   // close the generation and let the workers that are inside leave (their cursor is exhausted)
             open_gen.store(0, std::memory_order_seq_cst);
-            while (left.load(std::memory_order_seq_cst) != entered.load(std::memory_order_seq_cst)) { }
+            for (unsigned spins = 0; left.load(std::memory_order_seq_cst) != entered.load(std::memory_order_seq_cst);)
+                if (++spins > 4000) { std::this_thread::yield(); spins = 0; }
         }
         const auto tc = p1_now();
         p1_scan += std::chrono::duration<double, std::milli>(tc - ts).count();
@@ -475,8 +499,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         }
         if (!device_done && !(have_cand && have_prop) && !need_all_rows()) return HMK_INTERNAL_ROWS_FAILED;   // every other path below reads rows
         if (fast && !have_cand && !device_done) {
-            const unsigned hw = std::thread::hardware_concurrency();
-            const unsigned T = std::max(1u, std::min(16u, hw ? hw : 1u));
+            const unsigned T = std::max(1u, std::min(16u, usable_cpus()));
             const size_t nc = clusters.size();
             std::vector<std::vector<Cand>> found(T);     // thread t covers a contiguous run of leftovers
             // most neighbours are in no cluster at all: a bitmap over the sequences (n / 8 bytes, cache resident)

@@ -134,6 +134,10 @@ struct GreedyHooks {
 };
 constexpr int HMK_INTERNAL_ROWS_FAILED = -1;   // greedy_from_csr*: need_rows failed (the caller knows why)
 
+// CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota where there is one (a container on a
+// 256-thread host may own 8 of them: std::thread::hardware_concurrency() reports the host's).  At least 1.  (hmk_greedy.cpp)
+unsigned usable_cpus();
+
 // host greedy merge (hmk_greedy.cpp)
 // symmetric_scores: adj holds every edge under both ends with the same score (symmetric matrix)
 // upper: NULL, or per row the number of leading entries whose id is above the row's own (the row is laid out

@@ -261,6 +261,9 @@ typedef struct {
  * and id order, :96-113 pushes it again): the reference then works with a stale Cluster object and throws
  * NoSuchElementException or returns a list in which a sequence belongs to two clusters -- there is no cluster_id[] for
  * that (hmk_last_error names the cluster; four 6-mers suffice, tests/test_oracle.py). */
+int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int32_t *cluster_id,
+                         int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats);
+
 /* Optional.  Sizes the context's grow-only device and pinned buffers for a first hmk_greedy_cluster / hmk_clinkage_cluster
  * call on n_sequences sequences (edge buffer at the first guess of 0.3 % of the pair space, adjacency, CSR and second-loop
  * scratch: 36 GB at 10^6), so that a host which knows the sequence count early -- hammock-hip after it has read its input --
@@ -279,8 +282,7 @@ int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences);
  * where a new entry joins its bucket's chain and in what a resize does to a chain; cluster MEMBERSHIP differs only where a
  * tie of score, size and id order lets the chain start decide.  HMK_ERR_BAD_ARG for any other version. */
 int hmk_set_java_hashset(hmk_ctx *ctx, int version);
-int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int32_t *cluster_id,
-                         int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats);
+
 
 /* The host-side nearest-neighbour chain alone, on the edge list of a symmetric matrix as hmk_neighbors_shifted produces it
  * (each unordered pair once, any order; all shards concatenated).  Works on a host-only context (device = -1). */
