@@ -67,6 +67,7 @@ struct Plan {
     Tile *d_tiles = nullptr;
     std::vector<Group> groups;
     hmk_neighbor_stats stats{};
+    uint64_t band_pairs = 0;   // pairs inside the band tiles (of stats.pairs_scored)
 };
 
 struct PlanLocal {
@@ -120,6 +121,8 @@ struct hmk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // greedy tail: own stream + events, grow-only device scratch, pinned host staging (all made once per context)
     hipStream_t gstream = nullptr;
+    hipStream_t rest_stream = nullptr;   // lowest priority: the tiles outside the band, scored beside the band tiles (hmk_greedy_cluster)
+    hipEvent_t ev_rest = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_band = nullptr, ev_edges = nullptr, ev_csr = nullptr, ev_bandcsr = nullptr;
     DevBuf sb[SB_N];
     void *h_start = nullptr;  // pinned: uint64 start[n + 1], then uint32 up[n]
@@ -547,6 +550,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                         if (pairs == 0) continue;
                         S.pairs_scored += pairs;
                         t.pad0 = (r0 < band_end[la] || c0 < band_end[lb]) ? 1u : 0u;   // band tile (host-side flag)
+                        if (t.pad0) pl.band_pairs += pairs;
                         dst.push_back(t);
                     }
                 }
@@ -621,10 +625,11 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
 
 // which: LAUNCH_ALL, or only the band tiles of the plan (LAUNCH_BAND: also zeroes the counts) / only the others
 // (LAUNCH_REST: appends to the counts of the band launch)
-enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2 };
+enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2, LAUNCH_BAND_NOZERO = 3 };   // (NOZERO: the caller has zeroed the counts)
 int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
                          uint64_t capacity, void *d_counts, hipStream_t stream, int which = LAUNCH_ALL,
-                         int64_t band_rows = -1, uint32_t *d_deg = nullptr, uint32_t *d_deg_lo = nullptr, uint32_t *d_rank = nullptr) {
+                         int64_t band_rows = -1, uint32_t *d_deg = nullptr, uint32_t *d_deg_lo = nullptr, uint32_t *d_rank = nullptr,
+                         uint32_t shard_base = 0, uint32_t shard_mod = HMK_EDGE_SHARDS) {
     int st = need_device(ctx);
     if (st) return st;
     if (!d_edges || !d_counts || capacity < HMK_EDGE_SHARDS)
@@ -632,8 +637,9 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     st = build_plan(ctx, X, p, thr, part, n_parts, band_rows);
     if (st) return st;
     Plan &pl = ctx->plan;
-    if (which != LAUNCH_REST)
+    if (which != LAUNCH_REST && which != LAUNCH_BAND_NOZERO)
         HIPCHK(ctx, hipMemsetAsync(d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), stream));
+    if (which == LAUNCH_BAND_NOZERO) which = LAUNCH_BAND;
     NeighborParams P{};
     P.res_sorted = pl.d_res_sorted;
     P.perm = pl.d_perm;
@@ -651,7 +657,9 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     P.deg_up = d_rank ? d_deg : nullptr;
     P.deg_lo = d_rank ? d_deg_lo : nullptr;
     P.deg_m_offset = (!d_rank && d_deg && d_deg_lo) ? (uint32_t)(d_deg_lo - d_deg) : 0u;   // counting mode with split counters
-    P.pad_deg = 0;
+    P.shard_base = shard_base;
+    P.shard_mod = shard_mod;
+    P.pad_shard = 0;
     P.rank = d_rank;
     // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has a dozen of
     // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
@@ -670,7 +678,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
         if (!ctx->ev_fork) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         std::vector<hipStream_t> lend;
         if (getenv("HMK_OWN_SIDE_STREAMS") == nullptr && ctx->gstream && ctx->copy_stream) {
-            if (stream != ctx->gstream && stream != ctx->copy_stream) lend = {ctx->gstream, ctx->copy_stream};
+            if (stream != ctx->gstream && stream != ctx->copy_stream && stream != ctx->rest_stream) lend = {ctx->gstream, ctx->copy_stream};   // (rest_stream: a clustering call's second launch -- both are busy)
             else if (stream == ctx->gstream && which == LAUNCH_ALL) lend = {ctx->copy_stream};
         }
         int own = 0;
@@ -875,6 +883,8 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
     P.edges = d_edges;
     P.counts = d_counts;
     P.cap_per_shard = capacity / HMK_EDGE_SHARDS;
+    P.shard_base = 0;
+    P.shard_mod = HMK_EDGE_SHARDS;
     P.n_tiles = pl.n_tiles;
     P.lpad = 32;
     P.symmetric = 0;
@@ -1096,6 +1106,8 @@ void hmk_destroy(hmk_ctx *ctx) {
         if (ctx->d_counts) (void)hipFree(ctx->d_counts);
         if (ctx->d_rows_scratch) (void)hipFree(ctx->d_rows_scratch);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->rest_stream) (void)hipStreamDestroy(ctx->rest_stream);
+        if (ctx->ev_rest) (void)hipEventDestroy(ctx->ev_rest);
         for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
             if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
             if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
@@ -1438,6 +1450,8 @@ int greedy_streams(hmk_ctx *ctx) {
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_hi));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->rest_stream, hipStreamNonBlocking, prio_lo));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rest, hipEventDisableTiming));
     for (hipEvent_t *ev : {&ctx->ev_t0, &ctx->ev_band, &ctx->ev_edges, &ctx->ev_csr, &ctx->ev_bandcsr}) HIPCHK(ctx, hipEventCreate(ev));
     HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, HC_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     // fine-grained, so that a system-scope store of a running kernel is seen by the polling host (no such block: batches + syncs)
@@ -1600,8 +1614,9 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                            buf<uint64_t>(ctx, SB_BSCAN), buf<int>(ctx, SB_BRANGE), C));
         HIPCHK(ctx, hipMemcpyAsync(h_start, buf<uint64_t>(ctx, SB_BSTART), ((size_t)R1 + 1) * 8, hipMemcpyDeviceToHost, C));
 
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count, HMK_EDGE_SHARDS * sizeof(unsigned long long),
-                                   hipMemcpyDeviceToHost, C));
+        // (the band's own segments only: beside a pass that runs at the same time the other cursors are in motion)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count,
+                                   std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) * sizeof(unsigned long long), hipMemcpyDeviceToHost, C));
         HIPCHK(ctx, hipEventRecord(ctx->ev_bandcsr, C));
         band_pending = true;
     }
@@ -1662,7 +1677,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             band_pending = false;
             e = hipEventSynchronize(ctx->ev_bandcsr);
             bool ok = e == hipSuccess;
-            for (int q = 0; q < HMK_EDGE_SHARDS && ok; q++) ok = ctx->h_counts[HC_BAND + q] <= src.seg_cap;
+            for (uint32_t q = 0; q < std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) && ok; q++) ok = ctx->h_counts[HC_BAND + q] <= src.seg_cap;
             if (ok) {
                 const uint64_t entries = h_start[R1];
                 e = ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz);
@@ -2277,7 +2292,21 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         src.segs = shard_segments(ctx->d_edges, seg, ctx->d_counts);
         src.adj_bound = (ctx->symmetric ? 2 : 1) * ctx->d_edges_cap;
         src.band_rows = (uint32_t)band_rows;
-        src.band_segs = shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS));
+        // HMK_BAND_CONCURRENT=1 (measured, rejected, kept as a switch): the band tiles and the others scored AT THE SAME TIME, two
+        // streams, the others' at the lowest priority, each launch into output segments of its own (the band's share of the
+        // HMK_EDGE_SHARDS segments = its share of the pairs; the snapshot of the band's cursors then names complete segments only
+        // -- in shared segments the other launch's waves would have reserved places they have not written yet).  The idea: one
+        // launch after the other leaves the GPU half empty twice, at the band's tail and at the rest's start (10^5: 3.4 ms of
+        // scoring against 3.0 ms in one launch).  What happened: the scoring took 3.33 ms, and the band's launch, sharing every
+        // CU with the other one whatever the priorities say, finished with it -- band rows on the host at 3.4 instead of 1.7 ms,
+        // the call 6.3 instead of 5.0 ms.  Results identical (the GPU test suite passes either way).
+        uint32_t band_shards = 0;
+        if (band_rows > 0 && getenv("HMK_BAND_CONCURRENT") != nullptr && ctx->plan.stats.pairs_scored > 0) {
+            const double share = (double)ctx->plan.band_pairs / (double)ctx->plan.stats.pairs_scored;
+            band_shards = (uint32_t)std::min<double>(HMK_EDGE_SHARDS / 2, std::max<double>(2.0, std::ceil(share * HMK_EDGE_SHARDS)));
+        }
+        src.band_segs = band_shards ? shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS), 0, band_shards)
+                                    : shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS));
         // the neighbour kernel places every edge in the CSR as it writes it: per row an upper and a lower counter (they end
         // up as the sizes of the row's two sections; the upper ones ARE up[]) and, beside the edge, its two ranks
         const bool fuse = getenv("HMK_NO_FUSED_DEGREE") == nullptr;
@@ -2310,18 +2339,33 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         src.edges0 = ctx->d_edges;
         HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
         if (band_rows > 0) {
+            if (band_shards) {   // the cursors are zeroed HERE, ahead of the event the other launch's stream waits for
+                HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), S));
+                HIPCHK(ctx, hipEventRecord(ctx->ev_rest, S));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->rest_stream, ctx->ev_rest, 0));
+            }
             st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                      LAUNCH_BAND, band_req, d_deg, d_deg_lo, d_rank);
+                                      band_shards ? LAUNCH_BAND_NOZERO : LAUNCH_BAND, band_req, d_deg, d_deg_lo, d_rank, 0,
+                                      band_shards ? band_shards : HMK_EDGE_SHARDS);
             if (st) return st;
             HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long),
                                        hipMemcpyDeviceToDevice, S));
             HIPCHK(ctx, hipEventRecord(ctx->ev_band, S));
             call_lap("band tiles enqueued");
         }
-        st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, d_deg, d_deg_lo, d_rank);
+        if (band_rows > 0 && band_shards) {
+            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, ctx->rest_stream,
+                                      LAUNCH_REST, band_req, d_deg, d_deg_lo, d_rank, band_shards, HMK_EDGE_SHARDS - band_shards);
+            if (st == HMK_OK) {
+                HIPCHK(ctx, hipEventRecord(ctx->ev_rest, ctx->rest_stream));
+                HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_rest, 0));
+            }
+        } else {
+            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
+                                      band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, d_deg, d_deg_lo, d_rank);
+        }
         call_lap("all tiles enqueued");
-        if (st) { (void)hipStreamSynchronize(S); return st; }
+        if (st) { (void)hipStreamSynchronize(ctx->rest_stream); (void)hipStreamSynchronize(S); return st; }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S));
         HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
         st = cluster_on_device(ctx, src, max_clusters, cluster_id, result_order, member_rank, stats, t0);

@@ -64,7 +64,9 @@ struct NeighborParams {
     // atomics cost the pass 10 % and the scatter there is bound by its random writes, not by its atomics.
     uint32_t *deg;       // counting mode: total degrees -- or, with deg_m_offset = n, upper counts in deg[0, n) and lower counts in deg[n, 2n)
     uint32_t deg_m_offset;   // counting mode: the larger end m of an edge counts into deg[deg_m_offset + m] (0: one counter per row)
-    uint32_t pad_deg;
+    uint32_t shard_base;     // a tile writes into segment shard_base + tile % shard_mod (the whole pass: 0 and HMK_EDGE_SHARDS; a clustering
+    uint32_t shard_mod;      // call scores its band tiles and the others at the same time, each into segments of their own)
+    uint32_t pad_shard;
     uint32_t *deg_up;    // placing mode: the rows' upper counters ...
     uint32_t *deg_lo;    // ... and lower counters (symmetric only)
     uint32_t *rank;      // placing mode (else null)

@@ -45,7 +45,9 @@ hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile
 // (row_limit = n: the whole graph).  deg: zeroed uint32[row_limit]; cursor: zeroed uint32[2 row_limit], whose first half
 // holds the rows' upper-neighbour counts ("up[]") after the scatter; score_range: device int[3] = {min score, max
 // score, invalid edges}
-EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts);
+// (segments first .. first + count - 1 of a pass: all of them by default)
+EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t first = 0,
+                        uint32_t count = HMK_EDGE_SHARDS);
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
                                   uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s);
 hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uint64_t *start, uint32_t n, uint64_t *tile_scratch,

@@ -1322,10 +1322,10 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
 // -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------
-EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts) {
+EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t first, uint32_t count) {
     EdgeSegs sg{};
-    sg.n = HMK_EDGE_SHARDS;
-    for (uint32_t q = 0; q < HMK_EDGE_SHARDS; q++) sg.s[q] = EdgeSeg{edges + (uint64_t)q * cap_per_shard, counts + q, cap_per_shard};
+    sg.n = count;
+    for (uint32_t q = 0; q < count; q++) sg.s[q] = EdgeSeg{edges + (uint64_t)(first + q) * cap_per_shard, counts + first + q, cap_per_shard};
     return sg;
 }
 

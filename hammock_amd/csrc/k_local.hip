@@ -225,7 +225,7 @@ k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
     const int la = Cp->la, lb = Cp->lb;   // la: row (seq1) length, lb: column (seq2) length
-    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
@@ -383,7 +383,7 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
     const int la = Cp->la, lb = Cp->lb;
-    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
@@ -482,7 +482,7 @@ k_neighbors_local_literal(const NeighborParams P, const uint32_t tile_base, cons
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
     const int la = Cp->la, lb = Cp->lb;
-    const uint32_t shard = (tile_base + blockIdx.x) % HMK_EDGE_SHARDS;
+    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
     for (int e = tid; e < 576; e += 256) M[e] = Mg[e];

@@ -55,7 +55,7 @@ namespace hmk {
 #define HMK_ROWS_STAGE_EXACT 640
 #endif
 constexpr int rows_stage(bool exact) { return exact ? HMK_ROWS_STAGE_EXACT : HMK_ROWS_STAGE; }
-#ifndef HMK_ROWS_DBG   // measurement builds only (tools/ab_rows4.sh; wrong results): the flush 1 = does not rescore, 2 = drops its records, 3 = fetches one column for all lanes, 4 = stores nothing
+#ifndef HMK_ROWS_DBG   // measurement builds only (tools/ab_rows4.sh; wrong results): the flush 1 = does not rescore, 2 = drops its records, 3 = fetches one column for all lanes, 4 = stores nothing, 5 = no placing atomics, 6 = no rank store
 #define HMK_ROWS_DBG 0
 #endif
 #ifndef HMK_ROWS_FLUSH_UNROLLED   // 1: the flush of a one-length shape sums its planes from compile-time cell lists (0: the run-time loop of the capacity form)
@@ -345,7 +345,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         A.row0 = rows_const_load<uint32_t>(&Tp->row0);
         A.col0 = rows_const_load<uint32_t>(&Tp->col0);
         const TileClass *Cp = K->P.classes + rows_const_load<uint32_t>(&Tp->cls);
-        A.shard = tile % HMK_EDGE_SHARDS;
+        A.shard = K->P.shard_base + tile % K->P.shard_mod;
         A.threshold = 128 - rows_const_load<int32_t>(&Cp->g);
 #pragma unroll
         for (int q = 0; q < 8; q++) A.cinit[q] = (q * 4 < S::ND) ? rows_const_load<uint32_t>(&Cp->cinit[q]) : 0u;
@@ -408,7 +408,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
 #define HMK_FLUSH_ST_111(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0), [t1] "=&v"(t1), [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2), [tp] "v"(tp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
 #define HMK_FLUSH_ST(W_S, ...)                                                                          \
     do {                                                                                                  \
-        if (MODE == EDGES_PLACE && atomics) {                                                             \
+        if (MODE == EDGES_PLACE && atomics && HMK_ROWS_DBG != 5) {   /* (DBG 5: no placing atomics) */             \
             if constexpr (EXACT_LB || S::TW == 0) { if (A.perm_identity) HMK_FLUSH_ST_100(W_S, __VA_ARGS__); else HMK_FLUSH_ST_101(W_S, __VA_ARGS__); } \
             else { if (A.perm_identity) HMK_FLUSH_ST_110(W_S, __VA_ARGS__); else HMK_FLUSH_ST_111(W_S, __VA_ARGS__); } \
         } else {                                                                                          \
@@ -534,7 +534,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
             const unsigned long long e = ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
             const uint64_t *ep = A.edges + slot;
             asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(ep), "v"(e) : "memory");
-            if (MODE == EDGES_PLACE) {
+            if (MODE == EDGES_PLACE && HMK_ROWS_DBG != 6) {   // (DBG 6: no rank store)
                 const u32x2 rk = {rx, rm};
                 const uint32_t *rp = A.rank + 2 * slot;
                 asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(rp), "v"(rk) : "memory");
