@@ -44,6 +44,7 @@ enum {
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
     SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RANK, SB_RETRY, SB_PRECNT, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
+    SB_BANDCTR,   // [0] band tiles done (band_tile_done), [1] k_wait_counter gave up
     SB_PEER, SB_PEERCNT, SB_PEERBAND, SB_PEERDEG,                                                     // edge blocks gathered from other devices (root) / compacted for the root (peers)
     SB_N
 };
@@ -448,7 +449,11 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     pl.cols_per_tile = 65536;
     while (pl.cols_per_tile > 16384 && row_groups * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 8 * 1792)
         pl.cols_per_tile /= 2;
-    while (pl.cols_per_tile > 1024 && ((uint64_t)n / tile_rows + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
+    // (not below 4,096 columns: a tile's dead time -- its chain of dependent loads before the first table read, the flush after
+    // the last -- is about four 256-column batches long, and short tiles pay it several times over on every workgroup slot.
+    // 10^4 12-mers: 1,024 / 2,048 / 4,096 / 16,384 columns per tile 0.090 / 0.061 / 0.053 / 0.051 ms, although the last leaves
+    // a third of the slots empty; 3 x 10^4: 2,048 / 4,096 / 8,192 0.354 / 0.301 / 0.294 ms.)
+    while (pl.cols_per_tile > 4096 && ((uint64_t)n / tile_rows + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
         pl.cols_per_tile /= 2;
     if (const char *v = getenv("HMK_HOT_VARIANT")) pl.hot_variant = atoi(v);   // tuning knobs
     if (const char *v = getenv("HMK_COLS_PER_TILE")) pl.cols_per_tile = (uint32_t)std::min(65536, std::max(256, atoi(v)));   // hit records hold a 16-bit column offset
@@ -629,7 +634,7 @@ enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2, LAUNCH_BAND_NOZERO = 3 
 int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
                          uint64_t capacity, void *d_counts, hipStream_t stream, int which = LAUNCH_ALL,
                          int64_t band_rows = -1, uint32_t *d_deg = nullptr, uint32_t *d_deg_lo = nullptr, uint32_t *d_rank = nullptr,
-                         uint32_t shard_base = 0, uint32_t shard_mod = HMK_EDGE_SHARDS) {
+                         uint32_t shard_base = 0, uint32_t shard_mod = HMK_EDGE_SHARDS, uint32_t band_mod = 0, uint32_t *band_counter = nullptr) {
     int st = need_device(ctx);
     if (st) return st;
     if (!d_edges || !d_counts || capacity < HMK_EDGE_SHARDS)
@@ -659,7 +664,8 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     P.deg_m_offset = (!d_rank && d_deg && d_deg_lo) ? (uint32_t)(d_deg_lo - d_deg) : 0u;   // counting mode with split counters
     P.shard_base = shard_base;
     P.shard_mod = shard_mod;
-    P.pad_shard = 0;
+    P.band_mod = band_mod;
+    P.band_counter = band_counter;
     P.rank = d_rank;
     // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has a dozen of
     // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
@@ -885,6 +891,8 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
     P.cap_per_shard = capacity / HMK_EDGE_SHARDS;
     P.shard_base = 0;
     P.shard_mod = HMK_EDGE_SHARDS;
+    P.band_mod = 0;
+    P.band_counter = nullptr;
     P.n_tiles = pl.n_tiles;
     P.lpad = 32;
     P.symmetric = 0;
@@ -1444,6 +1452,19 @@ hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes, size_t keep) {
 
 int greedy_streams(hmk_ctx *ctx) {
     if (ctx->gstream) return HMK_OK;
+    // HMK_CU_RESERVE=k: the clustering stream may not use k of the device's CUs (a CU mask), so that the small kernels of the
+    // band hand-over, on their own stream, find a free CU at once instead of waiting for a workgroup of the scoring pass to end
+    int reserve = 0;
+    if (const char *v = getenv("HMK_CU_RESERVE")) reserve = std::max(0, std::min(64, atoi(v)));
+    if (reserve > 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        const int cus = prop.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0xFFFFFFFFu);
+        if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
+        for (int k = 0; k < reserve && k < cus; k++) mask[(size_t)k / 32] &= ~(1u << (k % 32));
+        HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ctx->gstream, (uint32_t)mask.size(), mask.data()));
+    } else
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking));
     // the band hand-over runs while the rest of the pair space is being scored: its small kernels must not queue behind
     // the thousands of workgroups of that launch, so its stream gets the highest priority
@@ -1484,6 +1505,7 @@ struct EdgeSource {
     uint64_t adj_bound = 0;            // upper bound of the adjacency entries (format_known only)
     uint64_t total_known = 0;          // exact number of edges, if known (else 0)
     uint32_t band_rows = 0;            // rows [0, band_rows) are complete in band_segs once ev_band has passed
+    const uint32_t *band_gave_up = nullptr;   // device word: 1 = the wait for the band tiles timed out (band_segs are NOT complete)
     EdgeSegs band_segs{};
     bool deg_fused = false;            // the neighbour kernel placed the edges itself: SB_CURSOR holds the rows' upper | lower counters
                                        // (zeroed before the pass), SB_RANK every edge's ranks (parallel to the buffer at edges0)
@@ -1617,6 +1639,9 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         // (the band's own segments only: beside a pass that runs at the same time the other cursors are in motion)
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count,
                                    std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) * sizeof(unsigned long long), hipMemcpyDeviceToHost, C));
+        ((uint32_t *)(ctx->h_counts + HC_MISC))[7] = 0;
+        if (src.band_gave_up)
+            HIPCHK(ctx, hipMemcpyAsync((uint32_t *)(ctx->h_counts + HC_MISC) + 7, src.band_gave_up, 4, hipMemcpyDeviceToHost, C));
         HIPCHK(ctx, hipEventRecord(ctx->ev_bandcsr, C));
         band_pending = true;
     }
@@ -1676,7 +1701,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (band_pending) {
             band_pending = false;
             e = hipEventSynchronize(ctx->ev_bandcsr);
-            bool ok = e == hipSuccess;
+            bool ok = e == hipSuccess && ((const uint32_t *)(ctx->h_counts + HC_MISC))[7] == 0;   // ([7]: the wait for the band tiles gave up)
             for (uint32_t q = 0; q < std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) && ok; q++) ok = ctx->h_counts[HC_BAND + q] <= src.seg_cap;
             if (ok) {
                 const uint64_t entries = h_start[R1];
@@ -2300,8 +2325,19 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         // scoring against 3.0 ms in one launch).  What happened: the scoring took 3.33 ms, and the band's launch, sharing every
         // CU with the other one whatever the priorities say, finished with it -- band rows on the host at 3.4 instead of 1.7 ms,
         // the call 6.3 instead of 5.0 ms.  Results identical (the GPU test suite passes either way).
+        // HMK_BAND_ONE_LAUNCH=1 (measured, rejected, kept as a switch): ONE launch, band tiles first in dispatch order, segments of
+        // their own for them (the same share rule), and a counter every band tile's workgroup bumps when its edges are out
+        // (band_tile_done): a one-wave kernel on the hand-over stream waits for the counter (launch_wait_counter), and what is
+        // enqueued behind it -- the snapshot of the band's cursors, the band CSR, the copies -- starts when the band is complete.
+        // What happened at 10^5: the waiting kernel (and everything behind it) got no workgroup slot before the pass was over --
+        // band rows on the host at 3.8 ms instead of 1.7, the call 6.4 instead of 4.9 ms; with CUs kept free for it
+        // (HMK_CU_RESERVE=8: the clustering stream under a CU mask) the rows came at 1.4 ms, but the masked pass took 3.55 ms and
+        // the call 5.0 ms.  A kernel of another stream does not get in while a launch has workgroups waiting; the band launch's
+        // END is what lets the hand-over in.  So: two launches, one after the other, as in rounds 2-3.
         uint32_t band_shards = 0;
-        if (band_rows > 0 && getenv("HMK_BAND_CONCURRENT") != nullptr && ctx->plan.stats.pairs_scored > 0) {
+        const bool band_one_launch = band_rows > 0 && getenv("HMK_BAND_ONE_LAUNCH") != nullptr && getenv("HMK_BAND_CONCURRENT") == nullptr &&
+                                     ctx->plan.stats.pairs_scored > 0;
+        if (band_rows > 0 && (band_one_launch || getenv("HMK_BAND_CONCURRENT") != nullptr) && ctx->plan.stats.pairs_scored > 0) {
             const double share = (double)ctx->plan.band_pairs / (double)ctx->plan.stats.pairs_scored;
             band_shards = (uint32_t)std::min<double>(HMK_EDGE_SHARDS / 2, std::max<double>(2.0, std::ceil(share * HMK_EDGE_SHARDS)));
         }
@@ -2337,6 +2373,26 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         src.deg_fused = fuse;
         src.placed = place;
         src.edges0 = ctx->d_edges;
+        if (band_one_launch) {
+            uint32_t n_band_tiles = 0;
+            for (const Group &g : ctx->plan.groups) n_band_tiles += g.band;
+            HIPCHK(ctx, ensure_buf(ctx, SB_BANDCTR, 64));
+            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BANDCTR), 0, 64, S));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
+            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
+                                      LAUNCH_ALL, band_req, d_deg, d_deg_lo, d_rank, band_shards, HMK_EDGE_SHARDS - band_shards, band_shards,
+                                      buf<uint32_t>(ctx, SB_BANDCTR));
+            call_lap("all tiles enqueued");
+            if (st) { (void)hipStreamSynchronize(S); return st; }
+            // the hand-over stream: behind the counter's memset, wait for the band tiles, then the snapshot of the band's cursors
+            hipStream_t C = ctx->copy_stream;
+            HIPCHK(ctx, hipStreamWaitEvent(C, ctx->ev_t0, 0));
+            HIPCHK(ctx, launch_wait_counter(buf<uint32_t>(ctx, SB_BANDCTR), n_band_tiles, buf<uint32_t>(ctx, SB_BANDCTR) + 1, C));
+            HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long),
+                                       hipMemcpyDeviceToDevice, C));
+            HIPCHK(ctx, hipEventRecord(ctx->ev_band, C));
+            src.band_gave_up = buf<uint32_t>(ctx, SB_BANDCTR) + 1;
+        } else {
         HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
         if (band_rows > 0) {
             if (band_shards) {   // the cursors are zeroed HERE, ahead of the event the other launch's stream waits for
@@ -2366,6 +2422,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         }
         call_lap("all tiles enqueued");
         if (st) { (void)hipStreamSynchronize(ctx->rest_stream); (void)hipStreamSynchronize(S); return st; }
+        }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S));
         HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
         st = cluster_on_device(ctx, src, max_clusters, cluster_id, result_order, member_rank, stats, t0);

@@ -184,6 +184,21 @@ __device__ __forceinline__ void place_edge(const NeighborParams &P, unsigned lon
     }
 }
 
+// Which output segment a tile writes (NeighborParams::shard_base / shard_mod / band_mod).
+__device__ __forceinline__ uint32_t tile_shard(const NeighborParams &P, const Tile &T, uint32_t tile) {
+    return (P.band_mod && T.pad0) ? tile % P.band_mod : P.shard_base + tile % P.shard_mod;
+}
+// A clustering call scores its band tiles (the rows phase 1 reads first) and all the others in ONE launch, band tiles first
+// in dispatch order, and learns from a counter when the band's edges are complete: called by every thread of a workgroup as
+// the last thing it does.
+__device__ __forceinline__ void band_tile_done(const NeighborParams &P, const Tile &T) {
+    if (P.band_counter && T.pad0) {   // workgroup-uniform
+        __threadfence();              // this wave's edge stores are visible device-wide ...
+        __syncthreads();              // ... and so are the other waves' ...
+        if (threadIdx.x == 0) atomicAdd(P.band_counter, 1u);   // ... before the tile counts as done
+    }
+}
+
 // Drains one wave's staged records to its output segment.  REC_DW dwords per
 // record: [0] column (sorted position), [1] row within the tile, [2..] the NW
 // accumulator dwords (SWAR) or the score itself (direct, NW == 0).

@@ -66,7 +66,9 @@ struct NeighborParams {
     uint32_t deg_m_offset;   // counting mode: the larger end m of an edge counts into deg[deg_m_offset + m] (0: one counter per row)
     uint32_t shard_base;     // a tile writes into segment shard_base + tile % shard_mod (the whole pass: 0 and HMK_EDGE_SHARDS; a clustering
     uint32_t shard_mod;      // call scores its band tiles and the others at the same time, each into segments of their own)
-    uint32_t pad_shard;
+    uint32_t band_mod;       // > 0: ONE launch scores band tiles (Tile::pad0) and the others; a band tile writes into segment tile % band_mod,
+                             // the others into shard_base + tile % shard_mod (shard_base >= band_mod)
+    uint32_t *band_counter;  // ... and every band tile's workgroup adds 1 here when its edges are out (band_tile_done, hmk_device.h)
     uint32_t *deg_up;    // placing mode: the rows' upper counters ...
     uint32_t *deg_lo;    // ... and lower counters (symmetric only)
     uint32_t *rank;      // placing mode (else null)

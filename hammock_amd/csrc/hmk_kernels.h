@@ -55,6 +55,8 @@ hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uin
 hipError_t launch_csr_scatter_ranked(const EdgeSegs &segs, const uint64_t *edges0, const uint32_t *rank, bool symmetric,
                                      const uint64_t *start, void *adj, bool packed, int base, hipStream_t s);   // deg[] already counted by the neighbour kernel (NeighborParams::deg)
 hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, uint32_t n, hipStream_t s);   // dst[k] += src[k]
+// stream s continues when *counter >= target (band tiles of a running pass) or after ~5 s (*timed_out = 1)
+hipError_t launch_wait_counter(const uint32_t *counter, uint32_t target, uint32_t *timed_out, hipStream_t s);
 size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
 size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)

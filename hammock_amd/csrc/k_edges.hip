@@ -1319,6 +1319,23 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
     }
 }
 
+// One wave that waits until *counter reaches target (the band tiles of a running neighbour pass, band_tile_done): what comes
+// after it on its stream starts when the band's edges are complete.  It gives up after ~5 s (*timed_out = 1: the caller then
+// waits for the whole pass instead), so the grid always drains.
+__global__ void k_wait_counter(const uint32_t *counter, uint32_t target, uint32_t *timed_out) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();   // 100 MHz
+    for (;;) {
+        if (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        if (wall_clock64() - t0 > 500000000ull) { *timed_out = 1u; break; }
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+hipError_t launch_wait_counter(const uint32_t *counter, uint32_t target, uint32_t *timed_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(64), 0, s, counter, target, timed_out);
+    return hipGetLastError();
+}
+
 // -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------

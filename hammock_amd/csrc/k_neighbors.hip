@@ -52,7 +52,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
     const TileClass *Cp = P.classes + T.cls;
     const int threshold = 128 - Cp->g;         // 8-bit lanes: lane value = 128 - threshold + score
     const uint32_t himask = 0x80808080u;
-    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
+    const uint32_t shard = tile_shard(P, T, tile_base + blockIdx.x);
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -196,6 +196,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
         }
     }
     flush_stage_compact<DEG>(stage, cnt, P, T, threshold, shard);
+    band_tile_done(P, T);
 }
 
 // -----------------------------------------------------------------------------
@@ -284,7 +285,7 @@ __global__ void __launch_bounds__(256, (NW == 2 && 2 * R + LBMAX <= 30) ? 6 : 1)
     const bool lane16 = Cp->path == PATH_U16;
     const int g = Cp->g;
     const uint32_t himask = lane16 ? 0x80008000u : 0x80808080u;
-    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
+    const uint32_t shard = tile_shard(P, T, tile_base + blockIdx.x);
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * STAGE_DW;   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
     // hit records (hmk_device.h flush_stage_packed): one dword when score - threshold fits 12 bits -- always with 8-bit lanes,
@@ -515,6 +516,7 @@ __global__ void __launch_bounds__(256, (NW == 2 && 2 * R + LBMAX <= 30) ? 6 : 1)
         }
     }
     flush_stage_packed<true>(stage, cnt, P, T, base_score, rec_dw, shard);
+    band_tile_done(P, T);
 }
 
 // -----------------------------------------------------------------------------
@@ -535,7 +537,7 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
     const int la = Cp->la, lb = Cp->lb;
-    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
+    const uint32_t shard = tile_shard(P, T, tile_base + blockIdx.x);
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
@@ -587,6 +589,7 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
         }
     }
     flush_stage<0>(stage, cnt, P, T, 0, false, shard);
+    band_tile_done(P, T);
 }
 
 // -----------------------------------------------------------------------------

@@ -345,7 +345,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         A.row0 = rows_const_load<uint32_t>(&Tp->row0);
         A.col0 = rows_const_load<uint32_t>(&Tp->col0);
         const TileClass *Cp = K->P.classes + rows_const_load<uint32_t>(&Tp->cls);
-        A.shard = K->P.shard_base + tile % K->P.shard_mod;
+        A.shard = (K->P.band_mod && rows_const_load<uint32_t>(&Tp->pad0)) ? tile % K->P.band_mod : K->P.shard_base + tile % K->P.shard_mod;   // tile_shard(), hmk_device.h
         A.threshold = 128 - rows_const_load<int32_t>(&Cp->g);
 #pragma unroll
         for (int q = 0; q < 8; q++) A.cinit[q] = (q * 4 < S::ND) ? rows_const_load<uint32_t>(&Cp->cinit[q]) : 0u;
@@ -758,6 +758,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
         rows_for_each_group(std::make_integer_sequence<int, G>{}, one_group);
     }
     flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, tab_addr, ka_lo, ka_hi);
+    band_tile_done(P, T);
 }
 
 
