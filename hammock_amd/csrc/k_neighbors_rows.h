@@ -55,8 +55,24 @@ namespace hmk {
 #define HMK_ROWS_STAGE_EXACT 640
 #endif
 constexpr int rows_stage(bool exact) { return exact ? HMK_ROWS_STAGE_EXACT : HMK_ROWS_STAGE; }
+// "Fat" records (one-length shapes of at most 12 residues): a hit is staged WITH its column's residue words (16 bytes: the
+// record + three words), so the flush needs nothing from global memory -- its gather of 64 columns from 30-60 cache lines was
+// the one round trip a flush iteration could not hide (0.27 of the 0.6 ms that 8 x 10^7 hits cost the 10^5 pass).  The main
+// loop keeps the words of a quad's four steps in registers (its batch loop is unrolled by four; a hit noted `back` steps
+// ago picks its step's words with <= 3 selects per word) and writes them with the record: ds_write_b128 instead of _b32.
+#ifndef HMK_ROWS_FAT
+#define HMK_ROWS_FAT 1
+#endif
+#ifndef HMK_ROWS_STAGE_FAT   // fat records a wave stages (16 bytes each)
+#define HMK_ROWS_STAGE_FAT 256
+#endif
+constexpr bool rows_fat(int cap, bool exact) { return HMK_ROWS_FAT != 0 && HMK_ROWS_DEFER != 0 && exact && cap <= 12; }
+constexpr int rows_stage_bytes(int cap, bool exact) { return rows_fat(cap, exact) ? HMK_ROWS_STAGE_FAT * 16 : rows_stage(exact) * 4; }   // per wave
 #ifndef HMK_ROWS_DBG   // measurement builds only (tools/ab_rows4.sh; wrong results): the flush 1 = does not rescore, 2 = drops its records, 3 = fetches one column for all lanes, 4 = stores nothing, 5 = no placing atomics, 6 = no rank store
 #define HMK_ROWS_DBG 0
+#endif
+#ifndef HMK_ROWS_COUNT_GROUPED   // 1: the counting flush adds a row's hits of one iteration with ONE atomic
+#define HMK_ROWS_COUNT_GROUPED 1
 #endif
 #ifndef HMK_ROWS_FLUSH_UNROLLED   // 1: the flush of a one-length shape sums its planes from compile-time cell lists (0: the run-time loop of the capacity form)
 #define HMK_ROWS_FLUSH_UNROLLED 1
@@ -101,7 +117,7 @@ constexpr int rows_tab_bytes(int x, int d, int cap, bool exact, int g) {
     return HMK_ROWS_COMPACT ? g * (cap + d + (exact ? 0 : nd - 1)) * 192 : nd * rows_slot_bytes();
 }
 constexpr int rows_lds_bytes(int x, int d, int cap, bool exact, int g) {   // must match the kernel's LDS map
-    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * rows_stage(exact) * 4;
+    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * rows_stage_bytes(cap, exact);
 }
 
 template <int N, class F, int... Is>
@@ -464,10 +480,16 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         const bool ok = live && pos < A.cap_per_shard;   // stored edges only (place_edge, hmk_device.h)
         const unsigned long long slot = (unsigned long long)A.shard * A.cap_per_shard + pos;
         if (MODE == EDGES_COUNT) {
-            if (ok) {   // fire-and-forget: nothing of these is waited for
+            // fire-and-forget: nothing of these is waited for.  With the sorted order = the caller's (one length bucket) the 64
+            // records' smaller ends are the tile's 8 or 16 rows: one atomic per distinct row with the group's size instead of
+            // one per record (atomics on 12.8 M edges' two ends cost the 10^5 pass 0.5 ms: they are served at ~50 G/s).
+            if (A.perm_identity && HMK_ROWS_COUNT_GROUPED) {
+                const WaveGroup g = wave_groups(x, ok);
+                if (ok && g.rank == 0) atomicAdd(&A.deg[x], g.size);
+            } else if (ok) {
                 atomicAdd(&A.deg[x], 1u);
-                if (A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
             }
+            if (ok && A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
         }
         // The record's ROW is byte r of every 8-byte table entry: the lane reads the 4-byte half that holds it (ds_read_b32: 1
         // LDS cycle per wave-instruction where the ds_read_b64 of all eight rows takes 2), sums the halves as they are -- four
@@ -566,8 +588,10 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     using S = RowsShape<X, D, CAP, EXACT_LB, G>;
     constexpr int ND = S::ND, NI = S::NI, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
     constexpr int R = 8 * G;
-    constexpr int STAGE_CAP = rows_stage(EXACT_LB);  // records per wave; flushed when fewer than 64 slots are free
-    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4;
+    constexpr bool FAT = rows_fat(CAP, EXACT_LB);
+    constexpr int STAGE_CAP = FAT ? HMK_ROWS_STAGE_FAT : rows_stage(EXACT_LB);  // records per wave; flushed when fewer than 64 slots are free
+    constexpr int STAGE_DW = FAT ? 4 : 1;                                       // dwords per record
+    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * STAGE_DW * 4;
     static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, EXACT_LB, G), "rows_lds_bytes must match the LDS map");
     // one STATIC LDS object: its base address is a compile-time constant, so table offsets fold into the ds_read immediate
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
@@ -583,7 +607,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     const bool case_b = Cp->case_b != 0;       // the column is the SHORTER sequence: cell = M[c][row[i]], else M[row[i]][c]
     const int tid = threadIdx.x;
     // 32-bit LDS pointer, wave-uniform (kept in a scalar register: nothing to spill around the flush call)
-    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_CAP;
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + __builtin_amdgcn_readfirstlane(tid >> 6) * (STAGE_CAP * STAGE_DW);
 
     build_begin();
     const uint32_t tab_addr = lds_addr(tab);
@@ -665,11 +689,25 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
         const uint32_t col0 = T.col0 + tid;
         S::load_words(res_sorted + (size_t)col0 * lpad_s, col0 < col_end, lbs, nwords, ntw);
     }
-    for (uint32_t bt = 0; bt < n_batches; bt++) {
+    constexpr int NWF = FAT ? (CAP + 3) / 4 : 1;   // residue words a fat record carries
+    uint32_t Wh[4][NWF];                           // fat records: the column words of the quad's four steps
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int k = 0; k < NWF; k++) Wh[q][k] = 0;
+    // one step of the batch loop; QT: the step's place in its quad (bt & 3) at compile time (fat records: which Wh[] it fills)
+    auto step = [&](const uint32_t bt, auto qt) {
+        constexpr int Q = decltype(qt)::value;
         const uint32_t colrel = bt * 256 + tid;
         const uint32_t col = T.col0 + colrel;
         uint32_t off[CAP], toff[S::NT];
-        if constexpr (AHEAD) {
+        if constexpr (FAT) {
+            uint32_t words[S::LPADW], tw[S::TWN];
+            S::load_words(res_sorted + (size_t)col * lpad_s, col < col_end, lbs, words, tw);
+#pragma unroll
+            for (int k = 0; k < NWF; k++) Wh[Q][k] = words[k];
+            S::offsets_of(words, tw, tab_addr, tab_addr, off, toff);
+        } else if constexpr (AHEAD) {
             // The wait for THIS step's column must stand before the next column is asked for: the compiler does not count loads
             // in flight across the loop's back edge, so a load issued above the first use of the words makes that use wait
             // for both (s_waitcnt vmcnt(0)) -- round 3's form of this switch, whose load was hoisted to the loop's top, prefetched
@@ -745,7 +783,24 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
                         // record: here a turn runs for the few lanes that still have a hit, and every instruction of it costs the
                         // wave a VALU slot (17 per turn with the decoding, 8 without)
                         const uint32_t q = (uint32_t)__builtin_ctz(hm);
-                        stage[cnt + mbcnt64(mask)] = (colrel | (uint32_t)g << 21) | q << 16;
+                        if constexpr (FAT) {
+                            // the hit was noted `back` steps ago: ITS column and ITS words (this step's place in the quad is Q, so
+                            // the history holds steps Q, Q - 1, ... 0 only: the wave looked last at the end of the quad before)
+                            const uint32_t back = 3u - (q & 3u);
+                            u32x4 rec;
+                            rec.x = ((colrel - back * 256u) | (uint32_t)g << 21) | q << 16;
+                            uint32_t w[3] = {0, 0, 0};
+#pragma unroll
+                            for (int k = 0; k < NWF; k++) {
+                                w[k] = Wh[Q][k];
+#pragma unroll
+                                for (int b = 1; b <= Q; b++) w[k] = back == (uint32_t)b ? Wh[Q - b][k] : w[k];
+                            }
+                            rec.y = w[0]; rec.z = w[1]; rec.w = w[2];
+                            reinterpret_cast<HMK_LDS u32x4 *>(stage)[cnt + mbcnt64(mask)] = rec;
+                        } else {
+                            stage[cnt + mbcnt64(mask)] = (colrel | (uint32_t)g << 21) | q << 16;
+                        }
                         hm &= hm - 1u;   // clear the lowest set bit
                     }
                     cnt += (uint32_t)__popcll(mask);
@@ -756,6 +811,16 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
             }
         };
         rows_for_each_group(std::make_integer_sequence<int, G>{}, one_group);
+    };
+    if constexpr (FAT) {   // (the loop unrolled by four: every step knows its place in the quad at compile time)
+        for (uint32_t bq = 0; bq < n_batches; bq += 4) {
+            step(bq, std::integral_constant<int, 0>{});
+            if (bq + 1 < n_batches) step(bq + 1, std::integral_constant<int, 1>{});
+            if (bq + 2 < n_batches) step(bq + 2, std::integral_constant<int, 2>{});
+            if (bq + 3 < n_batches) step(bq + 3, std::integral_constant<int, 3>{});
+        }
+    } else {
+        for (uint32_t bt = 0; bt < n_batches; bt++) step(bt, std::integral_constant<int, 0>{});
     }
     flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, tab_addr, ka_lo, ka_hi);
     band_tile_done(P, T);

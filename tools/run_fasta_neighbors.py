@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""A few plain neighbour passes over a FASTA file with the reference's default parameters (for rocprofv3):
+python3 tools/run_fasta_neighbors.py tests/golden/antibodies.fa.gz [passes]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import hammock_amd
+from hammock_amd import _native
+from bench import load_blosum62, load_fasta_unique, lds_ideal_ms
+
+path = sys.argv[1]
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+seqs, sizes = load_fasta_unique(path)
+L = np.array([len(q) for q in seqs])
+jr = lambda v: int(np.floor(v + 0.5))
+thr, X = jr(L.mean() * 1.7), min(jr(L.mean() / 4), int(L.min()) - 1)
+dev = torch.device("cuda", 0)
+S = _native.HMK_EDGE_SHARDS
+cap = (1 << 26) // S * S
+d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
+d_counts = torch.zeros(S, dtype=torch.int64, device=dev)
+ctx = hammock_amd.Context(load_blosum62(), device=0)
+ctx.set_sequences(seqs, sizes=sizes)
+ms = []
+for _ in range(passes):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    ctx.neighbors_shifted_dev(X, 0, thr, 0, 1, d_edges.data_ptr(), cap, d_counts.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    b.record()
+    torch.cuda.synchronize()
+    ms.append(a.elapsed_time(b))
+plan = ctx.last_plan()
+n = len(seqs)
+ideal = lds_ideal_ms(L, X)
+med = float(np.median(ms[2:]))
+print(json.dumps({"input": os.path.basename(path), "n": n, "lengths": [int(L.min()), int(L.max())], "X": X, "thr": thr, "kernel_ms": med,
+                  "kernel_ms_all": [round(v, 4) for v in ms], "pairs": int(plan.pairs_scored), "edges": int(d_counts.sum().item()),
+                  "hit_fraction": int(d_counts.sum().item()) / int(plan.pairs_scored), "overflowed": bool(int(d_counts.max().item()) > cap // S),
+                  "row_packed_classes": int(plan.classes_rows), "lds_ideal_ms": ideal, "frac": ideal / med}))
