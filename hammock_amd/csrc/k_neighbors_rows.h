@@ -55,13 +55,18 @@ namespace hmk {
 #define HMK_ROWS_STAGE_EXACT 640
 #endif
 constexpr int rows_stage(bool exact) { return exact ? HMK_ROWS_STAGE_EXACT : HMK_ROWS_STAGE; }
-// "Fat" records (one-length shapes of at most 12 residues): a hit is staged WITH its column's residue words (16 bytes: the
-// record + three words), so the flush needs nothing from global memory -- its gather of 64 columns from 30-60 cache lines was
-// the one round trip a flush iteration could not hide (0.27 of the 0.6 ms that 8 x 10^7 hits cost the 10^5 pass).  The main
-// loop keeps the words of a quad's four steps in registers (its batch loop is unrolled by four; a hit noted `back` steps
-// ago picks its step's words with <= 3 selects per word) and writes them with the record: ds_write_b128 instead of _b32.
+// "Fat" records (HMK_ROWS_FAT=1; one-length shapes of at most 12 residues; measured, rejected, kept as a switch): a hit is
+// staged WITH its column's residue words (16 bytes: the record + three words), so the flush needs nothing from global memory --
+// its gather of 64 columns from 30-60 cache lines is the one round trip a flush iteration cannot hide (0.27 of the 0.6 ms
+// that 8 x 10^7 hits cost the 10^5 pass: a build whose lanes all fetch ONE column, HMK_ROWS_DBG=3).  The main loop keeps the
+// words of a quad's four steps in registers (its batch loop unrolled by four; a hit noted `back` steps ago picks its step's
+// words with <= 3 selects per word) and writes them with the record, ds_write_b128 instead of _b32.  Result, 10^5 12-mers:
+// threshold 14 3.39 ms (thin records 3.07), threshold 20 2.75 (2.58), no hits 2.45 (2.40); 7-mers 1.76 (1.57).  The flush did
+// get cheaper -- but the selects and the wide write run in the APPEND loop, at full wave cost for a handful of live lanes,
+// on a VALU pipe that is as busy as the LDS pipe: what the flush saved, the hot loop paid twice.  (Not the drain frequency:
+// thin records with 256-record stages read 3.14 at threshold 14.)
 #ifndef HMK_ROWS_FAT
-#define HMK_ROWS_FAT 1
+#define HMK_ROWS_FAT 0
 #endif
 #ifndef HMK_ROWS_STAGE_FAT   // fat records a wave stages (16 bytes each)
 #define HMK_ROWS_STAGE_FAT 256
@@ -400,16 +405,28 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
     } nx;
     uint32_t rx = 0, rm = 0;   // the placing atomics' return values
     // decode the records of iteration k0 into nx.rt / nx.mcol and return the addresses the statement loads from
+    constexpr bool FAT = rows_fat(CAP, EXACT_LB);   // records carry their column's words: nothing to fetch (see HMK_ROWS_FAT)
     auto decode = [&](uint32_t k0) {
         const bool live = k0 + lane < cnt;
-        const uint32_t rec = live ? stage[k0 + lane] : 0u;
+        u32x4 fat = {0, 0, 0, 0};
+        if constexpr (FAT) { if (live) fat = reinterpret_cast<const HMK_LDS u32x4 *>(stage)[k0 + lane]; }
+        const uint32_t rec = FAT ? fat.x : (live ? stage[k0 + lane] : 0u);
         // the record (see the append loop): bit q of the lane's hit word at the step that looked, noted `back` steps earlier
         const uint32_t q = (rec >> 16) & 31u, grp = rec >> 21;
         const uint32_t b = DEFER ? q | 3u : q;                // where the bit was when its step noted it
         const uint32_t back = DEFER ? 3u - (q & 3u) : 0u;     // ... that many steps ago
         const uint32_t r = (b >> 3) + 4u - (b & 4u);          // bit 8r + 7: row r; bit 8r + 3: row 4 + r
         nx.rt = live ? grp * 8u + r : 0u;
-        nx.mcol = A.col0 + (live ? (rec & 0xFFFFu) - back * 256u : 0u);
+        nx.mcol = A.col0 + (live ? (rec & 0xFFFFu) - (FAT ? 0u : back * 256u) : 0u);   // (a fat record holds the hit's own column)
+        if constexpr (FAT) {
+            const uint32_t fw[3] = {fat.y, fat.z, fat.w};
+#pragma unroll
+            for (int t = 0; t < S::LPADW; t++) nx.w[t] = t < 3 ? fw[t < 3 ? t : 0] : 0u;
+#pragma unroll
+            for (int t = 0; t < S::TWN; t++) nx.tw[t] = 0;
+            nx.px = A.row0 + nx.rt;
+            nx.pm = nx.mcol;
+        }
     };
     // the statement: [atomics of the current records: ux / um += one, old values -> r0 / r1] + loads for the records decoded last
     // + the wait.  One asm per combination, each with exactly the operands it uses (outputs are early-clobber: a superset of
@@ -434,6 +451,17 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
     } while (0)
     // x, m, ok: the CURRENT records' edge ends and whether they are stored (atomics only when `atomics`)
     auto statement = [&](bool atomics, uint32_t x, uint32_t m, bool ok) {
+        if constexpr (FAT) {
+            if (MODE == EDGES_PLACE && atomics && HMK_ROWS_DBG != 5) {
+                const uint32_t *ux = A.deg_up + x, *um = A.symmetric ? A.deg_lo + m : A.deg_up + x;
+                const uint32_t one = ok ? 1u : 0u, one2 = A.symmetric ? one : 0u;
+                uint32_t r0 = 0, r1 = 0;
+                asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\ts_waitcnt vmcnt(0)"
+                             : [r0] "=&v"(r0), [r1] "=&v"(r1) : [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2) : "memory");
+                rx = r0; rm = A.symmetric ? r1 : 0u;
+            }
+            return;
+        }
         const uint8_t *colp = A.res_sorted + (size_t)(HMK_ROWS_DBG == 3 ? A.col0 : nx.mcol) * A.lpad;   // (DBG 3: every lane fetches the tile's first column)
         const uint8_t *tp = colp + (lbs - X);
         const uint32_t *pxp = A.perm + (A.row0 + nx.rt), *pmp = A.perm + nx.mcol;
@@ -475,6 +503,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         for (int t = 0; t < S::TWN; t++) tw[t] = nx.tw[t];
         const uint32_t rt = nx.rt, grp = rt >> 3, r = rt & 7u;
         uint32_t x = nx.px, m = nx.pm;
+        if constexpr (FAT) { if (!A.perm_identity && live) { x = A.perm[x]; m = A.perm[m]; } }   // (one-length plans keep the caller's order: never taken)
         if (A.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
         const unsigned long long pos = base + k;
         const bool ok = live && pos < A.cap_per_shard;   // stored edges only (place_edge, hmk_device.h)
@@ -789,14 +818,22 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
                             const uint32_t back = 3u - (q & 3u);
                             u32x4 rec;
                             rec.x = ((colrel - back * 256u) | (uint32_t)g << 21) | q << 16;
-                            uint32_t w[3] = {0, 0, 0};
-#pragma unroll
-                            for (int k = 0; k < NWF; k++) {
-                                w[k] = Wh[Q][k];
-#pragma unroll
-                                for (int b = 1; b <= Q; b++) w[k] = back == (uint32_t)b ? Wh[Q - b][k] : w[k];
-                            }
-                            rec.y = w[0]; rec.z = w[1]; rec.w = w[2];
+                            // (every candidate goes through an empty asm first: a select between two loads of the word history
+                            // is turned into ONE load at a selected address, and the history then lives in scratch memory --
+                            // 12 bytes per lane and step stored, 7.5 GB per pass)
+                            auto pick = [&](int k) -> uint32_t {
+                                if (k >= NWF) return 0u;
+                                uint32_t wk = Wh[Q][k < NWF ? k : 0];
+                                asm("" : "+v"(wk));
+                                rows_static_for<Q>([&](auto bt_) {
+                                    constexpr int B = decltype(bt_)::value + 1;
+                                    uint32_t cand = Wh[Q - B][k < NWF ? k : 0];
+                                    asm("" : "+v"(cand));
+                                    wk = back == (uint32_t)B ? cand : wk;
+                                });
+                                return wk;
+                            };
+                            rec.y = pick(0); rec.z = pick(1); rec.w = pick(2);
                             reinterpret_cast<HMK_LDS u32x4 *>(stage)[cnt + mbcnt64(mask)] = rec;
                         } else {
                             stage[cnt + mbcnt64(mask)] = (colrel | (uint32_t)g << 21) | q << 16;
