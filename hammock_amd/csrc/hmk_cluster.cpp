@@ -1,0 +1,621 @@
+// hmk_cluster.cpp -- cluster_on_device: edges -> CSR on the device, band hand-over, rows to the host merge on demand, pre-check and
+// the device-side second loop (LimitedGreedySequenceClusterer.java:39-120 / ClinkageSequenceClusterer.java:43-124 on the graph).
+#include "hmk_ctx.h"
+
+namespace hmk { namespace impl {
+
+// Builds the CSR adjacency on the device, hands rows to the host merge on demand, runs the merge.
+int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int32_t *cluster_id, int32_t *result_order,
+                      int32_t *member_rank, hmk_greedy_stats *stats, std::chrono::steady_clock::time_point t0) {
+    const uint32_t n = ctx->n;
+    hipStream_t S = ctx->gstream, C = ctx->copy_stream;
+    hmk_greedy_phases &ph = ctx->phases;
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
+    const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[hmk greedy] %s at %.2f ms\n", what, ms_since(t0));
+    };
+    bool packed = src.packed;
+    int base = src.base;
+    size_t esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
+    const bool symmetric = src.symmetric;
+
+    // ---- full CSR on the device, enqueued behind the scoring on S ---------------------------------------
+    HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
+    HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
+    HIPCHK(ctx, ensure_buf(ctx, SB_START, ((size_t)n + 1) * 8));
+    HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
+    HIPCHK(ctx, ensure_buf(ctx, SB_RANGE, 64));
+    const bool late_buffers = late_buffers_pending(ctx);   // hmk_reserve's thread is still getting SB_ADJ / SB_PART: the CSR is enqueued later
+    if (src.format_known && !late_buffers) HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(src.adj_bound, 1) * esz));
+    HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, ((size_t)n + 1) * 8 + (size_t)n * 4 + 64, 0));
+    uint64_t *h_start = (uint64_t *)ctx->h_start;
+    uint32_t *h_up = (uint32_t *)((char *)ctx->h_start + ((size_t)n + 1) * 8);
+    int *h_range = (int *)(ctx->h_counts + HC_RANGE);
+
+    // (multi-device calls enqueue it later, from wait_full(): the peers' edges are not there yet)
+    bool scatter_enqueued = false;
+    auto enqueue_scatter = [&]() -> hipError_t {
+        scatter_enqueued = true;
+        if (late_buffers && src.format_known) {
+            const hipError_t e = ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(src.adj_bound, 1) * esz);   // (joins the thread)
+            if (e != hipSuccess) return e;
+        }
+        if (csr_by_bucket(n, symmetric, packed, src.deg_fused && src.placed)) {   // large graphs: lower sections dealt by bucket
+            uint64_t records = 1;   // one per edge: at most what the segments hold
+            for (uint32_t q = 0; q < src.segs.n; q++) records += src.segs.s[q].cap;
+            hipError_t e = ensure_buf(ctx, SB_PART, records * 8);   // in place already when hmk_greedy_cluster scored the edges itself
+            if (e == hipSuccess) e = ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes());
+            if (e == hipSuccess)
+                e = launch_csr_scatter_partitioned(src.segs, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
+                                                   base, n, buf<uint64_t>(ctx, SB_PART), buf<void>(ctx, SB_PARTSCR),
+                                                   src.deg_fused && src.deg_split ? buf<uint32_t>(ctx, SB_DEG) + n : nullptr, S);
+            if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
+            return e;
+        }
+        hipError_t e = src.deg_fused && src.placed
+                           ? launch_csr_scatter_ranked(src.segs, src.edges0, buf<uint32_t>(ctx, SB_RANK), symmetric, buf<uint64_t>(ctx, SB_START),
+                                                       buf<void>(ctx, SB_ADJ), packed, base, S)
+                           : launch_csr_scatter(src.segs, symmetric, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR),
+                                                buf<void>(ctx, SB_ADJ), packed, base, n, S);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
+        return e;
+    };
+    auto enqueue_counts = [&]() -> hipError_t {
+        hipError_t e_;
+        if (src.deg_fused && src.placed) {
+            if ((e_ = (launch_csr_scan_only(buf<uint32_t>(ctx, SB_CURSOR), symmetric ? buf<uint32_t>(ctx, SB_CURSOR) + n : nullptr,
+                                             buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S))) != hipSuccess) return e_;
+        } else if (src.deg_fused) {
+            if ((e_ = (hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S))) != hipSuccess) return e_;
+            if ((e_ = (launch_csr_scan_only(buf<uint32_t>(ctx, SB_DEG), src.deg_split ? buf<uint32_t>(ctx, SB_DEG) + n : nullptr,
+                                             buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S))) != hipSuccess) return e_;
+        } else {
+            if ((e_ = (hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S))) != hipSuccess) return e_;
+            if ((e_ = (hipMemsetAsync(buf<void>(ctx, SB_DEG), 0, (size_t)n * 4, S))) != hipSuccess) return e_;
+            if ((e_ = (launch_csr_degree_scan(src.segs, n, n, symmetric, buf<uint32_t>(ctx, SB_DEG), buf<uint64_t>(ctx, SB_START),
+                                               buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S))) != hipSuccess) return e_;
+        }
+        if ((e_ = (hipMemcpyAsync(h_range, buf<int>(ctx, SB_RANGE), 3 * sizeof(int), hipMemcpyDeviceToHost, S))) != hipSuccess) return e_;
+        if ((e_ = (hipMemcpyAsync(&h_start[n], buf<uint64_t>(ctx, SB_START) + n, 8, hipMemcpyDeviceToHost, S))) != hipSuccess) return e_;
+    return hipSuccess;
+    };
+    bool full_enqueued = false;
+    auto enqueue_full = [&]() -> hipError_t {
+        full_enqueued = true;
+        hipError_t e = enqueue_counts();
+        if (e == hipSuccess && src.format_known) e = enqueue_scatter();
+        return e;
+    };
+    if (!src.before_full && !late_buffers) HIPCHK(ctx, enqueue_full());
+
+    // ---- band: the first rows' adjacency from the edges of the band launch, on the copy stream --------------
+    uint32_t rows_here = 0;          // rows [0, rows_here) are valid in h_start / h_adj
+    bool band_pending = false, band_used = false;
+    uint32_t R1 = src.band_rows;
+    if (R1 > 0 && src.before_band && src.before_band() != HMK_OK) R1 = 0;   // (the peers' band blocks did not make it: no band)
+    if (R1 > 0 && src.format_known) {
+        HIPCHK(ctx, ensure_buf(ctx, SB_BDEG, (size_t)R1 * 4));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BCURSOR, (size_t)R1 * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BSTART, ((size_t)R1 + 1) * 8));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(R1)));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
+        HIPCHK(ctx, hipStreamWaitEvent(C, ctx->ev_band, 0));
+        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BDEG), 0, (size_t)R1 * 4, C));
+        HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BCURSOR), 0, (size_t)R1 * 8, C));
+        HIPCHK(ctx, launch_csr_degree_scan(src.band_segs, n, R1, symmetric, buf<uint32_t>(ctx, SB_BDEG), buf<uint64_t>(ctx, SB_BSTART),
+                                           buf<uint64_t>(ctx, SB_BSCAN), buf<int>(ctx, SB_BRANGE), C));
+        HIPCHK(ctx, hipMemcpyAsync(h_start, buf<uint64_t>(ctx, SB_BSTART), ((size_t)R1 + 1) * 8, hipMemcpyDeviceToHost, C));
+
+        // (the band's own segments only: beside a pass that runs at the same time the other cursors are in motion)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count,
+                                   std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) * sizeof(unsigned long long), hipMemcpyDeviceToHost, C));
+        ((uint32_t *)(ctx->h_counts + HC_MISC))[7] = 0;
+        if (src.band_gave_up)
+            HIPCHK(ctx, hipMemcpyAsync((uint32_t *)(ctx->h_counts + HC_MISC) + 7, src.band_gave_up, 4, hipMemcpyDeviceToHost, C));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_bandcsr, C));
+        band_pending = true;
+    }
+    lap("scoring, CSR and band hand-over enqueued");
+
+    int status_inside = HMK_OK;   // failure inside a hook (the merge then stops with its own error)
+    std::string hook_err;
+    auto hook_fail = [&](int code, const std::string &msg) { status_inside = code; hook_err = msg; };
+
+    // the full CSR is complete (and trustworthy: no segment overflowed)
+    bool full_ready = false;
+    auto wait_full = [&]() -> bool {
+        if (full_ready) return true;
+        if (!full_enqueued) {   // multi-device: the peers' edges first; (or: the late buffers are ready only now)
+            const int r = src.before_full ? src.before_full() : HMK_OK;
+            if (r != HMK_OK) { hook_fail(r, ctx->err.empty() ? "gathering the peers' edges failed" : ctx->err); return false; }
+            const hipError_t e0 = enqueue_full();
+            if (e0 != hipSuccess) { hook_fail(e0 == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("CSR build: ") + hipGetErrorString(e0)); return false; }
+        }
+        hipError_t e = hipEventSynchronize(ctx->ev_edges);
+        if (e == hipSuccess && src.check_overflow) {
+            for (int q = 0; q < HMK_EDGE_SHARDS; q++)
+                if (ctx->h_counts[q] > src.seg_cap) { hook_fail(ST_RETRY_OVERFLOW, "edge segment overflow"); return false; }
+        }
+        if (e == hipSuccess && !scatter_enqueued) {
+            // the adjacency format depends on the scores found: 4-byte entries when they span at most 255
+            e = hipStreamSynchronize(S);
+            if (e == hipSuccess && h_range[2] != 0) {
+                hook_fail(HMK_ERR_BAD_ARG, "edge list references a sequence outside [0, n) or a self pair");
+                return false;
+            }
+            if (e == hipSuccess) {
+                packed = h_start[n] == 0 || ((long long)h_range[1] - h_range[0] <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr);
+                base = h_range[0];
+                esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
+                e = ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(h_start[n], 1) * esz);
+            }
+            if (e == hipSuccess) e = enqueue_scatter();
+        }
+        if (e == hipSuccess) e = hipEventSynchronize(ctx->ev_csr);
+        if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("CSR build: ") + hipGetErrorString(e)); return false; }
+        if (h_range[2] != 0) { hook_fail(HMK_ERR_BAD_ARG, "edge list references a sequence outside [0, n) or a self pair"); return false; }
+        const uint64_t want = src.total_known ? (symmetric ? 2 * src.total_known : src.total_known) : h_start[n];
+        if (h_start[n] != want) { hook_fail(HMK_ERR_DEVICE, "CSR build: adjacency size mismatch"); return false; }
+        full_ready = true;
+        lap("full CSR on the device");
+        return true;
+    };
+
+    GreedyHooks hooks;
+    double t_rows = 0;   // host time spent waiting for rows
+    hooks.need_rows = [&](uint32_t k) -> uint32_t {
+        if (ctx->wedged) return 0;   // (the second loop gave the device up: the merge stops here instead of waiting for it again)
+        if (k < rows_here) return rows_here;
+        const auto tw = std::chrono::steady_clock::now();
+        hipError_t e = hipSuccess;
+        if (band_pending) {
+            band_pending = false;
+            e = hipEventSynchronize(ctx->ev_bandcsr);
+            bool ok = e == hipSuccess && ((const uint32_t *)(ctx->h_counts + HC_MISC))[7] == 0;   // ([7]: the wait for the band tiles gave up)
+            for (uint32_t q = 0; q < std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) && ok; q++) ok = ctx->h_counts[HC_BAND + q] <= src.seg_cap;
+            if (ok) {
+                const uint64_t entries = h_start[R1];
+                e = ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz);
+                if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(entries, 1) * esz, 0);
+                if (e == hipSuccess)
+                    e = launch_csr_scatter(src.band_segs, symmetric, buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BCURSOR),
+                                           buf<void>(ctx, SB_BADJ), packed, base, R1, C);
+                if (e == hipSuccess && entries)
+                    e = hipMemcpyAsync(ctx->h_adj, buf<void>(ctx, SB_BADJ), entries * esz, hipMemcpyDeviceToHost, C);
+                // the band rows' upper-section sizes travel with them: upper[] must never hold a previous call's values for rows
+                // the merge may read (today every reader refetches from the full CSR first; this keeps it true by construction)
+                if (e == hipSuccess && symmetric)
+                    e = hipMemcpyAsync(h_up, buf<uint32_t>(ctx, SB_BCURSOR), (size_t)R1 * 4, hipMemcpyDeviceToHost, C);
+                if (e == hipSuccess) e = hipStreamSynchronize(C);
+                if (e == hipSuccess) {
+                    rows_here = R1;
+                    band_used = true;
+                    lap("band rows on the host");
+                }
+            }
+            if (e != hipSuccess) { hook_fail(HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return 0; }
+            if (k < rows_here) { t_rows += ms_since(tw); return rows_here; }
+        }
+        // more rows from the full CSR (which must be complete by now)
+        if (!wait_full()) return 0;
+        if (band_used) { rows_here = 0; band_used = false; }   // the band rows come again, in the full CSR's layout
+        uint32_t r_end = n;
+        if (k + 1 < n) r_end = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>({(uint64_t)k + 1, 2ull * rows_here, 8192ull}));
+        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
+        e = hipMemcpyAsync(h_start + rows_here, d_start + rows_here, ((size_t)(r_end - rows_here) + 1) * 8, hipMemcpyDeviceToHost, C);
+        if (e == hipSuccess && symmetric)
+            e = hipMemcpyAsync(h_up + rows_here, buf<uint32_t>(ctx, SB_CURSOR) + rows_here, (size_t)(r_end - rows_here) * 4, hipMemcpyDeviceToHost, C);
+        if (e == hipSuccess) e = hipStreamSynchronize(C);
+        if (e == hipSuccess) {
+            const uint64_t a0 = h_start[rows_here], a1 = h_start[r_end];
+            e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(a1, 1) * esz, a0 * esz);
+            if (e == hipSuccess && a1 > a0)
+                e = hipMemcpyAsync((char *)ctx->h_adj + a0 * esz, (const char *)buf<void>(ctx, SB_ADJ) + a0 * esz, (a1 - a0) * esz,
+                                   hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipStreamSynchronize(C);
+        }
+        if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("adjacency copy: ") + hipGetErrorString(e)); return 0; }
+        rows_here = r_end;
+        t_rows += ms_since(tw);
+        return rows_here;
+    };
+
+    // ---- second loop on the device-resident CSR ---------------------------------------------------------------
+    // (1) pre-check (k_greedy_precheck): per leftover the clusters that are feasible after phase 1 -> cand CSR on the device.
+    // Then either (2a) small / medium inputs: join-propagation lists (k_greedy_prop), the sequential loop runs on the
+    // host over those lists; or (2b) large inputs: the loop itself runs on the device level by level (k_greedy_level).
+    // pre_mode: 0 nothing yet, 1 = two passes done (cand_start[] are prefix sums: what the host-side consumers read),
+    // 2 = one pass done (every leftover's block lies where the global counter put it: the device loop takes either)
+    int pre_mode = 0;
+    uint32_t pre_total_c = 0;
+    auto device_precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<uint32_t> &leftover,
+                               bool single_pass) -> bool {
+        if (pre_mode == 1 || (pre_mode == 2 && single_pass)) return true;
+        if (getenv("HMK_HOST_PRECHECK")) return false;
+        if (getenv("HMK_PRECHECK_TWO_PASSES")) single_pass = false;
+        if (!wait_full()) return false;
+        const auto tp = std::chrono::steady_clock::now();
+        const uint32_t nl = (uint32_t)leftover.size();
+        hipError_t r = ensure_buf(ctx, SB_COF, (size_t)n * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_USIZE, std::max<size_t>(usize.size(), 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_LEFT, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CNT, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CSTART, ((size_t)nl + 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_OVER, 64);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>(nl, n)));
+        if (r != hipSuccess) return false;
+        int32_t *d_cof = buf<int32_t>(ctx, SB_COF), *d_usize = buf<int32_t>(ctx, SB_USIZE);
+        uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cnt = buf<uint32_t>(ctx, SB_CNT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
+        uint32_t *d_over = buf<uint32_t>(ctx, SB_OVER);                      // [0] table overflows, [2..3] the single pass's entry counter
+        unsigned long long *d_total = (unsigned long long *)(d_over + 2);
+        uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
+        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
+        const void *d_adj = buf<void>(ctx, SB_ADJ);
+        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
+        if (pre_mode == 0) {
+            // through a pinned block: an "async" upload from pageable memory is staged by the runtime chunk by chunk and the
+            // stream waits for it (0.3 ms for these 0.8 MB at 10^5, seen as the pre-check kernel starting late)
+            const size_t b_cof = (size_t)n * 4, b_us = usize.size() * 4, b_left = (size_t)nl * 4;
+            r = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + b_cof + b_us + b_left + 64, 0);
+            if (r != hipSuccess) return false;
+            char *hs = (char *)ctx->h_stage + HMK_PRE_REGIONS * sizeof(unsigned long long);   // (the block starts with the single pass's region counters)
+            std::memcpy(hs, cluster_of, b_cof);
+            std::memcpy(hs + b_cof, usize.data(), b_us);
+            std::memcpy(hs + b_cof + b_us, leftover.data(), b_left);
+            r = hipMemcpyAsync(d_cof, hs, b_cof, hipMemcpyHostToDevice, S);
+            if (r == hipSuccess) r = launch_cluster_bitmap(d_cof, n, buf<uint32_t>(ctx, SB_BITMAP), S);
+            if (r == hipSuccess && b_us) r = hipMemcpyAsync(d_usize, hs + b_cof, b_us, hipMemcpyHostToDevice, S);
+            if (r == hipSuccess && b_left) r = hipMemcpyAsync(d_left, hs + b_cof + b_us, b_left, hipMemcpyHostToDevice, S);
+        }
+        if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 16, S);
+        if (r == hipSuccess && single_pass) {
+            // One pass: every wave takes its block of entries from the counter of its workgroup's region of the buffer.  The
+            // buffer is sized from what previous calls needed (or 24 entries per leftover); a call that overruns a region falls
+            // back to the two passes below.
+            const size_t want = std::max<size_t>({ctx->sb[SB_CAND].cap / sizeof(GreedyCand), (size_t)nl * 24, (size_t)HMK_PRE_REGIONS * 64});
+            const unsigned long long region_cap = std::min<unsigned long long>(want, 0xFFFFFFFFull) / HMK_PRE_REGIONS;
+            r = ensure_buf(ctx, SB_CAND, (size_t)region_cap * HMK_PRE_REGIONS * sizeof(GreedyCand));
+            if (r == hipSuccess) r = ensure_buf(ctx, SB_PRECNT, HMK_PRE_REGIONS * sizeof(unsigned long long));
+            unsigned long long *d_regions = buf<unsigned long long>(ctx, SB_PRECNT);
+            if (r == hipSuccess) r = hipMemsetAsync(d_regions, 0, HMK_PRE_REGIONS * sizeof(unsigned long long), S);
+            // rows with few neighbours inside clusters (the estimate: average degree x the clustered share of the sequences) go
+            // through small tables first
+            size_t in_clusters = 0;
+            for (int32_t u : usize) in_clusters += (size_t)u;
+            const double est = (double)h_start[n] / std::max<uint32_t>(n, 1) * (double)in_clusters / std::max<uint32_t>(n, 1);
+            uint32_t *d_retry = nullptr;
+            const int first_slots = est <= 24.0 ? 128 : 512;   // ~5 x the expected number of distinct clusters in a row
+            // (10^6 default-threshold 12-mers give an estimate of 130; small tables first for them too -- 512 slots, five workgroups
+            // per CU instead of two -- was measured and loses: 22.0 against 18.7 ms, 38.9 against 25.8 ms in the reference's
+            // default order, where many rows see far more clusters than the average and are scanned twice)
+            double two_stage_limit = 100.0;
+            if (const char *v = getenv("HMK_PRECHECK_TWO_STAGE_LIMIT")) two_stage_limit = atof(v);
+            if (r == hipSuccess && est <= two_stage_limit && getenv("HMK_PRECHECK_ONE_STAGE") == nullptr) {
+                r = ensure_buf(ctx, SB_RETRY, std::max<size_t>(nl, 1) * 4);
+                d_retry = buf<uint32_t>(ctx, SB_RETRY);
+            }
+            if (r == hipSuccess) r = launch_greedy_precheck(2, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
+                                                            d_cnt, d_cstart, buf<GreedyCand>(ctx, SB_CAND), d_over, d_regions, region_cap,
+                                                            d_retry, d_over + 1, first_slots, S);
+            unsigned long long *h_regions = (unsigned long long *)ctx->h_stage;   // (sized with the uploads above: pre_mode is 0 here)
+            if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, S);
+            if (r == hipSuccess) r = hipMemcpyAsync(h_regions, d_regions, HMK_PRE_REGIONS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S);
+            if (r == hipSuccess) r = hipStreamSynchronize(S);
+            if (r != hipSuccess || h_misc[0] != 0) return false;   // a row overflowed its hash table: host pre-check
+            unsigned long long total = 0;
+            bool fits = true;
+            for (uint32_t g = 0; g < HMK_PRE_REGIONS; g++) { total += h_regions[g]; fits = fits && h_regions[g] <= region_cap; }
+            if (fits) {
+                pre_total_c = (uint32_t)total;
+                pre_mode = 2;
+                ph.cand_entries = pre_total_c;
+                ph.precheck_ms = ms_since(tp);
+                return true;
+            }
+            if (total > 0xFFFFFFFFull) return false;
+            r = hipMemsetAsync(d_over, 0, 16, S);   // more entries than a region holds: count, size, fill
+        }
+        if (r == hipSuccess) r = launch_greedy_precheck(0, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
+                                                        d_cnt, nullptr, nullptr, d_over, d_total, 0, nullptr, nullptr, 0, S);
+        if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[1], d_cstart + nl, 4, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess) r = hipStreamSynchronize(S);
+        if (r != hipSuccess || h_misc[0] != 0) return false;   // a row overflowed its hash table: host pre-check
+        pre_total_c = h_misc[1];
+        if (pre_total_c) {
+            r = ensure_buf(ctx, SB_CAND, (size_t)pre_total_c * sizeof(GreedyCand));
+            if (r == hipSuccess) r = launch_greedy_precheck(1, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
+                                                            d_cnt, d_cstart, buf<GreedyCand>(ctx, SB_CAND), d_over, d_total, 0, nullptr, nullptr, 0, S);
+            if (r != hipSuccess) return false;
+        }
+        pre_mode = 1;
+        ph.cand_entries = pre_total_c;
+        ph.precheck_ms = ms_since(tp);   // enqueue + count pass; the fill pass completes under the consumer's first wait
+        return true;
+    };
+    auto fetch_cand = [&](uint32_t nl, std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand) -> bool {
+        cand_start.assign((size_t)nl + 1, 0);
+        cand.resize(pre_total_c);
+        hipError_t r = hipMemcpyAsync(cand_start.data(), buf<uint32_t>(ctx, SB_CSTART), ((size_t)nl + 1) * 4, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess && pre_total_c)
+            r = hipMemcpyAsync(cand.data(), buf<GreedyCand>(ctx, SB_CAND), (size_t)pre_total_c * sizeof(GreedyCand), hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess) r = hipStreamSynchronize(S);
+        return r == hipSuccess;
+    };
+    const char *loop_mode = getenv("HMK_SECOND_LOOP");   // "device" / "lists" / "host": force one implementation (tests)
+    const bool force_device = loop_mode && std::strcmp(loop_mode, "device") == 0;
+    const bool forbid_device = loop_mode && !force_device;
+    const bool forbid_lists = loop_mode && std::strcmp(loop_mode, "lists") != 0;
+
+    hooks.device_loop = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<int64_t> &csize,
+                            const std::vector<int32_t> &cids, const std::vector<uint32_t> &leftover,
+                            std::vector<int32_t> &join_slot) -> bool {
+        if (forbid_device || !symmetric) return false;
+        if (!device_precheck(cluster_of, usize, leftover, true)) return false;
+        // (measured: the device-side loop beats the host loop over device-built lists at every size -- 1e5 uniform 12-mers
+        // 7.5 against 9.5 ms end to end, the antibodies example 14 against 18 ms; the lists stay as the second path)
+        const auto tl = std::chrono::steady_clock::now();
+        const uint32_t nl = (uint32_t)leftover.size();
+        const uint32_t ncl = (uint32_t)usize.size();
+        hipError_t r = ensure_buf(ctx, SB_JOINED, std::max<size_t>(ncl, 1) * 16);   // {joined, id, size} per cluster
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBSTART, ((size_t)ncl + 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBS, std::max<size_t>(pre_total_c, 1) * 8);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SUBS2, std::max<size_t>(pre_total_c, 1) * 8);   // merge scratch of the subscriber sort
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, ncl})));
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CSIZE, std::max<size_t>(ncl, 1) * 8);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CID, std::max<size_t>(ncl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_FIRST, std::max<size_t>(ncl, 1) * 12);   // first[], taken[], list cursor[] per cluster
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_STATUS, std::max<size_t>(nl, 1));
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_ACTIVE, std::max<size_t>(nl, 1) * 8);   // two eval lists
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_DIRTY, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CHOICE, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_ACCEPTED, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_JSLOT, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_LCOUNT, 64);
+        if (r == hipSuccess && ctx->has_sizes) r = ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4);
+        if (r != hipSuccess) return false;
+        // subscriber lists (count into FIRST as scratch, scan, fill, sort by leftover)
+        r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
+        if (r == hipSuccess) r = launch_loop_subscribers(false, nl, buf<uint32_t>(ctx, SB_CSTART), buf<uint32_t>(ctx, SB_CNT), buf<GreedyCand>(ctx, SB_CAND),
+                                                         buf<uint32_t>(ctx, SB_FIRST), nullptr, nullptr, S);
+        if (r == hipSuccess) r = launch_scan_u32(buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), ncl, buf<uint64_t>(ctx, SB_SCAN2), S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_FIRST), 0, (size_t)ncl * 4, S);
+        if (r == hipSuccess) r = launch_loop_subscribers(true, nl, buf<uint32_t>(ctx, SB_CSTART), buf<uint32_t>(ctx, SB_CNT), buf<GreedyCand>(ctx, SB_CAND),
+                                                         buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), S);
+        if (r == hipSuccess) r = launch_loop_sort_subscribers(ncl, buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), buf<uint64_t>(ctx, SB_SUBS2), S);
+        uint32_t *d_first = buf<uint32_t>(ctx, SB_FIRST), *d_taken = d_first + ncl, *d_clcursor = d_first + 2 * (size_t)ncl;
+        if (r == hipSuccess) r = hipMemsetAsync(d_taken, 0, (size_t)ncl * 4, S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_STATUS), 0, nl, S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JSLOT), 0xFF, (size_t)nl * 4, S);
+        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_LCOUNT), 0, 64, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CSIZE), csize.data(), (size_t)ncl * 8, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CID), cids.data(), (size_t)ncl * 4, hipMemcpyHostToDevice, S);
+        if (r == hipSuccess) r = launch_loop_init(ncl, buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID), buf<void>(ctx, SB_JOINED),
+                                                  buf<uint32_t>(ctx, SB_SUBSTART), d_clcursor, nl, buf<uint32_t>(ctx, SB_ACTIVE),
+                                                  buf<uint32_t>(ctx, SB_DIRTY), buf<uint32_t>(ctx, SB_LCOUNT), S);
+        if (r == hipSuccess && ctx->has_sizes)
+            r = hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, S);
+        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
+        uint32_t rounds = 0;
+        bool done = false;
+        // a second first/accept pass per round saves a third of the rounds; it pays once a round's apply and eval are big enough
+        int accept_passes = ncl >= 8192 ? 2 : 1;
+        if (const char *v = getenv("HMK_LOOP_PASSES")) accept_passes = std::min(8, std::max(1, atoi(v)));
+        // Every round accepts at least the earliest open leftover that has a feasible cluster, so nl + 1 rounds always suffice
+        // and a round without a join is the end.  The host keeps enqueuing rounds while it watches the progress word that
+        // k_loop_apply stores into pinned host memory (round << 32 | joins of that round), at most LOOKAHEAD rounds ahead of
+        // the device; rounds enqueued after the end find nothing to do.  Without the word: batches of rounds and a sync each.
+        auto one_round = [&]() {
+            r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
+                                  buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART), buf<uint32_t>(ctx, SB_CNT),
+                                  buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
+                                  buf<uint32_t>(ctx, SB_ACTIVE), buf<uint32_t>(ctx, SB_DIRTY), rounds, d_first, d_taken, d_clcursor,
+                                  ncl, accept_passes, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
+                                  buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), buf<void>(ctx, SB_JOINED),
+                                  ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), ctx->h_loop, S);
+            rounds++;
+        };
+        if (nl == 0 || ncl == 0) {
+            done = true;
+        } else if (ctx->h_loop && getenv("HMK_LOOP_BATCHES") == nullptr) {
+            uint32_t LOOKAHEAD = 4;   // a round is 4-6 small dependent kernels: a few rounds in the queue keep the device busy
+            if (const char *v = getenv("HMK_LOOP_LOOKAHEAD")) LOOKAHEAD = (uint32_t)std::max(1, atoi(v));
+            volatile unsigned long long *word = ctx->h_loop;
+            *word = 0;
+            const bool loop_trace = getenv("HMK_LOOP_TRACE") != nullptr;   // (with HMK_LOOP_LOOKAHEAD=1 every round is seen)
+            // never spin forever: the deadline runs from the last round the device was SEEN to finish (a long loop is fine, a
+            // stalled device is not) and is looked at on every poll (a few thousand spins apart)
+            auto t_progress = std::chrono::steady_clock::now();
+            uint32_t last_seen = 0;
+            bool stalled = false;
+            while (r == hipSuccess && !done && rounds <= nl + 8) {
+                one_round();
+                for (uint32_t spins = 0;; spins++) {
+                    const unsigned long long w = *word;
+                    const uint32_t seen = (uint32_t)(w >> 32);      // rounds the device has finished
+                    if (seen && (uint32_t)w == 0) { done = true; break; }
+                    if (rounds - seen < LOOKAHEAD) break;
+                    if (seen != last_seen) {
+                        last_seen = seen;
+                        t_progress = std::chrono::steady_clock::now();
+                        if (loop_trace) std::fprintf(stderr, "[hmk greedy] loop round %u: %u joins, %.3f ms since the loop began\n", seen, (uint32_t)w, ms_since(tl));
+                    }
+                    else if ((spins & 1023u) == 1023u && ms_since(t_progress) > 60e3) { stalled = true; break; }
+                    std::this_thread::yield();
+                }
+                if (stalled) break;
+            }
+            if (stalled) {
+                // No k_loop_* kernel may still be writing cand[] or the progress word when the host path takes over -- but a
+                // device that made no progress for a minute may never drain, and a blocking synchronise would spin forever
+                // after all: poll for ten more seconds, then give the call up (HMK_ERR_DEVICE) instead of falling back.
+                const auto t_drain = std::chrono::steady_clock::now();
+                hipError_t q = hipStreamQuery(S);
+                while (q == hipErrorNotReady && ms_since(t_drain) < 10e3) {
+                    std::this_thread::sleep_for(std::chrono::milliseconds(5));
+                    q = hipStreamQuery(S);
+                }
+                if (q == hipErrorNotReady) {
+                    ctx->wedged = true;
+                    status_inside = HMK_ERR_DEVICE;
+                    hook_err = "the device made no progress for 70 s inside the second loop: call given up (the context is unusable)";
+                }
+                r = hipErrorNotReady;
+            }
+            if (r == hipSuccess && !done) {                         // (only when nl + 8 rounds were not enough: impossible)
+                r = hipStreamSynchronize(S);
+                done = r == hipSuccess && (uint32_t)*word == 0;
+            }
+            if (r == hipSuccess) r = hipStreamSynchronize(S);       // drain the rounds enqueued past the end
+            if (loop_trace && r == hipSuccess) {   // (a build with -DHMK_APPLY_STATS=1 fills these)
+                uint32_t hc[16] = {0};
+                if (hipMemcpy(hc, buf<uint32_t>(ctx, SB_LCOUNT), 64, hipMemcpyDeviceToHost) == hipSuccess && (hc[8] | hc[10]))
+                    std::fprintf(stderr, "[hmk greedy] apply walked %u subscriber entries (longest list %u) and %u row entries (longest row %u); "
+                                         "joins took %.2f ms in all (longest %.1f us), of which table build %.2f ms, subscribers %.2f ms\n",
+                                 hc[8], hc[9], hc[10], hc[11], hc[12] * 1e-5, hc[13] * 1e-2, hc[14] * 1e-5, hc[15] * 1e-5);
+            }
+        } else {
+            for (uint32_t batch = 8; r == hipSuccess && !done && rounds <= nl + 8; batch = std::min<uint32_t>(batch * 2, 64)) {
+                for (uint32_t b = 0; b < batch && r == hipSuccess; b++) one_round();
+                if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[3], buf<uint32_t>(ctx, SB_LCOUNT) + 3, 4, hipMemcpyDeviceToHost, S);
+                if (r == hipSuccess) r = hipStreamSynchronize(S);
+                done = r == hipSuccess && h_misc[3] == 0;
+            }
+        }
+        if (r != hipSuccess || !done) return false;
+        join_slot.resize(nl);
+        if (nl) {   // through the pinned block (a copy into pageable memory is staged chunk by chunk)
+            r = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, (size_t)nl * 4 + 64, 0);
+            if (r == hipSuccess) r = hipMemcpyAsync(ctx->h_stage, buf<void>(ctx, SB_JSLOT), (size_t)nl * 4, hipMemcpyDeviceToHost, S);
+            if (r == hipSuccess) r = hipStreamSynchronize(S);
+            if (r == hipSuccess) std::memcpy(join_slot.data(), ctx->h_stage, (size_t)nl * 4);
+        }
+        if (r != hipSuccess) return false;
+        ph.device_loop_ms = ms_since(tl);
+        ph.loop_rounds = rounds;
+        lap("device second loop (rounds)");
+        return true;
+    };
+
+    hooks.precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<uint32_t> &leftover,
+                         bool want_prop, std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand,
+                         std::vector<uint32_t> &prop_start, std::vector<GreedyProp> &prop, bool *have_prop) -> bool {
+        *have_prop = false;
+        if (!device_precheck(cluster_of, usize, leftover, false)) return false;
+        const uint32_t nl = (uint32_t)leftover.size();
+        const uint32_t total_c = pre_total_c;
+        if (!fetch_cand(nl, cand_start, cand)) return false;
+        lap("device pre-check");
+        if (!want_prop || !symmetric || forbid_lists || getenv("HMK_HOST_PROPAGATION")) return true;
+        // ---- join-propagation lists -------------------------------------------------------------------------
+        const auto tq = std::chrono::steady_clock::now();
+        prop_start.assign((size_t)total_c + 1, 0);
+        prop.clear();
+        if (total_c == 0) { *have_prop = true; return true; }
+        hipError_t r = ensure_buf(ctx, SB_LIDX, (size_t)n * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_PCNT, (size_t)total_c * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_PSTART, ((size_t)total_c + 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, total_c})));
+        if (r != hipSuccess) return true;   // candidates are fine; the merge falls back to stamping rows
+        uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
+        int32_t *d_lidx = buf<int32_t>(ctx, SB_LIDX);
+        uint32_t *d_pcnt = buf<uint32_t>(ctx, SB_PCNT), *d_pstart = buf<uint32_t>(ctx, SB_PSTART);
+        const uint32_t *d_up = buf<uint32_t>(ctx, SB_CURSOR);
+        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
+        const void *d_adj = buf<void>(ctx, SB_ADJ);
+        const uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
+        r = launch_fill_lidx(d_left, nl, d_lidx, n, S);
+        if (r == hipSuccess) r = hipMemsetAsync(d_pcnt, 0, (size_t)total_c * 4, S);
+        if (r == hipSuccess) r = launch_greedy_prop(false, packed, d_start, d_up, d_adj, d_lidx, d_left, nl, d_cstart,
+                                                    buf<GreedyCand>(ctx, SB_CAND), d_pcnt, nullptr, nullptr, S);
+        if (r == hipSuccess) r = launch_scan_u32(d_pcnt, d_pstart, total_c, d_scan, S);
+        unsigned long long *h_total = ctx->h_counts + HC_TOTAL;   // the scan's 64-bit grand total (its uint32 start[] may wrap)
+        if (r == hipSuccess) r = hipMemcpyAsync(h_total, d_scan + scan_total_index(total_c), 8, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess) r = hipStreamSynchronize(S);
+        if (r != hipSuccess) return true;
+        if (*h_total > (1ull << 28)) return true;   // very dense families: let the host stamp rows instead (2 GB of lists)
+        const uint32_t total_p = (uint32_t)*h_total;
+        prop.resize(total_p);
+        r = hipMemcpyAsync(prop_start.data(), d_pstart, ((size_t)total_c + 1) * 4, hipMemcpyDeviceToHost, S);
+        if (r == hipSuccess && total_p) {
+            r = ensure_buf(ctx, SB_PROP, (size_t)total_p * sizeof(GreedyProp));
+            if (r == hipSuccess) r = hipMemsetAsync(d_pcnt, 0, (size_t)total_c * 4, S);
+            if (r == hipSuccess) r = launch_greedy_prop(true, packed, d_start, d_up, d_adj, d_lidx, d_left, nl, d_cstart,
+                                                        buf<GreedyCand>(ctx, SB_CAND), d_pcnt, d_pstart, buf<GreedyProp>(ctx, SB_PROP), S);
+            if (r == hipSuccess) r = hipMemcpyAsync(prop.data(), buf<GreedyProp>(ctx, SB_PROP), (size_t)total_p * sizeof(GreedyProp),
+                                                    hipMemcpyDeviceToHost, S);
+        }
+        if (r == hipSuccess) r = hipStreamSynchronize(S);
+        if (r != hipSuccess) { prop.clear(); return true; }
+        *have_prop = true;
+        ph.prop_ms = ms_since(tq);
+        ph.prop_entries = total_p;
+        lap("device join-propagation lists");
+        return true;
+    };
+
+    hooks.adj_base = [&]() -> const void * { return ctx->h_adj; };
+    GreedyTimes times{};
+    hooks.times = &times;
+    std::string err;
+    const int32_t *szs = ctx->has_sizes ? ctx->sizes.data() : nullptr;
+    if (src.clink) {
+        // clinkage mode: the chain needs every row; fetch the whole adjacency, then run it on the host
+        int cst = HMK_OK;
+        if (!src.format_known && !wait_full()) cst = -1;
+        if (cst == HMK_OK && n && hooks.need_rows(n - 1) < n) cst = -1;
+        if (cst == HMK_OK)
+            cst = packed ? clinkage_from_csr_packed(ctx->java_hashset, n, szs, h_start, (const NbrPacked *)ctx->h_adj, cluster_id, result_order, member_rank,
+                                                    src.clink, &err)
+                         : clinkage_from_csr(ctx->java_hashset, n, szs, h_start, (const Nbr *)ctx->h_adj, cluster_id, result_order, member_rank, src.clink,
+                                             &err);
+        (void)hipStreamSynchronize(S);
+        (void)hipStreamSynchronize(C);
+        if (status_inside == ST_RETRY_OVERFLOW) return ST_RETRY_OVERFLOW;
+        if (status_inside != HMK_OK) return fail(ctx, status_inside, hook_err);
+        if (cst) return fail(ctx, cst < 0 ? HMK_ERR_DEVICE : cst, err.empty() ? "clinkage: adjacency hand-over failed" : err);
+        src.clink->n_edges = src.total_known ? src.total_known : h_start[n] / 2;
+        return HMK_OK;
+    }
+    // the entry format is fixed before the merge starts unless it depends on the scores (then the first need_rows
+    // call settles it through wait_full(), before any row is read): dispatch on a flag the row provider may update
+    int st;
+    if (!src.format_known) {
+        if (!wait_full()) {
+            (void)hipStreamSynchronize(S);
+            (void)hipStreamSynchronize(C);
+            return status_inside == ST_RETRY_OVERFLOW ? ST_RETRY_OVERFLOW : fail(ctx, status_inside, hook_err);
+        }
+    }
+    st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)ctx->h_adj, symmetric ? h_up : nullptr, &hooks, symmetric,
+                                         max_clusters, cluster_id, result_order, member_rank, stats, &err)
+                : greedy_from_csr(n, szs, h_start, (const Nbr *)ctx->h_adj, symmetric ? h_up : nullptr, &hooks, symmetric, max_clusters,
+                                  cluster_id, result_order, member_rank, stats, &err);
+    // nothing of this call may still be running when the buffers are reused (a crash-parity exit leaves the pass in flight)
+    if (!ctx->wedged) {
+        (void)hipStreamSynchronize(S);
+        (void)hipStreamSynchronize(C);
+    }
+    if (status_inside == ST_RETRY_OVERFLOW) return ST_RETRY_OVERFLOW;
+    if (status_inside != HMK_OK) return fail(ctx, status_inside, hook_err);
+    if (st == HMK_OK || st == HMK_ERR_REFERENCE_WOULD_CRASH) {
+        // a crash-parity exit during phase 1 never looked at the final counts: an overflow must still be noticed
+        if (src.check_overflow)
+            for (int q = 0; q < HMK_EDGE_SHARDS; q++)
+                if (ctx->h_counts[q] > src.seg_cap) return ST_RETRY_OVERFLOW;
+    }
+    ph.phase1_ms = times.phase1_ms;
+    ph.sequential_ms = times.sequential_ms;
+    ph.wait_rows_ms = t_rows;
+    ph.host_precheck_ms = times.host_precheck_ms;
+    stats->n_edges = src.total_known ? src.total_known : (symmetric ? h_start[n] / 2 : h_start[n]);
+    if (st) return fail(ctx, st, err);
+    return HMK_OK;
+}
+
+} }  // namespace hmk::impl

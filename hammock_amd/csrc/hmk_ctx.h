@@ -1,0 +1,318 @@
+// hmk_ctx.h -- the context behind the C ABI and what the translation units of libhammock_hip.so's host side share:
+// hmk_api.cpp (the extern "C" entry points), hmk_common.cpp (errors, device, grow-only buffers, streams), hmk_plan.cpp (the
+// neighbour passes' planner), hmk_pass.cpp (launching the passes; the pair and block probes), hmk_cluster.cpp (CSR pipeline, row
+// hand-over, second-loop driver), hmk_multi.cpp (one process, several devices).  Not part of the public ABI.
+#ifndef HMK_CTX_H
+#define HMK_CTX_H
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <future>
+#include <memory>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <thread>
+#include <vector>
+
+#include "hmk_internal.h"
+#include "hmk_kernels.h"
+
+using namespace hmk;
+
+
+
+namespace hmk { namespace impl {
+
+struct Group {
+    int path;
+    int nw;
+    int lbk;  // column-length capacity of the kernel instantiation
+    uint32_t base, count;
+    uint32_t band;  // the first `band` tiles of the group touch a "band" row (caller index < Plan::band_rows)
+};
+
+// grow-only device scratch of the greedy tail (one hipMalloc per buffer and context, not per call)
+struct DevBuf { void *p = nullptr; size_t cap = 0; };
+enum {
+    SB_DEG, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ, SB_PART, SB_PARTSCR,   // full CSR (+ the bucketed lower sections)
+    SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
+    SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
+    SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
+    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RANK, SB_RETRY, SB_PRECNT, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
+    SB_BANDCTR,   // [0] band tiles done (band_tile_done), [1] k_wait_counter gave up
+    SB_PEER, SB_PEERCNT, SB_PEERBAND, SB_PEERDEG,                                                     // edge blocks gathered from other devices (root) / compacted for the root (peers)
+    SB_N
+};
+
+struct Plan {
+    bool valid = false;
+    int X = 0, p = 0, thr = 0;
+    uint32_t part = 0, n_parts = 1;
+    uint32_t band_rows = 0;   // tiles touching caller indices below this come first in every group (0: no band)
+    int64_t band_req = 0;     // what the caller asked for (the plan may have had to drop the band)
+    int lbmax = 12, lpad = 16;
+    bool exact = false;       // the shift-packed length-12 kernel (k_neighbors_swar; only with HMK_NO_ROWS_KERNEL)
+    bool rows_exact = false;  // one length for all and a row-packed instantiation for exactly that length
+    int hot_variant = 7;
+    uint32_t cols_per_tile = 16384;
+    uint8_t *d_res_sorted = nullptr;
+    uint32_t *d_perm = nullptr;
+    bool perm_identity = false;
+    uint8_t *d_mb = nullptr;
+    TileClass *d_classes = nullptr;
+    Tile *d_tiles = nullptr;
+    std::vector<Group> groups;
+    hmk_neighbor_stats stats{};
+    uint64_t band_pairs = 0;   // pairs inside the band tiles (of stats.pairs_scored)
+};
+
+struct PlanLocal {
+    bool valid = false;
+    uint32_t part = 0, n_parts = 1;
+    uint8_t *d_res_sorted = nullptr;
+    uint32_t *d_perm = nullptr;
+    bool perm_identity = false;
+    TileClass *d_classes = nullptr;
+    Tile *d_tiles = nullptr;
+    uint32_t n_tiles = 0;
+    uint64_t pairs = 0;
+};
+
+} }  // namespace hmk::impl
+using namespace hmk::impl;
+
+struct hmk_ctx {
+    int32_t M[HMK_ALPHABET * HMK_ALPHABET];
+    bool symmetric = true;
+    int min_m = 0, max_m = 0;
+    int device = -1;
+    bool has_device = false;
+    int java_hashset = 8;   // hmk_set_java_hashset: whose HashSet iteration order clinkage emulates
+
+    uint32_t n = 0;
+    std::vector<uint8_t> res;
+    std::vector<uint32_t> off;
+    std::vector<int32_t> sizes;
+    bool has_sizes = false;
+    std::vector<uint8_t> len;
+    int min_len = 0, max_len = 0;
+
+    uint8_t *d_res32 = nullptr;
+    uint8_t *d_len = nullptr;
+    int32_t *d_M = nullptr;
+
+    Plan plan;
+    PlanLocal plan_local;
+    uint64_t *d_edges = nullptr;  // internal buffer of the host-buffer entry points
+    uint64_t d_edges_cap = 0;
+    unsigned long long *d_counts = nullptr;
+    // side streams of the neighbour pass: the per-class launches of a mixed-length plan overlap their tails
+    static constexpr int N_SIDE = 8;     // created; HMK_SIDE_STREAMS (default 3) of them are used
+    hipStream_t side[N_SIDE] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr};
+    hipStream_t copy_stream = nullptr;   // band CSR + device-to-host copies of adjacency rows (hmk_greedy_cluster)
+    uint32_t *d_rows_scratch = nullptr;  // deg[n], cursor[n], misfit of hmk_pack_rows_dev
+    uint32_t d_rows_scratch_n = 0;
+
+    double last_kernel_ms = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // greedy tail: own stream + events, grow-only device scratch, pinned host staging (all made once per context)
+    hipStream_t gstream = nullptr;
+    hipStream_t rest_stream = nullptr;   // lowest priority: the tiles outside the band, scored beside the band tiles (hmk_greedy_cluster)
+    hipEvent_t ev_rest = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_band = nullptr, ev_edges = nullptr, ev_csr = nullptr, ev_bandcsr = nullptr;
+    DevBuf sb[SB_N];
+    void *h_start = nullptr;  // pinned: uint64 start[n + 1], then uint32 up[n]
+    size_t h_start_cap = 0;
+    void *h_stage = nullptr;  // pinned: what the merge uploads after phase 1 (cluster_of, sizes, leftovers, ...)
+    size_t h_stage_cap = 0;
+    void *h_adj = nullptr;    // pinned: adjacency rows fetched so far
+    size_t h_adj_cap = 0;
+    unsigned long long *h_loop = nullptr;    // pinned, coherent: progress word of the device-side second loop (written by k_loop_apply)
+    unsigned long long *h_counts = nullptr;  // pinned: final segment counts [HMK_EDGE_SHARDS], band snapshot [HMK_EDGE_SHARDS], misc (HC_* below)
+    hmk_greedy_phases phases{};
+
+    // hmk_create_multi: this context is the root (devices[0]); one sub-context per further device, each with its own
+    // copy of the sequences, its plan (shard d of n) and its edge buffer.  Empty for a single-device context.
+    std::vector<hmk_ctx *> peers;
+    // (in a peer's sub-context, created on the ROOT device:) the stream its blocks travel to the root on and the events the
+    // root's streams wait for
+    hipStream_t gather_stream = nullptr;
+    hipEvent_t ev_bandgather = nullptr, ev_gather = nullptr;
+
+    // hmk_reserve sizes the two buffers a clustering call needs LAST (adjacency, bucket records: 2 x 11 GB at 10^6) on its own
+    // thread: on some hosts a fresh 11 GB of device memory takes 0.3-1.5 s to get, and a call has 0.27 s of scoring to do
+    // before it writes to them.  Whoever touches SB_ADJ / SB_PART joins this first (ensure_buf does).
+    std::future<hipError_t> late_buffers;
+
+    bool wedged = false;   // a clustering call gave a stalled device up: nothing waits for it any more (calls fail with HMK_ERR_DEVICE)
+    std::string err;
+    mutable std::mutex mu;
+};
+
+namespace hmk { namespace impl {
+
+extern thread_local std::string g_last_error;
+int fail(hmk_ctx *ctx, int code, const std::string &msg);
+
+#define HIPCHK(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,          \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+// which: LAUNCH_ALL, or only the band tiles of the plan (LAUNCH_BAND: also zeroes the counts) / only the others
+// (LAUNCH_REST: appends to the counts of the band launch)
+enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2, LAUNCH_BAND_NOZERO = 3 };   // (NOZERO: the caller has zeroed the counts)
+
+constexpr int ST_RETRY_OVERFLOW = 1000;   // internal: an edge segment overflowed, grow the buffer and score again
+// layout of the small pinned block hmk_ctx::h_counts (64-bit words)
+enum { HC_COUNTS = 0, HC_BAND = HMK_EDGE_SHARDS, HC_PEER = 2 * HMK_EDGE_SHARDS, HC_RANGE = HC_PEER + 32, HC_MISC = HC_RANGE + 8, HC_TOTAL = HC_MISC + 8, HC_WORDS = HC_TOTAL + 16 };
+
+// (HMK_GREEDY_TIMING: what the grow-only buffers cost a call, i.e. the first call of a context)
+extern thread_local double g_alloc_ms;
+extern thread_local int g_allocs;
+struct AllocTimer {
+    const char *what;
+    size_t bytes;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    AllocTimer(const char *w, size_t b) : what(w), bytes(b) {}
+    ~AllocTimer() {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+        g_alloc_ms += ms;
+        g_allocs++;
+        static const bool timing = getenv("HMK_CLI_TIMING") != nullptr || getenv("HMK_GREEDY_TIMING") != nullptr;
+        if (timing && ms > 5.0) std::fprintf(stderr, "[hmk] %s of %.1f MB took %.1f ms\n", what, (double)bytes / 1048576.0, ms);
+    }
+};
+
+// Where the edges of one greedy call are, and what is already known about them.  Everything the caller enqueued
+// (scoring, snapshots) is on ctx->gstream; ev_edges has been recorded there after the last edge was written.
+struct EdgeSource {
+    EdgeSegs segs{};
+    bool symmetric = true;
+    bool check_overflow = false;       // segs are the HMK_EDGE_SHARDS segments of a neighbour pass: h_counts[0..16) receives
+    uint64_t seg_cap = 0;              // their counts (copied on gstream before ev_edges); a count above seg_cap = overflow
+    bool format_known = false;         // adjacency entry format decided without looking at the edges
+    bool packed = false;
+    int base = 0;
+    uint64_t adj_bound = 0;            // upper bound of the adjacency entries (format_known only)
+    uint64_t total_known = 0;          // exact number of edges, if known (else 0)
+    uint32_t band_rows = 0;            // rows [0, band_rows) are complete in band_segs once ev_band has passed
+    const uint32_t *band_gave_up = nullptr;   // device word: 1 = the wait for the band tiles timed out (band_segs are NOT complete)
+    EdgeSegs band_segs{};
+    bool deg_fused = false;            // the neighbour kernel placed the edges itself: SB_CURSOR holds the rows' upper | lower counters
+                                       // (zeroed before the pass), SB_RANK every edge's ranks (parallel to the buffer at edges0)
+    const uint64_t *edges0 = nullptr;
+    bool deg_split = false;            // deg_fused without ranks: SB_DEG holds upper counts [0, n) and lower counts [n, 2n) instead of totals
+    bool placed = false;               // deg_fused with ranks (else deg_fused = SB_DEG holds the rows' total degrees, counted by the pass)
+    hmk_clinkage_stats *clink = nullptr;   // non-null: run the clinkage nearest-neighbour chain instead of the greedy merge
+    // multi-device calls: the peers' blocks arrive while the calling thread is already inside cluster_on_device.
+    //   before_band  blocks until every peer's band block is on its way to the root and makes the copy stream wait for them;
+    //                non-zero: no band hand-over in this call (phase 1 then waits for the full graph)
+    //   before_full  blocks until every peer's edges are on their way, makes gstream wait for them and records ev_edges;
+    //                HMK_OK, ST_RETRY_OVERFLOW or an error code (the text is in the context)
+    std::function<int()> before_band, before_full;
+};
+
+// ---- hmk_common.cpp
+int need_device(hmk_ctx *ctx);
+int ensure_res32(hmk_ctx *ctx);
+hipError_t ensure_buf_now(hmk_ctx *ctx, int which, size_t bytes);
+bool late_buffers_pending(hmk_ctx *ctx);
+hipError_t join_late_buffers(hmk_ctx *ctx);
+hipError_t ensure_buf(hmk_ctx *ctx, int which, size_t bytes);
+template <class T> T *buf(hmk_ctx *ctx, int which) { return (T *)ctx->sb[which].p; }
+hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes, size_t keep);
+int greedy_streams(hmk_ctx *ctx);   // streams, events and pinned blocks of the clustering calls
+bool csr_by_bucket(uint32_t n, bool symmetric, bool packed, bool placed);
+int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, bool full = false, bool late_on_a_thread = false);
+uint64_t first_edge_capacity(const hmk_ctx *ctx, uint32_t n);
+int grow_edge_buffer(hmk_ctx *ctx, uint64_t cap);
+// ---- hmk_plan.cpp
+void free_plan(Plan &pl);
+void classify(const hmk_ctx *ctx, int la, int lb, int X, int p, int thr, TileClass *out, long long row_bound = -1,
+              long long *u8_row_limit = nullptr);
+int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, int64_t band_rows = -1);
+void free_plan_local(PlanLocal &pl);
+int build_plan_local(hmk_ctx *ctx, uint32_t part, uint32_t n_parts);
+// ---- hmk_pass.cpp
+int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
+                         uint64_t capacity, void *d_counts, hipStream_t stream, int which = LAUNCH_ALL,
+                         int64_t band_rows = -1, uint32_t *d_deg = nullptr, uint32_t *d_deg_lo = nullptr, uint32_t *d_rank = nullptr,
+                         uint32_t shard_base = 0, uint32_t shard_mod = HMK_EDGE_SHARDS, uint32_t band_mod = 0, uint32_t *band_counter = nullptr);
+bool local_enc(const hmk_ctx *ctx, int gap_open, int gap_extend);
+int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, uint64_t want_cap,
+                       unsigned long long counts[HMK_EDGE_SHARDS], double *kernel_ms);
+int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int thr, uint32_t part, uint32_t n_parts,
+                               uint64_t *d_edges, uint64_t capacity, unsigned long long *d_counts, hipStream_t stream);
+void timer_start(hmk_ctx *ctx);
+void timer_stop(hmk_ctx *ctx);
+int check_pairs(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, bool shifted, int X);
+int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, int a, int b,
+                int32_t *out, int32_t *out_shift = nullptr);
+int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int a, int b,
+                int32_t *out);
+// ---- hmk_cluster.cpp
+int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int32_t *cluster_id, int32_t *result_order,
+                      int32_t *member_rank, hmk_greedy_stats *stats, std::chrono::steady_clock::time_point t0);
+// ---- hmk_multi.cpp
+int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters, int32_t *cluster_id,
+                         int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats, hmk_clinkage_stats *clink = nullptr);
+
+template <typename LaunchFn>
+int neighbors_grow(hmk_ctx *ctx, uint64_t want_cap, unsigned long long counts[HMK_EDGE_SHARDS], double *kernel_ms,
+                   LaunchFn launch) {
+    int st = need_device(ctx);
+    if (st) return st;
+    if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
+    uint64_t cap = std::max<uint64_t>(want_cap, (uint64_t)1 << 20);
+    cap = (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (ctx->d_edges_cap < cap) {
+            if (ctx->d_edges) (void)hipFree(ctx->d_edges);
+            ctx->d_edges = nullptr;
+            ctx->d_edges_cap = 0;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_edges, cap * sizeof(uint64_t)));
+            ctx->d_edges_cap = cap;
+        }
+        HIPCHK(ctx, hipEventRecord(e0, nullptr));
+        st = launch(ctx->d_edges, ctx->d_edges_cap, ctx->d_counts);
+        if (st) break;
+        HIPCHK(ctx, hipEventRecord(e1, nullptr));
+        HIPCHK(ctx, hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+        if (kernel_ms) *kernel_ms = ms;
+        HIPCHK(ctx, hipMemcpy(counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long mx = 0;
+        for (int s = 0; s < HMK_EDGE_SHARDS; s++) mx = std::max(mx, counts[s]);
+        if (mx <= ctx->d_edges_cap / HMK_EDGE_SHARDS) {
+            st = HMK_OK;
+            break;
+        }
+        cap = (uint64_t)HMK_EDGE_SHARDS * (mx + mx / 8 + 1024);  // a segment overflowed: grow and rescore
+        st = HMK_ERR_CAPACITY;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (st == HMK_ERR_CAPACITY) return fail(ctx, HMK_ERR_DEVICE, "internal edge buffer kept overflowing");
+    return st;
+}
+
+
+} }  // namespace hmk::impl
+#endif

@@ -105,7 +105,7 @@ struct EdgeSeg { const uint64_t *edges; const unsigned long long *count; uint64_
 constexpr uint32_t HMK_MAX_SEGS = HMK_EDGE_SHARDS + 16;
 struct EdgeSegs { EdgeSeg s[HMK_MAX_SEGS]; uint32_t n; };
 
-// Optional device-side pre-check of the second loop (hmk_api.cpp provides it when the adjacency is still resident on
+// Optional device-side pre-check of the second loop (hmk_cluster.cpp provides it when the adjacency is still resident on
 // the GPU): given cluster_of[n] (-1 = none), the clusters' member counts and the leftover list, fill the candidate
 // CSR (cand_start[nl + 1], cand[]) and, if want_prop, the join-propagation lists (prop_start[cand.size() + 1], prop[];
 // *have_prop says whether they were produced).  Returns false if it could not (the merge then fetches the whole
@@ -115,13 +115,13 @@ using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::
                                           std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand,
                                           std::vector<uint32_t> &prop_start, std::vector<GreedyProp> &prop, bool *have_prop)>;
 
-// Hooks of the host merge for a caller that still has the adjacency on the device (hmk_api.cpp):
+// Hooks of the host merge for a caller that still has the adjacency on the device (hmk_cluster.cpp):
 //   precheck    see GreedyPrecheck (may be empty)
 //   need_rows   only a prefix of the rows may be in host memory yet: need_rows(k) returns R > k once start[0 .. R] and
 //               adj[0 .. start[R]) are valid on the host (it fetches more rows from the device if it has to).  Phase 1
 //               asks row by row; with the device pre-check and propagation lists the second loop needs no rows at all.
 //               Empty = everything is there already.
-// Optional device-side run of the whole second loop (hmk_api.cpp, k_loop_*): given the state after phase 1 --
+// Optional device-side run of the whole second loop (hmk_cluster.cpp, k_loop_*): given the state after phase 1 --
 // cluster_of[n], per cluster slot its member count, Cluster.size() and id, the leftover list -- fill join_slot[q] =
 // the slot leftover q joins or -1.  Returns false if it did not run (the merge then uses precheck / its host loop).
 using GreedyDeviceLoop = std::function<bool(const int32_t *cluster_of, const std::vector<int32_t> &usize,

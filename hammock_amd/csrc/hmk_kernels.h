@@ -1,4 +1,4 @@
-// hmk_kernels.h -- launchers of the HIP kernels (k_neighbors.hip, k_local.hip, k_edges.hip, k_pairs.hip), used by hmk_api.cpp.
+// hmk_kernels.h -- launchers of the HIP kernels (k_neighbors.hip, k_local.hip, k_edges.hip, k_pairs.hip), used by the host side (hmk_pass.cpp, hmk_cluster.cpp, hmk_multi.cpp, hmk_api.cpp).
 #ifndef HMK_KERNELS_H
 #define HMK_KERNELS_H
 

@@ -21,7 +21,7 @@
 // of one group that a column position can meet together are then >= 2248 - 192 bytes and never a multiple of 512 bytes
 // apart (rows_layout_ok below); blocks of different groups are read in different basic blocks.
 //
-// Lanes are 8 bits wide; hmk_api.cpp (classify) proves per length class -- or per row bound -- that every lane stays in
+// Lanes are 8 bits wide; hmk_plan.cpp (classify) proves per length class -- or per row bound -- that every lane stays in
 // [0, 255]: lane = g + penalty(s) - bias * cells(s) + sum of biased cells, g = 128 - threshold, so "score >= threshold" is the
 // lane's top bit.  Classes that do not fit, columns longer than the rows, and (X, D) pairs without an instantiation below run
 // the kernels of k_neighbors.hip.
@@ -108,11 +108,13 @@ constexpr bool rows_layout_ok(int nd) {
 }
 // waves per SIMD a shape is compiled for: what its LDS footprint lets a CU hold, and no more than its registers (column
 // offsets + 2 accumulators per plane + reads in flight and the rest) allow without spilling
-constexpr int rows_waves(int nd, int cap, int lds_bytes) {
+constexpr int rows_waves(int nd, int cap, int lds_bytes, bool exact) {
 #ifdef HMK_ROWS_WAVES
     return HMK_ROWS_WAVES;
 #endif
-    const int v = cap + 2 * nd + 36;
+    // (the capacity forms keep a second offset set and run-time bounds alive: at 8 waves the smallest of them spilled 40 bytes
+    // per lane inside the batch loop; 7 waves: BASELINE config 4a 4.30 -> 4.21 ms, 6 waves 4.27)
+    const int v = cap + 2 * nd + 36 + (exact ? 0 : 6);
     const int by_regs = v <= 64 ? 8 : v <= 72 ? 7 : v <= 80 ? 6 : v <= 96 ? 5 : 4;
     const int by_lds = 163840 / ((lds_bytes + 511) / 512 * 512);
     return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
@@ -612,7 +614,7 @@ __device__ __forceinline__ void rows_for_each_group(std::integer_sequence<int, I
 
 // MODE: what a flush does beside storing the edge (hmk_device.h)
 template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
-__global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, EXACT_LB, G)))
+__global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, EXACT_LB, G), EXACT_LB))
 k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     using S = RowsShape<X, D, CAP, EXACT_LB, G>;
     constexpr int ND = S::ND, NI = S::NI, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
