@@ -68,10 +68,23 @@ constexpr int rows_stage(bool exact) { return exact ? HMK_ROWS_STAGE_EXACT : HMK
 #ifndef HMK_ROWS_FAT
 #define HMK_ROWS_FAT 0
 #endif
+// Scores worked out IN the batch loop (HMK_ROWS_INLOOP=1, one-length shapes): a hit's lane cuts its row's byte out of every plane
+// right where the planes are in registers -- one v_perm_b32 per plane with a per-lane selector, v_max3 over the planes -- and
+// stages (column, row, score - threshold); the flush then only decodes and stores: no gather, no table reads.  No history word
+// (the planes of earlier steps are gone): the wave looks for hits at every step.
+#ifndef HMK_ROWS_INLOOP
+#define HMK_ROWS_INLOOP 0
+#endif
+#ifndef HMK_ROWS_INLOOP_MAXCELLS   // shapes with at most this many cells per pair keep the rescoring flush (short steps are VALU-bound already)
+#define HMK_ROWS_INLOOP_MAXCELLS 0
+#endif
+constexpr bool rows_inloop(int x, int cap, bool exact) {
+    return HMK_ROWS_INLOOP != 0 && exact && cap * (2 * x + 1) - x * (x + 1) > HMK_ROWS_INLOOP_MAXCELLS;
+}
 #ifndef HMK_ROWS_STAGE_FAT   // fat records a wave stages (16 bytes each)
 #define HMK_ROWS_STAGE_FAT 256
 #endif
-constexpr bool rows_fat(int cap, bool exact) { return HMK_ROWS_FAT != 0 && HMK_ROWS_DEFER != 0 && exact && cap <= 12; }
+constexpr bool rows_fat(int cap, bool exact) { return HMK_ROWS_FAT != 0 && HMK_ROWS_INLOOP == 0 && HMK_ROWS_DEFER != 0 && exact && cap <= 12; }
 constexpr int rows_stage_bytes(int cap, bool exact) { return rows_fat(cap, exact) ? HMK_ROWS_STAGE_FAT * 16 : rows_stage(exact) * 4; }   // per wave
 #ifndef HMK_ROWS_DBG   // measurement builds only (tools/ab_rows4.sh; wrong results): the flush 1 = does not rescore, 2 = drops its records, 3 = fetches one column for all lanes, 4 = stores nothing, 5 = no placing atomics, 6 = no rank store
 #define HMK_ROWS_DBG 0
@@ -408,6 +421,51 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
     uint32_t rx = 0, rm = 0;   // the placing atomics' return values
     // decode the records of iteration k0 into nx.rt / nx.mcol and return the addresses the statement loads from
     constexpr bool FAT = rows_fat(CAP, EXACT_LB);   // records carry their column's words: nothing to fetch (see HMK_ROWS_FAT)
+    if constexpr (rows_inloop(X, CAP, EXACT_LB)) {
+        // records carry their score (HMK_ROWS_INLOOP): column - first column | row in tile << 16 | (score - threshold) << 24
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&A.counts[A.shard], (unsigned long long)cnt);
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        base = ((unsigned long long)bhi << 32) | blo;
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const bool live = k < cnt;
+            const uint32_t rec = live ? stage[k] : 0u;
+            uint32_t x = A.row0 + ((rec >> 16) & 0x3Fu), m = A.col0 + (rec & 0xFFFFu);
+            if (!A.perm_identity && live) { x = A.perm[x]; m = A.perm[m]; }
+            if (A.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
+            const int score = A.threshold + (int)(rec >> 24);
+            const unsigned long long pos = base + k;
+            const bool ok = live && pos < A.cap_per_shard;
+            const unsigned long long slot = (unsigned long long)A.shard * A.cap_per_shard + pos;
+            if (MODE == EDGES_COUNT) {
+                if (A.perm_identity && HMK_ROWS_COUNT_GROUPED) {
+                    const WaveGroup g = wave_groups(x, ok);
+                    if (ok && g.rank == 0) atomicAdd(&A.deg[x], g.size);
+                } else if (ok) {
+                    atomicAdd(&A.deg[x], 1u);
+                }
+                if (ok && A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
+            }
+            uint32_t rx = 0, rm = 0;
+            if (MODE == EDGES_PLACE) {
+                const uint32_t *ux = A.deg_up + x, *um = A.symmetric ? A.deg_lo + m : A.deg_up + x;
+                const uint32_t one = ok ? 1u : 0u, one2 = A.symmetric ? one : 0u;
+                uint32_t r0 = 0, r1 = 0;
+                asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\ts_waitcnt vmcnt(0)"
+                             : [r0] "=&v"(r0), [r1] "=&v"(r1) : [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2) : "memory");
+                rx = r0; rm = A.symmetric ? r1 : 0u;
+            }
+            if (ok) {
+                A.edges[slot] = ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
+                if (MODE == EDGES_PLACE) reinterpret_cast<uint2 *>(A.rank)[slot] = make_uint2(rx, rm);
+            }
+        }
+        asm volatile("" ::: "memory");
+        drain_end();
+        return;
+    }
     auto decode = [&](uint32_t k0) {
         const bool live = k0 + lane < cnt;
         u32x4 fat = {0, 0, 0, 0};
@@ -702,7 +760,8 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     const uint32_t lpad_s = P.lpad;
 #endif
 
-    constexpr bool DEFER = HMK_ROWS_DEFER != 0 && EXACT_LB;   // (mixed lengths: short column runs, two groups -- 1.3 % slower with it)
+    constexpr bool INLOOP = rows_inloop(X, CAP, EXACT_LB);
+    constexpr bool DEFER = HMK_ROWS_DEFER != 0 && EXACT_LB && !INLOOP;   // (mixed lengths: short column runs, two groups -- 1.3 % slower with it)
     // Hits are rare per pair (0.26 % at the default threshold) but not per step: a wave tests 512 pairs at a time and finds
     // one in three steps out of four.  So the test's result is only NOTED at every step -- the top bits of the eight rows'
     // bytes, merged into one word per lane and shifted into a 4-step history (hm uses every 4th bit: step j of a quad lands on
@@ -814,7 +873,17 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
                         // record: here a turn runs for the few lanes that still have a hit, and every instruction of it costs the
                         // wave a VALU slot (17 per turn with the decoding, 8 without)
                         const uint32_t q = (uint32_t)__builtin_ctz(hm);
-                        if constexpr (FAT) {
+                        if constexpr (INLOOP) {
+                            // the hit's row r (bit 8r + 7: row r; bit 8r + 3: row 4 + r) is byte r of every plane's register pair:
+                            // one v_perm_b32 per plane (selector byte 0 = r: 0-3 pick from the low dword, 4-7 from the high one;
+                            // the other selector bytes give zero), the largest of them is the pair's lane = 128 - threshold + score
+                            const uint32_t r = (q >> 3) + 4u - (q & 4u);
+                            const uint32_t sel = 0x0c0c0c00u | r;
+                            uint32_t mx = __builtin_amdgcn_perm(W1[0], W0[0], sel);
+#pragma unroll
+                            for (int u = 1; u < ND; u++) mx = max(mx, __builtin_amdgcn_perm(W1[u], W0[u], sel));
+                            stage[cnt + mbcnt64(mask)] = colrel | ((uint32_t)(8 * g) + r) << 16 | (mx - 128u) << 24;
+                        } else if constexpr (FAT) {
                             // the hit was noted `back` steps ago: ITS column and ITS words (this step's place in the quad is Q, so
                             // the history holds steps Q, Q - 1, ... 0 only: the wave looked last at the end of the quad before)
                             const uint32_t back = 3u - (q & 3u);
