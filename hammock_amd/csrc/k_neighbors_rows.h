@@ -68,18 +68,26 @@ constexpr int rows_stage(bool exact) { return exact ? HMK_ROWS_STAGE_EXACT : HMK
 #ifndef HMK_ROWS_FAT
 #define HMK_ROWS_FAT 0
 #endif
-// Scores worked out IN the batch loop (HMK_ROWS_INLOOP=1, one-length shapes): a hit's lane cuts its row's byte out of every plane
-// right where the planes are in registers -- one v_perm_b32 per plane with a per-lane selector, v_max3 over the planes -- and
-// stages (column, row, score - threshold); the flush then only decodes and stores: no gather, no table reads.  No history word
-// (the planes of earlier steps are gone): the wave looks for hits at every step.
+// Scores worked out IN the batch loop (round 4's last step; HMK_ROWS_INLOOP=0: the rescoring flush): a hit's lane cuts its row's
+// byte out of every plane right where the planes are in registers -- one v_perm_b32 per plane with a per-lane selector, v_max over
+// the planes, 10 instructions at 7 planes -- and stages (column, row, score - threshold); the flush then only decodes and stores:
+// no gather of the hits' columns (the one round trip a flush iteration could not hide), no table reads.  No
+// history word (the planes of earlier steps are gone): the wave looks for hits at every step.  Round 3 had moved the extraction
+// OUT of the loop because the kernel was VALU-bound (99 % busy, 20.7 instructions per 64 pairs); at 15.8 there is room again.
+// 10^5 12-mers: threshold 20 2.56 -> 2.52 ms, threshold 14 3.07 -> 2.69, no hits 2.40 = 2.40.  Short one-length shapes are
+// VALU-bound by themselves (7-mers: VALU 104 % busy) and lose a little (7-mers 1.54 -> 1.57 ms, 9-mers 1.71 -> 1.76): shapes of
+// at most HMK_ROWS_INLOOP_MAXCELLS cells per pair keep the rescoring flush and the history word.
 #ifndef HMK_ROWS_INLOOP
-#define HMK_ROWS_INLOOP 0
+#define HMK_ROWS_INLOOP 1
 #endif
-#ifndef HMK_ROWS_INLOOP_MAXCELLS   // shapes with at most this many cells per pair keep the rescoring flush (short steps are VALU-bound already)
-#define HMK_ROWS_INLOOP_MAXCELLS 0
+#ifndef HMK_ROWS_INLOOP_MAXCELLS
+#define HMK_ROWS_INLOOP_MAXCELLS 45
+#endif
+#ifndef HMK_ROWS_INLOOP_CAPFORMS   // 1: the capacity forms (mixed lengths) too
+#define HMK_ROWS_INLOOP_CAPFORMS 1
 #endif
 constexpr bool rows_inloop(int x, int cap, bool exact) {
-    return HMK_ROWS_INLOOP != 0 && exact && cap * (2 * x + 1) - x * (x + 1) > HMK_ROWS_INLOOP_MAXCELLS;
+    return HMK_ROWS_INLOOP != 0 && (exact || HMK_ROWS_INLOOP_CAPFORMS != 0) && cap * (2 * x + 1) - x * (x + 1) > HMK_ROWS_INLOOP_MAXCELLS;
 }
 #ifndef HMK_ROWS_STAGE_FAT   // fat records a wave stages (16 bytes each)
 #define HMK_ROWS_STAGE_FAT 256
