@@ -54,7 +54,12 @@ namespace hmk {
 #ifndef HMK_ROWS_STAGE_EXACT
 #define HMK_ROWS_STAGE_EXACT 640
 #endif
-constexpr int rows_stage(bool exact) { return exact ? HMK_ROWS_STAGE_EXACT : HMK_ROWS_STAGE; }
+#ifndef HMK_ROWS_STAGE_SHORT   // one-length shapes that keep the rescoring flush (<= 45 cells per pair: 6- to 9-mers): a drain's fixed cost
+#define HMK_ROWS_STAGE_SHORT 1024   // (scalar loads, cursor, first gather) over more records -- 9-mers 1.74 -> 1.69 ms, 7-mers 1.61 -> 1.53
+#endif
+constexpr int rows_stage(int x, int cap, bool exact) {
+    return !exact ? HMK_ROWS_STAGE : cap * (2 * x + 1) - x * (x + 1) <= 45 ? HMK_ROWS_STAGE_SHORT : HMK_ROWS_STAGE_EXACT;
+}
 // "Fat" records (HMK_ROWS_FAT=1; one-length shapes of at most 12 residues; measured, rejected, kept as a switch): a hit is
 // staged WITH its column's residue words (16 bytes: the record + three words), so the flush needs nothing from global memory --
 // its gather of 64 columns from 30-60 cache lines is the one round trip a flush iteration cannot hide (0.27 of the 0.6 ms
@@ -93,7 +98,7 @@ constexpr bool rows_inloop(int x, int cap, bool exact) {
 #define HMK_ROWS_STAGE_FAT 256
 #endif
 constexpr bool rows_fat(int cap, bool exact) { return HMK_ROWS_FAT != 0 && HMK_ROWS_INLOOP == 0 && HMK_ROWS_DEFER != 0 && exact && cap <= 12; }
-constexpr int rows_stage_bytes(int cap, bool exact) { return rows_fat(cap, exact) ? HMK_ROWS_STAGE_FAT * 16 : rows_stage(exact) * 4; }   // per wave
+constexpr int rows_stage_bytes(int x, int cap, bool exact) { return rows_fat(cap, exact) ? HMK_ROWS_STAGE_FAT * 16 : rows_stage(x, cap, exact) * 4; }   // per wave
 #ifndef HMK_ROWS_DBG   // measurement builds only (tools/ab_rows4.sh; wrong results): the flush 1 = does not rescore, 2 = drops its records, 3 = fetches one column for all lanes, 4 = stores nothing, 5 = no placing atomics, 6 = no rank store
 #define HMK_ROWS_DBG 0
 #endif
@@ -145,7 +150,7 @@ constexpr int rows_tab_bytes(int x, int d, int cap, bool exact, int g) {
     return HMK_ROWS_COMPACT ? g * (cap + d + (exact ? 0 : nd - 1)) * 192 : nd * rows_slot_bytes();
 }
 constexpr int rows_lds_bytes(int x, int d, int cap, bool exact, int g) {   // must match the kernel's LDS map
-    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * rows_stage_bytes(cap, exact);
+    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * rows_stage_bytes(x, cap, exact);
 }
 
 template <int N, class F, int... Is>
@@ -579,7 +584,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         if (MODE == EDGES_COUNT) {
             // fire-and-forget: nothing of these is waited for.  With the sorted order = the caller's (one length bucket) the 64
             // records' smaller ends are the tile's 8 or 16 rows: one atomic per distinct row with the group's size instead of
-            // one per record (atomics on 12.8 M edges' two ends cost the 10^5 pass 0.5 ms: they are served at ~50 G/s).
+            // one per record (10^5 clustering call: scoring 3.43 -> 3.27 ms).
             if (A.perm_identity && HMK_ROWS_COUNT_GROUPED) {
                 const WaveGroup g = wave_groups(x, ok);
                 if (ok && g.rank == 0) atomicAdd(&A.deg[x], g.size);
@@ -686,7 +691,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     constexpr int ND = S::ND, NI = S::NI, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
     constexpr int R = 8 * G;
     constexpr bool FAT = rows_fat(CAP, EXACT_LB);
-    constexpr int STAGE_CAP = FAT ? HMK_ROWS_STAGE_FAT : rows_stage(EXACT_LB);  // records per wave; flushed when fewer than 64 slots are free
+    constexpr int STAGE_CAP = FAT ? HMK_ROWS_STAGE_FAT : rows_stage(X, CAP, EXACT_LB);  // records per wave; flushed when fewer than 64 slots are free
     constexpr int STAGE_DW = FAT ? 4 : 1;                                       // dwords per record
     constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * STAGE_DW * 4;
     static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, EXACT_LB, G), "rows_lds_bytes must match the LDS map");
@@ -982,7 +987,7 @@ static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uin
 // runs: D = 0).  `part` is the translation unit that holds the shape (k_rows_part.hip is compiled once per part, each a code
 // object of its own: a pass loads only the parts it launches from).
 #ifdef HMK_ROWS_MINIMAL   // tuning builds (tools/ab_rows.sh): the shapes the probes time only, seconds to compile
-#define HMK_ROWS_EXACT_LIST(F) F(0, 3, 12) F(3, 2, 7) F(3, 2, 9) F(4, 4, 15) F(6, 5, 20)
+#define HMK_ROWS_EXACT_LIST(F) F(0, 3, 10) F(0, 3, 12) F(3, 2, 7) F(3, 2, 8) F(3, 2, 9) F(4, 4, 15) F(6, 5, 20)
 #define HMK_ROWS_CAP_LIST(C) C(1, 3, 0, 12)
 #else
 #define HMK_ROWS_EXACT_LIST(F) \
