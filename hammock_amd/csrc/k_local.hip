@@ -305,8 +305,20 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ s16x2 pk(uint32_t u) { return __builtin_bit_cast(s16x2, u); }
 __device__ __forceinline__ uint32_t un(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
 
-template <int LBMAX>
-__device__ __forceinline__ uint32_t sw_row_pk(uint32_t row_q_addr, int strips, int ncols, const uint32_t (&boff_lo)[LBMAX],
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+template <int N> struct LocalIndex { static constexpr int value = N; };
+__device__ __forceinline__ u16x2 pku(uint32_t u) { return __builtin_bit_cast(u16x2, u); }
+__device__ __forceinline__ uint32_t unu(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// SAT = true (gap_open <= -1: every table entry below is a magnitude >= 0 and fits one byte): the up / left candidates are
+// he - magnitude with UNSIGNED SATURATION (v_pk_sub_u16 clamp).  A candidate below zero becomes 0 = "value 0, NOWHERE", which is
+// what the clamp of :63-67 makes of it when it wins -- so max(up, left) >= 0 always, the cell is max(diagonal, that) with no third
+// maximum against zero, the byte selector is ONE v_and_or_b32 (the table's high bytes are the constant 0, selector 0x0c) instead of
+// v_and + v_mad, and the columns leave the unrolled loop with a break, so no value has to be copied to keep two paths in the same
+// registers: 11 VALU instructions per pair of cells instead of 14.25.  SAT = false is the form of rounds 1-3
+// (signed candidates, two-table lookup), kept for gap_open == 0.
+template <int LBMAX, bool SAT>
+__device__ __forceinline__ uint32_t sw_row_pk(uint32_t row_q_addr, int strips, int nlines, int ncols, const uint32_t (&boff_lo)[LBMAX],
                                               const uint32_t (&boff_hi)[LBMAX], int gap_open, int gap_extend) {
     // 16-bit table entries by tag (0 NOWHERE, 1 LEFT, 2 UP, 3 DIAGONAL), split into low / high bytes
     const int pu[4] = {4 * gap_open + 2, 4 * gap_open + 1, 4 * gap_extend, 4 * gap_open - 1};
@@ -314,61 +326,101 @@ __device__ __forceinline__ uint32_t sw_row_pk(uint32_t row_q_addr, int strips, i
     uint32_t PUlo = 0, PUhi = 0, PLlo = 0, PLhi = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        PUlo |= ((uint32_t)pu[t] & 0xFFu) << (8 * t); PUhi |= (((uint32_t)pu[t] >> 8) & 0xFFu) << (8 * t);
-        PLlo |= ((uint32_t)pl[t] & 0xFFu) << (8 * t); PLhi |= (((uint32_t)pl[t] >> 8) & 0xFFu) << (8 * t);
+        const uint32_t u = (uint32_t)(SAT ? -pu[t] : pu[t]), l = (uint32_t)(SAT ? -pl[t] : pl[t]);
+        PUlo |= (u & 0xFFu) << (8 * t); PUhi |= ((u >> 8) & 0xFFu) << (8 * t);
+        PLlo |= (l & 0xFFu) << (8 * t); PLhi |= ((l >> 8) & 0xFFu) << (8 * t);
     }
     // v_perm_b32 reads at most one SGPR: pin one table of each pair in a VGPR once instead of a
     // v_mov per use
-    asm volatile("" : "+v"(PUlo));
-    asm volatile("" : "+v"(PLlo));
+    if (!SAT) {
+        asm volatile("" : "+v"(PUlo));
+        asm volatile("" : "+v"(PLlo));
+    }
     const uint32_t both = 0x00010001u;
     const s16x2 zero = pk(0u);
+    const uint32_t u_first = SAT ? 0u : (uint32_t)((4 * gap_open + 2) & 0xFFFF) * both;   // the candidates of line 0 / column 0: below zero
+    const uint32_t l_first = SAT ? 0u : (uint32_t)((4 * gap_open + 1) & 0xFFFF) * both;
     uint32_t H[LBMAX], U[LBMAX];
 #pragma unroll
-    for (int j = 0; j < LBMAX; j++) { H[j] = 3u * both; U[j] = (uint32_t)((4 * gap_open + 2) & 0xFFFF) * both; }
+    for (int j = 0; j < LBMAX; j++) { H[j] = 3u * both; U[j] = u_first; }
     s16x2 gm = zero;
-    for (int st = 0; st < strips; st++) {
-        const uint32_t strip_addr = row_q_addr + (uint32_t)st * 8u;
+    // (v_and_or_b32 is a VOP3: no literals, one scalar operand -- the mask in an SGPR, the constant in a VGPR)
+    uint32_t tag_mask = 0x00030003u, sel_high = 0x0c000c00u;
+    if (SAT) {
+        asm volatile("" : "+s"(tag_mask));
+        asm volatile("" : "+v"(sel_high));
+    }
+    // one strip of KL lines (4, or what is left of the row sequence in its last strip: the lines beyond it are padding that can
+    // never hold the maximum -- computing them anyway was 12 % of the cells at lengths 7..20)
+    auto strip = [&](auto KLc, int st) __attribute__((always_inline)) -> void {
+        constexpr int KL = decltype(KLc)::value;
+        uint32_t strip_addr = row_q_addr + (uint32_t)st * 8u;
+        if (SAT) asm volatile("" : "+s"(strip_addr));   // (or the 2 x LBMAX profile addresses of the last strip are computed above the choice of its form and held in VGPRs)
         uint32_t hd[4], lc[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) { hd[k] = 3u * both; lc[k] = (uint32_t)((4 * gap_open + 1) & 0xFFFF) * both; }
+        for (int k = 0; k < 4; k++) { hd[k] = 3u * both; lc[k] = l_first; }
+        // one column; SAT: the next one is reached from inside it, so "no more columns" LEAVES the chain (an exit per column,
+        // no join between columns: hd / lc / habove rotate by renaming, not by v_mov)
+        auto column = [&](auto self, auto J) __attribute__((always_inline)) -> void {
+            constexpr int j = decltype(J)::value;
+            if constexpr (j < LBMAX) {
+                if (SAT) { if (j >= ncols) return; }
+                if (SAT || j < ncols) {
+                    const u32x2 qa = lds_read<u32x2>(strip_addr + boff_lo[j]);   // lines 0,1 | 2,3 of sequence "lo"
+                    const u32x2 qb = lds_read<u32x2>(strip_addr + boff_hi[j]);   // ... of sequence "hi"
+                    uint32_t sc[4];
+                    sc[0] = __builtin_amdgcn_perm(qb.x, qa.x, 0x05040100u);
+                    sc[1] = __builtin_amdgcn_perm(qb.x, qa.x, 0x07060302u);
+                    sc[2] = __builtin_amdgcn_perm(qb.y, qa.y, 0x05040100u);
+                    sc[3] = __builtin_amdgcn_perm(qb.y, qa.y, 0x07060302u);
+                    uint32_t up = U[j];
+                    uint32_t habove = H[j];
 #pragma unroll
-        for (int j = 0; j < LBMAX; j++) {
-            if (j < ncols) {
-                const u32x2 qa = lds_read<u32x2>(strip_addr + boff_lo[j]);   // lines 0,1 | 2,3 of sequence "lo"
-                const u32x2 qb = lds_read<u32x2>(strip_addr + boff_hi[j]);   // ... of sequence "hi"
-                uint32_t sc[4];
-                sc[0] = __builtin_amdgcn_perm(qb.x, qa.x, 0x05040100u);
-                sc[1] = __builtin_amdgcn_perm(qb.x, qa.x, 0x07060302u);
-                sc[2] = __builtin_amdgcn_perm(qb.y, qa.y, 0x05040100u);
-                sc[3] = __builtin_amdgcn_perm(qb.y, qa.y, 0x07060302u);
-                uint32_t up = U[j];
-                uint32_t habove = H[j];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const s16x2 diag = pk(hd[k]) + pk(sc[k]);                                        // :59
-                    const s16x2 m1 = __builtin_elementwise_max(pk(up), pk(lc[k]));
-                    const s16x2 he = __builtin_elementwise_max(__builtin_elementwise_max(diag, m1), zero);  // :61-67
-                    gm = __builtin_elementwise_max(gm, he);                                          // :68-72
-                    const uint32_t heu = un(he);
-                    const uint32_t sel = (heu & 0x00030003u) * 0x0101u + 0x04000400u;
-                    const uint32_t padd_u = __builtin_amdgcn_perm(PUhi, PUlo, sel);
-                    const uint32_t padd_l = __builtin_amdgcn_perm(PLhi, PLlo, sel);
-                    hd[k] = habove;
-                    habove = heu | 0x00030003u;
-                    up = un(he + pk(padd_u));                                                         // :43-48,:57
-                    lc[k] = un(he + pk(padd_l));                                                      // :50-55,:58
+                    for (int k = 0; k < KL; k++) {
+                        const s16x2 diag = pk(hd[k]) + pk(sc[k]);                                        // :59
+                        const s16x2 m1 = __builtin_elementwise_max(pk(up), pk(lc[k]));
+                        s16x2 he = __builtin_elementwise_max(diag, m1);                                  // :61
+                        if (!SAT) he = __builtin_elementwise_max(he, zero);                              // :63-67 (SAT: m1 >= 0 already)
+                        gm = __builtin_elementwise_max(gm, he);                                          // :68-72
+                        const uint32_t heu = un(he);
+                        hd[k] = habove;
+                        habove = heu | 0x00030003u;
+                        if (SAT) {
+                            const uint32_t sel = (heu & tag_mask) | sel_high;                            // byte 2h = tag_h, byte 2h + 1 = the constant 0
+                            up = unu(__builtin_elementwise_sub_sat(pku(heu), pku(__builtin_amdgcn_perm(0u, PUlo, sel))));      // :43-48,:57
+                            lc[k] = unu(__builtin_elementwise_sub_sat(pku(heu), pku(__builtin_amdgcn_perm(0u, PLlo, sel))));   // :50-55,:58
+                        } else {
+                            const uint32_t sel = (heu & 0x00030003u) * 0x0101u + 0x04000400u;
+                            up = un(he + pk(__builtin_amdgcn_perm(PUhi, PUlo, sel)));
+                            lc[k] = un(he + pk(__builtin_amdgcn_perm(PLhi, PLlo, sel)));
+                        }
+                    }
+                    H[j] = habove;
+                    U[j] = up;
                 }
-                H[j] = habove;
-                U[j] = up;
+                self(self, LocalIndex<j + 1>{});
             }
-        }
+        };
+        column(column, LocalIndex<0>{});
+    };
+#ifndef HMK_LOCAL_PARTIAL_STRIP
+#define HMK_LOCAL_PARTIAL_STRIP 1
+#endif
+    if (SAT && HMK_LOCAL_PARTIAL_STRIP) {
+        const int last = strips - 1, kl = nlines - 4 * last;
+        for (int st = 0; st < last; st++) strip(LocalIndex<4>{}, st);
+        if (kl >= 4) strip(LocalIndex<4>{}, last);
+        else if (kl == 3) strip(LocalIndex<3>{}, last);
+        else if (kl == 2) strip(LocalIndex<2>{}, last);
+        else strip(LocalIndex<1>{}, last);
+    } else {
+        for (int st = 0; st < strips; st++) strip(LocalIndex<4>{}, st);
     }
     const uint32_t g = un(gm);
     return ((g & 0xFFFFu) >> 2) | (((g >> 16) >> 2) << 16);   // both maxima are >= 0
 }
 
-template <int LBMAX>
+template <int LBMAX, bool SAT>
 __global__ void __launch_bounds__(256)
 k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int32_t *__restrict__ Mg, int gap_open,
                      int gap_extend, int threshold) {
@@ -438,7 +490,7 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
             }
         }
         for (uint32_t r = 0; r < T.nrows; r++) {
-            const uint32_t g2 = sw_row_pk<LBMAX>(q_addr + r * QROW, strips, lb, boff[0], boff[1], gap_open, gap_extend);
+            const uint32_t g2 = sw_row_pk<LBMAX, SAT>(q_addr + r * QROW, strips, la, lb, boff[0], boff[1], gap_open, gap_extend);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int gmax = (int)((g2 >> (16 * h)) & 0xFFFFu);
@@ -548,13 +600,16 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
     if (n_tiles == 0) return hipSuccess;
 #define HMK_NL(LB, E) hipLaunchKernelGGL((k_neighbors_local<LB, E>), dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, \
                                          gap_open, gap_extend, threshold)
-#define HMK_NLP(LB) hipLaunchKernelGGL((k_neighbors_local_pk<LB>), dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, \
-                                       gap_open, gap_extend, threshold)
+#define HMK_NLP1(LB, SAT) hipLaunchKernelGGL((k_neighbors_local_pk<LB, SAT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, \
+                                             gap_open, gap_extend, threshold)
+#define HMK_NLP(LB) do { if (sat) HMK_NLP1(LB, true); else HMK_NLP1(LB, false); } while (0)
+    const bool sat = gap_open <= -1 && getenv("HMK_LOCAL_SIGNED") == nullptr;   // (enc already says -31 <= penalties <= 0)
     const bool packed = enc && getenv("HMK_LOCAL_NO_PK") == nullptr;   // two column sequences per lane
     if (lbmax <= 12) { if (packed) HMK_NLP(12); else if (enc) HMK_NL(12, true); else HMK_NL(12, false); }
     else if (lbmax <= 20) { if (packed) HMK_NLP(20); else if (enc) HMK_NL(20, true); else HMK_NL(20, false); }
     else { if (packed) HMK_NLP(32); else if (enc) HMK_NL(32, true); else HMK_NL(32, false); }
 #undef HMK_NLP
+#undef HMK_NLP1
 #undef HMK_NL
     return hipGetLastError();
 }

@@ -1279,7 +1279,8 @@ def test_cpp_host_classes_known_answers(gpu, known_answers, blosum62, coracle, t
 
 
 @pytest.mark.parametrize("cfg", [("blosum62", 7, 20, -5, -1, 22), ("blosum62", 12, 12, -5, -1, 25),
-                                 ("pam250", 5, 32, -3, -3, 30), ("blosum62", 9, 11, 0, 0, 26)])
+                                 ("pam250", 5, 32, -3, -3, 30), ("blosum62", 9, 11, 0, 0, 26),
+                                 ("blosum62", 7, 20, -1, 0, 30), ("pam250", 5, 32, -31, -31, 28), ("blosum62", 13, 19, -31, 0, 24)])
 def test_neighbors_local_vs_oracle(gpu, matrices, coracle, cfg):
     """LocalAlignmentScorer over ALL ordered pairs, thresholded: exact edge set (both orders, since
     score(a, b) != score(b, a) in general) against the oracle."""
@@ -1311,6 +1312,27 @@ def test_neighbors_local_vs_oracle(gpu, matrices, coracle, cfg):
         want2 = np.sort(hammock_amd.pack_edges(xx[keep], mm[keep], sc[keep]))
         got2, _ = sctx.neighbors_local(go2, ge2, thr2)
         assert np.array_equal(np.sort(got2), want2), (cfg, go2, ge2)
+
+
+def test_neighbors_local_signed_form_still_exact(gpu, matrices, coracle, monkeypatch):
+    """HMK_LOCAL_SIGNED=1 runs the packed DP of rounds 1-3 (signed candidates, a maximum against zero per cell, full last strip)
+    instead of the saturating form: what gap_open == 0 still takes.  Same edges."""
+    M = matrices["blosum62"]
+    res, off = synth_peptides(11, 900, 7, 20)
+    ctx, _, _ = ctx_for(M, res=res, off=off)
+    idx = np.arange(900, dtype=np.uint32)
+    for go, ge, thr in ((-5, -1, 22), (-1, 0, 30)):
+        st, sc = coracle.score_block(M, res, off, idx, idx, 1, go, ge)
+        mm, xx = np.meshgrid(idx, idx, indexing="ij")
+        keep = (sc >= thr) & (mm != xx)
+        want = np.sort(hammock_amd.pack_edges(xx[keep], mm[keep], sc[keep]))
+        monkeypatch.delenv("HMK_LOCAL_SIGNED", raising=False)
+        new, _ = ctx.neighbors_local(go, ge, thr)
+        monkeypatch.setenv("HMK_LOCAL_SIGNED", "1")
+        old, _ = ctx.neighbors_local(go, ge, thr)
+        monkeypatch.delenv("HMK_LOCAL_SIGNED")
+        assert np.array_equal(np.sort(new), want), (go, ge)
+        assert np.array_equal(np.sort(old), want), (go, ge)
 
 
 def test_neighbors_local_wide_matrix_literal_tier(gpu, coracle):
