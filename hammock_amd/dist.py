@@ -298,13 +298,13 @@ class PipelinedExchange:
         if self.fmt == "edges":
             tot = msgs[:, 0].tolist()
             if max(tot) > self.pad:
-                raise BufferError("exchange block overflow")
+                raise BufferError(f"exchange block overflow: {tot} edges per rank, blocks of {self.pad}")
             return torch.cat([msgs[r, 1:1 + int(tot[r])] for r in range(self.world)])
         n = self.ctx.n
         heads = msgs[:, :self.head_len]
         tail = heads[:, n:].tolist()   # per rank: [edges, misfits]
         if max(t[0] for t in tail) > self.pad:
-            raise BufferError("exchange block overflow")
+            raise BufferError(f"exchange block overflow: [edges, misfits] per rank {tail}, blocks of {self.pad}")
         if any(t[1] for t in tail):
             raise OverflowError("a score - threshold does not fit 8 bits: use fmt='edges' for these parameters")
         out = torch.empty(sum(t[0] for t in tail), dtype=torch.int64, device=self.device)

@@ -231,6 +231,15 @@ def test_row_blocks_round_trip_directed_edges_and_misfit():
 
 
 def _px_worker(rank, world, port, q):
+    try:
+        _px_worker_body(rank, world, port, q)
+    except BaseException as e:   # (a rank that dies silently costs the parent its whole timeout and hides the reason)
+        import traceback
+        q.put((rank, ["FAILED: " + repr(e) + "\n" + traceback.format_exc()]))
+        raise
+
+
+def _px_worker_body(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -270,6 +279,7 @@ def test_pipelined_exchange_two_ranks_one_gpu():
     for p in procs:
         p.start()
     out = [q.get(timeout=400) for _ in procs]
+    assert not any(str(oks[0]).startswith("FAILED") for _, oks in out), out
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -834,6 +834,34 @@ def test_hand_traced_vectors_on_gpu(gpu):
             assert ctx.member_rank[:n].tolist() == exp["member_rank"], (case["name"], version)
 
 
+def test_hand_traced_local_alignment_on_gpu(gpu, monkeypatch):
+    """The hand-filled LocalAlignmentScorer tables of tests/golden/hand_traces.json through every form of the device DP:
+    literal pairs, dense block (tagged), ordered-pairs pass (packed saturating, packed signed, one sequence per lane)."""
+    from conftest import hand_traces
+    ht, M = hand_traces()
+    seqs = sorted({c[k] for c in ht["local"] for k in ("seq1", "seq2")})
+    at = {s: k for k, s in enumerate(seqs)}
+    ctx, _, _ = ctx_for(M, seqs)
+    n = len(seqs)
+    for go, ge in sorted({(c["gap_open"], c["gap_extend"]) for c in ht["local"]}):
+        cases = [c for c in ht["local"] if (c["gap_open"], c["gap_extend"]) == (go, ge)]
+        i = np.array([at[c["seq1"]] for c in cases], dtype=np.uint32)
+        j = np.array([at[c["seq2"]] for c in cases], dtype=np.uint32)
+        want = [c["score"] for c in cases]
+        assert ctx.score_pairs_local(i, j, go, ge).tolist() == want, (go, ge)
+        block = ctx.score_block_local(0, n, 0, n, go, ge)            # [seq1 (row), seq2 (column)]
+        assert [int(block[a, b]) for a, b in zip(i, j)] == want, (go, ge)
+        for env in (None, "HMK_LOCAL_SIGNED", "HMK_LOCAL_NO_PK"):
+            if env:
+                monkeypatch.setenv(env, "1")
+            edges, _ = ctx.neighbors_local(go, ge, 1)
+            if env:
+                monkeypatch.delenv(env)
+            got = {(int(x), int(m)): int(sc) for x, m, sc in zip(*hammock_amd.edge_fields(edges))}   # score(seq1 = m, seq2 = x)
+            for c in cases:
+                assert got[(at[c["seq2"]], at[c["seq1"]])] == c["score"], (c["name"], env)
+
+
 # --------------------------------------------------------------------------------------
 # clinkage mode (ClinkageSequenceClusterer.cluster) end to end
 # --------------------------------------------------------------------------------------

@@ -481,6 +481,23 @@ def test_hand_traced_greedy_vectors_both_oracles(coracle):
             assert np.asarray(stats.member_rank)[:len(peps)].tolist() == exp["member_rank"], case["name"]
 
 
+def test_hand_traced_local_alignment_both_oracles(coracle):
+    """The four LocalAlignmentScorer DP tables of hand_traces.json (filled in by hand from LocalAlignmentScorer.java:31-86, every
+    cell in hand_traces.md): open + extend along a gap, DIAGONAL over UP over LEFT on ties, a zero that keeps its direction, the
+    gap through a DIAGONAL cell that pays gapOpen again (10 where Gotoh gives 11), and the argument-order dependence."""
+    from conftest import hand_traces
+    ht, M = hand_traces()
+    for case in ht["local"]:
+        go, ge = case["gap_open"], case["gap_extend"]
+        assert coracle.local_score(M, case["seq1"], case["seq2"], go, ge) == case["score"], case["name"]
+        sc = po.LocalAlignmentScorer(M.tolist(), go, ge)
+        assert sc.sequence_score(po.UniqueSequence(case["seq1"]), po.UniqueSequence(case["seq2"])) == case["score"], case["name"]
+        # the table's own largest cell is the score (a typo check of the fixture)
+        assert max(cell[3] for row in case["cells"] for cell in row) == case["score"], case["name"]
+    by = {c["name"]: c for c in ht["local"]}
+    assert (by["L3a"]["seq1"], by["L3a"]["seq2"]) == (by["L3b"]["seq2"], by["L3b"]["seq1"]) and by["L3a"]["score"] != by["L3b"]["score"]
+
+
 def test_hand_traced_clinkage_vectors_both_oracles(coracle):
     """The clinkage chains of hand_traces.json, traced by hand through ClinkageSequenceClusterer.java:43-124 for the HashSet
     iteration orders of Java 8 and of JDK 7u6+ (hand_traces.md works the bucket indices out)."""
