@@ -517,6 +517,89 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
 }
 
 // -----------------------------------------------------------------------------
+// k_local_block_pk: the dense block on the packed DP (two column sequences per lane, sw_row_pk)
+// -----------------------------------------------------------------------------
+// Same contract as k_local_block; a workgroup takes 16 rows x 512 columns (lane t: columns t and 256 + t of its slice).  Columns
+// are not length-sorted here, so a lane's sequences are padded with the pad residue up to the wave's longest one, and rows carry
+// their own length (strips and the last strip's lines per row).  Taken when the tagged range holds (|M| <= 31, -31 <= penalties
+// <= 0); SAT as in the neighbour pass (gap_open <= -1).
+template <int LBMAX, bool SAT>
+__global__ void __launch_bounds__(256)
+k_local_block_pk(const uint8_t *__restrict__ res32, const uint8_t *__restrict__ len, const int32_t *__restrict__ Mg,
+                 uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *__restrict__ out) {
+    constexpr int R = 16;
+    constexpr int QROW = 25 * 8 * 8;      // 25 residues x 8 strips x (4 lines x int16)
+    __shared__ __attribute__((aligned(16))) uint8_t smem[R * QROW + 576 + R * 32];
+    __shared__ int row_len[R];
+    int8_t *m8 = reinterpret_cast<int8_t *>(smem + R * QROW);
+    uint8_t *rowres = smem + R * QROW + 576;
+    const int tid = threadIdx.x;
+    const uint32_t width = c1 - c0;
+    const uint32_t row_base = r0 + blockIdx.y * R;
+    const uint32_t nrows = min((uint32_t)R, r1 - row_base);
+
+    for (int e = tid; e < 576; e += 256) m8[e] = (int8_t)Mg[e];
+    for (int e = tid; e < R * 32; e += 256) {
+        const uint32_t r = (uint32_t)e >> 5;
+        rowres[e] = r < nrows ? res32[(size_t)(row_base + r) * 32 + (e & 31)] : 0;
+    }
+    if (tid < R) row_len[tid] = (uint32_t)tid < nrows ? len[row_base + tid] : 0;
+    __syncthreads();
+    for (int e = tid; e < R * 25 * 8; e += 256) {
+        const int r = e / 200, rem = e - r * 200, c = rem >> 3, iq = rem & 7;
+        uint32_t w[2] = {0, 0};
+        for (int k = 0; k < 4; k++) {
+            const int i = iq * 4 + k;
+            int v = -128;
+            if (i < row_len[r] && c < 24) v = m8[rowres[r * 32 + i] * 24 + c] * 4;
+            w[k >> 1] |= ((uint32_t)v & 0xFFFFu) << (16 * (k & 1));
+        }
+        reinterpret_cast<u32x2 *>(smem)[e] = u32x2{w[0], w[1]};
+    }
+    __syncthreads();
+
+    uint32_t colv[2];
+    bool okv[2];
+    uint32_t boff[2][LBMAX];
+    int wmax = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        colv[h] = c0 + blockIdx.x * 512 + h * 256 + tid;
+        okv[h] = colv[h] < c1;
+        uint32_t words[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) words[q] = 0;
+        int len2 = 0;
+        if (okv[h]) {
+            const u32x4 *src = reinterpret_cast<const u32x4 *>(res32 + (size_t)colv[h] * 32);
+            const u32x4 v0 = src[0], v1 = src[1];
+            words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
+            words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
+            len2 = len[colv[h]];
+        }
+#pragma unroll
+        for (int j = 0; j < LBMAX; j++) {
+            const uint32_t c = j < len2 ? ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu) : 24u;
+            boff[h][j] = c * 64u;
+        }
+        wmax = max(wmax, len2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+
+    const uint32_t q_addr = lds_addr(smem);
+    for (uint32_t r = 0; r < nrows; r++) {
+        const int len1 = row_len[r];
+        uint32_t g2 = 0;
+        if (len1 > 0 && wmax > 0) g2 = sw_row_pk<LBMAX, SAT>(q_addr + r * QROW, (len1 + 3) >> 2, len1, wmax, boff[0], boff[1], gap_open, gap_extend);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+            if (okv[h]) out[(size_t)(row_base + r - r0) * width + (colv[h] - c0)] = (int32_t)((g2 >> (16 * h)) & 0xFFFFu);
+    }
+}
+
+// -----------------------------------------------------------------------------
 // k_neighbors_local_literal: the same pass with the literal DP (LocalAlignmentScorer.java:31-86 line by line)
 // -----------------------------------------------------------------------------
 // For what the striped kernels do not take: positive gap penalties (the reference imposes no sign, :43-55) and matrix
@@ -618,6 +701,15 @@ hipError_t launch_local_block(int lbmax, bool enc, const uint8_t *res32, const u
                               uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
                               hipStream_t s) {
     if (r1 <= r0 || c1 <= c0) return hipSuccess;
+    if (enc && getenv("HMK_LOCAL_NO_PK") == nullptr) {   // two column sequences per lane
+        const dim3 grid2((c1 - c0 + 511) / 512, (r1 - r0 + 15) / 16);
+        const bool sat = gap_open <= -1 && getenv("HMK_LOCAL_SIGNED") == nullptr;
+#define HMK_LBP(LB) do { if (sat) hipLaunchKernelGGL((k_local_block_pk<LB, true>), grid2, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, gap_open, gap_extend, out); \
+                         else hipLaunchKernelGGL((k_local_block_pk<LB, false>), grid2, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, gap_open, gap_extend, out); } while (0)
+        if (lbmax <= 12) HMK_LBP(12); else if (lbmax <= 20) HMK_LBP(20); else HMK_LBP(32);
+#undef HMK_LBP
+        return hipGetLastError();
+    }
     const dim3 grid((c1 - c0 + 255) / 256, (r1 - r0 + 15) / 16);
 #define HMK_LB(LB, E) hipLaunchKernelGGL((k_local_block<LB, E>), grid, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, \
                                          gap_open, gap_extend, out)
