@@ -54,6 +54,9 @@ namespace hmk {
 #ifndef HMK_ROWS_STAGE_EXACT
 #define HMK_ROWS_STAGE_EXACT 640
 #endif
+#ifndef HMK_ROWS_UNPACK_SDWA
+#define HMK_ROWS_UNPACK_SDWA 1
+#endif
 #ifndef HMK_ROWS_STAGE_SHORT   // one-length shapes that keep the rescoring flush (<= 45 cells per pair: 6- to 9-mers): a drain's fixed cost
 #define HMK_ROWS_STAGE_SHORT 1024   // (scalar loads, cursor, first gather) over more records -- 9-mers 1.74 -> 1.69 ms, 7-mers 1.61 -> 1.53
 #endif
@@ -232,8 +235,23 @@ struct RowsShape {
                 off[J] = add_byte<(J & 3)>(base, words[J >> 2]);
             });
         } else {
+#if HMK_ROWS_UNPACK_SDWA   // (byte select, then the shift: one v_lshlrev_b32_sdwa per residue -- no shifted copy of the word, no mask for byte 0;
+            // the compiler finds the form itself for bytes 1-3 and turns byte 0 back into shift + mask, hence the asm for that one)
+            const uint32_t three = 3u;   // (a VGPR operand: the same register the compiler keeps for its own SDWA shifts)
+#pragma unroll
+            for (int j = 0; j < CAP; j++) {
+                if ((j & 3) == 0) {
+                    uint32_t r;
+                    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(words_in[j >> 2]));
+                    off[j] = base + r;
+                } else {
+                    off[j] = base + (((words_in[j >> 2] >> ((j & 3) * 8)) & 0xFFu) << 3);
+                }
+            }
+#else
 #pragma unroll
             for (int j = 0; j < CAP; j++) off[j] = base + ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
+#endif
         }
         if (EXACT_LB) {
 #pragma unroll
