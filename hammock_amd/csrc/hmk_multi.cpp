@@ -37,8 +37,12 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
     const uint32_t n = ctx->n;
     if (HMK_EDGE_SHARDS + G - 1 > HMK_MAX_SEGS) return fail(ctx, HMK_ERR_BAD_ARG, "too many devices for one context");
     hipStream_t S = ctx->gstream, C = ctx->copy_stream;
+    // HMK_MULTI_SERIAL=1: the conservative form, for a machine where the overlapped one misbehaves -- no worker threads, no band, no
+    // peer copies: the peers score their shards one after the other from the calling thread, each is synchronised, and its block
+    // and row degrees travel through host memory (two plain hipMemcpy); then the root scores its shard and runs the same tail.
+    const bool serial = getenv("HMK_MULTI_SERIAL") != nullptr;
     int64_t band_req = 0;
-    if (!clink && max_clusters > 0 && n >= 16384 && getenv("HMK_NO_BAND") == nullptr) band_req = std::min<int64_t>(n, 2LL * max_clusters + 1024);
+    if (!serial && !clink && max_clusters > 0 && n >= 16384 && getenv("HMK_NO_BAND") == nullptr) band_req = std::min<int64_t>(n, 2LL * max_clusters + 1024);
     if (band_req * 2 > (int64_t)n) band_req = 0;
     uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006) / G * 1.25) + (1u << 20);
     if (const char *v = getenv("HMK_EDGE_GUESS")) guess = std::strtoull(v, nullptr, 10);   // tests: force the overflow / retry path
@@ -186,6 +190,22 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                 if (c->h_counts[q] > seg) { set_full(-2, HMK_OK, ""); return; }
             J.total = h_tot[0];
             h_tot[2] = J.total;
+            if (serial) {   // through the host, every step synchronous
+                std::vector<uint64_t> h_block(std::max<uint64_t>(J.total, 1));
+                std::vector<uint32_t> h_deg(p_deg ? n : 0);
+                e = hipStreamSynchronize(Q);
+                if (e == hipSuccess && J.total) e = hipMemcpy(h_block.data(), buf<uint64_t>(c, SB_PEER), J.total * sizeof(uint64_t), hipMemcpyDeviceToHost);
+                if (e == hipSuccess && p_deg) e = hipMemcpy(h_deg.data(), p_deg, (size_t)n * 4, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipSetDevice(root_dev);
+                if (e == hipSuccess && J.total) e = hipMemcpy(root_peer + J.off, h_block.data(), J.total * sizeof(uint64_t), hipMemcpyHostToDevice);
+                if (e == hipSuccess && p_deg) e = hipMemcpy(buf<uint32_t>(ctx, SB_PEERDEG) + (size_t)(J.part - 1) * n, h_deg.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(root_cnt + J.part, h_tot + 2, 8, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipEventRecord(c->ev_gather, c->gather_stream);   // (nothing is pending on that stream: complete at once)
+                (void)hipSetDevice(c->device);
+                if (e != hipSuccess) { hip_fail("edge hand-over through the host", e); return; }
+                set_full(1, HMK_OK, "");
+                return;
+            }
             e = hipSetDevice(root_dev);
             if (e == hipSuccess && J.total)
                 e = hipMemcpyPeerAsync(root_peer + J.off, root_dev, buf<uint64_t>(c, SB_PEER), c->device, J.total * sizeof(uint64_t), c->gather_stream);
@@ -197,7 +217,13 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             if (e != hipSuccess) { hip_fail("edge hand-over", e); return; }
             set_full(1, HMK_OK, "");
         };
-        for (auto &jp : jobs) { PeerJob *J = jp.get(); J->th = std::thread([&peer_main, J]() { peer_main(*J); }); }
+        if (serial) {
+            for (auto &jp : jobs) peer_main(*jp);
+            st = need_device(ctx);   // (back on the root's device)
+            if (st) return st;
+        } else {
+            for (auto &jp : jobs) { PeerJob *J = jp.get(); J->th = std::thread([&peer_main, J]() { peer_main(*J); }); }
+        }
         struct Joiner {   // on every way out: the workers are done before their state goes away
             std::vector<std::unique_ptr<PeerJob>> &jobs;
             ~Joiner() { for (auto &jp : jobs) if (jp->th.joinable()) jp->th.join(); }

@@ -452,8 +452,8 @@ def test_greedy_3e5_vs_oracle(gpu, blosum62, coracle):
     assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
 
 
-@pytest.mark.parametrize("devices", [pytest.param([0], id="dev0")] + multi_device_lists())
-def test_greedy_multi_device_context(gpu, blosum62, coracle, devices):
+@pytest.mark.parametrize("devices", [pytest.param([0], id="dev0")] + multi_device_lists(repeated=((0, 0), (0, 0, 0), (0,) * 8)))
+def test_greedy_multi_device_context(gpu, blosum62, coracle, devices, monkeypatch):
     """hmk_create_multi: the multi-GPU form below the C ABI.  On a one-GPU box the device list names it one, two and
     three times -- every "device" has its own context, worker thread, plan (shard d of n, band tiles first), edge buffer and
     streams; the peers' band blocks and edge blocks reach the root through hipMemcpyPeerAsync behind the peers' own events,
@@ -477,6 +477,16 @@ def test_greedy_multi_device_context(gpu, blosum62, coracle, devices):
         cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)
         assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
         assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+    if len(devices) > 1:
+        # HMK_MULTI_SERIAL=1, the conservative form kept beside the overlapped one: peers one after the other on the calling
+        # thread, no band, blocks and row degrees through host memory instead of peer copies
+        monkeypatch.setenv("HMK_MULTI_SERIAL", "1")
+        cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)
+        monkeypatch.delenv("HMK_MULTI_SERIAL")
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+        assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+        cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)   # and back
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
     single = hammock_amd.Context(blosum62, device=0)
     single.set_sequences(residues=res, offsets=off, sizes=sizes)
     _, _, sstats = single.greedy_cluster(3, 0, 20, 1000)
@@ -1253,6 +1263,14 @@ def test_million_peptides_greedy_end_to_end(gpu, blosum62, coracle, monkeypatch,
     cid2, order2, _ = ctx.greedy_cluster(3, 0, thr, maxc)
     assert ctx.greedy_phases()["loop_rounds"] == 0
     assert np.array_equal(cid, cid2) and np.array_equal(order, order2) and np.array_equal(rank, ctx.member_rank[:n])
+    monkeypatch.delenv("HMK_SECOND_LOOP")
+    del ctx
+    # ... and from EIGHT contexts on this one card (hmk_create_multi with the device named eight times: eight plans, shards, worker
+    # threads, band blocks and gathered blocks -- the one-process form of an 8-GPU node, minus the links)
+    ctx8 = hammock_amd.Context(blosum62, device=[0] * 8)
+    ctx8.set_sequences(residues=res, offsets=off)
+    cid8, order8, _ = ctx8.greedy_cluster(3, 0, thr, maxc)
+    assert np.array_equal(cid, cid8) and np.array_equal(order, order8) and np.array_equal(rank, ctx8.member_rank[:n])
 
 
 def test_million_peptide_shard_properties(gpu, blosum62, coracle):
