@@ -96,6 +96,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     bool band_pending = false, band_used = false;
     uint32_t R1 = src.band_rows;
     if (R1 > 0 && src.before_band && src.before_band() != HMK_OK) R1 = 0;   // (the peers' band blocks did not make it: no band)
+    if (getenv("HMK_BAND_NO_HANDOVER")) R1 = 0;   // (measurement: the band is launched on its own but nothing is built from it)
     if (R1 > 0 && src.format_known) {
         HIPCHK(ctx, ensure_buf(ctx, SB_BDEG, (size_t)R1 * 4));
         HIPCHK(ctx, ensure_buf(ctx, SB_BCURSOR, (size_t)R1 * 8));
@@ -182,7 +183,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(entries, 1) * esz, 0);
                 if (e == hipSuccess)
                     e = launch_csr_scatter(src.band_segs, symmetric, buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BCURSOR),
-                                           buf<void>(ctx, SB_BADJ), packed, base, R1, C);
+                                           buf<void>(ctx, SB_BADJ), packed, base, R1, C, n);
                 if (e == hipSuccess && entries)
                     e = hipMemcpyAsync(ctx->h_adj, buf<void>(ctx, SB_BADJ), entries * esz, hipMemcpyDeviceToHost, C);
                 // the band rows' upper-section sizes travel with them: upper[] must never hold a previous call's values for rows

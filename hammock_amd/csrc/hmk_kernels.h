@@ -64,7 +64,7 @@ size_t csr_partition_scratch_bytes();
 hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *start, uint32_t *cursor, void *adj, int base, uint32_t n,
                                           uint64_t *recs, void *scratch, const uint32_t *row_lower, hipStream_t s);
 hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
-                              bool packed, int base, uint32_t row_limit, hipStream_t s);
+                              bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n = 0);
 
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);

@@ -1346,11 +1346,24 @@ EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const uns
     return sg;
 }
 
+// Workgroups per segment of the kernels that walk an edge list restricted to rows < row_limit (the band hand-over, which runs on
+// its own stream BESIDE the neighbour pass): every one of them needs a slot on a machine that is full, and 512 x 64 segments =
+// 32,768 workgroups for the 1.5 x 10^6 band edges of a 10^5 call slowed the pass they ran beside from 2.95 to 3.35 ms (the whole
+// "cost of the band" of DESIGN.md 4.2; measured with HMK_BAND_NO_HANDOVER).  The kernels loop over their segment, so the grid is
+// sized for the edges to expect -- rows x n x 0.3 % -- at ~4,096 per workgroup, 4 .. 512 (10^5: 6 per segment; 2 .. 13 measure the
+// same, 32 costs the pass 0.1 ms, 128 and more 0.45 ms).
+static uint32_t band_grid_x(const EdgeSegs &segs, uint32_t n, uint32_t row_limit) {
+    if (const char *v = getenv("HMK_BAND_GRID")) return (uint32_t)std::max(1, std::min(512, atoi(v)));
+    if (row_limit >= n) return 512;
+    const double per_seg = (double)row_limit * (double)n * 0.003 / (double)std::max<uint32_t>(segs.n, 1);
+    return (uint32_t)std::max(4.0, std::min(512.0, per_seg / 4096.0));
+}
+
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
                                   uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s) {
     if (segs.n == 0 || segs.n > HMK_MAX_SEGS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_init_range, dim3(1), dim3(64), 0, s, score_range);
-    hipLaunchKernelGGL(k_edge_degree, dim3(512, segs.n), dim3(256), 0, s, segs, deg, symmetric ? 1 : 0, score_range, n, row_limit);
+    hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), segs.n), dim3(256), 0, s, segs, deg, symmetric ? 1 : 0, score_range, n, row_limit);
     launch_scan<uint64_t>(deg, start, row_limit, tile_scratch, nullptr, s);
     return hipGetLastError();
 }
@@ -1377,12 +1390,13 @@ hipError_t launch_csr_scatter_ranked(const EdgeSegs &segs, const uint64_t *edges
 }
 
 hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
-                              bool packed, int base, uint32_t row_limit, hipStream_t s) {
+                              bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n) {
+    const uint32_t gx = n ? band_grid_x(segs, n, row_limit) : 512;   // (n given: the band's rows beside a running pass)
     if (packed)
-        hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj,
+        hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(gx, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj,
                            symmetric ? 1 : 0, base, row_limit);
     else
-        hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (Nbr *)adj,
+        hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(gx, segs.n), dim3(256), 0, s, segs, start, cursor, (Nbr *)adj,
                            symmetric ? 1 : 0, base, row_limit);
     return hipGetLastError();
 }
@@ -1434,9 +1448,17 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
     return hipGetLastError();
 }
 
+// Workgroups per segment of the kernels that regroup a pass's edges for the exchange: in the pipelined step they run on the
+// communication stream BESIDE the next pass (band_grid_x above: every workgroup that wants a slot on a full machine costs the
+// pass it runs beside).  Sized from the segment's capacity -- about twice what a pass writes -- at ~4,096 entries each.
+static uint32_t pack_grid_x(uint64_t cap_per_shard) {
+    if (const char *v = getenv("HMK_PACK_GRID")) return (uint32_t)std::max(1, std::min(128, atoi(v)));
+    return (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(128, cap_per_shard / 4096));
+}
+
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s) {
-    hipLaunchKernelGGL(k_compact_edges, dim3(128, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, out,
+    hipLaunchKernelGGL(k_compact_edges, dim3(pack_grid_x(cap_per_shard), HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, out,
                        out_capacity, total);
     return hipGetLastError();
 }
@@ -1449,10 +1471,10 @@ hipError_t launch_pack_rows(const uint64_t *edges, uint64_t cap_per_shard, const
     if (e != hipSuccess) return e;
     uint32_t *deg = scratch, *cursor = scratch + n, *misfit = scratch + 2 * (size_t)n;
     uint64_t *tile_scratch = (uint64_t *)(scratch + 2 * (size_t)n + 2);
-    hipLaunchKernelGGL(k_rows_degree, dim3(128, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg, misfit,
+    hipLaunchKernelGGL(k_rows_degree, dim3(pack_grid_x(cap_per_shard), HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, deg, misfit,
                        threshold);
     launch_scan<uint32_t>(deg, row_start, n, tile_scratch, misfit, s);
-    hipLaunchKernelGGL(k_rows_scatter, dim3(128, HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, row_start,
+    hipLaunchKernelGGL(k_rows_scatter, dim3(pack_grid_x(cap_per_shard), HMK_EDGE_SHARDS), dim3(256), 0, s, edges, cap_per_shard, counts, row_start,
                        cursor, adj, adj_capacity, threshold);
     return hipGetLastError();
 }
