@@ -90,41 +90,47 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
     return HMK_OK;
 }
 
+// a call whose failure changes nothing here -- but says so under HMK_DESTROY_TRACE, and never leaves its error behind as the
+// thread's "last error" for the next launch wrapper's hipGetLastError() to pick up
+#define HMK_QUIET(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) { if (getenv("HMK_DESTROY_TRACE")) fprintf(stderr, "[hmk destroy] %s: %s\n", #call, hipGetErrorString(e_)); (void)hipGetLastError(); } } while (0)
 void hmk_destroy(hmk_ctx *ctx) {
     if (!ctx) return;
     for (hmk_ctx *peer : ctx->peers) hmk_destroy(peer);
     ctx->peers.clear();
     if (ctx->has_device) {
-        (void)hipSetDevice(ctx->device);
+        HMK_QUIET(hipSetDevice(ctx->device));
         (void)join_late_buffers(ctx);
         free_plan(ctx->plan);
         free_plan_local(ctx->plan_local);
-        if (ctx->d_res32) (void)hipFree(ctx->d_res32);
-        if (ctx->d_len) (void)hipFree(ctx->d_len);
-        if (ctx->d_M) (void)hipFree(ctx->d_M);
-        if (ctx->d_edges) (void)hipFree(ctx->d_edges);
-        if (ctx->d_counts) (void)hipFree(ctx->d_counts);
-        if (ctx->d_rows_scratch) (void)hipFree(ctx->d_rows_scratch);
-        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-        if (ctx->rest_stream) (void)hipStreamDestroy(ctx->rest_stream);
-        if (ctx->ev_rest) (void)hipEventDestroy(ctx->ev_rest);
+        if (ctx->d_res32) HMK_QUIET(hipFree(ctx->d_res32));
+        if (ctx->d_len) HMK_QUIET(hipFree(ctx->d_len));
+        if (ctx->d_M) HMK_QUIET(hipFree(ctx->d_M));
+        if (ctx->d_edges) HMK_QUIET(hipFree(ctx->d_edges));
+        if (ctx->d_counts) HMK_QUIET(hipFree(ctx->d_counts));
+        if (ctx->d_rows_scratch) HMK_QUIET(hipFree(ctx->d_rows_scratch));
+        if (ctx->copy_stream) HMK_QUIET(hipStreamDestroy(ctx->copy_stream));
+        if (ctx->rest_stream) HMK_QUIET(hipStreamDestroy(ctx->rest_stream));
+        if (ctx->ev_rest) HMK_QUIET(hipEventDestroy(ctx->ev_rest));
         for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
-            if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
-            if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
+            if (ctx->side[k]) HMK_QUIET(hipStreamDestroy(ctx->side[k]));
+            if (ctx->ev_join[k]) HMK_QUIET(hipEventDestroy(ctx->ev_join[k]));
         }
-        if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-        if (ctx->h_start) (void)hipHostFree(ctx->h_start);
-        if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-        if (ctx->h_adj) (void)hipHostFree(ctx->h_adj);
-        if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
-        if (ctx->h_loop) (void)hipHostFree(ctx->h_loop);
+        if (ctx->ev_fork) HMK_QUIET(hipEventDestroy(ctx->ev_fork));
+        if (ctx->gather_stream) HMK_QUIET(hipStreamDestroy(ctx->gather_stream));   // (a peer's transfers to the root, hmk_multi.cpp)
+        if (ctx->ev_bandgather) HMK_QUIET(hipEventDestroy(ctx->ev_bandgather));
+        if (ctx->ev_gather) HMK_QUIET(hipEventDestroy(ctx->ev_gather));
+        if (ctx->h_start) HMK_QUIET(hipHostFree(ctx->h_start));
+        if (ctx->h_stage) HMK_QUIET(hipHostFree(ctx->h_stage));
+        if (ctx->h_adj) HMK_QUIET(hipHostFree(ctx->h_adj));
+        if (ctx->h_counts) HMK_QUIET(hipHostFree(ctx->h_counts));
+        if (ctx->h_loop) HMK_QUIET(hipHostFree(ctx->h_loop));
         for (int b = 0; b < SB_N; b++)
-            if (ctx->sb[b].p) (void)hipFree(ctx->sb[b].p);
-        if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
+            if (ctx->sb[b].p) HMK_QUIET(hipFree(ctx->sb[b].p));
+        if (ctx->gstream) HMK_QUIET(hipStreamDestroy(ctx->gstream));
         for (hipEvent_t ev : {ctx->ev_t0, ctx->ev_band, ctx->ev_edges, ctx->ev_csr, ctx->ev_bandcsr})
-            if (ev) (void)hipEventDestroy(ev);
-        if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-        if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+            if (ev) HMK_QUIET(hipEventDestroy(ev));
+        if (ctx->ev0) HMK_QUIET(hipEventDestroy(ctx->ev0));
+        if (ctx->ev1) HMK_QUIET(hipEventDestroy(ctx->ev1));
     }
     delete ctx;
 }
@@ -559,6 +565,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_edges) == hipSuccess) ctx->phases.score_ms = ms;
     if (hipEventElapsedTime(&ms, ctx->ev_edges, ctx->ev_csr) == hipSuccess) ctx->phases.csr_ms = ms;
+    (void)hipGetLastError();   // (a call that left early never recorded these events: "invalid resource handle" must not stay behind as the thread's last error)
     ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     stats->neighbors_ms = ctx->phases.score_ms;
     if (getenv("HMK_GREEDY_TIMING"))

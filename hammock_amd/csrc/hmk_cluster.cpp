@@ -310,6 +310,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             unsigned long long total = 0;
             bool fits = true;
             for (uint32_t g = 0; g < HMK_PRE_REGIONS; g++) { total += h_regions[g]; fits = fits && h_regions[g] <= region_cap; }
+            if (fits && total > 0x7FFFFFFFull) return false;
             if (fits) {
                 pre_total_c = (uint32_t)total;
                 pre_mode = 2;
@@ -317,7 +318,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 ph.precheck_ms = ms_since(tp);
                 return true;
             }
-            if (total > 0xFFFFFFFFull) return false;
+            if (total > 0x7FFFFFFFull) return false;   // (entry indices: 31 bits, k_loop_subscribers' record keeps a flag in the 32nd)
             r = hipMemsetAsync(d_over, 0, 16, S);   // more entries than a region holds: count, size, fill
         }
         if (r == hipSuccess) r = launch_greedy_precheck(0, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
@@ -328,6 +329,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = hipStreamSynchronize(S);
         if (r != hipSuccess || h_misc[0] != 0) return false;   // a row overflowed its hash table: host pre-check
         pre_total_c = h_misc[1];
+        if (pre_total_c > 0x7FFFFFFFu) return false;
         if (pre_total_c) {
             r = ensure_buf(ctx, SB_CAND, (size_t)pre_total_c * sizeof(GreedyCand));
             if (r == hipSuccess) r = launch_greedy_precheck(1, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,

@@ -18,6 +18,9 @@ int need_device(hmk_ctx *ctx) {
     if (ctx->wedged) return fail(ctx, HMK_ERR_DEVICE, "an earlier call on this context gave up on a device that had stopped making progress");
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) return fail(ctx, HMK_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    // The launch wrappers report hipGetLastError(), which is the thread's last error from ANY earlier call -- e.g. one whose
+    // result was deliberately ignored while another context was torn down.  What this context does starts with a clean slate.
+    (void)hipGetLastError();
     return HMK_OK;
 }
 

@@ -312,6 +312,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_edges) == hipSuccess) ctx->phases.score_ms = ms;   // root shard + gather
     if (hipEventElapsedTime(&ms, ctx->ev_edges, ctx->ev_csr) == hipSuccess) ctx->phases.csr_ms = ms;
+    (void)hipGetLastError();   // (a call that left early never recorded these events: "invalid resource handle" must not stay behind as the thread's last error)
     ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (stats) stats->neighbors_ms = ctx->phases.score_ms;
     if (clink) clink->neighbors_ms = ctx->phases.score_ms;

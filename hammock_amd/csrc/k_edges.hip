@@ -893,8 +893,11 @@ k_greedy_prop(const uint64_t *__restrict__ start, const uint32_t *__restrict__ u
 //           feasible goes on the next round's eval list.
 // Rounds repeat until one accepts nobody.  The host applies the joins in leftover order afterwards.
 enum : uint8_t { LS_UNDECIDED = 0, LS_NEVER = 1, LS_JOINED = 2 };
+constexpr uint32_t LS_SINGLE = 0x80000000u, LS_ENTRY = 0x7FFFFFFFu;   // a subscriber record's low word: flag | candidate entry index
 
-// subscriber lists: per cluster the (leftover, candidate entry) pairs that list it, as uint64 = leftover << 32 | entry;
+// subscriber lists: per cluster the (leftover, candidate entry) pairs that list it, as uint64 = leftover << 32 | entry, bit 31 of
+// the entry index set when it is the leftover's ONLY candidate entry (k_loop_apply's chains; the driver keeps the entry count
+// below 2^31);
 // pass 0 counts, pass 1 fills (in arbitrary order: k_loop_sort_subs sorts them).  Leftover q's entries are
 // cand[cand_start[q] .. cand_start[q] + cand_cnt[q]) -- the blocks need not be in leftover order (single-pass pre-check).
 __global__ void __launch_bounds__(256)
@@ -905,7 +908,7 @@ k_loop_subscribers(uint32_t nl, const uint32_t *__restrict__ cand_start, const u
     if (q >= nl) return;
     for (uint32_t k = cand_start[q], ke = k + cand_cnt[q]; k < ke; k++) {
         const uint32_t pos = atomicAdd(&cursor[cand[k].c], 1u);
-        if (fill) subs[(size_t)sub_start[cand[k].c] + pos] = ((unsigned long long)q << 32) | k;
+        if (fill) subs[(size_t)sub_start[cand[k].c] + pos] = ((unsigned long long)q << 32) | k | (cand_cnt[q] == 1u ? LS_SINGLE : 0u);
     }
 }
 
@@ -1045,7 +1048,7 @@ loop_first(uint32_t block, uint32_t n_clusters, const uint32_t *__restrict__ sub
     auto valid_at = [&](uint32_t idx, uint32_t *q) -> bool {
         const unsigned long long e = subs[idx];
         *q = (uint32_t)(e >> 32);
-        return status[*q] == LS_UNDECIDED && cand[(uint32_t)e].covered == joined;
+        return status[*q] == LS_UNDECIDED && cand[(uint32_t)e & LS_ENTRY].covered == joined;
     };
     if (cu < end) {                                       // usually the holder of the previous pass still stands
         uint32_t q = 0;
@@ -1168,11 +1171,12 @@ static_assert(APPLY_SLOTS == 8192 || APPLY_SLOTS == 4096 || APPLY_SLOTS == 2048 
 template <class NbrT>
 __global__ void __launch_bounds__(256)
 k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, const NbrT *__restrict__ adj,
-             const uint32_t *__restrict__ leftover, const uint8_t *__restrict__ status, GreedyCand *__restrict__ cand,
+             const uint32_t *__restrict__ leftover, uint8_t *status, GreedyCand *__restrict__ cand,
              const uint32_t *__restrict__ choice, const uint32_t *__restrict__ accepted, const uint32_t *__restrict__ sub_start,
-             const unsigned long long *__restrict__ subs, const uint32_t *__restrict__ cursor, LoopCluster *__restrict__ cl,
+             const unsigned long long *__restrict__ subs, uint32_t *cursor, LoopCluster *__restrict__ cl,
              const int32_t *__restrict__ seq_size, uint32_t *__restrict__ dirty, uint32_t *__restrict__ next_list, uint32_t which,
-             uint32_t *__restrict__ counters, unsigned long long *host_word, uint32_t stamp) {
+             uint32_t *__restrict__ counters, unsigned long long *host_word, uint32_t stamp,
+             const uint32_t *__restrict__ cand_cnt, int32_t *join_slot, int chain) {
     // Packed adjacency (4-byte entries id << 8 | score): the table holds the entry itself -- 32 KB instead of 64, four workgroups
     // per CU instead of two, and a join is bound by its chain of dependent gathers (37 us on average at 10^6: 9 table build, 19
     // subscribers, 9 the loads before them), so the joins in flight are what counts.  Empty slot = 0: an entry of an UPPER section
@@ -1182,6 +1186,7 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
     __shared__ uint32_t keys[APPLY_SLOTS];
     __shared__ int32_t vals[PACKED ? 1 : APPLY_SLOTS];
     __shared__ uint32_t list_count, list_base;
+    __shared__ uint32_t next_idx;   // the earliest later subscriber that stays feasible after this join (chains, below)
     const uint32_t n_acc = counters[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) {                     // what the host polls: a round without a join is the end
         counters[3] = n_acc;
@@ -1194,12 +1199,26 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
         const unsigned long long ts0 = wall_clock64();   // 100 MHz
         unsigned long long ts_table = 0, ts_subs = 0;
 #endif
-        const uint32_t q = accepted[a];
-        const uint32_t y = leftover[q];
+        uint32_t q = accepted[a];
         const int32_t c = cand[choice[q]].c;
-        const int32_t joined = cl[c].joined;
-        const uint32_t sb = cursor[c] + 1, se = sub_start[c + 1];   // the list is sorted and the cursor stands at q itself
+        int32_t joined = cl[c].joined;
+        uint32_t sb = cursor[c] + 1;                             // the list is sorted and the cursor stands at q itself
+        const uint32_t se = sub_start[c + 1];
+        long long size_add = 0;
+        uint32_t links = 0;
+        // CHAINS.  After y has joined, the cluster's next holder is the earliest later subscriber that is still open and stays
+        // feasible (it is a neighbour of y) -- in the round scheme it is found by the next round's `first`, picked by `eval` and
+        // let in by `accept`: three launches per member of a family that joins one cluster (the reference's antibodies example:
+        // 151 rounds).  If that subscriber has ONE candidate entry in all (this cluster's: every other cluster was infeasible for
+        // it at the pre-check, for good), its pick is this cluster whatever else happens, no other cluster's list holds it, no
+        // other workgroup ever reads or writes its status or its entry -- so it joins here and now, exactly as the sequential
+        // loop has it join at its turn (LimitedGreedySequenceClusterer.java:59-66: every earlier open subscriber of the cluster
+        // was decided or infeasible, which is what "earliest that stays feasible" says), and the walk goes on from it.  A
+        // subscriber with several candidates ends the chain: its pick needs `eval`.
+        for (;;) {
+        const uint32_t y = leftover[q];
         const uint64_t b = start[y], e = b + up[y];              // later leftovers have larger ids: the upper section
+        if (threadIdx.x == 0) next_idx = 0xFFFFFFFFu;            // (read after the barriers of the chunk loop)
 #if HMK_APPLY_STATS   // probe build: how long are the lists a join walks? (counters[8..11], printed by HMK_LOOP_TRACE)
         if (threadIdx.x == 0) {
             atomicAdd(&counters[8], se - sb); atomicMax(&counters[9], se - sb);
@@ -1254,16 +1273,17 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                 // changes either way -- one more covered member, or infeasible from now on: its leftover re-picks
 #pragma unroll
                 for (int u = 0; u < APPLY_SUBS; u++)
-                    live[u] = live[u] && status[(uint32_t)(sub[u] >> 32)] == LS_UNDECIDED && cand[(uint32_t)sub[u]].covered == joined;
+                    live[u] = live[u] && status[(uint32_t)(sub[u] >> 32)] == LS_UNDECIDED && cand[(uint32_t)sub[u] & LS_ENTRY].covered == joined;
                 // (the ids are asked for AFTER this test on purpose: few subscribers pass it, and with the id gathered for every
                 // subscriber beside its status and entry -- one link less in the chain -- the loop got slower, 19.1 -> 20.1 ms)
                 uint32_t ids[APPLY_SUBS];
 #pragma unroll
                 for (int u = 0; u < APPLY_SUBS; u++) ids[u] = live[u] ? leftover[(uint32_t)(sub[u] >> 32)] : 0u;
                 uint32_t n_marks = 0, marks = 0;                 // this lane's new entries of the next eval list (bit u)
+                uint32_t best_next = 0xFFFFFFFFu;                // chains: (list index << 1 | "has other candidates") of this lane's earliest subscriber that stays feasible
 #pragma unroll
                 for (int u = 0; u < APPLY_SUBS; u++) {
-                    const uint32_t q2 = (uint32_t)(sub[u] >> 32), k2 = (uint32_t)sub[u];
+                    const uint32_t q2 = (uint32_t)(sub[u] >> 32), k2 = (uint32_t)sub[u] & LS_ENTRY;
                     if (live[u]) {
                         const uint32_t id = ids[u];
                         uint32_t sl = (id * 2654435761u) >> APPLY_SHIFT;
@@ -1274,12 +1294,18 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                                 const int32_t sc = PACKED ? (int32_t)(kk & 0xFFu) : vals[sl];
                                 cand[k2].covered = joined + 1;
                                 if (sc < cand[k2].mn) cand[k2].mn = sc;
+                                best_next = min(best_next, ((s0 + (uint32_t)u * 256 + threadIdx.x) << 1) | (((uint32_t)sub[u] & LS_SINGLE) ? 0u : 1u));
                                 break;
                             }
                             sl = (sl + 1) & (APPLY_SLOTS - 1);
                         }
                         if (first_chunk && atomicExch(&dirty[q2], 1u) == 0u) { marks |= 1u << u; n_marks++; }
                     }
+                }
+                if (chain && __ballot(best_next != 0xFFFFFFFFu)) {   // one LDS atomic per wave that found any
+#pragma unroll
+                    for (int o = 32; o; o >>= 1) best_next = min(best_next, (uint32_t)__shfl_xor((int)best_next, o));
+                    if ((threadIdx.x & 63) == 0) atomicMin(&next_idx, best_next);
                 }
                 if (first_chunk) {
                     // next round's eval list: ONE global atomic per workgroup and step.  (One per wave and subscriber slot was
@@ -1312,9 +1338,27 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
             atomicAdd(&counters[14], (uint32_t)ts_table); atomicAdd(&counters[15], (uint32_t)ts_subs);
         }
 #endif
+        joined += 1;
+        size_add += seq_size ? (long long)seq_size[y] : 1ll;
+        links++;
+        const uint32_t nx = next_idx;                            // (uniform: written before the chunk loop's last barrier)
+        if (nx == 0xFFFFFFFFu || (nx & 1u)) break;               // nobody stays feasible / the earliest one has other candidates: `eval` picks
+        const uint32_t ni = nx >> 1;
+        const uint32_t q2 = (uint32_t)(subs[ni] >> 32);
+        __syncthreads();                                         // (every thread has read next_idx)
         if (threadIdx.x == 0) {
-            cl[c].joined += 1;
-            cl[c].size += seq_size ? (long long)seq_size[y] : 1ll;
+            status[q2] = LS_JOINED;                              // :61-62
+            join_slot[q2] = c;
+        }
+        q = q2;
+        sb = ni + 1;
+        __threadfence_block();                                   // this link's entry updates and the status byte, for the next link's reads
+        __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            cl[c].joined = joined;
+            cl[c].size += size_add;
+            if (links > 1) cursor[c] = sb - 1;                   // stands at the chain's last member
         }
     }
 }
@@ -1605,12 +1649,21 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
                            first, taken, stamp, accepted, join_slot, counters);
     }
     const dim3 agrid(HMK_APPLY_GRID);
+    // Chains (k_loop_apply) pay when ONE cluster's joins are the loop's critical path -- families of near-duplicates that all join
+    // one cluster: thousands of rounds become a handful.  Where they are not (10^5 / 10^6 random peptides, the reference's antibodies
+    // example: 30 / 183 / 155 rounds, with or without), a chained join only makes its round longer: the joins it takes would have
+    // ridden along in later rounds for free (loop 0.70 -> 0.81 ms, 29.5 -> 29.7 ms, 3.6 -> 4.0 ms).  So they start once a loop has
+    // shown itself to be long; HMK_LOOP_CHAIN=0 / 1 forces never / from the first round.
+    const char *chain_env = getenv("HMK_LOOP_CHAIN");
+    const int chain = chain_env ? atoi(chain_env) : (round >= 256u ? 1 : 0);
     if (packed)
         hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
-                           choice, accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp);
+                           choice, accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp,
+                           cand_cnt, join_slot, chain);
     else
         hipLaunchKernelGGL((k_loop_apply<Nbr>), agrid, block, 0, s, start, up, (const Nbr *)adj, leftover, status, cand, choice,
-                           accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp);
+                           accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp,
+                           cand_cnt, join_slot, chain);
     return hipGetLastError();
 }
 

@@ -419,7 +419,8 @@ def test_greedy_device_loop_variants(gpu, blosum62, coracle, monkeypatch, env):
 def test_greedy_device_loop_long_subscriber_lists(gpu, blosum62, coracle, monkeypatch):
     """Three families of 10,000 near-duplicates, three clusters: every cluster is listed by ~10^4 leftovers, so the
     device loop's subscriber lists are longer than one LDS sort run (4,096) and go through two rounds of merges, its
-    joins come one per cluster and round (thousands of rounds), and the clusters grow to thousands of members."""
+    joins come one per cluster and round (thousands of rounds without the chains of round 4), and the clusters grow to thousands
+    of members."""
     rng = np.random.default_rng(3)
     seeds = [rng.integers(0, 20, 12).astype(np.uint8) for _ in range(3)]
     peps = {}
@@ -433,10 +434,18 @@ def test_greedy_device_loop_long_subscriber_lists(gpu, blosum62, coracle, monkey
     assert st == 0 and np.bincount(np.unique(ocid, return_inverse=True)[1]).max() > 5000
     monkeypatch.setenv("HMK_SECOND_LOOP", "device")
     ctx, _, _ = ctx_for(blosum62, res=res, off=off)
-    cid, order, stats = ctx.greedy_cluster(3, 0, 18, 3)
-    assert ctx.greedy_phases()["loop_rounds"] > 1000
-    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
-    assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+    # chains (round 4): a subscriber whose ONLY candidate is the cluster joins inside the join before it, without a round of its
+    # own -- these families then take a handful of rounds; HMK_LOOP_CHAIN=0 is the one-join-per-cluster-and-round scheme
+    # (default: chains start at round 256 -- a loop that has shown itself to be long)
+    for chain, rounds_ok in (("1", lambda r: r < 200), ("0", lambda r: r > 1000), (None, lambda r: 256 <= r < 456)):
+        if chain is None:
+            monkeypatch.delenv("HMK_LOOP_CHAIN")
+        else:
+            monkeypatch.setenv("HMK_LOOP_CHAIN", chain)
+        cid, order, stats = ctx.greedy_cluster(3, 0, 18, 3)
+        assert rounds_ok(ctx.greedy_phases()["loop_rounds"]), (chain, ctx.greedy_phases()["loop_rounds"])
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+        assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
 
 
 def test_greedy_3e5_vs_oracle(gpu, blosum62, coracle):

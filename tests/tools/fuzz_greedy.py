@@ -62,6 +62,8 @@ for trial in range(trials):
     ctx = hammock_amd.Context(M, device=[0, 0] if trial % 7 == 6 else 0)   # now and then a two-"device" context
     ctx.set_sequences(residues=res, offsets=off, sizes=sizes)
     info = {"trial": trial, "n": n, "len": [lo, hi], "X": X, "p": p, "thr": thr, "maxc": maxc, "second_loop": mode}
+    if os.environ.get("FUZZ_VERBOSE_FROM") and trial >= int(os.environ["FUZZ_VERBOSE_FROM"]):
+        print(json.dumps({**info, "devices": 2 if trial % 7 == 6 else 1, "oracle_status": int(st)}), flush=True)
     if st == c_oracle.HMO_ERR_REFERENCE_WOULD_CRASH:
         try:
             ctx.greedy_cluster(X, p, thr, maxc)
@@ -74,7 +76,11 @@ for trial in range(trials):
         crashes += 1
     else:
         assert st == 0, st
-        cid, order, gstats = ctx.greedy_cluster(X, p, thr, maxc)
+        try:
+            cid, order, gstats = ctx.greedy_cluster(X, p, thr, maxc)
+        except Exception as e:   # (not a parity failure: say which input it was)
+            print(json.dumps({"FAIL": "exception: " + repr(e), **info, "devices": 2 if trial % 7 == 6 else 1}))
+            raise
         if not (np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(ctx.member_rank[:n], ostats.member_rank)):
             print(json.dumps({"FAIL": "clusters differ", **info}))
             sys.exit(1)
