@@ -502,6 +502,30 @@ def test_greedy_multi_device_context(gpu, blosum62, coracle, devices, monkeypatc
     assert stats.n_edges == sstats.n_edges   # the shards together hold every edge exactly once
 
 
+@pytest.mark.parametrize("devices", [pytest.param(0, id="dev0"), pytest.param([0, 0], id="dev00")])
+def test_call_after_a_crash_parity_exit(gpu, blosum62, coracle, devices):
+    """A clustering call that ends with the reference's NullPointerException leaves phase 1 while the pass is still running and
+    never records the events its timing reads; the error of that timing call used to stay behind as the thread's last HIP error,
+    and the NEXT context's first kernel launch reported it ("invalid resource handle"; found by tests/tools/fuzz_greedy.py 500 12)."""
+    n = 20000
+    res, off = synth_peptides(5, n, 12)
+    st, _, _, ostats = coracle.greedy_cluster(blosum62, res, off, None, 0, 3, 0, 55, 500, 8)
+    assert st == coracle.HMO_ERR_REFERENCE_WOULD_CRASH
+    ctx = hammock_amd.Context(blosum62, device=devices)
+    ctx.set_sequences(residues=res, offsets=off)
+    with pytest.raises(hammock_amd.ReferenceWouldCrash) as ei:
+        ctx.greedy_cluster(3, 0, 55, 500)
+    assert (ei.value.case, ei.value.index) == (ostats.crash_case, ostats.crash_index)
+    del ctx
+    res2, off2 = synth_peptides(6, 3000, 7, 15)            # mixed lengths: side streams, several launches
+    st, ocid, oorder, _ = coracle.greedy_cluster(blosum62, res2, off2, None, 0, 3, -2, 19, 75, 8)
+    assert st == 0
+    ctx2 = hammock_amd.Context(blosum62, device=0)
+    ctx2.set_sequences(residues=res2, offsets=off2)
+    cid, order, _ = ctx2.greedy_cluster(3, -2, 19, 75)
+    assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+
+
 @pytest.mark.parametrize("delay_ms", [0, 150])
 def test_greedy_after_reserve_with_late_buffers(gpu, blosum62, coracle, monkeypatch, delay_ms):
     """hmk_reserve obtains the adjacency and bucket-record buffers on a thread of its own; a clustering call that starts while
