@@ -237,13 +237,35 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (pre_mode == 1 || (pre_mode == 2 && single_pass)) return true;
         if (getenv("HMK_HOST_PRECHECK")) return false;
         if (getenv("HMK_PRECHECK_TWO_PASSES")) single_pass = false;
-        if (!wait_full()) return false;
-        const auto tp = std::chrono::steady_clock::now();
         const uint32_t nl = (uint32_t)leftover.size();
         hipError_t r = ensure_buf(ctx, SB_COF, (size_t)n * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_USIZE, std::max<size_t>(usize.size(), 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_LEFT, std::max<size_t>(nl, 1) * 4);
+        if (r != hipSuccess) return false;
+        bool uploaded_early = false;
+        if (pre_mode == 0 && getenv("HMK_PRECHECK_LATE_UPLOAD") == nullptr) {
+            // Phase 1's result goes up on the copy stream NOW, while the pass and the CSR build are still running on the clustering
+            // stream (phase 1 ends before the scoring does at every size): three copies, the bitmap kernel and their launch latencies
+            // (~50 us at 10^5) leave the call's critical path.  Through a pinned block: an "async" upload from pageable memory is
+            // staged by the runtime chunk by chunk and the stream waits for it (0.3 ms for these 0.8 MB at 10^5).
+            const size_t b_cof = (size_t)n * 4, b_us = usize.size() * 4, b_left = (size_t)nl * 4;
+            r = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + b_cof + b_us + b_left + 64, 0);
+            if (r != hipSuccess) return false;
+            char *hs = (char *)ctx->h_stage + HMK_PRE_REGIONS * sizeof(unsigned long long);   // (the block starts with the single pass's region counters)
+            std::memcpy(hs, cluster_of, b_cof);
+            std::memcpy(hs + b_cof, usize.data(), b_us);
+            std::memcpy(hs + b_cof + b_us, leftover.data(), b_left);
+            r = hipMemcpyAsync(buf<int32_t>(ctx, SB_COF), hs, b_cof, hipMemcpyHostToDevice, C);
+            if (r == hipSuccess) r = launch_cluster_bitmap(buf<int32_t>(ctx, SB_COF), n, buf<uint32_t>(ctx, SB_BITMAP), C);
+            if (r == hipSuccess && b_us) r = hipMemcpyAsync(buf<int32_t>(ctx, SB_USIZE), hs + b_cof, b_us, hipMemcpyHostToDevice, C);
+            if (r == hipSuccess && b_left) r = hipMemcpyAsync(buf<uint32_t>(ctx, SB_LEFT), hs + b_cof + b_us, b_left, hipMemcpyHostToDevice, C);
+            if (r == hipSuccess) r = hipEventRecord(ctx->ev_bandcsr, C);   // (the band hand-over's event: that hand-over is long over, and in stream order before this)
+            if (r != hipSuccess) return false;
+            uploaded_early = true;
+        }
+        if (!wait_full()) return false;
+        const auto tp = std::chrono::steady_clock::now();
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CNT, std::max<size_t>(nl, 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_CSTART, ((size_t)nl + 1) * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_OVER, 64);
@@ -257,7 +279,9 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
         const void *d_adj = buf<void>(ctx, SB_ADJ);
         uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
-        if (pre_mode == 0) {
+        if (uploaded_early) {
+            r = hipStreamWaitEvent(S, ctx->ev_bandcsr, 0);
+        } else if (pre_mode == 0) {
             // through a pinned block: an "async" upload from pageable memory is staged by the runtime chunk by chunk and the
             // stream waits for it (0.3 ms for these 0.8 MB at 10^5, seen as the pre-check kernel starting late)
             const size_t b_cof = (size_t)n * 4, b_us = usize.size() * 4, b_left = (size_t)nl * 4;
@@ -392,15 +416,13 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                                          buf<uint32_t>(ctx, SB_FIRST), buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), S);
         if (r == hipSuccess) r = launch_loop_sort_subscribers(ncl, buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), buf<uint64_t>(ctx, SB_SUBS2), S);
         uint32_t *d_first = buf<uint32_t>(ctx, SB_FIRST), *d_taken = d_first + ncl, *d_clcursor = d_first + 2 * (size_t)ncl;
-        if (r == hipSuccess) r = hipMemsetAsync(d_taken, 0, (size_t)ncl * 4, S);
-        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_STATUS), 0, nl, S);
-        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_JSLOT), 0xFF, (size_t)nl * 4, S);
-        if (r == hipSuccess) r = hipMemsetAsync(buf<void>(ctx, SB_LCOUNT), 0, 64, S);
+        // (taken[], the statuses, the join slots and the counters are set by k_loop_init)
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CSIZE), csize.data(), (size_t)ncl * 8, hipMemcpyHostToDevice, S);
         if (r == hipSuccess) r = hipMemcpyAsync(buf<void>(ctx, SB_CID), cids.data(), (size_t)ncl * 4, hipMemcpyHostToDevice, S);
         if (r == hipSuccess) r = launch_loop_init(ncl, buf<long long>(ctx, SB_CSIZE), buf<int32_t>(ctx, SB_CID), buf<void>(ctx, SB_JOINED),
                                                   buf<uint32_t>(ctx, SB_SUBSTART), d_clcursor, nl, buf<uint32_t>(ctx, SB_ACTIVE),
-                                                  buf<uint32_t>(ctx, SB_DIRTY), buf<uint32_t>(ctx, SB_LCOUNT), S);
+                                                  buf<uint32_t>(ctx, SB_DIRTY), buf<uint32_t>(ctx, SB_LCOUNT), d_taken,
+                                                  buf<uint8_t>(ctx, SB_STATUS), buf<int32_t>(ctx, SB_JSLOT), S);
         if (r == hipSuccess && ctx->has_sizes)
             r = hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, S);
         uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);

@@ -106,8 +106,9 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
                              uint32_t *counters, unsigned long long *host_word, hipStream_t s);
 hipError_t launch_loop_sort_subscribers(uint32_t n_clusters, const uint32_t *sub_start, uint64_t *subs, uint64_t *tmp, hipStream_t s);
 // clusters: 16 bytes per cluster {joined = 0, id, size}, built on the device from the uploaded ids and sizes
-hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *clusters, const uint32_t *sub_start,
-                            uint32_t *cursor, uint32_t nl, uint32_t *list, uint32_t *dirty, uint32_t *counters, hipStream_t s);
+hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *cl, const uint32_t *sub_start,
+                            uint32_t *cursor, uint32_t nl, uint32_t *list, uint32_t *dirty, uint32_t *counters, uint32_t *taken,
+                            uint8_t *status, int32_t *join_slot, hipStream_t s);
 // join-propagation lists of the second loop (k_greedy_prop): lidx = sequence -> leftover index or -1
 hipError_t launch_fill_lidx(const uint32_t *leftover, uint32_t nl, int32_t *lidx, uint32_t n, hipStream_t s);
 hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, const uint32_t *up, const void *adj,

@@ -1589,22 +1589,23 @@ namespace hmk {
 __global__ void __launch_bounds__(256)
 k_loop_init(uint32_t n_clusters, const long long *__restrict__ csize, const int32_t *__restrict__ cid, LoopCluster *__restrict__ cl,
             const uint32_t *__restrict__ sub_start, uint32_t *__restrict__ cursor, uint32_t nl, uint32_t *__restrict__ list,
-            uint32_t *__restrict__ dirty, uint32_t *__restrict__ counters) {
+            uint32_t *__restrict__ dirty, uint32_t *__restrict__ counters, uint32_t *__restrict__ taken, uint8_t *__restrict__ status,
+            int32_t *__restrict__ join_slot) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n_clusters) { cl[t] = LoopCluster{0, cid[t], csize[t]}; cursor[t] = sub_start[t]; }
-    if (t < nl) { list[t] = t; dirty[t] = 1; }       // the first round evaluates every leftover
-    if (t == 0) counters[4] = nl;
+    if (t < n_clusters) { cl[t] = LoopCluster{0, cid[t], csize[t]}; cursor[t] = sub_start[t]; taken[t] = 0; }
+    if (t < nl) { list[t] = t; dirty[t] = 1; status[t] = LS_UNDECIDED; join_slot[t] = -1; }   // the first round evaluates every leftover
+    if (t < 16) counters[t] = t == 4 ? nl : 0u;      // (these were four fills of their own: ~8 us each on the call's critical path)
 }
 
 // state of the device-side second loop before its first round: per-cluster records (16 bytes each) from the uploaded sizes
 // and ids, the cursors at the heads of the (sorted) subscriber lists, eval list 0 = every leftover (counters: zeroed by
 // the caller beforehand)
 hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *cl, const uint32_t *sub_start,
-                            uint32_t *cursor, uint32_t nl, uint32_t *list, uint32_t *dirty, uint32_t *counters, hipStream_t s) {
-    const uint32_t m = std::max(n_clusters, nl);
-    if (m == 0) return hipSuccess;
+                            uint32_t *cursor, uint32_t nl, uint32_t *list, uint32_t *dirty, uint32_t *counters, uint32_t *taken,
+                            uint8_t *status, int32_t *join_slot, hipStream_t s) {
+    const uint32_t m = std::max<uint32_t>(std::max(n_clusters, nl), 16);
     hipLaunchKernelGGL(k_loop_init, dim3((m + 255) / 256), dim3(256), 0, s, n_clusters, csize, cid, (LoopCluster *)cl, sub_start, cursor,
-                       nl, list, dirty, counters);
+                       nl, list, dirty, counters, taken, status, join_slot);
     return hipGetLastError();
 }
 
