@@ -212,8 +212,14 @@ class PipelinedExchange:
         self.comm = torch.cuda.Stream(device)
         # warm-up pass sizes the score buffers (regrown if a segment overflows: denser data than uniform
         # random peptides) and the exchange block
+        # (torch.zeros / torch.empty run on the CURRENT stream; comp and comm are non-blocking streams that do not wait for it by
+        # themselves.  Without these waits the zero-fill of a freshly allocated counter block could land AFTER the warm-up pass had
+        # written it: the block then sized itself for 0 edges and the first real pass "overflowed" it -- once in ~15 runs of the
+        # two-rank test, and a possible failure of `bench.py --gpus N`.)
+        cur = torch.cuda.current_stream(device)
         while True:
             e, c = self._alloc_score()
+            self.comp.wait_stream(cur)
             ctx.neighbors_shifted_dev(*self.args, self.part, self.n_parts, e.data_ptr(), self.capacity, c.data_ptr(),
                                       self.comp.cuda_stream)
             self.comp.synchronize()
@@ -240,6 +246,8 @@ class PipelinedExchange:
         self.bytes_per_step = self.gathered[0].numel() * self.gathered[0].element_size()
         self.scored = [torch.cuda.Event() for _ in range(2)]
         self.packed = [torch.cuda.Event() for _ in range(2)]
+        self.comp.wait_stream(cur)   # the fills of buf[1] and msg[] above, before anything on the two streams touches them
+        self.comm.wait_stream(cur)
         self.work = [None, None]   # the all-gather in flight for each message buffer (async: the pack of the next
                                    # pass does not queue behind it on the communication stream)
         self.k = 0
