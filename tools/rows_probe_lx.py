@@ -29,14 +29,18 @@ out = {"L": L, "X": X, "lds_ideal_ms": round(ideal, 4)}
 for thr in thrs:
     ctx = hammock_amd.Context(load_blosum62(), device=0)
     ctx.set_sequences(residues=res, offsets=off)
-    ms = []
-    for _ in range(14):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        ctx.neighbors_shifted_dev(X, 0, thr, 0, 1, d_edges.data_ptr(), cap, d_counts.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
-        b.record()
-        torch.cuda.synchronize()
-        ms.append(a.elapsed_time(b))
+    # as bench.py measures: 12 settle passes back to back, then 20 timed ones between events on the launch stream, one synchronise
+    # (a synchronise after every pass let the GPU idle between passes: every figure 4-8 % slower than the same kernel in bench.py)
+    stream = torch.cuda.current_stream(dev)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for k in range(12 + 20):
+        if k >= 12:
+            evs[k - 12][0].record(stream)
+        ctx.neighbors_shifted_dev(X, 0, thr, 0, 1, d_edges.data_ptr(), cap, d_counts.data_ptr(), stream.cuda_stream)
+        if k >= 12:
+            evs[k - 12][1].record(stream)
+    torch.cuda.synchronize()
+    ms = [0.0] * 4 + [a.elapsed_time(b) for a, b in evs]
     med = float(np.median(ms[4:]))
     out[thr] = {"edges": int(d_counts.sum().item()), "ms_median": round(med, 4), "ms_min": round(float(min(ms[4:])), 4),
                 "frac": round(ideal / med, 3), "rows": int(ctx.last_plan().classes_rows)}
