@@ -195,26 +195,35 @@ def other_configs(M, dev, stream):
         n = len(lengths)
         cap = (1 << 22) // S * S
         d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
-        ms, sized = [], False
-        k = 0
-        while k < warm + reps:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
+        # a first pass sizes the edge buffer (its counts are exact even when a segment overflowed); then, as for the BASELINE line,
+        # `warm` untimed passes and `reps` timed ones BACK TO BACK, each between two events on the launch stream, one synchronise at
+        # the end (a synchronise after every pass lets the GPU idle between passes: 4-8 % slower figures, 30 % at 1e4)
+        est_ms = 1.0
+        for _ in range(2):
+            t_est = time.perf_counter()
             ctx.neighbors_shifted_dev(X, p, thr, part, n_parts, d_edges.data_ptr(), cap, d_counts.data_ptr(), stream.cuda_stream)
-            b.record(stream)
             torch.cuda.synchronize(dev)
-            if not sized:   # the counts of a pass are exact even when a segment overflowed: size the buffer from them, once
-                mx = int(d_counts.max().item())
-                if mx > cap // S:
-                    cap = (mx + mx // 8 + 1024) * S
-                    del d_edges
-                    d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
-                    sized = True
-                    continue
-                sized = True
+            est_ms = (time.perf_counter() - t_est) * 1e3
+            mx = int(d_counts.max().item())
+            if mx <= cap // S:
+                break
+            cap = (mx + mx // 8 + 1024) * S
+            del d_edges
+            d_edges = torch.empty(cap, dtype=torch.int64, device=dev)
+        t_est = time.perf_counter()   # (the passes above built the plan and sized the buffer: this one says how long a pass takes)
+        ctx.neighbors_shifted_dev(X, p, thr, part, n_parts, d_edges.data_ptr(), cap, d_counts.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        est_ms = (time.perf_counter() - t_est) * 1e3
+        warm = int(min(400, max(warm, np.ceil(40.0 / max(est_ms, 0.05)))))   # ~40 ms of load: the clocks of an idle MI355X settle in ~25 ms
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for k in range(warm + reps):
             if k >= warm:
-                ms.append(a.elapsed_time(b))
-            k += 1
+                evs[k - warm][0].record(stream)
+            ctx.neighbors_shifted_dev(X, p, thr, part, n_parts, d_edges.data_ptr(), cap, d_counts.data_ptr(), stream.cuda_stream)
+            if k >= warm:
+                evs[k - warm][1].record(stream)
+        torch.cuda.synchronize(dev)
+        ms = [a.elapsed_time(b) for a, b in evs]
         plan = ctx.last_plan()
         med = float(np.median(ms))
         ideal = lds_ideal_ms(lengths, X) * (int(plan.pairs_scored) / (n * (n - 1) / 2))
@@ -515,6 +524,13 @@ def main():
                             "band rows while the rest is scored, second loop on the device; phases overlap (see "
                             "include/hammock_hip.h hmk_greedy_phases)"}
             if not args.no_configs and n == N_SEQ:
+                # (the clustering context's streams go first: a process has few hardware queues, every live stream is mapped onto
+                # one of them, and the mixed-length pass of config 4a -- 26 launches dealt to three streams -- loses 8 % of its
+                # overlap when its streams share queues with idle ones: 4.53 ms inside this run against 4.17 ms on its own)
+                if not args.no_greedy:
+                    gctx.close()
+                if world == 1:
+                    ctx.close()   # (N > 1 still needs it for the end-to-end extra below)
                 t = time.perf_counter()
                 try:
                     line["configs"] = other_configs(M, dev, stream)
