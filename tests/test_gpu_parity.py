@@ -944,6 +944,12 @@ def test_clinkage_vs_oracle(gpu, blosum62, coracle, name):
             multi.set_sequences(residues=res, offsets=off, sizes=sizes)
             cid, order, _ = multi.clinkage_cluster(X, p, thr)
             assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(multi.member_rank[:len(cid)], orank)
+            os.environ["HMK_MULTI_SERIAL"] = "1"   # the conservative form of the multi-device call: same function, same answer
+            try:
+                cid, order, _ = multi.clinkage_cluster(X, p, thr)
+            finally:
+                del os.environ["HMK_MULTI_SERIAL"]
+            assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(multi.member_rank[:len(cid)], orank)
 
 
 @pytest.mark.parametrize("version", [7, 6])
