@@ -57,7 +57,13 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
         if (!ctx->ev_fork) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         std::vector<hipStream_t> lend;
         if (getenv("HMK_OWN_SIDE_STREAMS") == nullptr && ctx->gstream && ctx->copy_stream) {
-            if (stream != ctx->gstream && stream != ctx->copy_stream && stream != ctx->rest_stream) lend = {ctx->gstream, ctx->copy_stream};   // (rest_stream: a clustering call's second launch -- both are busy)
+            if (stream != ctx->gstream && stream != ctx->copy_stream && stream != ctx->rest_stream) {
+                // (rest_stream: a clustering call's second launch -- both are busy.)  HMK_LEND=prio: the high- and the low-priority
+                // stream instead of the clustering stream -- three priority classes are three hardware queues for certain, two
+                // normal-priority streams may share one
+                if (const char *v = getenv("HMK_LEND"); v && std::strcmp(v, "prio") == 0 && ctx->rest_stream) lend = {ctx->copy_stream, ctx->rest_stream};
+                else lend = {ctx->gstream, ctx->copy_stream};
+            }
             else if (stream == ctx->gstream && which == LAUNCH_ALL) lend = {ctx->copy_stream};
         }
         int own = 0;
