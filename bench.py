@@ -513,12 +513,17 @@ def main():
                 gctx.set_sequences(residues=res_sorted, offsets=off)
                 gctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, maxc)   # first call sizes the context's buffers
                 first = gctx.greedy_phases()
-                t = time.perf_counter()
-                cid, order, gstats = gctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, maxc)
-                wall = time.perf_counter() - t
+                walls, phases = [], []
+                for _ in range(3):   # three resident calls: the median is reported (one sample swings by 0.2 ms with the host)
+                    t = time.perf_counter()
+                    cid, order, gstats = gctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, maxc)
+                    walls.append(time.perf_counter() - t)
+                    phases.append(gctx.greedy_phases())
+                mid = int(np.argsort(walls)[1])
+                wall = walls[mid]
                 line["greedy_end_to_end"] = {
-                    "wall_s": wall, "first_call_s": first["total_ms"] * 1e-3, "host_sort_s": sort_s, "clusters": int(gstats.n_multi),
-                    "result_list": int(gstats.n_result_clusters), "phases_ms": gctx.greedy_phases(),
+                    "wall_s": wall, "wall_s_all": walls, "first_call_s": first["total_ms"] * 1e-3, "host_sort_s": sort_s, "clusters": int(gstats.n_multi),
+                    "result_list": int(gstats.n_result_clusters), "phases_ms": phases[mid],
                     "note": "hmk_greedy_cluster = the span of Hammock.java:409 on the sequences in the reference's default order "
                             "(-R size; host_sort_s = numpy's sort, the span of :407): scoring, CSR, phase 1 on the host over the "
                             "band rows while the rest is scored, second loop on the device; phases overlap (see "
