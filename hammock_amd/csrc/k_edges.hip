@@ -1396,18 +1396,39 @@ EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const uns
 // "cost of the band" of DESIGN.md 4.2; measured with HMK_BAND_NO_HANDOVER).  The kernels loop over their segment, so the grid is
 // sized for the edges to expect -- rows x n x 0.3 % -- at ~4,096 per workgroup, 4 .. 512 (10^5: 6 per segment; 2 .. 13 measure the
 // same, 32 costs the pass 0.1 ms, 128 and more 0.45 ms).
-static uint32_t band_grid_x(const EdgeSegs &segs, uint32_t n, uint32_t row_limit) {
+// (a multi-device root's list ends with one segment per peer that holds that peer's WHOLE block -- 64 times an ordinary segment:
+// `block` asks for the grid of those; the launchers below give the two kinds a launch each)
+static uint32_t band_grid_x(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool block = false) {
     if (const char *v = getenv("HMK_BAND_GRID")) return (uint32_t)std::max(1, std::min(512, atoi(v)));
     if (row_limit >= n) return 512;
-    const double per_seg = (double)row_limit * (double)n * 0.003 / (double)std::max<uint32_t>(segs.n, 1);
+    const double devices = segs.n > HMK_EDGE_SHARDS ? (double)(segs.n - HMK_EDGE_SHARDS + 1) : 1.0;
+    const double per_device = (double)row_limit * (double)n * 0.003 / devices;
+    const double per_seg = block ? per_device : per_device / HMK_EDGE_SHARDS;
     return (uint32_t)std::max(4.0, std::min(512.0, per_seg / 4096.0));
+}
+// the peers' block segments of a multi-device list as a list of their own (empty: a single-device list)
+static EdgeSegs peer_blocks(const EdgeSegs &segs) {
+    EdgeSegs b{};
+    for (uint32_t q = HMK_EDGE_SHARDS; q < segs.n; q++) b.s[b.n++] = segs.s[q];
+    return b;
+}
+static EdgeSegs own_segments(const EdgeSegs &segs) {
+    EdgeSegs o = segs;
+    o.n = std::min<uint32_t>(segs.n, HMK_EDGE_SHARDS);
+    return o;
 }
 
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
                                   uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s) {
     if (segs.n == 0 || segs.n > HMK_MAX_SEGS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_init_range, dim3(1), dim3(64), 0, s, score_range);
-    hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), segs.n), dim3(256), 0, s, segs, deg, symmetric ? 1 : 0, score_range, n, row_limit);
+    if (row_limit < n && segs.n > HMK_EDGE_SHARDS) {   // band of a multi-device root: its own segments and the peers' blocks, each at its size
+        const EdgeSegs own = own_segments(segs), blocks = peer_blocks(segs);
+        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), own.n), dim3(256), 0, s, own, deg, symmetric ? 1 : 0, score_range, n, row_limit);
+        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit, true), blocks.n), dim3(256), 0, s, blocks, deg, symmetric ? 1 : 0, score_range, n, row_limit);
+    } else {
+        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), segs.n), dim3(256), 0, s, segs, deg, symmetric ? 1 : 0, score_range, n, row_limit);
+    }
     launch_scan<uint64_t>(deg, start, row_limit, tile_scratch, nullptr, s);
     return hipGetLastError();
 }
@@ -1435,13 +1456,21 @@ hipError_t launch_csr_scatter_ranked(const EdgeSegs &segs, const uint64_t *edges
 
 hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
                               bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n) {
-    const uint32_t gx = n ? band_grid_x(segs, n, row_limit) : 512;   // (n given: the band's rows beside a running pass)
-    if (packed)
-        hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(gx, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj,
-                           symmetric ? 1 : 0, base, row_limit);
-    else
-        hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(gx, segs.n), dim3(256), 0, s, segs, start, cursor, (Nbr *)adj,
-                           symmetric ? 1 : 0, base, row_limit);
+    auto go = [&](const EdgeSegs &sg, uint32_t gx) {
+        if (sg.n == 0) return;
+        if (packed)
+            hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(gx, sg.n), dim3(256), 0, s, sg, start, cursor, (NbrPacked *)adj,
+                               symmetric ? 1 : 0, base, row_limit);
+        else
+            hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(gx, sg.n), dim3(256), 0, s, sg, start, cursor, (Nbr *)adj,
+                               symmetric ? 1 : 0, base, row_limit);
+    };
+    if (n && row_limit < n && segs.n > HMK_EDGE_SHARDS) {   // (n given: the band's rows beside a running pass; multi-device root: two kinds of segment)
+        go(own_segments(segs), band_grid_x(segs, n, row_limit));
+        go(peer_blocks(segs), band_grid_x(segs, n, row_limit, true));
+    } else {
+        go(segs, n ? band_grid_x(segs, n, row_limit) : 512);
+    }
     return hipGetLastError();
 }
 
