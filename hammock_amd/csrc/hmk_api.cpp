@@ -5,7 +5,6 @@
 
 using namespace hmk::impl;
 
-
 // =============================================================================
 // C ABI
 // =============================================================================

@@ -27,8 +27,6 @@
 
 using namespace hmk;
 
-
-
 namespace hmk { namespace impl {
 
 struct Group {
@@ -312,7 +310,6 @@ int neighbors_grow(hmk_ctx *ctx, uint64_t want_cap, unsigned long long counts[HM
     if (st == HMK_ERR_CAPACITY) return fail(ctx, HMK_ERR_DEVICE, "internal edge buffer kept overflowing");
     return st;
 }
-
 
 } }  // namespace hmk::impl
 #endif

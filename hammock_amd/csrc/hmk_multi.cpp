@@ -4,7 +4,6 @@
 
 namespace hmk { namespace impl {
 
-
 // hmk_greedy_cluster on a multi-device context: every device scores its row-block shard (no collective in the scoring),
 // the peers' edges travel to the root over xGMI as direct peer copies, every peer over its own link to the root, and the
 // root runs the usual tail on the union (CSR on the device, merge).
