@@ -268,7 +268,7 @@ def other_configs(M, dev, stream):
     lens = np.diff(off.astype(np.int64)).astype(np.float64)
     cells = float(lens.sum()) ** 2 - float((lens * lens).sum())      # sum over ordered pairs i != j of len_i * len_j
     issued_per_cell = None
-    for name in ("round4_neighbors_local_pmc.json", "round3_neighbors_local_pmc.json"):
+    for name in ("round5_neighbors_local_pmc.json", "round4_neighbors_local_pmc.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as fh:
                 issued_per_cell = float(json.load(fh)["valu_wave_instructions_per_64_cells"])
@@ -278,17 +278,33 @@ def other_configs(M, dev, stream):
     peak_lane_ops = 256 * 4 * 16 * 2.4e9
     med = float(np.median(ms[1:]))
     alg_lane_ops_per_cell = LOCAL_OPS_PER_CELL / 2.0
+    frac_convention = cells * alg_lane_ops_per_cell / (med * 1e-3) / peak_lane_ops
+    # Two figures under two names (they answer different questions, and neither is "percent of a floor"):
+    #   frac (= frac_at_6_lane_instructions_per_cell): the kernel's time against the time 6 lane-instructions per cell would take at
+    #     full VALU issue -- a CONVENTION (12 operations of the Java per cell, two cells per lane-operation), not a lower bound: a DP
+    #     step that needs fewer than 6 would read above 1.  The kernel's DP step proper is DP_STEP_LANE_INSTR_PER_CELL from the ISA.
+    #   frac_issued (= VALU-issue busy): what the hardware really issued (SQ_INSTS_VALU of the PMC pass, all in: DP step, table
+    #     loads' address arithmetic, threshold test, loop) x cells over the kernel time against the issue peak.  Bounded by 1.
+    DP_STEP_LANE_INSTR_PER_CELL = 10.75 / 2.0   # k_neighbors_local_pk's inner step: 10.75 VALU instructions per PAIR of cells
     out.append({"config": "4b: 1e5 x 7..20, LocalAlignmentScorer open -5, extend -1, all ordered pairs, thr 28", "kernel_ms": med,
                 "pairs": int(st.pairs_scored), "pairs_per_s": int(st.pairs_scored) / (med * 1e-3), "edges": int(len(edges)),
                 "dp_cells_per_s": cells / (med * 1e-3),
-                "roofline": {"bound": "valu-issue", "frac": cells * alg_lane_ops_per_cell / (med * 1e-3) / peak_lane_ops,
+                "roofline": {"bound": "valu-issue", "definition_version": 3,
+                             "frac": frac_convention,
+                             "frac_at_6_lane_instructions_per_cell": frac_convention,
+                             "frac_issued": (cells * issued_per_cell / (med * 1e-3) / peak_lane_ops) if issued_per_cell else None,
                              "algorithmic_ops_per_cell": LOCAL_OPS_PER_CELL, "cells_per_lane_operation": 2,
+                             "dp_step_lane_instructions_per_cell": DP_STEP_LANE_INSTR_PER_CELL,
                              "issued_valu_lane_instructions_per_cell": issued_per_cell,
-                             "definition": "DP cells x 12 integer operations per cell (LocalAlignmentScorer.java:43-81: 2 selects, 3 adds, 2 max, "
-                                           "1 clamp, 3 direction tests, 1 running max) / 2 cells per lane-operation (two column sequences in the "
-                                           "16-bit halves of a lane) over the kernel time, against 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz of "
-                                           "integer VALU issue; issued_valu_lane_instructions_per_cell (rocprofv3 SQ_INSTS_VALU) / 6 = what the "
-                                           "kernel spends beyond the algorithm's count"}})
+                             "definition": "VALU-issue busy at the algorithm's instruction CONVENTION, not a fraction of a floor: DP cells x 6 "
+                                           "lane-instructions per cell (LocalAlignmentScorer.java:43-81 counted as 12 operations -- 2 selects, 3 "
+                                           "adds, 2 max, 1 clamp, 3 direction tests, 1 running max -- / 2 cells per lane-operation: two column "
+                                           "sequences in the 16-bit halves of a lane) over the kernel time, against 256 CU x 4 SIMD x 16 lanes/clk "
+                                           "x 2.4 GHz.  The kernel's DP step is dp_step_lane_instructions_per_cell (ISA), all in it issues "
+                                           "issued_valu_lane_instructions_per_cell (rocprofv3 SQ_INSTS_VALU); frac_issued is the fraction from that "
+                                           "measured count (<= 1: the VALU pipe has no slack left), frac the one at the fixed 6.  What would make "
+                                           "config 4b faster is fewer instructions per cell, not better scheduling.  definition_version 3 (rounds "
+                                           "1-3: issued count; round 4: the convention only; now both)"}})
     ctx.close()
     return out
 

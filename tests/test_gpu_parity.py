@@ -834,6 +834,40 @@ def test_full_size_properties_1e5(gpu, blosum62, coracle):
     assert 1.5e-3 < len(edges) / stats.pairs_scored < 4e-3
 
 
+@pytest.mark.parametrize("case", [(7, 2, 12), (9, 2, 15), (15, 4, 26), (20, 5, 34), (12, 3, 14)],
+                         ids=["7mers", "9mers", "15mers", "20mers", "12mers_dense"])
+def test_full_size_properties_other_shapes_1e5(gpu, blosum62, coracle, case):
+    """The one-length shapes beside the BASELINE one at FULL size (10^5 peptides; a stale read in the flush showed in one
+    wave of four at this size and never at 1,400): the row-packed kernel runs, no edge twice, sampled edges carry the
+    oracle's score, complete rows have the oracle's degree -- and a second pass returns the same edge set (the stale-read
+    bug gave a different count every run).  (7, 2, 12), (9, 2, 15), (15, 4, 26), (20, 5, 34): the reference's defaults for
+    those lengths (Hammock.java:1409-1434); (12, 3, 14): the dense threshold on the BASELINE shape."""
+    L, X, thr = case
+    n = 100000
+    res, off = synth_peptides(L, n, L)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(X, 0, thr)
+    assert stats.classes_rows == 1 and stats.classes_u8 == 1, (case, stats.classes_rows, stats.classes_u8, stats.classes_u16)
+    assert stats.pairs_scored == n * (n - 1) // 2
+    first = np.sort(np.asarray(edges, dtype=np.uint64))
+    del edges
+    assert (first[1:] != first[:-1]).all(), "an edge was reported twice"
+    x, m, s = hammock_amd.edge_fields(first)
+    assert (x < m).all() and (s >= thr).all()
+    pick = np.random.default_rng(L).choice(len(first), 200000, replace=False)
+    st, want = coracle.score_pairs(blosum62, res, off, m[pick], x[pick], 0, X, 0)
+    assert st == 0 and np.array_equal(want, s[pick]), case
+    deg = np.bincount(x, minlength=n) + np.bincount(m, minlength=n)
+    del x, m, s
+    for r in np.random.default_rng(L + 1).choice(n, 40, replace=False):
+        st, sc = coracle.score_pairs(blosum62, res, off, np.arange(n, dtype=np.uint32), np.full(n, r, np.uint32), 0, X, 0)
+        sc[r] = -999
+        assert int((sc >= thr).sum()) == deg[r], (case, int(r))
+    again, _ = ctx.neighbors_shifted(X, 0, thr)
+    again = np.sort(np.asarray(again, dtype=np.uint64))
+    assert len(again) == len(first) and np.array_equal(again, first), (case, len(first), len(again))
+
+
 def test_score_with_shift_vs_oracle(gpu, blosum62, coracle):
     """AligningSequenceScorer.scoreWithShift: score AND shift (first strict maximum, sign rule :91-93)."""
     rng = np.random.default_rng(8)
