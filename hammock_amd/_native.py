@@ -58,9 +58,9 @@ class ClinkageStats(C.Structure):
 
 class GreedyPhases(C.Structure):
     """hmk_greedy_phases: where the time of the last greedy call went (milliseconds)."""
-    _fields_ = [(k, C.c_double) for k in ("plan_ms", "score_ms", "csr_ms", "wait_rows_ms", "phase1_ms", "precheck_ms", "prop_ms",
+    _fields_ = [(k, C.c_double) for k in ("plan_ms", "score_ms", "csr_ms", "wait_rows_ms", "phase1_ms", "precheck_ms", "exchange_ms",
                                           "device_loop_ms", "host_precheck_ms", "sequential_ms", "total_ms")] + \
-               [("cand_entries", C.c_uint64), ("prop_entries", C.c_uint64), ("loop_rounds", C.c_uint64)]
+               [("cand_entries", C.c_uint64), ("band_bytes", C.c_uint64), ("loop_rounds", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

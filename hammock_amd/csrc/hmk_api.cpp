@@ -33,7 +33,8 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
         }
     }
     ctx->device = device;
-    const bool timing = getenv("HMK_CLI_TIMING") != nullptr || getenv("HMK_GREEDY_TIMING") != nullptr;
+    ctx->sw.read();
+    const bool timing = ctx->sw.greedy_timing;
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -70,7 +71,7 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
         // What a first clustering call would otherwise pay: two HSA queues (streams), events, the pinned blocks (16-17 ms) and
         // the deferred load of the kernels' code objects (5-10 ms).  The reference constructs its scorer before it starts the
         // clock of "Clustering time" (Hammock.java:402-406), and a host can create the context while it still reads its input.
-        if (getenv("HMK_LAZY_CONTEXT") == nullptr) {
+        {
             bool ok = greedy_streams(ctx) == HMK_OK;
             lap("streams, events, pinned blocks, first copies");
             ok = ok && warm_neighbors_module() == hipSuccess;
@@ -89,9 +90,9 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
     return HMK_OK;
 }
 
-// a call whose failure changes nothing here -- but says so under HMK_DESTROY_TRACE, and never leaves its error behind as the
-// thread's "last error" for the next launch wrapper's hipGetLastError() to pick up
-#define HMK_QUIET(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) { if (getenv("HMK_DESTROY_TRACE")) fprintf(stderr, "[hmk destroy] %s: %s\n", #call, hipGetErrorString(e_)); (void)hipGetLastError(); } } while (0)
+// a call whose failure changes nothing here, and never leaves its error behind as the thread's "last error" for the next launch
+// wrapper's hipGetLastError() to pick up
+#define HMK_QUIET(call) do { if ((call) != hipSuccess) (void)hipGetLastError(); } while (0)
 void hmk_destroy(hmk_ctx *ctx) {
     if (!ctx) return;
     for (hmk_ctx *peer : ctx->peers) hmk_destroy(peer);
@@ -108,8 +109,6 @@ void hmk_destroy(hmk_ctx *ctx) {
         if (ctx->d_counts) HMK_QUIET(hipFree(ctx->d_counts));
         if (ctx->d_rows_scratch) HMK_QUIET(hipFree(ctx->d_rows_scratch));
         if (ctx->copy_stream) HMK_QUIET(hipStreamDestroy(ctx->copy_stream));
-        if (ctx->rest_stream) HMK_QUIET(hipStreamDestroy(ctx->rest_stream));
-        if (ctx->ev_rest) HMK_QUIET(hipEventDestroy(ctx->ev_rest));
         for (int k = 0; k < hmk_ctx::N_SIDE; k++) {
             if (ctx->side[k]) HMK_QUIET(hipStreamDestroy(ctx->side[k]));
             if (ctx->ev_join[k]) HMK_QUIET(hipEventDestroy(ctx->ev_join[k]));
@@ -138,6 +137,7 @@ int hmk_set_sequences(hmk_ctx *ctx, const uint8_t *residues, const uint32_t *off
                       uint32_t n) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     if (n > HMK_MAX_SEQUENCES) return fail(ctx, HMK_ERR_BAD_ARG, "more than 2^24 sequences");
     if (n && (!residues || !offsets)) return fail(ctx, HMK_ERR_BAD_ARG, "null residues/offsets");
     if (n && offsets[0] != 0) return fail(ctx, HMK_ERR_BAD_ARG, "offsets[0] must be 0");
@@ -233,6 +233,7 @@ int hmk_neighbors_shifted_dev(hmk_ctx *ctx, int max_shift, int shift_penalty, in
                               uint32_t n_parts, void *d_edges, uint64_t capacity, void *d_counts, void *stream) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     return neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, part, n_parts, d_edges, capacity, d_counts,
                                 (hipStream_t)stream);
 }
@@ -241,6 +242,7 @@ int hmk_compact_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t capacity, 
                           uint64_t out_capacity, void *d_total, void *stream) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     int st = need_device(ctx);
     if (st) return st;
     if (!d_edges || !d_counts || !d_out || !d_total || capacity < HMK_EDGE_SHARDS)
@@ -255,6 +257,7 @@ int hmk_pack_rows_dev(hmk_ctx *ctx, const void *d_edges, uint64_t capacity, cons
                       void *d_row_start, void *d_adj, uint64_t adj_capacity, void *stream) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     int st = need_device(ctx);
     if (st) return st;
     if (!d_edges || !d_counts || !d_row_start || !d_adj || capacity < HMK_EDGE_SHARDS)
@@ -281,6 +284,7 @@ int hmk_unpack_rows_dev(hmk_ctx *ctx, const void *d_row_start, const void *d_adj
                         uint64_t out_capacity, void *stream) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     int st = need_device(ctx);
     if (st) return st;
     if (!d_row_start || !d_adj || !d_edges_out) return fail(ctx, HMK_ERR_BAD_ARG, "hmk_unpack_rows_dev: null buffer");
@@ -293,6 +297,7 @@ int hmk_unpack_rows_dev(hmk_ctx *ctx, const void *d_row_start, const void *d_adj
 int hmk_neighbors_last_plan(hmk_ctx *ctx, hmk_neighbor_stats *stats) {
     if (!ctx || !stats) return fail(ctx, HMK_ERR_BAD_ARG, "null argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     if (!ctx->plan.valid) return fail(ctx, HMK_ERR_BAD_ARG, "no neighbour pass has been planned yet");
     *stats = ctx->plan.stats;
     return HMK_OK;
@@ -303,6 +308,7 @@ int hmk_neighbors_shifted(hmk_ctx *ctx, int max_shift, int shift_penalty, int th
                           hmk_neighbor_stats *stats) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     if (!n_edges) return fail(ctx, HMK_ERR_BAD_ARG, "n_edges must not be null");
     unsigned long long counts[HMK_EDGE_SHARDS];
     double ms = 0;
@@ -332,6 +338,7 @@ int hmk_neighbors_local(hmk_ctx *ctx, int gap_open, int gap_extend, int threshol
                         uint64_t *edges, uint64_t capacity, uint64_t *n_edges, hmk_neighbor_stats *stats) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     if (!n_edges) return fail(ctx, HMK_ERR_BAD_ARG, "n_edges must not be null");
     unsigned long long counts[HMK_EDGE_SHARDS];
     double ms = 0;
@@ -366,11 +373,12 @@ int hmk_greedy_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edges,
                           hmk_greedy_stats *stats) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     if (ctx->n && !cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
     if (n_edges && !edges) return fail(ctx, HMK_ERR_BAD_ARG, "null edge list");
     std::string err;
     int st = greedy_from_edges(ctx->n, ctx->has_sizes ? ctx->sizes.data() : nullptr, edges, n_edges, symmetric != 0,
-                               threshold, max_clusters, cluster_id, result_order, member_rank, stats, &err);
+                               threshold, max_clusters, cluster_id, result_order, member_rank, stats, &err, greedy_options(ctx));
     if (st) return fail(ctx, st, err);
     return HMK_OK;
 }
@@ -386,6 +394,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
                        int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     if (ctx->n && !cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
     hmk_greedy_stats local;
     if (!stats) stats = &local;
@@ -402,7 +411,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     if (!ctx->peers.empty())
         return greedy_cluster_multi(ctx, max_shift, shift_penalty, threshold, max_clusters, cluster_id, result_order, member_rank, stats);
     const auto t0 = std::chrono::steady_clock::now();
-    const bool call_timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+    const bool call_timing = ctx->sw.greedy_timing;
     auto call_lap = [&](const char *what) {
         if (call_timing) fprintf(stderr, "[hmk greedy] %s at %.2f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     };
@@ -412,7 +421,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     // stops once maxClusters clusters exist, normally a little after row maxClusters.  The tiles that complete the first
     // band_rows rows are launched first, their rows are handed to the host while the rest of the pair space is being scored.
     int64_t band_rows = 0;
-    if (max_clusters > 0 && n >= 16384 && getenv("HMK_NO_BAND") == nullptr)
+    if (max_clusters > 0 && n >= 16384 && !ctx->sw.no_band)
         band_rows = std::min<int64_t>(n, 2LL * max_clusters + 1024);
     if (band_rows * 2 > (int64_t)n) band_rows = 0;   // no point: the band would be most of the pass
     const int64_t band_req = band_rows;
@@ -426,7 +435,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     EdgeSource src;
     src.symmetric = ctx->symmetric;
     src.format_known = true;
-    src.packed = top - threshold <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr;
+    src.packed = top - threshold <= 255 && !ctx->sw.adj_8byte;
     src.base = threshold;
     src.check_overflow = true;
     if (!ctx->d_counts) HIPCHK(ctx, hipMalloc((void **)&ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long)));
@@ -446,112 +455,33 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
         src.segs = shard_segments(ctx->d_edges, seg, ctx->d_counts);
         src.adj_bound = (ctx->symmetric ? 2 : 1) * ctx->d_edges_cap;
         src.band_rows = (uint32_t)band_rows;
-        // HMK_BAND_CONCURRENT=1 (measured, rejected, kept as a switch): the band tiles and the others scored AT THE SAME TIME, two
-        // streams, the others' at the lowest priority, each launch into output segments of its own (the band's share of the
-        // HMK_EDGE_SHARDS segments = its share of the pairs; the snapshot of the band's cursors then names complete segments only
-        // -- in shared segments the other launch's waves would have reserved places they have not written yet).  The idea: one
-        // launch after the other leaves the GPU half empty twice, at the band's tail and at the rest's start (10^5: 3.4 ms of
-        // scoring against 3.0 ms in one launch).  What happened: the scoring took 3.33 ms, and the band's launch, sharing every
-        // CU with the other one whatever the priorities say, finished with it -- band rows on the host at 3.4 instead of 1.7 ms,
-        // the call 6.3 instead of 5.0 ms.  Results identical (the GPU test suite passes either way).
-        // HMK_BAND_ONE_LAUNCH=1 (measured, rejected, kept as a switch): ONE launch, band tiles first in dispatch order, segments of
-        // their own for them (the same share rule), and a counter every band tile's workgroup bumps when its edges are out
-        // (band_tile_done): a one-wave kernel on the hand-over stream waits for the counter (launch_wait_counter), and what is
-        // enqueued behind it -- the snapshot of the band's cursors, the band CSR, the copies -- starts when the band is complete.
-        // What happened at 10^5: the waiting kernel (and everything behind it) got no workgroup slot before the pass was over --
-        // band rows on the host at 3.8 ms instead of 1.7, the call 6.4 instead of 4.9 ms; with CUs kept free for it
-        // (HMK_CU_RESERVE=8: the clustering stream under a CU mask) the rows came at 1.4 ms, but the masked pass took 3.55 ms and
-        // the call 5.0 ms.  A kernel of another stream does not get in while a launch has workgroups waiting; the band launch's
-        // END is what lets the hand-over in.  So: two launches, one after the other, as in rounds 2-3.
-        uint32_t band_shards = 0;
-        const bool band_one_launch = band_rows > 0 && getenv("HMK_BAND_ONE_LAUNCH") != nullptr && getenv("HMK_BAND_CONCURRENT") == nullptr &&
-                                     ctx->plan.stats.pairs_scored > 0;
-        if (band_rows > 0 && (band_one_launch || getenv("HMK_BAND_CONCURRENT") != nullptr) && ctx->plan.stats.pairs_scored > 0) {
-            const double share = (double)ctx->plan.band_pairs / (double)ctx->plan.stats.pairs_scored;
-            band_shards = (uint32_t)std::min<double>(HMK_EDGE_SHARDS / 2, std::max<double>(2.0, std::ceil(share * HMK_EDGE_SHARDS)));
-        }
-        src.band_segs = band_shards ? shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS), 0, band_shards)
-                                    : shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS));
-        // the neighbour kernel places every edge in the CSR as it writes it: per row an upper and a lower counter (they end
-        // up as the sizes of the row's two sections; the upper ones ARE up[]) and, beside the edge, its two ranks
-        const bool fuse = getenv("HMK_NO_FUSED_DEGREE") == nullptr;
-        // (placing beat the atomic scatter up to 5 x 10^5 sequences -- 10^5 CSR 0.89 -> 0.42 ms, 3 x 10^5 6.0 -> 3.7 ms -- and lost to
-        // the bucketed one at every size: 10^5 0.31 ms, 3 x 10^5 2.1 ms, 5 x 10^5 5.7 against 12.1 ms, and the pass itself is 1-4 %
-        // faster without the returning atomics.  It stays as HMK_PLACE_EDGES=1.)
-        bool place = false;
-        if (const char *v = getenv("HMK_PLACE_EDGES")) place = fuse && atoi(v) != 0;
-        uint32_t *d_deg = nullptr, *d_deg_lo = nullptr, *d_rank = nullptr;
-        if (place) {
-            HIPCHK(ctx, ensure_buf(ctx, SB_CURSOR, (size_t)n * 8));
-            HIPCHK(ctx, ensure_buf(ctx, SB_RANK, ctx->d_edges_cap * 8));
-            d_deg = buf<uint32_t>(ctx, SB_CURSOR);
-            d_deg_lo = ctx->symmetric ? d_deg + n : nullptr;
-            d_rank = buf<uint32_t>(ctx, SB_RANK);
-            HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * 8, S));
-        } else if (fuse) {
-            // symmetric: the smaller end counts into up[], the larger into lo[] -- the same number of atomics as one total per
-            // row, and the lower counts give the bucket sizes of the CSR's dealing pass without a pass over the edges
-            // (k_lower_count, 2 ms at 10^6).  HMK_NO_SPLIT_DEGREE=1: one counter per row.
-            const bool split = ctx->symmetric && getenv("HMK_NO_SPLIT_DEGREE") == nullptr;
-            HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * (split ? 8 : 4)));
-            d_deg = buf<uint32_t>(ctx, SB_DEG);
-            d_deg_lo = split ? d_deg + n : nullptr;
-            HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * (split ? 8 : 4), S));
-            src.deg_split = split;
-        }
-        src.deg_fused = fuse;
-        src.placed = place;
-        src.edges0 = ctx->d_edges;
-        if (band_one_launch) {
-            uint32_t n_band_tiles = 0;
-            for (const Group &g : ctx->plan.groups) n_band_tiles += g.band;
-            HIPCHK(ctx, ensure_buf(ctx, SB_BANDCTR, 64));
-            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BANDCTR), 0, 64, S));
-            HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
-            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                      LAUNCH_ALL, band_req, d_deg, d_deg_lo, d_rank, band_shards, HMK_EDGE_SHARDS - band_shards, band_shards,
-                                      buf<uint32_t>(ctx, SB_BANDCTR));
-            call_lap("all tiles enqueued");
-            if (st) { (void)hipStreamSynchronize(S); return st; }
-            // the hand-over stream: behind the counter's memset, wait for the band tiles, then the snapshot of the band's cursors
-            hipStream_t C = ctx->copy_stream;
-            HIPCHK(ctx, hipStreamWaitEvent(C, ctx->ev_t0, 0));
-            HIPCHK(ctx, launch_wait_counter(buf<uint32_t>(ctx, SB_BANDCTR), n_band_tiles, buf<uint32_t>(ctx, SB_BANDCTR) + 1, C));
-            HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long),
-                                       hipMemcpyDeviceToDevice, C));
-            HIPCHK(ctx, hipEventRecord(ctx->ev_band, C));
-            src.band_gave_up = buf<uint32_t>(ctx, SB_BANDCTR) + 1;
-        } else {
+        // (Two launches, one after the other: the band launch's END is what lets the hand-over's kernels in -- a kernel of another
+        // stream gets no workgroup slot while a launch still has workgroups waiting.  Band and rest side by side on two streams, one
+        // launch with a counter the band tiles bump, CUs kept free by a mask: all measured, all slower)
+        src.band_segs = shard_segments(ctx->d_edges, seg, buf<unsigned long long>(ctx, SB_BCOUNTS));
+        // the neighbour kernel counts the rows' degrees while it writes the edges (the CSR build's first pass): symmetric scores: the
+        // smaller end counts into up[], the larger into lo[] -- the same number of atomics as one total per row, and the lower counts
+        // give the bucket sizes of the CSR's dealing pass without a pass over the edges (k_lower_count, 2 ms at 10^6)
+        const bool split = ctx->symmetric;
+        HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * (split ? 8 : 4)));
+        uint32_t *d_deg = buf<uint32_t>(ctx, SB_DEG), *d_deg_lo = split ? d_deg + n : nullptr;
+        HIPCHK(ctx, hipMemsetAsync(d_deg, 0, (size_t)n * (split ? 8 : 4), S));
+        src.deg_fused = true;
+        src.deg_split = split;
         HIPCHK(ctx, hipEventRecord(ctx->ev_t0, S));
         if (band_rows > 0) {
-            if (band_shards) {   // the cursors are zeroed HERE, ahead of the event the other launch's stream waits for
-                HIPCHK(ctx, hipMemsetAsync(ctx->d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), S));
-                HIPCHK(ctx, hipEventRecord(ctx->ev_rest, S));
-                HIPCHK(ctx, hipStreamWaitEvent(ctx->rest_stream, ctx->ev_rest, 0));
-            }
             st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                      band_shards ? LAUNCH_BAND_NOZERO : LAUNCH_BAND, band_req, d_deg, d_deg_lo, d_rank, 0,
-                                      band_shards ? band_shards : HMK_EDGE_SHARDS);
+                                      LAUNCH_BAND, band_req, d_deg, d_deg_lo);
             if (st) return st;
             HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_BCOUNTS), ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long),
                                        hipMemcpyDeviceToDevice, S));
             HIPCHK(ctx, hipEventRecord(ctx->ev_band, S));
             call_lap("band tiles enqueued");
         }
-        if (band_rows > 0 && band_shards) {
-            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, ctx->rest_stream,
-                                      LAUNCH_REST, band_req, d_deg, d_deg_lo, d_rank, band_shards, HMK_EDGE_SHARDS - band_shards);
-            if (st == HMK_OK) {
-                HIPCHK(ctx, hipEventRecord(ctx->ev_rest, ctx->rest_stream));
-                HIPCHK(ctx, hipStreamWaitEvent(S, ctx->ev_rest, 0));
-            }
-        } else {
-            st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
-                                      band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, d_deg, d_deg_lo, d_rank);
-        }
+        st = neighbors_dev_locked(ctx, max_shift, shift_penalty, threshold, 0, 1, ctx->d_edges, ctx->d_edges_cap, ctx->d_counts, S,
+                                  band_rows > 0 ? LAUNCH_REST : LAUNCH_ALL, band_req, d_deg, d_deg_lo);
         call_lap("all tiles enqueued");
-        if (st) { (void)hipStreamSynchronize(ctx->rest_stream); (void)hipStreamSynchronize(S); return st; }
-        }
+        if (st) { (void)hipStreamSynchronize(S); return st; }
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts, ctx->d_counts, HMK_EDGE_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S));
         HIPCHK(ctx, hipEventRecord(ctx->ev_edges, S));
         st = cluster_on_device(ctx, src, max_clusters, cluster_id, result_order, member_rank, stats, t0);
@@ -567,7 +497,7 @@ int hmk_greedy_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thres
     (void)hipGetLastError();   // (a call that left early never recorded these events: "invalid resource handle" must not stay behind as the thread's last error)
     ctx->phases.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     stats->neighbors_ms = ctx->phases.score_ms;
-    if (getenv("HMK_GREEDY_TIMING"))
+    if (call_timing)
         fprintf(stderr, "[hmk greedy] call %.2f ms: streams/events/pinned block %.2f, plan %.2f, %d buffer (re)allocations %.2f ms\n",
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_entry).count(),
                 std::chrono::duration<double, std::milli>(t0 - t_entry).count(), ctx->phases.plan_ms, g_allocs, g_alloc_ms);
@@ -612,6 +542,7 @@ int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     const auto t_call = std::chrono::steady_clock::now();
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     if (!ctx->has_device || n_sequences < 2) return HMK_OK;   // nothing to size
     const auto t_lock = std::chrono::steady_clock::now();
     int st = need_device(ctx);
@@ -625,7 +556,7 @@ int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences) {
         // what is there, and sizes the root's adjacency from it -- the single-device guess made those twice as large as needed)
         const uint64_t G = 1 + ctx->peers.size();
         uint64_t cap = first_edge_capacity(ctx, n_sequences);
-        if (G > 1 && getenv("HMK_EDGE_GUESS") == nullptr)
+        if (G > 1 && ctx->sw.edge_guess == 0)
             cap = std::max<uint64_t>({(uint64_t)((double)cap / G * 1.25), (uint64_t)1 << 20, ctx->d_edges_cap});
         st = grow_edge_buffer(ctx, (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS);
     }
@@ -633,8 +564,8 @@ int hmk_reserve(hmk_ctx *ctx, uint32_t n_sequences) {
     const int64_t maxc = (int64_t)(n_sequences * 0.025 + 0.5);      // Hammock.java:398-401, the default cluster limit
     int64_t band = n_sequences >= 16384 ? std::min<int64_t>(n_sequences, 2 * maxc + 1024) : 0;
     if (band * 2 > (int64_t)n_sequences) band = 0;
-    st = reserve_tail_buffers(ctx, n_sequences, true, (uint32_t)band, true, getenv("HMK_NO_LATE_BUFFERS") == nullptr);
-    if (getenv("HMK_GREEDY_TIMING") || getenv("HMK_CLI_TIMING")) {
+    st = reserve_tail_buffers(ctx, n_sequences, true, (uint32_t)band, true, true);
+    if (ctx->sw.greedy_timing) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         std::fprintf(stderr, "[hmk] hmk_reserve(%u): waited for the context %.1f ms, device + streams %.1f ms, buffers %.1f ms\n", n_sequences,
                      ms(t_call, t_lock), ms(t_lock, t_streams), ms(t_streams, std::chrono::steady_clock::now()));
@@ -646,6 +577,7 @@ int hmk_set_java_hashset(hmk_ctx *ctx, int version) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     if (version != 8 && version != 7 && version != 6) return fail(ctx, HMK_ERR_BAD_ARG, "hmk_set_java_hashset: 8 (Java 8+), 7 (JDK 7u6+) or 6 (JDK 6 / 7 before 7u6)");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     ctx->java_hashset = version;
     for (hmk_ctx *peer : ctx->peers) peer->java_hashset = version;
     return HMK_OK;
@@ -657,6 +589,7 @@ int hmk_greedy_from_edges_dev(hmk_ctx *ctx, const void *d_edges, uint64_t n_edge
                               int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *stats) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     int st = need_device(ctx);
     if (st) return st;
     if (ctx->n && !cluster_id) return fail(ctx, HMK_ERR_BAD_ARG, "null cluster_id");
@@ -692,6 +625,7 @@ int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                          int32_t *result_order, int32_t *member_rank, hmk_clinkage_stats *stats) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     hmk_clinkage_stats local;
     if (!stats) stats = &local;
     std::memset(stats, 0, sizeof(*stats));
@@ -727,7 +661,7 @@ int hmk_clinkage_cluster(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
     src.symmetric = true;
     src.segs = shard_segments(ctx->d_edges, ctx->d_edges_cap / HMK_EDGE_SHARDS, ctx->d_counts);
     src.format_known = true;
-    src.packed = top - threshold <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr;
+    src.packed = top - threshold <= 255 && !ctx->sw.adj_8byte;
     src.base = threshold;
     src.total_known = total;
     src.adj_bound = 2 * total;
@@ -746,6 +680,7 @@ int hmk_clinkage_from_edges(hmk_ctx *ctx, const uint64_t *edges, uint64_t n_edge
                             int32_t *member_rank, hmk_clinkage_stats *stats) {
     if (!ctx) return fail(nullptr, HMK_ERR_BAD_ARG, "null context");
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     hmk_clinkage_stats local;
     if (!stats) stats = &local;
     std::memset(stats, 0, sizeof(*stats));

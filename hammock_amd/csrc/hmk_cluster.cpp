@@ -13,7 +13,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     auto ms_since = [&](std::chrono::steady_clock::time_point a) {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
     };
-    const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+    const Switches &sw = ctx->sw;
+    const bool timing = sw.greedy_timing;
     auto lap = [&](const char *what) {
         if (timing) fprintf(stderr, "[hmk greedy] %s at %.2f ms\n", what, ms_since(t0));
     };
@@ -43,7 +44,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             const hipError_t e = ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(src.adj_bound, 1) * esz);   // (joins the thread)
             if (e != hipSuccess) return e;
         }
-        if (csr_by_bucket(n, symmetric, packed, src.deg_fused && src.placed)) {   // large graphs: lower sections dealt by bucket
+        if (csr_by_bucket(symmetric, packed)) {   // lower sections dealt by bucket
             uint64_t records = 1;   // one per edge: at most what the segments hold
             for (uint32_t q = 0; q < src.segs.n; q++) records += src.segs.s[q].cap;
             hipError_t e = ensure_buf(ctx, SB_PART, records * 8);   // in place already when hmk_greedy_cluster scored the edges itself
@@ -51,24 +52,18 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             if (e == hipSuccess)
                 e = launch_csr_scatter_partitioned(src.segs, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
                                                    base, n, buf<uint64_t>(ctx, SB_PART), buf<void>(ctx, SB_PARTSCR),
-                                                   src.deg_fused && src.deg_split ? buf<uint32_t>(ctx, SB_DEG) + n : nullptr, S);
+                                                   src.deg_fused && src.deg_split ? buf<uint32_t>(ctx, SB_DEG) + n : nullptr, sw.csr_bucket_shift, S);
             if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
             return e;
         }
-        hipError_t e = src.deg_fused && src.placed
-                           ? launch_csr_scatter_ranked(src.segs, src.edges0, buf<uint32_t>(ctx, SB_RANK), symmetric, buf<uint64_t>(ctx, SB_START),
-                                                       buf<void>(ctx, SB_ADJ), packed, base, S)
-                           : launch_csr_scatter(src.segs, symmetric, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR),
-                                                buf<void>(ctx, SB_ADJ), packed, base, n, S);
+        hipError_t e = launch_csr_scatter(src.segs, symmetric, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR),
+                                          buf<void>(ctx, SB_ADJ), packed, base, n, S);
         if (e == hipSuccess) e = hipEventRecord(ctx->ev_csr, S);
         return e;
     };
     auto enqueue_counts = [&]() -> hipError_t {
         hipError_t e_;
-        if (src.deg_fused && src.placed) {
-            if ((e_ = (launch_csr_scan_only(buf<uint32_t>(ctx, SB_CURSOR), symmetric ? buf<uint32_t>(ctx, SB_CURSOR) + n : nullptr,
-                                             buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S))) != hipSuccess) return e_;
-        } else if (src.deg_fused) {
+        if (src.deg_fused) {
             if ((e_ = (hipMemsetAsync(buf<void>(ctx, SB_CURSOR), 0, (size_t)n * 8, S))) != hipSuccess) return e_;
             if ((e_ = (launch_csr_scan_only(buf<uint32_t>(ctx, SB_DEG), src.deg_split ? buf<uint32_t>(ctx, SB_DEG) + n : nullptr,
                                              buf<uint64_t>(ctx, SB_START), n, buf<uint64_t>(ctx, SB_SCAN), buf<int>(ctx, SB_RANGE), S))) != hipSuccess) return e_;
@@ -92,17 +87,36 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     if (!src.before_full && !late_buffers) HIPCHK(ctx, enqueue_full());
 
     // ---- band: the first rows' adjacency from the edges of the band launch, on the copy stream --------------
-    uint32_t rows_here = 0;          // rows [0, rows_here) are valid in h_start / h_adj
+    uint32_t rows_lo = 0, rows_here = 0;   // rows [rows_lo, rows_here) are valid in h_start / the host adjacency block
+    uint64_t adj_off = 0;                  // ... which starts at entry adj_off of the CSR's adj[] (a window that begins past row 0)
     bool band_pending = false, band_used = false;
     uint32_t R1 = src.band_rows;
     if (R1 > 0 && src.before_band && src.before_band() != HMK_OK) R1 = 0;   // (the peers' band blocks did not make it: no band)
-    if (getenv("HMK_BAND_NO_HANDOVER")) R1 = 0;   // (measurement: the band is launched on its own but nothing is built from it)
+    // symmetric scores in 4-byte entries: the band reaches the host PREPARED for phase 1 (BandPack: near rows, best far
+    // candidates, transposed lists -- k_band_*); else as whole rows
+    const bool prepared = R1 > 0 && src.format_known && symmetric && packed;
+    constexpr uint32_t FAR_T = 8;
     if (R1 > 0 && src.format_known) {
         HIPCHK(ctx, ensure_buf(ctx, SB_BDEG, (size_t)R1 * 4));
         HIPCHK(ctx, ensure_buf(ctx, SB_BCURSOR, (size_t)R1 * 8));
         HIPCHK(ctx, ensure_buf(ctx, SB_BSTART, ((size_t)R1 + 1) * 8));
-        HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(R1)));
+        HIPCHK(ctx, ensure_buf(ctx, SB_BSCAN, scan_scratch_bytes(prepared ? n : R1)));
         HIPCHK(ctx, ensure_buf(ctx, SB_BRANGE, 64));
+        if (prepared) {
+            HIPCHK(ctx, ensure_buf(ctx, SB_BNCNT, (size_t)R1 * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_BNUP, (size_t)R1 * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_BNSTART, ((size_t)R1 + 1) * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_BFTOP, (size_t)R1 * FAR_T * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_BFMORE, (size_t)R1 + 64));
+            HIPCHK(ctx, ensure_buf(ctx, SB_FDEG, (size_t)n * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_FSTART, ((size_t)n + 1) * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_FCUR, (size_t)n * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_FOWNER, (size_t)n * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_TRCNT, (size_t)R1 * BandPack::TR_PER_ROW * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_TRSTART, ((size_t)R1 * BandPack::TR_PER_ROW + 1) * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_TROWNER, (size_t)R1 * BandPack::TR_PER_ROW * 4));
+            if (ctx->has_sizes) HIPCHK(ctx, ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4));
+        }
         HIPCHK(ctx, hipStreamWaitEvent(C, ctx->ev_band, 0));
         HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BDEG), 0, (size_t)R1 * 4, C));
         HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BCURSOR), 0, (size_t)R1 * 8, C));
@@ -113,9 +127,12 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         // (the band's own segments only: beside a pass that runs at the same time the other cursors are in motion)
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count,
                                    std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) * sizeof(unsigned long long), hipMemcpyDeviceToHost, C));
-        ((uint32_t *)(ctx->h_counts + HC_MISC))[7] = 0;
-        if (src.band_gave_up)
-            HIPCHK(ctx, hipMemcpyAsync((uint32_t *)(ctx->h_counts + HC_MISC) + 7, src.band_gave_up, 4, hipMemcpyDeviceToHost, C));
+        if (prepared) {   // (beside the degree pass: nothing below depends on the host)
+            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_FDEG), 0, (size_t)n * 4, C));
+            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_FCUR), 0, (size_t)n * 4, C));
+            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_FOWNER), 0, (size_t)n * 4, C));
+            if (ctx->has_sizes) HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, C));
+        }
         HIPCHK(ctx, hipEventRecord(ctx->ev_bandcsr, C));
         band_pending = true;
     }
@@ -148,7 +165,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 return false;
             }
             if (e == hipSuccess) {
-                packed = h_start[n] == 0 || ((long long)h_range[1] - h_range[0] <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr);
+                packed = h_start[n] == 0 || ((long long)h_range[1] - h_range[0] <= 255 && !sw.adj_8byte);
                 base = h_range[0];
                 esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
                 e = ensure_buf(ctx, SB_ADJ, std::max<uint64_t>(h_start[n], 1) * esz);
@@ -167,44 +184,161 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
 
     GreedyHooks hooks;
     double t_rows = 0;   // host time spent waiting for rows
-    hooks.need_rows = [&](uint32_t k) -> uint32_t {
+    // The band's row starts have landed and no band segment overflowed: its CSR is built on the device (copy stream).
+    // -> the number of entries, or -1: no band in this call (phase 1 then waits for the full graph)
+    auto band_csr = [&]() -> int64_t {
+        hipError_t e = hipEventSynchronize(ctx->ev_bandcsr);
+        bool ok = e == hipSuccess;
+        for (uint32_t q = 0; q < std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) && ok; q++) ok = ctx->h_counts[HC_BAND + q] <= src.seg_cap;
+        if (!ok) {
+            if (e != hipSuccess) hook_fail(HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e));
+            return -1;
+        }
+        const uint64_t entries = h_start[R1];
+        e = ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz);
+        if (e == hipSuccess)
+            e = launch_csr_scatter(src.band_segs, symmetric, buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BCURSOR),
+                                   buf<void>(ctx, SB_BADJ), packed, base, R1, C, n);
+        if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return -1; }
+        return (int64_t)entries;
+    };
+    // ---- the band, prepared for phase 1 (BandPack, hmk_internal.h) ---------------------------------------------------------
+    BandPack pack;
+    if (prepared) {
+        hooks.band_pack = [&]() -> const BandPack * {
+            if (!band_pending || ctx->wedged) return nullptr;
+            band_pending = false;
+            const auto tw = std::chrono::steady_clock::now();
+            const int64_t entries = band_csr();
+            if (entries < 0) return nullptr;
+            const uint32_t TRN = R1 * BandPack::TR_PER_ROW;
+            const uint64_t cap = std::max<uint64_t>((uint64_t)entries, 1);   // no list is longer than the band has entries
+            hipError_t e = ensure_buf(ctx, SB_BNEAR, cap * 4);
+            if (e == hipSuccess) e = ensure_buf(ctx, SB_FADJ, cap * 4);
+            if (e == hipSuccess) e = ensure_buf(ctx, SB_TR, cap * 4);
+            const uint64_t *d_bstart = buf<uint64_t>(ctx, SB_BSTART);
+            const uint32_t *d_bup = buf<uint32_t>(ctx, SB_BCURSOR);
+            uint32_t *d_ncnt = buf<uint32_t>(ctx, SB_BNCNT), *d_nup = buf<uint32_t>(ctx, SB_BNUP), *d_nstart = buf<uint32_t>(ctx, SB_BNSTART);
+            uint32_t *d_ftop = buf<uint32_t>(ctx, SB_BFTOP), *d_fdeg = buf<uint32_t>(ctx, SB_FDEG), *d_fstart = buf<uint32_t>(ctx, SB_FSTART);
+            uint32_t *d_trcnt = buf<uint32_t>(ctx, SB_TRCNT), *d_trstart = buf<uint32_t>(ctx, SB_TRSTART), *d_trowner = buf<uint32_t>(ctx, SB_TROWNER);
+            uint64_t *d_scan = buf<uint64_t>(ctx, SB_BSCAN);
+            if (e == hipSuccess)
+                e = launch_band_split(d_bstart, d_bup, buf<void>(ctx, SB_BADJ), R1, FAR_T, ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr,
+                                      d_ncnt, d_nup, d_ftop, buf<uint8_t>(ctx, SB_BFMORE), d_fdeg, C);
+            if (e == hipSuccess) e = launch_scan_u32(d_ncnt, d_nstart, R1, d_scan, C);
+            if (e == hipSuccess) e = launch_scan_u32(d_fdeg, d_fstart, n, d_scan, C);
+            if (e == hipSuccess)
+                e = launch_band_fill(d_bstart, d_bup, buf<void>(ctx, SB_BADJ), R1, d_nstart, buf<uint32_t>(ctx, SB_BNEAR), d_fstart,
+                                     buf<uint32_t>(ctx, SB_FCUR), buf<uint32_t>(ctx, SB_FADJ), C);
+            if (e == hipSuccess) e = launch_band_tr_claim(d_ftop, R1, FAR_T, BandPack::TR_PER_ROW, d_fdeg, buf<uint32_t>(ctx, SB_FOWNER), d_trcnt, C);
+            if (e == hipSuccess) e = launch_scan_u32(d_trcnt, d_trstart, TRN, d_scan, C);
+            if (e == hipSuccess)
+                e = launch_band_tr_fill(d_ftop, R1, FAR_T, BandPack::TR_PER_ROW, buf<uint32_t>(ctx, SB_FOWNER), d_fstart, d_fdeg, buf<uint32_t>(ctx, SB_FADJ),
+                                        d_trstart, d_trowner, buf<uint32_t>(ctx, SB_TR), C);
+            // the small arrays first (they hold the two totals), then the entries: one pinned block
+            //   near_start [R1 + 1] | near_up [R1] | far_top [R1 x FAR_T] | tr_owner [TRN] | tr_start [TRN + 1] | far_more [R1, padded] | near | tr
+            const size_t o_nstart = 0, o_nup = o_nstart + ((size_t)R1 + 1) * 4, o_ftop = o_nup + (size_t)R1 * 4, o_trowner = o_ftop + (size_t)R1 * FAR_T * 4,
+                         o_trstart = o_trowner + (size_t)TRN * 4, o_fmore = o_trstart + ((size_t)TRN + 1) * 4, o_near = (o_fmore + R1 + 63) / 64 * 64;
+            if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, o_near + 64, 0);
+            char *hb = (char *)ctx->h_adj;
+            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_nstart, d_nstart, ((size_t)R1 + 1) * 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_trstart, d_trstart, ((size_t)TRN + 1) * 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipStreamSynchronize(C);
+            uint64_t n_near = 0, n_tr = 0;
+            if (e == hipSuccess) {
+                n_near = ((const uint32_t *)(hb + o_nstart))[R1];
+                n_tr = ((const uint32_t *)(hb + o_trstart))[TRN];
+                if (n_near > cap || n_tr > cap) { hook_fail(HMK_ERR_DEVICE, "band hand-over: list sizes beyond the band's entries"); return nullptr; }
+            }
+            const size_t o_tr = o_near + (n_near * 4 + 63) / 64 * 64;
+            if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, o_tr + n_tr * 4 + 64, o_near);
+            hb = (char *)ctx->h_adj;
+            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_nup, d_nup, (size_t)R1 * 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_ftop, d_ftop, (size_t)R1 * FAR_T * 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_trowner, d_trowner, (size_t)TRN * 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_fmore, buf<void>(ctx, SB_BFMORE), R1, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess && n_near) e = hipMemcpyAsync(hb + o_near, buf<void>(ctx, SB_BNEAR), n_near * 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess && n_tr) e = hipMemcpyAsync(hb + o_tr, buf<void>(ctx, SB_TR), n_tr * 4, hipMemcpyDeviceToHost, C);
+            // (band_far reads a band row's upper section off the device: the rows' upper sizes are kept at hand)
+            if (e == hipSuccess) e = hipMemcpyAsync(h_up, d_bup, (size_t)R1 * 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipStreamSynchronize(C);
+            if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return nullptr; }
+            pack.rows = R1;
+            pack.far_t = FAR_T;
+            pack.near_start = (const uint32_t *)(hb + o_nstart);
+            pack.near_up = (const uint32_t *)(hb + o_nup);
+            pack.near = (const uint32_t *)(hb + o_near);
+            pack.far_top = (const uint32_t *)(hb + o_ftop);
+            pack.far_more = (const uint8_t *)(hb + o_fmore);
+            pack.tr_owner = (const uint32_t *)(hb + o_trowner);
+            pack.tr_start = (const uint32_t *)(hb + o_trstart);
+            pack.tr = (const uint32_t *)(hb + o_tr);
+            ph.band_bytes = (uint64_t)(o_tr + n_tr * 4);
+            t_rows += ms_since(tw);
+            lap("band prepared and on the host");
+            return &pack;
+        };
+        // a far sequence's band neighbours / a band row's far part, straight from the device (rare: a candidate beyond the lists sent)
+        hooks.far_row = [&](uint32_t id, std::vector<uint32_t> &out) -> bool {
+            out.clear();
+            uint32_t se[2] = {0, 0};
+            hipError_t e = hipMemcpyAsync(se, buf<uint32_t>(ctx, SB_FSTART) + id, 8, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipStreamSynchronize(C);
+            if (e == hipSuccess && se[1] > se[0]) {
+                out.resize(se[1] - se[0]);
+                e = hipMemcpyAsync(out.data(), buf<uint32_t>(ctx, SB_FADJ) + se[0], (size_t)(se[1] - se[0]) * 4, hipMemcpyDeviceToHost, C);
+                if (e == hipSuccess) e = hipStreamSynchronize(C);
+            }
+            if (e != hipSuccess) { hook_fail(HMK_ERR_DEVICE, std::string("band hand-over (a far sequence's list): ") + hipGetErrorString(e)); return false; }
+            return true;
+        };
+        hooks.band_far = [&](uint32_t x, std::vector<uint32_t> &out) -> bool {
+            out.clear();
+            const uint32_t up = h_up[x];
+            std::vector<uint32_t> row(up);
+            hipError_t e = hipSuccess;
+            if (up) {
+                e = hipMemcpyAsync(row.data(), buf<uint32_t>(ctx, SB_BADJ) + h_start[x], (size_t)up * 4, hipMemcpyDeviceToHost, C);
+                if (e == hipSuccess) e = hipStreamSynchronize(C);
+            }
+            if (e != hipSuccess) { hook_fail(HMK_ERR_DEVICE, std::string("band hand-over (a row's far part): ") + hipGetErrorString(e)); return false; }
+            for (uint32_t ent : row)
+                if ((ent >> 8) >= R1) out.push_back(ent);
+            return true;
+        };
+    }
+    hooks.need_rows = [&](uint32_t k, uint32_t from) -> uint32_t {
         if (ctx->wedged) return 0;   // (the second loop gave the device up: the merge stops here instead of waiting for it again)
-        if (k < rows_here) return rows_here;
+        if (from >= rows_lo && k < rows_here) return rows_here;
         const auto tw = std::chrono::steady_clock::now();
         hipError_t e = hipSuccess;
-        if (band_pending) {
+        if (band_pending) {   // (the band as whole rows: asymmetric scores or 8-byte entries)
             band_pending = false;
-            e = hipEventSynchronize(ctx->ev_bandcsr);
-            bool ok = e == hipSuccess && ((const uint32_t *)(ctx->h_counts + HC_MISC))[7] == 0;   // ([7]: the wait for the band tiles gave up)
-            for (uint32_t q = 0; q < std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) && ok; q++) ok = ctx->h_counts[HC_BAND + q] <= src.seg_cap;
-            if (ok) {
-                const uint64_t entries = h_start[R1];
-                e = ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz);
-                if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(entries, 1) * esz, 0);
-                if (e == hipSuccess)
-                    e = launch_csr_scatter(src.band_segs, symmetric, buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BCURSOR),
-                                           buf<void>(ctx, SB_BADJ), packed, base, R1, C, n);
+            const int64_t entries = band_csr();
+            if (entries < 0 && status_inside != HMK_OK) return 0;
+            if (entries >= 0) {
+                e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>((uint64_t)entries, 1) * esz, 0);
                 if (e == hipSuccess && entries)
-                    e = hipMemcpyAsync(ctx->h_adj, buf<void>(ctx, SB_BADJ), entries * esz, hipMemcpyDeviceToHost, C);
+                    e = hipMemcpyAsync(ctx->h_adj, buf<void>(ctx, SB_BADJ), (uint64_t)entries * esz, hipMemcpyDeviceToHost, C);
                 // the band rows' upper-section sizes travel with them: upper[] must never hold a previous call's values for rows
-                // the merge may read (today every reader refetches from the full CSR first; this keeps it true by construction)
+                // the merge may read
                 if (e == hipSuccess && symmetric)
                     e = hipMemcpyAsync(h_up, buf<uint32_t>(ctx, SB_BCURSOR), (size_t)R1 * 4, hipMemcpyDeviceToHost, C);
                 if (e == hipSuccess) e = hipStreamSynchronize(C);
-                if (e == hipSuccess) {
-                    rows_here = R1;
-                    band_used = true;
-                    lap("band rows on the host");
-                }
+                if (e != hipSuccess) { hook_fail(HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return 0; }
+                rows_lo = 0;
+                rows_here = R1;
+                adj_off = 0;
+                band_used = true;
+                lap("band rows on the host");
+                if (from == 0 && k < rows_here) { t_rows += ms_since(tw); return rows_here; }
             }
-            if (e != hipSuccess) { hook_fail(HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return 0; }
-            if (k < rows_here) { t_rows += ms_since(tw); return rows_here; }
         }
-        // more rows from the full CSR (which must be complete by now)
+        // rows from the full CSR (which must be complete by now): the window [rows_lo, rows_here) grows at its end, or begins anew
         if (!wait_full()) return 0;
-        if (band_used) { rows_here = 0; band_used = false; }   // the band rows come again, in the full CSR's layout
+        if (band_used || from < rows_lo || rows_here == rows_lo) { rows_lo = rows_here = from; band_used = false; }   // (band rows come again, in the full CSR's layout)
         uint32_t r_end = n;
-        if (k + 1 < n) r_end = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>({(uint64_t)k + 1, 2ull * rows_here, 8192ull}));
+        if (k + 1 < n) r_end = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>({(uint64_t)k + 1, (uint64_t)rows_here + (rows_here - rows_lo), (uint64_t)rows_here + 8192}));
         const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
         e = hipMemcpyAsync(h_start + rows_here, d_start + rows_here, ((size_t)(r_end - rows_here) + 1) * 8, hipMemcpyDeviceToHost, C);
         if (e == hipSuccess && symmetric)
@@ -212,9 +346,10 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (e == hipSuccess) e = hipStreamSynchronize(C);
         if (e == hipSuccess) {
             const uint64_t a0 = h_start[rows_here], a1 = h_start[r_end];
-            e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(a1, 1) * esz, a0 * esz);
+            if (rows_here == rows_lo) adj_off = a0;
+            e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(a1 - adj_off, 1) * esz, (a0 - adj_off) * esz);
             if (e == hipSuccess && a1 > a0)
-                e = hipMemcpyAsync((char *)ctx->h_adj + a0 * esz, (const char *)buf<void>(ctx, SB_ADJ) + a0 * esz, (a1 - a0) * esz,
+                e = hipMemcpyAsync((char *)ctx->h_adj + (a0 - adj_off) * esz, (const char *)buf<void>(ctx, SB_ADJ) + a0 * esz, (a1 - a0) * esz,
                                    hipMemcpyDeviceToHost, C);
             if (e == hipSuccess) e = hipStreamSynchronize(C);
         }
@@ -226,8 +361,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
 
     // ---- second loop on the device-resident CSR ---------------------------------------------------------------
     // (1) pre-check (k_greedy_precheck): per leftover the clusters that are feasible after phase 1 -> cand CSR on the device.
-    // Then either (2a) small / medium inputs: join-propagation lists (k_greedy_prop), the sequential loop runs on the
-    // host over those lists; or (2b) large inputs: the loop itself runs on the device level by level (k_greedy_level).
+    // (2) the loop itself on the device in optimistic rounds (k_loop_*); where that does not apply (asymmetric scores, a
+    // table overflow, HMK_SECOND_LOOP=host) the host's sequential loop takes the candidate lists.
     // pre_mode: 0 nothing yet, 1 = two passes done (cand_start[] are prefix sums: what the host-side consumers read),
     // 2 = one pass done (every leftover's block lies where the global counter put it: the device loop takes either)
     int pre_mode = 0;
@@ -235,8 +370,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     auto device_precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<uint32_t> &leftover,
                                bool single_pass) -> bool {
         if (pre_mode == 1 || (pre_mode == 2 && single_pass)) return true;
-        if (getenv("HMK_HOST_PRECHECK")) return false;
-        if (getenv("HMK_PRECHECK_TWO_PASSES")) single_pass = false;
+        if (sw.precheck == 1) single_pass = false;   // (HMK_PRECHECK=two_passes: the count + fill form a region overrun falls back to)
         const uint32_t nl = (uint32_t)leftover.size();
         hipError_t r = ensure_buf(ctx, SB_COF, (size_t)n * 4);
         if (r == hipSuccess) r = ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4);
@@ -244,7 +378,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = ensure_buf(ctx, SB_LEFT, std::max<size_t>(nl, 1) * 4);
         if (r != hipSuccess) return false;
         bool uploaded_early = false;
-        if (pre_mode == 0 && getenv("HMK_PRECHECK_LATE_UPLOAD") == nullptr) {
+        if (pre_mode == 0) {
             // Phase 1's result goes up on the copy stream NOW, while the pass and the CSR build are still running on the clustering
             // stream (phase 1 ends before the scoring does at every size): three copies, the bitmap kernel and their launch latencies
             // (~50 us at 10^5) leave the call's critical path.  Through a pinned block: an "async" upload from pageable memory is
@@ -281,20 +415,6 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
         if (uploaded_early) {
             r = hipStreamWaitEvent(S, ctx->ev_bandcsr, 0);
-        } else if (pre_mode == 0) {
-            // through a pinned block: an "async" upload from pageable memory is staged by the runtime chunk by chunk and the
-            // stream waits for it (0.3 ms for these 0.8 MB at 10^5, seen as the pre-check kernel starting late)
-            const size_t b_cof = (size_t)n * 4, b_us = usize.size() * 4, b_left = (size_t)nl * 4;
-            r = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + b_cof + b_us + b_left + 64, 0);
-            if (r != hipSuccess) return false;
-            char *hs = (char *)ctx->h_stage + HMK_PRE_REGIONS * sizeof(unsigned long long);   // (the block starts with the single pass's region counters)
-            std::memcpy(hs, cluster_of, b_cof);
-            std::memcpy(hs + b_cof, usize.data(), b_us);
-            std::memcpy(hs + b_cof + b_us, leftover.data(), b_left);
-            r = hipMemcpyAsync(d_cof, hs, b_cof, hipMemcpyHostToDevice, S);
-            if (r == hipSuccess) r = launch_cluster_bitmap(d_cof, n, buf<uint32_t>(ctx, SB_BITMAP), S);
-            if (r == hipSuccess && b_us) r = hipMemcpyAsync(d_usize, hs + b_cof, b_us, hipMemcpyHostToDevice, S);
-            if (r == hipSuccess && b_left) r = hipMemcpyAsync(d_left, hs + b_cof + b_us, b_left, hipMemcpyHostToDevice, S);
         }
         if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 16, S);
         if (r == hipSuccess && single_pass) {
@@ -317,9 +437,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             // (10^6 default-threshold 12-mers give an estimate of 130; small tables first for them too -- 512 slots, five workgroups
             // per CU instead of two -- was measured and loses: 22.0 against 18.7 ms, 38.9 against 25.8 ms in the reference's
             // default order, where many rows see far more clusters than the average and are scanned twice)
-            double two_stage_limit = 100.0;
-            if (const char *v = getenv("HMK_PRECHECK_TWO_STAGE_LIMIT")) two_stage_limit = atof(v);
-            if (r == hipSuccess && est <= two_stage_limit && getenv("HMK_PRECHECK_ONE_STAGE") == nullptr) {
+            const double two_stage_limit = 100.0;
+            if (r == hipSuccess && est <= two_stage_limit && sw.precheck != 2) {   // (HMK_PRECHECK=one_stage: what dense rows run)
                 r = ensure_buf(ctx, SB_RETRY, std::max<size_t>(nl, 1) * 4);
                 d_retry = buf<uint32_t>(ctx, SB_RETRY);
             }
@@ -374,15 +493,12 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (r == hipSuccess) r = hipStreamSynchronize(S);
         return r == hipSuccess;
     };
-    const char *loop_mode = getenv("HMK_SECOND_LOOP");   // "device" / "lists" / "host": force one implementation (tests)
-    const bool force_device = loop_mode && std::strcmp(loop_mode, "device") == 0;
-    const bool forbid_device = loop_mode && !force_device;
-    const bool forbid_lists = loop_mode && std::strcmp(loop_mode, "lists") != 0;
+    const bool forbid_device = sw.second_loop == 2;   // HMK_SECOND_LOOP=host (tests: the host's sequential loop over the candidate lists)
 
     hooks.device_loop = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<int64_t> &csize,
                             const std::vector<int32_t> &cids, const std::vector<uint32_t> &leftover,
                             std::vector<int32_t> &join_slot) -> bool {
-        if (forbid_device || !symmetric) return false;
+        if (forbid_device || !symmetric || !ctx->h_loop) return false;   // (no coherent host block for the progress word: the host loop)
         if (!device_precheck(cluster_of, usize, leftover, true)) return false;
         // (measured: the device-side loop beats the host loop over device-built lists at every size -- 1e5 uniform 12-mers
         // 7.5 against 9.5 ms end to end, the antibodies example 14 against 18 ms; the lists stay as the second path)
@@ -425,16 +541,14 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                                   buf<uint8_t>(ctx, SB_STATUS), buf<int32_t>(ctx, SB_JSLOT), S);
         if (r == hipSuccess && ctx->has_sizes)
             r = hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, S);
-        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
         uint32_t rounds = 0;
         bool done = false;
         // a second first/accept pass per round saves a third of the rounds; it pays once a round's apply and eval are big enough
-        int accept_passes = ncl >= 8192 ? 2 : 1;
-        if (const char *v = getenv("HMK_LOOP_PASSES")) accept_passes = std::min(8, std::max(1, atoi(v)));
+        const int accept_passes = sw.loop_passes > 0 ? sw.loop_passes : ncl >= 8192 ? 2 : 1;
         // Every round accepts at least the earliest open leftover that has a feasible cluster, so nl + 1 rounds always suffice
         // and a round without a join is the end.  The host keeps enqueuing rounds while it watches the progress word that
         // k_loop_apply stores into pinned host memory (round << 32 | joins of that round), at most LOOKAHEAD rounds ahead of
-        // the device; rounds enqueued after the end find nothing to do.  Without the word: batches of rounds and a sync each.
+        // the device; rounds enqueued after the end find nothing to do.
         auto one_round = [&]() {
             r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
                                   buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART), buf<uint32_t>(ctx, SB_CNT),
@@ -442,17 +556,15 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                   buf<uint32_t>(ctx, SB_ACTIVE), buf<uint32_t>(ctx, SB_DIRTY), rounds, d_first, d_taken, d_clcursor,
                                   ncl, accept_passes, buf<uint32_t>(ctx, SB_ACCEPTED), buf<int32_t>(ctx, SB_JSLOT),
                                   buf<uint32_t>(ctx, SB_SUBSTART), buf<uint64_t>(ctx, SB_SUBS), buf<void>(ctx, SB_JOINED),
-                                  ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), ctx->h_loop, S);
+                                  ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_LCOUNT), ctx->h_loop, sw.loop_chain, S);
             rounds++;
         };
         if (nl == 0 || ncl == 0) {
             done = true;
-        } else if (ctx->h_loop && getenv("HMK_LOOP_BATCHES") == nullptr) {
-            uint32_t LOOKAHEAD = 4;   // a round is 4-6 small dependent kernels: a few rounds in the queue keep the device busy
-            if (const char *v = getenv("HMK_LOOP_LOOKAHEAD")) LOOKAHEAD = (uint32_t)std::max(1, atoi(v));
+        } else {
+            const uint32_t LOOKAHEAD = 4;   // a round is 4-6 small dependent kernels: a few rounds in the queue keep the device busy
             volatile unsigned long long *word = ctx->h_loop;
             *word = 0;
-            const bool loop_trace = getenv("HMK_LOOP_TRACE") != nullptr;   // (with HMK_LOOP_LOOKAHEAD=1 every round is seen)
             // never spin forever: the deadline runs from the last round the device was SEEN to finish (a long loop is fine, a
             // stalled device is not) and is looked at on every poll (a few thousand spins apart)
             auto t_progress = std::chrono::steady_clock::now();
@@ -468,7 +580,6 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                     if (seen != last_seen) {
                         last_seen = seen;
                         t_progress = std::chrono::steady_clock::now();
-                        if (loop_trace) std::fprintf(stderr, "[hmk greedy] loop round %u: %u joins, %.3f ms since the loop began\n", seen, (uint32_t)w, ms_since(tl));
                     }
                     else if ((spins & 1023u) == 1023u && ms_since(t_progress) > 60e3) { stalled = true; break; }
                     std::this_thread::yield();
@@ -497,20 +608,6 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 done = r == hipSuccess && (uint32_t)*word == 0;
             }
             if (r == hipSuccess) r = hipStreamSynchronize(S);       // drain the rounds enqueued past the end
-            if (loop_trace && r == hipSuccess) {   // (a build with -DHMK_APPLY_STATS=1 fills these)
-                uint32_t hc[16] = {0};
-                if (hipMemcpy(hc, buf<uint32_t>(ctx, SB_LCOUNT), 64, hipMemcpyDeviceToHost) == hipSuccess && (hc[8] | hc[10]))
-                    std::fprintf(stderr, "[hmk greedy] apply walked %u subscriber entries (longest list %u) and %u row entries (longest row %u); "
-                                         "joins took %.2f ms in all (longest %.1f us), of which table build %.2f ms, subscribers %.2f ms\n",
-                                 hc[8], hc[9], hc[10], hc[11], hc[12] * 1e-5, hc[13] * 1e-2, hc[14] * 1e-5, hc[15] * 1e-5);
-            }
-        } else {
-            for (uint32_t batch = 8; r == hipSuccess && !done && rounds <= nl + 8; batch = std::min<uint32_t>(batch * 2, 64)) {
-                for (uint32_t b = 0; b < batch && r == hipSuccess; b++) one_round();
-                if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[3], buf<uint32_t>(ctx, SB_LCOUNT) + 3, 4, hipMemcpyDeviceToHost, S);
-                if (r == hipSuccess) r = hipStreamSynchronize(S);
-                done = r == hipSuccess && h_misc[3] == 0;
-            }
         }
         if (r != hipSuccess || !done) return false;
         join_slot.resize(nl);
@@ -528,63 +625,14 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     };
 
     hooks.precheck = [&](const int32_t *cluster_of, const std::vector<int32_t> &usize, const std::vector<uint32_t> &leftover,
-                         bool want_prop, std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand,
-                         std::vector<uint32_t> &prop_start, std::vector<GreedyProp> &prop, bool *have_prop) -> bool {
-        *have_prop = false;
+                         std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand) -> bool {
         if (!device_precheck(cluster_of, usize, leftover, false)) return false;
-        const uint32_t nl = (uint32_t)leftover.size();
-        const uint32_t total_c = pre_total_c;
-        if (!fetch_cand(nl, cand_start, cand)) return false;
+        if (!fetch_cand((uint32_t)leftover.size(), cand_start, cand)) return false;
         lap("device pre-check");
-        if (!want_prop || !symmetric || forbid_lists || getenv("HMK_HOST_PROPAGATION")) return true;
-        // ---- join-propagation lists -------------------------------------------------------------------------
-        const auto tq = std::chrono::steady_clock::now();
-        prop_start.assign((size_t)total_c + 1, 0);
-        prop.clear();
-        if (total_c == 0) { *have_prop = true; return true; }
-        hipError_t r = ensure_buf(ctx, SB_LIDX, (size_t)n * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_PCNT, (size_t)total_c * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_PSTART, ((size_t)total_c + 1) * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>({nl, n, total_c})));
-        if (r != hipSuccess) return true;   // candidates are fine; the merge falls back to stamping rows
-        uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
-        int32_t *d_lidx = buf<int32_t>(ctx, SB_LIDX);
-        uint32_t *d_pcnt = buf<uint32_t>(ctx, SB_PCNT), *d_pstart = buf<uint32_t>(ctx, SB_PSTART);
-        const uint32_t *d_up = buf<uint32_t>(ctx, SB_CURSOR);
-        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
-        const void *d_adj = buf<void>(ctx, SB_ADJ);
-        const uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
-        r = launch_fill_lidx(d_left, nl, d_lidx, n, S);
-        if (r == hipSuccess) r = hipMemsetAsync(d_pcnt, 0, (size_t)total_c * 4, S);
-        if (r == hipSuccess) r = launch_greedy_prop(false, packed, d_start, d_up, d_adj, d_lidx, d_left, nl, d_cstart,
-                                                    buf<GreedyCand>(ctx, SB_CAND), d_pcnt, nullptr, nullptr, S);
-        if (r == hipSuccess) r = launch_scan_u32(d_pcnt, d_pstart, total_c, d_scan, S);
-        unsigned long long *h_total = ctx->h_counts + HC_TOTAL;   // the scan's 64-bit grand total (its uint32 start[] may wrap)
-        if (r == hipSuccess) r = hipMemcpyAsync(h_total, d_scan + scan_total_index(total_c), 8, hipMemcpyDeviceToHost, S);
-        if (r == hipSuccess) r = hipStreamSynchronize(S);
-        if (r != hipSuccess) return true;
-        if (*h_total > (1ull << 28)) return true;   // very dense families: let the host stamp rows instead (2 GB of lists)
-        const uint32_t total_p = (uint32_t)*h_total;
-        prop.resize(total_p);
-        r = hipMemcpyAsync(prop_start.data(), d_pstart, ((size_t)total_c + 1) * 4, hipMemcpyDeviceToHost, S);
-        if (r == hipSuccess && total_p) {
-            r = ensure_buf(ctx, SB_PROP, (size_t)total_p * sizeof(GreedyProp));
-            if (r == hipSuccess) r = hipMemsetAsync(d_pcnt, 0, (size_t)total_c * 4, S);
-            if (r == hipSuccess) r = launch_greedy_prop(true, packed, d_start, d_up, d_adj, d_lidx, d_left, nl, d_cstart,
-                                                        buf<GreedyCand>(ctx, SB_CAND), d_pcnt, d_pstart, buf<GreedyProp>(ctx, SB_PROP), S);
-            if (r == hipSuccess) r = hipMemcpyAsync(prop.data(), buf<GreedyProp>(ctx, SB_PROP), (size_t)total_p * sizeof(GreedyProp),
-                                                    hipMemcpyDeviceToHost, S);
-        }
-        if (r == hipSuccess) r = hipStreamSynchronize(S);
-        if (r != hipSuccess) { prop.clear(); return true; }
-        *have_prop = true;
-        ph.prop_ms = ms_since(tq);
-        ph.prop_entries = total_p;
-        lap("device join-propagation lists");
         return true;
     };
 
-    hooks.adj_base = [&]() -> const void * { return ctx->h_adj; };
+    hooks.adj_base = [&]() -> const void * { return (const char *)ctx->h_adj - adj_off * esz; };
     GreedyTimes times{};
     hooks.times = &times;
     std::string err;
@@ -593,7 +641,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         // clinkage mode: the chain needs every row; fetch the whole adjacency, then run it on the host
         int cst = HMK_OK;
         if (!src.format_known && !wait_full()) cst = -1;
-        if (cst == HMK_OK && n && hooks.need_rows(n - 1) < n) cst = -1;
+        if (cst == HMK_OK && n && hooks.need_rows(n - 1, 0) < n) cst = -1;
         if (cst == HMK_OK)
             cst = packed ? clinkage_from_csr_packed(ctx->java_hashset, n, szs, h_start, (const NbrPacked *)ctx->h_adj, cluster_id, result_order, member_rank,
                                                     src.clink, &err)
@@ -617,10 +665,11 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             return status_inside == ST_RETRY_OVERFLOW ? ST_RETRY_OVERFLOW : fail(ctx, status_inside, hook_err);
         }
     }
+    const GreedyOptions gopt = greedy_options(ctx);
     st = packed ? greedy_from_csr_packed(n, szs, h_start, (const NbrPacked *)ctx->h_adj, symmetric ? h_up : nullptr, &hooks, symmetric,
-                                         max_clusters, cluster_id, result_order, member_rank, stats, &err)
+                                         max_clusters, cluster_id, result_order, member_rank, stats, &err, gopt)
                 : greedy_from_csr(n, szs, h_start, (const Nbr *)ctx->h_adj, symmetric ? h_up : nullptr, &hooks, symmetric, max_clusters,
-                                  cluster_id, result_order, member_rank, stats, &err);
+                                  cluster_id, result_order, member_rank, stats, &err, gopt);
     // nothing of this call may still be running when the buffers are reused (a crash-parity exit leaves the pass in flight)
     if (!ctx->wedged) {
         (void)hipStreamSynchronize(S);

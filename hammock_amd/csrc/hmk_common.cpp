@@ -6,6 +6,47 @@ namespace hmk { namespace impl {
 
 thread_local std::string g_last_error;
 
+// The environment switches, read once per entry-point call (hmk_ctx.h; INTEGRATION.md "Environment switches").
+void Switches::read() {
+    auto flag = [](const char *name) { return getenv(name) != nullptr; };
+    auto num = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+    *this = Switches();
+    greedy_timing = flag("HMK_GREEDY_TIMING");
+    no_band = flag("HMK_NO_BAND");
+    no_rows_kernel = flag("HMK_NO_ROWS_KERNEL");
+    adj_8byte = flag("HMK_ADJ_8BYTE");
+    local_literal = flag("HMK_LOCAL_LITERAL");
+    local_signed = flag("HMK_LOCAL_SIGNED");
+    local_no_pk = flag("HMK_LOCAL_NO_PK");
+    multi_serial = flag("HMK_MULTI_SERIAL");
+    if (const char *v = getenv("HMK_SECOND_LOOP")) second_loop = std::strcmp(v, "device") == 0 ? 1 : 2;
+    phase1_threads = std::max(0, num("HMK_PHASE1_THREADS", 0));
+    phase1_window = std::max(0, num("HMK_PHASE1_WINDOW", 0));
+    if (const char *v = getenv("HMK_PHASE1_HOST_BAND")) {
+        host_band_rows = std::max(0, atoi(v));
+        if (const char *c = std::strchr(v, ',')) host_band_far_t = std::max(0, atoi(c + 1));
+    }
+    loop_chain = getenv("HMK_LOOP_CHAIN") ? (num("HMK_LOOP_CHAIN", 0) != 0 ? 1 : 0) : -1;
+    loop_passes = std::min(8, std::max(0, num("HMK_LOOP_PASSES", 0)));
+    if (const char *v = getenv("HMK_PRECHECK")) precheck = std::strcmp(v, "two_passes") == 0 ? 1 : std::strcmp(v, "one_stage") == 0 ? 2 : 0;
+    late_buffers_delay_ms = std::max(0, num("HMK_LATE_BUFFERS_DELAY_MS", 0));
+    csr_bucket_shift = num("HMK_CSR_BUCKET_SHIFT", 0);
+    if (const char *v = getenv("HMK_EDGE_GUESS")) edge_guess = std::strtoull(v, nullptr, 10);
+}
+void refresh_switches(hmk_ctx *ctx) {
+    ctx->sw.read();
+    for (hmk_ctx *peer : ctx->peers) peer->sw = ctx->sw;
+}
+GreedyOptions greedy_options(const hmk_ctx *ctx) {
+    GreedyOptions o;
+    o.phase1_threads = ctx->sw.phase1_threads;
+    o.phase1_window = ctx->sw.phase1_window;
+    o.timing = ctx->sw.greedy_timing;
+    o.host_band_rows = ctx->sw.host_band_rows;
+    o.host_band_far_t = ctx->sw.host_band_far_t;
+    return o;
+}
+
 int fail(hmk_ctx *ctx, int code, const std::string &msg) {
     g_last_error = msg;
     if (ctx) ctx->err = msg;
@@ -86,27 +127,12 @@ hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes, size_t keep) {
 
 int greedy_streams(hmk_ctx *ctx) {
     if (ctx->gstream) return HMK_OK;
-    // HMK_CU_RESERVE=k: the clustering stream may not use k of the device's CUs (a CU mask), so that the small kernels of the
-    // band hand-over, on their own stream, find a free CU at once instead of waiting for a workgroup of the scoring pass to end
-    int reserve = 0;
-    if (const char *v = getenv("HMK_CU_RESERVE")) reserve = std::max(0, std::min(64, atoi(v)));
-    if (reserve > 0) {
-        hipDeviceProp_t prop;
-        HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
-        const int cus = prop.multiProcessorCount;
-        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0xFFFFFFFFu);
-        if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
-        for (int k = 0; k < reserve && k < cus; k++) mask[(size_t)k / 32] &= ~(1u << (k % 32));
-        HIPCHK(ctx, hipExtStreamCreateWithCUMask(&ctx->gstream, (uint32_t)mask.size(), mask.data()));
-    } else
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking));
     // the band hand-over runs while the rest of the pair space is being scored: its small kernels must not queue behind
     // the thousands of workgroups of that launch, so its stream gets the highest priority
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_stream, hipStreamNonBlocking, prio_hi));
-    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->rest_stream, hipStreamNonBlocking, prio_lo));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_rest, hipEventDisableTiming));
     for (hipEvent_t *ev : {&ctx->ev_t0, &ctx->ev_band, &ctx->ev_edges, &ctx->ev_csr, &ctx->ev_bandcsr}) HIPCHK(ctx, hipEventCreate(ev));
     HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_counts, HC_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
     // fine-grained, so that a system-scope store of a running kernel is seen by the polling host (no such block: batches + syncs)
@@ -126,25 +152,15 @@ int greedy_streams(hmk_ctx *ctx) {
     return HMK_OK;
 }
 // The CSR scatter with its lower sections dealt by bucket (k_edges.hip, k_lower_*): for graphs whose scatter is bound by random
-// writes.  Packed symmetric adjacency only; edges that were placed while they were written have their own atomic-free scatter.
-// The default at every size (10^5: CSR 0.44 -> 0.31 ms, 10^6: 58 -> 23 ms); HMK_CSR_BY_BUCKET=0 scatters with atomics.
-bool csr_by_bucket(uint32_t n, bool symmetric, bool packed, bool placed) {
-    if (!symmetric || !packed || placed) return false;
-    if (const char *v = getenv("HMK_CSR_BY_BUCKET")) return atoi(v) != 0;
-    (void)n;
-    return true;
-}
+// writes.  Packed symmetric adjacency, at every size (10^5: CSR 0.44 -> 0.31 ms, 10^6: 58 -> 23 ms); asymmetric matrices and
+// 8-byte entries scatter with atomics (k_edge_scatter).
+bool csr_by_bucket(bool symmetric, bool packed) { return symmetric && packed; }
 // The grow-only device and pinned buffers the tail of a clustering call on n sequences asks for (the edge buffer must have
 // its size already): hmk_greedy_cluster before it enqueues the pass, hmk_reserve from a host that knows n early.
 int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, bool full, bool late_on_a_thread) {
     const size_t esz0 = packed ? sizeof(NbrPacked) : sizeof(Nbr);
     const size_t adj_bytes = std::max<uint64_t>((ctx->symmetric ? 2 : 1) * ctx->d_edges_cap, 1) * esz0;
-    size_t part_bytes = 0;
-    {
-        bool place0 = false;
-        if (const char *v = getenv("HMK_PLACE_EDGES")) place0 = getenv("HMK_NO_FUSED_DEGREE") == nullptr && atoi(v) != 0;
-        if (csr_by_bucket(n, ctx->symmetric, packed, place0)) part_bytes = (ctx->d_edges_cap + 1) * 8;
-    }
+    const size_t part_bytes = csr_by_bucket(ctx->symmetric, packed) ? (ctx->d_edges_cap + 1) * 8 : 0;
     const bool late = late_on_a_thread || late_buffers_pending(ctx);   // (pending: the call's CSR step joins the thread and checks the sizes)
     if (!late) HIPCHK(ctx, ensure_buf(ctx, SB_ADJ, adj_bytes));
     HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 8));   // (upper and lower counts of the fused pass)
@@ -204,9 +220,9 @@ int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, boo
     if (late_on_a_thread) (void)join_late_buffers(ctx);   // (an earlier hmk_reserve's thread may still be writing the two sizes read next)
     if (late_on_a_thread && (ctx->sb[SB_ADJ].cap < adj_bytes || ctx->sb[SB_PART].cap < part_bytes)) {
         const int device = ctx->device;
-        ctx->late_buffers = std::async(std::launch::async, [ctx, device, adj_bytes, part_bytes]() -> hipError_t {
-            if (const char *v = getenv("HMK_LATE_BUFFERS_DELAY_MS"))   // tests: a host on which device memory is slow to get
-                std::this_thread::sleep_for(std::chrono::milliseconds(std::max(0, atoi(v))));
+        const int delay_ms = ctx->sw.late_buffers_delay_ms;   // tests: a host on which device memory is slow to get
+        ctx->late_buffers = std::async(std::launch::async, [ctx, device, adj_bytes, part_bytes, delay_ms]() -> hipError_t {
+            if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
             hipError_t e = hipSetDevice(device);
             if (e == hipSuccess) e = ensure_buf_now(ctx, SB_ADJ, adj_bytes);
             if (e == hipSuccess && part_bytes) e = ensure_buf_now(ctx, SB_PART, part_bytes);
@@ -220,7 +236,7 @@ uint64_t first_edge_capacity(const hmk_ctx *ctx, uint32_t n) {
     // first guess of the edge buffer: 0.3 % of the pair space (uniform random 12-mers at the default threshold give
     // 0.26 %); a segment that overflows makes the call size the buffer to the counts and score again
     uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006)) + (1u << 20);
-    if (const char *v = getenv("HMK_EDGE_GUESS")) guess = std::strtoull(v, nullptr, 10);   // tests: force the overflow / retry path
+    if (ctx->sw.edge_guess) guess = ctx->sw.edge_guess;   // tests: force the overflow / retry path
     uint64_t cap = std::max<uint64_t>({std::min<uint64_t>(guess, 1ull << 31), (uint64_t)1 << 20, ctx->d_edges_cap});
     return (cap + HMK_EDGE_SHARDS - 1) / HMK_EDGE_SHARDS * HMK_EDGE_SHARDS;
 }

@@ -42,12 +42,35 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 enum {
     SB_DEG, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ, SB_PART, SB_PARTSCR,   // full CSR (+ the bucketed lower sections)
     SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
+    SB_BNCNT, SB_BNUP, SB_BNSTART, SB_BNEAR, SB_BFTOP, SB_BFMORE, SB_FDEG, SB_FSTART, SB_FCUR, SB_FADJ, SB_FOWNER, SB_TRCNT, SB_TRSTART, SB_TROWNER, SB_TR,   // the band prepared for phase 1 (BandPack)
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
-    SB_LIDX, SB_PCNT, SB_PSTART, SB_PROP,
-    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RANK, SB_RETRY, SB_PRECNT, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop                                                 // join-propagation lists
-    SB_BANDCTR,   // [0] band tiles done (band_tile_done), [1] k_wait_counter gave up
+    SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RETRY, SB_PRECNT, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop
     SB_PEER, SB_PEERCNT, SB_PEERBAND, SB_PEERDEG,                                                     // edge blocks gathered from other devices (root) / compacted for the root (peers)
     SB_N
+};
+
+// The library's environment switches (INTEGRATION.md lists them: every one is a test or diagnostic aid, none is needed for a
+// result or for speed).  Read ONCE per entry-point call (refresh_switches, under the context's lock) -- never from a launch loop
+// or a worker thread.
+struct Switches {
+    bool greedy_timing = false;   // HMK_GREEDY_TIMING: a clustering call's timeline, the plan's and the merge's phases on stderr
+    bool no_band = false;         // HMK_NO_BAND: no band hand-over, phase 1 waits for the whole pass
+    bool no_rows_kernel = false;  // HMK_NO_ROWS_KERNEL: the shift-packed tier (k_neighbors.hip) for every class
+    bool adj_8byte = false;       // HMK_ADJ_8BYTE: 8-byte adjacency entries even where 4 bytes hold every score
+    bool local_literal = false;   // HMK_LOCAL_LITERAL: LocalAlignmentScorer through the literal DP
+    bool local_signed = false;    // HMK_LOCAL_SIGNED: the signed tagged-max form (what gap_open = 0 runs) for every penalty
+    bool local_no_pk = false;     // HMK_LOCAL_NO_PK: one column sequence per lane in the tagged-max DP
+    bool multi_serial = false;    // HMK_MULTI_SERIAL: the conservative multi-device call (no worker threads, copies through the host)
+    int second_loop = 0;          // HMK_SECOND_LOOP=device|host: 1 / 2 force that implementation of the second loop (0: the default choice)
+    int phase1_threads = 0, phase1_window = 0;        // HMK_PHASE1_THREADS, HMK_PHASE1_WINDOW (GreedyOptions)
+    int host_band_rows = 0, host_band_far_t = 0;      // HMK_PHASE1_HOST_BAND=rows[,far_t] (GreedyOptions)
+    int loop_chain = -1;          // HMK_LOOP_CHAIN=0|1: chained joins never / from the first round (-1: from round 256 on)
+    int loop_passes = 0;          // HMK_LOOP_PASSES: first/accept passes per round of the device-side loop (0: by cluster count)
+    int precheck = 0;             // HMK_PRECHECK=two_passes|one_stage: 1 = count + fill passes, 2 = full-size tables for every row at once
+    int late_buffers_delay_ms = 0;   // HMK_LATE_BUFFERS_DELAY_MS: hmk_reserve's buffer thread sleeps first (a host where device memory is slow to get)
+    int csr_bucket_shift = 0;     // HMK_CSR_BUCKET_SHIFT: rows per bucket = 2^shift in the CSR's dealing pass (the wide buckets of n > 2^21)
+    uint64_t edge_guess = 0;      // HMK_EDGE_GUESS: first edge-buffer capacity (forces the overflow / retry path)
+    void read();
 };
 
 struct Plan {
@@ -59,7 +82,7 @@ struct Plan {
     int lbmax = 12, lpad = 16;
     bool exact = false;       // the shift-packed length-12 kernel (k_neighbors_swar; only with HMK_NO_ROWS_KERNEL)
     bool rows_exact = false;  // one length for all and a row-packed instantiation for exactly that length
-    int hot_variant = 7;
+    bool no_rows_kernel = false;   // the switch this plan was built under (part of the cache key)
     uint32_t cols_per_tile = 16384;
     uint8_t *d_res_sorted = nullptr;
     uint32_t *d_perm = nullptr;
@@ -94,6 +117,7 @@ struct hmk_ctx {
     int device = -1;
     bool has_device = false;
     int java_hashset = 8;   // hmk_set_java_hashset: whose HashSet iteration order clinkage emulates
+    Switches sw;            // this call's environment switches (refresh_switches)
 
     uint32_t n = 0;
     std::vector<uint8_t> res;
@@ -113,7 +137,7 @@ struct hmk_ctx {
     uint64_t d_edges_cap = 0;
     unsigned long long *d_counts = nullptr;
     // side streams of the neighbour pass: the per-class launches of a mixed-length plan overlap their tails
-    static constexpr int N_SIDE = 8;     // created; HMK_SIDE_STREAMS (default 3) of them are used
+    static constexpr int N_SIDE = 3;     // streams the launches are dealt to (the pass's own and two others)
     hipStream_t side[N_SIDE] = {nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr};
     hipStream_t copy_stream = nullptr;   // band CSR + device-to-host copies of adjacency rows (hmk_greedy_cluster)
@@ -124,8 +148,6 @@ struct hmk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // greedy tail: own stream + events, grow-only device scratch, pinned host staging (all made once per context)
     hipStream_t gstream = nullptr;
-    hipStream_t rest_stream = nullptr;   // lowest priority: the tiles outside the band, scored beside the band tiles (hmk_greedy_cluster)
-    hipEvent_t ev_rest = nullptr;
     hipEvent_t ev_t0 = nullptr, ev_band = nullptr, ev_edges = nullptr, ev_csr = nullptr, ev_bandcsr = nullptr;
     DevBuf sb[SB_N];
     void *h_start = nullptr;  // pinned: uint64 start[n + 1], then uint32 up[n]
@@ -171,7 +193,7 @@ int fail(hmk_ctx *ctx, int code, const std::string &msg);
 
 // which: LAUNCH_ALL, or only the band tiles of the plan (LAUNCH_BAND: also zeroes the counts) / only the others
 // (LAUNCH_REST: appends to the counts of the band launch)
-enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2, LAUNCH_BAND_NOZERO = 3 };   // (NOZERO: the caller has zeroed the counts)
+enum { LAUNCH_ALL = 0, LAUNCH_BAND = 1, LAUNCH_REST = 2 };
 
 constexpr int ST_RETRY_OVERFLOW = 1000;   // internal: an edge segment overflowed, grow the buffer and score again
 // layout of the small pinned block hmk_ctx::h_counts (64-bit words)
@@ -189,7 +211,7 @@ struct AllocTimer {
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
         g_alloc_ms += ms;
         g_allocs++;
-        static const bool timing = getenv("HMK_CLI_TIMING") != nullptr || getenv("HMK_GREEDY_TIMING") != nullptr;
+        static const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;   // (a destructor without a context: read once per process)
         if (timing && ms > 5.0) std::fprintf(stderr, "[hmk] %s of %.1f MB took %.1f ms\n", what, (double)bytes / 1048576.0, ms);
     }
 };
@@ -207,13 +229,9 @@ struct EdgeSource {
     uint64_t adj_bound = 0;            // upper bound of the adjacency entries (format_known only)
     uint64_t total_known = 0;          // exact number of edges, if known (else 0)
     uint32_t band_rows = 0;            // rows [0, band_rows) are complete in band_segs once ev_band has passed
-    const uint32_t *band_gave_up = nullptr;   // device word: 1 = the wait for the band tiles timed out (band_segs are NOT complete)
     EdgeSegs band_segs{};
-    bool deg_fused = false;            // the neighbour kernel placed the edges itself: SB_CURSOR holds the rows' upper | lower counters
-                                       // (zeroed before the pass), SB_RANK every edge's ranks (parallel to the buffer at edges0)
-    const uint64_t *edges0 = nullptr;
-    bool deg_split = false;            // deg_fused without ranks: SB_DEG holds upper counts [0, n) and lower counts [n, 2n) instead of totals
-    bool placed = false;               // deg_fused with ranks (else deg_fused = SB_DEG holds the rows' total degrees, counted by the pass)
+    bool deg_fused = false;            // the neighbour kernel counted the rows' degrees while it wrote the edges (SB_DEG, zeroed before the pass)
+    bool deg_split = false;            // ... as upper counts [0, n) and lower counts [n, 2n) instead of totals
     hmk_clinkage_stats *clink = nullptr;   // non-null: run the clinkage nearest-neighbour chain instead of the greedy merge
     // multi-device calls: the peers' blocks arrive while the calling thread is already inside cluster_on_device.
     //   before_band  blocks until every peer's band block is on its way to the root and makes the copy stream wait for them;
@@ -224,6 +242,8 @@ struct EdgeSource {
 };
 
 // ---- hmk_common.cpp
+void refresh_switches(hmk_ctx *ctx);              // the root's and its peers' (under the context's lock, once per entry-point call)
+GreedyOptions greedy_options(const hmk_ctx *ctx);
 int need_device(hmk_ctx *ctx);
 int ensure_res32(hmk_ctx *ctx);
 hipError_t ensure_buf_now(hmk_ctx *ctx, int which, size_t bytes);
@@ -233,7 +253,7 @@ hipError_t ensure_buf(hmk_ctx *ctx, int which, size_t bytes);
 template <class T> T *buf(hmk_ctx *ctx, int which) { return (T *)ctx->sb[which].p; }
 hipError_t ensure_pinned(void **p, size_t *cap, size_t bytes, size_t keep);
 int greedy_streams(hmk_ctx *ctx);   // streams, events and pinned blocks of the clustering calls
-bool csr_by_bucket(uint32_t n, bool symmetric, bool packed, bool placed);
+bool csr_by_bucket(bool symmetric, bool packed);
 int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, bool full = false, bool late_on_a_thread = false);
 uint64_t first_edge_capacity(const hmk_ctx *ctx, uint32_t n);
 int grow_edge_buffer(hmk_ctx *ctx, uint64_t cap);
@@ -247,8 +267,7 @@ int build_plan_local(hmk_ctx *ctx, uint32_t part, uint32_t n_parts);
 // ---- hmk_pass.cpp
 int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
                          uint64_t capacity, void *d_counts, hipStream_t stream, int which = LAUNCH_ALL,
-                         int64_t band_rows = -1, uint32_t *d_deg = nullptr, uint32_t *d_deg_lo = nullptr, uint32_t *d_rank = nullptr,
-                         uint32_t shard_base = 0, uint32_t shard_mod = HMK_EDGE_SHARDS, uint32_t band_mod = 0, uint32_t *band_counter = nullptr);
+                         int64_t band_rows = -1, uint32_t *d_deg = nullptr, uint32_t *d_deg_lo = nullptr);
 bool local_enc(const hmk_ctx *ctx, int gap_open, int gap_extend);
 int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, uint64_t want_cap,
                        unsigned long long counts[HMK_EDGE_SHARDS], double *kernel_ms);

@@ -123,81 +123,34 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 
 // Wave priority (s_setprio) in the neighbour kernels.  A wave that is issuing table reads goes ahead of the waves of its SIMD
 // that are testing accumulators or staging hits, so the LDS queue -- the unit that bounds these kernels -- is fed first
-// (length-12 kernel: 3.329 -> 3.297 ms, 0.917 -> 0.926 of the LDS peak with priority 2; 1 and 3 gave 3.304 / 3.309 ms).  A
-// wave that drains its stage goes ahead of everything: the drain is a chain of round trips (segment counter, then -- when the
-// pass also places the edges in the CSR -- two returning atomics per edge), and at the lowest priority its few instructions
-// waited behind every other wave's VALU work (-DHMK_SETPRIO_DRAIN=0: within the noise on the plain pass, 3.296-3.300 against
-// 3.291-3.295 ms).  A priority for the batch's column fetch + unpack changed nothing either.  Passes that place the edges in the
-// CSR keep equal priorities for the read phase: with them the 10^5 call scored in 4.50 instead of 4.40 ms (3 x 10^5: 33.0 against
-// 33.3 ms), -DHMK_SETPRIO_PLACE=1.  A tile's table build runs at
-// priority 3 as well (HMK_SETPRIO_BUILD): until its tables stand a workgroup contributes no table reads at all, and at priority 0
-// its build waited behind the other workgroups' read phases -- mixed lengths (short tiles: a build every 28 batches) 5.29 ->
-// 5.21 ms on one box, the length-12 pass 3.320 -> 3.298 ms; priorities 1 / 2 for the build gave 5.29 / 5.28 ms.  Moving the start
-// of the read phase of the mixed-length kernel up to the batch's column fetch changed nothing.
-// -DHMK_SETPRIO=0 builds without any of it (tools/ab_flags.sh rebuilds and times the variants).
-#ifndef HMK_SETPRIO
-#define HMK_SETPRIO 2
-#endif
-#ifndef HMK_SETPRIO_PLACE
-#define HMK_SETPRIO_PLACE 0
-#endif
-__device__ __forceinline__ void read_phase_begin(bool on) {
-    if (HMK_SETPRIO > 0 && on) __builtin_amdgcn_s_setprio(HMK_SETPRIO);
-}
-__device__ __forceinline__ void read_phase_end(bool on) {
-    if (HMK_SETPRIO > 0 && on) __builtin_amdgcn_s_setprio(0);
-}
-#ifndef HMK_SETPRIO_BUILD
-#define HMK_SETPRIO_BUILD 3
-#endif
-__device__ __forceinline__ void build_begin() {   // a tile's table build
-    if (HMK_SETPRIO > 0 && HMK_SETPRIO_BUILD > 0) __builtin_amdgcn_s_setprio(HMK_SETPRIO_BUILD);
-}
-__device__ __forceinline__ void build_end() {
-    if (HMK_SETPRIO > 0 && HMK_SETPRIO_BUILD > 0) __builtin_amdgcn_s_setprio(0);
-}
-#ifndef HMK_SETPRIO_DRAIN
-#define HMK_SETPRIO_DRAIN 3
-#endif
-__device__ __forceinline__ void drain_begin() {
-    if (HMK_SETPRIO > 0 && HMK_SETPRIO_DRAIN > 0) __builtin_amdgcn_s_setprio(HMK_SETPRIO_DRAIN);
-}
-__device__ __forceinline__ void drain_end() {
-    if (HMK_SETPRIO > 0 && HMK_SETPRIO_DRAIN > 0) __builtin_amdgcn_s_setprio(0);
-}
+// (length-12 shift-packed kernel: 3.329 -> 3.297 ms with priority 2; 1 and 3 gave 3.304 / 3.309 ms).  A wave that drains its
+// stage goes ahead of everything: the drain is a chain of round trips, and at the lowest priority its few instructions waited
+// behind every other wave's VALU work.  A tile's table build runs at priority 3 as well: until its tables stand a workgroup
+// contributes no table reads at all (mixed lengths, a build every 28 batches: 5.29 -> 5.21 ms).
+constexpr int PRIO_READ = 2, PRIO_BUILD = 3, PRIO_DRAIN = 3;
+__device__ __forceinline__ void read_phase_begin(bool on) { if (on) __builtin_amdgcn_s_setprio(PRIO_READ); }
+__device__ __forceinline__ void read_phase_end(bool on) { if (on) __builtin_amdgcn_s_setprio(0); }
+__device__ __forceinline__ void build_begin() { __builtin_amdgcn_s_setprio(PRIO_BUILD); }   // a tile's table build
+__device__ __forceinline__ void build_end() { __builtin_amdgcn_s_setprio(0); }
+__device__ __forceinline__ void drain_begin() { __builtin_amdgcn_s_setprio(PRIO_DRAIN); }
+__device__ __forceinline__ void drain_end() { __builtin_amdgcn_s_setprio(0); }
 
-// The CSR place of a stored edge (NeighborParams::deg): its rank in row x's upper section and in row m's lower one.  Only
-// STORED edges are placed: an edge dropped by a segment overflow must not be counted, or the CSR sized from the counters
-// (its scatter is enqueued before the host notices the overflow) would expect entries that are not there.
-enum { EDGES_PLAIN = 0, EDGES_RUNTIME = 1, EDGES_COUNT = 2, EDGES_PLACE = 3 };   // what a flush does beside storing the edge
+// What a flush does beside storing the edge: nothing, or counting the rows' degrees (NeighborParams::deg: the CSR build's first
+// pass, fused into the scoring of a clustering call; fire-and-forget atomics).  EDGES_RUNTIME: decided by P.deg at run time.
+// Only STORED edges are counted: an edge dropped by a segment overflow must not be, or the CSR sized from the counters (its
+// scatter is enqueued before the host notices the overflow) would expect entries that are not there.
+enum { EDGES_PLAIN = 0, EDGES_RUNTIME = 1, EDGES_COUNT = 2 };
 template <int MODE = EDGES_RUNTIME>
-__device__ __forceinline__ void place_edge(const NeighborParams &P, unsigned long long slot, uint32_t x, uint32_t m) {
-    if (MODE == EDGES_PLACE || (MODE == EDGES_RUNTIME && P.rank)) {   // (run time: wave-uniform)
-        // (deg_up, not deg: with one pointer for both modes the compiler hoists the first atomic out of the branch as a
-        // RETURNING one, and the counting mode then waits for it at the top of the next record -- +10 % on the 10^6 pass)
-        const uint32_t rx = atomicAdd(&P.deg_up[x], 1u);
-        const uint32_t rm = P.symmetric ? atomicAdd(&P.deg_lo[m], 1u) : 0u;
-        reinterpret_cast<uint2 *>(P.rank)[slot] = make_uint2(rx, rm);
-    } else if (MODE == EDGES_COUNT || (MODE == EDGES_RUNTIME && P.deg)) {   // counting only (deg = the rows' total degrees): fire-and-forget atomics
+__device__ __forceinline__ void place_edge(const NeighborParams &P, uint32_t x, uint32_t m) {
+    if (MODE == EDGES_COUNT || (MODE == EDGES_RUNTIME && P.deg)) {   // (run time: wave-uniform)
         atomicAdd(&P.deg[x], 1u);
         if (P.symmetric) atomicAdd(&P.deg[P.deg_m_offset + m], 1u);
     }
 }
 
-// Which output segment a tile writes (NeighborParams::shard_base / shard_mod / band_mod).
-__device__ __forceinline__ uint32_t tile_shard(const NeighborParams &P, const Tile &T, uint32_t tile) {
-    return (P.band_mod && T.pad0) ? tile % P.band_mod : P.shard_base + tile % P.shard_mod;
-}
-// A clustering call scores its band tiles (the rows phase 1 reads first) and all the others in ONE launch, band tiles first
-// in dispatch order, and learns from a counter when the band's edges are complete: called by every thread of a workgroup as
-// the last thing it does.
-__device__ __forceinline__ void band_tile_done(const NeighborParams &P, const Tile &T) {
-    if (P.band_counter && T.pad0) {   // workgroup-uniform
-        __threadfence();              // this wave's edge stores are visible device-wide ...
-        __syncthreads();              // ... and so are the other waves' ...
-        if (threadIdx.x == 0) atomicAdd(P.band_counter, 1u);   // ... before the tile counts as done
-    }
-}
+// Which output segment a tile writes: each of the HMK_EDGE_SHARDS segments has its own cursor (returning atomics on ONE address
+// from 256 CUs are served one after the other, ~100 ns each).
+__device__ __forceinline__ uint32_t tile_shard(uint32_t tile) { return tile % HMK_EDGE_SHARDS; }
 
 // Drains one wave's staged records to its output segment.  REC_DW dwords per
 // record: [0] column (sorted position), [1] row within the tile, [2..] the NW
@@ -245,7 +198,7 @@ __device__ __forceinline__ void flush_stage(const HMK_LDS uint32_t *stage, uint3
             // degrees of STORED edges only: an edge dropped by a segment overflow must not be counted, or the CSR built
             // from the counters (its scatter is enqueued before the host notices the overflow) would be sized for edges that
             // are not there and overrun the adjacency buffer
-            if (DEG && (P.deg || P.rank)) place_edge<EDGES_RUNTIME>(P, (unsigned long long)shard * P.cap_per_shard + pos, x, m);   // wave-uniform test; stored edges only
+            if (DEG) place_edge<EDGES_RUNTIME>(P, x, m);   // stored edges only
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
@@ -278,7 +231,7 @@ __device__ __forceinline__ void flush_stage_compact(const HMK_LDS uint32_t *stag
         if (pos < P.cap_per_shard) {
             P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
                 ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
-            if (MODE != EDGES_PLAIN) place_edge<MODE>(P, (unsigned long long)shard * P.cap_per_shard + pos, x, m);   // stored edges only
+            if (MODE != EDGES_PLAIN) place_edge<MODE>(P, x, m);   // stored edges only
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused
@@ -310,7 +263,7 @@ __device__ __forceinline__ void flush_stage_packed(const HMK_LDS uint32_t *stage
         if (pos < P.cap_per_shard) {
             P.edges[(unsigned long long)shard * P.cap_per_shard + pos] =
                 ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
-            if (DEG && (P.deg || P.rank)) place_edge<EDGES_RUNTIME>(P, (unsigned long long)shard * P.cap_per_shard + pos, x, m);   // wave-uniform test; stored edges only
+            if (DEG) place_edge<EDGES_RUNTIME>(P, x, m);   // stored edges only
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads done before the stage is reused

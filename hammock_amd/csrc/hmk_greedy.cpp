@@ -82,7 +82,8 @@ inline bool better(int32_t s, int64_t size, int32_t id, int32_t bs, int64_t bsiz
 
 int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
                       bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,
-                      int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
+                      int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err,
+                      const GreedyOptions &opt) {
     auto t0 = std::chrono::steady_clock::now();
     (void)threshold;  // every stored edge already satisfies score >= threshold
     // ---- CSR adjacency: adj[x] = {(m, sequenceScore(m, x))} -----------------
@@ -107,8 +108,65 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
             if (symmetric) adj[fill[m]++] = Nbr{x, s};
         }
     }
-    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), nullptr, nullptr, symmetric, max_clusters, cluster_id,
-                                   result_order, member_rank, st, err);
+    // HMK_PHASE1_HOST_BAND: the prepared band (BandPack) built here, literally, from the whole graph
+    GreedyHooks hooks;
+    std::vector<uint32_t> b_near_start, b_near_up, b_near, b_far_top, b_tr_owner, b_tr_start, b_tr;
+    std::vector<uint8_t> b_far_more;
+    BandPack pack;
+    bool use_pack = opt.host_band_rows > 0 && symmetric && n > 0;
+    if (use_pack)
+        for (const Nbr &a : adj)
+            if (a.s - threshold < 0 || a.s - threshold > 255) { use_pack = false; break; }
+    if (use_pack) {
+        const uint32_t R1 = std::min<uint32_t>((uint32_t)opt.host_band_rows, n), FT = (uint32_t)std::max(1, opt.host_band_far_t > 0 ? opt.host_band_far_t : 8);
+        auto ent = [&](uint32_t id, int32_t s) { return id << 8 | (uint32_t)(s - threshold); };
+        auto far_key = [&](const Nbr &a) {   // (score, Cluster.size(), smaller id), larger = better
+            return std::make_tuple(a.s, (int64_t)(sizes ? sizes[a.m] : 1), -(int64_t)a.m);
+        };
+        auto band_nbrs = [&](uint32_t id, std::vector<uint32_t> &out) {   // the rows below R1 that have `id` as a neighbour
+            for (uint64_t q = start[id]; q < start[id + 1]; q++)
+                if (adj[q].m < R1) out.push_back(ent(adj[q].m, adj[q].s));
+        };
+        b_near_start.assign((size_t)R1 + 1, 0);
+        b_near_up.assign(R1, 0);
+        b_far_top.assign((size_t)R1 * FT, ~0u);
+        b_far_more.assign(R1, 0);
+        b_tr_start.assign((size_t)BandPack::TR_PER_ROW * R1 + 1, 0);
+        b_tr_owner.resize((size_t)BandPack::TR_PER_ROW * R1);
+        for (size_t u = 0; u < b_tr_owner.size(); u++) b_tr_owner[u] = (uint32_t)u;   // (here every slot carries its own copy)
+        for (uint32_t x = 0; x < R1; x++) {
+            std::vector<Nbr> far;
+            for (int pass = 0; pass < 2; pass++)   // the neighbours above x first
+                for (uint64_t q = start[x]; q < start[x + 1]; q++) {
+                    const Nbr &a = adj[q];
+                    if (a.m >= R1) { if (pass == 0) far.push_back(a); continue; }
+                    if ((pass == 0) == (a.m > x)) { b_near.push_back(ent(a.m, a.s)); if (pass == 0) b_near_up[x]++; }
+                }
+            b_near_start[x + 1] = (uint32_t)b_near.size();
+            std::sort(far.begin(), far.end(), [&](const Nbr &p, const Nbr &q) { return far_key(p) > far_key(q); });
+            for (uint32_t t = 0; t < FT && t < far.size(); t++) b_far_top[(size_t)x * FT + t] = ent(far[t].m, far[t].s);
+            b_far_more[x] = far.size() > FT;
+            for (uint32_t t = 0; t < BandPack::TR_PER_ROW; t++) {
+                if (t < FT && t < far.size()) band_nbrs(far[t].m, b_tr);
+                b_tr_start[(size_t)BandPack::TR_PER_ROW * x + t + 1] = (uint32_t)b_tr.size();
+            }
+        }
+        pack.rows = R1; pack.far_t = FT;
+        pack.near_start = b_near_start.data(); pack.near_up = b_near_up.data(); pack.near = b_near.data();
+        pack.far_top = b_far_top.data(); pack.far_more = b_far_more.data();
+        pack.tr_owner = b_tr_owner.data(); pack.tr_start = b_tr_start.data(); pack.tr = b_tr.data();
+        hooks.band_pack = [&]() -> const BandPack * { return &pack; };
+        hooks.far_row = [&](uint32_t id, std::vector<uint32_t> &out) -> bool { out.clear(); band_nbrs(id, out); return true; };
+        hooks.band_far = [&](uint32_t x, std::vector<uint32_t> &out) -> bool {
+            out.clear();
+            for (uint64_t q = start[x]; q < start[x + 1]; q++)
+                if (adj[q].m >= R1) out.push_back(ent(adj[q].m, adj[q].s));
+            return true;
+        };
+        hooks.need_rows = [&](uint32_t, uint32_t) -> uint32_t { return n; };   // everything is here
+    }
+    const int rc = greedy_from_csr(n, sizes, start.data(), adj.data(), nullptr, use_pack ? &hooks : nullptr, symmetric, max_clusters, cluster_id,
+                                   result_order, member_rank, st, err, opt);
     if (st) {
         st->n_edges = n_edges;
         st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -122,7 +180,7 @@ template <class NbrT>
 static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrT *adj_in,
                                 const uint32_t *upper, const GreedyHooks *hooks, bool symmetric_scores, int max_clusters,
                                 int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
-                                std::string *err) {
+                                std::string *err, const GreedyOptions &opt) {
     auto t0 = std::chrono::steady_clock::now();
     hmk_greedy_stats local;
     if (!st) st = &local;
@@ -241,10 +299,9 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         T = std::max(1u, std::min(8u, hw / 2));
     }
     bool pool_decided = false;                        // the threads start with the first window, if the rows are long enough (below)
-    if (const char *v = getenv("HMK_PHASE1_THREADS"))   // tests: any input, any thread count
-        if (symmetric_scores) { T = (unsigned)std::max(1, std::min(32, atoi(v))); pool_decided = true; }
+    if (opt.phase1_threads > 0 && symmetric_scores) { T = (unsigned)std::min(32, opt.phase1_threads); pool_decided = true; }   // tests: any input, any thread count
     uint32_t W = T > 1 ? 4 * T : 1;                   // positions per window (more positions: more scans a commit invalidates)
-    if (const char *v = getenv("HMK_PHASE1_WINDOW")) W = (uint32_t)std::max(1, std::min(4096, atoi(v)));
+    if (opt.phase1_window > 0) W = (uint32_t)std::min(4096, opt.phase1_window);
     if (!symmetric_scores) W = 1;   // (a commit patches the later rows' scans with its OWN row's scores: exact for symmetric scores only)
     std::vector<RowScan> res(W);
     std::vector<int32_t> ahead_score(W, INT_MIN);     // commit of k: score(k, x) for the window's later rows x that have k as a neighbour
@@ -300,15 +357,163 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     int64_t index = 0;
     uint32_t k = 0;         // sequence behind initialList.get(index)
     uint32_t rows_here = partial ? 0 : n;   // rows [0, rows_here) of the adjacency are on the host
-    const bool p1_timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+    const bool p1_timing = opt.timing;
     double p1_scan = 0, p1_commit = 0, p1_rows = 0;
     uint64_t p1_windows = 0, p1_scanned = 0, p1_rescans = 0;
     auto p1_now = []() { return std::chrono::steady_clock::now(); };
+    uint32_t rows_lo = 0;   // ... or rows [rows_lo, rows_here), once the prepared band has served the rows below rows_lo
+
+    // ---- firstPhase on the PREPARED band (BandPack, hmk_internal.h) --------------------------------------------------------
+    // The loop above reads whole adjacency rows: 2,560 entries per step at 10^6 sequences, of which it needs little.  What a
+    // step needs, by where a neighbour lies (R = the band's row limit, a little above 2 * maxClusters):
+    //   * :93, the best later singleton: among the neighbours x < id < R (the near row's leading section: their states change in
+    //     this loop) and the FAR neighbours, whose state changes only by being absorbed -- the device lists each row's best few
+    //     far candidates in the reference's order, and the first one still free is the answer;
+    //   * :92, the clusters whose EVERY member is a neighbour (ClinkageClusterScorer.java:36-48): kept INCREMENTALLY instead of
+    //     being recounted.  feas[x] lists the clusters that have been feasible for the later band row x, each with its minimum score
+    //     and `covered`, the number of its members known to be neighbours of x; an entry is feasible iff covered == the cluster's
+    //     member count.  Seeding {k, B} (:99-101, :108-110) creates entries for the later rows that have BOTH as neighbours (k's
+    //     near row, stamped, against B's band neighbours: B's own near row, or the transposed list the device sent for a far B);
+    //     k joining c (:97, :104) counts one more covered member in the entries of c's later rows that have k as a neighbour and
+    //     leaves the others behind for good (complete linkage is monotone).  Scores are symmetric (checked by the caller).
+    // A step costs the near row's leading section plus a few short lists: a few hundred entries instead of the whole row, no
+    // random access outside the band's own state.  The steps, their order and every comparison are those of the loop below;
+    // rows at and beyond R (a loop that runs past the band) are served by that loop.
+    if (partial && symmetric_scores && hooks->band_pack && max_clusters > 0) {
+        const auto tb0 = p1_now();
+        const BandPack *bp = hooks->band_pack();
+        p1_rows += std::chrono::duration<double, std::milli>(p1_now() - tb0).count();
+        if (bp && bp->rows > 0) {
+            const uint32_t R1 = std::min<uint32_t>(bp->rows, n), FT = bp->far_t;
+            struct FeasEnt { int32_t c, mn, covered; };
+            std::vector<std::vector<FeasEnt>> feas(R1);
+            std::vector<std::vector<std::pair<uint32_t, uint32_t>>> fc;   // per cluster slot: (later band row, its entry's index in feas[row])
+            fc.reserve(slots_max);
+            std::vector<uint64_t> stamp(R1, 0);   // step << 32 | score(k, x) for the rows x of step k's leading near section
+            uint64_t step = 0;
+            std::vector<uint32_t> fetched;
+            auto consider = [&](Found &B, uint32_t m, int32_t s) {   // NearestClusterRunner's order over singletons (scan_row above)
+                if (B.kind == NEAR_NULL || s > B.score ||
+                    (s == B.score && better(s, seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot)))
+                    B = Found{NEAR_REAL, (int32_t)m, s};
+            };
+            while (k < R1 && remaining > 0 && (int64_t)clusters.size() < max_clusters) {
+                if (state[k] != ST_FREE) { k++; continue; }   // removed from initialList (:101, :110)
+                step++;
+                const uint32_t *row = bp->near + bp->near_start[k];
+                const uint32_t n_up = bp->near_up[k];
+                Found A{NEAR_NULL, -1, 0};                      // :92
+                if (clusters.empty()) A = Found{NEAR_DUMMY, -1, INT_MIN};   // :138-140
+                else
+                    for (const FeasEnt &f : feas[k])
+                        if (f.covered == clusters[f.c].usize &&
+                            (A.kind == NEAR_NULL || better(f.mn, clusters[f.c].size, clusters[f.c].id, A.score, clusters[A.slot].size, clusters[A.slot].id)))
+                            A = Found{NEAR_REAL, f.c, f.mn};
+                Found B{NEAR_NULL, -1, 0};                      // :93
+                const uint32_t *ft = bp->far_top + (size_t)k * FT;
+                if (remaining - 1 == 0) B = Found{NEAR_DUMMY, -1, INT_MIN};
+                else {
+                    for (uint32_t q = 0; q < n_up; q++) {
+                        const uint32_t m = row[q] >> 8;
+                        if (state[m] == ST_FREE) consider(B, m, (int32_t)(row[q] & 0xFFu));
+                    }
+                    uint32_t t = 0;
+                    bool far_found = false;
+                    for (; t < FT && ft[t] != ~0u; t++)
+                        if (state[ft[t] >> 8] == ST_FREE) { consider(B, ft[t] >> 8, (int32_t)(ft[t] & 0xFFu)); far_found = true; break; }
+                    if (!far_found && t == FT && bp->far_more[k]) {   // every listed candidate has been absorbed and the row has more: ask for them
+                        if (!hooks->band_far || !hooks->band_far(k, fetched)) return HMK_INTERNAL_ROWS_FAILED;
+                        for (uint32_t e : fetched)
+                            if (state[e >> 8] == ST_FREE) consider(B, e >> 8, (int32_t)(e & 0xFFu));
+                    }
+                }
+                bool absorb = false;
+                int32_t joined = -1;
+                if (A.kind != NEAR_NULL) {                          // :94
+                    if (B.kind != NEAR_NULL) {                      // :95
+                        if (A.score >= B.score) {                   // :96
+                            if (A.kind == NEAR_DUMMY) { st->crash_case = 2; st->crash_index = (int32_t)index; goto crash; }
+                            joined = A.slot;                        // :97
+                        } else absorb = true;                       // :99-101
+                    } else {
+                        if (A.kind == NEAR_DUMMY) { st->crash_case = 1; st->crash_index = (int32_t)index; goto crash; }
+                        joined = A.slot;                            // :104
+                    }
+                } else if (B.kind != NEAR_NULL) {                   // :107
+                    if (B.kind == NEAR_DUMMY) { st->crash_case = 3; st->crash_index = (int32_t)index; goto crash; }
+                    absorb = true;                                  // :108-110
+                } else {
+                    state[k] = ST_ORPHAN;                           // :112
+                    orphans.push_back(k);
+                }
+                if (absorb || joined >= 0)
+                    for (uint32_t q = 0; q < n_up; q++) stamp[row[q] >> 8] = step << 32 | (row[q] & 0xFFu);
+                if (joined >= 0) {
+                    const int32_t before = clusters[joined].usize;
+                    insert_into(joined, k);
+                    std::vector<std::pair<uint32_t, uint32_t>> &lst = fc[joined];
+                    size_t w = 0;
+                    for (const std::pair<uint32_t, uint32_t> &pr : lst) {
+                        if (pr.first <= k) continue;                            // its turn is over
+                        FeasEnt &f = feas[pr.first][pr.second];
+                        if (f.covered != before) continue;                      // lost earlier, for good
+                        const uint64_t sw = stamp[pr.first];
+                        if ((sw >> 32) != step) continue;                       // k is not its neighbour: lost now
+                        f.covered++;
+                        f.mn = std::min(f.mn, (int32_t)(uint32_t)sw);
+                        lst[w++] = pr;
+                    }
+                    lst.resize(w);
+                } else if (absorb) {
+                    const int32_t c = (int32_t)clusters.size();
+                    clusters.push_back(ClusterRec{(int32_t)k, 1, seq_size(k)});
+                    cluster_of[k] = c;
+                    state[k] = ST_IN_CLUSTER;
+                    insert_into(c, (uint32_t)B.slot);
+                    remaining--;  // initialList.remove(B)
+                    fc.emplace_back();
+                    // the band rows that have B as a neighbour
+                    const uint32_t b = (uint32_t)B.slot;
+                    const uint32_t *bl = nullptr;
+                    uint32_t bn = 0;
+                    if (b < R1) { bl = bp->near + bp->near_start[b]; bn = bp->near_start[b + 1] - bp->near_start[b]; }
+                    else {
+                        for (uint32_t t = 0; t < BandPack::TR_PER_ROW && t < FT && !bl; t++)
+                            if (ft[t] != ~0u && (ft[t] >> 8) == b) {
+                                const size_t u = bp->tr_owner[(size_t)BandPack::TR_PER_ROW * k + t];
+                                bl = bp->tr + bp->tr_start[u];
+                                bn = bp->tr_start[u + 1] - bp->tr_start[u];
+                            }
+                        if (!bl) {
+                            if (!hooks->far_row || !hooks->far_row(b, fetched)) return HMK_INTERNAL_ROWS_FAILED;
+                            bl = fetched.data();
+                            bn = (uint32_t)fetched.size();
+                        }
+                    }
+                    for (uint32_t q = 0; q < bn; q++) {
+                        const uint32_t x = bl[q] >> 8;
+                        if (x <= k || x >= R1 || state[x] != ST_FREE) continue;
+                        const uint64_t sw = stamp[x];
+                        if ((sw >> 32) != step) continue;               // k is not a neighbour of x: {k, B} is never feasible for it
+                        feas[x].push_back(FeasEnt{c, std::min((int32_t)(uint32_t)sw, (int32_t)(bl[q] & 0xFFu)), 2});
+                        fc[c].emplace_back(x, (uint32_t)feas[x].size() - 1);
+                    }
+                }
+                remaining--;
+                index++;          // :115
+                k++;
+            }
+            rows_lo = rows_here = k < R1 ? 0 : R1;   // (the loop below takes over at row R1, if at all)
+            if (p1_timing)
+                fprintf(stderr, "[hmk greedy] phase 1 on the prepared band: %.2f ms for %llu steps (%.2f ms of it waiting for the band), stopped at row %u of %u\n",
+                        std::chrono::duration<double, std::milli>(p1_now() - tb0).count(), (unsigned long long)step, p1_rows, k, R1);
+        }
+    }
     while (k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters) {
         if (state[k] != ST_FREE) { k++; continue; }  // removed from initialList (:101, :110)
         if (k >= rows_here) {                                   // row k must have landed
             const auto tw = p1_now();
-            rows_here = hooks->need_rows(k);
+            rows_here = hooks->need_rows(k, rows_lo);
             if (rows_here <= k) return HMK_INTERNAL_ROWS_FAILED;
             if (hooks->adj_base) adj = (const NbrT *)hooks->adj_base();
             p1_rows += std::chrono::duration<double, std::milli>(p1_now() - tw).count();
@@ -319,11 +524,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             // against 3.2 / 2.7 ms, 3 x 10^5 (770) 21.8 / 14.5 against 17.0 / 14.4, 5 x 10^5 (1,280) 47.6 / 35.1 against
             // 46.1 / 38.2, 10^6 (2,560) 95 / 60 against 137 / 105.
             pool_decided = true;
-            double min_row = 1600.0;
-            if (const char *v = getenv("HMK_PHASE1_MIN_ROW")) min_row = atof(v);
-            const double avg_row = rows_here ? (double)start[rows_here] / (double)rows_here : 0.0;
+            const double min_row = 1600.0;
+            const double avg_row = rows_here > rows_lo ? (double)(start[rows_here] - start[rows_lo]) / (double)(rows_here - rows_lo) : 0.0;
             if (T > 1 && avg_row >= min_row) spawn_pool();
-            else { T = 1; if (getenv("HMK_PHASE1_WINDOW") == nullptr) W = 1; }
+            else { T = 1; if (opt.phase1_window <= 0) W = 1; }
         }
         const auto ts = p1_now();
         // ---- scan a window of positions against the current state ----
@@ -458,8 +662,9 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     {
         // ---- cluster() second loop, :59-66 ---------------------------------
         auto need_all_rows = [&]() -> bool {
-            if (n && rows_here < n) {
-                rows_here = hooks->need_rows(n - 1);
+            if (n && (rows_here < n || rows_lo > 0)) {
+                rows_here = hooks->need_rows(n - 1, 0);
+                rows_lo = 0;
                 if (hooks->adj_base) adj = (const NbrT *)hooks->adj_base();
             }
             return rows_here >= n;
@@ -479,9 +684,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         std::vector<uint32_t> cand_start(nl + 1, 0);     // CSR of candidate clusters per leftover
         std::vector<Cand> cand;
         const bool fast = !clusters.empty() && nl > 512;
-        bool have_cand = false, have_prop = false;
-        std::vector<uint32_t> prop_start;                // per candidate entry: the later entries a join must update
-        std::vector<GreedyProp> prop;
+        bool have_cand = false;
         bool device_done = false;
         std::vector<int32_t> join_slot;
         if (fast && symmetric_scores && hooks && hooks->device_loop) {   // large inputs: the whole loop on the GPU, in optimistic rounds
@@ -493,11 +696,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         if (fast && !device_done && hooks && hooks->precheck) {   // the adjacency is still on the GPU: pre-check there
             std::vector<int32_t> usize(clusters.size());
             for (size_t c = 0; c < clusters.size(); c++) usize[c] = clusters[c].usize;
-            have_cand = hooks->precheck(cluster_of.data(), usize, leftover, symmetric_scores, cand_start, cand, prop_start,
-                                        prop, &have_prop);
-            if (!have_cand) { cand_start.assign(nl + 1, 0); cand.clear(); have_prop = false; }
+            have_cand = hooks->precheck(cluster_of.data(), usize, leftover, cand_start, cand);
+            if (!have_cand) { cand_start.assign(nl + 1, 0); cand.clear(); }
         }
-        if (!device_done && !(have_cand && have_prop) && !need_all_rows()) return HMK_INTERNAL_ROWS_FAILED;   // every other path below reads rows
+        if (!device_done && !need_all_rows()) return HMK_INTERNAL_ROWS_FAILED;   // every other path below reads rows
         if (fast && !have_cand && !device_done) {
             const unsigned T = std::max(1u, std::min(16u, usable_cpus()));
             const size_t nc = clusters.size();
@@ -539,14 +741,14 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         }
         const double t_pre = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (hooks && hooks->times) { hooks->times->phase1_ms = t_phase1; hooks->times->host_precheck_ms = t_pre - t_phase1; }
-        if (getenv("HMK_GREEDY_TIMING"))
+        if (opt.timing)
             fprintf(stderr, "[hmk greedy] phase1 %.2f ms, pre-check %.2f ms (%zu leftovers)\n", t_phase1, t_pre - t_phase1, nl);
         // "Subscribers": per cluster, the leftovers that listed it as a candidate.  When y joins cluster c,
         // y's neighbours are stamped into a sequence-indexed scratch (one sequential pass over adj[y]) and
         // only c's later subscribers are visited: a subscriber that is a neighbour of y counts one more
         // covered member (and folds the score into its min); at its own turn a candidate is still feasible
         // iff covered == members joined since the pre-check.
-        const bool use_subs = fast && symmetric_scores && !have_prop && !device_done;
+        const bool use_subs = fast && symmetric_scores && !device_done;
         struct Sub { uint32_t w; int32_t k; };           // the subscriber (sequence id), index of its candidate in `cand`;
                                                          // per cluster in leftover order = increasing id
         std::vector<uint32_t> sub_start;                 // CSR of subscribers per cluster
@@ -570,9 +772,8 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         }
         uint32_t stamp = 0;
         std::vector<uint32_t> rest;
-        std::vector<int32_t> joined_dev(have_prop ? clusters.size() : 0, 0);   // members that joined each cluster in this loop
         double t_scan = 0, t_push = 0;
-        const bool timing = getenv("HMK_GREEDY_TIMING") != nullptr;
+        const bool timing = opt.timing;
         auto now = []() { return std::chrono::steady_clock::now(); };
         for (size_t q = 0; q < nl; q++) {
             const uint32_t y = leftover[q];
@@ -580,32 +781,6 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             if (device_done) {   // decided on the device (k_loop_*); joins are applied in loop order
                 if (join_slot[q] >= 0) insert_into(join_slot[q], y);                 // :61-62
                 else rest.push_back(y);                                              // :64
-                continue;
-            }
-            if (have_prop) {
-                // device-built propagation lists: the same bookkeeping as "Subscribers" below, but the entries a join
-                // has to update were listed by the GPU (k_greedy_prop), so no adjacency row is read here
-                int32_t kf = -1;
-                for (uint32_t k = cand_start[q]; k < cand_start[q + 1]; k++) {
-                    const Cand cd = cand[k];
-                    if (cd.covered != joined_dev[cd.c]) continue;        // some new member is not a neighbour of y
-                    if (F.kind == NEAR_NULL ||
-                        better(cd.mn, clusters[cd.c].size, clusters[cd.c].id, F.score, clusters[F.slot].size, clusters[F.slot].id)) {
-                        F = Found{NEAR_REAL, cd.c, cd.mn};
-                        kf = (int32_t)k;
-                    }
-                }
-                if (F.kind == NEAR_REAL) {
-                    insert_into(F.slot, y);                                          // :61-62
-                    joined_dev[F.slot]++;
-                    for (uint32_t u = prop_start[kf]; u < prop_start[kf + 1]; u++) {
-                        Cand &cw = cand[prop[u].k];
-                        cw.covered++;
-                        if (prop[u].score < cw.mn) cw.mn = prop[u].score;
-                    }
-                } else {
-                    rest.push_back(y);                                               // :64
-                }
                 continue;
             }
             if (!use_subs) {
@@ -651,7 +826,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                 rest.push_back(y);                          // :64
             }
         }
-        if (getenv("HMK_GREEDY_TIMING")) {
+        if (opt.timing) {
             size_t surv = 0;
             for (size_t q = 0; q < nl; q++) surv += !fast || cand_start[q + 1] > cand_start[q];
             fprintf(stderr, "[hmk greedy] full scans %.2f ms, join propagation %.2f ms (%zu candidate subscriptions, subscribers=%d)\n",
@@ -677,7 +852,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
     }
     st->greedy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (hooks && hooks->times) hooks->times->sequential_ms = st->greedy_ms - hooks->times->phase1_ms - hooks->times->host_precheck_ms;
-    if (getenv("HMK_GREEDY_TIMING")) fprintf(stderr, "[hmk greedy] total %.2f ms\n", st->greedy_ms);
+    if (opt.timing) fprintf(stderr, "[hmk greedy] total %.2f ms\n", st->greedy_ms);
     return HMK_OK;
 
 crash:
@@ -690,17 +865,17 @@ crash:
 
 int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, const uint32_t *upper,
                     const GreedyHooks *hooks, bool symmetric_scores, int max_clusters, int32_t *cluster_id,
-                    int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err) {
+                    int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err, const GreedyOptions &opt) {
     return greedy_from_csr_impl<Nbr>(n, sizes, start, adj, upper, hooks, symmetric_scores, max_clusters, cluster_id,
-                                     result_order, member_rank, st, err);
+                                     result_order, member_rank, st, err, opt);
 }
 
 int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj,
                            const uint32_t *upper, const GreedyHooks *hooks, bool symmetric_scores, int max_clusters,
                            int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
-                           std::string *err) {
+                           std::string *err, const GreedyOptions &opt) {
     return greedy_from_csr_impl<NbrPacked>(n, sizes, start, adj, upper, hooks, symmetric_scores, max_clusters, cluster_id,
-                                           result_order, member_rank, st, err);
+                                           result_order, member_rank, st, err, opt);
 }
 
 }  // namespace hmk

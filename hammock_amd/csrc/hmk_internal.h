@@ -55,23 +55,10 @@ struct NeighborParams {
     uint32_t symmetric;          // 1: emit (min, max) caller indices
     uint32_t row_is_m;           // 1: the tile's ROW is seq1 (= m of the edge), LocalAlignmentScorer tiles
     uint32_t perm_identity;      // 1: sorted position == caller index (one length bucket, no reordering): skip the perm loads
-    // optional (may be null): the CSR the greedy tail builds from these edges is PLACED while the edges are written.
-    // deg_up[x] counts row x's "upper" entries (symmetric: the neighbours with a larger index; else all of them), deg_lo[m]
-    // row m's lower ones (symmetric only); both zeroed uint32[n].  The value an edge's atomicAdd returns is its place inside
-    // the row's section: rank[2 * slot] / rank[2 * slot + 1] for the edge stored in slot = segment * cap_per_shard +
-    // position.  The scatter that follows needs no atomics and no pass that counts degrees.  rank == null: deg[] just counts
-    // the rows' total degrees (both ends of a symmetric edge), with fire-and-forget atomics -- at 10^6 the 2.5 x 10^9 returning
-    // atomics cost the pass 10 % and the scatter there is bound by its random writes, not by its atomics.
-    uint32_t *deg;       // counting mode: total degrees -- or, with deg_m_offset = n, upper counts in deg[0, n) and lower counts in deg[n, 2n)
-    uint32_t deg_m_offset;   // counting mode: the larger end m of an edge counts into deg[deg_m_offset + m] (0: one counter per row)
-    uint32_t shard_base;     // a tile writes into segment shard_base + tile % shard_mod (the whole pass: 0 and HMK_EDGE_SHARDS; a clustering
-    uint32_t shard_mod;      // call scores its band tiles and the others at the same time, each into segments of their own)
-    uint32_t band_mod;       // > 0: ONE launch scores band tiles (Tile::pad0) and the others; a band tile writes into segment tile % band_mod,
-                             // the others into shard_base + tile % shard_mod (shard_base >= band_mod)
-    uint32_t *band_counter;  // ... and every band tile's workgroup adds 1 here when its edges are out (band_tile_done, hmk_device.h)
-    uint32_t *deg_up;    // placing mode: the rows' upper counters ...
-    uint32_t *deg_lo;    // ... and lower counters (symmetric only)
-    uint32_t *rank;      // placing mode (else null)
+    // optional (may be null): the rows' degrees, counted while the edges are written (the CSR build's first pass, fused into the
+    // scoring of a clustering call) with fire-and-forget atomics.  Zeroed by the caller.
+    uint32_t *deg;       // total degrees -- or, with deg_m_offset = n, upper counts (the edge's smaller end) in deg[0, n) and lower counts in deg[n, 2n)
+    uint32_t deg_m_offset;   // the larger end m of a symmetric edge counts into deg[deg_m_offset + m] (0: one counter per row)
 };
 
 // one directed neighbour: sequenceScore(seq1 = m, seq2 = x) = s for the row x it is stored under
@@ -95,10 +82,6 @@ struct NbrPacked {
 // later and are neighbours too (starts at 0).
 struct GreedyCand { int32_t c, mn, covered; };
 
-// One entry of a join-propagation list (k_greedy_prop): candidate entry k (index into the cand array) belongs to a later
-// leftover that is a neighbour of the joining sequence, with that pair's score.
-struct GreedyProp { uint32_t k; int32_t score; };
-
 // A run of packed edges in device memory: min(*count, cap) entries at `edges`.  The CSR kernels take a short list of
 // them: the HMK_EDGE_SHARDS segments of one neighbour pass, or those plus the blocks gathered from other devices.
 struct EdgeSeg { const uint64_t *edges; const unsigned long long *count; uint64_t cap; };
@@ -107,19 +90,54 @@ struct EdgeSegs { EdgeSeg s[HMK_MAX_SEGS]; uint32_t n; };
 
 // Optional device-side pre-check of the second loop (hmk_cluster.cpp provides it when the adjacency is still resident on
 // the GPU): given cluster_of[n] (-1 = none), the clusters' member counts and the leftover list, fill the candidate
-// CSR (cand_start[nl + 1], cand[]) and, if want_prop, the join-propagation lists (prop_start[cand.size() + 1], prop[];
-// *have_prop says whether they were produced).  Returns false if it could not (the merge then fetches the whole
-// adjacency and runs its threaded host version).
+// CSR (cand_start[nl + 1], cand[]).  Returns false if it could not (the merge then fetches the whole adjacency and runs
+// its threaded host version).
 using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::vector<int32_t> &usize,
-                                          const std::vector<uint32_t> &leftover, bool want_prop,
-                                          std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand,
-                                          std::vector<uint32_t> &prop_start, std::vector<GreedyProp> &prop, bool *have_prop)>;
+                                          const std::vector<uint32_t> &leftover,
+                                          std::vector<uint32_t> &cand_start, std::vector<GreedyCand> &cand)>;
+
+// The band of a clustering call as the device prepares it for phase 1 (firstPhase, LimitedGreedySequenceClusterer.java:77-120;
+// hmk_cluster.cpp, k_band_* in k_edges.hip): what a step of the loop needs of row x < rows, split by where the neighbour lies.
+//   near        the neighbours with an id below `rows` (band rows themselves): near[near_start[x] .. near_start[x + 1]), the
+//               first near_up[x] of them with an id above x.  Entries are id << 8 | (score - base), as in the packed adjacency.
+//   far_top     the row's best FAR neighbours (id >= rows) by the reference's key (score, Cluster.size(), smaller id --
+//               ClinkageSequenceClusterer.java:166-173, :275-289), best first, far_t per row, ~0u = no more; far_more[x] != 0:
+//               the row has far neighbours beyond the far_t listed.  A far sequence changes state in phase 1 only by being
+//               absorbed (:99-101, :108-110), so the first entry that is still free IS the best far candidate of :93.
+//   tr          for the row's first TR_PER_ROW far candidates c: the band rows that have c as a neighbour (c's row restricted
+//               to ids below `rows`), entries band row << 8 | (score - base): what the new cluster {x, c} needs to know which
+//               later band rows it is feasible for.  A sequence's list travels once: slot u = TR_PER_ROW * x + t finds it at
+//               v = tr_owner[u], tr[tr_start[v] .. tr_start[v + 1]).  Any other far sequence's list comes through
+//               GreedyHooks::far_row.
+struct BandPack {
+    static constexpr uint32_t TR_PER_ROW = 2;
+    uint32_t rows = 0, far_t = 0;
+    const uint32_t *near_start = nullptr, *near_up = nullptr, *near = nullptr;
+    const uint32_t *far_top = nullptr;
+    const uint8_t *far_more = nullptr;
+    const uint32_t *tr_owner = nullptr, *tr_start = nullptr, *tr = nullptr;
+};
+
+// test / diagnostic options of the host merge (the library reads its environment switches once per call, hmk_ctx.h Switches)
+struct GreedyOptions {
+    int phase1_threads = 0;   // > 0: HMK_PHASE1_THREADS (any input, that many threads for the window scans)
+    int phase1_window = 0;    // > 0: HMK_PHASE1_WINDOW (positions per window)
+    bool timing = false;      // HMK_GREEDY_TIMING: the phases' times on stderr
+    // HMK_PHASE1_HOST_BAND=rows[,far_t] (greedy_from_edges only, symmetric scores): phase 1 runs on a BandPack that is built on
+    // the HOST from the whole graph -- the literal statement of what the device's k_band_* kernels must produce, and the CPU test
+    // of the incremental phase 1 against the oracle
+    int host_band_rows = 0, host_band_far_t = 0;
+};
 
 // Hooks of the host merge for a caller that still has the adjacency on the device (hmk_cluster.cpp):
 //   precheck    see GreedyPrecheck (may be empty)
-//   need_rows   only a prefix of the rows may be in host memory yet: need_rows(k) returns R > k once start[0 .. R] and
-//               adj[0 .. start[R]) are valid on the host (it fetches more rows from the device if it has to).  Phase 1
-//               asks row by row; with the device pre-check and propagation lists the second loop needs no rows at all.
+//   band_pack   the prepared band (blocks until it is on the host), or null: phase 1 then reads whole rows (need_rows)
+//   far_row     band neighbours of far sequence `id` (entries band row << 8 | score - base), fetched from the device on demand
+//   band_far    the far part of band row x (entries id << 8 | score - base), on demand
+//   need_rows   only some rows may be in host memory yet: need_rows(k, from) returns R > k once start[from .. R] and
+//               adj[start[from] .. start[R]) are valid on the host (it fetches more rows from the device if it has to; adj_base
+//               says where adj[0] would lie).  Phase 1 asks row by row -- from 0, or from the band's row limit once the
+//               prepared band has served the rows below it; with the device pre-check the second loop needs no rows at all.
 //               Empty = everything is there already.
 // Optional device-side run of the whole second loop (hmk_cluster.cpp, k_loop_*): given the state after phase 1 --
 // cluster_of[n], per cluster slot its member count, Cluster.size() and id, the leftover list -- fill join_slot[q] =
@@ -132,7 +150,9 @@ struct GreedyTimes { double phase1_ms, host_precheck_ms, sequential_ms; };   // 
 struct GreedyHooks {
     GreedyPrecheck precheck;
     GreedyDeviceLoop device_loop;
-    std::function<uint32_t(uint32_t)> need_rows;   // a return value <= k means the rows could not be had: the merge stops
+    std::function<const BandPack *()> band_pack;
+    std::function<bool(uint32_t, std::vector<uint32_t> &)> far_row, band_far;
+    std::function<uint32_t(uint32_t, uint32_t)> need_rows;   // a return value <= k means the rows could not be had: the merge stops
     std::function<const void *()> adj_base;        // with need_rows: where adj[] is now (the host buffer may move when it grows)
     GreedyTimes *times = nullptr;
 };
@@ -150,13 +170,14 @@ unsigned usable_cpus();
 int greedy_from_csr(uint32_t n, const int32_t *sizes, const uint64_t *start, const Nbr *adj, const uint32_t *upper,
                     const GreedyHooks *hooks, bool symmetric_scores, int max_clusters,
                     int32_t *cluster_id, int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st,
-                    std::string *err);
+                    std::string *err, const GreedyOptions &opt = GreedyOptions());
 int greedy_from_csr_packed(uint32_t n, const int32_t *sizes, const uint64_t *start, const NbrPacked *adj,
                            const uint32_t *upper, const GreedyHooks *hooks, bool symmetric_scores, int max_clusters, int32_t *cluster_id, int32_t *result_order, int32_t *member_rank,
-                           hmk_greedy_stats *st, std::string *err);
+                           hmk_greedy_stats *st, std::string *err, const GreedyOptions &opt = GreedyOptions());
 int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, uint64_t n_edges,
                       bool symmetric, int threshold, int max_clusters, int32_t *cluster_id,
-                      int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err);
+                      int32_t *result_order, int32_t *member_rank, hmk_greedy_stats *st, std::string *err,
+                      const GreedyOptions &opt = GreedyOptions());
 
 // exact complete linkage by nearest-neighbour chain on a symmetric CSR adjacency (hmk_clinkage.cpp)
 // hashset_version: 8 (Java 8+), 7 (JDK 7u6+) or 6 (JDK 6 / early 7): whose java.util.HashSet iteration order picks the chain

@@ -10,11 +10,11 @@
 namespace hmk {
 
 // rows per tile the SWAR kernel instantiation (lbmax, nw) was built with
-int swar_rows_per_tile(int lbmax, int nw, bool exact, int hot_variant);
+int swar_rows_per_tile(int lbmax, int nw, bool exact);
 // smallest instantiated column-length capacity that holds columns of length lb
 int swar_lbmax_for(int lb);
 
-hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant, const NeighborParams &P,
+hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, const NeighborParams &P,
                                  uint32_t tile_base, uint32_t n_tiles, hipStream_t s);
 // row-packed kernels (k_neighbors_rows.hip): 8 rows per 8-byte table entry, one accumulator pair per shift.
 // exact: a set of one length lb (its own instantiation); else the capacity form, rows_cap_for(lb) >= lb.
@@ -34,8 +34,9 @@ hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, co
                         uint32_t width, int a, int b, int32_t *out, int32_t *out_shift, hipStream_t s);
 
 // LocalAlignmentScorer all ordered pairs, thresholded (tiles of one (row length, column length) class, lpad 32)
-hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
-                                  const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s);
+// force_signed / force_unpacked: the test switches HMK_LOCAL_SIGNED / HMK_LOCAL_NO_PK
+hipError_t launch_neighbors_local(int lbmax, bool enc, bool force_signed, bool force_unpacked, const NeighborParams &P, uint32_t tile_base,
+                                  uint32_t n_tiles, const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s);
 
 // the same pass with the literal DP: any gap penalties, any matrix range
 hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, const int32_t *d_matrix,
@@ -52,19 +53,26 @@ hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row
                                   uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s);
 hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uint64_t *start, uint32_t n, uint64_t *tile_scratch,
                                 int *score_range, hipStream_t s);
-hipError_t launch_csr_scatter_ranked(const EdgeSegs &segs, const uint64_t *edges0, const uint32_t *rank, bool symmetric,
-                                     const uint64_t *start, void *adj, bool packed, int base, hipStream_t s);   // deg[] already counted by the neighbour kernel (NeighborParams::deg)
 hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, uint32_t n, hipStream_t s);   // dst[k] += src[k]
-// stream s continues when *counter >= target (band tiles of a running pass) or after ~5 s (*timed_out = 1)
-hipError_t launch_wait_counter(const uint32_t *counter, uint32_t target, uint32_t *timed_out, hipStream_t s);
 size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
 size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)
 size_t csr_partition_scratch_bytes();
 hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *start, uint32_t *cursor, void *adj, int base, uint32_t n,
-                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, hipStream_t s);
+                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, int forced_shift, hipStream_t s);
 hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
                               bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n = 0);
+
+// the band, prepared for phase 1 (BandPack, hmk_internal.h; k_band_* in k_edges.hip).  bstart / bup / badj: the band's CSR (packed
+// entries, rows [upper | lower]); fdeg, fcur, owner_of: zeroed uint32[n]; every output array is sized by the caller.
+hipError_t launch_band_split(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, uint32_t ft, const int32_t *seq_size,
+                             uint32_t *near_cnt, uint32_t *near_up, uint32_t *far_top, uint8_t *far_more, uint32_t *fdeg, hipStream_t s);
+hipError_t launch_band_fill(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, const uint32_t *near_start, uint32_t *near,
+                            const uint32_t *fstart, uint32_t *fcur, uint32_t *fadj, hipStream_t s);
+hipError_t launch_band_tr_claim(const uint32_t *far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *fdeg, uint32_t *owner_of,
+                                uint32_t *tr_cnt, hipStream_t s);
+hipError_t launch_band_tr_fill(const uint32_t *far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *owner_of, const uint32_t *fstart,
+                               const uint32_t *fdeg, const uint32_t *fadj, const uint32_t *tr_start, uint32_t *tr_owner, uint32_t *tr, hipStream_t s);
 
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);
@@ -103,21 +111,16 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
                              uint32_t *choice, uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken,
                              uint32_t *cursor, uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
                              const uint32_t *sub_start, const uint64_t *subs, void *clusters, const int32_t *seq_size,
-                             uint32_t *counters, unsigned long long *host_word, hipStream_t s);
+                             uint32_t *counters, unsigned long long *host_word, int chain_mode, hipStream_t s);
 hipError_t launch_loop_sort_subscribers(uint32_t n_clusters, const uint32_t *sub_start, uint64_t *subs, uint64_t *tmp, hipStream_t s);
 // clusters: 16 bytes per cluster {joined = 0, id, size}, built on the device from the uploaded ids and sizes
 hipError_t launch_loop_init(uint32_t n_clusters, const long long *csize, const int32_t *cid, void *cl, const uint32_t *sub_start,
                             uint32_t *cursor, uint32_t nl, uint32_t *list, uint32_t *dirty, uint32_t *counters, uint32_t *taken,
                             uint8_t *status, int32_t *join_slot, hipStream_t s);
-// join-propagation lists of the second loop (k_greedy_prop): lidx = sequence -> leftover index or -1
-hipError_t launch_fill_lidx(const uint32_t *leftover, uint32_t nl, int32_t *lidx, uint32_t n, hipStream_t s);
-hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, const uint32_t *up, const void *adj,
-                              const int32_t *lidx, const uint32_t *leftover, uint32_t nl, const uint32_t *cand_start,
-                              const GreedyCand *cand, uint32_t *pcnt, const uint32_t *pstart, GreedyProp *prop, hipStream_t s);
 
 // LocalAlignmentScorer dense block, register-resident DP (needs |M| <= 127, gap penalties <= 0, len <= lbmax)
 // enc: the tagged-max DP (needs |M| <= 31 and -31 <= gap penalties <= 0)
-hipError_t launch_local_block(int lbmax, bool enc, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,
+hipError_t launch_local_block(int lbmax, bool enc, bool force_signed, bool force_unpacked, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix, uint32_t r0,
                               uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
                               hipStream_t s);
 

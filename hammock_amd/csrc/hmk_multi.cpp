@@ -39,17 +39,17 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
     // HMK_MULTI_SERIAL=1: the conservative form, for a machine where the overlapped one misbehaves -- no worker threads, no band, no
     // peer copies: the peers score their shards one after the other from the calling thread, each is synchronised, and its block
     // and row degrees travel through host memory (two plain hipMemcpy); then the root scores its shard and runs the same tail.
-    const bool serial = getenv("HMK_MULTI_SERIAL") != nullptr;
+    const bool serial = ctx->sw.multi_serial;
     int64_t band_req = 0;
-    if (!serial && !clink && max_clusters > 0 && n >= 16384 && getenv("HMK_NO_BAND") == nullptr) band_req = std::min<int64_t>(n, 2LL * max_clusters + 1024);
+    if (!serial && !clink && max_clusters > 0 && n >= 16384 && !ctx->sw.no_band) band_req = std::min<int64_t>(n, 2LL * max_clusters + 1024);
     if (band_req * 2 > (int64_t)n) band_req = 0;
     uint64_t guess = (uint64_t)((double)n * (n - 1) / 2 * (ctx->symmetric ? 0.003 : 0.006) / G * 1.25) + (1u << 20);
-    if (const char *v = getenv("HMK_EDGE_GUESS")) guess = std::strtoull(v, nullptr, 10);   // tests: force the overflow / retry path
+    if (ctx->sw.edge_guess) guess = ctx->sw.edge_guess;   // tests: force the overflow / retry path
     const long long top = (long long)ctx->max_len * std::max(0, ctx->max_m) +
                           (long long)std::max(0, shift_penalty) * ((ctx->max_len - ctx->min_len) + 2LL * max_shift);
     // every device counts the row degrees of the edges it writes (the CSR's first pass, fused into the scoring as in the
     // single-device call); the peers' counters travel with their blocks and are added to the root's
-    const bool fuse = ctx->symmetric && getenv("HMK_NO_FUSED_DEGREE") == nullptr;
+    const bool fuse = ctx->symmetric;
     int st = HMK_OK;
     for (int attempt = 0; attempt < 4; attempt++) {
         // ---- edge buffers (grown to the counts of the last attempt if a segment overflowed) and the root-side regions -----
@@ -103,7 +103,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             if (!c->ev_gather) HIPCHK(ctx, hipEventCreateWithFlags(&c->ev_gather, hipEventDisableTiming));
         }
         // everything the tail will want on the root, before anything is enqueued (a hipMalloc waits for running kernels)
-        const bool packed = top - threshold <= 255 && getenv("HMK_ADJ_8BYTE") == nullptr;
+        const bool packed = top - threshold <= 255 && !ctx->sw.adj_8byte;
         {
             uint64_t all_cap = ctx->d_edges_cap + off;
             const size_t esz0 = packed ? sizeof(NbrPacked) : sizeof(Nbr);
@@ -114,7 +114,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             HIPCHK(ctx, ensure_buf(ctx, SB_SCAN, scan_scratch_bytes(n)));
             HIPCHK(ctx, ensure_buf(ctx, SB_RANGE, 64));
             HIPCHK(ctx, ensure_pinned(&ctx->h_start, &ctx->h_start_cap, ((size_t)n + 1) * 8 + (size_t)n * 4 + 64, 0));
-            if (csr_by_bucket(n, ctx->symmetric, packed, false)) {
+            if (csr_by_bucket(ctx->symmetric, packed)) {
                 HIPCHK(ctx, ensure_buf(ctx, SB_PART, (all_cap + 1) * 8));
                 HIPCHK(ctx, ensure_buf(ctx, SB_PARTSCR, csr_partition_scratch_bytes()));
             }
@@ -124,7 +124,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
         unsigned long long *root_cnt = buf<unsigned long long>(ctx, SB_PEERCNT);
 
         // ---- a peer's whole share: plan, band tiles, band block, the rest, the whole block; each hand-over as soon as it can go ----
-        auto peer_main = [&](PeerJob &J) {
+        auto peer_body = [&](PeerJob &J) {
             hmk_ctx *c = J.c;
             auto set_band = [&](int v) { { std::lock_guard<std::mutex> l(J.mu); J.band_state = v; } J.cv.notify_all(); };
             auto set_full = [&](int v, int code, const std::string &msg) {
@@ -216,6 +216,26 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             if (e != hipSuccess) { hip_fail("edge hand-over", e); return; }
             set_full(1, HMK_OK, "");
         };
+        // (an exception inside a worker -- bad_alloc from the plan, from a staging vector -- must end as this call's error, not
+        // as std::terminate: the job is marked failed, which also releases whoever waits for its band or its edges)
+        auto peer_main = [&](PeerJob &J) {
+            try { peer_body(J); }
+            catch (const std::bad_alloc &) { std::lock_guard<std::mutex> l(J.mu); J.full_state = -1; J.status = HMK_ERR_OOM; J.err = "out of host memory in a peer's worker"; if (J.band_state == 0) J.band_state = -1; J.cv.notify_all(); }
+            catch (const std::exception &ex) { std::lock_guard<std::mutex> l(J.mu); J.full_state = -1; J.status = HMK_ERR_DEVICE; J.err = ex.what(); if (J.band_state == 0) J.band_state = -1; J.cv.notify_all(); }
+        };
+        struct Joiner {   // on every way out: the workers are done and nothing they enqueued is still in flight before their state goes away
+            std::vector<std::unique_ptr<PeerJob>> &jobs;
+            hipStream_t S, C;
+            const hmk_ctx *root;
+            ~Joiner() {
+                for (auto &jp : jobs) if (jp->th.joinable()) jp->th.join();
+                if (root->wedged) return;   // (a device that stopped making progress: nothing waits for it any more)
+                for (auto &jp : jobs) if (jp->c->gather_stream) (void)hipStreamSynchronize(jp->c->gather_stream);   // peer copies into the root's blocks
+                (void)hipStreamSynchronize(S);
+                (void)hipStreamSynchronize(C);
+                (void)hipGetLastError();
+            }
+        } joiner{jobs, S, C, ctx};   // (before the first thread starts: a std::thread constructor that throws leaves no joinable thread behind)
         if (serial) {
             for (auto &jp : jobs) peer_main(*jp);
             st = need_device(ctx);   // (back on the root's device)
@@ -223,10 +243,6 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
         } else {
             for (auto &jp : jobs) { PeerJob *J = jp.get(); J->th = std::thread([&peer_main, J]() { peer_main(*J); }); }
         }
-        struct Joiner {   // on every way out: the workers are done before their state goes away
-            std::vector<std::unique_ptr<PeerJob>> &jobs;
-            ~Joiner() { for (auto &jp : jobs) if (jp->th.joinable()) jp->th.join(); }
-        } joiner{jobs};
 
         // ---- the root's own shard, on the calling thread ----------------------------------------------------------
         st = build_plan(ctx, max_shift, shift_penalty, threshold, 0, G, band_req);

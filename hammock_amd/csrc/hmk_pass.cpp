@@ -6,8 +6,7 @@ namespace hmk { namespace impl {
 
 int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
                          uint64_t capacity, void *d_counts, hipStream_t stream, int which,
-                         int64_t band_rows, uint32_t *d_deg, uint32_t *d_deg_lo, uint32_t *d_rank,
-                         uint32_t shard_base, uint32_t shard_mod, uint32_t band_mod, uint32_t *band_counter) {
+                         int64_t band_rows, uint32_t *d_deg, uint32_t *d_deg_lo) {
     int st = need_device(ctx);
     if (st) return st;
     if (!d_edges || !d_counts || capacity < HMK_EDGE_SHARDS)
@@ -15,9 +14,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     st = build_plan(ctx, X, p, thr, part, n_parts, band_rows);
     if (st) return st;
     Plan &pl = ctx->plan;
-    if (which != LAUNCH_REST && which != LAUNCH_BAND_NOZERO)
-        HIPCHK(ctx, hipMemsetAsync(d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), stream));
-    if (which == LAUNCH_BAND_NOZERO) which = LAUNCH_BAND;
+    if (which != LAUNCH_REST) HIPCHK(ctx, hipMemsetAsync(d_counts, 0, HMK_EDGE_SHARDS * sizeof(unsigned long long), stream));
     NeighborParams P{};
     P.res_sorted = pl.d_res_sorted;
     P.perm = pl.d_perm;
@@ -31,21 +28,13 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     P.n_tiles = pl.stats.n_tiles;
     P.lpad = (uint32_t)pl.lpad;
     P.symmetric = ctx->symmetric ? 1u : 0u;
-    P.deg = d_rank ? nullptr : d_deg;
-    P.deg_up = d_rank ? d_deg : nullptr;
-    P.deg_lo = d_rank ? d_deg_lo : nullptr;
-    P.deg_m_offset = (!d_rank && d_deg && d_deg_lo) ? (uint32_t)(d_deg_lo - d_deg) : 0u;   // counting mode with split counters
-    P.shard_base = shard_base;
-    P.shard_mod = shard_mod;
-    P.band_mod = band_mod;
-    P.band_counter = band_counter;
-    P.rank = d_rank;
+    P.deg = d_deg;
+    P.deg_m_offset = (d_deg && d_deg_lo) ? (uint32_t)(d_deg_lo - d_deg) : 0u;   // split counters: upper counts, then lower counts
     // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has a dozen of
     // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
     // start, and join back into `stream`.
-    const bool fork = pl.groups.size() > 2 && getenv("HMK_NO_SIDE_STREAMS") == nullptr;
-    int n_side = 3;
-    if (const char *v = getenv("HMK_SIDE_STREAMS")) n_side = std::max(1, std::min((int)hmk_ctx::N_SIDE, atoi(v)));
+    const bool fork = pl.groups.size() > 2;
+    constexpr int n_side = hmk_ctx::N_SIDE;
     // The streams the launches are dealt to: the pass's own stream and n_side - 1 others.  A process gets few hardware queues
     // (4 by default), and streams beyond them share one and serialise: with the clustering calls' two streams created first
     // (hmk_create), three more side streams cost this pass 5 % (5.36 -> 5.65 ms on BASELINE config 4a).  So a pass that does
@@ -56,14 +45,8 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     if (fork) {
         if (!ctx->ev_fork) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
         std::vector<hipStream_t> lend;
-        if (getenv("HMK_OWN_SIDE_STREAMS") == nullptr && ctx->gstream && ctx->copy_stream) {
-            if (stream != ctx->gstream && stream != ctx->copy_stream && stream != ctx->rest_stream) {
-                // (rest_stream: a clustering call's second launch -- both are busy.)  HMK_LEND=prio: the high- and the low-priority
-                // stream instead of the clustering stream -- three priority classes are three hardware queues for certain, two
-                // normal-priority streams may share one
-                if (const char *v = getenv("HMK_LEND"); v && std::strcmp(v, "prio") == 0 && ctx->rest_stream) lend = {ctx->copy_stream, ctx->rest_stream};
-                else lend = {ctx->gstream, ctx->copy_stream};
-            }
+        if (ctx->gstream && ctx->copy_stream) {
+            if (stream != ctx->gstream && stream != ctx->copy_stream) lend = {ctx->gstream, ctx->copy_stream};
             else if (stream == ctx->gstream && which == LAUNCH_ALL) lend = {ctx->copy_stream};
         }
         int own = 0;
@@ -93,7 +76,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
         else if (g.path == PATH_ROWS)
             HIPCHK(ctx, launch_neighbors_rows(X, g.nw, g.lbk, pl.rows_exact, P, t0, cnt, s));
         else
-            HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, pl.hot_variant, P, t0, cnt, s));
+            HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, P, t0, cnt, s));
     }
     if (fork)
         for (int k = 1; k < n_side; k++) {
@@ -107,8 +90,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
 // every segment fits, and returns the per-segment counts.
 // the tagged-max SW kernels carry 4 * value + direction in int8 table bytes
 bool local_enc(const hmk_ctx *ctx, int gap_open, int gap_extend) {
-    return ctx->min_m >= -31 && ctx->max_m <= 31 && gap_open >= -31 && gap_extend >= -31 && gap_open <= 0 &&
-           gap_extend <= 0 && getenv("HMK_LOCAL_PLAIN") == nullptr;
+    return ctx->min_m >= -31 && ctx->max_m <= 31 && gap_open >= -31 && gap_extend >= -31 && gap_open <= 0 && gap_extend <= 0;
 }
 
 int neighbors_internal(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, uint64_t want_cap,
@@ -123,7 +105,7 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
     if (st) return st;
     // the striped register kernels take gap penalties <= 0 and int8 matrix entries; anything else (the reference imposes
     // neither, LocalAlignmentScorer.java:43-55) runs the literal DP on the same tiles
-    const bool literal = gap_open > 0 || gap_extend > 0 || ctx->min_m < -127 || ctx->max_m > 127 || getenv("HMK_LOCAL_LITERAL") != nullptr;
+    const bool literal = gap_open > 0 || gap_extend > 0 || ctx->min_m < -127 || ctx->max_m > 127 || ctx->sw.local_literal;
     {   // edge scores travel as int16
         const long long top = (long long)ctx->max_len * std::max(0, ctx->max_m) +
                               2LL * ctx->max_len * (long long)std::max(0, std::max(gap_open, gap_extend));
@@ -144,10 +126,6 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
     P.edges = d_edges;
     P.counts = d_counts;
     P.cap_per_shard = capacity / HMK_EDGE_SHARDS;
-    P.shard_base = 0;
-    P.shard_mod = HMK_EDGE_SHARDS;
-    P.band_mod = 0;
-    P.band_counter = nullptr;
     P.n_tiles = pl.n_tiles;
     P.lpad = 32;
     P.symmetric = 0;
@@ -155,7 +133,8 @@ int neighbors_local_dev_locked(hmk_ctx *ctx, int gap_open, int gap_extend, int t
     if (literal)
         HIPCHK(ctx, launch_neighbors_local_literal(P, 0, pl.n_tiles, ctx->d_M, gap_open, gap_extend, thr, stream));
     else
-        HIPCHK(ctx, launch_neighbors_local(ctx->max_len, local_enc(ctx, gap_open, gap_extend), P, 0, pl.n_tiles, ctx->d_M, gap_open, gap_extend, thr, stream));
+        HIPCHK(ctx, launch_neighbors_local(ctx->max_len, local_enc(ctx, gap_open, gap_extend), ctx->sw.local_signed, ctx->sw.local_no_pk, P, 0, pl.n_tiles,
+                                           ctx->d_M, gap_open, gap_extend, thr, stream));
     return HMK_OK;
 }
 
@@ -188,6 +167,7 @@ int check_pairs(hmk_ctx *ctx, const uint32_t *i, const uint32_t *j, uint64_t n_p
 int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, uint64_t n_pairs, int a, int b,
                 int32_t *out, int32_t *out_shift) {
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     int st = need_device(ctx);
     if (st) return st;
     if (scorer == 0 && a < 0) return fail(ctx, HMK_ERR_BAD_ARG, "max_shift must be >= 0");
@@ -228,6 +208,7 @@ int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, 
 int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int a, int b,
                 int32_t *out) {
     std::lock_guard<std::mutex> lock(ctx->mu);
+    refresh_switches(ctx);
     int st = need_device(ctx);
     if (st) return st;
     if (ctx->n == 0) return fail(ctx, HMK_ERR_NO_SEQUENCES, "no sequences set (hmk_set_sequences)");
@@ -253,10 +234,10 @@ int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0,
     hipError_t e;
     timer_start(ctx);
     // LocalAlignmentScorer: the register-resident striped kernel when its preconditions hold
-    const bool fast_local = scorer == 1 && a <= 0 && b <= 0 && ctx->min_m >= -127 && ctx->max_m <= 127 &&
-                            getenv("HMK_LOCAL_LITERAL") == nullptr;
+    const bool fast_local = scorer == 1 && a <= 0 && b <= 0 && ctx->min_m >= -127 && ctx->max_m <= 127 && !ctx->sw.local_literal;
     if (fast_local)
-        e = launch_local_block(ctx->max_len, local_enc(ctx, a, b), ctx->d_res32, ctx->d_len, ctx->d_M, r0, r1, c0, c1, a, b, d_out, nullptr);
+        e = launch_local_block(ctx->max_len, local_enc(ctx, a, b), ctx->sw.local_signed, ctx->sw.local_no_pk, ctx->d_res32, ctx->d_len, ctx->d_M, r0, r1,
+                               c0, c1, a, b, d_out, nullptr);
     else
         e = launch_pairs(scorer, ctx->d_res32, ctx->d_len, ctx->d_M, nullptr, nullptr, n_pairs, r0, c0, c1 - c0, a, b,
                          d_out, nullptr, nullptr);

@@ -106,12 +106,12 @@ void classify(const hmk_ctx *ctx, int la, int lb, int X, int p, int thr, TileCla
 int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, int64_t band_rows) {
     Plan &pl = ctx->plan;
     if (pl.valid && pl.X == X && pl.p == p && pl.thr == thr && pl.part == part && pl.n_parts == n_parts &&
-        (band_rows < 0 || pl.band_req == band_rows))
+        (band_rows < 0 || pl.band_req == band_rows) && pl.no_rows_kernel == ctx->sw.no_rows_kernel)
         return HMK_OK;
     free_plan(pl);
     if (band_rows < 0) band_rows = 0;
     const int64_t band_req = band_rows;
-    const bool plan_timing = getenv("HMK_PLAN_TIMING") != nullptr;
+    const bool plan_timing = ctx->sw.greedy_timing;
     const auto plan_t0 = std::chrono::steady_clock::now();
     auto plan_lap = [&](const char *what) {
         if (plan_timing)
@@ -160,7 +160,6 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
             classify(ctx, la, lb, X, p, thr, &tc, -1, &limit);
             if (tc.path != PATH_U8 && limit >= 0) refine = true;
         }
-    if (getenv("HMK_NO_ROW_BOUNDS")) refine = false;
     std::vector<uint32_t> bound_sorted;  // bound of the sequence at each sorted position (refine only)
     constexpr uint32_t BCAP = 4095;      // bounds are only compared with limits < 65536; clamped for the counting sort
     // refine, but EVERY row of every class that needs its bound has one within the class's limit (uniform 15- or 20-mers at the
@@ -184,7 +183,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         {
             uint32_t bucket_max[HMK_MAX_LEN + 2] = {0};
             for (uint32_t k = 0; k < n; k++) bucket_max[ctx->len[k]] = std::max(bucket_max[ctx->len[k]], bound[k]);
-            all_rows_fit = getenv("HMK_ALWAYS_SORT_BOUNDS") == nullptr;
+            all_rows_fit = true;
             for (int la = 1; la <= HMK_MAX_LEN && all_rows_fit; la++)
                 for (int lb = 1; lb <= HMK_MAX_LEN && all_rows_fit; lb++) {
                     if (bucket[la] == bucket[la + 1] || bucket[lb] == bucket[lb + 1]) continue;
@@ -228,25 +227,21 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     // lanes in 8-byte entries.  It reads residues pre-multiplied by the entry size (see res_sorted below).
     // Row-packed kernels (k_neighbors_rows.hip) take every 8-bit-lane class they have an instantiation for; a set of one
     // length may have one with the length at compile time.  HMK_NO_ROWS_KERNEL=1: the shift-packed kernels of round 1-2.
-    const bool use_rows = getenv("HMK_NO_ROWS_KERNEL") == nullptr;
+    const bool use_rows = !ctx->sw.no_rows_kernel;
+    pl.no_rows_kernel = ctx->sw.no_rows_kernel;
     pl.exact = false;
     pl.rows_exact = false;
     if (use_rows && ctx->min_len == ctx->max_len) {
         TileClass t1;
         classify(ctx, ctx->min_len, ctx->min_len, X, p, thr, &t1);
         // (8-bit lanes for any pair of the class, or -- by their score bounds -- for every row the set has)
-        pl.rows_exact = (t1.path == PATH_U8 || (refine && all_rows_fit)) && rows_kernel_available(X, ctx->min_len, ctx->min_len, true) &&
-                        getenv("HMK_NO_ROWS_EXACT") == nullptr;
+        pl.rows_exact = (t1.path == PATH_U8 || (refine && all_rows_fit)) && rows_kernel_available(X, ctx->min_len, ctx->min_len, true);
     }
     if (!use_rows && ctx->min_len == 12 && ctx->max_len == 12 && X == 3) {
         TileClass t12;
         classify(ctx, 12, 12, X, p, thr, &t12);
         pl.exact = t12.path == PATH_U8 && t12.nw == 2;
     }
-    // Tiling (measured on MI355X, tools/tune_hot.py): 6 rows x 2 columns per lane and long
-    // column runs win (7 workgroups/CU, table build amortised); shrink the runs for small
-    // inputs so the grid still has a few thousand workgroups.
-    pl.hot_variant = 7;
     // Column runs: long runs amortise the table build (65,536 columns: 3.55 ms for the whole 10^5 pass against
     // 3.60 ms with 16,384), short ones keep the tail of a small launch short (a 1/8 shard: 0.478 ms with 16,384,
     // 0.532 ms with 65,536).  Take the longest run that still leaves ~8 rounds of workgroups (256 CUs x 7).
@@ -261,15 +256,13 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
     // a third of the slots empty; 3 x 10^4: 2,048 / 4,096 / 8,192 0.354 / 0.301 / 0.294 ms.)
     while (pl.cols_per_tile > 4096 && ((uint64_t)n / tile_rows + 1) * ((uint64_t)n / (2 * pl.cols_per_tile) + 1) < 4096)
         pl.cols_per_tile /= 2;
-    if (const char *v = getenv("HMK_HOT_VARIANT")) pl.hot_variant = atoi(v);   // tuning knobs
-    if (const char *v = getenv("HMK_COLS_PER_TILE")) pl.cols_per_tile = (uint32_t)std::min(65536, std::max(256, atoi(v)));   // hit records hold a 16-bit column offset
 
     // ---- classes and tiles --------------------------------------------------------
     std::vector<TileClass> classes;
     std::map<int, int> class_of;  // la * 64 + lb
     std::map<std::tuple<int, int, int>, std::vector<Tile>> grouped;  // (path, nw, column capacity)
     const uint32_t COLS = pl.cols_per_tile;
-    const bool equal_runs = getenv("HMK_NO_EQUAL_RUNS") == nullptr;
+    const bool equal_runs = true;
     hmk_neighbor_stats &S = pl.stats;
     S = hmk_neighbor_stats{};
     S.symmetric = ctx->symmetric;
@@ -321,7 +314,7 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
                                   (pl.rows_exact || rows_kernel_available(X, la, lb, false));
                 const int lbk = rows ? (pl.rows_exact ? lb : rows_cap_for(lb)) : pl.exact ? 12 : swar_lbmax_for(lb);
                 const uint32_t R = rows ? (uint32_t)rows_per_tile_rows(X, la - lb, lbk, pl.rows_exact)
-                                        : tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(lbk, tc.nw, pl.exact, pl.hot_variant);
+                                        : tc.path == PATH_DIRECT ? 16u : (uint32_t)swar_rows_per_tile(lbk, tc.nw, pl.exact);
                 if (rows) S.classes_rows++;
                 std::vector<Tile> &dst = grouped[rows ? std::make_tuple((int)PATH_ROWS, la - lb, lbk)
                                                       : std::make_tuple((int)tc.path, tc.path == PATH_DIRECT ? 0 : (int)tc.nw,
@@ -375,13 +368,10 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
         // workgroups are dispatched in tile order: biggest tiles first keeps the tail of the launch short
         // (band tiles first: they are launched on their own by hmk_greedy_cluster)
         // (10^6 sequences: a million tiles; the stable sort of them was 30 of the plan's 55 ms on one thread)
-        if (getenv("HMK_NO_LPT") == nullptr)
-            parallel_stable_sort(kv.second, [](const Tile &a, const Tile &b) {
-                if (a.pad0 != b.pad0) return a.pad0 > b.pad0;
-                return (uint64_t)a.nrows * a.ncols > (uint64_t)b.nrows * b.ncols;
-            });
-        else
-            parallel_stable_sort(kv.second, [](const Tile &a, const Tile &b) { return a.pad0 > b.pad0; });
+        parallel_stable_sort(kv.second, [](const Tile &a, const Tile &b) {
+            if (a.pad0 != b.pad0) return a.pad0 > b.pad0;
+            return (uint64_t)a.nrows * a.ncols > (uint64_t)b.nrows * b.ncols;
+        });
         uint32_t n_band = 0;
         for (const Tile &t : kv.second) n_band += t.pad0;
         pl.groups.push_back(Group{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),

@@ -153,7 +153,7 @@ static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *til
 // the upper section grows from the row's start, the lower one backwards from its end, so no per-row split point has
 // to be known beforehand -- afterwards cursor[r] IS the number of upper neighbours ("up[r]").  Consumers that only
 // care about later (larger-id) neighbours walk just the first section.
-template <class NbrT, bool LOWER = true>   // LOWER = false: the upper sections only (the lower ones by bucket, below)
+template <class NbrT>
 __global__ void __launch_bounds__(256)
 k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, NbrT *__restrict__ adj,
                int symmetric, int base, uint32_t row_limit) {
@@ -174,7 +174,7 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t
         if (vx && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
         basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
         if (!valid) continue;
-        const bool vm = LOWER && symmetric && m < row_limit;
+        const bool vm = symmetric && m < row_limit;
         if constexpr (sizeof(NbrT) == 4) {
             const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
             if (vx) adj[start[x] + basex + g.rank] = NbrT{(m << 8) | rel};
@@ -195,10 +195,7 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t
 // the adjacency.  Three streaming passes over the edges instead of one pass of random writes.
 constexpr uint32_t LB_MAX_BUCKETS = 4096;   // LDS tables of the partition kernel: 2 x 16 KB
 constexpr uint32_t LB_MAX_ROWS = 4096;      // rows of a bucket (shift <= 12)
-#ifndef HMK_LB_LOADS
-#define HMK_LB_LOADS 16
-#endif
-constexpr int LB_LOADS = HMK_LB_LOADS;        // edges a thread of the dealing kernel holds: all of them loads in flight at once
+constexpr int LB_LOADS = 16;                  // edges a thread of the dealing kernel holds: all of them loads in flight at once (4 / 8 / 16: 22.1 / 21.5 / 20.4 ms at 10^6)
 constexpr uint32_t LB_CHUNK = LB_LOADS * 1024;   // edges a workgroup deals at a time
 
 // an edge the degree pass counted (k_edge_degree: both ends in [0, n), no self pair); ~0 marks "no edge" in the unrolled loads
@@ -277,9 +274,8 @@ k_lower_offsets(const unsigned long long *__restrict__ bucket_cnt, uint32_t nb, 
 }
 
 // records: row m << 32 | the packed entry (x << 8 | score - base) of m's lower section
-// UPPER: the same pass over the edges also writes the entries of the UPPER sections (row x = the smaller end) straight into the
-// adjacency, as k_edge_scatter<.., false> does -- one read of the edge list less (10 GB at 10^6).
-template <bool UPPER>
+// The same pass over the edges also writes the entries of the UPPER sections (row x = the smaller end) straight into the
+// adjacency, with k_edge_scatter's wave-grouped atomics -- one read of the edge list less (10 GB at 10^6).
 __global__ void __launch_bounds__(1024)
 k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, int base, const unsigned long long *__restrict__ bucket_off,
                   unsigned long long *__restrict__ bucket_fill, uint64_t *__restrict__ recs, const uint64_t *__restrict__ start,
@@ -320,7 +316,7 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
             for (int q0 = 0; q0 < LB_LOADS; q0 += LB_WB) {
                 uint32_t basex[LB_WB], lr[LB_WB];
                 uint64_t st[LB_WB];
-                if (UPPER) {   // (whole waves: wave_groups needs all 64 lanes; a wave's edges come from a handful of rows)
+                {   // (whole waves: wave_groups needs all 64 lanes; a wave's edges come from a handful of rows)
 #pragma unroll
                     for (int u = 0; u < LB_WB; u++) {
                         const uint64_t e = ev[q0 + u];
@@ -454,35 +450,6 @@ k_lower_place_sorted(const uint64_t *__restrict__ recs, const unsigned long long
     if (t < rows) cursor[row_limit + row0 + t] = filled[t];
 }
 
-// The same CSR from edges that were PLACED while they were written (NeighborParams::rank: every edge's rank inside its
-// two row sections): no atomics -- with one returning atomic per edge the scatter above takes 0.83 ms for the 1.28 x 10^7
-// edges of the 10^5 pass and 63 ms at 10^6.  up[] = the rows' upper counters (NeighborParams::deg), already complete.
-// The score range goes to score_range (the packed format is chosen beforehand here; the range is only checked).
-template <class NbrT>
-__global__ void __launch_bounds__(256)
-k_edge_scatter_ranked(const EdgeSegs segs, const uint64_t *__restrict__ edges0, const uint2 *__restrict__ rank,
-                      const uint64_t *__restrict__ start, NbrT *__restrict__ adj, int symmetric, int base) {
-    const EdgeSeg sg = segs.s[blockIdx.y];
-    const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
-    const uint64_t *seg = sg.edges;
-    const uint2 *rk = rank + (sg.edges - edges0);
-    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * 256) {
-        const uint64_t e = seg[k];
-        const uint2 r = rk[k];
-        const uint32_t x = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
-        const uint32_t m = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
-        const int32_t s = HMK_EDGE_SCORE(e);
-        if constexpr (sizeof(NbrT) == 4) {
-            const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
-            adj[start[x] + r.x] = NbrT{(m << 8) | rel};
-            if (symmetric) adj[start[m + 1] - 1 - r.y] = NbrT{(x << 8) | rel};
-        } else {
-            adj[start[x] + r.x] = NbrT{m, s};
-            if (symmetric) adj[start[m + 1] - 1 - r.y] = NbrT{x, s};
-        }
-    }
-}
-
 // The HMK_EDGE_SHARDS output segments -> one contiguous block (device to device), so a
 // fixed-size collective can ship a rank's edges without any host round trip.
 __global__ void __launch_bounds__(256)
@@ -600,19 +567,11 @@ k_rows_unpack(const uint32_t *__restrict__ start, const uint32_t *__restrict__ a
 // clusters are counted in a per-wave LDS hash table (key = cluster, count, min score); a row with more distinct clusters
 // than the table takes is walked once per class of clusters (see the kernel); only beyond 64 classes does it raise
 // *overflow (the host then runs its own pre-check).
-#ifndef HMK_PRE_WAVES
-#define HMK_PRE_WAVES 2
-#endif
 // waves (= leftovers in flight) per workgroup of the pre-check: a wave's tables are 14 KB, so 4 / 2 / 1 waves per workgroup put
 // 8 / 10 / 11 waves on a CU: 14.9 / 12.8 / 12.6 ms at 10^6 (22.3 / 19.4 in the reference's default order), no difference at 10^5
-constexpr int PRE_WAVES = HMK_PRE_WAVES;
-#ifndef HMK_PRE_UNROLL
-#define HMK_PRE_UNROLL 16
-#endif
-#ifndef HMK_PRE_SLOTS
-#define HMK_PRE_SLOTS 1024
-#endif
-constexpr int PRE_SLOTS = HMK_PRE_SLOTS;   // per wave; 14 KB of tables.  (PRE_SLOTS_SMALL: the first stage of the single pass, see below)
+constexpr int PRE_WAVES = 2;
+constexpr int PRE_UNROLL = 16;   // row entries in flight per lane (see scan_row in the kernel)
+constexpr int PRE_SLOTS = 1024;   // per wave; 14 KB of tables.  (PRE_SLOTS_SMALL: the first stage of the single pass, see below)
 constexpr int PRE_SLOTS_SMALL = 128, PRE_SLOTS_MEDIUM = 512;
 
 __device__ __forceinline__ uint32_t nbr_id(const Nbr &a) { return a.m; }
@@ -699,7 +658,6 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
         // a lane has many entries in flight (10^6 sequences, 10 GB of rows: 2 / 4 / 8 / 12 / 16 / 24 entries per lane:
         // 22.0 / 18.6 / 16.3 / 15.3 / 14.9 / 14.6 ms).
         auto scan_row = [&](uint32_t part, uint32_t parts) {
-            constexpr int PRE_UNROLL = HMK_PRE_UNROLL;
             for (uint64_t k0 = b; k0 < e; k0 += 64 * PRE_UNROLL) {   // wave-uniform
                 NbrT nb[PRE_UNROLL];
                 bool in[PRE_UNROLL];
@@ -810,52 +768,6 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
                 scan_row(part, parts);
                 at += harvest(true, base, region_end, at);
                 clean();
-            }
-        }
-    }
-}
-
-// -----------------------------------------------------------------------------
-// join propagation lists of the second loop, on the device-resident adjacency
-// -----------------------------------------------------------------------------
-// When leftover y joins cluster c (LimitedGreedySequenceClusterer.java:61-62), every LATER leftover w that still lists
-// c as a candidate must learn whether the new member is one of its neighbours (complete linkage: c stays feasible for
-// w only if it is) and with which score.  The host used to find that out by stamping y's whole adjacency row
-// (2,500 entries at 10^6 peptides) per join; here the device lists, for every candidate entry k1 = (y, c), exactly the
-// entries k2 = (w, c) with w > y and w a neighbour of y: prop[prop_start[k1] ..) = {k2, score(y, w)}.  The sequential
-// host loop then touches only these few entries per join and never the adjacency itself.
-// One wave per leftover that has candidates; it walks the row's "upper" section (ids above y: the leftover list is in
-// increasing id order, so later in the loop == larger id).
-__global__ void __launch_bounds__(256) k_fill_lidx(const uint32_t *__restrict__ leftover, uint32_t nl, int32_t *__restrict__ lidx) {
-    const uint32_t q = blockIdx.x * 256 + threadIdx.x;
-    if (q < nl) lidx[leftover[q]] = (int32_t)q;
-}
-
-template <class NbrT, bool FILL>
-__global__ void __launch_bounds__(256)
-k_greedy_prop(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, const NbrT *__restrict__ adj,
-              const int32_t *__restrict__ lidx, const uint32_t *__restrict__ leftover, uint32_t nl,
-              const uint32_t *__restrict__ cand_start, const GreedyCand *__restrict__ cand, uint32_t *__restrict__ pcnt,
-              const uint32_t *__restrict__ pstart, GreedyProp *__restrict__ prop) {
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (uint32_t q = blockIdx.x * 4 + wv; q < nl; q += gridDim.x * 4) {
-        const uint32_t k1b = cand_start[q], k1e = cand_start[q + 1];
-        if (k1b == k1e) continue;                       // no feasible cluster: y can never join, nothing to propagate
-        const uint32_t y = leftover[q];
-        const uint64_t b = start[y], e = b + up[y];
-        for (uint64_t k = b + lane; k < e; k += 64) {
-            const NbrT nb = adj[k];
-            const int32_t lw = lidx[nbr_id(nb)];
-            if (lw < 0) continue;                       // the neighbour is already in a cluster
-            const uint32_t k2b = cand_start[lw], k2e = cand_start[lw + 1];
-            for (uint32_t k2 = k2b; k2 < k2e; k2++) {
-                const int32_t c2 = cand[k2].c;
-                for (uint32_t k1 = k1b; k1 < k1e; k1++) {
-                    if (cand[k1].c != c2) continue;
-                    const uint32_t pos = atomicAdd(&pcnt[k1], 1u);
-                    if (FILL) prop[pstart[k1] + pos] = GreedyProp{k2, nbr_score(nb)};
-                    break;                              // a leftover lists a cluster once
-                }
             }
         }
     }
@@ -985,10 +897,7 @@ struct __attribute__((aligned(16))) LoopCluster {
 // chains beat one pass of the longest chain far beyond that: allowing 1 / 4 / 16 / 64 passes, the 10^6 loop takes 27.0 / 26.0 /
 // 23.8 / 23.5 ms (44 / 36 / 35 ms in the reference's default order), no difference at 10^5 and 3 x 10^5.
 constexpr uint32_t LOOP_GRID = 1024;
-#ifndef HMK_LOOP_EVAL_PASSES
-#define HMK_LOOP_EVAL_PASSES 32
-#endif
-constexpr uint32_t LOOP_EVAL_PASSES = HMK_LOOP_EVAL_PASSES;
+constexpr uint32_t LOOP_EVAL_PASSES = 32;
 __device__ __forceinline__ void
 loop_eval(uint32_t block, uint32_t n_blocks, const uint32_t *__restrict__ list, uint32_t which, const uint32_t *__restrict__ cand_start,
           const uint32_t *__restrict__ cand_cnt, const GreedyCand *__restrict__ cand, const LoopCluster *__restrict__ cl, uint8_t *__restrict__ status,
@@ -1147,26 +1056,11 @@ k_loop_accept(uint32_t n_clusters, const uint32_t *__restrict__ cand_start, cons
 // One workgroup per accepted join (y -> c): y's later neighbours go into an LDS hash table, chunk by chunk, and the
 // cluster's subscribers after y probe it -- a subscriber that is a neighbour counts one more covered member and folds
 // the pair's score into its minimum; the others' entries turn infeasible when joined[c] advances.
-#ifndef HMK_APPLY_SUBS
-#define HMK_APPLY_SUBS 8
-#endif
-constexpr int APPLY_SUBS = HMK_APPLY_SUBS;   // subscribers a thread of k_loop_apply has in flight
-#ifndef HMK_APPLY_STATS
-#define HMK_APPLY_STATS 0
-#endif
-#ifndef HMK_APPLY_SLOTS
-#define HMK_APPLY_SLOTS 8192
-#endif
-#ifndef HMK_APPLY_GRID
-#define HMK_APPLY_GRID 2048
-#endif
-#ifndef HMK_APPLY_ROW
-#define HMK_APPLY_ROW 8
-#endif
-constexpr int APPLY_ROW = HMK_APPLY_ROW;   // row entries a thread of k_loop_apply loads before it inserts them
-constexpr int APPLY_SLOTS = HMK_APPLY_SLOTS, APPLY_CHUNK = HMK_APPLY_SLOTS / 2;
-constexpr int APPLY_SHIFT = APPLY_SLOTS == 8192 ? 19 : APPLY_SLOTS == 4096 ? 20 : APPLY_SLOTS == 2048 ? 21 : 22;
-static_assert(APPLY_SLOTS == 8192 || APPLY_SLOTS == 4096 || APPLY_SLOTS == 2048 || APPLY_SLOTS == 1024, "table sizes");   // 64 KB of LDS, load factor <= 1/2 (4,096 slots and 1,280 workgroups: no faster)
+constexpr int APPLY_SUBS = 8;    // subscribers a thread of k_loop_apply has in flight
+constexpr int APPLY_ROW = 8;     // row entries a thread of k_loop_apply loads before it inserts them
+constexpr int APPLY_GRID = 2048; // workgroups of k_loop_apply (it loops over the round's joins)
+constexpr int APPLY_SLOTS = 8192, APPLY_CHUNK = APPLY_SLOTS / 2;   // 32 KB (4-byte entries) / 64 KB of LDS, load factor <= 1/2 (4,096 slots and 1,280 workgroups: no faster)
+constexpr int APPLY_SHIFT = 19;  // top 13 bits of the hash
 
 template <class NbrT>
 __global__ void __launch_bounds__(256)
@@ -1195,10 +1089,6 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
         if (host_word) __hip_atomic_store(host_word, ((unsigned long long)stamp << 32) | n_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (uint32_t a = blockIdx.x; a < n_acc; a += gridDim.x) {   // workgroup-uniform loop
-#if HMK_APPLY_STATS
-        const unsigned long long ts0 = wall_clock64();   // 100 MHz
-        unsigned long long ts_table = 0, ts_subs = 0;
-#endif
         uint32_t q = accepted[a];
         const int32_t c = cand[choice[q]].c;
         int32_t joined = cl[c].joined;
@@ -1219,19 +1109,10 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
         const uint32_t y = leftover[q];
         const uint64_t b = start[y], e = b + up[y];              // later leftovers have larger ids: the upper section
         if (threadIdx.x == 0) next_idx = 0xFFFFFFFFu;            // (read after the barriers of the chunk loop)
-#if HMK_APPLY_STATS   // probe build: how long are the lists a join walks? (counters[8..11], printed by HMK_LOOP_TRACE)
-        if (threadIdx.x == 0) {
-            atomicAdd(&counters[8], se - sb); atomicMax(&counters[9], se - sb);
-            atomicAdd(&counters[10], (uint32_t)(e - b)); atomicMax(&counters[11], (uint32_t)(e - b));
-        }
-#endif
         bool first_chunk = true;
         for (uint64_t c0 = b; c0 < e || first_chunk; c0 += APPLY_CHUNK) {
             for (uint32_t sl = threadIdx.x; sl < (uint32_t)APPLY_SLOTS; sl += 256) keys[sl] = EMPTY;
             __syncthreads();
-#if HMK_APPLY_STATS
-            const unsigned long long tc0 = wall_clock64();
-#endif
             const uint64_t c1 = min(e, c0 + (uint64_t)APPLY_CHUNK);
             for (uint64_t k0 = c0 + threadIdx.x; k0 < c1; k0 += 256 * APPLY_ROW) {   // APPLY_ROW entries of the row in flight per thread
                 NbrT nbs[APPLY_ROW];
@@ -1253,10 +1134,6 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                 }
             }
             __syncthreads();
-#if HMK_APPLY_STATS
-            const unsigned long long tc1 = wall_clock64();
-            ts_table += tc1 - tc0;
-#endif
             // the subscribers after the cursor, APPLY_SUBS per thread and step: a subscriber is a chain of dependent gathers (list
             // entry -> status and candidate entry -> its id -> the table), and with one per thread the workgroup waits for memory
             // at every link of every 256 subscribers (popular clusters have thousands)
@@ -1326,18 +1203,8 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
                 }
             }
             __syncthreads();
-#if HMK_APPLY_STATS
-            ts_subs += wall_clock64() - tc1;
-#endif
             first_chunk = false;
         }
-#if HMK_APPLY_STATS   // (units of 10 ns)
-        if (threadIdx.x == 0) {
-            const unsigned long long ts1 = wall_clock64();
-            atomicAdd(&counters[12], (uint32_t)(ts1 - ts0)); atomicMax(&counters[13], (uint32_t)(ts1 - ts0));
-            atomicAdd(&counters[14], (uint32_t)ts_table); atomicAdd(&counters[15], (uint32_t)ts_subs);
-        }
-#endif
         joined += 1;
         size_add += seq_size ? (long long)seq_size[y] : 1ll;
         links++;
@@ -1363,23 +1230,6 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
     }
 }
 
-// One wave that waits until *counter reaches target (the band tiles of a running neighbour pass, band_tile_done): what comes
-// after it on its stream starts when the band's edges are complete.  It gives up after ~5 s (*timed_out = 1: the caller then
-// waits for the whole pass instead), so the grid always drains.
-__global__ void k_wait_counter(const uint32_t *counter, uint32_t target, uint32_t *timed_out) {
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();   // 100 MHz
-    for (;;) {
-        if (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-        if (wall_clock64() - t0 > 500000000ull) { *timed_out = 1u; break; }
-        __builtin_amdgcn_s_sleep(64);
-    }
-}
-hipError_t launch_wait_counter(const uint32_t *counter, uint32_t target, uint32_t *timed_out, hipStream_t s) {
-    hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(64), 0, s, counter, target, timed_out);
-    return hipGetLastError();
-}
-
 // -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------
@@ -1393,13 +1243,12 @@ EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const uns
 // Workgroups per segment of the kernels that walk an edge list restricted to rows < row_limit (the band hand-over, which runs on
 // its own stream BESIDE the neighbour pass): every one of them needs a slot on a machine that is full, and 512 x 64 segments =
 // 32,768 workgroups for the 1.5 x 10^6 band edges of a 10^5 call slowed the pass they ran beside from 2.95 to 3.35 ms (the whole
-// "cost of the band" of DESIGN.md 4.2; measured with HMK_BAND_NO_HANDOVER).  The kernels loop over their segment, so the grid is
+// "cost of the band" of DESIGN.md 4.2).  The kernels loop over their segment, so the grid is
 // sized for the edges to expect -- rows x n x 0.3 % -- at ~4,096 per workgroup, 4 .. 512 (10^5: 6 per segment; 2 .. 13 measure the
 // same, 32 costs the pass 0.1 ms, 128 and more 0.45 ms).
 // (a multi-device root's list ends with one segment per peer that holds that peer's WHOLE block -- 64 times an ordinary segment:
 // `block` asks for the grid of those; the launchers below give the two kinds a launch each)
 static uint32_t band_grid_x(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool block = false) {
-    if (const char *v = getenv("HMK_BAND_GRID")) return (uint32_t)std::max(1, std::min(512, atoi(v)));
     if (row_limit >= n) return 512;
     const double devices = segs.n > HMK_EDGE_SHARDS ? (double)(segs.n - HMK_EDGE_SHARDS + 1) : 1.0;
     const double per_device = (double)row_limit * (double)n * 0.003 / devices;
@@ -1441,19 +1290,6 @@ hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uin
     return hipGetLastError();
 }
 
-// rank: the uint32 pairs the neighbour pass wrote beside the edges at edges0 (all segments lie inside that buffer)
-hipError_t launch_csr_scatter_ranked(const EdgeSegs &segs, const uint64_t *edges0, const uint32_t *rank, bool symmetric,
-                                     const uint64_t *start, void *adj, bool packed, int base, hipStream_t s) {
-    const uint2 *rk = reinterpret_cast<const uint2 *>(rank);
-    if (packed)
-        hipLaunchKernelGGL((k_edge_scatter_ranked<NbrPacked>), dim3(512, segs.n), dim3(256), 0, s, segs, edges0, rk, start, (NbrPacked *)adj,
-                           symmetric ? 1 : 0, base);
-    else
-        hipLaunchKernelGGL((k_edge_scatter_ranked<Nbr>), dim3(512, segs.n), dim3(256), 0, s, segs, edges0, rk, start, (Nbr *)adj,
-                           symmetric ? 1 : 0, base);
-    return hipGetLastError();
-}
-
 hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
                               bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n) {
     auto go = [&](const EdgeSegs &sg, uint32_t gx) {
@@ -1476,20 +1312,17 @@ hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64
 
 // The packed symmetric CSR with the lower sections dealt by bucket (k_lower_*): scratch = 3 x (LB_MAX_BUCKETS + 1) uint64,
 // recs = one uint64 per edge.  n < 2^24 (edge format), so 2^shift rows per bucket with shift <= 12 always give <= 4096 buckets.
-static uint32_t csr_partition_grid() {
-    if (const char *v = getenv("HMK_CSR_PARTITION_GRID")) return (uint32_t)std::max(1, atoi(v));
-    return 512;   // two 1,024-thread workgroups per CU (256 / 512 / 1024: 19.8 / 19.4 / 19.5 ms for the CSR at 10^6)
-}
-uint32_t csr_partition_shift(uint32_t n) {
+constexpr uint32_t CSR_PARTITION_GRID = 512;   // two 1,024-thread workgroups per CU (256 / 512 / 1024: 19.8 / 19.4 / 19.5 ms for the CSR at 10^6)
+uint32_t csr_partition_shift(uint32_t n, int forced_shift) {
     uint32_t shift = 9;
-    if (const char *v = getenv("HMK_CSR_BUCKET_SHIFT")) shift = (uint32_t)std::min(12, std::max(9, atoi(v)));   // tests: the wide buckets of n > 2^21
+    if (forced_shift > 0) shift = (uint32_t)std::min(12, std::max(9, forced_shift));   // tests (HMK_CSR_BUCKET_SHIFT): the wide buckets of n > 2^21
     while (((uint64_t)n + (1u << shift) - 1) >> shift > LB_MAX_BUCKETS) shift++;
     return shift;
 }
 size_t csr_partition_scratch_bytes() { return 3 * ((size_t)LB_MAX_BUCKETS + 1) * sizeof(unsigned long long); }
 hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *start, uint32_t *cursor, void *adj, int base, uint32_t n,
-                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, hipStream_t s) {
-    const uint32_t shift = csr_partition_shift(n);
+                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, int forced_shift, hipStream_t s) {
+    const uint32_t shift = csr_partition_shift(n, forced_shift);
     const uint32_t nb = (uint32_t)(((uint64_t)n + (1u << shift) - 1) >> shift);
     if (shift > 12 || nb > LB_MAX_BUCKETS) return hipErrorInvalidValue;
     unsigned long long *cnt = (unsigned long long *)scratch, *off = cnt + LB_MAX_BUCKETS + 1, *fill = off + LB_MAX_BUCKETS + 1;
@@ -1503,18 +1336,10 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
     hipLaunchKernelGGL(k_lower_offsets, dim3(1), dim3(1024), 0, s, cnt, nb, off, fill);
     // (10^6 sequences, round 2: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms with ONE load in flight per thread;
     // the kernel is bound by memory latency: 4 loads in flight 22.1 ms, 8: 21.5, 16 with the chunk kept in registers: 19.8)
-    // the upper sections in the same pass over the edges (HMK_CSR_FUSED_UPPER=0: their own kernel, as in round 2)
-    const char *fu = getenv("HMK_CSR_FUSED_UPPER");
-    if (fu == nullptr || atoi(fu) != 0) {
-        hipLaunchKernelGGL(k_lower_partition<true>, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, n, base, off, fill, recs, start,
-                           cursor, (NbrPacked *)adj);
-    } else {
-        hipLaunchKernelGGL(k_lower_partition<false>, dim3(csr_partition_grid()), dim3(1024), 0, s, segs, shift, nb, n, base, off, fill, recs, start,
-                           cursor, (NbrPacked *)adj);
-        hipLaunchKernelGGL((k_edge_scatter<NbrPacked, false>), dim3(512, segs.n), dim3(256), 0, s, segs, start, cursor, (NbrPacked *)adj, 1, base, n);
-    }
-    const bool sorted_place = getenv("HMK_CSR_PLACE_UNSORTED") == nullptr;   // (the tests run both)
-    if (sorted_place && (1u << shift) <= LP_ROWS)
+    // the upper sections in the same pass over the edges
+    hipLaunchKernelGGL(k_lower_partition, dim3(CSR_PARTITION_GRID), dim3(1024), 0, s, segs, shift, nb, n, base, off, fill, recs, start,
+                       cursor, (NbrPacked *)adj);
+    if ((1u << shift) <= LP_ROWS)
         hipLaunchKernelGGL(k_lower_place_sorted, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
     else
         hipLaunchKernelGGL(k_lower_place, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
@@ -1525,7 +1350,6 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
 // communication stream BESIDE the next pass (band_grid_x above: every workgroup that wants a slot on a full machine costs the
 // pass it runs beside).  Sized from the segment's capacity -- about twice what a pass writes -- at ~4,096 entries each.
 static uint32_t pack_grid_x(uint64_t cap_per_shard) {
-    if (const char *v = getenv("HMK_PACK_GRID")) return (uint32_t)std::max(1, std::min(128, atoi(v)));
     return (uint32_t)std::max<uint64_t>(4, std::min<uint64_t>(128, cap_per_shard / 4096));
 }
 
@@ -1662,7 +1486,7 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
                              uint32_t *choice, uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken,
                              uint32_t *cursor, uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
                              const uint32_t *sub_start, const uint64_t *subs, void *clusters, const int32_t *seq_size,
-                             uint32_t *counters, unsigned long long *host_word, hipStream_t s) {
+                             uint32_t *counters, unsigned long long *host_word, int chain_mode, hipStream_t s) {
     if (nl == 0 || n_clusters == 0) return hipSuccess;
     LoopCluster *cl = (LoopCluster *)clusters;
     const dim3 grid((uint32_t)std::min<uint64_t>(LOOP_GRID, ((uint64_t)nl * 8 + 255) / 256)), block(256);
@@ -1678,14 +1502,13 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
         hipLaunchKernelGGL(k_loop_accept, dim3((n_clusters * ACCEPT_LANES + 255) / 256), block, 0, s, n_clusters, cand_start, cand_cnt, cand, cl, status, choice,
                            first, taken, stamp, accepted, join_slot, counters);
     }
-    const dim3 agrid(HMK_APPLY_GRID);
+    const dim3 agrid(APPLY_GRID);
     // Chains (k_loop_apply) pay when ONE cluster's joins are the loop's critical path -- families of near-duplicates that all join
     // one cluster: thousands of rounds become a handful.  Where they are not (10^5 / 10^6 random peptides, the reference's antibodies
     // example: 30 / 183 / 155 rounds, with or without), a chained join only makes its round longer: the joins it takes would have
     // ridden along in later rounds for free (loop 0.70 -> 0.81 ms, 29.5 -> 29.7 ms, 3.6 -> 4.0 ms).  So they start once a loop has
-    // shown itself to be long; HMK_LOOP_CHAIN=0 / 1 forces never / from the first round.
-    const char *chain_env = getenv("HMK_LOOP_CHAIN");
-    const int chain = chain_env ? atoi(chain_env) : (round >= 256u ? 1 : 0);
+    // shown itself to be long; chain_mode 0 / 1 (HMK_LOOP_CHAIN) forces never / from the first round.
+    const int chain = chain_mode >= 0 ? chain_mode : (round >= 256u ? 1 : 0);
     if (packed)
         hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
                            choice, accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp,
@@ -1697,24 +1520,153 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
     return hipGetLastError();
 }
 
-hipError_t launch_fill_lidx(const uint32_t *leftover, uint32_t nl, int32_t *lidx, uint32_t n, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(lidx, 0xFF, (size_t)n * 4, s);   // -1 everywhere
-    if (e != hipSuccess || nl == 0) return e;
-    hipLaunchKernelGGL(k_fill_lidx, dim3((nl + 255) / 256), dim3(256), 0, s, leftover, nl, lidx);
-    return hipGetLastError();
+// -----------------------------------------------------------------------------
+// the band, prepared for phase 1 (BandPack, hmk_internal.h)
+// -----------------------------------------------------------------------------
+// firstPhase (LimitedGreedySequenceClusterer.java:77-120) reads the first rows of the graph in order.  Round 4 shipped the band's
+// whole adjacency to the host (522 MB over PCIe at 10^6) and the host walked every row in full; here the device splits every
+// band row x < R by where a neighbour lies:
+//   near   (id < R)   kept, the ids above x first: the only neighbours whose state changes step by step;
+//   far    (id >= R)  reduced to the row's FT best candidates in the reference's order (score, Cluster.size(), smaller id --
+//                     ClinkageSequenceClusterer.java:166-173, :275-289) + a flag "there are more";
+// and transposes the far part (far sequence -> the band rows that have it as a neighbour), of which the host gets the lists of the
+// sequences that are some row's first or second far candidate -- what a new cluster {x, candidate} needs (:99-101, :108-110).
+// Input: the band's CSR as k_edge_scatter leaves it (rows [upper | lower], bup[x] = the upper section's size), packed entries.
+// One wave per row.
+__device__ __forceinline__ unsigned long long band_far_key(uint32_t entry, const int32_t *__restrict__ seq_size) {
+    const uint32_t id = entry >> 8;
+    const uint32_t size = seq_size ? (uint32_t)seq_size[id] : 1u;
+    return ((unsigned long long)(entry & 0xFFu) << 56) | ((unsigned long long)size << 24) | (unsigned long long)(~id & 0xFFFFFFu);
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const unsigned long long w = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
 }
 
-// counts (fill = false: pcnt[k1] = list length) or fills (pcnt = zeroed cursors) the propagation lists
-hipError_t launch_greedy_prop(bool fill, bool packed, const uint64_t *start, const uint32_t *up, const void *adj,
-                              const int32_t *lidx, const uint32_t *leftover, uint32_t nl, const uint32_t *cand_start,
-                              const GreedyCand *cand, uint32_t *pcnt, const uint32_t *pstart, GreedyProp *prop, hipStream_t s) {
-    if (nl == 0) return hipSuccess;
-    const dim3 grid(std::min<uint32_t>((nl + 3) / 4, 256 * 16)), block(256);
-#define HMK_PROP(T, F) hipLaunchKernelGGL((k_greedy_prop<T, F>), grid, block, 0, s, start, up, (const T *)adj, lidx, leftover, nl, \
-                                          cand_start, cand, pcnt, pstart, prop)
-    if (packed) { if (fill) HMK_PROP(NbrPacked, true); else HMK_PROP(NbrPacked, false); }
-    else { if (fill) HMK_PROP(Nbr, true); else HMK_PROP(Nbr, false); }
-#undef HMK_PROP
+__global__ void __launch_bounds__(256)
+k_band_split(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bup, const uint32_t *__restrict__ badj, uint32_t R, uint32_t ft,
+             const int32_t *__restrict__ seq_size, uint32_t *__restrict__ near_cnt, uint32_t *__restrict__ near_up,
+             uint32_t *__restrict__ far_top, uint8_t *__restrict__ far_more, uint32_t *__restrict__ fdeg) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6); x < R; x += gridDim.x * 4) {   // wave-uniform
+        const uint64_t b = bstart[x], e = bstart[x + 1];
+        const uint32_t up = bup[x];
+        uint32_t n_near_up = 0, n_far = 0;
+        for (uint32_t k0 = 0; k0 < up; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t ent = k < up ? badj[b + k] : 0u;
+            const bool far = k < up && (ent >> 8) >= R;
+            if (far) atomicAdd(&fdeg[ent >> 8], 1u);
+            n_far += (uint32_t)__popcll(__ballot(far));
+            n_near_up += (uint32_t)__popcll(__ballot(k < up && !far));
+        }
+        // the FT best far candidates, one per turn: the largest key below the last one taken (keys are unique: they end in the id)
+        unsigned long long bound = ~0ull;
+        for (uint32_t t = 0; t < ft; t++) {
+            unsigned long long best = 0;   // (a key is never 0: ~id & 0xFFFFFF is 0 for id 0xFFFFFF only, and size >= 1)
+            if (t < n_far)
+                for (uint32_t k = lane; k < up; k += 64) {
+                    const uint32_t ent = badj[b + k];
+                    if ((ent >> 8) < R) continue;
+                    const unsigned long long key = band_far_key(ent, seq_size);
+                    if (key < bound && key > best) best = key;
+                }
+            best = wave_max_u64(best);
+            if (lane == 0) far_top[(size_t)x * ft + t] = best ? ((uint32_t)(~best & 0xFFFFFFull) << 8) | (uint32_t)(best >> 56) : ~0u;
+            bound = best ? best : 0ull;
+        }
+        if (lane == 0) {
+            near_up[x] = n_near_up;
+            near_cnt[x] = n_near_up + (uint32_t)(e - b - up);   // + the lower section: ids below x, all of them near
+            far_more[x] = n_far > ft ? 1 : 0;
+        }
+    }
+}
+
+// near rows (upper section's near entries, then the lower section) and the transposed far part: fadj[fstart[id] ..) = the band
+// rows that have far sequence id as a neighbour, band row << 8 | (score - base)
+__global__ void __launch_bounds__(256)
+k_band_fill(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bup, const uint32_t *__restrict__ badj, uint32_t R,
+            const uint32_t *__restrict__ near_start, uint32_t *__restrict__ near, const uint32_t *__restrict__ fstart,
+            uint32_t *__restrict__ fcur, uint32_t *__restrict__ fadj) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6); x < R; x += gridDim.x * 4) {   // wave-uniform
+        const uint64_t b = bstart[x], e = bstart[x + 1];
+        const uint32_t up = bup[x], len = (uint32_t)(e - b);
+        uint32_t w = near_start[x];
+        for (uint32_t k0 = 0; k0 < len; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t ent = k < len ? badj[b + k] : 0u;
+            const bool far = k < up && (ent >> 8) >= R;
+            const bool keep = k < len && !far;
+            const uint64_t mask = __ballot(keep);
+            if (keep) near[w + mbcnt64(mask)] = ent;
+            w += (uint32_t)__popcll(mask);
+            if (far) fadj[fstart[ent >> 8] + atomicAdd(&fcur[ent >> 8], 1u)] = (x << 8) | (ent & 0xFFu);
+        }
+    }
+}
+
+// which transposed lists travel: those of the sequences that are a band row's first or second far candidate, each once.
+// owner_of[id] (zeroed) = 1 + the slot u = TR * x + t that ships id's list; tr_cnt[u] = its length for the owner, 0 for the others
+__global__ void __launch_bounds__(256)
+k_band_tr_claim(const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *__restrict__ fdeg,
+                uint32_t *__restrict__ owner_of, uint32_t *__restrict__ tr_cnt) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= R * tr_per_row) return;
+    const uint32_t x = u / tr_per_row, t = u - x * tr_per_row;
+    const uint32_t ent = t < ft ? far_top[(size_t)x * ft + t] : ~0u;
+    uint32_t cnt = 0;
+    if (ent != ~0u && atomicCAS(&owner_of[ent >> 8], 0u, u + 1u) == 0u) cnt = fdeg[ent >> 8];
+    tr_cnt[u] = cnt;
+}
+// tr_owner[u] = the slot that ships the list of slot u's candidate; the owners copy their lists (one wave per slot)
+__global__ void __launch_bounds__(256)
+k_band_tr_fill(const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *__restrict__ owner_of,
+               const uint32_t *__restrict__ fstart, const uint32_t *__restrict__ fdeg, const uint32_t *__restrict__ fadj,
+               const uint32_t *__restrict__ tr_start, uint32_t *__restrict__ tr_owner, uint32_t *__restrict__ tr) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t u = blockIdx.x * 4 + (threadIdx.x >> 6); u < R * tr_per_row; u += gridDim.x * 4) {   // wave-uniform
+        const uint32_t x = u / tr_per_row, t = u - x * tr_per_row;
+        const uint32_t ent = t < ft ? far_top[(size_t)x * ft + t] : ~0u;
+        if (ent == ~0u) { if (lane == 0) tr_owner[u] = u; continue; }
+        const uint32_t id = ent >> 8, own = owner_of[id] - 1u;
+        if (lane == 0) tr_owner[u] = own;
+        if (own != u) continue;
+        const uint32_t src = fstart[id], cnt = fdeg[id], dst = tr_start[u];
+        for (uint32_t k = lane; k < cnt; k += 64) tr[dst + k] = fadj[src + k];
+    }
+}
+
+hipError_t launch_band_split(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, uint32_t ft, const int32_t *seq_size,
+                             uint32_t *near_cnt, uint32_t *near_up, uint32_t *far_top, uint8_t *far_more, uint32_t *fdeg, hipStream_t s) {
+    if (R == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_band_split, dim3(std::min<uint32_t>((R + 3) / 4, 4096)), dim3(256), 0, s, bstart, bup, (const uint32_t *)badj, R, ft, seq_size,
+                       near_cnt, near_up, far_top, far_more, fdeg);
+    return hipGetLastError();
+}
+hipError_t launch_band_fill(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, const uint32_t *near_start, uint32_t *near,
+                            const uint32_t *fstart, uint32_t *fcur, uint32_t *fadj, hipStream_t s) {
+    if (R == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_band_fill, dim3(std::min<uint32_t>((R + 3) / 4, 4096)), dim3(256), 0, s, bstart, bup, (const uint32_t *)badj, R, near_start, near,
+                       fstart, fcur, fadj);
+    return hipGetLastError();
+}
+hipError_t launch_band_tr_claim(const uint32_t *far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *fdeg, uint32_t *owner_of,
+                                uint32_t *tr_cnt, hipStream_t s) {
+    if (R == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_band_tr_claim, dim3((R * tr_per_row + 255) / 256), dim3(256), 0, s, far_top, R, ft, tr_per_row, fdeg, owner_of, tr_cnt);
+    return hipGetLastError();
+}
+hipError_t launch_band_tr_fill(const uint32_t *far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *owner_of, const uint32_t *fstart,
+                               const uint32_t *fdeg, const uint32_t *fadj, const uint32_t *tr_start, uint32_t *tr_owner, uint32_t *tr, hipStream_t s) {
+    if (R == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_band_tr_fill, dim3(std::min<uint32_t>((R * tr_per_row + 3) / 4, 4096)), dim3(256), 0, s, far_top, R, ft, tr_per_row, owner_of,
+                       fstart, fdeg, fadj, tr_start, tr_owner, tr);
     return hipGetLastError();
 }
 

@@ -225,7 +225,7 @@ k_neighbors_local(const NeighborParams P, const uint32_t tile_base, const int32_
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
     const int la = Cp->la, lb = Cp->lb;   // la: row (seq1) length, lb: column (seq2) length
-    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
+    const uint32_t shard = tile_shard(tile_base + blockIdx.x);
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
@@ -403,10 +403,7 @@ __device__ __forceinline__ uint32_t sw_row_pk(uint32_t row_q_addr, int strips, i
         };
         column(column, LocalIndex<0>{});
     };
-#ifndef HMK_LOCAL_PARTIAL_STRIP
-#define HMK_LOCAL_PARTIAL_STRIP 1
-#endif
-    if (SAT && HMK_LOCAL_PARTIAL_STRIP) {
+    if (SAT) {   // the last strip with the lines it has
         const int last = strips - 1, kl = nlines - 4 * last;
         for (int st = 0; st < last; st++) strip(LocalIndex<4>{}, st);
         if (kl >= 4) strip(LocalIndex<4>{}, last);
@@ -435,7 +432,7 @@ k_neighbors_local_pk(const NeighborParams P, const uint32_t tile_base, const int
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
     const int la = Cp->la, lb = Cp->lb;
-    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
+    const uint32_t shard = tile_shard(tile_base + blockIdx.x);
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
@@ -617,7 +614,7 @@ k_neighbors_local_literal(const NeighborParams P, const uint32_t tile_base, cons
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
     const int la = Cp->la, lb = Cp->lb;
-    const uint32_t shard = P.shard_base + (tile_base + blockIdx.x) % P.shard_mod;
+    const uint32_t shard = tile_shard(tile_base + blockIdx.x);
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);
     for (int e = tid; e < 576; e += 256) M[e] = Mg[e];
@@ -678,7 +675,9 @@ hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile
 // -----------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------
-hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
+// force_signed / force_unpacked (the test switches HMK_LOCAL_SIGNED / HMK_LOCAL_NO_PK): the signed tagged-max form where the
+// saturating one would run (it is what gap_open = 0 runs) / the one-column-per-lane form of the tagged-max DP.
+hipError_t launch_neighbors_local(int lbmax, bool enc, bool force_signed, bool force_unpacked, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles,
                                   const int32_t *d_matrix, int gap_open, int gap_extend, int threshold, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
 #define HMK_NL(LB, E) hipLaunchKernelGGL((k_neighbors_local<LB, E>), dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, \
@@ -686,8 +685,8 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
 #define HMK_NLP1(LB, SAT) hipLaunchKernelGGL((k_neighbors_local_pk<LB, SAT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base, d_matrix, \
                                              gap_open, gap_extend, threshold)
 #define HMK_NLP(LB) do { if (sat) HMK_NLP1(LB, true); else HMK_NLP1(LB, false); } while (0)
-    const bool sat = gap_open <= -1 && getenv("HMK_LOCAL_SIGNED") == nullptr;   // (enc already says -31 <= penalties <= 0)
-    const bool packed = enc && getenv("HMK_LOCAL_NO_PK") == nullptr;   // two column sequences per lane
+    const bool sat = gap_open <= -1 && !force_signed;   // (enc already says -31 <= penalties <= 0)
+    const bool packed = enc && !force_unpacked;   // two column sequences per lane
     if (lbmax <= 12) { if (packed) HMK_NLP(12); else if (enc) HMK_NL(12, true); else HMK_NL(12, false); }
     else if (lbmax <= 20) { if (packed) HMK_NLP(20); else if (enc) HMK_NL(20, true); else HMK_NL(20, false); }
     else { if (packed) HMK_NLP(32); else if (enc) HMK_NL(32, true); else HMK_NL(32, false); }
@@ -697,13 +696,13 @@ hipError_t launch_neighbors_local(int lbmax, bool enc, const NeighborParams &P, 
     return hipGetLastError();
 }
 
-hipError_t launch_local_block(int lbmax, bool enc, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix,
+hipError_t launch_local_block(int lbmax, bool enc, bool force_signed, bool force_unpacked, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix,
                               uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int gap_open, int gap_extend, int32_t *out,
                               hipStream_t s) {
     if (r1 <= r0 || c1 <= c0) return hipSuccess;
-    if (enc && getenv("HMK_LOCAL_NO_PK") == nullptr) {   // two column sequences per lane
+    if (enc && !force_unpacked) {   // two column sequences per lane
         const dim3 grid2((c1 - c0 + 511) / 512, (r1 - r0 + 15) / 16);
-        const bool sat = gap_open <= -1 && getenv("HMK_LOCAL_SIGNED") == nullptr;
+        const bool sat = gap_open <= -1 && !force_signed;
 #define HMK_LBP(LB) do { if (sat) hipLaunchKernelGGL((k_local_block_pk<LB, true>), grid2, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, gap_open, gap_extend, out); \
                          else hipLaunchKernelGGL((k_local_block_pk<LB, false>), grid2, dim3(256), 0, s, res32, len, d_matrix, r0, r1, c0, c1, gap_open, gap_extend, out); } while (0)
         if (lbmax <= 12) HMK_LBP(12); else if (lbmax <= 20) HMK_LBP(20); else HMK_LBP(32);

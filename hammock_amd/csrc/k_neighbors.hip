@@ -25,7 +25,7 @@ namespace hmk {
 //   stage   4 waves * STAGE_CAP records  hits waiting to be written out
 // DEG: also count the CSR degrees while writing edges (NeighborParams::deg, hmk_greedy_cluster); the plain neighbour pass
 // is its own instantiation so that it keeps its spill-free 72-VGPR allocation.
-template <int NW, int R, int CPL, int LBMAX, bool EXACT, int DEG>   // DEG: EDGES_PLAIN / EDGES_COUNT / EDGES_PLACE (hmk_device.h)
+template <int NW, int R, int CPL, int LBMAX, bool EXACT, int DEG>   // DEG: EDGES_PLAIN / EDGES_COUNT (hmk_device.h)
 // The production tiling (R = 6, CPL = 2) is held to 72 VGPRs = 7 waves/SIMD, which its 18.7 KB of LDS allow as well
 // (80 VGPRs would mean 6 waves): +2.4 % measured.
 __global__ void __launch_bounds__(256, (R >= 5 && R <= 7 && CPL == 2) ? 7 : 1)
@@ -52,7 +52,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
     const TileClass *Cp = P.classes + T.cls;
     const int threshold = 128 - Cp->g;         // 8-bit lanes: lane value = 128 - threshold + score
     const uint32_t himask = 0x80808080u;
-    const uint32_t shard = tile_shard(P, T, tile_base + blockIdx.x);
+    const uint32_t shard = tile_shard(tile_base + blockIdx.x);
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -125,7 +125,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
                 const u32x4 *src = reinterpret_cast<const u32x4 *>(P.res_sorted + (size_t)col * P.lpad);
                 const u32x4 v0 = src[0];
                 words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
-                if (LPADW == 8) {
+                if constexpr (LPADW == 8) {
                     const u32x4 v1 = src[1];
                     words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
                 }
@@ -142,7 +142,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
             if ((uint32_t)r < T.nrows) {
                 // all CPL accumulations first (CPL * LB independent LDS reads in flight), tests after
                 uint32_t W[CPL][NW];
-                read_phase_begin(DEG != EDGES_PLACE || HMK_SETPRIO_PLACE);
+                read_phase_begin(true);
 #pragma unroll
                 for (int p = 0; p < CPL; p++) {
 #pragma unroll
@@ -167,7 +167,7 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
                         }
                     }
                 }
-                read_phase_end(DEG != EDGES_PLACE || HMK_SETPRIO_PLACE);
+                read_phase_end(true);
 #pragma unroll
                 for (int p = 0; p < CPL; p++) {
                     uint32_t any = W[p][0];
@@ -196,7 +196,6 @@ k_neighbors_swar(const NeighborParams P, const uint32_t tile_base) {
         }
     }
     flush_stage_compact<DEG>(stage, cnt, P, T, threshold, shard);
-    band_tile_done(P, T);
 }
 
 // -----------------------------------------------------------------------------
@@ -225,24 +224,13 @@ constexpr int plane64_bytes(int lbmax) { return lbmax * 24 * 8 + 8; }
 // fuse two table reads off one address register into a same-bank ds_read2[st64] (see "Plane strides" above).
 constexpr int planes_per_tile(int r, int nw) { return r * (nw / 2) + ((r + 1) / 2) * (nw & 1); }
 constexpr int rows_for(int rowbytes, int nw) {  // rows per tile: table bytes and R x NW accumulator registers, tuned on config 4a
-#ifndef HMK_TAB_BUDGET
-#define HMK_TAB_BUDGET 24576
-#endif
-#ifndef HMK_ACC_CAP
-#define HMK_ACC_CAP 16
-#endif
-    int r = HMK_TAB_BUDGET / rowbytes;
-    if (r > HMK_ACC_CAP / nw) r = HMK_ACC_CAP / nw;
+    constexpr int TAB_BUDGET = 24576, ACC_CAP = 16;
+    int r = TAB_BUDGET / rowbytes;
+    if (r > ACC_CAP / nw) r = ACC_CAP / nw;
     r = r > 16 ? 16 : (r < 1 ? 1 : r);
     // odd NW reads the last dword of two rows at once (pair planes): an odd row count wastes half of one such read per
-    // position, measured 0.74 against 0.83 of the LDS ideal for the instantiations with R = 5 / 3
-#ifndef HMK_ODD_R_POLICY
-#define HMK_ODD_R_POLICY 1
-#endif
-    if ((nw & 1) && r > 1 && (r & 1)) {
-        if (HMK_ODD_R_POLICY == 1) r -= 1;
-        else if (HMK_ODD_R_POLICY == 2) r = ((r + 1) * nw <= HMK_ACC_CAP + 4 && (r + 1) * rowbytes <= HMK_TAB_BUDGET + 4096) ? r + 1 : r - 1;
-    }
+    // position, measured 0.74 against 0.83 of the LDS ideal for the instantiations with R = 5 / 3: one row less
+    if ((nw & 1) && r > 1 && (r & 1)) r -= 1;
     return r;
 }
 constexpr int planes_rowbytes(int lbmax, int nw) { return (2 * (nw / 2) + (nw & 1)) * plane64_bytes(lbmax) / 2; }   // table bytes per row
@@ -285,13 +273,13 @@ __global__ void __launch_bounds__(256, (NW == 2 && 2 * R + LBMAX <= 30) ? 6 : 1)
     const bool lane16 = Cp->path == PATH_U16;
     const int g = Cp->g;
     const uint32_t himask = lane16 ? 0x80008000u : 0x80808080u;
-    const uint32_t shard = tile_shard(P, T, tile_base + blockIdx.x);
+    const uint32_t shard = tile_shard(tile_base + blockIdx.x);
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * STAGE_DW;   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
     // hit records (hmk_device.h flush_stage_packed): one dword when score - threshold fits 12 bits -- always with 8-bit lanes,
     // where it is lane - 128 -- else two
     const uint32_t rec_dw = lane16 ? 2u : 1u;
-    const bool prio = P.rank == nullptr || HMK_SETPRIO_PLACE;   // wave priority for the read phase (hmk_device.h), wave-uniform
+    const bool prio = true;   // wave priority for the read phase (hmk_device.h)
     const int base_score = (lane16 ? 32768 : 128) - g;   // the score of a lane that just reaches the threshold
 
     build_begin();
@@ -397,7 +385,7 @@ __global__ void __launch_bounds__(256, (NW == 2 && 2 * R + LBMAX <= 30) ? 6 : 1)
                 const u32x4 *src = reinterpret_cast<const u32x4 *>(P.res_sorted + (size_t)col * P.lpad);
                 const u32x4 v0 = src[0];
                 words[0] = v0.x; words[1] = v0.y; words[2] = v0.z; words[3] = v0.w;
-                if (LPADW == 8) {
+                if constexpr (LPADW == 8) {
                     const u32x4 v1 = src[1];
                     words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
                 }
@@ -516,7 +504,6 @@ __global__ void __launch_bounds__(256, (NW == 2 && 2 * R + LBMAX <= 30) ? 6 : 1)
         }
     }
     flush_stage_packed<true>(stage, cnt, P, T, base_score, rec_dw, shard);
-    band_tile_done(P, T);
 }
 
 // -----------------------------------------------------------------------------
@@ -537,7 +524,7 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
     const Tile T = P.tiles[tile_base + blockIdx.x];
     const TileClass *Cp = P.classes + T.cls;
     const int la = Cp->la, lb = Cp->lb;
-    const uint32_t shard = tile_shard(P, T, tile_base + blockIdx.x);
+    const uint32_t shard = tile_shard(tile_base + blockIdx.x);
     const int tid = threadIdx.x;
     HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + (tid >> 6) * (STAGE_CAP * REC_DW);   // 32-bit LDS pointer: no 64-bit flat pointer held (and spilled) across the tile
 
@@ -589,7 +576,6 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
         }
     }
     flush_stage<0>(stage, cnt, P, T, 0, false, shard);
-    band_tile_done(P, T);
 }
 
 // -----------------------------------------------------------------------------
@@ -597,18 +583,15 @@ k_neighbors_direct(const NeighborParams P, const uint32_t tile_base, const int32
 // -----------------------------------------------------------------------------
 template <int NW, int R, int CPL, int LBMAX, bool EXACT>
 static hipError_t launch_swar_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
-    if (P.rank)
-        hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, EDGES_PLACE>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
-    else if (P.deg)
+    if (P.deg)
         hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, EDGES_COUNT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
     else
         hipLaunchKernelGGL((k_neighbors_swar<NW, R, CPL, LBMAX, EXACT, EDGES_PLAIN>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
     return hipGetLastError();
 }
 
-// Hot-path tilings of the exact length-12, NW = 2 kernel: {rows per tile, columns per lane}.
-static const int kHotVariants[][2] = {{16, 2}, {8, 2}, {12, 2}, {8, 4}, {5, 2}, {7, 2}, {4, 2}, {6, 2}, {6, 3}, {6, 1}};
-constexpr int kNumHotVariants = sizeof(kHotVariants) / sizeof(kHotVariants[0]);
+// The exact length-12, NW = 2 kernel's tiling: 6 rows per tile, 2 columns per lane (of the ten tilings rounds 1-2 timed).
+constexpr int SWAR12_ROWS = 6, SWAR12_CPL = 2;
 
 // Generic instantiations: column-length capacity LBMAX x dwords per entry NW.  Rows per tile
 // R = what fits a 40 KB table budget (<= 16); 2 columns per lane for the narrow entries.
@@ -618,30 +601,15 @@ constexpr int swar_r(int lbmax, int nw) {
 
 int swar_lbmax_for(int lb) { return lb <= 12 ? 12 : lb <= 16 ? 16 : lb <= 20 ? 20 : 32; }  // plane strides need >= 11 positions
 
-int swar_rows_per_tile(int lbmax, int nw, bool exact, int hot_variant) {
-    if (exact && lbmax == 12 && nw == 2 && hot_variant >= 0 && hot_variant < kNumHotVariants)
-        return kHotVariants[hot_variant][0];
+int swar_rows_per_tile(int lbmax, int nw, bool exact) {
+    if (exact && lbmax == 12 && nw == 2) return SWAR12_ROWS;
     return swar_r(lbmax, nw);
 }
 
-hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, int hot_variant, const NeighborParams &P,
+hipError_t launch_neighbors_swar(int lbmax, int nw, bool exact, const NeighborParams &P,
                                  uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    if (exact && lbmax == 12 && nw == 2) {
-        switch (hot_variant) {
-            case 0: return launch_swar_t<2, 16, 2, 12, true>(P, tile_base, n_tiles, s);
-            case 1: return launch_swar_t<2, 8, 2, 12, true>(P, tile_base, n_tiles, s);
-            case 2: return launch_swar_t<2, 12, 2, 12, true>(P, tile_base, n_tiles, s);
-            case 3: return launch_swar_t<2, 8, 4, 12, true>(P, tile_base, n_tiles, s);
-            case 4: return launch_swar_t<2, 5, 2, 12, true>(P, tile_base, n_tiles, s);
-            case 5: return launch_swar_t<2, 7, 2, 12, true>(P, tile_base, n_tiles, s);
-            case 6: return launch_swar_t<2, 4, 2, 12, true>(P, tile_base, n_tiles, s);
-            case 7: return launch_swar_t<2, 6, 2, 12, true>(P, tile_base, n_tiles, s);
-            case 8: return launch_swar_t<2, 6, 3, 12, true>(P, tile_base, n_tiles, s);
-            case 9: return launch_swar_t<2, 6, 1, 12, true>(P, tile_base, n_tiles, s);
-            default: return hipErrorInvalidValue;
-        }
-    }
+    if (exact && lbmax == 12 && nw == 2) return launch_swar_t<2, SWAR12_ROWS, SWAR12_CPL, 12, true>(P, tile_base, n_tiles, s);
 #define HMK_CASE(LB, NWV)                                                                                             \
     if (lbmax == LB && nw == NWV) {                                                                                   \
         hipLaunchKernelGGL((k_neighbors_planes<NWV, swar_r(LB, NWV), LB>), dim3(n_tiles), dim3(256), 0, s, P, tile_base); \

@@ -9,22 +9,27 @@
 //
 // and a pair of (8 rows, 1 column) is scored by one ds_read_b64 per (u, j) inside the overlap + one v_add3 per two reads and
 // dword: 8 rows advance together, one accumulator pair per shift plane.  Nothing is read that the reference does not add:
-// 72 reads per 8 pairs at length 12 / max shift 3 = 72 B of LDS per pair, where the shift-packed tables of
-// k_neighbors_swar / k_neighbors_planes (k_neighbors.hip: 7 shift lanes + 1 pad lane per 8-byte entry, zero cells of the
-// partial overlaps included) read 96 B.  The binding unit is the LDS byte rate (ds_read_b64: 256 B/clk/CU), so bytes are time.
+// 72 reads per 8 pairs at length 12 / max shift 3 = 72 B of LDS per pair.  The binding unit is the LDS byte rate (ds_read_b64:
+// 256 B/clk/CU), so bytes are time.  A position's 24 entries are 48 consecutive dwords: any set of residues in a wave reads
+// without a bank conflict (ds_read_b64 has 64 banks).
 //
-// Table placement.  The reads of one column position go to the same address register with immediates 192 x k bytes apart, and
-// the compiler fuses two such ds_read_b64 into one ds_read2_b64 -- which moves 128 B/clk/CU instead of 256
-// (MI355X_MICROARCH.md, LDS table) -- whenever their immediates are < 2048 B or a multiple of 512 B apart.  So the ND row
-// positions one column position can meet are kept SLOT = 2248 bytes apart: position i lives in slot i mod ND, and the
-// 192-byte blocks that share a slot (positions ND apart, the other row groups, the end table) fill its sub-slots.  Two blocks
-// of one group that a column position can meet together are then >= 2248 - 192 bytes and never a multiple of 512 bytes
-// apart (rows_layout_ok below); blocks of different groups are read in different basic blocks.
+// Table reads are VOLATILE LDS loads: the compiler's load/store optimiser fuses two plain ds_read_b64 off one address register
+// into a ds_read2_b64, which moves 128 B/clk/CU instead of 256 (MI355X_MICROARCH.md, LDS table); volatile loads are left alone
+// and still take the immediate offset, so the tables are packed (192 bytes per row position).
 //
 // Lanes are 8 bits wide; hmk_plan.cpp (classify) proves per length class -- or per row bound -- that every lane stays in
 // [0, 255]: lane = g + penalty(s) - bias * cells(s) + sum of biased cells, g = 128 - threshold, so "score >= threshold" is the
 // lane's top bit.  Classes that do not fit, columns longer than the rows, and (X, D) pairs without an instantiation below run
 // the kernels of k_neighbors.hip.
+//
+// Hits.  Two forms, chosen per shape (rows_inloop):
+//   * more than ROWS_INLOOP_MAXCELLS cells per pair (10-mers and longer): the hit's score is cut out of the planes right where
+//     they are in registers (one v_perm_b32 per plane) and staged with the record; the flush decodes and stores.
+//   * short shapes (6- to 9-mers, the X = 1 capacity forms) are VALU-bound by themselves: a step only NOTES its hits in a
+//     history word, the wave looks once per four steps, stages bare records, and the flush -- where every lane has a record of
+//     its own -- fetches the record's column again and rescores it against its row group's table.
+// What was measured on the way to this (fat records, prefetching the next column, a placing flush that ranked every edge inside
+// its CSR row, spread-out tables, ...) is in DESIGN.md 5.7 with the commit that held the code.
 //
 // Integer scoring only: no MFMA, no dense contraction.
 #ifndef HMK_NEIGHBORS_ROWS_H
@@ -33,127 +38,46 @@
 
 namespace hmk {
 
-#ifndef HMK_ROWS_DEFER       // 1: a wave looks for hits once per four steps (the history word of the kernel's batch loop)
-#define HMK_ROWS_DEFER 1
-#endif
-#ifndef HMK_ROWS_ARGCOPY     // 1: the batch loop's two kernel arguments are copied out of the argument block (see the kernel)
-#define HMK_ROWS_ARGCOPY 0
-#endif
-#ifndef HMK_ROWS_AHEAD       // 1: a step loads the NEXT step's column while its own table reads run (measured: 2.54 against 2.53 ms, config 4a
-                             // 4.49-4.53 against 4.37-4.44 ms -- eight waves per SIMD hide that load already; off)
-#define HMK_ROWS_AHEAD 0
-#endif
 // Records a wave stages before it drains them.  Every drain takes its place in the output segment with ONE returning atomic
-// on the segment's cursor, and atomics on one address are served one after the other (~100 ns each from 256 CUs): with 16
-// segments and 320-record stages the pass over 10^5 7-mers (1.06 x 10^8 edges: 4 x 10^5 drains) took 2.76 ms, 1.63 ms with
-// 640-record stages, both far above its 1.15 ms without hits.  One-length shapes have small tables (2.3 KB at length 12) and
-// take the larger stage; the capacity forms' tables are 4-5 x that and LDS bounds their occupancy.
-#ifndef HMK_ROWS_STAGE
-#define HMK_ROWS_STAGE 320
-#endif
-#ifndef HMK_ROWS_STAGE_EXACT
-#define HMK_ROWS_STAGE_EXACT 640
-#endif
-#ifndef HMK_ROWS_UNPACK_SDWA
-#define HMK_ROWS_UNPACK_SDWA 1
-#endif
-#ifndef HMK_ROWS_STAGE_SHORT   // one-length shapes that keep the rescoring flush (<= 45 cells per pair: 6- to 9-mers): a drain's fixed cost
-#define HMK_ROWS_STAGE_SHORT 1024   // (scalar loads, cursor, first gather) over more records -- 9-mers 1.74 -> 1.69 ms, 7-mers 1.61 -> 1.53
-#endif
+// on the segment's cursor and pays a fixed cost (scalar loads, first gather): the short shapes, whose hits are dense at the
+// reference's default thresholds (7-mers: 2.1 % of the pairs), take the largest stage; the capacity forms' tables are 4-5 x the
+// one-length ones and LDS bounds their occupancy.
+constexpr int ROWS_STAGE_CAPFORM = 320, ROWS_STAGE_EXACT = 640, ROWS_STAGE_SHORT = 1024;
+constexpr int ROWS_INLOOP_MAXCELLS = 45;   // shapes of at most this many cells per pair keep the rescoring flush
+constexpr int rows_cells(int x, int cap) { return cap * (2 * x + 1) - x * (x + 1); }   // cells per pair of equal lengths
+constexpr bool rows_inloop(int x, int cap) { return rows_cells(x, cap) > ROWS_INLOOP_MAXCELLS; }
 constexpr int rows_stage(int x, int cap, bool exact) {
-    return !exact ? HMK_ROWS_STAGE : cap * (2 * x + 1) - x * (x + 1) <= 45 ? HMK_ROWS_STAGE_SHORT : HMK_ROWS_STAGE_EXACT;
+    return !exact ? ROWS_STAGE_CAPFORM : rows_inloop(x, cap) ? ROWS_STAGE_EXACT : ROWS_STAGE_SHORT;
 }
-// "Fat" records (HMK_ROWS_FAT=1; one-length shapes of at most 12 residues; measured, rejected, kept as a switch): a hit is
-// staged WITH its column's residue words (16 bytes: the record + three words), so the flush needs nothing from global memory --
-// its gather of 64 columns from 30-60 cache lines is the one round trip a flush iteration cannot hide (0.27 of the 0.6 ms
-// that 8 x 10^7 hits cost the 10^5 pass: a build whose lanes all fetch ONE column, HMK_ROWS_DBG=3).  The main loop keeps the
-// words of a quad's four steps in registers (its batch loop unrolled by four; a hit noted `back` steps ago picks its step's
-// words with <= 3 selects per word) and writes them with the record, ds_write_b128 instead of _b32.  Result, 10^5 12-mers:
-// threshold 14 3.39 ms (thin records 3.07), threshold 20 2.75 (2.58), no hits 2.45 (2.40); 7-mers 1.76 (1.57).  The flush did
-// get cheaper -- but the selects and the wide write run in the APPEND loop, at full wave cost for a handful of live lanes,
-// on a VALU pipe that is as busy as the LDS pipe: what the flush saved, the hot loop paid twice.  (Not the drain frequency:
-// thin records with 256-record stages read 3.14 at threshold 14.)
-#ifndef HMK_ROWS_FAT
-#define HMK_ROWS_FAT 0
-#endif
-// Scores worked out IN the batch loop (round 4's last step; HMK_ROWS_INLOOP=0: the rescoring flush): a hit's lane cuts its row's
-// byte out of every plane right where the planes are in registers -- one v_perm_b32 per plane with a per-lane selector, v_max over
-// the planes, 10 instructions at 7 planes -- and stages (column, row, score - threshold); the flush then only decodes and stores:
-// no gather of the hits' columns (the one round trip a flush iteration could not hide), no table reads.  No
-// history word (the planes of earlier steps are gone): the wave looks for hits at every step.  Round 3 had moved the extraction
-// OUT of the loop because the kernel was VALU-bound (99 % busy, 20.7 instructions per 64 pairs); at 15.8 there is room again.
-// 10^5 12-mers: threshold 20 2.56 -> 2.52 ms, threshold 14 3.07 -> 2.69, no hits 2.40 = 2.40.  Short one-length shapes are
-// VALU-bound by themselves (7-mers: VALU 104 % busy) and lose a little (7-mers 1.54 -> 1.57 ms, 9-mers 1.71 -> 1.76): shapes of
-// at most HMK_ROWS_INLOOP_MAXCELLS cells per pair keep the rescoring flush and the history word.
-#ifndef HMK_ROWS_INLOOP
-#define HMK_ROWS_INLOOP 1
-#endif
-#ifndef HMK_ROWS_INLOOP_MAXCELLS
-#define HMK_ROWS_INLOOP_MAXCELLS 45
-#endif
-#ifndef HMK_ROWS_INLOOP_CAPFORMS   // 1: the capacity forms (mixed lengths) too
-#define HMK_ROWS_INLOOP_CAPFORMS 1
-#endif
-constexpr bool rows_inloop(int x, int cap, bool exact) {
-    return HMK_ROWS_INLOOP != 0 && (exact || HMK_ROWS_INLOOP_CAPFORMS != 0) && cap * (2 * x + 1) - x * (x + 1) > HMK_ROWS_INLOOP_MAXCELLS;
+// groups of 8 rows per tile.  Capacity forms (a length bucket's short column runs): 1 / 2 / 3 / 4 groups measured 4.87 / 4.48 /
+// 4.58 / 4.74 ms on BASELINE config 4a.  One-length shapes: long column runs, one group (2.65-2.67 ms with 1 or 2 at length
+// 12) -- but the short ones, where what a step does once per COLUMN (fetch, offsets) is a quarter of its VALU work and VALU is as
+// busy as the LDS pipe, take two.
+constexpr int rows_groups(int x, int /*d*/, int cap, bool exact) {
+    return !exact ? 2 : rows_inloop(x, cap) ? 1 : 2;
 }
-#ifndef HMK_ROWS_STAGE_FAT   // fat records a wave stages (16 bytes each)
-#define HMK_ROWS_STAGE_FAT 256
-#endif
-constexpr bool rows_fat(int cap, bool exact) { return HMK_ROWS_FAT != 0 && HMK_ROWS_INLOOP == 0 && HMK_ROWS_DEFER != 0 && exact && cap <= 12; }
-constexpr int rows_stage_bytes(int x, int cap, bool exact) { return rows_fat(cap, exact) ? HMK_ROWS_STAGE_FAT * 16 : rows_stage(x, cap, exact) * 4; }   // per wave
-#ifndef HMK_ROWS_DBG   // measurement builds only (tools/ab_rows4.sh; wrong results): the flush 1 = does not rescore, 2 = drops its records, 3 = fetches one column for all lanes, 4 = stores nothing, 5 = no placing atomics, 6 = no rank store
-#define HMK_ROWS_DBG 0
-#endif
-#ifndef HMK_ROWS_COUNT_GROUPED   // 1: the counting flush adds a row's hits of one iteration with ONE atomic
-#define HMK_ROWS_COUNT_GROUPED 1
-#endif
-#ifndef HMK_ROWS_FLUSH_UNROLLED   // 1: the flush of a one-length shape sums its planes from compile-time cell lists (0: the run-time loop of the capacity form)
-#define HMK_ROWS_FLUSH_UNROLLED 1
-#endif
-// HMK_ROWS_COMPACT=1 (default): the table reads are VOLATILE loads, which the compiler's load/store optimiser leaves alone, and
-// the tables are packed (192 bytes per row position); 0: plain loads and the spread-out placement described above.
-#ifndef HMK_ROWS_COMPACT
-#define HMK_ROWS_COMPACT 1
-#endif
-constexpr int rows_slot_bytes() { return 2248; }
+// the rescoring flush of a two-group one-length shape drains ONE group per wave-instruction (two-ended stage, see the kernel)
+constexpr bool rows_two_ended(int x, int cap, bool exact, int g) { return exact && !rows_inloop(x, cap) && g == 2; }
+
 template <typename T>
 __device__ __forceinline__ T rows_table_read(uint32_t addr) {
-#if HMK_ROWS_COMPACT
     return *reinterpret_cast<const volatile HMK_LDS T *>((uintptr_t)addr);
-#else
-    return lds_read<T>(addr);
-#endif
-}
-// no two table blocks of one group within a window of nd row positions may be fusable into a ds_read2[st64]_b64:
-// their distance a * SLOT + b * 192 (a slots, b = -1..1 sub-slots) must exceed 2040 bytes and not be a multiple of 512
-constexpr bool rows_layout_ok(int nd) {
-    for (int a = 1; a < nd; a++)
-        for (int b = -1; b <= 1; b++) {
-            const int dist = a * rows_slot_bytes() + b * 192;
-            if (dist <= 2040 || dist % 512 == 0) return false;
-        }
-    return true;
 }
 // waves per SIMD a shape is compiled for: what its LDS footprint lets a CU hold, and no more than its registers (column
 // offsets + 2 accumulators per plane + reads in flight and the rest) allow without spilling
+// (the capacity forms keep a second offset set and run-time bounds alive: at 8 waves the smallest of them spilled 40 bytes
+// per lane inside the batch loop; 7 waves: BASELINE config 4a 4.30 -> 4.21 ms, 6 waves 4.27)
 constexpr int rows_waves(int nd, int cap, int lds_bytes, bool exact) {
-#ifdef HMK_ROWS_WAVES
-    return HMK_ROWS_WAVES;
-#endif
-    // (the capacity forms keep a second offset set and run-time bounds alive: at 8 waves the smallest of them spilled 40 bytes
-    // per lane inside the batch loop; 7 waves: BASELINE config 4a 4.30 -> 4.21 ms, 6 waves 4.27)
     const int v = cap + 2 * nd + 36 + (exact ? 0 : 6);
     const int by_regs = v <= 64 ? 8 : v <= 72 ? 7 : v <= 80 ? 6 : v <= 96 ? 5 : 4;
     const int by_lds = 163840 / ((lds_bytes + 511) / 512 * 512);
     return by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
 }
 constexpr int rows_tab_bytes(int x, int d, int cap, bool exact, int g) {
-    const int nd = 2 * x + d + 1;
-    return HMK_ROWS_COMPACT ? g * (cap + d + (exact ? 0 : nd - 1)) * 192 : nd * rows_slot_bytes();
+    return g * (cap + d + (exact ? 0 : 2 * x + d)) * 192;   // positions + (capacity form) the end table's ND - 1 positions
 }
 constexpr int rows_lds_bytes(int x, int d, int cap, bool exact, int g) {   // must match the kernel's LDS map
-    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * rows_stage_bytes(x, cap, exact);
+    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * rows_stage(x, cap, exact) * 4;
 }
 
 template <int N, class F, int... Is>
@@ -168,26 +92,22 @@ struct RowsShape {
     static constexpr int ND = 2 * X + D + 1;          // shift planes
     static constexpr int NI = CAP + D;                // row positions held per group
     static constexpr int ENT = 192;                   // bytes per row position: 24 residues x 8 rows
-    static constexpr int SLOT = rows_slot_bytes();    // see "Table placement" above
-    static constexpr int SUB = (NI + ND - 1) / ND;    // sub-slots a group's positions take
     static constexpr int NEND = EXACT_LB ? 0 : ND - 1;   // end table: the row's last ND - 1 positions again, indexed from the row's end
     static constexpr int TAB_BYTES = rows_tab_bytes(X, D, CAP, EXACT_LB, G);
     static constexpr int LPADW = (CAP <= 8) ? 2 : (CAP <= 16) ? 4 : 8; // residue dwords a lane loads (rows are P.lpad bytes apart)
     static constexpr int TW = (X + 3) / 4;            // dwords holding the last X residues of a column
+    static constexpr int TWN = TW > 0 ? TW : 1;
     static constexpr int NT = X > 0 ? X : 1;
     static_assert(X >= 0 && D >= 0 && CAP >= 2 * X && CAP >= 1 && CAP <= 32 && G >= 1 && G <= 8, "shape");
-    static_assert(HMK_ROWS_COMPACT || (G * (SUB + (NEND > 0 ? 1 : 0)) * ENT <= SLOT && rows_layout_ok(ND)), "sub-slots must fit the slot; no fusable pair");
     static_assert(TAB_BYTES <= 65536, "table offsets must fit the DS immediate");
-    // byte address of row position i of group g / of the position e places before the row's end; both are linear in g
-    // (GROUP_STEP / END_STEP bytes per group), which lets the flush add a per-lane group to the offsets instead
-    static constexpr int GROUP_STEP = HMK_ROWS_COMPACT ? NI * ENT : SUB * ENT;
-    static constexpr int pos_addr(int g, int i) { return HMK_ROWS_COMPACT ? (g * NI + i) * ENT : (i % ND) * SLOT + (g * SUB + i / ND) * ENT; }
-    static constexpr int end_addr(int g, int e) { return HMK_ROWS_COMPACT ? (G * NI + g * NEND + e) * ENT : e * SLOT + (G * SUB + g) * ENT; }
+    // byte address of row position i of group g / of the position e places before the row's end; position tables are linear
+    // in g (GROUP_STEP bytes per group), which lets the flush add a per-record group to the offsets instead
+    static constexpr int GROUP_STEP = NI * ENT;
+    static constexpr int pos_addr(int g, int i) { return (g * NI + i) * ENT; }
+    static constexpr int end_addr(int g, int e) { return (G * NI + g * NEND + e) * ENT; }
 
-    // A column's residues -> table offsets (residue * 8): off[j] for position j, toff[q] for position lbs - X + q (the last X).
-    // `base` is added to every offset (the table's LDS address + a per-lane group displacement), `tbase` to the tail ones.
-    static constexpr int TWN = TW > 0 ? TW : 1;
-    // the column's residue words as they lie in memory (zero for a lane without a column)
+    // the column's residue words as they lie in memory (zero for a lane without a column); tw: the last X residues, wherever
+    // the column ends (capacity form only: unaligned dword loads; the array is padded)
     static __device__ __forceinline__ void load_words(const uint8_t *rowp, bool live, int lbs, uint32_t (&words)[LPADW], uint32_t (&tw)[TWN]) {
 #pragma unroll
         for (int q = 0; q < LPADW; q++) words[q] = 0;
@@ -205,14 +125,14 @@ struct RowsShape {
                 const u32x4 v1 = reinterpret_cast<const u32x4 *>(rowp)[1];
                 words[4] = v1.x; words[5] = v1.y; words[6] = v1.z; words[7] = v1.w;
             }
-            if (!EXACT_LB && TW > 0) {   // the last X residues, wherever the column ends (unaligned dword loads; the array is padded)
+            if (!EXACT_LB && TW > 0) {
 #pragma unroll
                 for (int q = 0; q < TW; q++) __builtin_memcpy(&tw[q], rowp + (lbs - X) + 4 * q, 4);
             }
         }
     }
     // base + byte k of w in ONE instruction (sub-dword operand select); the plain C form costs a v_bfe and a v_add when the base
-    // is a per-lane value (the flush: table + group + row byte) -- with a compile-time base (the main loop) the v_bfe alone
+    // is a per-lane value (the flush: table + group) -- with a compile-time base (the main loop) the v_bfe alone
     template <int K>
     static __device__ __forceinline__ uint32_t add_byte(uint32_t base, uint32_t w) {
         uint32_t r;
@@ -222,20 +142,22 @@ struct RowsShape {
         else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(w));
         return r;
     }
+    // A column's residues -> table offsets (residue * 8): off[j] for position j, toff[q] for position lbs - X + q (the last X).
+    // `base` is added to every offset (the table's LDS address; LANE_BASE: + a per-lane displacement), `tbase` to the tail ones.
     template <bool LANE_BASE = false>
     static __device__ __forceinline__ void offsets_of(const uint32_t (&words_in)[LPADW], const uint32_t (&tw_in)[TWN], uint32_t base, uint32_t tbase,
                                                       uint32_t (&off)[CAP], uint32_t (&toff)[NT]) {
-        uint32_t words[LPADW], tw[TWN];
-        // residues are < 32, so byte k of (word << 3) is residue * 8 exactly (the three bits that move in are zero)
-#pragma unroll
-        for (int q = 0; q < LPADW; q++) words[q] = words_in[q] << 3;
         if constexpr (LANE_BASE) {
+            // residues are < 32, so byte k of (word << 3) is residue * 8 exactly (the three bits that move in are zero)
+            uint32_t words[LPADW];
+#pragma unroll
+            for (int q = 0; q < LPADW; q++) words[q] = words_in[q] << 3;
             rows_static_for<CAP>([&](auto jt) {
                 constexpr int J = decltype(jt)::value;
                 off[J] = add_byte<(J & 3)>(base, words[J >> 2]);
             });
         } else {
-#if HMK_ROWS_UNPACK_SDWA   // (byte select, then the shift: one v_lshlrev_b32_sdwa per residue -- no shifted copy of the word, no mask for byte 0;
+            // (byte select, then the shift: one v_lshlrev_b32_sdwa per residue -- no shifted copy of the word, no mask for byte 0;
             // the compiler finds the form itself for bytes 1-3 and turns byte 0 back into shift + mask, hence the asm for that one)
             const uint32_t three = 3u;   // (a VGPR operand: the same register the compiler keeps for its own SDWA shifts)
 #pragma unroll
@@ -248,15 +170,12 @@ struct RowsShape {
                     off[j] = base + (((words_in[j >> 2] >> ((j & 3) * 8)) & 0xFFu) << 3);
                 }
             }
-#else
-#pragma unroll
-            for (int j = 0; j < CAP; j++) off[j] = base + ((words[j >> 2] >> ((j & 3) * 8)) & 0xFFu);
-#endif
         }
         if (EXACT_LB) {
 #pragma unroll
             for (int q = 0; q < X; q++) toff[q] = off[CAP - X + q];
         } else {
+            uint32_t tw[TWN];
 #pragma unroll
             for (int q = 0; q < TWN; q++) tw[q] = tw_in[q] << 3;
 #pragma unroll
@@ -271,9 +190,7 @@ struct RowsShape {
     }
 
     // All shift sums of (8 rows of group GI) x (this lane's column): W0 / W1[u] = the 8 byte lanes of plane u.
-    // LOWP (the flush): a scheduling barrier after every position pair, so that the compiler does not put all of a column's
-    // reads in flight at once (2 x 72 registers at length 12) beside the main loop's live state.
-    template <int GI, bool LOWP = false>
+    template <int GI>
     static __device__ __forceinline__ void accumulate(const uint32_t (&off)[CAP], const uint32_t (&toff)[NT], int lbs,
                                                       const uint32_t (&ci)[ND], uint32_t (&W0)[ND], uint32_t (&W1)[ND]) {
         if constexpr (EXACT_LB) {
@@ -299,7 +216,6 @@ struct RowsShape {
                     a0 = a0 + e0.x + e1.x; a1 = a1 + e0.y + e1.y;
                 }
                 W0[u] = a0; W1[u] = a1;
-                if (LOWP) __builtin_amdgcn_sched_barrier(0);
             }
             return;
         }
@@ -319,7 +235,7 @@ struct RowsShape {
         auto add_pairs = [&](auto start_tag) {
             constexpr int J0 = decltype(start_tag)::value;
             int nmain = lbs - X;
-            if (!EXACT_LB) asm volatile("" : "+s"(nmain));   // keep the tests scalar (s_cmp + s_cbranch), see k_neighbors_planes
+            asm volatile("" : "+s"(nmain));   // keep the tests scalar (s_cmp + s_cbranch), see k_neighbors_planes
 #pragma unroll
             for (int j = J0; j + 1 < CAP - X; j += 2) {
                 if (j + 1 >= nmain) break;
@@ -336,7 +252,6 @@ struct RowsShape {
                         W0[u] += e1.x; W1[u] += e1.y;
                     }
                 }
-                if (LOWP) __builtin_amdgcn_sched_barrier(0);
             }
         };
         if ((lbs - X) & 1) {
@@ -345,7 +260,6 @@ struct RowsShape {
         } else {
             add_pairs(std::integral_constant<int, 0>{});
         }
-        if (LOWP) __builtin_amdgcn_sched_barrier(0);
         // the last X column positions: position lbs - X + q pairs with row position lbs - 2X + q + u, which is inside the
         // row (length lbs + D) for planes u <= ND - 2 - q only; that row position is ND - 2 - q - u places before the row's
         // end, whatever the column length (end table)
@@ -354,7 +268,7 @@ struct RowsShape {
 #pragma unroll
             for (int q = 0; q < X; q++) {
                 if (u <= ND - 2 - q) {
-                    const u32x2 e = rows_table_read<u32x2>(toff[q] + (uint32_t)(EXACT_LB ? pos_addr(GI, CAP - 2 * X + q + u) : end_addr(GI, ND - 2 - q - u)));
+                    const u32x2 e = rows_table_read<u32x2>(toff[q] + (uint32_t)end_addr(GI, ND - 2 - q - u));
                     W0[u] += e.x; W1[u] += e.y;
                 }
             }
@@ -362,13 +276,12 @@ struct RowsShape {
     }
 };
 
-// The flush is a function that is NOT inlined: inlined, it (it scores whole columns again and wants registers of its own) made
-// the compiler keep the append loop's state in scratch memory on every pass.  What it needs beside the wave's stage -- the
-// kernel's arguments, the tile and its class -- it reads where the kernel reads them: the kernel passes the address of its
-// kernarg segment, the workgroup id reaches a callee as an implicit scalar input, and everything behind them is uniform
-// read-only memory, so all of it arrives by scalar loads in SGPRs and the function's vector registers are free for the rescoring.
-// (Round 3 handed a 160-byte block over through LDS: read with ds_read, every field occupied a VGPR -- 40 of the function's
-// 64 -- and an unrolled rescoring spilled; by-value arguments travelled through the stack per lane, 1.2 GB per pass.)
+// The flush is a function that is NOT inlined: inlined, it (the rescoring kind scores whole columns again and wants registers of
+// its own) made the compiler keep the append loop's state in scratch memory on every pass.  What it needs beside the wave's
+// stage -- the kernel's arguments, the tile and its class -- it reads where the kernel reads them: the kernel passes the
+// address of its kernarg segment (the intrinsic is null inside a callee), the workgroup id reaches a callee as an implicit
+// scalar input, and everything behind them is uniform read-only memory, so all of it arrives by scalar loads in SGPRs and the
+// function's vector registers are free for the rescoring.
 typedef const __attribute__((address_space(4))) uint8_t *RowsConstBytes;
 template <typename T>
 __device__ __forceinline__ T rows_const_load(const void *p) {   // a uniform address in read-only memory: s_load
@@ -376,43 +289,49 @@ __device__ __forceinline__ T rows_const_load(const void *p) {   // a uniform add
 }
 struct RowsKernArgs { NeighborParams P; uint32_t tile_base; };   // k_neighbors_rows' explicit arguments as they lie in the kernarg segment
 
-// Drains one wave's staged records ((column - tile's first column) | row within the tile << 16).  A record says WHICH pair
-// reached the threshold; its score is worked out here, where every lane has a record of its own: the pair's column is
-// fetched again and scored against its row's byte of the row group's tables.  In the main loop the same extraction ran for
-// one or two live lanes per wave-instruction and was a fifth of the kernel's VALU work (VALU 99 % busy beside LDS 88 %).
+// Drains one wave's staged records.  MODE: what a flush does beside storing the edge (EDGES_PLAIN / EDGES_COUNT: the rows'
+// degree counters of a clustering call, fire-and-forget atomics).
+//   in-loop shapes:  record = column - tile's first column | row within the tile << 16 | (score - threshold) << 24.
+//   rescoring shapes: record = column | the hit's bit in its lane's history word << 16 | group << 21; its score is worked out
+//   here.  Two-ended stages (rows_two_ended): group 0's records are stage[0 .. cnt), group 1's stage[CAP - cnt_hi .. CAP), and a
+//   wave-instruction of the rescoring touches ONE group's table: its ds_read_b64 (64 banks, a position's 24 entries are 48
+//   dwords) are conflict-free for any set of residues.  (Round 4 read the 4-byte half that holds the record's row, ds_read_b32:
+//   32 banks for the same 48 dwords, and with two groups' tables 336 dwords apart -- SQ_LDS_BANK_CONFLICT counted 1.9 extra
+//   cycles per read at the 7-mers' default threshold, a tenth of the pass's CU cycles.)
 template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
-__device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_t *stage_v, uint32_t cnt_v, uint32_t tab_addr, uint32_t ka_lo, uint32_t ka_hi) {
+__device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_t *stage_v, uint32_t cnt_v, uint32_t cnt_hi_v, uint32_t tab_addr,
+                                                           uint32_t ka_lo, uint32_t ka_hi) {
     using S = RowsShape<X, D, CAP, EXACT_LB, G>;
+    constexpr bool TWO = rows_two_ended(X, CAP, EXACT_LB, G);
+    constexpr int STAGE_CAP = rows_stage(X, CAP, EXACT_LB);
     // (arguments arrive in vector registers; all of them are wave-uniform)
-    const uint32_t cnt = __builtin_amdgcn_readfirstlane(cnt_v);
+    const uint32_t cnt_lo = __builtin_amdgcn_readfirstlane(cnt_v);
+    const uint32_t cnt_hi = TWO ? __builtin_amdgcn_readfirstlane(cnt_hi_v) : 0u;
+    const uint32_t cnt = cnt_lo + cnt_hi;
     if (cnt == 0) return;
-#if HMK_ROWS_DBG == 2   // (measurement only: records are dropped)
-    return;
-#endif
     const HMK_LDS uint32_t *stage = (const HMK_LDS uint32_t *)(uintptr_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)stage_v);
     struct {
         const uint8_t *res_sorted; const uint32_t *perm; uint64_t *edges; unsigned long long *counts; uint64_t cap_per_shard;
-        uint32_t *deg, *deg_up, *deg_lo, *rank;
+        uint32_t *deg;
         uint32_t lpad, symmetric, perm_identity, row0, col0, shard, deg_m_offset;
         int threshold;
         uint32_t cinit[8];
     } A;
     int lbs;
     {
-        // (the kernarg segment pointer is an intrinsic of kernels only: the kernel passes it)
         const RowsConstBytes ka = (RowsConstBytes)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(ka_hi) << 32) |
                                                    (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(ka_lo));   // (the builtin returns int: no sign extension)
         const auto *K = reinterpret_cast<const __attribute__((address_space(4))) RowsKernArgs *>(ka);
         const uint32_t tile = K->tile_base + blockIdx.x;
         A.res_sorted = K->P.res_sorted; A.perm = K->P.perm; A.edges = K->P.edges; A.counts = K->P.counts;
         A.cap_per_shard = K->P.cap_per_shard;
-        A.deg = K->P.deg; A.deg_up = K->P.deg_up; A.deg_lo = K->P.deg_lo; A.rank = K->P.rank;
+        A.deg = K->P.deg;
         A.lpad = K->P.lpad; A.symmetric = K->P.symmetric; A.perm_identity = K->P.perm_identity; A.deg_m_offset = K->P.deg_m_offset;
         const Tile *Tp = K->P.tiles + tile;
         A.row0 = rows_const_load<uint32_t>(&Tp->row0);
         A.col0 = rows_const_load<uint32_t>(&Tp->col0);
         const TileClass *Cp = K->P.classes + rows_const_load<uint32_t>(&Tp->cls);
-        A.shard = (K->P.band_mod && rows_const_load<uint32_t>(&Tp->pad0)) ? tile % K->P.band_mod : K->P.shard_base + tile % K->P.shard_mod;   // tile_shard(), hmk_device.h
+        A.shard = tile % HMK_EDGE_SHARDS;   // tile_shard(), hmk_device.h
         A.threshold = 128 - rows_const_load<int32_t>(&Cp->g);
 #pragma unroll
         for (int q = 0; q < 8; q++) A.cinit[q] = (q * 4 < S::ND) ? rows_const_load<uint32_t>(&Cp->cinit[q]) : 0u;
@@ -423,39 +342,22 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
     const uint32_t lane = threadIdx.x & 63u;                // (not mbcnt: see flush_stage, hmk_device.h)
     const int la = lbs + D;
     const uint32_t tab = __builtin_amdgcn_readfirstlane(tab_addr);
-    constexpr bool DEFER = HMK_ROWS_DEFER != 0 && EXACT_LB;
-
-    // ---- vector memory by hand --------------------------------------------------------------------------------------------
-    // Left to the compiler, an iteration of this loop (64 records) is a chain of round trips: the records' columns, (mixed
-    // lengths: the permutation,) the placing atomics' return values, and -- because the compiler does not count loads and
-    // stores in flight across a loop's back edge and waits with vmcnt(0) wherever it needs one of them -- the edge stores'
-    // completion as well.  Here ONE asm statement per iteration issues the atomics of these 64 records and the loads for the
-    // NEXT 64 (columns, tails, permutation) and waits for all of them (cdna_hip_programming.md, inline asm: "the loads and
-    // their s_waitcnt in ONE statement", early-clobber outputs -- the only form in which no value the compiler can see is
-    // still in flight), and the stores, issued by asm after it, have the next iteration's rescoring to complete: one round
-    // trip per 64 records instead of three or four.  Everything is issued by all 64 lanes at valid addresses (a lane without
-    // a record reads the tile's first column and adds 0 to its first row's counter): no branch inside the statement.
-    // (A first version let the rescoring run between the issue and the wait, each load an asm statement of its own with a
-    // "=v" output: the compiler copied such a register -- v_mov of a loaded word, hoisted above the wait -- before the load
-    // had written it, and 7-mers at a dense threshold got stale columns in one wave of four, now and then.  The rescoring is
-    // a fifth of a round trip: hiding it there was not worth a value in flight.)
-    // What it bought ("where a hit's time goes"): the clustering calls' placing pass, whose every iteration used
-    // to wait for two returning atomics on top of the gather (10^5: 3.61 -> 3.41 ms); the plain pass did not move -- there an
-    // iteration's time is the latency of ONE thing, the gather of 64 columns from 30-60 different cache lines, with or without
-    // the rescoring (0.03 ms of the 0.6 ms that 8 x 10^7 hits cost the 10^5 pass), the stores (nothing) and the append loop (0.07 ms;
-    // builds that leave one part out, HMK_ROWS_DBG).
-    struct Next {
-        uint32_t rt, mcol;                  // row within the tile, column (sorted position)
-        uint32_t w[S::LPADW], tw[S::TWN];   // the column's residue words
-        uint32_t px, pm;                    // perm[row], perm[column], or the indices themselves
-    } nx;
-    uint32_t rx = 0, rm = 0;   // the placing atomics' return values
-    // decode the records of iteration k0 into nx.rt / nx.mcol and return the addresses the statement loads from
-    constexpr bool FAT = rows_fat(CAP, EXACT_LB);   // records carry their column's words: nothing to fetch (see HMK_ROWS_FAT)
-    if constexpr (rows_inloop(X, CAP, EXACT_LB)) {
-        // records carry their score (HMK_ROWS_INLOOP): column - first column | row in tile << 16 | (score - threshold) << 24
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&A.counts[A.shard], (unsigned long long)cnt);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&A.counts[A.shard], (unsigned long long)cnt);
+    // the rows' degree counters of a clustering call: fire-and-forget, nothing of these is waited for.  With the sorted order =
+    // the caller's (one length bucket) the 64 records' smaller ends are the tile's 8 or 16 rows: one atomic per distinct row
+    // with the group's size instead of one per record (10^5 clustering call: scoring 3.43 -> 3.27 ms).  Stored edges only.
+    auto count_degrees = [&](uint32_t x, uint32_t m, bool ok) {
+        if (MODE != EDGES_COUNT) return;
+        if (A.perm_identity) {
+            const WaveGroup g = wave_groups(x, ok);
+            if (ok && g.rank == 0) atomicAdd(&A.deg[x], g.size);
+        } else if (ok) {
+            atomicAdd(&A.deg[x], 1u);
+        }
+        if (ok && A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
+    };
+    if constexpr (rows_inloop(X, CAP)) {
         const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
         const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
         base = ((unsigned long long)bhi << 32) | blo;
@@ -469,99 +371,64 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
             const int score = A.threshold + (int)(rec >> 24);
             const unsigned long long pos = base + k;
             const bool ok = live && pos < A.cap_per_shard;
-            const unsigned long long slot = (unsigned long long)A.shard * A.cap_per_shard + pos;
-            if (MODE == EDGES_COUNT) {
-                if (A.perm_identity && HMK_ROWS_COUNT_GROUPED) {
-                    const WaveGroup g = wave_groups(x, ok);
-                    if (ok && g.rank == 0) atomicAdd(&A.deg[x], g.size);
-                } else if (ok) {
-                    atomicAdd(&A.deg[x], 1u);
-                }
-                if (ok && A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
-            }
-            uint32_t rx = 0, rm = 0;
-            if (MODE == EDGES_PLACE) {
-                const uint32_t *ux = A.deg_up + x, *um = A.symmetric ? A.deg_lo + m : A.deg_up + x;
-                const uint32_t one = ok ? 1u : 0u, one2 = A.symmetric ? one : 0u;
-                uint32_t r0 = 0, r1 = 0;
-                asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\ts_waitcnt vmcnt(0)"
-                             : [r0] "=&v"(r0), [r1] "=&v"(r1) : [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2) : "memory");
-                rx = r0; rm = A.symmetric ? r1 : 0u;
-            }
-            if (ok) {
-                A.edges[slot] = ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
-                if (MODE == EDGES_PLACE) reinterpret_cast<uint2 *>(A.rank)[slot] = make_uint2(rx, rm);
-            }
+            count_degrees(x, m, ok);
+            if (ok)
+                A.edges[(unsigned long long)A.shard * A.cap_per_shard + pos] =
+                    ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
         }
         asm volatile("" ::: "memory");
         drain_end();
         return;
-    }
+    } else {
+    // ---- rescoring: vector memory by hand --------------------------------------------------------------------------------
+    // Left to the compiler, an iteration of this loop (64 records) is a chain of round trips: the records' columns, (mixed
+    // lengths: the permutation,) and -- because the compiler does not count loads and stores in flight across a loop's back
+    // edge and waits with vmcnt(0) wherever it needs one of them -- the edge stores' completion as well.  Here ONE asm
+    // statement per iteration issues the loads for the NEXT 64 records (columns, tails, permutation) and waits for them
+    // (cdna_hip_programming.md, inline asm: "the loads and their s_waitcnt in ONE statement", early-clobber outputs -- the only
+    // form in which no value the compiler can see is still in flight), and the stores, issued by asm after it, have the next
+    // iteration's rescoring to complete.  Every lane issues everything at valid addresses (a lane without a record reads the
+    // tile's first column): no branch inside the statement.
+    // (A first version let the rescoring run between the issue and the wait, each load an asm statement of its own with a
+    // "=v" output: the compiler copied such a register -- v_mov of a loaded word, hoisted above the wait -- before the load
+    // had written it, and 7-mers at a dense threshold got stale columns in one wave of four, now and then.)
+    constexpr bool DEFER = EXACT_LB;   // records of a history word (see the kernel)
+    struct Next {
+        uint32_t rt, mcol;                  // row within the tile, column (sorted position)
+        uint32_t w[S::LPADW], tw[S::TWN];   // the column's residue words
+        uint32_t px, pm;                    // perm[row], perm[column], or the indices themselves
+    } nx;
+    // record index -> where it lies in the stage (two-ended: indices >= cnt_lo count down from the stage's top)
+    auto stage_at = [&](uint32_t k) -> uint32_t { return (TWO && k >= cnt_lo) ? stage[(uint32_t)STAGE_CAP - 1u - (k - cnt_lo)] : stage[k]; };
     auto decode = [&](uint32_t k0) {
         const bool live = k0 + lane < cnt;
-        u32x4 fat = {0, 0, 0, 0};
-        if constexpr (FAT) { if (live) fat = reinterpret_cast<const HMK_LDS u32x4 *>(stage)[k0 + lane]; }
-        const uint32_t rec = FAT ? fat.x : (live ? stage[k0 + lane] : 0u);
+        const uint32_t rec = live ? stage_at(k0 + lane) : 0u;
         // the record (see the append loop): bit q of the lane's hit word at the step that looked, noted `back` steps earlier
         const uint32_t q = (rec >> 16) & 31u, grp = rec >> 21;
         const uint32_t b = DEFER ? q | 3u : q;                // where the bit was when its step noted it
         const uint32_t back = DEFER ? 3u - (q & 3u) : 0u;     // ... that many steps ago
         const uint32_t r = (b >> 3) + 4u - (b & 4u);          // bit 8r + 7: row r; bit 8r + 3: row 4 + r
         nx.rt = live ? grp * 8u + r : 0u;
-        nx.mcol = A.col0 + (live ? (rec & 0xFFFFu) - (FAT ? 0u : back * 256u) : 0u);   // (a fat record holds the hit's own column)
-        if constexpr (FAT) {
-            const uint32_t fw[3] = {fat.y, fat.z, fat.w};
-#pragma unroll
-            for (int t = 0; t < S::LPADW; t++) nx.w[t] = t < 3 ? fw[t < 3 ? t : 0] : 0u;
-#pragma unroll
-            for (int t = 0; t < S::TWN; t++) nx.tw[t] = 0;
-            nx.px = A.row0 + nx.rt;
-            nx.pm = nx.mcol;
-        }
+        nx.mcol = A.col0 + (live ? (rec & 0xFFFFu) - back * 256u : 0u);
     };
-    // the statement: [atomics of the current records: ux / um += one, old values -> r0 / r1] + loads for the records decoded last
-    // + the wait.  One asm per combination, each with exactly the operands it uses (outputs are early-clobber: a superset of
-    // operands cost 16 registers and a spill).  W_S / W_OUT: the column words' load(s) and destination(s).
-#define HMK_FLUSH_ST_000(W_S, ...) asm volatile(W_S "s_waitcnt vmcnt(0)" : __VA_ARGS__ : [colp] "v"(colp) : "memory")
-#define HMK_FLUSH_ST_001(W_S, ...) asm volatile(W_S "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
-#define HMK_FLUSH_ST_010(W_S, ...) asm volatile(W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [t0] "=&v"(t0), [t1] "=&v"(t1) : [colp] "v"(colp), [tp] "v"(tp) : "memory")
-#define HMK_FLUSH_ST_011(W_S, ...) asm volatile(W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [t0] "=&v"(t0), [t1] "=&v"(t1), [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [tp] "v"(tp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
-#define HMK_FLUSH_ST_100(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2) : "memory")
-#define HMK_FLUSH_ST_101(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1), [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
-#define HMK_FLUSH_ST_110(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0), [t1] "=&v"(t1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2), [tp] "v"(tp) : "memory")
-#define HMK_FLUSH_ST_111(W_S, ...) asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\t" W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [r0] "=&v"(r0), [r1] "=&v"(r1), [t0] "=&v"(t0), [t1] "=&v"(t1), [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2), [tp] "v"(tp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
-#define HMK_FLUSH_ST(W_S, ...)                                                                          \
-    do {                                                                                                  \
-        if (MODE == EDGES_PLACE && atomics && HMK_ROWS_DBG != 5) {   /* (DBG 5: no placing atomics) */             \
-            if constexpr (EXACT_LB || S::TW == 0) { if (A.perm_identity) HMK_FLUSH_ST_100(W_S, __VA_ARGS__); else HMK_FLUSH_ST_101(W_S, __VA_ARGS__); } \
-            else { if (A.perm_identity) HMK_FLUSH_ST_110(W_S, __VA_ARGS__); else HMK_FLUSH_ST_111(W_S, __VA_ARGS__); } \
-        } else {                                                                                          \
-            if constexpr (EXACT_LB || S::TW == 0) { if (A.perm_identity) HMK_FLUSH_ST_000(W_S, __VA_ARGS__); else HMK_FLUSH_ST_001(W_S, __VA_ARGS__); } \
-            else { if (A.perm_identity) HMK_FLUSH_ST_010(W_S, __VA_ARGS__); else HMK_FLUSH_ST_011(W_S, __VA_ARGS__); } \
-        }                                                                                                 \
+    // the statement: loads for the records decoded last + the wait.  One asm per combination, each with exactly the operands
+    // it uses (outputs are early-clobber: a superset of operands cost 16 registers and a spill).
+#define HMK_FLUSH_ST_00(W_S, ...) asm volatile(W_S "s_waitcnt vmcnt(0)" : __VA_ARGS__ : [colp] "v"(colp) : "memory")
+#define HMK_FLUSH_ST_01(W_S, ...) asm volatile(W_S "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
+#define HMK_FLUSH_ST_10(W_S, ...) asm volatile(W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [t0] "=&v"(t0), [t1] "=&v"(t1) : [colp] "v"(colp), [tp] "v"(tp) : "memory")
+#define HMK_FLUSH_ST_11(W_S, ...) asm volatile(W_S "global_load_dword %[t0], %[tp], off\n\tglobal_load_dword %[t1], %[tp], off offset:4\n\t" "global_load_dword %[p0], %[pxp], off\n\tglobal_load_dword %[p1], %[pmp], off\n\t" "s_waitcnt vmcnt(0)" : __VA_ARGS__, [t0] "=&v"(t0), [t1] "=&v"(t1), [p0] "=&v"(p0), [p1] "=&v"(p1) : [colp] "v"(colp), [tp] "v"(tp), [pxp] "v"(pxp), [pmp] "v"(pmp) : "memory")
+#define HMK_FLUSH_ST(W_S, ...)                                                                                              \
+    do {                                                                                                                  \
+        if constexpr (EXACT_LB || S::TW == 0) { if (A.perm_identity) HMK_FLUSH_ST_00(W_S, __VA_ARGS__); else HMK_FLUSH_ST_01(W_S, __VA_ARGS__); } \
+        else { if (A.perm_identity) HMK_FLUSH_ST_10(W_S, __VA_ARGS__); else HMK_FLUSH_ST_11(W_S, __VA_ARGS__); }             \
     } while (0)
-    // x, m, ok: the CURRENT records' edge ends and whether they are stored (atomics only when `atomics`)
-    auto statement = [&](bool atomics, uint32_t x, uint32_t m, bool ok) {
-        if constexpr (FAT) {
-            if (MODE == EDGES_PLACE && atomics && HMK_ROWS_DBG != 5) {
-                const uint32_t *ux = A.deg_up + x, *um = A.symmetric ? A.deg_lo + m : A.deg_up + x;
-                const uint32_t one = ok ? 1u : 0u, one2 = A.symmetric ? one : 0u;
-                uint32_t r0 = 0, r1 = 0;
-                asm volatile("global_atomic_add %[r0], %[ux], %[one], off sc0\n\tglobal_atomic_add %[r1], %[um], %[one2], off sc0\n\ts_waitcnt vmcnt(0)"
-                             : [r0] "=&v"(r0), [r1] "=&v"(r1) : [ux] "v"(ux), [um] "v"(um), [one] "v"(one), [one2] "v"(one2) : "memory");
-                rx = r0; rm = A.symmetric ? r1 : 0u;
-            }
-            return;
-        }
-        const uint8_t *colp = A.res_sorted + (size_t)(HMK_ROWS_DBG == 3 ? A.col0 : nx.mcol) * A.lpad;   // (DBG 3: every lane fetches the tile's first column)
+    auto statement = [&]() {
+        const uint8_t *colp = A.res_sorted + (size_t)nx.mcol * A.lpad;
         const uint8_t *tp = colp + (lbs - X);
         const uint32_t *pxp = A.perm + (A.row0 + nx.rt), *pmp = A.perm + nx.mcol;
-        // (an asymmetric matrix has no lower counters: its second atomic adds 0 to the upper one)
-        const uint32_t *ux = A.deg_up + x, *um = A.symmetric ? A.deg_lo + m : A.deg_up + x;
-        const uint32_t one = ok ? 1u : 0u, one2 = A.symmetric ? one : 0u;
         u32x2 w2 = {0, 0};
         u32x4 wa = {0, 0, 0, 0}, wb = {0, 0, 0, 0};
-        uint32_t t0 = 0, t1 = 0, p0 = 0, p1 = 0, r0 = 0, r1 = 0;
+        uint32_t t0 = 0, t1 = 0, p0 = 0, p1 = 0;
         if constexpr (S::LPADW == 2) HMK_FLUSH_ST("global_load_dwordx2 %[w2], %[colp], off\n\t", [w2] "=&v"(w2));
         else if constexpr (S::LPADW == 4) HMK_FLUSH_ST("global_load_dwordx4 %[wa], %[colp], off\n\t", [wa] "=&v"(wa));
         else HMK_FLUSH_ST("global_load_dwordx4 %[wa], %[colp], off\n\tglobal_load_dwordx4 %[wb], %[colp], off offset:16\n\t", [wa] "=&v"(wa), [wb] "=&v"(wb));
@@ -575,125 +442,145 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         if constexpr (!EXACT_LB && S::TW > 0) { nx.tw[0] = t0; if constexpr (S::TW > 1) nx.tw[1] = t1; }
         nx.px = A.perm_identity ? A.row0 + nx.rt : p0;
         nx.pm = A.perm_identity ? nx.mcol : p1;
-        if (MODE == EDGES_PLACE && atomics) { rx = r0; rm = A.symmetric ? r1 : 0u; }
     };
     decode(0);
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&A.counts[A.shard], (unsigned long long)cnt);
-    statement(false, 0u, 0u, false);
+    statement();
     const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
     const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
     base = ((unsigned long long)bhi << 32) | blo;
-    for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {   // wave-uniform trip count: the table reads below run for whole waves
-        const uint32_t k = k0 + lane;
-        const bool live = k < cnt;
+    // Two-ended stages: the iterations [0, cnt_lo) hold group 0's records, those from the next multiple of 64 on group 1's -- an
+    // iteration never mixes groups.  k indexes RECORDS (what decode / stage_at take); `it` walks iterations.
+    const uint32_t lo_iters = TWO ? (cnt_lo + 63u) / 64u : (cnt + 63u) / 64u;
+    const uint32_t n_iters = TWO ? lo_iters + (cnt_hi + 63u) / 64u : lo_iters;
+    // first record and record count of iteration `it`
+    auto iter_first = [&](uint32_t it) -> uint32_t { return (TWO && it >= lo_iters) ? cnt_lo + (it - lo_iters) * 64u : it * 64u; };
+    auto iter_end = [&](uint32_t it) -> uint32_t { return (TWO && it < lo_iters) ? cnt_lo : cnt; };
+    if constexpr (TWO) {   // (the first decode above read records 0 .. 63 of the plain order: redo it for the iteration's bounds)
+        const uint32_t f = iter_first(0), e = iter_end(0);
+        const bool live = f + lane < e;
+        const uint32_t rec = live ? stage_at(f + lane) : 0u;
+        const uint32_t q = (rec >> 16) & 31u, grp = rec >> 21, b = q | 3u, back = 3u - (q & 3u), r = (b >> 3) + 4u - (b & 4u);
+        nx.rt = live ? grp * 8u + r : 0u;
+        nx.mcol = A.col0 + (live ? (rec & 0xFFFFu) - back * 256u : 0u);
+        statement();
+    }
+    for (uint32_t it = 0; it < n_iters; it++) {   // wave-uniform trip count: the table reads below run for whole waves
+        const uint32_t k = iter_first(it) + lane;
+        const bool live = k < iter_end(it);
         uint32_t words[S::LPADW], tw[S::TWN];
 #pragma unroll
         for (int t = 0; t < S::LPADW; t++) words[t] = nx.w[t];
 #pragma unroll
         for (int t = 0; t < S::TWN; t++) tw[t] = nx.tw[t];
-        const uint32_t rt = nx.rt, grp = rt >> 3, r = rt & 7u;
+        const uint32_t rt = nx.rt, r = rt & 7u;
         uint32_t x = nx.px, m = nx.pm;
-        if constexpr (FAT) { if (!A.perm_identity && live) { x = A.perm[x]; m = A.perm[m]; } }   // (one-length plans keep the caller's order: never taken)
         if (A.symmetric && x > m) { const uint32_t t = x; x = m; m = t; }
         const unsigned long long pos = base + k;
-        const bool ok = live && pos < A.cap_per_shard;   // stored edges only (place_edge, hmk_device.h)
+        const bool ok = live && pos < A.cap_per_shard;   // stored edges only
         const unsigned long long slot = (unsigned long long)A.shard * A.cap_per_shard + pos;
-        if (MODE == EDGES_COUNT) {
-            // fire-and-forget: nothing of these is waited for.  With the sorted order = the caller's (one length bucket) the 64
-            // records' smaller ends are the tile's 8 or 16 rows: one atomic per distinct row with the group's size instead of
-            // one per record (10^5 clustering call: scoring 3.43 -> 3.27 ms).
-            if (A.perm_identity && HMK_ROWS_COUNT_GROUPED) {
-                const WaveGroup g = wave_groups(x, ok);
-                if (ok && g.rank == 0) atomicAdd(&A.deg[x], g.size);
-            } else if (ok) {
-                atomicAdd(&A.deg[x], 1u);
-            }
-            if (ok && A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
-        }
-        // The record's ROW is byte r of every 8-byte table entry: the lane reads the 4-byte half that holds it (ds_read_b32: 1
-        // LDS cycle per wave-instruction where the ds_read_b64 of all eight rows takes 2), sums the halves as they are -- four
-        // byte lanes, proven not to carry -- and cuts its byte out of each plane's sum: one v_add3 per two cells + one v_bfe
-        // per plane.  (Round 3 read the whole entries again, two accumulators per plane.  Reading just the byte, ds_read_u8,
-        // looks cheaper still and is not: lanes that read DIFFERENT bytes of one dword are not served together the way lanes
-        // reading the same dword are -- SQ_LDS_BANK_CONFLICT counted two extra cycles per such read, 10 % of the pass's LDS
-        // cycles at threshold 14.)
+        count_degrees(x, m, ok);
         uint32_t off[CAP], toff[S::NT];
-        S::template offsets_of<true>(words, tw, tab + grp * (uint32_t)S::GROUP_STEP + (r & 4u), 0u, off, toff);
-        const uint32_t sh = (r & 3u) * 8u;
         uint32_t mx = 0;   // best shift = largest plane sum
-#if HMK_ROWS_DBG == 1   // (measurement only: no rescoring, wrong scores)
-        mx = off[0] & 0xFFu;
-        if constexpr (false) {
-#else
-        if constexpr (EXACT_LB && HMK_ROWS_FLUSH_UNROLLED) {
-#endif
-            // one length: every plane's cells are known at compile time (plane u pairs column position j with row position
-            // i = j + u - X wherever 0 <= i < la -- ShiftedScorer.java:67-77), one plane's reads (<= CAP registers) in
-            // flight at a time.
+        if constexpr (TWO) {
+            // ONE group per iteration (wave-uniform): whole 8-byte entries, conflict-free, both halves summed, the record's row
+            // cut out of the pair with one v_perm_b32 per plane (selector byte 0 = r: 0-3 pick from the low dword, 4-7 from the
+            // high one; the other selector bytes give zero)
+            const uint32_t gbase = tab + (it >= lo_iters ? (uint32_t)S::GROUP_STEP : 0u);
+            S::template offsets_of<true>(words, tw, gbase, 0u, off, toff);
+            const uint32_t sel = 0x0c0c0c00u | r;
 #pragma unroll
             for (int u = 0; u < S::ND; u++) {
                 constexpr int LA = CAP + D;
                 const int jlo = X - u > 0 ? X - u : 0, jhi = LA + X - u < CAP ? LA + X - u : CAP;
-                uint32_t a = ((A.cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
+                uint32_t a0 = ((A.cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u, a1 = a0;
                 int j = jlo;
-                if ((jhi - jlo) & 1) { a += rows_table_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, j + u - X)); j++; }
+                if ((jhi - jlo) & 1) { const u32x2 e = rows_table_read<u32x2>(off[j] + (uint32_t)S::pos_addr(0, j + u - X)); a0 += e.x; a1 += e.y; j++; }
 #pragma unroll
                 for (; j + 1 < jhi; j += 2) {
-                    const uint32_t e0 = rows_table_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, j + u - X));
-                    const uint32_t e1 = rows_table_read<uint32_t>(off[j + 1] + (uint32_t)S::pos_addr(0, j + 1 + u - X));
-                    a = a + e0 + e1;
+                    const u32x2 e0 = rows_table_read<u32x2>(off[j] + (uint32_t)S::pos_addr(0, j + u - X));
+                    const u32x2 e1 = rows_table_read<u32x2>(off[j + 1] + (uint32_t)S::pos_addr(0, j + 1 + u - X));
+                    a0 = a0 + e0.x + e1.x; a1 = a1 + e0.y + e1.y;
                 }
-                // (an empty volatile asm that "modifies" the sum: the plane's adds must stand before the next plane's volatile
-                // reads are issued.  A scheduling barrier alone does not do it -- the adds are sunk below all 72 reads before the
+                // (an empty volatile asm that "modifies" the sums: the plane's adds must stand before the next plane's volatile
+                // reads are issued.  A scheduling barrier alone does not do it -- the adds are sunk below all the reads before the
                 // scheduler runs, and the reads' results spill.)
-                asm volatile("" : "+v"(a));
-                mx = max(mx, (a >> sh) & 0xFFu);
+                asm volatile("" : "+v"(a0), "+v"(a1));
+                mx = max(mx, __builtin_amdgcn_perm(a1, a0, sel));
             }
         } else {
-            // One plane at a time, in a loop that is NOT unrolled (this path is cold and must stay small in registers): the
-            // plane's cells straight from the position table, row position i = j + u - X wherever it lies inside the row -- the
-            // literal form of ShiftedScorer.java:67-77 on the packed cells, independent of the main loop's unrolled schedule.
-#pragma unroll 1
-            for (int u = 0; u < S::ND; u++) {
-                uint32_t cw = A.cinit[0];
+            // The record's ROW is byte r of every 8-byte table entry: the lane reads the 4-byte half that holds it (ds_read_b32),
+            // sums the halves as they are -- four byte lanes, proven not to carry -- and cuts its byte out of each plane's sum.
+            const uint32_t grp = rt >> 3;
+            S::template offsets_of<true>(words, tw, tab + grp * (uint32_t)S::GROUP_STEP + (r & 4u), 0u, off, toff);
+            const uint32_t sh = (r & 3u) * 8u;
+            if constexpr (EXACT_LB) {
+                // one length: every plane's cells are known at compile time (plane u pairs column position j with row position
+                // i = j + u - X wherever 0 <= i < la -- ShiftedScorer.java:67-77), one plane's reads in flight at a time
 #pragma unroll
-                for (int q = 1; q < 8; q++) cw = (u >> 2) == q ? A.cinit[q] : cw;
-                uint32_t a = ((cw >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
+                for (int u = 0; u < S::ND; u++) {
+                    constexpr int LA = CAP + D;
+                    const int jlo = X - u > 0 ? X - u : 0, jhi = LA + X - u < CAP ? LA + X - u : CAP;
+                    uint32_t a = ((A.cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
+                    int j = jlo;
+                    if ((jhi - jlo) & 1) { a += rows_table_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, j + u - X)); j++; }
 #pragma unroll
-                for (int j = 0; j < CAP; j++) {
-                    const int i = j + u - X;
-                    if (j < lbs && i >= 0 && i < la)   // wave-uniform
-                        a += lds_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, i));
+                    for (; j + 1 < jhi; j += 2) {
+                        const uint32_t e0 = rows_table_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, j + u - X));
+                        const uint32_t e1 = rows_table_read<uint32_t>(off[j + 1] + (uint32_t)S::pos_addr(0, j + 1 + u - X));
+                        a = a + e0 + e1;
+                    }
+                    asm volatile("" : "+v"(a));
+                    mx = max(mx, (a >> sh) & 0xFFu);
                 }
-                mx = max(mx, (a >> sh) & 0xFFu);
+            } else {
+                // One plane at a time, in a loop that is NOT unrolled (this path is cold and must stay small in registers): the
+                // plane's cells straight from the position table, row position i = j + u - X wherever it lies inside the row -- the
+                // literal form of ShiftedScorer.java:67-77 on the packed cells, independent of the main loop's unrolled schedule.
+#pragma unroll 1
+                for (int u = 0; u < S::ND; u++) {
+                    uint32_t cw = A.cinit[0];
+#pragma unroll
+                    for (int q = 1; q < 8; q++) cw = (u >> 2) == q ? A.cinit[q] : cw;
+                    uint32_t a = ((cw >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
+#pragma unroll
+                    for (int j = 0; j < CAP; j++) {
+                        const int i = j + u - X;
+                        if (j < lbs && i >= 0 && i < la)   // wave-uniform
+                            a += lds_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, i));
+                    }
+                    mx = max(mx, (a >> sh) & 0xFFu);
+                }
             }
         }
         const int score = (int)mx - 128 + A.threshold;   // lane = 128 - threshold + score
-        decode(k0 + 64);   // (past the last record: every lane reads the tile's first column -- harmless, and no branch)
-        statement(true, x, m, ok);
-        if (ok && (HMK_ROWS_DBG != 4 || score == 0x7fff)) {   // (DBG 4: nothing is stored)
+        // the next iteration's records (past the last one: every lane reads the tile's first column -- harmless, and no branch)
+        {
+            const uint32_t f = it + 1 < n_iters ? iter_first(it + 1) : cnt, e = it + 1 < n_iters ? iter_end(it + 1) : cnt;
+            if constexpr (TWO) {
+                const bool lv = f + lane < e;
+                const uint32_t rec = lv ? stage_at(f + lane) : 0u;
+                const uint32_t q = (rec >> 16) & 31u, grp = rec >> 21, b = q | 3u, back = 3u - (q & 3u), rr = (b >> 3) + 4u - (b & 4u);
+                nx.rt = lv ? grp * 8u + rr : 0u;
+                nx.mcol = A.col0 + (lv ? (rec & 0xFFFFu) - back * 256u : 0u);
+            } else {
+                decode(f);
+            }
+        }
+        statement();
+        if (ok) {
             const unsigned long long e = ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);
             const uint64_t *ep = A.edges + slot;
             asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(ep), "v"(e) : "memory");
-            if (MODE == EDGES_PLACE && HMK_ROWS_DBG != 6) {   // (DBG 6: no rank store)
-                const u32x2 rk = {rx, rm};
-                const uint32_t *rp = A.rank + 2 * slot;
-                asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(rp), "v"(rk) : "memory");
-            }
         }
     }
 #undef HMK_FLUSH_ST
-#undef HMK_FLUSH_ST_000
-#undef HMK_FLUSH_ST_001
-#undef HMK_FLUSH_ST_010
-#undef HMK_FLUSH_ST_011
-#undef HMK_FLUSH_ST_100
-#undef HMK_FLUSH_ST_101
-#undef HMK_FLUSH_ST_110
-#undef HMK_FLUSH_ST_111
+#undef HMK_FLUSH_ST_00
+#undef HMK_FLUSH_ST_01
+#undef HMK_FLUSH_ST_10
+#undef HMK_FLUSH_ST_11
     asm volatile("" ::: "memory");   // (the stage's reads are done: their values were used)
     drain_end();
+    }
 }
 
 template <class F, int... Is>
@@ -708,10 +595,8 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     using S = RowsShape<X, D, CAP, EXACT_LB, G>;
     constexpr int ND = S::ND, NI = S::NI, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
     constexpr int R = 8 * G;
-    constexpr bool FAT = rows_fat(CAP, EXACT_LB);
-    constexpr int STAGE_CAP = FAT ? HMK_ROWS_STAGE_FAT : rows_stage(X, CAP, EXACT_LB);  // records per wave; flushed when fewer than 64 slots are free
-    constexpr int STAGE_DW = FAT ? 4 : 1;                                       // dwords per record
-    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * STAGE_DW * 4;
+    constexpr int STAGE_CAP = rows_stage(X, CAP, EXACT_LB);  // records per wave; flushed when fewer than 64 slots are free
+    constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4;
     static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, EXACT_LB, G), "rows_lds_bytes must match the LDS map");
     // one STATIC LDS object: its base address is a compile-time constant, so table offsets fold into the ds_read immediate
     __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
@@ -727,7 +612,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     const bool case_b = Cp->case_b != 0;       // the column is the SHORTER sequence: cell = M[c][row[i]], else M[row[i]][c]
     const int tid = threadIdx.x;
     // 32-bit LDS pointer, wave-uniform (kept in a scalar register: nothing to spill around the flush call)
-    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + __builtin_amdgcn_readfirstlane(tid >> 6) * (STAGE_CAP * STAGE_DW);
+    HMK_LDS uint32_t *stage = (HMK_LDS uint32_t *)stage_all + __builtin_amdgcn_readfirstlane(tid >> 6) * STAGE_CAP;
 
     build_begin();
     const uint32_t tab_addr = lds_addr(tab);
@@ -768,82 +653,38 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
 #pragma unroll
     for (int u = 0; u < ND; u++) ci[u] = ((Cp->cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
 
-    uint32_t cnt = 0;  // staged records of this wave (wave-uniform)
+    constexpr bool TWO = rows_two_ended(X, CAP, EXACT_LB, G);
+    uint32_t cnt = 0;     // staged records of this wave (wave-uniform); two-ended: group 0's, from the stage's bottom
+    uint32_t cnt_hi = 0;  // two-ended: group 1's, from the stage's top
     const uint32_t col_end = T.col0 + T.ncols;
     const uint32_t n_batches = (T.ncols + 255) / 256;
     const bool interior = T.diag == 0 && T.ncols % 256 == 0;  // every lane's column is a real pair
-    const bool prio = MODE != EDGES_PLACE || HMK_SETPRIO_PLACE;
+    const bool prio = true;
 
-    // The batch loop needs two of the kernel's arguments.  As fields of P they keep the WHOLE argument block (16 SGPRs, one
-    // s_load_dwordx16) alive through the loop, and with the flush call's register needs the allocator parks that block in VGPR
-    // lanes and reads all 16 back at every step: 18 v_readlane of a step's 150 VALU instructions.  Copies made by an
-    // instruction of their own (HMK_ROWS_ARGCOPY=1) are values of their own and the v_readlane go away -- and the pass gets
-    // SLOWER, 2.560 against 2.525 ms on the same box, twice: the VALU pipe is not what the kernel waits for (the LDS pipe
-    // is), and the 18 instructions sit where the step's global load is in flight.  Kept as a switch, off.
-#if HMK_ROWS_ARGCOPY
-    uint64_t res_sorted_s;
-    uint32_t lpad_s;
-    asm volatile("s_mov_b64 %0, %1" : "=s"(res_sorted_s) : "s"((uint64_t)(uintptr_t)P.res_sorted));
-    asm volatile("s_mov_b32 %0, %1" : "=s"(lpad_s) : "s"(P.lpad));
-    const uint8_t *const res_sorted = (const uint8_t *)(uintptr_t)res_sorted_s;
-#else
+    // (The batch loop needs two of the kernel's arguments.  As fields of P they keep the WHOLE argument block -- 16 SGPRs -- alive
+    // through the loop, and around the flush call the allocator parks that block in VGPR lanes and reads all 16 back at every step:
+    // 18 v_readlane of a step's 150 VALU instructions.  Copying the two out removes them and makes the pass SLOWER, 2.560 against
+    // 2.525 ms: they sit where the step's global load is in flight.  DESIGN.md 5.7.)
     const uint8_t *const res_sorted = P.res_sorted;
     const uint32_t lpad_s = P.lpad;
-#endif
 
-    constexpr bool INLOOP = rows_inloop(X, CAP, EXACT_LB);
-    constexpr bool DEFER = HMK_ROWS_DEFER != 0 && EXACT_LB && !INLOOP;   // (mixed lengths: short column runs, two groups -- 1.3 % slower with it)
-    // Hits are rare per pair (0.26 % at the default threshold) but not per step: a wave tests 512 pairs at a time and finds
-    // one in three steps out of four.  So the test's result is only NOTED at every step -- the top bits of the eight rows'
-    // bytes, merged into one word per lane and shifted into a 4-step history (hm uses every 4th bit: step j of a quad lands on
-    // the bits = j mod 4) -- and the wave looks at the history once per quad: one ballot, one append loop whose number of
-    // turns is the largest number of hits any LANE has in the quad (1.1 on average) instead of four of them.
+    constexpr bool INLOOP = rows_inloop(X, CAP);
+    constexpr bool DEFER = EXACT_LB && !INLOOP;   // (mixed lengths: short column runs, two groups -- 1.3 % slower with it)
+    // Hits are rare per pair (0.26 % at the default threshold of 12-mers) but not per step: a wave tests 512 pairs at a time.
+    // DEFER: the test's result is only NOTED at every step -- the top bits of the eight rows' bytes, merged into one word per
+    // lane and shifted into a 4-step history (hm uses every 4th bit: step j of a quad lands on the bits = j mod 4) -- and the
+    // wave looks at the history once per quad: one ballot, one append loop whose number of turns is the largest number of hits
+    // any LANE has in the quad instead of four of them.
     const uint64_t ka64 = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t ka_lo = (uint32_t)ka64, ka_hi = (uint32_t)(ka64 >> 32);
     uint32_t acc[G];
 #pragma unroll
     for (int g = 0; g < G; g++) acc[g] = 0;
-    // the column of the NEXT step is asked for while this step's table reads run (HMK_ROWS_AHEAD=0: at the step's start)
-    constexpr bool AHEAD = HMK_ROWS_AHEAD != 0;
-    uint32_t nwords[S::LPADW], ntw[S::TWN];
-    if constexpr (AHEAD) {
-        const uint32_t col0 = T.col0 + tid;
-        S::load_words(res_sorted + (size_t)col0 * lpad_s, col0 < col_end, lbs, nwords, ntw);
-    }
-    constexpr int NWF = FAT ? (CAP + 3) / 4 : 1;   // residue words a fat record carries
-    uint32_t Wh[4][NWF];                           // fat records: the column words of the quad's four steps
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-#pragma unroll
-        for (int k = 0; k < NWF; k++) Wh[q][k] = 0;
-    // one step of the batch loop; QT: the step's place in its quad (bt & 3) at compile time (fat records: which Wh[] it fills)
-    auto step = [&](const uint32_t bt, auto qt) {
-        constexpr int Q = decltype(qt)::value;
+    for (uint32_t bt = 0; bt < n_batches; bt++) {
         const uint32_t colrel = bt * 256 + tid;
         const uint32_t col = T.col0 + colrel;
         uint32_t off[CAP], toff[S::NT];
-        if constexpr (FAT) {
-            uint32_t words[S::LPADW], tw[S::TWN];
-            S::load_words(res_sorted + (size_t)col * lpad_s, col < col_end, lbs, words, tw);
-#pragma unroll
-            for (int k = 0; k < NWF; k++) Wh[Q][k] = words[k];
-            S::offsets_of(words, tw, tab_addr, tab_addr, off, toff);
-        } else if constexpr (AHEAD) {
-            // The wait for THIS step's column must stand before the next column is asked for: the compiler does not count loads
-            // in flight across the loop's back edge, so a load issued above the first use of the words makes that use wait
-            // for both (s_waitcnt vmcnt(0)) -- round 3's form of this switch, whose load was hoisted to the loop's top, prefetched
-            // nothing.  An empty asm that "modifies" the words pins their wait; its memory clobber keeps the next load below it.
-            uint32_t cw[S::LPADW], ctw[S::TWN];
-#pragma unroll
-            for (int q = 0; q < S::LPADW; q++) { cw[q] = nwords[q]; asm volatile("" : "+v"(cw[q]) : : "memory"); }
-#pragma unroll
-            for (int q = 0; q < S::TWN; q++) { ctw[q] = ntw[q]; asm volatile("" : "+v"(ctw[q]) : : "memory"); }
-            const uint32_t coln = col + 256;
-            S::load_words(res_sorted + (size_t)coln * lpad_s, bt + 1 < n_batches && coln < col_end, lbs, nwords, ntw);
-            S::offsets_of(cw, ctw, tab_addr, tab_addr, off, toff);
-        } else {
-            S::offsets(res_sorted + (size_t)col * lpad_s, col < col_end, lbs, tab_addr, tab_addr, off, toff);
-        }
+        S::offsets(res_sorted + (size_t)col * lpad_s, col < col_end, lbs, tab_addr, tab_addr, off, toff);
         const bool look = !DEFER || (bt & 3u) == 3u || bt + 1 == n_batches;   // wave-uniform
 
         auto one_group = [&](auto gt) {
@@ -889,20 +730,16 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
                 acc[g] = 0;
                 if (__ballot(hm != 0) == 0) return;
             }
-            // (the flush sits OUTSIDE the append loop: it scores whole columns again and needs most of the register file; inside the
-            // loop the compiler kept the loop's state in scratch memory for every turn of it)
+            // (the flush sits OUTSIDE the append loop: the rescoring kind needs most of the register file; inside the loop the
+            // compiler kept the loop's state in scratch memory for every turn of it)
             for (;;) {
                 bool full = false;
                 for (;;) {
                     const bool any = hm != 0;
                     const uint64_t mask = __ballot(any);
                     if (mask == 0) break;
-                    if (cnt > (uint32_t)(STAGE_CAP - 64)) { full = true; break; }   // keep room for one wave of hits
+                    if (cnt + cnt_hi > (uint32_t)(STAGE_CAP - 64)) { full = true; break; }   // keep room for one wave of hits
                     if (any) {
-                        // the record: this step's column | the hit's bit << 16 | group << 21.  Which row and which of the quad's
-                        // steps the bit stands for is worked out by the flush (rows_record_decode), where all 64 lanes have a
-                        // record: here a turn runs for the few lanes that still have a hit, and every instruction of it costs the
-                        // wave a VALU slot (17 per turn with the decoding, 8 without)
                         const uint32_t q = (uint32_t)__builtin_ctz(hm);
                         if constexpr (INLOOP) {
                             // the hit's row r (bit 8r + 7: row r; bit 8r + 3: row 4 + r) is byte r of every plane's register pair:
@@ -914,85 +751,39 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
 #pragma unroll
                             for (int u = 1; u < ND; u++) mx = max(mx, __builtin_amdgcn_perm(W1[u], W0[u], sel));
                             stage[cnt + mbcnt64(mask)] = colrel | ((uint32_t)(8 * g) + r) << 16 | (mx - 128u) << 24;
-                        } else if constexpr (FAT) {
-                            // the hit was noted `back` steps ago: ITS column and ITS words (this step's place in the quad is Q, so
-                            // the history holds steps Q, Q - 1, ... 0 only: the wave looked last at the end of the quad before)
-                            const uint32_t back = 3u - (q & 3u);
-                            u32x4 rec;
-                            rec.x = ((colrel - back * 256u) | (uint32_t)g << 21) | q << 16;
-                            // (every candidate goes through an empty asm first: a select between two loads of the word history
-                            // is turned into ONE load at a selected address, and the history then lives in scratch memory --
-                            // 12 bytes per lane and step stored, 7.5 GB per pass)
-                            auto pick = [&](int k) -> uint32_t {
-                                if (k >= NWF) return 0u;
-                                uint32_t wk = Wh[Q][k < NWF ? k : 0];
-                                asm("" : "+v"(wk));
-                                rows_static_for<Q>([&](auto bt_) {
-                                    constexpr int B = decltype(bt_)::value + 1;
-                                    uint32_t cand = Wh[Q - B][k < NWF ? k : 0];
-                                    asm("" : "+v"(cand));
-                                    wk = back == (uint32_t)B ? cand : wk;
-                                });
-                                return wk;
-                            };
-                            rec.y = pick(0); rec.z = pick(1); rec.w = pick(2);
-                            reinterpret_cast<HMK_LDS u32x4 *>(stage)[cnt + mbcnt64(mask)] = rec;
                         } else {
-                            stage[cnt + mbcnt64(mask)] = (colrel | (uint32_t)g << 21) | q << 16;
+                            // the record: this step's column | the hit's bit << 16 | group << 21.  Which row and which of the quad's
+                            // steps the bit stands for is worked out by the flush, where all 64 lanes have a record: here a turn
+                            // runs for the few lanes that still have a hit, and every instruction of it costs the wave a VALU slot
+                            const uint32_t rec = (colrel | (uint32_t)g << 21) | q << 16;
+                            if constexpr (TWO && g == 1) stage[(uint32_t)(STAGE_CAP - 1) - (cnt_hi + mbcnt64(mask))] = rec;
+                            else stage[cnt + mbcnt64(mask)] = rec;
                         }
                         hm &= hm - 1u;   // clear the lowest set bit
                     }
-                    cnt += (uint32_t)__popcll(mask);
+                    if constexpr (TWO && g == 1) cnt_hi += (uint32_t)__popcll(mask);
+                    else cnt += (uint32_t)__popcll(mask);
                 }
                 if (!full) break;
-                flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, tab_addr, ka_lo, ka_hi);
+                flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, cnt_hi, tab_addr, ka_lo, ka_hi);
                 cnt = 0;
+                cnt_hi = 0;
             }
         };
         rows_for_each_group(std::make_integer_sequence<int, G>{}, one_group);
-    };
-    if constexpr (FAT) {   // (the loop unrolled by four: every step knows its place in the quad at compile time)
-        for (uint32_t bq = 0; bq < n_batches; bq += 4) {
-            step(bq, std::integral_constant<int, 0>{});
-            if (bq + 1 < n_batches) step(bq + 1, std::integral_constant<int, 1>{});
-            if (bq + 2 < n_batches) step(bq + 2, std::integral_constant<int, 2>{});
-            if (bq + 3 < n_batches) step(bq + 3, std::integral_constant<int, 3>{});
-        }
-    } else {
-        for (uint32_t bt = 0; bt < n_batches; bt++) step(bt, std::integral_constant<int, 0>{});
     }
-    flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, tab_addr, ka_lo, ka_hi);
-    band_tile_done(P, T);
+    flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, cnt_hi, tab_addr, ka_lo, ka_hi);
 }
 
 
 // -----------------------------------------------------------------------------
 // shapes, parts and launchers
 // -----------------------------------------------------------------------------
-#ifndef HMK_ROWS_G          // capacity form (mixed lengths: a length bucket's short column runs; 1 / 2 / 3 / 4 groups: 4.87 / 4.48 / 4.58 /
-#define HMK_ROWS_G 2        // 4.74 ms on BASELINE config 4a)
-#endif
-#ifndef HMK_ROWS_G_EXACT    // one length for all: long column runs, the tile's dead time is small either way (2.65-2.67 ms with 1 or 2)
-#define HMK_ROWS_G_EXACT 1
-#endif
-// groups of 8 rows per tile: HMK_ROWS_G, or as many as the sub-slots of a slot hold
-constexpr int rows_groups(int x, int d, int cap, bool exact) {
-    const int nd = 2 * x + d + 1, sub = (cap + d + nd - 1) / nd + (exact ? 0 : 1);
-    const int fit = HMK_ROWS_COMPACT ? 8 : rows_slot_bytes() / 192 / sub;
-    // (short one-length shapes -- 7-mers add 29 cells per pair -- take two groups per tile: what a step does once per column,
-    // fetch and offsets, is a quarter of its VALU work there, and VALU is as busy as the LDS pipe: 1.17 -> 1.12 ms without hits)
-    const int cells = cap * (2 * x + 1) - x * (x + 1);
-    const int want = exact ? (HMK_ROWS_G_EXACT == 1 && cells <= 36 ? 2 : HMK_ROWS_G_EXACT) : HMK_ROWS_G;
-    return fit < 1 ? 0 : fit < want ? fit : want;
-}
-
 template <int X, int D, int CAP, bool EXACT_LB>
 static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
     constexpr int G = rows_groups(X, D, CAP, EXACT_LB);
-    // the flush's mode is a template parameter: with the run-time form the placing branch's registers spill in every mode
-    if (P.rank)
-        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_PLACE>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
-    else if (P.deg)
+    // the flush's mode is a template parameter: with the run-time form the counting branch's registers spill in every mode
+    if (P.deg)
         hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_COUNT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
     else
         hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_PLAIN>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
@@ -1004,10 +795,6 @@ static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uin
 // capacity form, column length <= CAP at run time, rows D longer (mixed lengths; also what a uniform set with another -x
 // runs: D = 0).  `part` is the translation unit that holds the shape (k_rows_part.hip is compiled once per part, each a code
 // object of its own: a pass loads only the parts it launches from).
-#ifdef HMK_ROWS_MINIMAL   // tuning builds (tools/ab_rows.sh): the shapes the probes time only, seconds to compile
-#define HMK_ROWS_EXACT_LIST(F) F(0, 3, 10) F(0, 3, 12) F(3, 2, 7) F(3, 2, 8) F(3, 2, 9) F(4, 4, 15) F(6, 5, 20)
-#define HMK_ROWS_CAP_LIST(C) C(1, 3, 0, 12)
-#else
 #define HMK_ROWS_EXACT_LIST(F) \
     F(0, 3, 10) F(0, 3, 11) F(0, 3, 12) F(0, 3, 13) \
     F(3, 2, 6) F(3, 2, 7) F(3, 2, 8) F(3, 2, 9) \
@@ -1028,7 +815,6 @@ static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uin
     C(6, 5, 0, 12) C(6, 5, 1, 12) C(6, 5, 2, 12) \
     C(6, 5, 0, 16) C(6, 5, 1, 16) C(6, 5, 2, 16) C(6, 5, 3, 16) C(6, 5, 4, 16) \
     C(6, 5, 0, 20) C(6, 5, 1, 20) C(6, 5, 2, 20) C(6, 5, 3, 20) C(6, 5, 4, 20)
-#endif
 
 // one launcher per part (k_rows_part.hip, -DHMK_ROWS_PART=p); hipErrorInvalidValue: no such shape in that part
 #define HMK_ROWS_PART_DECL(p) \

@@ -323,14 +323,9 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
                             "column of multi-member clusters is NA)");
         logger.logAndStderr("Ready. Total time: " + std::to_string(ms()));                     // :427
         logger.logAndStderr("Saving results to output files...");
-        if (std::getenv("HMK_CLI_SERIAL_WRITERS")) {   // the reference's three calls in a row
-            FileIOManager::saveClusterSequencesToCsv(clusters, initialClustersSequencesCsv, labels);                              // :429
-            FileIOManager::saveClusterSequencesToCsvOrdered(clusters, initialClustersSequencesOrderedCsv, labels, initialSequences);  // :431
-            FileIOManager::SaveClustersToCsv(clusters, initialClusters, labels);                                                  // :432
-        } else {                                       // the same three files written side by side
-            FileIOManager::saveInitialClusters(clusters, initialClustersSequencesCsv, initialClustersSequencesOrderedCsv, initialClusters,
-                                               labels, initialSequences);
-        }
+        // the reference's three calls in a row (:429, :431, :432), written side by side
+        FileIOManager::saveInitialClusters(clusters, initialClustersSequencesCsv, initialClustersSequencesOrderedCsv, initialClusters,
+                                           labels, initialSequences);
         cliLap("result files written");
         logger.logAndStderr(std::string(clinkage ? "Clinkage" : "Greedy") + " clustering results in: " + initialClusters);
         logger.logAndStderr("and: " + initialClustersSequencesCsv);
@@ -338,16 +333,14 @@ int runSequenceClustering(const std::vector<std::string> &args, bool clinkage) {
         logger.logWithTime("Program successfully ended.");
         // Everything is on disk (the writers and the logger close their files).  Tearing down 10^6 sequence and cluster
         // objects one by one and handing 36 GB of device buffers back costs 0.3-0.5 s that change nothing: leave at once,
-        // the driver reclaims the device memory with the process.  (HMK_CLI_TEARDOWN=1: the ordinary way out.  Handing the
+        // the driver reclaims the device memory with the process.  (Handing the
         // context back on another thread while the files are written was measured too: the writers lose 0.1 s to it and the
         // process still needs 0.17 s to go, 1.42-1.51 s against 1.17-1.45 s.)
         cliLap("log closed, leaving");
-        if (std::getenv("HMK_CLI_TEARDOWN") == nullptr) {
-            std::cout.flush();
-            std::cerr.flush();
-            std::fflush(nullptr);
-            std::_Exit(0);
-        }
+        std::cout.flush();
+        std::cerr.flush();
+        std::fflush(nullptr);
+        std::_Exit(0);
         return 0;
     } catch (const CLIException &) {
         throw;
@@ -474,11 +467,7 @@ int apiSelftest(const std::vector<std::string> &args) {
 int main(int argc, char **argv) {
     // 10^6 sequences are 4 x 10^6 small allocations made on 16 threads: glibc grows a thread's arena by `top_pad` (128 KB) per
     // mprotect call, and every such call stops the page faults of all other threads; larger steps, fewer calls
-    {
-        const char *v = std::getenv("HMK_CLI_TOP_PAD_MB");
-        const int mb = v ? std::atoi(v) : 64;
-        if (mb > 0) mallopt(M_TOP_PAD, mb << 20);
-    }
+    mallopt(M_TOP_PAD, 64 << 20);
     std::vector<std::string> args(argv + 1, argv + argc);
     if (args.empty() || args[0] == "--help" || args[0] == "-h") { printHelp(); return args.empty() ? 2 : 0; }
     try {

@@ -50,7 +50,6 @@ namespace hammock {
 
 // how many threads the host-side helpers below may use (parsing, object construction, formatting)
 inline unsigned hostThreads() {
-    if (const char *v = std::getenv("HMK_HOST_THREADS")) return (unsigned)std::max(1, std::atoi(v));
     const unsigned hw = std::thread::hardware_concurrency();
     return std::max(1u, std::min(16u, hw ? hw : 1u));
 }

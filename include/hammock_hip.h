@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HMK_ABI_VERSION 3
+#define HMK_ABI_VERSION 4
 #define HMK_ALPHABET 24
 #define HMK_MAX_LEN 32          /* longest sequence the GPU kernels accept */
 #define HMK_MAX_SEQUENCES (1u << 24)
@@ -300,13 +300,14 @@ typedef struct {
     double wait_rows_ms;     /* host waiting for adjacency rows (band hand-over, later fetches) */
     double phase1_ms;        /* firstPhase, LimitedGreedySequenceClusterer.java:77-120 (includes wait_rows_ms) */
     double precheck_ms;      /* device pre-check of the second loop (:59-66) incl. copies */
-    double prop_ms;          /* device join-propagation lists incl. copies (medium inputs) */
+    double exchange_ms;      /* multi-device calls: routing the edges to the devices that own their rows, until the last block has landed */
     double device_loop_ms;   /* the second loop on the device in optimistic rounds (large inputs), incl. copies */
-    double host_precheck_ms; /* host-side part between phase 1 and the sequential loop (includes the two above) */
+    double host_precheck_ms; /* host wall time between the end of phase 1 and the sequential part: the wait for the full CSR, the
+                              * pre-check and the device-side loop (includes precheck_ms and device_loop_ms) */
     double sequential_ms;    /* the order-dependent loop :59-66 itself */
     double total_ms;
     uint64_t cand_entries;   /* (leftover, feasible cluster) pairs after phase 1 */
-    uint64_t prop_entries;   /* entries of the join-propagation lists */
+    uint64_t band_bytes;     /* bytes of the band, as prepared for phase 1, that crossed PCIe (0: the band went as whole rows, or not at all) */
     uint64_t loop_rounds;    /* rounds of the device-side second loop, 0 if the loop ran on the host */
 } hmk_greedy_phases;
 int hmk_greedy_last_phases(const hmk_ctx *ctx, hmk_greedy_phases *out);

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(N.SYMBOLS)
     for name in declared:
         assert hasattr(N.lib, name), name
-    assert N.lib.hmk_abi_version() == 3
+    assert N.lib.hmk_abi_version() == 4
 
 
 def test_no_gpu_fails_loudly(blosum62):
@@ -165,6 +165,42 @@ def test_greedy_phase1_window_scans_match_oracle(blosum62, coracle, monkeypatch,
     peps = [peps[k] for k in perm]
     cid = run_both(coracle, blosum62, peps, None if sizes is None else sizes[perm], 3, 0, [30, 26, 24][seed], [400, 500, 700][seed])
     assert cid is not None
+
+
+@pytest.mark.parametrize("band", ["40,1", "150,2", "400,8", "100000,3"])
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_greedy_phase1_on_the_prepared_band_matches_oracle(blosum62, coracle, monkeypatch, seed, band):
+    """Phase 1 on a PREPARED band (BandPack, hmk_internal.h: near rows, the rows' best far candidates, transposed lists of the
+    first two) keeps the feasible clusters of every later band row incrementally instead of recounting whole rows.
+    HMK_PHASE1_HOST_BAND=rows,far_t builds the band on the host from the whole graph -- the literal statement of what the
+    device's k_band_* kernels produce -- so the loop can be checked on the CPU against the oracle's sequential loop: bands that
+    end before, inside and after phase 1 (the whole-row loop takes over at the band's last row), far lists of 1-3 candidates
+    (absorbed candidates force the on-demand fetches), counts (size order and size tie-breaks), dense low-complexity inputs."""
+    monkeypatch.setenv("HMK_PHASE1_HOST_BAND", band)
+    rng = np.random.default_rng(5000 + seed)
+    n = [700, 1200, 1800, 2500][seed]
+    peps = random_peptides(rng, n, 12, 12, alphabet=[3, 4, 5, 6][seed])
+    sizes = rng.integers(1, 4, size=len(peps)).astype(np.int32) if seed != 1 else None
+    res, off = coracle.pack(peps)
+    perm = coracle.sort_order(res, off, sizes, "size" if seed % 2 == 0 else "alphabetic")
+    peps = [peps[k] for k in perm]
+    cid = run_both(coracle, blosum62, peps, None if sizes is None else sizes[perm], 3, 0, [30, 26, 24, 22][seed], [300, 500, 700, 60][seed])
+    assert cid is not None
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_greedy_phase1_on_the_prepared_band_small_inputs(blosum62, coracle, monkeypatch, seed):
+    """The same on many small inputs, crash-parity outcomes included (the three NullPointerExceptions of
+    LimitedGreedySequenceClusterer.java:97/104/108 must come out of the incremental loop with the oracle's case and index)."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(2, 220))
+    monkeypatch.setenv("HMK_PHASE1_HOST_BAND", f"{int(rng.integers(1, n + 5))},{int(rng.integers(1, 5))}")
+    peps = random_peptides(rng, n, 9 if seed % 2 else 12, 12, alphabet=3 + seed % 4)
+    sizes = rng.integers(1, 5, size=len(peps)).astype(np.int32) if seed % 3 else None
+    res, off = coracle.pack(peps)
+    perm = coracle.sort_order(res, off, sizes, ["size", "alphabetic", "input"][seed % 3])
+    peps = [peps[k] for k in perm]
+    run_both(coracle, blosum62, peps, None if sizes is None else sizes[perm], 2 + seed % 2, -(seed % 2), 14 + seed % 12, int(rng.integers(1, 40)))
 
 
 # --------------------------------------------------------------------------------------
