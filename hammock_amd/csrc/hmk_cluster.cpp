@@ -108,18 +108,20 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             HIPCHK(ctx, ensure_buf(ctx, SB_BNSTART, ((size_t)R1 + 1) * 4));
             HIPCHK(ctx, ensure_buf(ctx, SB_BFTOP, (size_t)R1 * FAR_T * 4));
             HIPCHK(ctx, ensure_buf(ctx, SB_BFMORE, (size_t)R1 + 64));
-            HIPCHK(ctx, ensure_buf(ctx, SB_FDEG, (size_t)n * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_FSTART, ((size_t)n + 1) * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_FCUR, (size_t)n * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_FOWNER, (size_t)n * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_FDEG, (size_t)n * 12 + 64));   // fdeg | fcur | owner_of (one fill), then the two totals
+            HIPCHK(ctx, ensure_buf(ctx, SB_FSTART, (size_t)n * 4));
             HIPCHK(ctx, ensure_buf(ctx, SB_TRCNT, (size_t)R1 * BandPack::TR_PER_ROW * 4));
             HIPCHK(ctx, ensure_buf(ctx, SB_TRSTART, ((size_t)R1 * BandPack::TR_PER_ROW + 1) * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_TROWNER, (size_t)R1 * BandPack::TR_PER_ROW * 4));
             if (ctx->has_sizes) HIPCHK(ctx, ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4));
         }
-        HIPCHK(ctx, hipStreamWaitEvent(C, ctx->ev_band, 0));
+        // (the fills first: they run beside the band launch, whose end the rest waits for)
         HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BDEG), 0, (size_t)R1 * 4, C));
         HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_BCURSOR), 0, (size_t)R1 * 8, C));
+        if (prepared) {
+            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_FDEG), 0, (size_t)n * 12 + 16, C));   // (+ the totals and the list allocator's counter)
+            if (ctx->has_sizes) HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, C));
+        }
+        HIPCHK(ctx, hipStreamWaitEvent(C, ctx->ev_band, 0));
         HIPCHK(ctx, launch_csr_degree_scan(src.band_segs, n, R1, symmetric, buf<uint32_t>(ctx, SB_BDEG), buf<uint64_t>(ctx, SB_BSTART),
                                            buf<uint64_t>(ctx, SB_BSCAN), buf<int>(ctx, SB_BRANGE), C));
         HIPCHK(ctx, hipMemcpyAsync(h_start, buf<uint64_t>(ctx, SB_BSTART), ((size_t)R1 + 1) * 8, hipMemcpyDeviceToHost, C));
@@ -127,12 +129,6 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         // (the band's own segments only: beside a pass that runs at the same time the other cursors are in motion)
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_counts + HC_BAND, src.band_segs.s[0].count,
                                    std::min<uint32_t>(src.band_segs.n, HMK_EDGE_SHARDS) * sizeof(unsigned long long), hipMemcpyDeviceToHost, C));
-        if (prepared) {   // (beside the degree pass: nothing below depends on the host)
-            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_FDEG), 0, (size_t)n * 4, C));
-            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_FCUR), 0, (size_t)n * 4, C));
-            HIPCHK(ctx, hipMemsetAsync(buf<void>(ctx, SB_FOWNER), 0, (size_t)n * 4, C));
-            if (ctx->has_sizes) HIPCHK(ctx, hipMemcpyAsync(buf<void>(ctx, SB_SEQSZ), ctx->sizes.data(), (size_t)n * 4, hipMemcpyHostToDevice, C));
-        }
         HIPCHK(ctx, hipEventRecord(ctx->ev_bandcsr, C));
         band_pending = true;
     }
@@ -213,56 +209,28 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             if (entries < 0) return nullptr;
             const uint32_t TRN = R1 * BandPack::TR_PER_ROW;
             const uint64_t cap = std::max<uint64_t>((uint64_t)entries, 1);   // no list is longer than the band has entries
-            hipError_t e = ensure_buf(ctx, SB_BNEAR, cap * 4);
-            if (e == hipSuccess) e = ensure_buf(ctx, SB_FADJ, cap * 4);
-            if (e == hipSuccess) e = ensure_buf(ctx, SB_TR, cap * 4);
-            const uint64_t *d_bstart = buf<uint64_t>(ctx, SB_BSTART);
-            const uint32_t *d_bup = buf<uint32_t>(ctx, SB_BCURSOR);
-            uint32_t *d_ncnt = buf<uint32_t>(ctx, SB_BNCNT), *d_nup = buf<uint32_t>(ctx, SB_BNUP), *d_nstart = buf<uint32_t>(ctx, SB_BNSTART);
-            uint32_t *d_ftop = buf<uint32_t>(ctx, SB_BFTOP), *d_fdeg = buf<uint32_t>(ctx, SB_FDEG), *d_fstart = buf<uint32_t>(ctx, SB_FSTART);
-            uint32_t *d_trcnt = buf<uint32_t>(ctx, SB_TRCNT), *d_trstart = buf<uint32_t>(ctx, SB_TRSTART), *d_trowner = buf<uint32_t>(ctx, SB_TROWNER);
-            uint64_t *d_scan = buf<uint64_t>(ctx, SB_BSCAN);
-            if (e == hipSuccess)
-                e = launch_band_split(d_bstart, d_bup, buf<void>(ctx, SB_BADJ), R1, FAR_T, ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr,
-                                      d_ncnt, d_nup, d_ftop, buf<uint8_t>(ctx, SB_BFMORE), d_fdeg, C);
-            if (e == hipSuccess) e = launch_scan_u32(d_ncnt, d_nstart, R1, d_scan, C);
-            if (e == hipSuccess) e = launch_scan_u32(d_fdeg, d_fstart, n, d_scan, C);
-            if (e == hipSuccess)
-                e = launch_band_fill(d_bstart, d_bup, buf<void>(ctx, SB_BADJ), R1, d_nstart, buf<uint32_t>(ctx, SB_BNEAR), d_fstart,
-                                     buf<uint32_t>(ctx, SB_FCUR), buf<uint32_t>(ctx, SB_FADJ), C);
-            if (e == hipSuccess) e = launch_band_tr_claim(d_ftop, R1, FAR_T, BandPack::TR_PER_ROW, d_fdeg, buf<uint32_t>(ctx, SB_FOWNER), d_trcnt, C);
-            if (e == hipSuccess) e = launch_scan_u32(d_trcnt, d_trstart, TRN, d_scan, C);
-            if (e == hipSuccess)
-                e = launch_band_tr_fill(d_ftop, R1, FAR_T, BandPack::TR_PER_ROW, buf<uint32_t>(ctx, SB_FOWNER), d_fstart, d_fdeg, buf<uint32_t>(ctx, SB_FADJ),
-                                        d_trstart, d_trowner, buf<uint32_t>(ctx, SB_TR), C);
-            // the small arrays first (they hold the two totals), then the entries: one pinned block
-            //   near_start [R1 + 1] | near_up [R1] | far_top [R1 x FAR_T] | tr_owner [TRN] | tr_start [TRN + 1] | far_more [R1, padded] | near | tr
+            hipError_t e = ensure_buf(ctx, SB_FADJ, cap * 4);
+            // the host's block (pinned; the kernels store into it themselves: no copy launches, no second round trip for sizes):
+            //   near_start [R1 + 1] | near_up [R1] | far_top [R1 x FAR_T] | tr_owner [TRN] | tr_start [TRN + 1] | far_more [R1, padded] | near [cap] | tr [cap]
             const size_t o_nstart = 0, o_nup = o_nstart + ((size_t)R1 + 1) * 4, o_ftop = o_nup + (size_t)R1 * 4, o_trowner = o_ftop + (size_t)R1 * FAR_T * 4,
-                         o_trstart = o_trowner + (size_t)TRN * 4, o_fmore = o_trstart + ((size_t)TRN + 1) * 4, o_near = (o_fmore + R1 + 63) / 64 * 64;
-            if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, o_near + 64, 0);
-            char *hb = (char *)ctx->h_adj;
-            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_nstart, d_nstart, ((size_t)R1 + 1) * 4, hipMemcpyDeviceToHost, C);
-            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_trstart, d_trstart, ((size_t)TRN + 1) * 4, hipMemcpyDeviceToHost, C);
-            if (e == hipSuccess) e = hipStreamSynchronize(C);
-            uint64_t n_near = 0, n_tr = 0;
-            if (e == hipSuccess) {
-                n_near = ((const uint32_t *)(hb + o_nstart))[R1];
-                n_tr = ((const uint32_t *)(hb + o_trstart))[TRN];
-                if (n_near > cap || n_tr > cap) { hook_fail(HMK_ERR_DEVICE, "band hand-over: list sizes beyond the band's entries"); return nullptr; }
-            }
-            const size_t o_tr = o_near + (n_near * 4 + 63) / 64 * 64;
-            if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, o_tr + n_tr * 4 + 64, o_near);
-            hb = (char *)ctx->h_adj;
-            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_nup, d_nup, (size_t)R1 * 4, hipMemcpyDeviceToHost, C);
-            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_ftop, d_ftop, (size_t)R1 * FAR_T * 4, hipMemcpyDeviceToHost, C);
-            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_trowner, d_trowner, (size_t)TRN * 4, hipMemcpyDeviceToHost, C);
-            if (e == hipSuccess) e = hipMemcpyAsync(hb + o_fmore, buf<void>(ctx, SB_BFMORE), R1, hipMemcpyDeviceToHost, C);
-            if (e == hipSuccess && n_near) e = hipMemcpyAsync(hb + o_near, buf<void>(ctx, SB_BNEAR), n_near * 4, hipMemcpyDeviceToHost, C);
-            if (e == hipSuccess && n_tr) e = hipMemcpyAsync(hb + o_tr, buf<void>(ctx, SB_TR), n_tr * 4, hipMemcpyDeviceToHost, C);
-            // (band_far reads a band row's upper section off the device: the rows' upper sizes are kept at hand)
-            if (e == hipSuccess) e = hipMemcpyAsync(h_up, d_bup, (size_t)R1 * 4, hipMemcpyDeviceToHost, C);
+                         o_trstart = o_trowner + (size_t)TRN * 4, o_fmore = o_trstart + ((size_t)TRN + 1) * 4, o_near = (o_fmore + R1 + 63) / 64 * 64,
+                         o_tr = o_near + (cap * 4 + 63) / 64 * 64;
+            if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, o_tr + cap * 4 + 64, 0);
+            char *hb = (char *)ctx->h_adj, *db = nullptr;
+            if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&db, hb, 0);
+            uint32_t *d_fdeg = buf<uint32_t>(ctx, SB_FDEG), *d_fcur = d_fdeg + n, *d_owner = d_fdeg + 2 * (size_t)n, *d_totals = d_fdeg + 3 * (size_t)n;
+            if (e == hipSuccess)
+                e = launch_band_prepare(buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BCURSOR), buf<void>(ctx, SB_BADJ), R1, (uint64_t)entries, n, FAR_T,
+                                        BandPack::TR_PER_ROW, ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_BNCNT),
+                                        buf<uint32_t>(ctx, SB_BNUP), buf<uint32_t>(ctx, SB_BNSTART), buf<uint32_t>(ctx, SB_BFTOP), buf<uint8_t>(ctx, SB_BFMORE),
+                                        d_fdeg, d_fcur, d_owner, d_totals, buf<uint32_t>(ctx, SB_FSTART), buf<uint32_t>(ctx, SB_FADJ),
+                                        buf<uint32_t>(ctx, SB_TRCNT), buf<uint32_t>(ctx, SB_TRSTART), (uint32_t *)(db + o_nstart), (uint32_t *)(db + o_nup),
+                                        (uint32_t *)(db + o_ftop), (uint8_t *)(db + o_fmore), (uint32_t *)(db + o_near), (uint32_t *)(db + o_trowner),
+                                        (uint32_t *)(db + o_trstart), (uint32_t *)(db + o_tr), C);
             if (e == hipSuccess) e = hipStreamSynchronize(C);
             if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return nullptr; }
+            const uint64_t n_near = ((const uint32_t *)(hb + o_nstart))[R1], n_tr = ((const uint32_t *)(hb + o_trstart))[TRN];
+            if (n_near > cap || n_tr > cap) { hook_fail(HMK_ERR_DEVICE, "band hand-over: list sizes beyond the band's entries"); return nullptr; }
             pack.rows = R1;
             pack.far_t = FAR_T;
             pack.near_start = (const uint32_t *)(hb + o_nstart);
@@ -273,37 +241,44 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             pack.tr_owner = (const uint32_t *)(hb + o_trowner);
             pack.tr_start = (const uint32_t *)(hb + o_trstart);
             pack.tr = (const uint32_t *)(hb + o_tr);
-            ph.band_bytes = (uint64_t)(o_tr + n_tr * 4);
+            ph.band_bytes = (uint64_t)(o_near + n_near * 4 + n_tr * 4);
             t_rows += ms_since(tw);
             lap("band prepared and on the host");
             return &pack;
         };
         // a far sequence's band neighbours / a band row's far part, straight from the device (rare: a candidate beyond the lists sent)
+        // (into PINNED memory: a copy into pageable memory issued while the pass runs took 8 ms -- 12 such fetches made phase 1 of
+        // the 10^6 call 200 ms longer)
         hooks.far_row = [&](uint32_t id, std::vector<uint32_t> &out) -> bool {
             out.clear();
-            uint32_t se[2] = {0, 0};
-            hipError_t e = hipMemcpyAsync(se, buf<uint32_t>(ctx, SB_FSTART) + id, 8, hipMemcpyDeviceToHost, C);
+            uint32_t *se = (uint32_t *)(ctx->h_counts + HC_MISC) + 10;   // pinned: the list's start and length
+            hipError_t e = hipMemcpyAsync(se, buf<uint32_t>(ctx, SB_FSTART) + id, 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipMemcpyAsync(se + 1, buf<uint32_t>(ctx, SB_FDEG) + id, 4, hipMemcpyDeviceToHost, C);
             if (e == hipSuccess) e = hipStreamSynchronize(C);
-            if (e == hipSuccess && se[1] > se[0]) {
-                out.resize(se[1] - se[0]);
-                e = hipMemcpyAsync(out.data(), buf<uint32_t>(ctx, SB_FADJ) + se[0], (size_t)(se[1] - se[0]) * 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess && se[1] > 0) {
+                const size_t len = se[1], from = se[0];
+                e = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, len * 4 + 64, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_stage, buf<uint32_t>(ctx, SB_FADJ) + from, len * 4, hipMemcpyDeviceToHost, C);
                 if (e == hipSuccess) e = hipStreamSynchronize(C);
+                if (e == hipSuccess) out.assign((const uint32_t *)ctx->h_stage, (const uint32_t *)ctx->h_stage + len);
             }
             if (e != hipSuccess) { hook_fail(HMK_ERR_DEVICE, std::string("band hand-over (a far sequence's list): ") + hipGetErrorString(e)); return false; }
             return true;
         };
         hooks.band_far = [&](uint32_t x, std::vector<uint32_t> &out) -> bool {
             out.clear();
-            const uint32_t up = h_up[x];
-            std::vector<uint32_t> row(up);
-            hipError_t e = hipSuccess;
+            uint32_t *h_one = (uint32_t *)(ctx->h_counts + HC_MISC) + 12;   // pinned: the row's upper-section size
+            hipError_t e = hipMemcpyAsync(h_one, buf<uint32_t>(ctx, SB_BCURSOR) + x, 4, hipMemcpyDeviceToHost, C);
+            if (e == hipSuccess) e = hipStreamSynchronize(C);
+            const uint32_t up = e == hipSuccess ? *h_one : 0u;
             if (up) {
-                e = hipMemcpyAsync(row.data(), buf<uint32_t>(ctx, SB_BADJ) + h_start[x], (size_t)up * 4, hipMemcpyDeviceToHost, C);
+                e = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, (size_t)up * 4 + 64, 0);
+                if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_stage, buf<uint32_t>(ctx, SB_BADJ) + h_start[x], (size_t)up * 4, hipMemcpyDeviceToHost, C);
                 if (e == hipSuccess) e = hipStreamSynchronize(C);
             }
             if (e != hipSuccess) { hook_fail(HMK_ERR_DEVICE, std::string("band hand-over (a row's far part): ") + hipGetErrorString(e)); return false; }
-            for (uint32_t ent : row)
-                if ((ent >> 8) >= R1) out.push_back(ent);
+            for (uint32_t q = 0; q < up; q++)
+                if ((((const uint32_t *)ctx->h_stage)[q] >> 8) >= R1) out.push_back(((const uint32_t *)ctx->h_stage)[q]);
             return true;
         };
     }

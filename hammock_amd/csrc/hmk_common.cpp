@@ -192,7 +192,11 @@ int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, boo
         if (r1) {   // the band's adjacency: device + pinned host copy (0.8 GB at 10^6: the pinned allocation alone took 0.1 s of a first call)
             const uint64_t entries = (uint64_t)r1 * avg_deg;
             HIPCHK(ctx, ensure_buf(ctx, SB_BADJ, std::max<uint64_t>(entries, 1) * esz0));
-            HIPCHK(ctx, ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(entries, 1) * esz0, 0));
+            // (the prepared band: transposed far part on the device; near rows + travelling lists in the host's pinned block)
+            HIPCHK(ctx, ensure_buf(ctx, SB_FADJ, std::max<uint64_t>(entries, 1) * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_FDEG, (size_t)n * 12 + 64));
+            HIPCHK(ctx, ensure_buf(ctx, SB_FSTART, (size_t)n * 4));
+            HIPCHK(ctx, ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(entries, 1) * 2 * esz0 + (size_t)r1 * 64 + 4096, 0));
         }
         const size_t ncl = (size_t)(n * 0.025 + 2), nl = n, cands = (size_t)n * 16;   // second loop on the device
         HIPCHK(ctx, ensure_buf(ctx, SB_USIZE, ncl * 4));

@@ -42,7 +42,7 @@ struct DevBuf { void *p = nullptr; size_t cap = 0; };
 enum {
     SB_DEG, SB_CURSOR, SB_START, SB_SCAN, SB_RANGE, SB_ADJ, SB_PART, SB_PARTSCR,   // full CSR (+ the bucketed lower sections)
     SB_BDEG, SB_BCURSOR, SB_BSTART, SB_BSCAN, SB_BRANGE, SB_BADJ, SB_BCOUNTS,     // band CSR (first rows only)
-    SB_BNCNT, SB_BNUP, SB_BNSTART, SB_BNEAR, SB_BFTOP, SB_BFMORE, SB_FDEG, SB_FSTART, SB_FCUR, SB_FADJ, SB_FOWNER, SB_TRCNT, SB_TRSTART, SB_TROWNER, SB_TR,   // the band prepared for phase 1 (BandPack)
+    SB_BNCNT, SB_BNUP, SB_BNSTART, SB_BFTOP, SB_BFMORE, SB_FDEG, SB_FSTART, SB_FADJ, SB_TRCNT, SB_TRSTART,   // the band prepared for phase 1 (BandPack)
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RETRY, SB_PRECNT, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop
     SB_PEER, SB_PEERCNT, SB_PEERBAND, SB_PEERDEG,                                                     // edge blocks gathered from other devices (root) / compacted for the root (peers)

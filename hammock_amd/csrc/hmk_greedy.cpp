@@ -385,13 +385,19 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         p1_rows += std::chrono::duration<double, std::milli>(p1_now() - tb0).count();
         if (bp && bp->rows > 0) {
             const uint32_t R1 = std::min<uint32_t>(bp->rows, n), FT = bp->far_t;
-            struct FeasEnt { int32_t c, mn, covered; };
-            std::vector<std::vector<FeasEnt>> feas(R1);
-            std::vector<std::vector<std::pair<uint32_t, uint32_t>>> fc;   // per cluster slot: (later band row, its entry's index in feas[row])
-            fc.reserve(slots_max);
-            std::vector<uint64_t> stamp(R1, 0);   // step << 32 | score(k, x) for the rows x of step k's leading near section
-            uint64_t step = 0;
+            // One pool of entries, two singly linked lists through each: the entries of a band row (walked at the row's turn) and the
+            // entries of a cluster (walked when a member joins; dead entries are unlinked on the way).  No allocation per row or cluster.
+            constexpr uint32_t NIL = 0xFFFFFFFFu;
+            struct FeasEnt { int32_t c, mn, covered; uint32_t x, next_row, next_cl; };
+            std::vector<FeasEnt> pool;
+            pool.reserve((size_t)R1 * 4);
+            std::vector<uint32_t> row_head(R1, NIL), cl_head;
+            cl_head.reserve(slots_max);
+            std::vector<uint32_t> stamp(R1, 0);   // (step & 0xFFFFFF) << 8 | score(k, x) - base for the rows x of step k's leading near section
+            uint32_t step = 0;                    // (steps <= rows of the band < 2^24)
             std::vector<uint32_t> fetched;
+            uint64_t n_far_row = 0, n_band_far = 0;   // on-demand fetches (timing output)
+            double t_fetch = 0;
             auto consider = [&](Found &B, uint32_t m, int32_t s) {   // NearestClusterRunner's order over singletons (scan_row above)
                 if (B.kind == NEAR_NULL || s > B.score ||
                     (s == B.score && better(s, seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot)))
@@ -405,10 +411,12 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                 Found A{NEAR_NULL, -1, 0};                      // :92
                 if (clusters.empty()) A = Found{NEAR_DUMMY, -1, INT_MIN};   // :138-140
                 else
-                    for (const FeasEnt &f : feas[k])
+                    for (uint32_t e = row_head[k]; e != NIL; e = pool[e].next_row) {
+                        const FeasEnt &f = pool[e];
                         if (f.covered == clusters[f.c].usize &&
                             (A.kind == NEAR_NULL || better(f.mn, clusters[f.c].size, clusters[f.c].id, A.score, clusters[A.slot].size, clusters[A.slot].id)))
                             A = Found{NEAR_REAL, f.c, f.mn};
+                    }
                 Found B{NEAR_NULL, -1, 0};                      // :93
                 const uint32_t *ft = bp->far_top + (size_t)k * FT;
                 if (remaining - 1 == 0) B = Found{NEAR_DUMMY, -1, INT_MIN};
@@ -422,7 +430,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     for (; t < FT && ft[t] != ~0u; t++)
                         if (state[ft[t] >> 8] == ST_FREE) { consider(B, ft[t] >> 8, (int32_t)(ft[t] & 0xFFu)); far_found = true; break; }
                     if (!far_found && t == FT && bp->far_more[k]) {   // every listed candidate has been absorbed and the row has more: ask for them
+                        const auto tf = p1_now();
                         if (!hooks->band_far || !hooks->band_far(k, fetched)) return HMK_INTERNAL_ROWS_FAILED;
+                        n_band_far++;
+                        t_fetch += std::chrono::duration<double, std::milli>(p1_now() - tf).count();
                         for (uint32_t e : fetched)
                             if (state[e >> 8] == ST_FREE) consider(B, e >> 8, (int32_t)(e & 0xFFu));
                     }
@@ -447,23 +458,20 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     orphans.push_back(k);
                 }
                 if (absorb || joined >= 0)
-                    for (uint32_t q = 0; q < n_up; q++) stamp[row[q] >> 8] = step << 32 | (row[q] & 0xFFu);
+                    for (uint32_t q = 0; q < n_up; q++) stamp[row[q] >> 8] = step << 8 | (row[q] & 0xFFu);
                 if (joined >= 0) {
                     const int32_t before = clusters[joined].usize;
                     insert_into(joined, k);
-                    std::vector<std::pair<uint32_t, uint32_t>> &lst = fc[joined];
-                    size_t w = 0;
-                    for (const std::pair<uint32_t, uint32_t> &pr : lst) {
-                        if (pr.first <= k) continue;                            // its turn is over
-                        FeasEnt &f = feas[pr.first][pr.second];
-                        if (f.covered != before) continue;                      // lost earlier, for good
-                        const uint64_t sw = stamp[pr.first];
-                        if ((sw >> 32) != step) continue;                       // k is not its neighbour: lost now
+                    uint32_t *link = &cl_head[joined];
+                    for (uint32_t e = *link; e != NIL; e = *link) {
+                        FeasEnt &f = pool[e];
+                        const uint32_t sw = stamp[f.x];
+                        // its turn is over / lost earlier, for good / k is not its neighbour (lost now): out of the cluster's list
+                        if (f.x <= k || f.covered != before || (sw >> 8) != step) { *link = f.next_cl; continue; }
                         f.covered++;
-                        f.mn = std::min(f.mn, (int32_t)(uint32_t)sw);
-                        lst[w++] = pr;
+                        f.mn = std::min(f.mn, (int32_t)(sw & 0xFFu));
+                        link = &f.next_cl;
                     }
-                    lst.resize(w);
                 } else if (absorb) {
                     const int32_t c = (int32_t)clusters.size();
                     clusters.push_back(ClusterRec{(int32_t)k, 1, seq_size(k)});
@@ -471,7 +479,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     state[k] = ST_IN_CLUSTER;
                     insert_into(c, (uint32_t)B.slot);
                     remaining--;  // initialList.remove(B)
-                    fc.emplace_back();
+                    cl_head.push_back(NIL);
                     // the band rows that have B as a neighbour
                     const uint32_t b = (uint32_t)B.slot;
                     const uint32_t *bl = nullptr;
@@ -485,7 +493,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                                 bn = bp->tr_start[u + 1] - bp->tr_start[u];
                             }
                         if (!bl) {
+                            const auto tf = p1_now();
                             if (!hooks->far_row || !hooks->far_row(b, fetched)) return HMK_INTERNAL_ROWS_FAILED;
+                            n_far_row++;
+                            t_fetch += std::chrono::duration<double, std::milli>(p1_now() - tf).count();
                             bl = fetched.data();
                             bn = (uint32_t)fetched.size();
                         }
@@ -493,10 +504,12 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     for (uint32_t q = 0; q < bn; q++) {
                         const uint32_t x = bl[q] >> 8;
                         if (x <= k || x >= R1 || state[x] != ST_FREE) continue;
-                        const uint64_t sw = stamp[x];
-                        if ((sw >> 32) != step) continue;               // k is not a neighbour of x: {k, B} is never feasible for it
-                        feas[x].push_back(FeasEnt{c, std::min((int32_t)(uint32_t)sw, (int32_t)(bl[q] & 0xFFu)), 2});
-                        fc[c].emplace_back(x, (uint32_t)feas[x].size() - 1);
+                        const uint32_t sw = stamp[x];
+                        if ((sw >> 8) != step) continue;                // k is not a neighbour of x: {k, B} is never feasible for it
+                        const uint32_t e = (uint32_t)pool.size();
+                        pool.push_back(FeasEnt{c, std::min((int32_t)(sw & 0xFFu), (int32_t)(bl[q] & 0xFFu)), 2, x, row_head[x], cl_head[c]});
+                        row_head[x] = e;
+                        cl_head[c] = e;
                     }
                 }
                 remaining--;
@@ -505,8 +518,10 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             }
             rows_lo = rows_here = k < R1 ? 0 : R1;   // (the loop below takes over at row R1, if at all)
             if (p1_timing)
-                fprintf(stderr, "[hmk greedy] phase 1 on the prepared band: %.2f ms for %llu steps (%.2f ms of it waiting for the band), stopped at row %u of %u\n",
-                        std::chrono::duration<double, std::milli>(p1_now() - tb0).count(), (unsigned long long)step, p1_rows, k, R1);
+                fprintf(stderr, "[hmk greedy] phase 1 on the prepared band: %.2f ms for %llu steps (%.2f ms of it waiting for the band; %llu far lists and %llu rows' far parts "
+                                "fetched on demand in %.2f ms), stopped at row %u of %u\n",
+                        std::chrono::duration<double, std::milli>(p1_now() - tb0).count(), (unsigned long long)step, p1_rows, (unsigned long long)n_far_row,
+                        (unsigned long long)n_band_far, t_fetch, k, R1);
         }
     }
     while (k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters) {

@@ -110,7 +110,8 @@ using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::
 //               v = tr_owner[u], tr[tr_start[v] .. tr_start[v + 1]).  Any other far sequence's list comes through
 //               GreedyHooks::far_row.
 struct BandPack {
-    static constexpr uint32_t TR_PER_ROW = 2;
+    static constexpr uint32_t TR_PER_ROW = 4;   // (2: a dozen lists per 25,000 steps had to be fetched on demand at 10^6 -- and a small copy issued while
+                                                // the pass runs waits milliseconds for a slot)
     uint32_t rows = 0, far_t = 0;
     const uint32_t *near_start = nullptr, *near_up = nullptr, *near = nullptr;
     const uint32_t *far_top = nullptr;

@@ -50,7 +50,7 @@ hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile
 EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t first = 0,
                         uint32_t count = HMK_EDGE_SHARDS);
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
-                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s);
+                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s, uint32_t row_lo = 0);
 hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uint64_t *start, uint32_t n, uint64_t *tile_scratch,
                                 int *score_range, hipStream_t s);
 hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, uint32_t n, hipStream_t s);   // dst[k] += src[k]
@@ -59,20 +59,20 @@ size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scrat
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)
 size_t csr_partition_scratch_bytes();
 hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *start, uint32_t *cursor, void *adj, int base, uint32_t n,
-                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, int forced_shift, hipStream_t s);
+                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, int forced_shift, hipStream_t s,
+                                          uint32_t row_lo = 0, uint32_t row_hi = 0xFFFFFFFFu);   // rows [row_lo, row_hi) only: what a device of a multi-device call owns
 hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
-                              bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n = 0);
+                              bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n = 0, uint32_t row_lo = 0);
 
 // the band, prepared for phase 1 (BandPack, hmk_internal.h; k_band_* in k_edges.hip).  bstart / bup / badj: the band's CSR (packed
-// entries, rows [upper | lower]); fdeg, fcur, owner_of: zeroed uint32[n]; every output array is sized by the caller.
-hipError_t launch_band_split(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, uint32_t ft, const int32_t *seq_size,
-                             uint32_t *near_cnt, uint32_t *near_up, uint32_t *far_top, uint8_t *far_more, uint32_t *fdeg, hipStream_t s);
-hipError_t launch_band_fill(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, const uint32_t *near_start, uint32_t *near,
-                            const uint32_t *fstart, uint32_t *fcur, uint32_t *fadj, hipStream_t s);
-hipError_t launch_band_tr_claim(const uint32_t *far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *fdeg, uint32_t *owner_of,
-                                uint32_t *tr_cnt, hipStream_t s);
-hipError_t launch_band_tr_fill(const uint32_t *far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *owner_of, const uint32_t *fstart,
-                               const uint32_t *fdeg, const uint32_t *fadj, const uint32_t *tr_start, uint32_t *tr_owner, uint32_t *tr, hipStream_t s);
+// entries, rows [upper | lower]); fdeg, fcur, owner_of: zeroed uint32[n]; totals: zeroed uint32[4] ([0] near entries, [1] entries of the
+// travelling lists); h_*: the HOST's pinned block by its device-visible addresses -- the kernels store the pack there themselves (near
+// and tr each hold at most `entries`); every other array is sized by the caller.
+hipError_t launch_band_prepare(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, uint64_t entries, uint32_t n, uint32_t ft,
+                               uint32_t tr_per_row, const int32_t *seq_size, uint32_t *near_cnt, uint32_t *near_up, uint32_t *near_start, uint32_t *far_top,
+                               uint8_t *far_more, uint32_t *fdeg, uint32_t *fcur, uint32_t *owner_of, uint32_t *totals, uint32_t *fstart, uint32_t *fadj,
+                               uint32_t *tr_cnt, uint32_t *tr_start, uint32_t *h_near_start, uint32_t *h_near_up, uint32_t *h_far_top, uint8_t *h_far_more,
+                               uint32_t *h_near, uint32_t *h_tr_owner, uint32_t *h_tr_start, uint32_t *h_tr, hipStream_t s);
 
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);

@@ -15,8 +15,9 @@ namespace hmk {
 // score_range[2]: edges that name a sequence outside [0, n) or a self pair (not counted; the caller gives up)
 __global__ void __launch_bounds__(256)
 k_edge_degree(const EdgeSegs segs, uint32_t *__restrict__ deg, int symmetric, int *__restrict__ score_range, uint32_t n,
-              uint32_t row_limit) {
-    // row_limit: only rows [0, row_limit) are counted (the "band" a first phase-1 hand-over needs); n otherwise
+              uint32_t row_lo, uint32_t row_limit) {
+    // only rows [row_lo, row_limit) are counted: [0, n) for the whole graph, [0, R) for the "band" a first phase-1 hand-over
+    // needs, the range of rows a device owns in a multi-device call (deg[] is indexed by the row itself)
     const EdgeSeg sg = segs.s[blockIdx.y];
     const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
     const uint64_t *seg = sg.edges;
@@ -33,9 +34,10 @@ k_edge_degree(const EdgeSegs segs, uint32_t *__restrict__ deg, int symmetric, in
         // symmetric: the edge is stored under both ends
         const uint32_t ea = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
         const uint32_t eb = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
-        const WaveGroup g = wave_groups(ea, valid && ea < row_limit);
-        if (valid && ea < row_limit && g.rank == 0) atomicAdd(&deg[ea], g.size);
-        if (valid && symmetric && eb < row_limit) atomicAdd(&deg[eb], 1u);
+        const bool va = valid && ea >= row_lo && ea < row_limit;
+        const WaveGroup g = wave_groups(ea, va);
+        if (va && g.rank == 0) atomicAdd(&deg[ea], g.size);
+        if (valid && symmetric && eb >= row_lo && eb < row_limit) atomicAdd(&deg[eb], 1u);
         if (valid) {
             const int sc = HMK_EDGE_SCORE(e);
             lo = min(lo, sc);
@@ -156,8 +158,8 @@ static void launch_scan(const uint32_t *deg, T *start, uint32_t n, uint64_t *til
 template <class NbrT>
 __global__ void __launch_bounds__(256)
 k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t *__restrict__ cursor, NbrT *__restrict__ adj,
-               int symmetric, int base, uint32_t row_limit) {
-    // cursor: uint32[2 * row_limit]; rows at and beyond row_limit are not stored
+               int symmetric, int base, uint32_t row_lo, uint32_t row_limit) {
+    // cursor: uint32[2 * row_limit]; only rows [row_lo, row_limit) are stored
     const EdgeSeg sg = segs.s[blockIdx.y];
     const uint64_t cnt = min((uint64_t)*sg.count, sg.cap);
     const uint64_t *seg = sg.edges;
@@ -168,13 +170,13 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t
         const uint32_t x = symmetric ? min(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_X(e);
         const uint32_t m = symmetric ? max(HMK_EDGE_X(e), HMK_EDGE_M(e)) : HMK_EDGE_M(e);
         const int32_t s = HMK_EDGE_SCORE(e);
-        const bool vx = valid && x < row_limit;
+        const bool vx = valid && x >= row_lo && x < row_limit;
         const WaveGroup g = wave_groups(x, vx);   // one atomic per distinct x of the wave
         uint32_t basex = 0;
         if (vx && g.rank == 0) basex = atomicAdd(&cursor[x], g.size);
         basex = (uint32_t)__shfl((int)basex, (int)g.leader, 64);
         if (!valid) continue;
-        const bool vm = symmetric && m < row_limit;
+        const bool vm = symmetric && m >= row_lo && m < row_limit;
         if constexpr (sizeof(NbrT) == 4) {
             const uint32_t rel = (uint32_t)(s - base) & 0xFFu;
             if (vx) adj[start[x] + basex + g.rank] = NbrT{(m << 8) | rel};
@@ -204,7 +206,7 @@ __device__ __forceinline__ bool lower_record_ok(uint64_t e, uint32_t n) {
 }
 
 __global__ void __launch_bounds__(1024)
-k_lower_count(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, unsigned long long *__restrict__ bucket_cnt) {
+k_lower_count(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, uint32_t row_lo, uint32_t row_hi, unsigned long long *__restrict__ bucket_cnt) {
     __shared__ uint32_t hist[LB_MAX_BUCKETS];
     for (uint32_t b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
     __syncthreads();
@@ -219,7 +221,10 @@ k_lower_count(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, unsi
             for (int q = 0; q < 4; q++) e[q] = k + q * stride < cnt ? sg.edges[k + q * stride] : ~0ull;
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (lower_record_ok(e[q], n)) atomicAdd(&hist[max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q])) >> shift], 1u);
+                if (lower_record_ok(e[q], n)) {
+                    const uint32_t m = max(HMK_EDGE_X(e[q]), HMK_EDGE_M(e[q]));
+                    if (m >= row_lo && m < row_hi) atomicAdd(&hist[m >> shift], 1u);
+                }
         }
     }
     __syncthreads();
@@ -277,7 +282,7 @@ k_lower_offsets(const unsigned long long *__restrict__ bucket_cnt, uint32_t nb, 
 // The same pass over the edges also writes the entries of the UPPER sections (row x = the smaller end) straight into the
 // adjacency, with k_edge_scatter's wave-grouped atomics -- one read of the edge list less (10 GB at 10^6).
 __global__ void __launch_bounds__(1024)
-k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, int base, const unsigned long long *__restrict__ bucket_off,
+k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, uint32_t row_lo, uint32_t row_hi, int base, const unsigned long long *__restrict__ bucket_off,
                   unsigned long long *__restrict__ bucket_fill, uint64_t *__restrict__ recs, const uint64_t *__restrict__ start,
                   uint32_t *__restrict__ cursor, NbrPacked *__restrict__ adj) {
     __shared__ uint32_t hist[LB_MAX_BUCKETS];
@@ -297,9 +302,13 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
             uint64_t ev[LB_LOADS];
 #pragma unroll
             for (int q = 0; q < LB_LOADS; q++) ev[q] = threadIdx.x + q * 1024 < len ? sg.edges[k0 + threadIdx.x + q * 1024] : ~0ull;
+            // (row_lo / row_hi: the rows this device owns -- a multi-device call builds every row's sections where the row lives;
+            // an end outside the range is some other device's entry)
+            auto lower_here = [&](uint64_t e) { const uint32_t m = max(HMK_EDGE_X(e), HMK_EDGE_M(e)); return lower_record_ok(e, n) && m >= row_lo && m < row_hi; };
+            auto upper_here = [&](uint64_t e) { const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)); return lower_record_ok(e, n) && x >= row_lo && x < row_hi; };
 #pragma unroll
             for (int q = 0; q < LB_LOADS; q++)
-                if (lower_record_ok(ev[q], n)) atomicAdd(&hist[max(HMK_EDGE_X(ev[q]), HMK_EDGE_M(ev[q])) >> shift], 1u);
+                if (lower_here(ev[q])) atomicAdd(&hist[max(HMK_EDGE_X(ev[q]), HMK_EDGE_M(ev[q])) >> shift], 1u);
             __syncthreads();
             for (uint32_t b = threadIdx.x; b < nb; b += 1024) {
                 const uint32_t h = hist[b];
@@ -320,7 +329,7 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
 #pragma unroll
                     for (int u = 0; u < LB_WB; u++) {
                         const uint64_t e = ev[q0 + u];
-                        const bool ok = lower_record_ok(e, n);
+                        const bool ok = upper_here(e);
                         const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e));
                         const WaveGroup g = wave_groups(x, ok);   // one atomic per distinct x of the wave
                         basex[u] = 0;
@@ -331,7 +340,7 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
 #pragma unroll
                     for (int u = 0; u < LB_WB; u++) {
                         const uint64_t e = ev[q0 + u];
-                        const bool ok = lower_record_ok(e, n);
+                        const bool ok = upper_here(e);
                         const uint32_t m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
                         const uint32_t rel = (uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu;
                         const uint32_t bx = (uint32_t)__shfl((int)basex[u], (int)(lr[u] & 0xFFu), 64);
@@ -341,7 +350,7 @@ k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, 
 #pragma unroll
                 for (int u = 0; u < LB_WB; u++) {
                     const uint64_t e = ev[q0 + u];
-                    if (!lower_record_ok(e, n)) continue;
+                    if (!lower_here(e)) continue;
                     const uint32_t x = min(HMK_EDGE_X(e), HMK_EDGE_M(e)), m = max(HMK_EDGE_X(e), HMK_EDGE_M(e));
                     const uint32_t rel = (uint32_t)(HMK_EDGE_SCORE(e) - base) & 0xFFu;
                     const uint32_t b = m >> shift;
@@ -1268,15 +1277,15 @@ static EdgeSegs own_segments(const EdgeSegs &segs) {
 }
 
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
-                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s) {
+                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s, uint32_t row_lo) {
     if (segs.n == 0 || segs.n > HMK_MAX_SEGS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_init_range, dim3(1), dim3(64), 0, s, score_range);
     if (row_limit < n && segs.n > HMK_EDGE_SHARDS) {   // band of a multi-device root: its own segments and the peers' blocks, each at its size
         const EdgeSegs own = own_segments(segs), blocks = peer_blocks(segs);
-        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), own.n), dim3(256), 0, s, own, deg, symmetric ? 1 : 0, score_range, n, row_limit);
-        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit, true), blocks.n), dim3(256), 0, s, blocks, deg, symmetric ? 1 : 0, score_range, n, row_limit);
+        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), own.n), dim3(256), 0, s, own, deg, symmetric ? 1 : 0, score_range, n, row_lo, row_limit);
+        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit, true), blocks.n), dim3(256), 0, s, blocks, deg, symmetric ? 1 : 0, score_range, n, row_lo, row_limit);
     } else {
-        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), segs.n), dim3(256), 0, s, segs, deg, symmetric ? 1 : 0, score_range, n, row_limit);
+        hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), segs.n), dim3(256), 0, s, segs, deg, symmetric ? 1 : 0, score_range, n, row_lo, row_limit);
     }
     launch_scan<uint64_t>(deg, start, row_limit, tile_scratch, nullptr, s);
     return hipGetLastError();
@@ -1291,15 +1300,15 @@ hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uin
 }
 
 hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64_t *start, uint32_t *cursor, void *adj,
-                              bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n) {
+                              bool packed, int base, uint32_t row_limit, hipStream_t s, uint32_t n, uint32_t row_lo) {
     auto go = [&](const EdgeSegs &sg, uint32_t gx) {
         if (sg.n == 0) return;
         if (packed)
             hipLaunchKernelGGL((k_edge_scatter<NbrPacked>), dim3(gx, sg.n), dim3(256), 0, s, sg, start, cursor, (NbrPacked *)adj,
-                               symmetric ? 1 : 0, base, row_limit);
+                               symmetric ? 1 : 0, base, row_lo, row_limit);
         else
             hipLaunchKernelGGL((k_edge_scatter<Nbr>), dim3(gx, sg.n), dim3(256), 0, s, sg, start, cursor, (Nbr *)adj,
-                               symmetric ? 1 : 0, base, row_limit);
+                               symmetric ? 1 : 0, base, row_lo, row_limit);
     };
     if (n && row_limit < n && segs.n > HMK_EDGE_SHARDS) {   // (n given: the band's rows beside a running pass; multi-device root: two kinds of segment)
         go(own_segments(segs), band_grid_x(segs, n, row_limit));
@@ -1321,7 +1330,9 @@ uint32_t csr_partition_shift(uint32_t n, int forced_shift) {
 }
 size_t csr_partition_scratch_bytes() { return 3 * ((size_t)LB_MAX_BUCKETS + 1) * sizeof(unsigned long long); }
 hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *start, uint32_t *cursor, void *adj, int base, uint32_t n,
-                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, int forced_shift, hipStream_t s) {
+                                          uint64_t *recs, void *scratch, const uint32_t *row_lower, int forced_shift, hipStream_t s,
+                                          uint32_t row_lo, uint32_t row_hi) {
+    if (row_hi > n) row_hi = n;
     const uint32_t shift = csr_partition_shift(n, forced_shift);
     const uint32_t nb = (uint32_t)(((uint64_t)n + (1u << shift) - 1) >> shift);
     if (shift > 12 || nb > LB_MAX_BUCKETS) return hipErrorInvalidValue;
@@ -1331,13 +1342,13 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
     } else {
         hipError_t e = hipMemsetAsync(cnt, 0, (size_t)nb * sizeof(unsigned long long), s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_lower_count, dim3(512), dim3(1024), 0, s, segs, shift, nb, n, cnt);
+        hipLaunchKernelGGL(k_lower_count, dim3(512), dim3(1024), 0, s, segs, shift, nb, n, row_lo, row_hi, cnt);
     }
     hipLaunchKernelGGL(k_lower_offsets, dim3(1), dim3(1024), 0, s, cnt, nb, off, fill);
     // (10^6 sequences, round 2: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms with ONE load in flight per thread;
     // the kernel is bound by memory latency: 4 loads in flight 22.1 ms, 8: 21.5, 16 with the chunk kept in registers: 19.8)
     // the upper sections in the same pass over the edges
-    hipLaunchKernelGGL(k_lower_partition, dim3(CSR_PARTITION_GRID), dim3(1024), 0, s, segs, shift, nb, n, base, off, fill, recs, start,
+    hipLaunchKernelGGL(k_lower_partition, dim3(CSR_PARTITION_GRID), dim3(1024), 0, s, segs, shift, nb, n, row_lo, row_hi, base, off, fill, recs, start,
                        cursor, (NbrPacked *)adj);
     if ((1u << shift) <= LP_ROWS)
         hipLaunchKernelGGL(k_lower_place_sorted, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
@@ -1547,6 +1558,9 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return v;
 }
 
+// Rows of at most BAND_REG_ROW upper entries keep their far keys in registers (one read of the row); longer rows are read again for
+// every candidate taken (they come from the L2: a row is a few KB).
+constexpr uint32_t BAND_REG_KEYS = 8, BAND_REG_ROW = 64 * BAND_REG_KEYS;
 __global__ void __launch_bounds__(256)
 k_band_split(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bup, const uint32_t *__restrict__ badj, uint32_t R, uint32_t ft,
              const int32_t *__restrict__ seq_size, uint32_t *__restrict__ near_cnt, uint32_t *__restrict__ near_up,
@@ -1555,29 +1569,48 @@ k_band_split(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ b
     for (uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6); x < R; x += gridDim.x * 4) {   // wave-uniform
         const uint64_t b = bstart[x], e = bstart[x + 1];
         const uint32_t up = bup[x];
+        const bool in_regs = up <= BAND_REG_ROW;   // wave-uniform
+        unsigned long long keys[BAND_REG_KEYS];
+#pragma unroll
+        for (uint32_t j = 0; j < BAND_REG_KEYS; j++) keys[j] = 0;
         uint32_t n_near_up = 0, n_far = 0;
-        for (uint32_t k0 = 0; k0 < up; k0 += 64) {
-            const uint32_t k = k0 + lane;
+        auto visit = [&](uint32_t k, unsigned long long *key_out) {
             const uint32_t ent = k < up ? badj[b + k] : 0u;
             const bool far = k < up && (ent >> 8) >= R;
             if (far) atomicAdd(&fdeg[ent >> 8], 1u);
+            if (key_out) *key_out = far ? band_far_key(ent, seq_size) : 0ull;
             n_far += (uint32_t)__popcll(__ballot(far));
             n_near_up += (uint32_t)__popcll(__ballot(k < up && !far));
+        };
+        if (in_regs) {
+#pragma unroll
+            for (uint32_t j = 0; j < BAND_REG_KEYS; j++)
+                if (j * 64 < up) visit(j * 64 + lane, &keys[j]);   // wave-uniform test
+        } else {
+            for (uint32_t k0 = 0; k0 < up; k0 += 64) visit(k0 + lane, nullptr);
         }
-        // the FT best far candidates, one per turn: the largest key below the last one taken (keys are unique: they end in the id)
+        // the FT best far candidates, one per turn: the largest key below the last one taken (keys are unique: they end in the id;
+        // a key is never 0: Cluster.size() >= 1)
         unsigned long long bound = ~0ull;
         for (uint32_t t = 0; t < ft; t++) {
-            unsigned long long best = 0;   // (a key is never 0: ~id & 0xFFFFFF is 0 for id 0xFFFFFF only, and size >= 1)
-            if (t < n_far)
-                for (uint32_t k = lane; k < up; k += 64) {
-                    const uint32_t ent = badj[b + k];
-                    if ((ent >> 8) < R) continue;
-                    const unsigned long long key = band_far_key(ent, seq_size);
-                    if (key < bound && key > best) best = key;
+            unsigned long long best = 0;
+            if (t < n_far) {
+                if (in_regs) {
+#pragma unroll
+                    for (uint32_t j = 0; j < BAND_REG_KEYS; j++)
+                        if (keys[j] < bound && keys[j] > best) best = keys[j];
+                } else {
+                    for (uint32_t k = lane; k < up; k += 64) {
+                        const uint32_t ent = badj[b + k];
+                        if ((ent >> 8) < R) continue;
+                        const unsigned long long key = band_far_key(ent, seq_size);
+                        if (key < bound && key > best) best = key;
+                    }
                 }
-            best = wave_max_u64(best);
+                best = wave_max_u64(best);
+            }
             if (lane == 0) far_top[(size_t)x * ft + t] = best ? ((uint32_t)(~best & 0xFFFFFFull) << 8) | (uint32_t)(best >> 56) : ~0u;
-            bound = best ? best : 0ull;
+            bound = best;   // (0 once the row has no more: nothing lies below it)
         }
         if (lane == 0) {
             near_up[x] = n_near_up;
@@ -1587,17 +1620,97 @@ k_band_split(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ b
     }
 }
 
-// near rows (upper section's near entries, then the lower section) and the transposed far part: fadj[fstart[id] ..) = the band
-// rows that have far sequence id as a neighbour, band row << 8 | (score - base)
+// Where every far sequence's transposed list starts: fstart[id] = a block of fdeg[id] entries taken from one counter, a wave's 64
+// blocks with ONE atomic (prefix sums inside the wave) -- the lists need no order among themselves.  *counter zeroed.
+// The same launch also settles which transposed lists travel: those of the sequences that are a band row's first TR far candidates,
+// each once -- owner_of[id] (zeroed) = 1 + the slot u = TR * x + t that ships id's list, tr_cnt[u] = its length for the owner, 0 for
+// the others.
 __global__ void __launch_bounds__(256)
-k_band_fill(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bup, const uint32_t *__restrict__ badj, uint32_t R,
-            const uint32_t *__restrict__ near_start, uint32_t *__restrict__ near, const uint32_t *__restrict__ fstart,
-            uint32_t *__restrict__ fcur, uint32_t *__restrict__ fadj) {
+k_band_falloc(const uint32_t *__restrict__ fdeg, uint32_t n, uint32_t *__restrict__ fstart, uint32_t *__restrict__ counter,
+              const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, uint32_t *__restrict__ owner_of,
+              uint32_t *__restrict__ tr_cnt) {
+    for (uint32_t u = blockIdx.x * 256 + threadIdx.x; u < R * tr_per_row; u += gridDim.x * 256) {
+        const uint32_t x = u / tr_per_row, t = u - x * tr_per_row;
+        const uint32_t ent = t < ft ? far_top[(size_t)x * ft + t] : ~0u;
+        uint32_t cnt = 0;
+        if (ent != ~0u && atomicCAS(&owner_of[ent >> 8], 0u, u + 1u) == 0u) cnt = fdeg[ent >> 8];
+        tr_cnt[u] = cnt;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; k0 < n; k0 += gridDim.x * 256) {   // wave-uniform
+        const uint32_t id = k0 + lane;
+        const uint32_t v = id < n ? fdeg[id] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((int)lane >= d) incl += t;
+        }
+        const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+        uint32_t base = 0;
+        if (lane == 0 && tot) base = atomicAdd(counter, tot);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if (id < n) fstart[id] = base + incl - v;
+    }
+}
+
+// One workgroup of 256 threads (NOT more: a larger workgroup waits for a CU with that many free wave slots while the scoring pass
+// keeps every CU full of 256-thread workgroups -- a 1,024-thread one waited for the END of the pass), between the split and the
+// fill: exclusive prefix sums near_cnt -> near_start[R + 1] and tr_cnt -> tr_start[R * TR + 1]; totals[0] = near entries,
+// totals[1] = entries of the travelling lists.
+__device__ void band_block_scan(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, uint32_t n, uint32_t *wsum) {   // wsum: LDS uint32[8]
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    uint32_t carry = 0;
+    for (uint32_t k0 = 0; k0 < n; k0 += 1024) {   // tiles of 4 consecutive counters per thread (coalesced), workgroup-uniform
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t k = k0 + t * 4 + q; v[q] = k < n ? src[k] : 0u; sum += v[q]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((int)lane >= d) incl += u;
+        }
+        __syncthreads();   // (wsum of the previous tile has been read)
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < wv; w++) before += wsum[w];
+        uint32_t run = before + incl - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t k = k0 + t * 4 + q; if (k < n) dst[k] = run; run += v[q]; }
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    if (t == 0) dst[n] = carry;
+}
+__global__ void __launch_bounds__(256)
+k_band_offsets(uint32_t R, uint32_t tr_per_row, const uint32_t *__restrict__ near_cnt, uint32_t *__restrict__ near_start,
+               const uint32_t *__restrict__ tr_cnt, uint32_t *__restrict__ tr_start, uint32_t *__restrict__ totals) {
+    __shared__ uint32_t wsum[8];
+    band_block_scan(near_cnt, near_start, R, wsum);
+    __syncthreads();
+    band_block_scan(tr_cnt, tr_start, R * tr_per_row, wsum);
+    __syncthreads();
+    if (threadIdx.x == 0) { totals[0] = near_start[R]; totals[1] = tr_start[R * tr_per_row]; }
+}
+
+// near rows (upper section's near entries, then the lower section) and the transposed far part: fadj[fstart[id] ..) = the band
+// rows that have far sequence id as a neighbour, band row << 8 | (score - base).
+// `near` and the h_* arrays are the HOST's block (pinned, mapped): the kernel's stores travel over PCIe as they are made -- no copy
+// afterwards (a copy is a launch of its own that waits for a slot beside the pass: 0.9 ms for 2.5 MB at 10^5).
+__global__ void __launch_bounds__(256)
+k_band_fill(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bup, const uint32_t *__restrict__ badj, uint32_t R, uint32_t ft,
+            const uint32_t *__restrict__ near_start, const uint32_t *__restrict__ near_up, const uint32_t *__restrict__ far_top,
+            const uint8_t *__restrict__ far_more, uint32_t *__restrict__ near, const uint32_t *__restrict__ fstart,
+            uint32_t *__restrict__ fcur, uint32_t *__restrict__ fadj, uint32_t *__restrict__ h_near_start, uint32_t *__restrict__ h_near_up,
+            uint32_t *__restrict__ h_far_top, uint8_t *__restrict__ h_far_more) {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6); x < R; x += gridDim.x * 4) {   // wave-uniform
         const uint64_t b = bstart[x], e = bstart[x + 1];
         const uint32_t up = bup[x], len = (uint32_t)(e - b);
         uint32_t w = near_start[x];
+        if (lane == 0) { h_near_start[x] = w; h_near_up[x] = near_up[x]; h_far_more[x] = far_more[x]; if (x + 1 == R) h_near_start[R] = near_start[R]; }
+        if (lane < ft) h_far_top[(size_t)x * ft + lane] = far_top[(size_t)x * ft + lane];
         for (uint32_t k0 = 0; k0 < len; k0 += 64) {
             const uint32_t k = k0 + lane;
             const uint32_t ent = k < len ? badj[b + k] : 0u;
@@ -1611,28 +1724,17 @@ k_band_fill(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bu
     }
 }
 
-// which transposed lists travel: those of the sequences that are a band row's first or second far candidate, each once.
-// owner_of[id] (zeroed) = 1 + the slot u = TR * x + t that ships id's list; tr_cnt[u] = its length for the owner, 0 for the others
-__global__ void __launch_bounds__(256)
-k_band_tr_claim(const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *__restrict__ fdeg,
-                uint32_t *__restrict__ owner_of, uint32_t *__restrict__ tr_cnt) {
-    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= R * tr_per_row) return;
-    const uint32_t x = u / tr_per_row, t = u - x * tr_per_row;
-    const uint32_t ent = t < ft ? far_top[(size_t)x * ft + t] : ~0u;
-    uint32_t cnt = 0;
-    if (ent != ~0u && atomicCAS(&owner_of[ent >> 8], 0u, u + 1u) == 0u) cnt = fdeg[ent >> 8];
-    tr_cnt[u] = cnt;
-}
 // tr_owner[u] = the slot that ships the list of slot u's candidate; the owners copy their lists (one wave per slot)
 __global__ void __launch_bounds__(256)
 k_band_tr_fill(const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *__restrict__ owner_of,
                const uint32_t *__restrict__ fstart, const uint32_t *__restrict__ fdeg, const uint32_t *__restrict__ fadj,
-               const uint32_t *__restrict__ tr_start, uint32_t *__restrict__ tr_owner, uint32_t *__restrict__ tr) {
+               const uint32_t *__restrict__ tr_start, uint32_t *__restrict__ tr_owner, uint32_t *__restrict__ tr, uint32_t *__restrict__ h_tr_start) {
+    // (tr_owner, tr and h_tr_start are the host's block, as in k_band_fill)
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t u = blockIdx.x * 4 + (threadIdx.x >> 6); u < R * tr_per_row; u += gridDim.x * 4) {   // wave-uniform
         const uint32_t x = u / tr_per_row, t = u - x * tr_per_row;
         const uint32_t ent = t < ft ? far_top[(size_t)x * ft + t] : ~0u;
+        if (lane == 0) { h_tr_start[u] = tr_start[u]; if (u + 1 == R * tr_per_row) h_tr_start[u + 1] = tr_start[u + 1]; }
         if (ent == ~0u) { if (lane == 0) tr_owner[u] = u; continue; }
         const uint32_t id = ent >> 8, own = owner_of[id] - 1u;
         if (lane == 0) tr_owner[u] = own;
@@ -1642,31 +1744,30 @@ k_band_tr_fill(const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, ui
     }
 }
 
-hipError_t launch_band_split(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, uint32_t ft, const int32_t *seq_size,
-                             uint32_t *near_cnt, uint32_t *near_up, uint32_t *far_top, uint8_t *far_more, uint32_t *fdeg, hipStream_t s) {
-    if (R == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_band_split, dim3(std::min<uint32_t>((R + 3) / 4, 4096)), dim3(256), 0, s, bstart, bup, (const uint32_t *)badj, R, ft, seq_size,
-                       near_cnt, near_up, far_top, far_more, fdeg);
-    return hipGetLastError();
+// Workgroups of the hand-over's kernels: they run BESIDE the scoring pass, where every workgroup has to wait for a slot and costs the
+// pass (band_grid_x above) -- but a wave walks its rows one after the other, each a chain of dependent loads: sized for the band's
+// entries at ~4,096 per workgroup, 32 .. 1024 (10^5: 366 for 1.5 x 10^6 entries, four rows per wave).
+static uint32_t band_prep_grid(uint64_t entries, uint32_t items) {
+    const uint64_t by_work = std::max<uint64_t>(32, std::min<uint64_t>(1024, entries / 4096));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(by_work, ((uint64_t)items + 3) / 4));
 }
-hipError_t launch_band_fill(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, const uint32_t *near_start, uint32_t *near,
-                            const uint32_t *fstart, uint32_t *fcur, uint32_t *fadj, hipStream_t s) {
+// The whole preparation behind the band's CSR, one stream, no host round trip: split -> list allocation + which lists travel -> the two
+// prefix sums -> near rows and transposed far part -> travelling lists.  h_*: the host's pinned block (device-visible addresses).
+hipError_t launch_band_prepare(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, uint64_t entries, uint32_t n, uint32_t ft,
+                               uint32_t tr_per_row, const int32_t *seq_size, uint32_t *near_cnt, uint32_t *near_up, uint32_t *near_start, uint32_t *far_top,
+                               uint8_t *far_more, uint32_t *fdeg, uint32_t *fcur, uint32_t *owner_of, uint32_t *totals, uint32_t *fstart, uint32_t *fadj,
+                               uint32_t *tr_cnt, uint32_t *tr_start, uint32_t *h_near_start, uint32_t *h_near_up, uint32_t *h_far_top, uint8_t *h_far_more,
+                               uint32_t *h_near, uint32_t *h_tr_owner, uint32_t *h_tr_start, uint32_t *h_tr, hipStream_t s) {
     if (R == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_band_fill, dim3(std::min<uint32_t>((R + 3) / 4, 4096)), dim3(256), 0, s, bstart, bup, (const uint32_t *)badj, R, near_start, near,
-                       fstart, fcur, fadj);
-    return hipGetLastError();
-}
-hipError_t launch_band_tr_claim(const uint32_t *far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *fdeg, uint32_t *owner_of,
-                                uint32_t *tr_cnt, hipStream_t s) {
-    if (R == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_band_tr_claim, dim3((R * tr_per_row + 255) / 256), dim3(256), 0, s, far_top, R, ft, tr_per_row, fdeg, owner_of, tr_cnt);
-    return hipGetLastError();
-}
-hipError_t launch_band_tr_fill(const uint32_t *far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *owner_of, const uint32_t *fstart,
-                               const uint32_t *fdeg, const uint32_t *fadj, const uint32_t *tr_start, uint32_t *tr_owner, uint32_t *tr, hipStream_t s) {
-    if (R == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_band_tr_fill, dim3(std::min<uint32_t>((R * tr_per_row + 3) / 4, 4096)), dim3(256), 0, s, far_top, R, ft, tr_per_row, owner_of,
-                       fstart, fdeg, fadj, tr_start, tr_owner, tr);
+    const uint32_t *adj = (const uint32_t *)badj;
+    hipLaunchKernelGGL(k_band_split, dim3(band_prep_grid(entries, R)), dim3(256), 0, s, bstart, bup, adj, R, ft, seq_size, near_cnt, near_up, far_top, far_more, fdeg);
+    hipLaunchKernelGGL(k_band_falloc, dim3(std::max<uint32_t>(8, std::min<uint32_t>(256, n / 16384))), dim3(256), 0, s, fdeg, n, fstart, totals + 2,
+                       far_top, R, ft, tr_per_row, owner_of, tr_cnt);
+    hipLaunchKernelGGL(k_band_offsets, dim3(1), dim3(256), 0, s, R, tr_per_row, near_cnt, near_start, tr_cnt, tr_start, totals);
+    hipLaunchKernelGGL(k_band_fill, dim3(band_prep_grid(entries, R)), dim3(256), 0, s, bstart, bup, adj, R, ft, near_start, near_up, far_top, far_more, h_near,
+                       fstart, fcur, fadj, h_near_start, h_near_up, h_far_top, h_far_more);
+    hipLaunchKernelGGL(k_band_tr_fill, dim3(band_prep_grid(entries, R * tr_per_row)), dim3(256), 0, s, far_top, R, ft, tr_per_row, owner_of,
+                       fstart, fdeg, fadj, tr_start, h_tr_owner, h_tr, h_tr_start);
     return hipGetLastError();
 }
 
