@@ -114,9 +114,7 @@ void hmk_destroy(hmk_ctx *ctx) {
             if (ctx->ev_join[k]) HMK_QUIET(hipEventDestroy(ctx->ev_join[k]));
         }
         if (ctx->ev_fork) HMK_QUIET(hipEventDestroy(ctx->ev_fork));
-        if (ctx->gather_stream) HMK_QUIET(hipStreamDestroy(ctx->gather_stream));   // (a peer's transfers to the root, hmk_multi.cpp)
-        if (ctx->ev_bandgather) HMK_QUIET(hipEventDestroy(ctx->ev_bandgather));
-        if (ctx->ev_gather) HMK_QUIET(hipEventDestroy(ctx->ev_gather));
+        if (ctx->xfer_stream) HMK_QUIET(hipStreamDestroy(ctx->xfer_stream));   // (this device's transfers to the others, hmk_multi.cpp)
         if (ctx->h_start) HMK_QUIET(hipHostFree(ctx->h_start));
         if (ctx->h_stage) HMK_QUIET(hipHostFree(ctx->h_stage));
         if (ctx->h_adj) HMK_QUIET(hipHostFree(ctx->h_adj));

@@ -4,6 +4,101 @@
 
 namespace hmk { namespace impl {
 
+// CSR of the rows [r0, r1) of the graph from `segs`, on c's device, enqueued on q.  The whole graph ([0, n)) in a single-device call; in a
+// multi-device call the piece this device owns -- start[] / up[] are indexed by the row itself, rows outside the piece stay empty.
+hipError_t piece_enqueue_csr(hmk_ctx *c, const EdgeSegs &segs, bool symmetric, bool packed, int base, uint32_t n, uint32_t r0, uint32_t r1,
+                             bool deg_fused, bool deg_split, hipStream_t q) {
+    const size_t esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
+    uint64_t records = 1;   // one per edge: at most what the segments hold
+    for (uint32_t k = 0; k < segs.n; k++) records += segs.s[k].cap;
+    hipError_t e = ensure_buf(c, SB_DEG, (size_t)n * 8);
+    if (e == hipSuccess) e = ensure_buf(c, SB_CURSOR, (size_t)n * 8);
+    if (e == hipSuccess) e = ensure_buf(c, SB_START, ((size_t)n + 1) * 8);
+    if (e == hipSuccess) e = ensure_buf(c, SB_SCAN, scan_scratch_bytes(n));
+    if (e == hipSuccess) e = ensure_buf(c, SB_RANGE, 64);
+    if (e == hipSuccess) e = ensure_buf(c, SB_ADJ, (symmetric ? 2 : 1) * records * esz);
+    if (e != hipSuccess) return e;
+    uint32_t *d_deg = buf<uint32_t>(c, SB_DEG), *d_cursor = buf<uint32_t>(c, SB_CURSOR);
+    uint64_t *d_start = buf<uint64_t>(c, SB_START);
+    const bool whole = r0 == 0 && r1 >= n;
+    if ((e = hipMemsetAsync(d_cursor, 0, (size_t)n * 8, q)) != hipSuccess) return e;
+    if (deg_fused) {
+        e = launch_csr_scan_only(d_deg, deg_split ? d_deg + n : nullptr, d_start, n, buf<uint64_t>(c, SB_SCAN), buf<int>(c, SB_RANGE), q);
+    } else {
+        if ((e = hipMemsetAsync(d_deg, 0, (size_t)n * 4, q)) != hipSuccess) return e;
+        e = launch_csr_degree_scan(segs, n, whole ? n : r1, symmetric, d_deg, d_start, buf<uint64_t>(c, SB_SCAN), buf<int>(c, SB_RANGE), q, whole ? 0 : r0, n);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_counts + HC_RANGE, buf<int>(c, SB_RANGE), 3 * sizeof(int), hipMemcpyDeviceToHost, q);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_counts + HC_TOTAL, d_start + n, 8, hipMemcpyDeviceToHost, q);
+    if (e != hipSuccess) return e;
+    if (csr_by_bucket(symmetric, packed)) {   // lower sections dealt by bucket
+        e = ensure_buf(c, SB_PART, records * 8);
+        if (e == hipSuccess) e = ensure_buf(c, SB_PARTSCR, csr_partition_scratch_bytes());
+        if (e == hipSuccess)
+            e = launch_csr_scatter_partitioned(segs, d_start, d_cursor, buf<void>(c, SB_ADJ), base, n, buf<uint64_t>(c, SB_PART), buf<void>(c, SB_PARTSCR),
+                                               deg_fused && deg_split ? d_deg + n : nullptr, c->sw.csr_bucket_shift, q, whole ? 0 : r0, whole ? n : r1);
+    } else {
+        e = launch_csr_scatter(segs, symmetric, d_start, d_cursor, buf<void>(c, SB_ADJ), packed, base, whole ? n : r1, q, 0, whole ? 0 : r0);
+    }
+    if (e == hipSuccess) e = hipEventRecord(c->ev_csr, q);
+    return e;
+}
+
+// Phase 1's result -- cluster_of, the clusters' member counts, the leftover list -- to c's device, on its copy stream (while the pass and
+// the CSR build are still running on the clustering stream: three copies, the bitmap kernel and their launch latencies leave the call's
+// critical path); records c->ev_bandcsr (the band hand-over's event: that hand-over is long over, and in stream order before this).
+hipError_t piece_precheck_upload(hmk_ctx *c, const PreIn &in) {
+    hipError_t r = ensure_buf(c, SB_COF, (size_t)in.n * 4);
+    if (r == hipSuccess) r = ensure_buf(c, SB_BITMAP, ((size_t)in.n + 31) / 32 * 4);
+    if (r == hipSuccess) r = ensure_buf(c, SB_USIZE, std::max<size_t>(in.ncl, 1) * 4);
+    if (r == hipSuccess) r = ensure_buf(c, SB_LEFT, std::max<size_t>(in.nl, 1) * 4);
+    if (r != hipSuccess) return r;
+    hipStream_t C = c->copy_stream;
+    r = hipMemcpyAsync(buf<int32_t>(c, SB_COF), in.h_block, in.b_cof, hipMemcpyHostToDevice, C);
+    if (r == hipSuccess) r = launch_cluster_bitmap(buf<int32_t>(c, SB_COF), in.n, buf<uint32_t>(c, SB_BITMAP), C);
+    if (r == hipSuccess && in.b_us) r = hipMemcpyAsync(buf<int32_t>(c, SB_USIZE), in.h_block + in.b_cof, in.b_us, hipMemcpyHostToDevice, C);
+    if (r == hipSuccess && in.b_left) r = hipMemcpyAsync(buf<uint32_t>(c, SB_LEFT), in.h_block + in.b_cof + in.b_us, in.b_left, hipMemcpyHostToDevice, C);
+    if (r == hipSuccess) r = hipEventRecord(c->ev_bandcsr, C);
+    return r;
+}
+
+// The single-pass pre-check of the leftovers whose rows c's device holds ([r0, r1)), entries into the regions [region_base, + region_count)
+// of the candidate buffer.  One pass: every wave takes its block of entries from the counter of its workgroup's region; rows with few
+// neighbours inside clusters go through small tables first (in.two_stage).
+int piece_precheck(hmk_ctx *c, const PreIn &in, uint32_t r0, uint32_t r1, uint32_t region_base, uint32_t region_count, hipStream_t q,
+                   bool upload, unsigned long long *total) {
+    *total = 0;
+    if (upload && piece_precheck_upload(c, in) != hipSuccess) return -1;
+    const uint32_t nl = in.nl;
+    hipError_t r = ensure_buf(c, SB_CNT, std::max<size_t>(nl, 1) * 4);
+    if (r == hipSuccess) r = ensure_buf(c, SB_CSTART, ((size_t)nl + 1) * 4);
+    if (r == hipSuccess) r = ensure_buf(c, SB_OVER, 64);
+    if (r == hipSuccess) r = ensure_buf(c, SB_CAND, (size_t)in.region_cap * HMK_PRE_REGIONS * sizeof(GreedyCand));
+    if (r == hipSuccess) r = ensure_buf(c, SB_PRECNT, HMK_PRE_REGIONS * sizeof(unsigned long long));
+    if (r == hipSuccess) r = ensure_pinned(&c->h_stage, &c->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + 64, 0);
+    if (r == hipSuccess && in.two_stage) r = ensure_buf(c, SB_RETRY, std::max<size_t>(nl, 1) * 4);
+    if (r != hipSuccess) return -1;
+    uint32_t *d_over = buf<uint32_t>(c, SB_OVER);                      // [0] table overflows, [1] rows of the second stage
+    unsigned long long *d_regions = buf<unsigned long long>(c, SB_PRECNT);
+    uint32_t *h_misc = (uint32_t *)(c->h_counts + HC_MISC);
+    unsigned long long *h_regions = (unsigned long long *)c->h_stage;   // (the block's first HMK_PRE_REGIONS words; the root's PreIn block lies behind them)
+    r = hipStreamWaitEvent(q, c->ev_bandcsr, 0);
+    if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 16, q);
+    if (r == hipSuccess) r = hipMemsetAsync(d_regions, 0, HMK_PRE_REGIONS * sizeof(unsigned long long), q);
+    if (r == hipSuccess)
+        r = launch_greedy_precheck(2, in.packed, buf<uint64_t>(c, SB_START), buf<void>(c, SB_ADJ), buf<int32_t>(c, SB_COF), buf<uint32_t>(c, SB_BITMAP),
+                                   buf<int32_t>(c, SB_USIZE), buf<uint32_t>(c, SB_LEFT), nl, buf<uint32_t>(c, SB_CNT), buf<uint32_t>(c, SB_CSTART),
+                                   buf<GreedyCand>(c, SB_CAND), d_over, d_regions, in.region_cap, in.two_stage ? buf<uint32_t>(c, SB_RETRY) : nullptr,
+                                   d_over + 1, in.first_slots, q, r0, r1, region_base, region_count);
+    if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, q);
+    if (r == hipSuccess) r = hipMemcpyAsync(h_regions, d_regions, HMK_PRE_REGIONS * sizeof(unsigned long long), hipMemcpyDeviceToHost, q);
+    if (r == hipSuccess) r = hipStreamSynchronize(q);
+    if (r != hipSuccess || h_misc[0] != 0) return -1;   // a row overflowed its hash table: host pre-check
+    bool fits = true;
+    for (uint32_t g = region_base; g < region_base + region_count; g++) { *total += h_regions[g]; fits = fits && h_regions[g] <= in.region_cap; }
+    return fits ? 0 : 1;
+}
+
 // Builds the CSR adjacency on the device, hands rows to the host merge on demand, runs the merge.
 int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int32_t *cluster_id, int32_t *result_order,
                       int32_t *member_rank, hmk_greedy_stats *stats, std::chrono::steady_clock::time_point t0) {
@@ -22,6 +117,12 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     int base = src.base;
     size_t esz = packed ? sizeof(NbrPacked) : sizeof(Nbr);
     const bool symmetric = src.symmetric;
+    // multi-device calls: the adjacency is built in pieces by the devices' workers (hmk_multi.cpp); piece_base[d] = the entries of
+    // the pieces before d (where piece d's rows begin in the host's single adj[] when rows are fetched)
+    const bool multi = src.pieces.size() > 1;
+    std::vector<EdgeSource::Piece> pieces = src.pieces;
+    if (pieces.empty()) pieces.push_back(EdgeSource::Piece{ctx, 0, n});
+    std::vector<uint64_t> piece_base(pieces.size() + 1, 0);
 
     // ---- full CSR on the device, enqueued behind the scoring on S ---------------------------------------
     HIPCHK(ctx, ensure_buf(ctx, SB_DEG, (size_t)n * 4));
@@ -84,7 +185,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (e == hipSuccess && src.format_known) e = enqueue_scatter();
         return e;
     };
-    if (!src.before_full && !late_buffers) HIPCHK(ctx, enqueue_full());
+    if (!multi && !src.before_full && !late_buffers) HIPCHK(ctx, enqueue_full());
 
     // ---- band: the first rows' adjacency from the edges of the band launch, on the copy stream --------------
     uint32_t rows_lo = 0, rows_here = 0;   // rows [rows_lo, rows_here) are valid in h_start / the host adjacency block
@@ -142,7 +243,25 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
     bool full_ready = false;
     auto wait_full = [&]() -> bool {
         if (full_ready) return true;
-        if (!full_enqueued) {   // multi-device: the peers' edges first; (or: the late buffers are ready only now)
+        if (multi) {
+            const int r = src.before_full ? src.before_full() : HMK_ERR_DEVICE;
+            if (r != HMK_OK) { hook_fail(r, ctx->err.empty() ? "building the adjacency pieces failed" : ctx->err); return false; }
+            uint64_t sum = 0;
+            for (size_t d = 0; d < pieces.size(); d++) {
+                const int *rg = (const int *)(pieces[d].c->h_counts + HC_RANGE);
+                if (rg[2] != 0) { hook_fail(HMK_ERR_BAD_ARG, "edge list references a sequence outside [0, n) or a self pair"); return false; }
+                piece_base[d] = sum;
+                sum += pieces[d].c->h_counts[HC_TOTAL];
+            }
+            piece_base[pieces.size()] = sum;
+            h_start[n] = sum;
+            const uint64_t want = symmetric ? 2 * src.total_edges : src.total_edges;
+            if (sum != want) { hook_fail(HMK_ERR_DEVICE, "CSR build: the pieces' entries do not add up to the edges scored"); return false; }
+            full_enqueued = scatter_enqueued = full_ready = true;
+            lap("every piece of the CSR on its device");
+            return true;
+        }
+        if (!full_enqueued) {   // (the late buffers are ready only now)
             const int r = src.before_full ? src.before_full() : HMK_OK;
             if (r != HMK_OK) { hook_fail(r, ctx->err.empty() ? "gathering the peers' edges failed" : ctx->err); return false; }
             const hipError_t e0 = enqueue_full();
@@ -314,20 +433,29 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         if (band_used || from < rows_lo || rows_here == rows_lo) { rows_lo = rows_here = from; band_used = false; }   // (band rows come again, in the full CSR's layout)
         uint32_t r_end = n;
         if (k + 1 < n) r_end = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>({(uint64_t)k + 1, (uint64_t)rows_here + (rows_here - rows_lo), (uint64_t)rows_here + 8192}));
-        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
-        e = hipMemcpyAsync(h_start + rows_here, d_start + rows_here, ((size_t)(r_end - rows_here) + 1) * 8, hipMemcpyDeviceToHost, C);
-        if (e == hipSuccess && symmetric)
-            e = hipMemcpyAsync(h_up + rows_here, buf<uint32_t>(ctx, SB_CURSOR) + rows_here, (size_t)(r_end - rows_here) * 4, hipMemcpyDeviceToHost, C);
-        if (e == hipSuccess) e = hipStreamSynchronize(C);
-        if (e == hipSuccess) {
-            const uint64_t a0 = h_start[rows_here], a1 = h_start[r_end];
-            if (rows_here == rows_lo) adj_off = a0;
+        // rows [rows_here, r_end) from the piece(s) that hold them: row starts and upper sizes first (a piece's starts count from its own
+        // first entry: + piece_base), then the entries, into the host's one adj[]
+        for (size_t d = 0; d < pieces.size() && e == hipSuccess; d++) {
+            const uint32_t a = std::max(rows_here, pieces[d].r0), b = std::min(r_end, pieces[d].r1);
+            if (a >= b) continue;
+            hmk_ctx *pc = pieces[d].c;
+            if (multi) (void)hipSetDevice(pc->device);
+            e = hipMemcpyAsync(h_start + a, buf<uint64_t>(pc, SB_START) + a, ((size_t)(b - a) + 1) * 8, hipMemcpyDeviceToHost, pc->copy_stream);
+            if (e == hipSuccess && symmetric)
+                e = hipMemcpyAsync(h_up + a, buf<uint32_t>(pc, SB_CURSOR) + a, (size_t)(b - a) * 4, hipMemcpyDeviceToHost, pc->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(pc->copy_stream);
+            if (e != hipSuccess) break;
+            const uint64_t l0 = h_start[a], l1 = h_start[b];                       // (the piece's own offsets)
+            const uint64_t a0 = piece_base[d] + l0, a1 = piece_base[d] + l1;
+            if (a == rows_lo && rows_here == rows_lo) adj_off = a0;
             e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, std::max<uint64_t>(a1 - adj_off, 1) * esz, (a0 - adj_off) * esz);
             if (e == hipSuccess && a1 > a0)
-                e = hipMemcpyAsync((char *)ctx->h_adj + (a0 - adj_off) * esz, (const char *)buf<void>(ctx, SB_ADJ) + a0 * esz, (a1 - a0) * esz,
-                                   hipMemcpyDeviceToHost, C);
-            if (e == hipSuccess) e = hipStreamSynchronize(C);
+                e = hipMemcpyAsync((char *)ctx->h_adj + (a0 - adj_off) * esz, (const char *)buf<void>(pc, SB_ADJ) + l0 * esz, (a1 - a0) * esz,
+                                   hipMemcpyDeviceToHost, pc->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(pc->copy_stream);
+            if (piece_base[d]) for (uint32_t x = a; x <= b; x++) h_start[x] += piece_base[d];
         }
+        if (multi) (void)hipSetDevice(ctx->device);
         if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("adjacency copy: ") + hipGetErrorString(e)); return 0; }
         rows_here = r_end;
         t_rows += ms_since(tw);
@@ -346,90 +474,60 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                bool single_pass) -> bool {
         if (pre_mode == 1 || (pre_mode == 2 && single_pass)) return true;
         if (sw.precheck == 1) single_pass = false;   // (HMK_PRECHECK=two_passes: the count + fill form a region overrun falls back to)
+        if (multi && !single_pass) return false;     // (the pieces run the single pass only: the host's pre-check otherwise)
         const uint32_t nl = (uint32_t)leftover.size();
-        hipError_t r = ensure_buf(ctx, SB_COF, (size_t)n * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_BITMAP, ((size_t)n + 31) / 32 * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_USIZE, std::max<size_t>(usize.size(), 1) * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_LEFT, std::max<size_t>(nl, 1) * 4);
-        if (r != hipSuccess) return false;
+        PreIn in;
+        in.n = n; in.nl = nl; in.ncl = (uint32_t)usize.size(); in.packed = packed;
+        in.b_cof = (size_t)n * 4; in.b_us = usize.size() * 4; in.b_left = (size_t)nl * 4;
         bool uploaded_early = false;
+        hipError_t r = hipSuccess;
         if (pre_mode == 0) {
-            // Phase 1's result goes up on the copy stream NOW, while the pass and the CSR build are still running on the clustering
-            // stream (phase 1 ends before the scoring does at every size): three copies, the bitmap kernel and their launch latencies
-            // (~50 us at 10^5) leave the call's critical path.  Through a pinned block: an "async" upload from pageable memory is
-            // staged by the runtime chunk by chunk and the stream waits for it (0.3 ms for these 0.8 MB at 10^5).
-            const size_t b_cof = (size_t)n * 4, b_us = usize.size() * 4, b_left = (size_t)nl * 4;
-            r = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + b_cof + b_us + b_left + 64, 0);
+            // Phase 1's result into a pinned block (an "async" upload from pageable memory is staged by the runtime chunk by chunk and
+            // the stream waits for it: 0.3 ms for these 0.8 MB at 10^5); it goes up NOW, on the copy stream, while the pass and the CSR
+            // build are still running (phase 1 ends before the scoring does at every size)
+            r = ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + in.b_cof + in.b_us + in.b_left + 64, 0);
             if (r != hipSuccess) return false;
             char *hs = (char *)ctx->h_stage + HMK_PRE_REGIONS * sizeof(unsigned long long);   // (the block starts with the single pass's region counters)
-            std::memcpy(hs, cluster_of, b_cof);
-            std::memcpy(hs + b_cof, usize.data(), b_us);
-            std::memcpy(hs + b_cof + b_us, leftover.data(), b_left);
-            r = hipMemcpyAsync(buf<int32_t>(ctx, SB_COF), hs, b_cof, hipMemcpyHostToDevice, C);
-            if (r == hipSuccess) r = launch_cluster_bitmap(buf<int32_t>(ctx, SB_COF), n, buf<uint32_t>(ctx, SB_BITMAP), C);
-            if (r == hipSuccess && b_us) r = hipMemcpyAsync(buf<int32_t>(ctx, SB_USIZE), hs + b_cof, b_us, hipMemcpyHostToDevice, C);
-            if (r == hipSuccess && b_left) r = hipMemcpyAsync(buf<uint32_t>(ctx, SB_LEFT), hs + b_cof + b_us, b_left, hipMemcpyHostToDevice, C);
-            if (r == hipSuccess) r = hipEventRecord(ctx->ev_bandcsr, C);   // (the band hand-over's event: that hand-over is long over, and in stream order before this)
-            if (r != hipSuccess) return false;
-            uploaded_early = true;
+            std::memcpy(hs, cluster_of, in.b_cof);
+            std::memcpy(hs + in.b_cof, usize.data(), in.b_us);
+            std::memcpy(hs + in.b_cof + in.b_us, leftover.data(), in.b_left);
+            in.h_block = hs;
+            if (!multi) {
+                if (piece_precheck_upload(ctx, in) != hipSuccess) return false;
+                uploaded_early = true;
+            }
         }
+        in.h_block = (char *)ctx->h_stage + HMK_PRE_REGIONS * sizeof(unsigned long long);
         if (!wait_full()) return false;
         const auto tp = std::chrono::steady_clock::now();
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_CNT, std::max<size_t>(nl, 1) * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_CSTART, ((size_t)nl + 1) * 4);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_OVER, 64);
-        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>(nl, n)));
-        if (r != hipSuccess) return false;
-        int32_t *d_cof = buf<int32_t>(ctx, SB_COF), *d_usize = buf<int32_t>(ctx, SB_USIZE);
-        uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cnt = buf<uint32_t>(ctx, SB_CNT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
-        uint32_t *d_over = buf<uint32_t>(ctx, SB_OVER);                      // [0] table overflows, [2..3] the single pass's entry counter
-        unsigned long long *d_total = (unsigned long long *)(d_over + 2);
-        uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
-        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
-        const void *d_adj = buf<void>(ctx, SB_ADJ);
-        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
-        if (uploaded_early) {
-            r = hipStreamWaitEvent(S, ctx->ev_bandcsr, 0);
-        }
-        if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 16, S);
-        if (r == hipSuccess && single_pass) {
-            // One pass: every wave takes its block of entries from the counter of its workgroup's region of the buffer.  The
-            // buffer is sized from what previous calls needed (or 24 entries per leftover); a call that overruns a region falls
-            // back to the two passes below.
-            const size_t want = std::max<size_t>({ctx->sb[SB_CAND].cap / sizeof(GreedyCand), (size_t)nl * 24, (size_t)HMK_PRE_REGIONS * 64});
-            const unsigned long long region_cap = std::min<unsigned long long>(want, 0xFFFFFFFFull) / HMK_PRE_REGIONS;
-            r = ensure_buf(ctx, SB_CAND, (size_t)region_cap * HMK_PRE_REGIONS * sizeof(GreedyCand));
-            if (r == hipSuccess) r = ensure_buf(ctx, SB_PRECNT, HMK_PRE_REGIONS * sizeof(unsigned long long));
-            unsigned long long *d_regions = buf<unsigned long long>(ctx, SB_PRECNT);
-            if (r == hipSuccess) r = hipMemsetAsync(d_regions, 0, HMK_PRE_REGIONS * sizeof(unsigned long long), S);
-            // rows with few neighbours inside clusters (the estimate: average degree x the clustered share of the sequences) go
-            // through small tables first
-            size_t in_clusters = 0;
-            for (int32_t u : usize) in_clusters += (size_t)u;
-            const double est = (double)h_start[n] / std::max<uint32_t>(n, 1) * (double)in_clusters / std::max<uint32_t>(n, 1);
-            uint32_t *d_retry = nullptr;
-            const int first_slots = est <= 24.0 ? 128 : 512;   // ~5 x the expected number of distinct clusters in a row
-            // (10^6 default-threshold 12-mers give an estimate of 130; small tables first for them too -- 512 slots, five workgroups
-            // per CU instead of two -- was measured and loses: 22.0 against 18.7 ms, 38.9 against 25.8 ms in the reference's
-            // default order, where many rows see far more clusters than the average and are scanned twice)
-            const double two_stage_limit = 100.0;
-            if (r == hipSuccess && est <= two_stage_limit && sw.precheck != 2) {   // (HMK_PRECHECK=one_stage: what dense rows run)
-                r = ensure_buf(ctx, SB_RETRY, std::max<size_t>(nl, 1) * 4);
-                d_retry = buf<uint32_t>(ctx, SB_RETRY);
-            }
-            if (r == hipSuccess) r = launch_greedy_precheck(2, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
-                                                            d_cnt, d_cstart, buf<GreedyCand>(ctx, SB_CAND), d_over, d_regions, region_cap,
-                                                            d_retry, d_over + 1, first_slots, S);
-            unsigned long long *h_regions = (unsigned long long *)ctx->h_stage;   // (sized with the uploads above: pre_mode is 0 here)
-            if (r == hipSuccess) r = hipMemcpyAsync(&h_misc[0], d_over, 4, hipMemcpyDeviceToHost, S);
-            if (r == hipSuccess) r = hipMemcpyAsync(h_regions, d_regions, HMK_PRE_REGIONS * sizeof(unsigned long long), hipMemcpyDeviceToHost, S);
-            if (r == hipSuccess) r = hipStreamSynchronize(S);
-            if (r != hipSuccess || h_misc[0] != 0) return false;   // a row overflowed its hash table: host pre-check
+        // The candidate buffer is sized from what previous calls needed (or 24 entries per leftover), HMK_PRE_REGIONS regions; a call that
+        // overruns a region falls back to the two passes below.
+        const size_t want = std::max<size_t>({ctx->sb[SB_CAND].cap / sizeof(GreedyCand), (size_t)nl * 24, (size_t)HMK_PRE_REGIONS * 64});
+        in.region_cap = std::min<unsigned long long>(want, 0xFFFFFFFFull) / HMK_PRE_REGIONS;
+        // rows with few neighbours inside clusters (the estimate: average degree x the clustered share of the sequences) go through small
+        // tables first.  (10^6 default-threshold 12-mers give an estimate of 130; small tables first for them too -- 512 slots, five
+        // workgroups per CU instead of two -- was measured and loses: 22.0 against 18.7 ms, 38.9 against 25.8 ms in the reference's
+        // default order, where many rows see far more clusters than the average and are scanned twice)
+        size_t in_clusters = 0;
+        for (int32_t u : usize) in_clusters += (size_t)u;
+        const double est = (double)h_start[n] / std::max<uint32_t>(n, 1) * (double)in_clusters / std::max<uint32_t>(n, 1);
+        in.first_slots = est <= 24.0 ? 128 : 512;   // ~5 x the expected number of distinct clusters in a row
+        in.two_stage = est <= 100.0 && sw.precheck != 2;   // (HMK_PRECHECK=one_stage: what dense rows run)
+        if (multi) {
             unsigned long long total = 0;
-            bool fits = true;
-            for (uint32_t g = 0; g < HMK_PRE_REGIONS; g++) { total += h_regions[g]; fits = fits && h_regions[g] <= region_cap; }
-            if (fits && total > 0x7FFFFFFFull) return false;
-            if (fits) {
+            if (!src.precheck_pieces || !src.precheck_pieces(in, &total) || total > 0x7FFFFFFFull) return false;
+            pre_total_c = (uint32_t)total;
+            pre_mode = 2;
+            ph.cand_entries = pre_total_c;
+            ph.precheck_ms = ms_since(tp);
+            return true;
+        }
+        if (single_pass) {
+            unsigned long long total = 0;
+            const int fit = piece_precheck(ctx, in, 0, n, 0, HMK_PRE_REGIONS, S, !uploaded_early && pre_mode == 0, &total);
+            if (fit < 0) return false;
+            if (fit == 0 && total > 0x7FFFFFFFull) return false;
+            if (fit == 0) {
                 pre_total_c = (uint32_t)total;
                 pre_mode = 2;
                 ph.cand_entries = pre_total_c;
@@ -437,8 +535,24 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 return true;
             }
             if (total > 0x7FFFFFFFull) return false;   // (entry indices: 31 bits, k_loop_subscribers' record keeps a flag in the 32nd)
-            r = hipMemsetAsync(d_over, 0, 16, S);   // more entries than a region holds: count, size, fill
+            uploaded_early = true;                      // (more entries than a region holds: count, size, fill -- the inputs are up)
         }
+        if (!uploaded_early && pre_mode == 0 && piece_precheck_upload(ctx, in) != hipSuccess) return false;
+        r = ensure_buf(ctx, SB_CNT, std::max<size_t>(nl, 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_CSTART, ((size_t)nl + 1) * 4);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_OVER, 64);
+        if (r == hipSuccess) r = ensure_buf(ctx, SB_SCAN2, scan_scratch_bytes(std::max<uint32_t>(nl, n)));
+        if (r != hipSuccess) return false;
+        int32_t *d_cof = buf<int32_t>(ctx, SB_COF), *d_usize = buf<int32_t>(ctx, SB_USIZE);
+        uint32_t *d_left = buf<uint32_t>(ctx, SB_LEFT), *d_cnt = buf<uint32_t>(ctx, SB_CNT), *d_cstart = buf<uint32_t>(ctx, SB_CSTART);
+        uint32_t *d_over = buf<uint32_t>(ctx, SB_OVER);                      // [0] table overflows, [2..3] the count pass's entry counter
+        unsigned long long *d_total = (unsigned long long *)(d_over + 2);
+        uint64_t *d_scan = buf<uint64_t>(ctx, SB_SCAN2);
+        const uint64_t *d_start = buf<uint64_t>(ctx, SB_START);
+        const void *d_adj = buf<void>(ctx, SB_ADJ);
+        uint32_t *h_misc = (uint32_t *)(ctx->h_counts + HC_MISC);
+        r = hipStreamWaitEvent(S, ctx->ev_bandcsr, 0);
+        if (r == hipSuccess) r = hipMemsetAsync(d_over, 0, 16, S);
         if (r == hipSuccess) r = launch_greedy_precheck(0, packed, d_start, d_adj, d_cof, buf<uint32_t>(ctx, SB_BITMAP), d_usize, d_left, nl,
                                                         d_cnt, nullptr, nullptr, d_over, d_total, 0, nullptr, nullptr, 0, S);
         if (r == hipSuccess) r = launch_scan_u32(d_cnt, d_cstart, nl, d_scan, S);
@@ -524,8 +638,37 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
         // and a round without a join is the end.  The host keeps enqueuing rounds while it watches the progress word that
         // k_loop_apply stores into pinned host memory (round << 32 | joins of that round), at most LOOKAHEAD rounds ahead of
         // the device; rounds enqueued after the end find nothing to do.
+        // where the joiners' rows are read: this device's CSR, or (multi-device) every piece where it lives -- in the peers' memory, or in
+        // the copies the root made of their pieces (no peer access to that device; HMK_MULTI_REPLICATE)
+        RowPieces rowp{};
+        rowp.rows_per = multi ? src.rows_per : 0;
+        for (size_t d = 0; d < pieces.size() && r == hipSuccess; d++) {
+            hmk_ctx *pc = pieces[d].c;
+            rowp.start[d] = buf<uint64_t>(pc, SB_START);
+            rowp.up[d] = buf<uint32_t>(pc, SB_CURSOR);
+            rowp.adj[d] = buf<void>(pc, SB_ADJ);
+            if (multi && d > 0 && (!pc->peer_loads_ok || sw.multi_replicate)) {
+                const uint64_t entries = pc->h_counts[HC_TOTAL];
+                const size_t o_start = 0, o_up = ((size_t)n + 1) * 8, o_adj = (o_up + (size_t)n * 4 + 63) / 64 * 64, bytes = o_adj + std::max<uint64_t>(entries, 1) * esz;
+                DevBuf &rb = pc->sb[SB_REPL];   // (allocated on the ROOT's device, kept in the peer's context)
+                if (rb.cap < bytes) {
+                    if (rb.p) (void)hipFree(rb.p);
+                    rb.p = nullptr; rb.cap = 0;
+                    r = hipMalloc(&rb.p, bytes + bytes / 8);
+                    if (r == hipSuccess) rb.cap = bytes + bytes / 8;
+                }
+                char *rp = (char *)rb.p;
+                if (r == hipSuccess) r = hipMemcpyPeerAsync(rp + o_start, ctx->device, rowp.start[d], pc->device, ((size_t)n + 1) * 8, S);
+                if (r == hipSuccess) r = hipMemcpyPeerAsync(rp + o_up, ctx->device, rowp.up[d], pc->device, (size_t)n * 4, S);
+                if (r == hipSuccess && entries) r = hipMemcpyPeerAsync(rp + o_adj, ctx->device, rowp.adj[d], pc->device, entries * esz, S);
+                rowp.start[d] = (const uint64_t *)(rp + o_start);
+                rowp.up[d] = (const uint32_t *)(rp + o_up);
+                rowp.adj[d] = rp + o_adj;
+            }
+        }
+        if (r != hipSuccess) return false;
         auto one_round = [&]() {
-            r = launch_loop_round(packed, buf<uint64_t>(ctx, SB_START), buf<uint32_t>(ctx, SB_CURSOR), buf<void>(ctx, SB_ADJ),
+            r = launch_loop_round(packed, rowp,
                                   buf<uint32_t>(ctx, SB_LEFT), nl, buf<uint32_t>(ctx, SB_CSTART), buf<uint32_t>(ctx, SB_CNT),
                                   buf<GreedyCand>(ctx, SB_CAND), buf<uint8_t>(ctx, SB_STATUS), buf<uint32_t>(ctx, SB_CHOICE),
                                   buf<uint32_t>(ctx, SB_ACTIVE), buf<uint32_t>(ctx, SB_DIRTY), rounds, d_first, d_taken, d_clcursor,

@@ -18,7 +18,7 @@ void Switches::read() {
     local_literal = flag("HMK_LOCAL_LITERAL");
     local_signed = flag("HMK_LOCAL_SIGNED");
     local_no_pk = flag("HMK_LOCAL_NO_PK");
-    multi_serial = flag("HMK_MULTI_SERIAL");
+    multi_replicate = flag("HMK_MULTI_REPLICATE");
     if (const char *v = getenv("HMK_SECOND_LOOP")) second_loop = std::strcmp(v, "device") == 0 ? 1 : 2;
     phase1_threads = std::max(0, num("HMK_PHASE1_THREADS", 0));
     phase1_window = std::max(0, num("HMK_PHASE1_WINDOW", 0));

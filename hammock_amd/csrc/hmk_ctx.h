@@ -45,7 +45,9 @@ enum {
     SB_BNCNT, SB_BNUP, SB_BNSTART, SB_BFTOP, SB_BFMORE, SB_FDEG, SB_FSTART, SB_FADJ, SB_TRCNT, SB_TRSTART,   // the band prepared for phase 1 (BandPack)
     SB_COF, SB_BITMAP, SB_USIZE, SB_LEFT, SB_CNT, SB_CSTART, SB_OVER, SB_SCAN2, SB_CAND,             // pre-check of the second loop
     SB_JOINED, SB_CSIZE, SB_CID, SB_SEQSZ, SB_STATUS, SB_CHOICE, SB_FIRST, SB_ACTIVE, SB_DIRTY, SB_SUBS2, SB_RETRY, SB_PRECNT, SB_ACCEPTED, SB_JSLOT, SB_LCOUNT, SB_SUBSTART, SB_SUBS,   // device-side second loop
-    SB_PEER, SB_PEERCNT, SB_PEERBAND, SB_PEERDEG,                                                     // edge blocks gathered from other devices (root) / compacted for the root (peers)
+    SB_PEER, SB_PEERCNT, SB_PEERBAND, SB_PEERDEG,   // multi-device calls: the inbox of edge blocks from the other devices + their counts, band blocks (peers: compacted; root: gathered), degree slices
+    SB_ROUTE, SB_ROUTECNT,                          // ... this device's edges dealt into one block per owning device; counts / offsets / cursors
+    SB_REPL,                                        // ... (in a peer's context, on the ROOT's device) the peer's piece copied to the root: no peer access, or HMK_MULTI_REPLICATE
     SB_N
 };
 
@@ -60,7 +62,8 @@ struct Switches {
     bool local_literal = false;   // HMK_LOCAL_LITERAL: LocalAlignmentScorer through the literal DP
     bool local_signed = false;    // HMK_LOCAL_SIGNED: the signed tagged-max form (what gap_open = 0 runs) for every penalty
     bool local_no_pk = false;     // HMK_LOCAL_NO_PK: one column sequence per lane in the tagged-max DP
-    bool multi_serial = false;    // HMK_MULTI_SERIAL: the conservative multi-device call (no worker threads, copies through the host)
+    bool multi_replicate = false; // HMK_MULTI_REPLICATE: a multi-device root copies the peers' finished adjacency pieces to itself instead of
+                                  // reading them in place (what a machine without peer access between two of its devices runs)
     int second_loop = 0;          // HMK_SECOND_LOOP=device|host: 1 / 2 force that implementation of the second loop (0: the default choice)
     int phase1_threads = 0, phase1_window = 0;        // HMK_PHASE1_THREADS, HMK_PHASE1_WINDOW (GreedyOptions)
     int host_band_rows = 0, host_band_far_t = 0;      // HMK_PHASE1_HOST_BAND=rows[,far_t] (GreedyOptions)
@@ -163,10 +166,9 @@ struct hmk_ctx {
     // hmk_create_multi: this context is the root (devices[0]); one sub-context per further device, each with its own
     // copy of the sequences, its plan (shard d of n) and its edge buffer.  Empty for a single-device context.
     std::vector<hmk_ctx *> peers;
-    // (in a peer's sub-context, created on the ROOT device:) the stream its blocks travel to the root on and the events the
-    // root's streams wait for
-    hipStream_t gather_stream = nullptr;
-    hipEvent_t ev_bandgather = nullptr, ev_gather = nullptr;
+    // the stream this device's blocks travel to the other devices on (multi-device calls; a stream of this device)
+    hipStream_t xfer_stream = nullptr;
+    bool peer_loads_ok = true;   // (a peer:) the root's kernels may read this device's memory in place
 
     // hmk_reserve sizes the two buffers a clustering call needs LAST (adjacency, bucket records: 2 x 11 GB at 10^6) on its own
     // thread: on some hosts a fresh 11 GB of device memory takes 0.3-1.5 s to get, and a call has 0.27 s of scoring to do
@@ -232,11 +234,19 @@ struct EdgeSource {
     EdgeSegs band_segs{};
     bool deg_fused = false;            // the neighbour kernel counted the rows' degrees while it wrote the edges (SB_DEG, zeroed before the pass)
     bool deg_split = false;            // ... as upper counts [0, n) and lower counts [n, 2n) instead of totals
+    // Multi-device calls: the adjacency is built in PIECES, piece d = the rows [d * rows_per, (d + 1) * rows_per) on device d, by that
+    // device's worker (hmk_multi.cpp): `segs` is not used; before_full says when every piece's CSR has been built, precheck_pieces runs
+    // the second loop's pre-check on every device for the leftovers whose rows it holds.
+    struct Piece { hmk_ctx *c; uint32_t r0, r1; };
+    std::vector<Piece> pieces;         // empty: one piece, the whole graph on this context
+    uint32_t rows_per = 0;
+    uint64_t total_edges = 0;          // (pieces: set by before_full) edges of all devices: the pieces' entries must add up to twice that
+    std::function<bool(const struct PreIn &, unsigned long long *total)> precheck_pieces;   // -> every piece fits; *total = candidate entries
     hmk_clinkage_stats *clink = nullptr;   // non-null: run the clinkage nearest-neighbour chain instead of the greedy merge
     // multi-device calls: the peers' blocks arrive while the calling thread is already inside cluster_on_device.
     //   before_band  blocks until every peer's band block is on its way to the root and makes the copy stream wait for them;
     //                non-zero: no band hand-over in this call (phase 1 then waits for the full graph)
-    //   before_full  blocks until every peer's edges are on their way, makes gstream wait for them and records ev_edges;
+    //   before_full  blocks until every device's piece of the adjacency is complete (its size in the device's h_counts[HC_TOTAL]);
     //                HMK_OK, ST_RETRY_OVERFLOW or an error code (the text is in the context)
     std::function<int()> before_band, before_full;
 };
@@ -281,6 +291,26 @@ int score_pairs(hmk_ctx *ctx, int scorer, const uint32_t *i, const uint32_t *j, 
 int score_block(hmk_ctx *ctx, int scorer, uint32_t r0, uint32_t r1, uint32_t c0, uint32_t c1, int a, int b,
                 int32_t *out);
 // ---- hmk_cluster.cpp
+// What the second loop's pre-check needs of the host (pinned, read-only while the pieces run): cluster_of | usize | leftover in one block
+struct PreIn {
+    uint32_t n = 0, nl = 0, ncl = 0;
+    bool packed = true;
+    const char *h_block = nullptr;       // pinned: cluster_of int32[n], usize int32[ncl], leftover uint32[nl]
+    size_t b_cof = 0, b_us = 0, b_left = 0;
+    unsigned long long region_cap = 0;   // entries per region of the candidate buffer (HMK_PRE_REGIONS regions)
+    int first_slots = 128;               // table size of the first stage
+    bool two_stage = true;
+};
+// CSR of the rows [r0, r1) from `segs` on c's device, enqueued on q (counts or the fused counters, scan, scatter); records c->ev_csr;
+// the piece's entry count lands in c->h_counts[HC_TOTAL], the score range / invalid edges in c->h_counts + HC_RANGE
+hipError_t piece_enqueue_csr(hmk_ctx *c, const EdgeSegs &segs, bool symmetric, bool packed, int base, uint32_t n, uint32_t r0, uint32_t r1,
+                             bool deg_fused, bool deg_split, hipStream_t q);
+// the pre-check of one piece (k_greedy_precheck, single pass with region counters): upload on c's copy stream, kernels on q behind the piece's
+// CSR, counters back, q synchronised.  -> 0: fits (entries in *total), 1: a region overran (count + fill passes needed), -1: failed / a row
+// overflowed its tables (the host's pre-check)
+int piece_precheck(hmk_ctx *c, const PreIn &in, uint32_t r0, uint32_t r1, uint32_t region_base, uint32_t region_count, hipStream_t q,
+                   bool upload, unsigned long long *total);
+hipError_t piece_precheck_upload(hmk_ctx *c, const PreIn &in);   // (the upload alone, on c's copy stream: records c->ev_bandcsr)
 int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int32_t *cluster_id, int32_t *result_order,
                       int32_t *member_rank, hmk_greedy_stats *stats, std::chrono::steady_clock::time_point t0);
 // ---- hmk_multi.cpp

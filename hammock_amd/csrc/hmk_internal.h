@@ -88,6 +88,17 @@ struct EdgeSeg { const uint64_t *edges; const unsigned long long *count; uint64_
 constexpr uint32_t HMK_MAX_SEGS = HMK_EDGE_SHARDS + 16;
 struct EdgeSegs { EdgeSeg s[HMK_MAX_SEGS]; uint32_t n; };
 
+// Where the adjacency rows of a clustering call live on the device side: one piece (this device's CSR), or -- a multi-device call --
+// one piece per device, device d holding the rows [d * rows_per, (d + 1) * rows_per) (its start[] / up[] are indexed by the row itself,
+// rows it does not own are empty).  The second loop's kernels run on the root and read a joiner's row where it lives.
+constexpr uint32_t HMK_MAX_DEVICES = 16;
+struct RowPieces {
+    const uint64_t *start[HMK_MAX_DEVICES];
+    const uint32_t *up[HMK_MAX_DEVICES];
+    const void *adj[HMK_MAX_DEVICES];
+    uint32_t rows_per;   // 0: one piece
+};
+
 // Optional device-side pre-check of the second loop (hmk_cluster.cpp provides it when the adjacency is still resident on
 // the GPU): given cluster_of[n] (-1 = none), the clusters' member counts and the leftover list, fill the candidate
 // CSR (cand_start[nl + 1], cand[]).  Returns false if it could not (the merge then fetches the whole adjacency and runs

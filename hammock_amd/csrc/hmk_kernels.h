@@ -50,10 +50,17 @@ hipError_t launch_neighbors_local_literal(const NeighborParams &P, uint32_t tile
 EdgeSegs shard_segments(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts, uint32_t first = 0,
                         uint32_t count = HMK_EDGE_SHARDS);
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
-                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s, uint32_t row_lo = 0);
+                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s, uint32_t row_lo = 0, uint32_t scan_rows = 0);
+// (only rows [row_lo, row_limit) are counted; scan_rows != 0: start[] gets that many rows + 1 -- a piece of a multi-device call)
 hipError_t launch_csr_scan_only(const uint32_t *deg, const uint32_t *deg_lo, uint64_t *start, uint32_t n, uint64_t *tile_scratch,
                                 int *score_range, hipStream_t s);
 hipError_t launch_add_u32(uint32_t *dst, const uint32_t *src, uint32_t n, hipStream_t s);   // dst[k] += src[k]
+// multi-device calls (rows [d * rows_per, (d + 1) * rows_per) belong to device d): a shard's edges dealt into one block per owning device
+// -- cnt / off / cur: device uint64[HMK_MAX_DEVICES + 1] each; block d = out[off[d] .. off[d + 1]) -- and the owner's degree counters
+// (its own + the g - 1 slices the others sent; rows it does not own cleared)
+hipError_t launch_route_edges(const EdgeSegs &segs, uint32_t rows_per, uint32_t g, unsigned long long *cnt, unsigned long long *off, unsigned long long *cur,
+                              uint64_t *out, uint64_t out_cap, hipStream_t s);
+hipError_t launch_owned_degrees(uint32_t *deg, uint32_t n, uint32_t r0, uint32_t r1, const uint32_t *const *slices, uint32_t n_slices, hipStream_t s);
 size_t scan_scratch_bytes(uint32_t n);       // bytes of tile_scratch for n counters
 size_t pack_rows_scratch_bytes(uint32_t n);  // bytes of launch_pack_rows' scratch
 // adj: Nbr[] or, if packed, NbrPacked[] = m << 8 | (score - base)
@@ -96,7 +103,9 @@ constexpr uint32_t HMK_PRE_REGIONS = 256;
 hipError_t launch_greedy_precheck(int mode, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
                                   const uint32_t *in_cluster, const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
                                   uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, unsigned long long *total,
-                                  unsigned long long capacity, uint32_t *retry, uint32_t *retry_count, int first_stage_slots, hipStream_t s);
+                                  unsigned long long capacity, uint32_t *retry, uint32_t *retry_count, int first_stage_slots, hipStream_t s,
+                                  uint32_t own_lo = 0, uint32_t own_hi = 0xFFFFFFFFu, uint32_t region_base = 0, uint32_t region_count = 0);
+// (own_lo / own_hi: only the leftovers with an id in that range; region_base / region_count: the regions of cand[] this launch fills, 0 = all)
 hipError_t launch_scan_u32(const uint32_t *counts, uint32_t *start, uint32_t n, uint64_t *tile_scratch, hipStream_t s);
 // where launch_scan_u32 leaves the 64-bit grand total inside tile_scratch (the uint32 start[n] wraps beyond 2^32 - 1)
 size_t scan_total_index(uint32_t n);
@@ -106,7 +115,7 @@ hipError_t launch_loop_subscribers(bool fill, uint32_t nl, const uint32_t *cand_
                                    uint32_t *cursor, const uint32_t *sub_start, uint64_t *subs, hipStream_t s);
 // one round; counters: device uint32[4] ([3] = tentative joiners the round's eval saw: 0 means the loop is over),
 // first / first_next: uint32[n_clusters] each; first must be all ones, first_next is reset for the next round
-hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
+hipError_t launch_loop_round(bool packed, const RowPieces &rows, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, const uint32_t *cand_cnt, GreedyCand *cand, uint8_t *status,
                              uint32_t *choice, uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken,
                              uint32_t *cursor, uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,

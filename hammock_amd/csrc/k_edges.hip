@@ -622,7 +622,10 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
                   const uint32_t *__restrict__ in_cluster,
                   const int32_t *__restrict__ usize, const uint32_t *__restrict__ leftover, uint32_t nl,
                   uint32_t *__restrict__ cand_cnt, uint32_t *__restrict__ cand_start, GreedyCand *__restrict__ cand,
-                  uint32_t *__restrict__ overflow, unsigned long long *__restrict__ total, unsigned long long capacity) {
+                  uint32_t *__restrict__ overflow, unsigned long long *__restrict__ total, unsigned long long capacity,
+                  uint32_t own_lo, uint32_t own_hi, uint32_t region_base, uint32_t region_count) {
+    // own_lo / own_hi: only the leftovers with an id in [own_lo, own_hi) are this launch's (a multi-device call checks every
+    // leftover where its adjacency row lives); region_base / region_count: the regions of cand[] this launch fills (PRE_SINGLE)
     __shared__ int32_t keys_all[PRE_WAVES * SLOTS];
     __shared__ uint32_t cnt_all[PRE_WAVES * SLOTS];
     __shared__ int32_t mn_all[PRE_WAVES * SLOTS];
@@ -643,6 +646,7 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
     for (uint32_t w = blockIdx.x * PRE_WAVES + wv; w < n_work; w += gridDim.x * PRE_WAVES) {
         const uint32_t q = work ? work[w] : w;
         const uint32_t y = leftover[q];
+        if (y < own_lo || y >= own_hi) continue;   // (wave-uniform)
         const uint64_t b = start[y], e = start[y + 1];
         bool full = false;
         auto insert = [&](const NbrT nb, int32_t c) {
@@ -720,7 +724,7 @@ k_greedy_precheck(const uint32_t *__restrict__ work, const uint32_t *__restrict_
         auto place = [&](uint32_t found) -> unsigned long long {
             unsigned long long base = 0;
             if (MODE == PRE_SINGLE) {
-                const uint32_t region = blockIdx.x % PRE_REGIONS;
+                const uint32_t region = region_base + blockIdx.x % region_count;
                 if (lane == 0 && found) base = atomicAdd(&total[region], (unsigned long long)found);
                 base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
                 region_end = (unsigned long long)(region + 1) * capacity;
@@ -1073,7 +1077,7 @@ constexpr int APPLY_SHIFT = 19;  // top 13 bits of the hash
 
 template <class NbrT>
 __global__ void __launch_bounds__(256)
-k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up, const NbrT *__restrict__ adj,
+k_loop_apply(const RowPieces rows,
              const uint32_t *__restrict__ leftover, uint8_t *status, GreedyCand *__restrict__ cand,
              const uint32_t *__restrict__ choice, const uint32_t *__restrict__ accepted, const uint32_t *__restrict__ sub_start,
              const unsigned long long *__restrict__ subs, uint32_t *cursor, LoopCluster *__restrict__ cl,
@@ -1116,7 +1120,11 @@ k_loop_apply(const uint64_t *__restrict__ start, const uint32_t *__restrict__ up
         // subscriber with several candidates ends the chain: its pick needs `eval`.
         for (;;) {
         const uint32_t y = leftover[q];
-        const uint64_t b = start[y], e = b + up[y];              // later leftovers have larger ids: the upper section
+        // the joiner's row lives on the device that owns it (one piece: this device's CSR; a multi-device call reads a peer's
+        // memory over xGMI -- a few KB per join)
+        const uint32_t piece = rows.rows_per ? y / rows.rows_per : 0u;
+        const NbrT *__restrict__ adj = (const NbrT *)rows.adj[piece];
+        const uint64_t b = rows.start[piece][y], e = b + rows.up[piece][y];   // later leftovers have larger ids: the upper section
         if (threadIdx.x == 0) next_idx = 0xFFFFFFFFu;            // (read after the barriers of the chunk loop)
         bool first_chunk = true;
         for (uint64_t c0 = b; c0 < e || first_chunk; c0 += APPLY_CHUNK) {
@@ -1277,7 +1285,7 @@ static EdgeSegs own_segments(const EdgeSegs &segs) {
 }
 
 hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row_limit, bool symmetric, uint32_t *deg,
-                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s, uint32_t row_lo) {
+                                  uint64_t *start, uint64_t *tile_scratch, int *score_range, hipStream_t s, uint32_t row_lo, uint32_t scan_rows) {
     if (segs.n == 0 || segs.n > HMK_MAX_SEGS) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_init_range, dim3(1), dim3(64), 0, s, score_range);
     if (row_limit < n && segs.n > HMK_EDGE_SHARDS) {   // band of a multi-device root: its own segments and the peers' blocks, each at its size
@@ -1287,7 +1295,7 @@ hipError_t launch_csr_degree_scan(const EdgeSegs &segs, uint32_t n, uint32_t row
     } else {
         hipLaunchKernelGGL(k_edge_degree, dim3(band_grid_x(segs, n, row_limit), segs.n), dim3(256), 0, s, segs, deg, symmetric ? 1 : 0, score_range, n, row_lo, row_limit);
     }
-    launch_scan<uint64_t>(deg, start, row_limit, tile_scratch, nullptr, s);
+    launch_scan<uint64_t>(deg, start, scan_rows ? scan_rows : row_limit, tile_scratch, nullptr, s);   // (scan_rows: deg[] covers more rows than were counted)
     return hipGetLastError();
 }
 
@@ -1407,12 +1415,14 @@ hipError_t launch_cluster_bitmap(const int32_t *cluster_of, uint32_t n, uint32_t
 hipError_t launch_greedy_precheck(int mode, bool packed, const uint64_t *start, const void *adj, const int32_t *cluster_of,
                                   const uint32_t *in_cluster, const int32_t *usize, const uint32_t *leftover, uint32_t nl, uint32_t *cand_cnt,
                                   uint32_t *cand_start, GreedyCand *cand, uint32_t *overflow, unsigned long long *total,
-                                  unsigned long long capacity, uint32_t *retry, uint32_t *retry_count, int first_stage_slots, hipStream_t s) {
+                                  unsigned long long capacity, uint32_t *retry, uint32_t *retry_count, int first_stage_slots, hipStream_t s,
+                                  uint32_t own_lo, uint32_t own_hi, uint32_t region_base, uint32_t region_count) {
     if (nl == 0) return hipSuccess;
+    if (region_count == 0) { region_base = 0; region_count = PRE_REGIONS; }
     const dim3 block(64 * PRE_WAVES);
 #define HMK_PRE(T, F, SL, GRID, WORK, WCNT, RETRY, RCNT)                                                                              \
     hipLaunchKernelGGL((k_greedy_precheck<T, F, SL>), dim3(GRID), block, 0, s, WORK, WCNT, RETRY, RCNT, start, (const T *)adj, cluster_of, \
-                       in_cluster, usize, leftover, nl, cand_cnt, cand_start, cand, overflow, total, capacity)
+                       in_cluster, usize, leftover, nl, cand_cnt, cand_start, cand, overflow, total, capacity, own_lo, own_hi, region_base, region_count)
     const uint32_t grid_big = std::min<uint32_t>((nl + PRE_WAVES - 1) / PRE_WAVES, 256 * 12 * 4 / PRE_WAVES),
                    grid_small = std::min<uint32_t>((nl + PRE_WAVES - 1) / PRE_WAVES, 256 * 32 * 4 / PRE_WAVES);
     if (mode == PRE_SINGLE && retry) {
@@ -1492,7 +1502,7 @@ hipError_t launch_loop_sort_subscribers(uint32_t n_clusters, const uint32_t *sub
 // one round of the device-side second loop (see k_loop_eval): eval, `passes` x (first, accept), apply.  counters: device
 // uint32[8]; lists2: two uint32[nl] eval lists, list (round & 1) is read and the other written; first, taken, cursor:
 // uint32[n_clusters] each (taken zeroed before the first round)
-hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t *up, const void *adj, const uint32_t *leftover,
+hipError_t launch_loop_round(bool packed, const RowPieces &rows, const uint32_t *leftover,
                              uint32_t nl, const uint32_t *cand_start, const uint32_t *cand_cnt, GreedyCand *cand, uint8_t *status,
                              uint32_t *choice, uint32_t *lists2, uint32_t *dirty, uint32_t round, uint32_t *first, uint32_t *taken,
                              uint32_t *cursor, uint32_t n_clusters, int passes, uint32_t *accepted, int32_t *join_slot,
@@ -1521,11 +1531,11 @@ hipError_t launch_loop_round(bool packed, const uint64_t *start, const uint32_t 
     // shown itself to be long; chain_mode 0 / 1 (HMK_LOOP_CHAIN) forces never / from the first round.
     const int chain = chain_mode >= 0 ? chain_mode : (round >= 256u ? 1 : 0);
     if (packed)
-        hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, start, up, (const NbrPacked *)adj, leftover, status, cand,
+        hipLaunchKernelGGL((k_loop_apply<NbrPacked>), agrid, block, 0, s, rows, leftover, status, cand,
                            choice, accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp,
                            cand_cnt, join_slot, chain);
     else
-        hipLaunchKernelGGL((k_loop_apply<Nbr>), agrid, block, 0, s, start, up, (const Nbr *)adj, leftover, status, cand, choice,
+        hipLaunchKernelGGL((k_loop_apply<Nbr>), agrid, block, 0, s, rows, leftover, status, cand, choice,
                            accepted, sub_start, sb, cursor, cl, seq_size, dirty, list_next, which, counters, host_word, stamp,
                            cand_cnt, join_slot, chain);
     return hipGetLastError();
@@ -1768,6 +1778,100 @@ hipError_t launch_band_prepare(const uint64_t *bstart, const uint32_t *bup, cons
                        fstart, fcur, fadj, h_near_start, h_near_up, h_far_top, h_far_more);
     hipLaunchKernelGGL(k_band_tr_fill, dim3(band_prep_grid(entries, R * tr_per_row)), dim3(256), 0, s, far_top, R, ft, tr_per_row, owner_of,
                        fstart, fdeg, fadj, tr_start, h_tr_owner, h_tr, h_tr_start);
+    return hipGetLastError();
+}
+
+// -----------------------------------------------------------------------------
+// multi-device calls: every row's adjacency is built on the device that OWNS the row
+// -----------------------------------------------------------------------------
+// Device d owns the rows [d * rows_per, (d + 1) * rows_per).  A device has scored a shard of the pair space; each of its edges
+// (x, m) goes to owner(x) and to owner(m) (once if they are the same device): one block per destination, counted first so that the
+// blocks lie back to back in `out` (off[dst] .. off[dst + 1]).  The blocks then travel device to device (all pairs at once: every
+// xGMI link carries its own pair's traffic, none more than 2 / G of a shard) instead of all of them to one root.
+__global__ void __launch_bounds__(256)
+k_route_count(const EdgeSegs segs, uint32_t rows_per, uint32_t g, unsigned long long *__restrict__ cnt) {
+    __shared__ uint32_t hist[HMK_MAX_DEVICES];
+    if (threadIdx.x < HMK_MAX_DEVICES) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const EdgeSeg sg = segs.s[blockIdx.y];
+    const uint64_t n_edges = min((uint64_t)*sg.count, sg.cap);
+    for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n_edges; k += (uint64_t)gridDim.x * 256) {
+        const uint64_t e = sg.edges[k];
+        const uint32_t dx = min(HMK_EDGE_X(e) / rows_per, g - 1), dm = min(HMK_EDGE_M(e) / rows_per, g - 1);
+        atomicAdd(&hist[dx], 1u);
+        if (dm != dx) atomicAdd(&hist[dm], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < g && hist[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+// off[0 .. g] = prefix sums of cnt, cur[] = 0 (one thread)
+__global__ void k_route_offsets(const unsigned long long *__restrict__ cnt, uint32_t g, unsigned long long *__restrict__ off, unsigned long long *__restrict__ cur) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    unsigned long long run = 0;
+    for (uint32_t d = 0; d < g; d++) { off[d] = run; run += cnt[d]; cur[d] = 0; }
+    off[g] = run;
+}
+__global__ void __launch_bounds__(256)
+k_route_fill(const EdgeSegs segs, uint32_t rows_per, uint32_t g, const unsigned long long *__restrict__ off, unsigned long long *__restrict__ cur,
+             uint64_t *__restrict__ out, unsigned long long out_cap) {
+    __shared__ uint32_t hist[HMK_MAX_DEVICES];
+    __shared__ unsigned long long base[HMK_MAX_DEVICES];
+    const EdgeSeg sg = segs.s[blockIdx.y];
+    const uint64_t n_edges = min((uint64_t)*sg.count, sg.cap);
+    for (uint64_t k0 = (uint64_t)blockIdx.x * 256; k0 < n_edges; k0 += (uint64_t)gridDim.x * 256) {   // workgroup-uniform
+        if (threadIdx.x < HMK_MAX_DEVICES) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t k = k0 + threadIdx.x;
+        const bool live = k < n_edges;
+        const uint64_t e = live ? sg.edges[k] : 0;
+        const uint32_t dx = min(HMK_EDGE_X(e) / rows_per, g - 1), dm = min(HMK_EDGE_M(e) / rows_per, g - 1);
+        uint32_t px = 0, pm = 0;
+        if (live) { px = atomicAdd(&hist[dx], 1u); if (dm != dx) pm = atomicAdd(&hist[dm], 1u); }
+        __syncthreads();
+        if (threadIdx.x < g && hist[threadIdx.x]) base[threadIdx.x] = off[threadIdx.x] + atomicAdd(&cur[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+        __syncthreads();
+        if (live) {
+            if (base[dx] + px < out_cap) out[base[dx] + px] = e;
+            if (dm != dx && base[dm] + pm < out_cap) out[base[dm] + pm] = e;
+        }
+        __syncthreads();
+    }
+}
+hipError_t launch_route_edges(const EdgeSegs &segs, uint32_t rows_per, uint32_t g, unsigned long long *cnt, unsigned long long *off, unsigned long long *cur,
+                              uint64_t *out, uint64_t out_cap, hipStream_t s) {
+    if (g == 0 || g > HMK_MAX_DEVICES || segs.n == 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(cnt, 0, HMK_MAX_DEVICES * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_route_count, dim3(128, segs.n), dim3(256), 0, s, segs, rows_per, g, cnt);
+    hipLaunchKernelGGL(k_route_offsets, dim3(1), dim3(64), 0, s, cnt, g, off, cur);
+    hipLaunchKernelGGL(k_route_fill, dim3(128, segs.n), dim3(256), 0, s, segs, rows_per, g, off, cur, out, (unsigned long long)out_cap);
+    return hipGetLastError();
+}
+
+// The rows' degree counters of the OWNING device: every device counted upper and lower degrees (deg[0, n) and deg[n, 2n)) of ALL rows over
+// the edges it scored; the owner of [r0, r1) adds the other devices' counters of its rows (slices[d]: up[r1 - r0] then lo[r1 - r0], g - 1 of
+// them) to its own and clears the rows it does not own -- the CSR it builds holds its rows only.
+struct DegSlices { const uint32_t *p[HMK_MAX_DEVICES]; uint32_t n; };
+__global__ void __launch_bounds__(256)
+k_owned_degrees(uint32_t *__restrict__ deg, uint32_t n, uint32_t r0, uint32_t r1, const DegSlices slices) {
+    const uint32_t len = r1 - r0;
+    for (uint32_t x = blockIdx.x * 256 + threadIdx.x; x < n; x += gridDim.x * 256) {
+        uint32_t up = 0, lo = 0;
+        if (x >= r0 && x < r1) {
+            up = deg[x];
+            lo = deg[n + x];
+            for (uint32_t d = 0; d < slices.n; d++) { up += slices.p[d][x - r0]; lo += slices.p[d][len + x - r0]; }
+        }
+        deg[x] = up;
+        deg[n + x] = lo;
+    }
+}
+hipError_t launch_owned_degrees(uint32_t *deg, uint32_t n, uint32_t r0, uint32_t r1, const uint32_t *const *slices, uint32_t n_slices, hipStream_t s) {
+    if (n_slices > HMK_MAX_DEVICES) return hipErrorInvalidValue;
+    DegSlices ds{};
+    ds.n = n_slices;
+    for (uint32_t d = 0; d < n_slices; d++) ds.p[d] = slices[d];
+    hipLaunchKernelGGL(k_owned_degrees, dim3(std::min<uint32_t>((n + 255) / 256, 2048)), dim3(256), 0, s, deg, n, r0, r1, ds);
     return hipGetLastError();
 }
 

@@ -464,12 +464,13 @@ def test_greedy_3e5_vs_oracle(gpu, blosum62, coracle):
 
 @pytest.mark.parametrize("devices", [pytest.param([0], id="dev0")] + multi_device_lists(repeated=((0, 0), (0, 0, 0), (0,) * 8)))
 def test_greedy_multi_device_context(gpu, blosum62, coracle, devices, monkeypatch):
-    """hmk_create_multi: the multi-GPU form below the C ABI.  On a one-GPU box the device list names it one, two and
-    three times -- every "device" has its own context, worker thread, plan (shard d of n, band tiles first), edge buffer and
-    streams; the peers' band blocks and edge blocks reach the root through hipMemcpyPeerAsync behind the peers' own events,
-    the root builds the band's adjacency and later the CSR over root segments + gathered blocks while phase 1 runs on the
-    host.  With two or more GPUs the same test runs on distinct ordinals (peer access, real xGMI copies).  Must equal the
-    single-device call and the oracle."""
+    """hmk_create_multi: the multi-GPU form below the C ABI.  On a one-GPU box the device list names it one, two, three and
+    eight times -- every "device" has its own context, worker thread, plan (shard d of n, band tiles first), edge buffer and
+    streams, and OWNS a range of rows: its edges are dealt into one block per owning device and travel device to device
+    (hipMemcpyPeerAsync), every device builds the CSR of its own rows and pre-checks the leftovers whose rows it holds; the
+    root builds the band's adjacency, runs phase 1 on the host and the second loop over all candidate lists, reading a joiner's
+    row where it lives.  With two or more GPUs the same test runs on distinct ordinals (peer access, real xGMI copies).  Must
+    equal the single-device call and the oracle."""
     n = 40000
     res, off = synth_peptides(21, n, 12)
     rng = np.random.default_rng(21)
@@ -487,14 +488,24 @@ def test_greedy_multi_device_context(gpu, blosum62, coracle, devices, monkeypatc
         cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)
         assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
         assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+    assert ctx.greedy_phases()["loop_rounds"] > 0          # the second loop ran on the device (over the pieces)
     if len(devices) > 1:
-        # HMK_MULTI_SERIAL=1, the conservative form kept beside the overlapped one: peers one after the other on the calling
-        # thread, no band, blocks and row degrees through host memory instead of peer copies
-        monkeypatch.setenv("HMK_MULTI_SERIAL", "1")
+        # HMK_MULTI_REPLICATE=1: what a machine without peer access between two of its devices runs -- the root copies the
+        # peers' finished pieces to itself and reads the joiners' rows there
+        monkeypatch.setenv("HMK_MULTI_REPLICATE", "1")
         cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)
-        monkeypatch.delenv("HMK_MULTI_SERIAL")
+        monkeypatch.delenv("HMK_MULTI_REPLICATE")
         assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
         assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+        monkeypatch.setenv("HMK_SECOND_LOOP", "host")          # the host's loop over rows fetched from the pieces
+        cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)
+        monkeypatch.delenv("HMK_SECOND_LOOP")
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+        assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+        monkeypatch.setenv("HMK_NO_BAND", "1")                 # phase 1 over whole rows fetched from the pieces
+        cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)
+        monkeypatch.delenv("HMK_NO_BAND")
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
         cid, order, stats = ctx.greedy_cluster(3, 0, 20, 1000)   # and back
         assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
     single = hammock_amd.Context(blosum62, device=0)
@@ -969,11 +980,7 @@ def test_clinkage_vs_oracle(gpu, blosum62, coracle, name):
             multi.set_sequences(residues=res, offsets=off, sizes=sizes)
             cid, order, _ = multi.clinkage_cluster(X, p, thr)
             assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(multi.member_rank[:len(cid)], orank)
-            os.environ["HMK_MULTI_SERIAL"] = "1"   # the conservative form of the multi-device call: same function, same answer
-            try:
-                cid, order, _ = multi.clinkage_cluster(X, p, thr)
-            finally:
-                del os.environ["HMK_MULTI_SERIAL"]
+            cid, order, _ = multi.clinkage_cluster(X, p, thr)   # (a second call: grown buffers, cached plans)
             assert np.array_equal(cid, ocid) and np.array_equal(order, oorder) and np.array_equal(multi.member_rank[:len(cid)], orank)
 
 
