@@ -513,6 +513,9 @@ def main():
             "edges_per_step": int(tot_edges.item()),
         }
         if px is not None:
+            # (both are asserted above: a line that exists has passed them)
+            line["checks"] = {"pairs_of_all_ranks_equal_the_pair_space": True, "gathered_edges_equal_the_sum_of_the_shards": True,
+                              "backend": os.environ.get("HMK_BENCH_BACKEND", "nccl"), "ranks_share_one_gpu": os.environ.get("HMK_BENCH_SHARE_GPU") == "1"}
             line["exchange"] = {"format": px.fmt, "gathered_bytes_per_rank_per_step": px.bytes_per_step,
                                 "collectives_per_step": 1}
         maxc = int(np.floor(n * 0.025 + 0.5))

@@ -33,6 +33,7 @@ struct DevJob {
     uint64_t edges = 0, band_total = 0, band_region = 0, band_off = 0;
     unsigned long long pre_total = 0;
     uint64_t need_edges = 0, need_inbox = 0;   // (-2) what the next attempt must hold
+    double t_band = 0, t_scored = 0, t_sent = 0, t_csr = 0, t_pre = 0;   // HMK_GREEDY_TIMING: ms since the call began
 };
 
 int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters, int32_t *cluster_id,
@@ -167,6 +168,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             unsigned long long *h_rcnt = c->h_counts + HC_PEER;                          // pinned: the G block sizes, then [16] the band block's
             uint64_t *d_route = buf<uint64_t>(c, SB_ROUTE);
             hipError_t e = hipSuccess;
+            auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
             r = build_plan(c, max_shift, shift_penalty, threshold, d, G, band_req);
             if (r) { fail_job(J, r, c->err); return; }
             if (d == 0) ctx->phases.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -206,6 +208,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                         if (e == hipSuccess) e = hipMemcpyPeerAsync(root_cnt + HMK_MAX_SEGS + d, ctx->device, d_rcnt + HMK_MAX_DEVICES, c->device, 8, X);
                         if (e == hipSuccess) e = hipStreamSynchronize(X);   // (landed: the root's copy stream needs no event of another device)
                         if (e != hipSuccess) { hip_fail("band hand-over", e); return; }
+                        J.t_band = now_ms();
                         set_state(&DevJob::band_state, J, 1);
                     }
                 } else set_state(&DevJob::band_state, J, -1);
@@ -213,6 +216,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             // -- the blocks to their owners: once the shard is scored and dealt --
             e = hipEventSynchronize(c->ev_edges);
             if (e != hipSuccess) { hip_fail("shard", e); return; }
+            J.t_scored = now_ms();
             {
                 unsigned long long mx = 0;
                 J.edges = 0;
@@ -247,6 +251,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             }
             if (e == hipSuccess) e = hipStreamSynchronize(X);
             if (e != hipSuccess) { hip_fail("edge blocks to their owners", e); return; }
+            J.t_sent = now_ms();
             set_state(&DevJob::sent_state, J, 1);
             // -- its piece of the CSR: the rows [r0, r1) from its own block and the G - 1 it received --
             if (wait_all(&DevJob::sent_state) < 0) return;
@@ -262,6 +267,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                 if (e == hipSuccess) e = piece_enqueue_csr(c, in, symmetric, packed, threshold, n, J.r0, J.r1, fuse, fuse, Q);
                 if (e != hipSuccess) { hip_fail("CSR piece", e); return; }
                 set_state(&DevJob::csr_state, J, 1);
+                if (ctx->sw.greedy_timing && hipEventSynchronize(c->ev_csr) == hipSuccess) J.t_csr = now_ms();
             }
             // -- the second loop's pre-check for the leftovers whose rows live here, once phase 1 is over on the host --
             {
@@ -292,6 +298,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                 if (e == hipSuccess) e = hipStreamSynchronize(X);
                 if (e != hipSuccess) { hip_fail("candidate lists to the root", e); set_state(&DevJob::pre_state, J, -1); return; }
             }
+            J.t_pre = now_ms();
             set_state(&DevJob::pre_state, J, 1);
         };
         // (an exception inside a worker -- bad_alloc from the plan -- must end as this call's error, not as std::terminate; whatever
@@ -383,6 +390,12 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
         }
         cv.notify_all();
         for (auto &jp : jobs) if (jp->th.joinable()) jp->th.join();
+        if (ctx->sw.greedy_timing)
+            for (auto &jp : jobs)
+                fprintf(stderr, "[hmk greedy] device %u of %u (HIP device %d, rows %u..%u): band block on the root at %.2f ms, shard scored and dealt at %.2f, blocks on their "
+                                "owners at %.2f, its CSR piece done at %.2f (%llu entries), its pre-check on the root at %.2f (%llu candidate entries)\n",
+                        jp->d, G, jp->c->device, jp->r0, jp->r1, jp->t_band, jp->t_scored, jp->t_sent, jp->t_csr, (unsigned long long)jp->c->h_counts[HC_TOTAL], jp->t_pre,
+                        jp->pre_total);
         for (auto &jp : jobs) {
             if (jp->sent_state == -2) overflow = true;
             want_edges[jp->d] = std::max(want_edges[jp->d], jp->need_edges);
