@@ -197,8 +197,10 @@ k_edge_scatter(const EdgeSegs segs, const uint64_t *__restrict__ start, uint32_t
 // the adjacency.  Three streaming passes over the edges instead of one pass of random writes.
 constexpr uint32_t LB_MAX_BUCKETS = 4096;   // LDS tables of the partition kernel: 2 x 16 KB
 constexpr uint32_t LB_MAX_ROWS = 4096;      // rows of a bucket (shift <= 12)
-constexpr int LB_LOADS = 16;                  // edges a thread of the dealing kernel holds: all of them loads in flight at once (4 / 8 / 16: 22.1 / 21.5 / 20.4 ms at 10^6)
-constexpr uint32_t LB_CHUNK = LB_LOADS * 1024;   // edges a workgroup deals at a time
+// Edges a thread of the dealing kernel holds (all of them loads in flight at once: 4 / 8 / 16 gave 22.1 / 21.5 / 20.4 ms at 10^6); a workgroup
+// deals LOADS x 1024 edges at a time.  Small graphs take 4: the 12.8 M edges of a 10^5 call are 195 chunks of 16,384 -- fewer than the grid's
+// workgroups, each a 160 us chain -- but 780 of 4,096.
+constexpr int LB_LOADS_LARGE = 16, LB_LOADS_SMALL = 4;
 
 // an edge the degree pass counted (k_edge_degree: both ends in [0, n), no self pair); ~0 marks "no edge" in the unrolled loads
 __device__ __forceinline__ bool lower_record_ok(uint64_t e, uint32_t n) {
@@ -281,12 +283,14 @@ k_lower_offsets(const unsigned long long *__restrict__ bucket_cnt, uint32_t nb, 
 // records: row m << 32 | the packed entry (x << 8 | score - base) of m's lower section
 // The same pass over the edges also writes the entries of the UPPER sections (row x = the smaller end) straight into the
 // adjacency, with k_edge_scatter's wave-grouped atomics -- one read of the edge list less (10 GB at 10^6).
+template <int LB_LOADS>
 __global__ void __launch_bounds__(1024)
 k_lower_partition(const EdgeSegs segs, uint32_t shift, uint32_t nb, uint32_t n, uint32_t row_lo, uint32_t row_hi, int base, const unsigned long long *__restrict__ bucket_off,
                   unsigned long long *__restrict__ bucket_fill, uint64_t *__restrict__ recs, const uint64_t *__restrict__ start,
                   uint32_t *__restrict__ cursor, NbrPacked *__restrict__ adj) {
     __shared__ uint32_t hist[LB_MAX_BUCKETS];
     __shared__ uint32_t first[LB_MAX_BUCKETS];   // where this chunk's records of a bucket start, relative to bucket_off (< 2^32: a bucket holds < 2^12 rows x 2^20)
+    constexpr uint32_t LB_CHUNK = LB_LOADS * 1024;
     uint32_t g = blockIdx.x;                     // chunk index over the concatenated segments
     for (uint32_t sgi = 0; sgi < segs.n; sgi++) {
         const EdgeSeg sg = segs.s[sgi];
@@ -1331,7 +1335,10 @@ hipError_t launch_csr_scatter(const EdgeSegs &segs, bool symmetric, const uint64
 // recs = one uint64 per edge.  n < 2^24 (edge format), so 2^shift rows per bucket with shift <= 12 always give <= 4096 buckets.
 constexpr uint32_t CSR_PARTITION_GRID = 512;   // two 1,024-thread workgroups per CU (256 / 512 / 1024: 19.8 / 19.4 / 19.5 ms for the CSR at 10^6)
 uint32_t csr_partition_shift(uint32_t n, int forced_shift) {
+    // 512 rows per bucket (2,048 workgroups of the placing kernel at 10^6); small graphs take smaller buckets so that the placing kernel still
+    // has a few hundred workgroups (10^5: 128 rows, 782 buckets -- with 512 rows its 196 workgroups placed 65,536 records each, one after the other)
     uint32_t shift = 9;
+    while (shift > 6 && (n >> shift) < 512) shift--;
     if (forced_shift > 0) shift = (uint32_t)std::min(12, std::max(9, forced_shift));   // tests (HMK_CSR_BUCKET_SHIFT): the wide buckets of n > 2^21
     while (((uint64_t)n + (1u << shift) - 1) >> shift > LB_MAX_BUCKETS) shift++;
     return shift;
@@ -1356,8 +1363,14 @@ hipError_t launch_csr_scatter_partitioned(const EdgeSegs &segs, const uint64_t *
     // (10^6 sequences, round 2: 64 / 128 / 256 / 512 workgroups gave a CSR in 57 / 42 / 35 / 36 ms with ONE load in flight per thread;
     // the kernel is bound by memory latency: 4 loads in flight 22.1 ms, 8: 21.5, 16 with the chunk kept in registers: 19.8)
     // the upper sections in the same pass over the edges
-    hipLaunchKernelGGL(k_lower_partition, dim3(CSR_PARTITION_GRID), dim3(1024), 0, s, segs, shift, nb, n, row_lo, row_hi, base, off, fill, recs, start,
-                       cursor, (NbrPacked *)adj);
+    uint64_t held = 0;   // edges the segments can hold: which chunk size the dealing takes
+    for (uint32_t q = 0; q < segs.n; q++) held += segs.s[q].cap;
+    if (held >= (uint64_t)CSR_PARTITION_GRID * LB_LOADS_LARGE * 1024 * 8)
+        hipLaunchKernelGGL(k_lower_partition<LB_LOADS_LARGE>, dim3(CSR_PARTITION_GRID), dim3(1024), 0, s, segs, shift, nb, n, row_lo, row_hi, base, off, fill, recs,
+                           start, cursor, (NbrPacked *)adj);
+    else
+        hipLaunchKernelGGL(k_lower_partition<LB_LOADS_SMALL>, dim3(CSR_PARTITION_GRID), dim3(1024), 0, s, segs, shift, nb, n, row_lo, row_hi, base, off, fill, recs,
+                           start, cursor, (NbrPacked *)adj);
     if ((1u << shift) <= LP_ROWS)
         hipLaunchKernelGGL(k_lower_place_sorted, dim3(nb), dim3(512), 0, s, recs, off, shift, n, start, cursor, n, (NbrPacked *)adj);
     else
