@@ -52,12 +52,12 @@ def load_blosum62():
 
 def pmc_traffic(n, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/round4_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
+    (profiles/round5_pmc_summary.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very
     command, gfx950 x2 read correction applied).  Counters cannot be read from inside the timed
     run, so the value is only reported for the workload it was collected on; otherwise null."""
     try:
         d = None
-        for name in ("round4_pmc_summary.json", "round3_pmc_summary.json"):
+        for name in ("round5_pmc_summary.json", "round4_pmc_summary.json"):
             path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(path):
                 with open(path) as fh:
@@ -394,7 +394,7 @@ def main():
         else:
             px.step(t0, t1)
 
-    # An idle MI355X needs about 25 ms of load to reach its clocks (tools/probes/warmup.sh: 20 timed steps after 3 / 5 / 10 / 20
+    # An idle MI355X needs about 25 ms of load to reach its clocks (profiles/round3_bench_warmup.log: 20 timed steps after 3 / 5 / 10 / 20
     # untimed ones take 2.60 / 2.58 / 2.53 / 2.53 ms each): SETTLE_STEPS untimed passes first, then the W warm-up steps the
     # contract asks for, then exactly K timed steps.  Reported in the line as "settle_steps".
     # First the contract's sequence taken literally -- W warm-up steps from an idle GPU, then K timed steps -- reported beside
@@ -505,7 +505,7 @@ def main():
                                         f"{lds_per_pair} LDS bytes per pair ({SEQ_LEN} ds_read_b64 table lookups) ") +
                                        "x pairs per launch / kernel time, against 256 B/clk/CU x 256 CU x 2.4 GHz "
                                        "(MI355X_MICROARCH.md, LDS table)",
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/round4_pmc_summary.json); "
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes (profiles/round5_pmc_summary.json, tools/collect_round5.sh); "
                                          "null when the workload differs from the one the counters were collected on",
                          "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,

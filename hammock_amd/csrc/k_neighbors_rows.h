@@ -400,11 +400,11 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
     } nx;
     // record index -> where it lies in the stage (two-ended: indices >= cnt_lo count down from the stage's top)
     auto stage_at = [&](uint32_t k) -> uint32_t { return (TWO && k >= cnt_lo) ? stage[(uint32_t)STAGE_CAP - 1u - (k - cnt_lo)] : stage[k]; };
-    auto decode = [&](uint32_t k0) {
-        const bool live = k0 + lane < cnt;
-        const uint32_t rec = live ? stage_at(k0 + lane) : 0u;
-        // the record (see the append loop): bit q of the lane's hit word at the step that looked, noted `back` steps earlier
-        const uint32_t q = (rec >> 16) & 31u, grp = rec >> 21;
+    // records [f, e) of the wave's stage, one per lane, decoded into nx (see the append loop for the record's fields)
+    auto decode = [&](uint32_t f, uint32_t e) {
+        const bool live = f + lane < e;
+        const uint32_t rec = live ? stage_at(f + lane) : 0u;
+        const uint32_t q = (rec >> 16) & 31u, grp = rec >> 21;   // bit q of the lane's hit word at the step that looked
         const uint32_t b = DEFER ? q | 3u : q;                // where the bit was when its step noted it
         const uint32_t back = DEFER ? 3u - (q & 3u) : 0u;     // ... that many steps ago
         const uint32_t r = (b >> 3) + 4u - (b & 4u);          // bit 8r + 7: row r; bit 8r + 3: row 4 + r
@@ -443,8 +443,6 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         nx.px = A.perm_identity ? A.row0 + nx.rt : p0;
         nx.pm = A.perm_identity ? nx.mcol : p1;
     };
-    decode(0);
-    statement();
     const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
     const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
     base = ((unsigned long long)bhi << 32) | blo;
@@ -452,18 +450,11 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
     // iteration never mixes groups.  k indexes RECORDS (what decode / stage_at take); `it` walks iterations.
     const uint32_t lo_iters = TWO ? (cnt_lo + 63u) / 64u : (cnt + 63u) / 64u;
     const uint32_t n_iters = TWO ? lo_iters + (cnt_hi + 63u) / 64u : lo_iters;
-    // first record and record count of iteration `it`
+    // first record and the end of the records of iteration `it`
     auto iter_first = [&](uint32_t it) -> uint32_t { return (TWO && it >= lo_iters) ? cnt_lo + (it - lo_iters) * 64u : it * 64u; };
     auto iter_end = [&](uint32_t it) -> uint32_t { return (TWO && it < lo_iters) ? cnt_lo : cnt; };
-    if constexpr (TWO) {   // (the first decode above read records 0 .. 63 of the plain order: redo it for the iteration's bounds)
-        const uint32_t f = iter_first(0), e = iter_end(0);
-        const bool live = f + lane < e;
-        const uint32_t rec = live ? stage_at(f + lane) : 0u;
-        const uint32_t q = (rec >> 16) & 31u, grp = rec >> 21, b = q | 3u, back = 3u - (q & 3u), r = (b >> 3) + 4u - (b & 4u);
-        nx.rt = live ? grp * 8u + r : 0u;
-        nx.mcol = A.col0 + (live ? (rec & 0xFFFFu) - back * 256u : 0u);
-        statement();
-    }
+    decode(iter_first(0), iter_end(0));
+    statement();
     for (uint32_t it = 0; it < n_iters; it++) {   // wave-uniform trip count: the table reads below run for whole waves
         const uint32_t k = iter_first(it) + lane;
         const bool live = k < iter_end(it);
@@ -513,59 +504,28 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
             const uint32_t grp = rt >> 3;
             S::template offsets_of<true>(words, tw, tab + grp * (uint32_t)S::GROUP_STEP + (r & 4u), 0u, off, toff);
             const uint32_t sh = (r & 3u) * 8u;
-            if constexpr (EXACT_LB) {
-                // one length: every plane's cells are known at compile time (plane u pairs column position j with row position
-                // i = j + u - X wherever 0 <= i < la -- ShiftedScorer.java:67-77), one plane's reads in flight at a time
-#pragma unroll
-                for (int u = 0; u < S::ND; u++) {
-                    constexpr int LA = CAP + D;
-                    const int jlo = X - u > 0 ? X - u : 0, jhi = LA + X - u < CAP ? LA + X - u : CAP;
-                    uint32_t a = ((A.cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
-                    int j = jlo;
-                    if ((jhi - jlo) & 1) { a += rows_table_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, j + u - X)); j++; }
-#pragma unroll
-                    for (; j + 1 < jhi; j += 2) {
-                        const uint32_t e0 = rows_table_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, j + u - X));
-                        const uint32_t e1 = rows_table_read<uint32_t>(off[j + 1] + (uint32_t)S::pos_addr(0, j + 1 + u - X));
-                        a = a + e0 + e1;
-                    }
-                    asm volatile("" : "+v"(a));
-                    mx = max(mx, (a >> sh) & 0xFFu);
-                }
-            } else {
-                // One plane at a time, in a loop that is NOT unrolled (this path is cold and must stay small in registers): the
-                // plane's cells straight from the position table, row position i = j + u - X wherever it lies inside the row -- the
-                // literal form of ShiftedScorer.java:67-77 on the packed cells, independent of the main loop's unrolled schedule.
+            static_assert(!EXACT_LB, "one-length rescoring shapes are two-ended");
+            // One plane at a time, in a loop that is NOT unrolled (this path is cold and must stay small in registers): the
+            // plane's cells straight from the position table, row position i = j + u - X wherever it lies inside the row -- the
+            // literal form of ShiftedScorer.java:67-77 on the packed cells, independent of the main loop's unrolled schedule.
 #pragma unroll 1
-                for (int u = 0; u < S::ND; u++) {
-                    uint32_t cw = A.cinit[0];
+            for (int u = 0; u < S::ND; u++) {
+                uint32_t cw = A.cinit[0];
 #pragma unroll
-                    for (int q = 1; q < 8; q++) cw = (u >> 2) == q ? A.cinit[q] : cw;
-                    uint32_t a = ((cw >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
+                for (int q = 1; q < 8; q++) cw = (u >> 2) == q ? A.cinit[q] : cw;
+                uint32_t a = ((cw >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
 #pragma unroll
-                    for (int j = 0; j < CAP; j++) {
-                        const int i = j + u - X;
-                        if (j < lbs && i >= 0 && i < la)   // wave-uniform
-                            a += lds_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, i));
-                    }
-                    mx = max(mx, (a >> sh) & 0xFFu);
+                for (int j = 0; j < CAP; j++) {
+                    const int i = j + u - X;
+                    if (j < lbs && i >= 0 && i < la)   // wave-uniform
+                        a += lds_read<uint32_t>(off[j] + (uint32_t)S::pos_addr(0, i));
                 }
+                mx = max(mx, (a >> sh) & 0xFFu);
             }
         }
         const int score = (int)mx - 128 + A.threshold;   // lane = 128 - threshold + score
         // the next iteration's records (past the last one: every lane reads the tile's first column -- harmless, and no branch)
-        {
-            const uint32_t f = it + 1 < n_iters ? iter_first(it + 1) : cnt, e = it + 1 < n_iters ? iter_end(it + 1) : cnt;
-            if constexpr (TWO) {
-                const bool lv = f + lane < e;
-                const uint32_t rec = lv ? stage_at(f + lane) : 0u;
-                const uint32_t q = (rec >> 16) & 31u, grp = rec >> 21, b = q | 3u, back = 3u - (q & 3u), rr = (b >> 3) + 4u - (b & 4u);
-                nx.rt = lv ? grp * 8u + rr : 0u;
-                nx.mcol = A.col0 + (lv ? (rec & 0xFFFFu) - back * 256u : 0u);
-            } else {
-                decode(f);
-            }
-        }
+        if (it + 1 < n_iters) decode(iter_first(it + 1), iter_end(it + 1)); else decode(cnt, cnt);
         statement();
         if (ok) {
             const unsigned long long e = ((unsigned long long)x << 40) | ((unsigned long long)m << 16) | (unsigned long long)((uint32_t)score & 0xFFFFu);

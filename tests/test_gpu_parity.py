@@ -930,7 +930,7 @@ def test_hand_traced_local_alignment_on_gpu(gpu, monkeypatch):
         assert ctx.score_pairs_local(i, j, go, ge).tolist() == want, (go, ge)
         block = ctx.score_block_local(0, n, 0, n, go, ge)            # [seq1 (row), seq2 (column)]
         assert [int(block[a, b]) for a, b in zip(i, j)] == want, (go, ge)
-        for env in (None, "HMK_LOCAL_SIGNED", "HMK_LOCAL_NO_PK"):
+        for env in (None, "HMK_LOCAL_SIGNED", "HMK_LOCAL_NO_PK", "HMK_LOCAL_LITERAL"):
             if env:
                 monkeypatch.setenv(env, "1")
             edges, _ = ctx.neighbors_local(go, ge, 1)
@@ -1218,8 +1218,10 @@ def test_cli_greedy_random_order_and_label_filter(gpu, blosum62, coracle, tmp_pa
             fh.write(f">{k}|{1 + int(rng.integers(0, 9))}|{lab}\n{s}\n" if lab else f">{k}\n{s}\n")
     out = str(tmp_path / "out")
     r = subprocess.run([cli, "greedy", "-i", fa, "-d", out, "-R", "random", "-S", "7", "-l", "lab_a,no_label",
-                        "-p", "-1", "-x", "2", "-g", "0x12"], capture_output=True, text=True)
+                        "-p", "-1", "-x", "2", "-g", "0x12"], capture_output=True, text=True,
+                       env=dict(os.environ, HMK_CLI_TIMING="1"))   # the stage timings on stderr change no file
     assert r.returncode == 0, r.stderr
+    assert "[hammock-hip]" in r.stderr
     labels = ["lab_a", "no_label"]
     seqs = []
     for s in po.load_unique_sequences_from_fasta(fa):  # filterSequencesForLabels, Hammock.java:1661-1675
@@ -1433,7 +1435,8 @@ def test_neighbors_local_vs_oracle(gpu, matrices, coracle, cfg):
 
 def test_neighbors_local_signed_form_still_exact(gpu, matrices, coracle, monkeypatch):
     """HMK_LOCAL_SIGNED=1 runs the packed DP of rounds 1-3 (signed candidates, a maximum against zero per cell, full last strip)
-    instead of the saturating form: what gap_open == 0 still takes.  Same edges."""
+    instead of the saturating form: what gap_open == 0 still takes; HMK_LOCAL_LITERAL=1 the one-pair-per-lane literal DP
+    (what matrices beyond int8 take).  Same edges."""
     M = matrices["blosum62"]
     res, off = synth_peptides(11, 900, 7, 20)
     ctx, _, _ = ctx_for(M, res=res, off=off)
@@ -1448,8 +1451,12 @@ def test_neighbors_local_signed_form_still_exact(gpu, matrices, coracle, monkeyp
         monkeypatch.setenv("HMK_LOCAL_SIGNED", "1")
         old, _ = ctx.neighbors_local(go, ge, thr)
         monkeypatch.delenv("HMK_LOCAL_SIGNED")
+        monkeypatch.setenv("HMK_LOCAL_LITERAL", "1")
+        lit, _ = ctx.neighbors_local(go, ge, thr)
+        monkeypatch.delenv("HMK_LOCAL_LITERAL")
         assert np.array_equal(np.sort(new), want), (go, ge)
         assert np.array_equal(np.sort(old), want), (go, ge)
+        assert np.array_equal(np.sort(lit), want), (go, ge)
 
 
 def test_neighbors_local_wide_matrix_literal_tier(gpu, coracle):

@@ -156,6 +156,10 @@ def test_greedy_phase1_window_scans_match_oracle(blosum62, coracle, monkeypatch,
     and the cluster limit is high enough that phase 1 runs over most of the list.  Ids, list order, member order and the
     phase-1 counters must equal the oracle's literal sequential loop for every thread count."""
     monkeypatch.setenv("HMK_PHASE1_THREADS", str(threads))
+    if threads == 5:
+        monkeypatch.setenv("HMK_PHASE1_WINDOW", "3")       # positions a thread scans ahead per round (default 16)
+    if threads == 2:
+        monkeypatch.setenv("HMK_GREEDY_TIMING", "1")       # the timeline on stderr changes nothing
     rng = np.random.default_rng(4000 + seed)
     n = [900, 1500, 2500][seed]
     peps = random_peptides(rng, n, 12, 12, alphabet=[3, 4, 5][seed])

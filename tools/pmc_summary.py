@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condenses the rocprofv3 outputs of tools/collect_profiles.sh into the files profiles/ keeps:
+"""Condenses the rocprofv3 outputs of tools/collect_round5.sh bench into the files profiles/ keeps:
 
     <round>_kernel_stats.csv          rocprofv3's own per-kernel stats (all dispatches)
     <round>_kernel_steady_state.json  the hot kernel's average over the TIMED dispatches only (warm-up dropped)
