@@ -385,19 +385,28 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         p1_rows += std::chrono::duration<double, std::milli>(p1_now() - tb0).count();
         if (bp && bp->rows > 0) {
             const uint32_t R1 = std::min<uint32_t>(bp->rows, n), FT = bp->far_t;
-            // One pool of entries, two singly linked lists through each: the entries of a band row (walked at the row's turn) and the
-            // entries of a cluster (walked when a member joins; dead entries are unlinked on the way).  No allocation per row or cluster.
-            constexpr uint32_t NIL = 0xFFFFFFFFu;
-            struct FeasEnt { int32_t c, mn, covered; uint32_t x, next_row, next_cl; };
+            // One pool of entries in CHUNKS of 8 (two cache lines): a band row's entries are the slots of its chain of chunks, walked at
+            // the row's turn -- made one by one over thousands of steps, they would otherwise lie a cache miss apart each (measured at
+            // 10^6 in the default order: 60 ns per entry visited, more than the near rows' scans) --; a cluster's entries are a singly
+            // linked list through the slots (walked when a member joins; dead entries are unlinked on the way).  No allocation per row
+            // or cluster; a slot's index never changes.
+            constexpr uint32_t NIL = 0xFFFFFFFFu, CHUNK = 8;
+            struct FeasEnt { int32_t c, covered; uint32_t next_cl, x_mn; };   // x_mn: row << 8 | minimum score - threshold
             std::vector<FeasEnt> pool;
-            pool.reserve((size_t)R1 * 4);
-            std::vector<uint32_t> row_head(R1, NIL), cl_head;
+            std::vector<uint32_t> chunk_next;                         // per chunk: the row's next chunk
+            pool.reserve((size_t)R1 * 16);
+            chunk_next.reserve((size_t)R1 * 2);
+            std::vector<uint32_t> row_first(R1, NIL), row_last(R1, NIL), cl_head;   // a row's first chunk / its last entry made
             cl_head.reserve(slots_max);
             std::vector<uint32_t> stamp(R1, 0);   // (step & 0xFFFFFF) << 8 | score(k, x) - base for the rows x of step k's leading near section
             uint32_t step = 0;                    // (steps <= rows of the band < 2^24)
-            std::vector<uint32_t> fetched;
+            std::vector<uint32_t> fetched, picked;
             uint64_t n_far_row = 0, n_band_far = 0;   // on-demand fetches (timing output)
             double t_fetch = 0;
+            // timing output: ticks and entries visited per section (row's entries, near candidates, stamps, join walk, seed walk)
+            uint64_t sec_t[5] = {0, 0, 0, 0, 0}, sec_n[5] = {0, 0, 0, 0, 0}, sec_mark = 0, n_near_b = 0;
+            auto sec_begin = [&]() { if (p1_timing) sec_mark = __builtin_ia32_rdtsc(); };
+            auto sec_end = [&](int which, uint64_t visited) { if (p1_timing) { sec_t[which] += __builtin_ia32_rdtsc() - sec_mark; sec_n[which] += visited; } };
             auto consider = [&](Found &B, uint32_t m, int32_t s) {   // NearestClusterRunner's order over singletons (scan_row above)
                 if (B.kind == NEAR_NULL || s > B.score ||
                     (s == B.score && better(s, seq_size(m), (int32_t)m, B.score, seq_size((uint32_t)B.slot), B.slot)))
@@ -406,24 +415,44 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             while (k < R1 && remaining > 0 && (int64_t)clusters.size() < max_clusters) {
                 if (state[k] != ST_FREE) { k++; continue; }   // removed from initialList (:101, :110)
                 step++;
+                // The pack was written by the device: every line of it comes from memory, and the lists are short (no hardware stream
+                // builds up).  Ask for the next row's near section now.
+                if (k + 2 < R1) {
+                    const uint32_t *nr = bp->near + bp->near_start[k + 1];
+                    for (uint32_t l = 0, nl = std::min<uint32_t>(bp->near_up[k + 1], 48 * 16); l < nl; l += 16) __builtin_prefetch(nr + l);
+                }
                 const uint32_t *row = bp->near + bp->near_start[k];
                 const uint32_t n_up = bp->near_up[k];
                 Found A{NEAR_NULL, -1, 0};                      // :92
+                sec_begin();
+                uint64_t visited = 0;
                 if (clusters.empty()) A = Found{NEAR_DUMMY, -1, INT_MIN};   // :138-140
                 else
-                    for (uint32_t e = row_head[k]; e != NIL; e = pool[e].next_row) {
-                        const FeasEnt &f = pool[e];
-                        if (f.covered == clusters[f.c].usize &&
-                            (A.kind == NEAR_NULL || better(f.mn, clusters[f.c].size, clusters[f.c].id, A.score, clusters[A.slot].size, clusters[A.slot].id)))
-                            A = Found{NEAR_REAL, f.c, f.mn};
+                    for (uint32_t ch = row_first[k]; ch != NIL; ch = chunk_next[ch]) {
+                        if (chunk_next[ch] != NIL) __builtin_prefetch(&pool[(size_t)chunk_next[ch] * CHUNK]);
+                        const uint32_t cnt = chunk_next[ch] != NIL ? CHUNK : row_last[k] - ch * CHUNK + 1;
+                        for (uint32_t q = 0; q < cnt; q++) {
+                            const FeasEnt &f = pool[(size_t)ch * CHUNK + q];
+                            const int32_t mn = (int32_t)(f.x_mn & 0xFFu);
+                            visited++;
+                            if (f.covered == clusters[f.c].usize &&
+                                (A.kind == NEAR_NULL || better(mn, clusters[f.c].size, clusters[f.c].id, A.score, clusters[A.slot].size, clusters[A.slot].id)))
+                                A = Found{NEAR_REAL, f.c, mn};
+                        }
                     }
+                sec_end(0, visited);
+                sec_begin();
                 Found B{NEAR_NULL, -1, 0};                      // :93
                 const uint32_t *ft = bp->far_top + (size_t)k * FT;
                 if (remaining - 1 == 0) B = Found{NEAR_DUMMY, -1, INT_MIN};
                 else {
+                    // (whether a neighbour is still free is a coin toss: no branch on it -- a taken one only where a candidate can
+                    // still win, which is rare after the first few)
+                    int32_t bar = 0;
                     for (uint32_t q = 0; q < n_up; q++) {
                         const uint32_t m = row[q] >> 8;
-                        if (state[m] == ST_FREE) consider(B, m, (int32_t)(row[q] & 0xFFu));
+                        const int32_t s = (int32_t)(row[q] & 0xFFu), s_free = state[m] == ST_FREE ? s : -1;
+                        if (s_free >= bar) { consider(B, m, s); bar = B.score; }
                     }
                     uint32_t t = 0;
                     bool far_found = false;
@@ -438,6 +467,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                             if (state[e >> 8] == ST_FREE) consider(B, e >> 8, (int32_t)(e & 0xFFu));
                     }
                 }
+                sec_end(1, n_up);
                 bool absorb = false;
                 int32_t joined = -1;
                 if (A.kind != NEAR_NULL) {                          // :94
@@ -457,34 +487,14 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     state[k] = ST_ORPHAN;                           // :112
                     orphans.push_back(k);
                 }
-                if (absorb || joined >= 0)
-                    for (uint32_t q = 0; q < n_up; q++) stamp[row[q] >> 8] = step << 8 | (row[q] & 0xFFu);
-                if (joined >= 0) {
-                    const int32_t before = clusters[joined].usize;
-                    insert_into(joined, k);
-                    uint32_t *link = &cl_head[joined];
-                    for (uint32_t e = *link; e != NIL; e = *link) {
-                        FeasEnt &f = pool[e];
-                        const uint32_t sw = stamp[f.x];
-                        // its turn is over / lost earlier, for good / k is not its neighbour (lost now): out of the cluster's list
-                        if (f.x <= k || f.covered != before || (sw >> 8) != step) { *link = f.next_cl; continue; }
-                        f.covered++;
-                        f.mn = std::min(f.mn, (int32_t)(sw & 0xFFu));
-                        link = &f.next_cl;
-                    }
-                } else if (absorb) {
-                    const int32_t c = (int32_t)clusters.size();
-                    clusters.push_back(ClusterRec{(int32_t)k, 1, seq_size(k)});
-                    cluster_of[k] = c;
-                    state[k] = ST_IN_CLUSTER;
-                    insert_into(c, (uint32_t)B.slot);
-                    remaining--;  // initialList.remove(B)
-                    cl_head.push_back(NIL);
-                    // the band rows that have B as a neighbour
+                // (seeding) the band rows that have B as a neighbour: B's own near row, or the list the device sent for a far B.  Found
+                // and asked for HERE, before the stamps are written: the list's lines come from memory (the device wrote them) and
+                // have the stamping to arrive in.
+                const uint32_t *bl = nullptr;
+                uint32_t bn = 0;
+                if (absorb) {
                     const uint32_t b = (uint32_t)B.slot;
-                    const uint32_t *bl = nullptr;
-                    uint32_t bn = 0;
-                    if (b < R1) { bl = bp->near + bp->near_start[b]; bn = bp->near_start[b + 1] - bp->near_start[b]; }
+                    if (b < R1) { bl = bp->near + bp->near_start[b]; bn = bp->near_start[b + 1] - bp->near_start[b]; n_near_b++; }
                     else {
                         for (uint32_t t = 0; t < BandPack::TR_PER_ROW && t < FT && !bl; t++)
                             if (ft[t] != ~0u && (ft[t] >> 8) == b) {
@@ -501,17 +511,64 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                             bn = (uint32_t)fetched.size();
                         }
                     }
+                    for (uint32_t l = 0; l < bn && l < 64 * 16; l += 16) __builtin_prefetch(bl + l);
+                }
+                sec_begin();
+                if (absorb || joined >= 0)
+                    for (uint32_t q = 0; q < n_up; q++) stamp[row[q] >> 8] = step << 8 | (row[q] & 0xFFu);
+                sec_end(2, n_up);
+                sec_begin();
+                visited = 0;
+                if (joined >= 0) {
+                    const int32_t before = clusters[joined].usize;
+                    insert_into(joined, k);
+                    uint32_t *link = &cl_head[joined];
+                    for (uint32_t e = *link; e != NIL; e = *link) {
+                        FeasEnt &f = pool[e];
+                        const uint32_t fx = f.x_mn >> 8, sw = stamp[fx];
+                        visited++;
+                        // its turn is over / lost earlier, for good / k is not its neighbour (lost now): out of the cluster's list
+                        if (fx <= k || f.covered != before || (sw >> 8) != step) { *link = f.next_cl; continue; }
+                        f.covered++;
+                        f.x_mn = fx << 8 | std::min(f.x_mn & 0xFFu, sw & 0xFFu);
+                        link = &f.next_cl;
+                    }
+                } else if (absorb) {
+                    const int32_t c = (int32_t)clusters.size();
+                    clusters.push_back(ClusterRec{(int32_t)k, 1, seq_size(k)});
+                    cluster_of[k] = c;
+                    state[k] = ST_IN_CLUSTER;
+                    insert_into(c, (uint32_t)B.slot);
+                    remaining--;  // initialList.remove(B)
+                    cl_head.push_back(NIL);
+                    // two passes: the entries of B's list that are later band rows AND neighbours of k (stamped), picked out without a
+                    // branch on the data (the three tests fail two times in three, unpredictably: 10.7 ticks per entry with branches),
+                    // then the few that are left
+                    picked.resize(bn);
+                    uint32_t np = 0;
                     for (uint32_t q = 0; q < bn; q++) {
-                        const uint32_t x = bl[q] >> 8;
-                        if (x <= k || x >= R1 || state[x] != ST_FREE) continue;
-                        const uint32_t sw = stamp[x];
-                        if ((sw >> 8) != step) continue;                // k is not a neighbour of x: {k, B} is never feasible for it
-                        const uint32_t e = (uint32_t)pool.size();
-                        pool.push_back(FeasEnt{c, std::min((int32_t)(sw & 0xFFu), (int32_t)(bl[q] & 0xFFu)), 2, x, row_head[x], cl_head[c]});
-                        row_head[x] = e;
+                        const uint32_t x = bl[q] >> 8, xs = x < R1 ? x : 0;   // (row 0 is never later than k)
+                        picked[np] = q;
+                        np += (uint32_t)((xs > k) & ((stamp[xs] >> 8) == step));
+                    }
+                    for (uint32_t i = 0; i < np; i++) {
+                        const uint32_t q = picked[i], x = bl[q] >> 8, sw = stamp[x];
+                        if (state[x] != ST_FREE) continue;
+                        uint32_t e = row_last[x] + 1;
+                        if (row_last[x] == NIL || e % CHUNK == 0) {     // the row's first entry, or its last chunk is full: a new chunk
+                            const uint32_t ch = (uint32_t)chunk_next.size();
+                            chunk_next.push_back(NIL);
+                            pool.resize(pool.size() + CHUNK);
+                            if (row_last[x] == NIL) row_first[x] = ch; else chunk_next[row_last[x] / CHUNK] = ch;
+                            e = ch * CHUNK;
+                        }
+                        pool[e] = FeasEnt{c, 2, cl_head[c], x << 8 | std::min(sw & 0xFFu, bl[q] & 0xFFu)};
+                        row_last[x] = e;
                         cl_head[c] = e;
                     }
+                    visited = bn;
                 }
+                sec_end(joined >= 0 ? 3 : 4, visited);
                 remaining--;
                 index++;          // :115
                 k++;
@@ -522,6 +579,11 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                                 "fetched on demand in %.2f ms), stopped at row %u of %u\n",
                         std::chrono::duration<double, std::milli>(p1_now() - tb0).count(), (unsigned long long)step, p1_rows, (unsigned long long)n_far_row,
                         (unsigned long long)n_band_far, t_fetch, k, R1);
+            if (p1_timing)
+                fprintf(stderr, "[hmk greedy] phase 1 sections, Mticks / entries visited: the row's entries %.1f / %llu, near candidates %.1f / %llu, stamps %.1f / %llu, "
+                                "join walks %.1f / %llu, seed walks %.1f / %llu; %zu entry slots, %llu seeds with a near B\n",
+                        sec_t[0] / 1e6, (unsigned long long)sec_n[0], sec_t[1] / 1e6, (unsigned long long)sec_n[1], sec_t[2] / 1e6, (unsigned long long)sec_n[2],
+                        sec_t[3] / 1e6, (unsigned long long)sec_n[3], sec_t[4] / 1e6, (unsigned long long)sec_n[4], pool.size(), (unsigned long long)n_near_b);
         }
     }
     while (k < n && remaining > 0 && (int64_t)clusters.size() < max_clusters) {
