@@ -51,4 +51,13 @@ for n in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [100000]:
                 "edges": int(st.n_edges), "phase1_stop_index": int(st.phase1_stop_index)}
         line.update(ctx.greedy_phases())
         print(json.dumps(line), flush=True)
+    if "--tight" in sys.argv:   # 20 calls with nothing between them: what a resident caller that issues calls back to back sees
+        walls, scores = [], []
+        for call in range(20):
+            t = time.perf_counter()
+            ctx.greedy_cluster(3, 0, 20, maxc)
+            walls.append((time.perf_counter() - t) * 1e3)
+            scores.append(ctx.greedy_phases()["score_ms"])
+        print(json.dumps({"n": n, "order": "size" if SORTED else "input", "tight_calls": 20, "wall_ms_median": float(np.median(walls)), "wall_ms_min": min(walls),
+                          "wall_ms_all": [round(w, 3) for w in walls], "score_ms_median": float(np.median(scores))}), flush=True)
     ctx.close()
