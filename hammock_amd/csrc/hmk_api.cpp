@@ -92,7 +92,6 @@ int hmk_create(const int32_t *matrix, int device, hmk_ctx **out) {
 
 // a call whose failure changes nothing here, and never leaves its error behind as the thread's "last error" for the next launch
 // wrapper's hipGetLastError() to pick up
-#define HMK_QUIET(call) do { if ((call) != hipSuccess) (void)hipGetLastError(); } while (0)
 void hmk_destroy(hmk_ctx *ctx) {
     if (!ctx) return;
     for (hmk_ctx *peer : ctx->peers) hmk_destroy(peer);

@@ -140,7 +140,7 @@ struct hmk_ctx {
     uint64_t d_edges_cap = 0;
     unsigned long long *d_counts = nullptr;
     // side streams of the neighbour pass: the per-class launches of a mixed-length plan overlap their tails
-    static constexpr int N_SIDE = 3;     // streams the launches are dealt to (the pass's own and two others)
+    static constexpr int N_SIDE = 3;     // streams a mixed-length pass's launches are dealt to (hmk_pass.cpp)
     hipStream_t side[N_SIDE] = {nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[N_SIDE] = {nullptr};
     hipStream_t copy_stream = nullptr;   // band CSR + device-to-host copies of adjacency rows (hmk_greedy_cluster)
@@ -192,6 +192,9 @@ int fail(hmk_ctx *ctx, int code, const std::string &msg);
             return fail(ctx, e_ == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE,          \
                         std::string(#expr) + ": " + hipGetErrorString(e_));                     \
     } while (0)
+
+// a HIP call whose failure is not this call's business (teardown): the error must not stay behind as the thread's last one
+#define HMK_QUIET(call) do { if ((call) != hipSuccess) (void)hipGetLastError(); } while (0)
 
 // which: LAUNCH_ALL, or only the band tiles of the plan (LAUNCH_BAND: also zeroes the counts) / only the others
 // (LAUNCH_REST: appends to the counts of the band launch)

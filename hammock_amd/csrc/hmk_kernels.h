@@ -29,6 +29,7 @@ hipError_t launch_neighbors_direct(const NeighborParams &P, uint32_t tile_base, 
                                    hipStream_t s);
 // scorer 0: ShiftedScorer(a = maxShift, b = shiftPenalty); 1: LocalAlignmentScorer(a = gapOpen, b = gapExtend).
 // pi == nullptr: dense block mode, pair k = (r0 + k / width, c0 + k % width).
+hipError_t launch_probe_spin(unsigned long long *when, long long ticks, hipStream_t s);   // when[0] / [1]: start / end, 100 MHz wall clock
 hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, const int32_t *d_matrix,
                         const uint32_t *pi, const uint32_t *pj, uint64_t n_pairs, uint32_t r0, uint32_t c0,
                         uint32_t width, int a, int b, int32_t *out, int32_t *out_shift, hipStream_t s);

@@ -4,6 +4,50 @@
 
 namespace hmk { namespace impl {
 
+// The side streams of a mixed-length pass: three streams that RUN SIDE BY SIDE.  Streams share the process's few hardware queues
+// (4 per priority by default) and two streams on one queue serialise; which queue a new stream lands on depends on how many
+// the process has created before (a probe of ten fresh streams: queues a b c d d c b a d c), so "three new streams" may be two
+// queues -- BASELINE config 4a took 4.13 ms in a fresh process, 4.57-4.61 ms at the end of a bench.py run and 5.27 ms on three
+// streams created one after the other behind the context's own (round 3's sweep: 1 / 2 / 3 streams 5.73 / 4.56 / 4.41 ms).
+// Measured with the probe in place: 4.26-4.37 ms inside bench.py and on its own alike (0.82-0.84 of the LDS-byte ideal); four probed
+// streams 4.62, one or two of them at high priority 4.31-4.60, five / six 4.50 / 4.62.
+// So the streams are PROBED, once per context: a one-wave kernel that spins for 60 us notes its start and end on each of two
+// streams; they run side by side iff the second started before the first ended.  New streams are created until three pass
+// pairwise (at most 12; whatever was found is used then).
+static int make_side_streams(hmk_ctx *ctx) {
+    constexpr int n_side = hmk_ctx::N_SIDE, MAX_TRIES = 12;
+    unsigned long long *when = nullptr;
+    HIPCHK(ctx, hipHostMalloc((void **)&when, 64, hipHostMallocDefault));
+    auto side_by_side = [&](hipStream_t a, hipStream_t b, bool *yes) -> hipError_t {
+        std::memset(when, 0, 64);
+        hipError_t e = launch_probe_spin(when, 6000, a);
+        if (e == hipSuccess) e = launch_probe_spin(when + 2, 6000, b);
+        if (e == hipSuccess) e = hipStreamSynchronize(a);
+        if (e == hipSuccess) e = hipStreamSynchronize(b);
+        *yes = when[2] < when[1] && when[0] < when[3];
+        return e;
+    };
+    std::vector<hipStream_t> kept, dropped;
+    hipError_t e = hipSuccess;
+    for (int t = 0; t < MAX_TRIES && (int)kept.size() < n_side && e == hipSuccess; t++) {
+        hipStream_t s = nullptr;
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e != hipSuccess) break;
+        bool ok = true;
+        for (size_t k = 0; k < kept.size() && ok && e == hipSuccess; k++) e = side_by_side(kept[k], s, &ok);
+        (ok ? kept : dropped).push_back(s);
+    }
+    while ((int)kept.size() < n_side && !dropped.empty()) { kept.push_back(dropped.back()); dropped.pop_back(); }   // (fewer queues than streams: serialise)
+    for (hipStream_t s : dropped) HMK_QUIET(hipStreamDestroy(s));
+    HMK_QUIET(hipHostFree(when));
+    if (e != hipSuccess || (int)kept.size() < n_side) {
+        for (hipStream_t s : kept) HMK_QUIET(hipStreamDestroy(s));
+        return fail(ctx, HMK_ERR_DEVICE, std::string("side streams of the mixed-length pass: ") + hipGetErrorString(e != hipSuccess ? e : hipErrorUnknown));
+    }
+    for (int k = 0; k < n_side; k++) ctx->side[k] = kept[k];
+    return HMK_OK;
+}
+
 int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_parts, void *d_edges,
                          uint64_t capacity, void *d_counts, hipStream_t stream, int which,
                          int64_t band_rows, uint32_t *d_deg, uint32_t *d_deg_lo) {
@@ -30,36 +74,19 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     P.symmetric = ctx->symmetric ? 1u : 0u;
     P.deg = d_deg;
     P.deg_m_offset = (d_deg && d_deg_lo) ? (uint32_t)(d_deg_lo - d_deg) : 0u;   // split counters: upper counts, then lower counts
-    // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has a dozen of
-    // them: fork them round-robin onto side streams so that one group's tail overlaps the next group's
-    // start, and join back into `stream`.
+    // one launch per (lane path, entry width, column capacity) group.  A mixed-length plan has two dozen of them: fork them
+    // round-robin onto three side streams so that one group's tail overlaps the next group's start, and join back into `stream`,
+    // which itself only records the fork event and waits for the joins.
     const bool fork = pl.groups.size() > 2;
     constexpr int n_side = hmk_ctx::N_SIDE;
-    // The streams the launches are dealt to: the pass's own stream and n_side - 1 others.  A process gets few hardware queues
-    // (4 by default), and streams beyond them share one and serialise: with the clustering calls' two streams created first
-    // (hmk_create), three more side streams cost this pass 5 % (5.36 -> 5.65 ms on BASELINE config 4a).  So a pass that does
-    // not run on the clustering stream borrows those two (idle: calls on a context are serialised); a clustering call without
-    // a band borrows the copy stream and creates one side stream; one with a band, whose hand-over needs the copy stream for
-    // itself, creates two.
-    hipStream_t sides[hmk_ctx::N_SIDE] = {nullptr};
+    hipStream_t *sides = ctx->side;
     if (fork) {
         if (!ctx->ev_fork) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        std::vector<hipStream_t> lend;
-        if (ctx->gstream && ctx->copy_stream) {
-            if (stream != ctx->gstream && stream != ctx->copy_stream) lend = {ctx->gstream, ctx->copy_stream};
-            else if (stream == ctx->gstream && which == LAUNCH_ALL) lend = {ctx->copy_stream};
-        }
-        int own = 0;
-        sides[0] = stream;
-        for (int k = 1; k < n_side; k++) {
-            if ((size_t)(k - 1) < lend.size()) { sides[k] = lend[k - 1]; continue; }
-            if (!ctx->side[own]) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->side[own], hipStreamNonBlocking));
-            sides[k] = ctx->side[own++];
-        }
-        for (int k = 1; k < n_side; k++)
+        if (!ctx->side[n_side - 1]) { const int rc = make_side_streams(ctx); if (rc != HMK_OK) return rc; }
+        for (int k = 0; k < n_side; k++)
             if (!ctx->ev_join[k]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork, stream));
-        for (int k = 1; k < n_side; k++) HIPCHK(ctx, hipStreamWaitEvent(sides[k], ctx->ev_fork, 0));
+        for (int k = 0; k < n_side; k++) HIPCHK(ctx, hipStreamWaitEvent(sides[k], ctx->ev_fork, 0));
     }
     // biggest groups first
     std::vector<const Group *> order;
@@ -79,7 +106,7 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
             HIPCHK(ctx, launch_neighbors_swar(g.lbk, g.nw, pl.exact, P, t0, cnt, s));
     }
     if (fork)
-        for (int k = 1; k < n_side; k++) {
+        for (int k = 0; k < n_side; k++) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_join[k], sides[k]));
             HIPCHK(ctx, hipStreamWaitEvent(stream, ctx->ev_join[k], 0));
         }

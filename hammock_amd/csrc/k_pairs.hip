@@ -59,4 +59,18 @@ hipError_t launch_pairs(int scorer, const uint8_t *res32, const uint8_t *len, co
     return hipGetLastError();
 }
 
+// -----------------------------------------------------------------------------
+// do two streams run side by side?  (hmk_pass.cpp: the side streams of a mixed-length pass)
+// -----------------------------------------------------------------------------
+// One wave that notes when it started, spins for `ticks` of the 100 MHz wall clock and notes when it ended.
+__global__ void k_probe_spin(unsigned long long *when, long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+    if (threadIdx.x == 0) { when[0] = (unsigned long long)t0; when[1] = (unsigned long long)wall_clock64(); }
+}
+hipError_t launch_probe_spin(unsigned long long *when, long long ticks, hipStream_t s) {
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, s, when, ticks);
+    return hipGetLastError();
+}
+
 }  // namespace hmk
