@@ -330,25 +330,27 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             const uint64_t cap = std::max<uint64_t>((uint64_t)entries, 1);   // no list is longer than the band has entries
             hipError_t e = ensure_buf(ctx, SB_FADJ, cap * 4);
             // the host's block (pinned; the kernels store into it themselves: no copy launches, no second round trip for sizes):
-            //   near_start [R1 + 1] | near_up [R1] | far_top [R1 x FAR_T] | tr_owner [TRN] | tr_start [TRN + 1] | far_more [R1, padded] | near [cap] | tr [cap]
+            //   near_start [R1 + 1] | near_up [R1] | far_top [R1 x FAR_T] | tr_cnt [TRN] | tr_start [TRN + 1] | far_more [R1, padded] | near [cap] | tr [cap]
             const size_t o_nstart = 0, o_nup = o_nstart + ((size_t)R1 + 1) * 4, o_ftop = o_nup + (size_t)R1 * 4, o_trowner = o_ftop + (size_t)R1 * FAR_T * 4,
                          o_trstart = o_trowner + (size_t)TRN * 4, o_fmore = o_trstart + ((size_t)TRN + 1) * 4, o_near = (o_fmore + R1 + 63) / 64 * 64,
                          o_tr = o_near + (cap * 4 + 63) / 64 * 64;
             if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, o_tr + cap * 4 + 64, 0);
             char *hb = (char *)ctx->h_adj, *db = nullptr;
             if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&db, hb, 0);
-            uint32_t *d_fdeg = buf<uint32_t>(ctx, SB_FDEG), *d_fcur = d_fdeg + n, *d_owner = d_fdeg + 2 * (size_t)n, *d_totals = d_fdeg + 3 * (size_t)n;
+            uint32_t *d_fdeg = buf<uint32_t>(ctx, SB_FDEG), *d_fcur = d_fdeg + n, *d_totals = d_fdeg + 3 * (size_t)n;
             if (e == hipSuccess)
                 e = launch_band_prepare(buf<uint64_t>(ctx, SB_BSTART), buf<uint32_t>(ctx, SB_BCURSOR), buf<void>(ctx, SB_BADJ), R1, (uint64_t)entries, n, FAR_T,
                                         BandPack::TR_PER_ROW, ctx->has_sizes ? buf<int32_t>(ctx, SB_SEQSZ) : nullptr, buf<uint32_t>(ctx, SB_BNCNT),
                                         buf<uint32_t>(ctx, SB_BNUP), buf<uint32_t>(ctx, SB_BNSTART), buf<uint32_t>(ctx, SB_BFTOP), buf<uint8_t>(ctx, SB_BFMORE),
-                                        d_fdeg, d_fcur, d_owner, d_totals, buf<uint32_t>(ctx, SB_FSTART), buf<uint32_t>(ctx, SB_FADJ),
-                                        buf<uint32_t>(ctx, SB_TRCNT), buf<uint32_t>(ctx, SB_TRSTART), (uint32_t *)(db + o_nstart), (uint32_t *)(db + o_nup),
+                                        d_fdeg, d_fcur, d_totals, buf<uint32_t>(ctx, SB_FSTART), buf<uint32_t>(ctx, SB_FADJ),
+                                        buf<uint32_t>(ctx, SB_TRCNT), buf<uint32_t>(ctx, SB_TRSTART), cap, (uint32_t *)(db + o_nstart), (uint32_t *)(db + o_nup),
                                         (uint32_t *)(db + o_ftop), (uint8_t *)(db + o_fmore), (uint32_t *)(db + o_near), (uint32_t *)(db + o_trowner),
                                         (uint32_t *)(db + o_trstart), (uint32_t *)(db + o_tr), C);
             if (e == hipSuccess) e = hipStreamSynchronize(C);
             if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return nullptr; }
-            const uint64_t n_near = ((const uint32_t *)(hb + o_nstart))[R1], n_tr = ((const uint32_t *)(hb + o_trstart))[TRN];
+            const uint64_t n_near = ((const uint32_t *)(hb + o_nstart))[R1];
+            uint64_t n_tr = 0;   // what was written of the intersections (their room, tr_start, is an upper bound)
+            for (uint32_t u = 0; u < TRN; u++) { const uint32_t c = ((const uint32_t *)(hb + o_trowner))[u]; if (c != ~0u) n_tr += c; }
             if (n_near > cap || n_tr > cap) { hook_fail(HMK_ERR_DEVICE, "band hand-over: list sizes beyond the band's entries"); return nullptr; }
             pack.rows = R1;
             pack.far_t = FAR_T;
@@ -357,7 +359,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             pack.near = (const uint32_t *)(hb + o_near);
             pack.far_top = (const uint32_t *)(hb + o_ftop);
             pack.far_more = (const uint8_t *)(hb + o_fmore);
-            pack.tr_owner = (const uint32_t *)(hb + o_trowner);
+            pack.tr_cnt = (const uint32_t *)(hb + o_trowner);
             pack.tr_start = (const uint32_t *)(hb + o_trstart);
             pack.tr = (const uint32_t *)(hb + o_tr);
             ph.band_bytes = (uint64_t)(o_near + n_near * 4 + n_tr * 4);

@@ -110,7 +110,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
     }
     // HMK_PHASE1_HOST_BAND: the prepared band (BandPack) built here, literally, from the whole graph
     GreedyHooks hooks;
-    std::vector<uint32_t> b_near_start, b_near_up, b_near, b_far_top, b_tr_owner, b_tr_start, b_tr;
+    std::vector<uint32_t> b_near_start, b_near_up, b_near, b_far_top, b_tr_cnt, b_tr_start, b_tr;
     std::vector<uint8_t> b_far_more;
     BandPack pack;
     bool use_pack = opt.host_band_rows > 0 && symmetric && n > 0;
@@ -132,8 +132,8 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
         b_far_top.assign((size_t)R1 * FT, ~0u);
         b_far_more.assign(R1, 0);
         b_tr_start.assign((size_t)BandPack::TR_PER_ROW * R1 + 1, 0);
-        b_tr_owner.resize((size_t)BandPack::TR_PER_ROW * R1);
-        for (size_t u = 0; u < b_tr_owner.size(); u++) b_tr_owner[u] = (uint32_t)u;   // (here every slot carries its own copy)
+        b_tr_cnt.assign((size_t)BandPack::TR_PER_ROW * R1, 0);
+        std::vector<int32_t> of_x(R1, INT_MIN);   // score(x, row) for the rows above x that are its neighbours
         for (uint32_t x = 0; x < R1; x++) {
             std::vector<Nbr> far;
             for (int pass = 0; pass < 2; pass++)   // the neighbours above x first
@@ -146,15 +146,31 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
             std::sort(far.begin(), far.end(), [&](const Nbr &p, const Nbr &q) { return far_key(p) > far_key(q); });
             for (uint32_t t = 0; t < FT && t < far.size(); t++) b_far_top[(size_t)x * FT + t] = ent(far[t].m, far[t].s);
             b_far_more[x] = far.size() > FT;
+            // the later band rows that have both x and the candidate as neighbours, with the smaller of the two scores; every fifth slot
+            // is left unprepared (~0u), as the device leaves a row beyond its table: the loop then filters the whole list itself
+            for (uint64_t q = start[x]; q < start[x + 1]; q++)
+                if (adj[q].m > x && adj[q].m < R1) of_x[adj[q].m] = adj[q].s;
             for (uint32_t t = 0; t < BandPack::TR_PER_ROW; t++) {
-                if (t < FT && t < far.size()) band_nbrs(far[t].m, b_tr);
-                b_tr_start[(size_t)BandPack::TR_PER_ROW * x + t + 1] = (uint32_t)b_tr.size();
+                const size_t u = (size_t)BandPack::TR_PER_ROW * x + t;
+                if (t < FT && t < far.size()) {
+                    if ((x + t) % 5 == 4) b_tr_cnt[u] = ~0u;
+                    else {
+                        const uint32_t c = far[t].m;
+                        for (uint64_t q = start[c]; q < start[c + 1]; q++) {
+                            const uint32_t y = adj[q].m;
+                            if (y > x && y < R1 && of_x[y] != INT_MIN) { b_tr.push_back(ent(y, std::min(of_x[y], adj[q].s))); b_tr_cnt[u]++; }
+                        }
+                    }
+                }
+                b_tr_start[u + 1] = (uint32_t)b_tr.size();
             }
+            for (uint64_t q = start[x]; q < start[x + 1]; q++)
+                if (adj[q].m > x && adj[q].m < R1) of_x[adj[q].m] = INT_MIN;
         }
         pack.rows = R1; pack.far_t = FT;
         pack.near_start = b_near_start.data(); pack.near_up = b_near_up.data(); pack.near = b_near.data();
         pack.far_top = b_far_top.data(); pack.far_more = b_far_more.data();
-        pack.tr_owner = b_tr_owner.data(); pack.tr_start = b_tr_start.data(); pack.tr = b_tr.data();
+        pack.tr_cnt = b_tr_cnt.data(); pack.tr_start = b_tr_start.data(); pack.tr = b_tr.data();
         hooks.band_pack = [&]() -> const BandPack * { return &pack; };
         hooks.far_row = [&](uint32_t id, std::vector<uint32_t> &out) -> bool { out.clear(); band_nbrs(id, out); return true; };
         hooks.band_far = [&](uint32_t x, std::vector<uint32_t> &out) -> bool {
@@ -487,20 +503,24 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     state[k] = ST_ORPHAN;                           // :112
                     orphans.push_back(k);
                 }
-                // (seeding) the band rows that have B as a neighbour: B's own near row, or the list the device sent for a far B.  Found
-                // and asked for HERE, before the stamps are written: the list's lines come from memory (the device wrote them) and
-                // have the stamping to arrive in.
+                // (seeding) the later band rows the new cluster {k, B} is feasible for.  A far B that is one of k's first far candidates:
+                // the device sent them ready (`ready`: rows with the cluster's score).  Otherwise B's band neighbours -- its own near row,
+                // or its whole list fetched from the device -- are filtered against k's stamped row below.  Found and asked for HERE,
+                // before the stamps are written: the list's lines come from memory (the device wrote them).
                 const uint32_t *bl = nullptr;
                 uint32_t bn = 0;
+                bool ready = false;
                 if (absorb) {
                     const uint32_t b = (uint32_t)B.slot;
                     if (b < R1) { bl = bp->near + bp->near_start[b]; bn = bp->near_start[b + 1] - bp->near_start[b]; n_near_b++; }
                     else {
                         for (uint32_t t = 0; t < BandPack::TR_PER_ROW && t < FT && !bl; t++)
                             if (ft[t] != ~0u && (ft[t] >> 8) == b) {
-                                const size_t u = bp->tr_owner[(size_t)BandPack::TR_PER_ROW * k + t];
+                                const size_t u = (size_t)BandPack::TR_PER_ROW * k + t;
+                                if (bp->tr_cnt[u] == ~0u) break;            // not prepared: the whole list, below
                                 bl = bp->tr + bp->tr_start[u];
-                                bn = bp->tr_start[u + 1] - bp->tr_start[u];
+                                bn = bp->tr_cnt[u];
+                                ready = true;
                             }
                         if (!bl) {
                             const auto tf = p1_now();
@@ -514,9 +534,9 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     for (uint32_t l = 0; l < bn && l < 64 * 16; l += 16) __builtin_prefetch(bl + l);
                 }
                 sec_begin();
-                if (absorb || joined >= 0)
+                if (joined >= 0 || (absorb && !ready))   // (k's row, for the walks that ask "is k a neighbour of this row, and with what score")
                     for (uint32_t q = 0; q < n_up; q++) stamp[row[q] >> 8] = step << 8 | (row[q] & 0xFFu);
-                sec_end(2, n_up);
+                sec_end(2, joined >= 0 || (absorb && !ready) ? n_up : 0);
                 sec_begin();
                 visited = 0;
                 if (joined >= 0) {
@@ -546,13 +566,15 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                     // then the few that are left
                     picked.resize(bn);
                     uint32_t np = 0;
-                    for (uint32_t q = 0; q < bn; q++) {
-                        const uint32_t x = bl[q] >> 8, xs = x < R1 ? x : 0;   // (row 0 is never later than k)
-                        picked[np] = q;
-                        np += (uint32_t)((xs > k) & ((stamp[xs] >> 8) == step));
-                    }
+                    if (ready) np = bn;   // (every entry is a later band row with both as neighbours, its score already the minimum)
+                    else
+                        for (uint32_t q = 0; q < bn; q++) {
+                            const uint32_t x = bl[q] >> 8, xs = x < R1 ? x : 0;   // (row 0 is never later than k)
+                            picked[np] = q;
+                            np += (uint32_t)((xs > k) & ((stamp[xs] >> 8) == step));
+                        }
                     for (uint32_t i = 0; i < np; i++) {
-                        const uint32_t q = picked[i], x = bl[q] >> 8, sw = stamp[x];
+                        const uint32_t q = ready ? i : picked[i], x = bl[q] >> 8, sw = ready ? 0xFFu : stamp[x];
                         if (state[x] != ST_FREE) continue;
                         uint32_t e = row_last[x] + 1;
                         if (row_last[x] == NIL || e % CHUNK == 0) {     // the row's first entry, or its last chunk is full: a new chunk

@@ -115,11 +115,12 @@ using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::
 //               ClinkageSequenceClusterer.java:166-173, :275-289), best first, far_t per row, ~0u = no more; far_more[x] != 0:
 //               the row has far neighbours beyond the far_t listed.  A far sequence changes state in phase 1 only by being
 //               absorbed (:99-101, :108-110), so the first entry that is still free IS the best far candidate of :93.
-//   tr          for the row's first TR_PER_ROW far candidates c: the band rows that have c as a neighbour (c's row restricted
-//               to ids below `rows`), entries band row << 8 | (score - base): what the new cluster {x, c} needs to know which
-//               later band rows it is feasible for.  A sequence's list travels once: slot u = TR_PER_ROW * x + t finds it at
-//               v = tr_owner[u], tr[tr_start[v] .. tr_start[v + 1]).  Any other far sequence's list comes through
-//               GreedyHooks::far_row.
+//   tr          for the row's first TR_PER_ROW far candidates c, slot u = TR_PER_ROW * x + t: the LATER band rows that have both x
+//               and c as neighbours, tr[tr_start[u] .. + tr_cnt[u]), entries band row << 8 | (min(score(x, row), score(c, row)) -
+//               base): the rows the new cluster {x, c} is feasible for, with its score (ClinkageClusterScorer.java:36-48) --
+//               intersected on the device (k_band_isect).  tr_cnt[u] == ~0u: not prepared (a row or list beyond the kernel's
+//               table / room); then, and for a far candidate beyond the first TR_PER_ROW, c's whole list comes through
+//               GreedyHooks::far_row and the host filters it against x's row.
 struct BandPack {
     static constexpr uint32_t TR_PER_ROW = 4;   // (2: a dozen lists per 25,000 steps had to be fetched on demand at 10^6 -- and a small copy issued while
                                                 // the pass runs waits milliseconds for a slot)
@@ -127,7 +128,7 @@ struct BandPack {
     const uint32_t *near_start = nullptr, *near_up = nullptr, *near = nullptr;
     const uint32_t *far_top = nullptr;
     const uint8_t *far_more = nullptr;
-    const uint32_t *tr_owner = nullptr, *tr_start = nullptr, *tr = nullptr;
+    const uint32_t *tr_cnt = nullptr, *tr_start = nullptr, *tr = nullptr;
 };
 
 // test / diagnostic options of the host merge (the library reads its environment switches once per call, hmk_ctx.h Switches)

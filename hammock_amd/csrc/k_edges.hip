@@ -1645,19 +1645,16 @@ k_band_split(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ b
 
 // Where every far sequence's transposed list starts: fstart[id] = a block of fdeg[id] entries taken from one counter, a wave's 64
 // blocks with ONE atomic (prefix sums inside the wave) -- the lists need no order among themselves.  *counter zeroed.
-// The same launch also settles which transposed lists travel: those of the sequences that are a band row's first TR far candidates,
-// each once -- owner_of[id] (zeroed) = 1 + the slot u = TR * x + t that ships id's list, tr_cnt[u] = its length for the owner, 0 for
-// the others.
+// The same launch also sizes what travels for every slot u = TR * x + t (row x's t-th far candidate B): room for the later band rows
+// that have BOTH x and B as neighbours, at most min(rows that have B, x's near neighbours above it) -- k_band_isect writes the list.
 __global__ void __launch_bounds__(256)
 k_band_falloc(const uint32_t *__restrict__ fdeg, uint32_t n, uint32_t *__restrict__ fstart, uint32_t *__restrict__ counter,
-              const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, uint32_t *__restrict__ owner_of,
+              const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *__restrict__ near_up,
               uint32_t *__restrict__ tr_cnt) {
     for (uint32_t u = blockIdx.x * 256 + threadIdx.x; u < R * tr_per_row; u += gridDim.x * 256) {
         const uint32_t x = u / tr_per_row, t = u - x * tr_per_row;
         const uint32_t ent = t < ft ? far_top[(size_t)x * ft + t] : ~0u;
-        uint32_t cnt = 0;
-        if (ent != ~0u && atomicCAS(&owner_of[ent >> 8], 0u, u + 1u) == 0u) cnt = fdeg[ent >> 8];
-        tr_cnt[u] = cnt;
+        tr_cnt[u] = ent != ~0u ? min(fdeg[ent >> 8], near_up[x]) : 0u;
     }
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t k0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; k0 < n; k0 += gridDim.x * 256) {   // wave-uniform
@@ -1747,23 +1744,63 @@ k_band_fill(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bu
     }
 }
 
-// tr_owner[u] = the slot that ships the list of slot u's candidate; the owners copy their lists (one wave per slot)
+// What seeding a cluster {x, B} needs (LimitedGreedySequenceClusterer.java:99-101, :108-110 with a far B): the LATER band rows that have
+// both x and B as neighbours, each with min(score(x, row), score(B, row)) -- the new cluster's score for that row
+// (ClinkageClusterScorer.java:36-48).  Round 5 first shipped B's whole transposed list and let the host filter it against x's stamped
+// row (a third of phase 1's host time); here the device intersects: one workgroup per band row x hashes x's near neighbours above it
+// (id -> score) in LDS, and wave t walks the list of x's t-th far candidate and writes the matches straight into the host's block:
+// tr[tr_start[u] ..) = row << 8 | min score, h_tr_cnt[u] = how many.  A row with more near neighbours than the table takes, or a list
+// the block has no room for, gets h_tr_cnt[u] = ~0: the host then asks for B's whole list and filters it itself (the old way).
+constexpr uint32_t ISECT_SLOTS = 4096, ISECT_MAX_KEYS = 2800;
 __global__ void __launch_bounds__(256)
-k_band_tr_fill(const uint32_t *__restrict__ far_top, uint32_t R, uint32_t ft, uint32_t tr_per_row, const uint32_t *__restrict__ owner_of,
-               const uint32_t *__restrict__ fstart, const uint32_t *__restrict__ fdeg, const uint32_t *__restrict__ fadj,
-               const uint32_t *__restrict__ tr_start, uint32_t *__restrict__ tr_owner, uint32_t *__restrict__ tr, uint32_t *__restrict__ h_tr_start) {
-    // (tr_owner, tr and h_tr_start are the host's block, as in k_band_fill)
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t u = blockIdx.x * 4 + (threadIdx.x >> 6); u < R * tr_per_row; u += gridDim.x * 4) {   // wave-uniform
-        const uint32_t x = u / tr_per_row, t = u - x * tr_per_row;
+k_band_isect(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bup, const uint32_t *__restrict__ badj, uint32_t R, uint32_t ft,
+             uint32_t tr_per_row, const uint32_t *__restrict__ near_up, const uint32_t *__restrict__ far_top, const uint32_t *__restrict__ fstart,
+             const uint32_t *__restrict__ fdeg, const uint32_t *__restrict__ fadj, const uint32_t *__restrict__ tr_start, uint64_t tr_cap,
+             uint32_t *__restrict__ tr, uint32_t *__restrict__ h_tr_start, uint32_t *__restrict__ h_tr_cnt) {
+    __shared__ uint32_t table[ISECT_SLOTS];   // id + 1 << 8 | score; 0 = empty
+    const uint32_t lane = threadIdx.x & 63u, t = threadIdx.x >> 6;
+    for (uint32_t x = blockIdx.x; x < R; x += gridDim.x) {   // workgroup-uniform
+        const uint64_t b = bstart[x];
+        const uint32_t up = bup[x], keys = near_up[x];
+        const bool hashed = keys <= ISECT_MAX_KEYS;
+        __syncthreads();   // (the previous row's probes are done)
+        if (hashed) {
+            for (uint32_t k = threadIdx.x; k < ISECT_SLOTS; k += 256) table[k] = 0u;
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < up; k += 256) {
+                const uint32_t ent = badj[b + k], id = ent >> 8;
+                if (id >= R) continue;                         // far
+                const uint32_t v = ((id + 1u) << 8) | (ent & 0xFFu);
+                uint32_t h = (id * 2654435761u) >> 20;     // 12 bits
+                while (atomicCAS(&table[h], 0u, v) != 0u) h = (h + 1u) & (ISECT_SLOTS - 1u);
+            }
+        }
+        __syncthreads();
+        if (t >= tr_per_row) continue;
+        const uint32_t u = x * tr_per_row + t;
         const uint32_t ent = t < ft ? far_top[(size_t)x * ft + t] : ~0u;
-        if (lane == 0) { h_tr_start[u] = tr_start[u]; if (u + 1 == R * tr_per_row) h_tr_start[u + 1] = tr_start[u + 1]; }
-        if (ent == ~0u) { if (lane == 0) tr_owner[u] = u; continue; }
-        const uint32_t id = ent >> 8, own = owner_of[id] - 1u;
-        if (lane == 0) tr_owner[u] = own;
-        if (own != u) continue;
-        const uint32_t src = fstart[id], cnt = fdeg[id], dst = tr_start[u];
-        for (uint32_t k = lane; k < cnt; k += 64) tr[dst + k] = fadj[src + k];
+        const uint32_t dst = tr_start[u];
+        if (lane == 0) { h_tr_start[u] = dst; if (u + 1 == R * tr_per_row) h_tr_start[u + 1] = tr_start[u + 1]; }
+        if (ent == ~0u) { if (lane == 0) h_tr_cnt[u] = 0u; continue; }
+        const uint32_t id = ent >> 8, src = fstart[id], cnt = fdeg[id];
+        if (!hashed || (uint64_t)dst + min(cnt, keys) > tr_cap) { if (lane == 0) h_tr_cnt[u] = ~0u; continue; }
+        uint32_t w = 0;
+        for (uint32_t k0 = 0; k0 < cnt; k0 += 64) {            // wave-uniform
+            const uint32_t k = k0 + lane;
+            const uint32_t fe = k < cnt ? fadj[src + k] : 0u, y = fe >> 8;
+            uint32_t found = 0;
+            if (k < cnt && y > x) {
+                uint32_t h = (y * 2654435761u) >> 20;
+                for (uint32_t v = table[h]; v != 0u; v = table[h]) {
+                    if ((v >> 8) == y + 1u) { found = v; break; }
+                    h = (h + 1u) & (ISECT_SLOTS - 1u);
+                }
+            }
+            const uint64_t mask = __ballot(found != 0u);
+            if (found) tr[dst + w + mbcnt64(mask)] = (y << 8) | min(found & 0xFFu, fe & 0xFFu);
+            w += (uint32_t)__popcll(mask);
+        }
+        if (lane == 0) h_tr_cnt[u] = w;
     }
 }
 
@@ -1774,23 +1811,24 @@ static uint32_t band_prep_grid(uint64_t entries, uint32_t items) {
     const uint64_t by_work = std::max<uint64_t>(32, std::min<uint64_t>(1024, entries / 4096));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(by_work, ((uint64_t)items + 3) / 4));
 }
-// The whole preparation behind the band's CSR, one stream, no host round trip: split -> list allocation + which lists travel -> the two
-// prefix sums -> near rows and transposed far part -> travelling lists.  h_*: the host's pinned block (device-visible addresses).
+// The whole preparation behind the band's CSR, one stream, no host round trip: split -> list allocation + room for what travels -> the two
+// prefix sums -> near rows and transposed far part -> the intersections.  h_*: the host's pinned block (device-visible addresses).
 hipError_t launch_band_prepare(const uint64_t *bstart, const uint32_t *bup, const void *badj, uint32_t R, uint64_t entries, uint32_t n, uint32_t ft,
                                uint32_t tr_per_row, const int32_t *seq_size, uint32_t *near_cnt, uint32_t *near_up, uint32_t *near_start, uint32_t *far_top,
-                               uint8_t *far_more, uint32_t *fdeg, uint32_t *fcur, uint32_t *owner_of, uint32_t *totals, uint32_t *fstart, uint32_t *fadj,
-                               uint32_t *tr_cnt, uint32_t *tr_start, uint32_t *h_near_start, uint32_t *h_near_up, uint32_t *h_far_top, uint8_t *h_far_more,
-                               uint32_t *h_near, uint32_t *h_tr_owner, uint32_t *h_tr_start, uint32_t *h_tr, hipStream_t s) {
+                               uint8_t *far_more, uint32_t *fdeg, uint32_t *fcur, uint32_t *totals, uint32_t *fstart, uint32_t *fadj,
+                               uint32_t *tr_cnt, uint32_t *tr_start, uint64_t tr_cap, uint32_t *h_near_start, uint32_t *h_near_up, uint32_t *h_far_top,
+                               uint8_t *h_far_more, uint32_t *h_near, uint32_t *h_tr_cnt, uint32_t *h_tr_start, uint32_t *h_tr, hipStream_t s) {
     if (R == 0) return hipSuccess;
+    if (tr_per_row > 4) return hipErrorInvalidValue;   // (k_band_isect: one wave of its workgroup per candidate)
     const uint32_t *adj = (const uint32_t *)badj;
     hipLaunchKernelGGL(k_band_split, dim3(band_prep_grid(entries, R)), dim3(256), 0, s, bstart, bup, adj, R, ft, seq_size, near_cnt, near_up, far_top, far_more, fdeg);
     hipLaunchKernelGGL(k_band_falloc, dim3(std::max<uint32_t>(8, std::min<uint32_t>(256, n / 16384))), dim3(256), 0, s, fdeg, n, fstart, totals + 2,
-                       far_top, R, ft, tr_per_row, owner_of, tr_cnt);
+                       far_top, R, ft, tr_per_row, near_up, tr_cnt);
     hipLaunchKernelGGL(k_band_offsets, dim3(1), dim3(256), 0, s, R, tr_per_row, near_cnt, near_start, tr_cnt, tr_start, totals);
     hipLaunchKernelGGL(k_band_fill, dim3(band_prep_grid(entries, R)), dim3(256), 0, s, bstart, bup, adj, R, ft, near_start, near_up, far_top, far_more, h_near,
                        fstart, fcur, fadj, h_near_start, h_near_up, h_far_top, h_far_more);
-    hipLaunchKernelGGL(k_band_tr_fill, dim3(band_prep_grid(entries, R * tr_per_row)), dim3(256), 0, s, far_top, R, ft, tr_per_row, owner_of,
-                       fstart, fdeg, fadj, tr_start, h_tr_owner, h_tr, h_tr_start);
+    hipLaunchKernelGGL(k_band_isect, dim3(std::min<uint32_t>(R, band_prep_grid(entries, R * 4))), dim3(256), 0, s, bstart, bup, adj, R, ft, tr_per_row, near_up,
+                       far_top, fstart, fdeg, fadj, tr_start, tr_cap, h_tr, h_tr_start, h_tr_cnt);
     return hipGetLastError();
 }
 
