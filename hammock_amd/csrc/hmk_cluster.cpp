@@ -207,7 +207,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             HIPCHK(ctx, ensure_buf(ctx, SB_BNCNT, (size_t)R1 * 4));
             HIPCHK(ctx, ensure_buf(ctx, SB_BNUP, (size_t)R1 * 4));
             HIPCHK(ctx, ensure_buf(ctx, SB_BNSTART, ((size_t)R1 + 1) * 4));
-            HIPCHK(ctx, ensure_buf(ctx, SB_BFTOP, (size_t)R1 * FAR_T * 4));
+            HIPCHK(ctx, ensure_buf(ctx, SB_BFTOP, (size_t)R1 * (FAR_T + BandPack::NEAR_T) * 4));   // far_top, then near_top
             HIPCHK(ctx, ensure_buf(ctx, SB_BFMORE, (size_t)R1 + 64));
             HIPCHK(ctx, ensure_buf(ctx, SB_FDEG, (size_t)n * 12 + 64));   // fdeg | fcur | owner_of (one fill), then the two totals
             HIPCHK(ctx, ensure_buf(ctx, SB_FSTART, (size_t)n * 4));
@@ -330,9 +330,10 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             const uint64_t cap = std::max<uint64_t>((uint64_t)entries, 1);   // no list is longer than the band has entries
             hipError_t e = ensure_buf(ctx, SB_FADJ, cap * 4);
             // the host's block (pinned; the kernels store into it themselves: no copy launches, no second round trip for sizes):
-            //   near_start [R1 + 1] | near_up [R1] | far_top [R1 x FAR_T] | tr_cnt [TRN] | tr_start [TRN + 1] | far_more [R1, padded] | near [cap] | tr [cap]
+            //   near_start [R1 + 1] | near_up [R1] | far_top [R1 x FAR_T] | tr_cnt [TRN] | tr_start [TRN + 1] | near_top [R1 x NEAR_T] | far_more [R1, padded] | near [cap] | tr [cap]
             const size_t o_nstart = 0, o_nup = o_nstart + ((size_t)R1 + 1) * 4, o_ftop = o_nup + (size_t)R1 * 4, o_trowner = o_ftop + (size_t)R1 * FAR_T * 4,
-                         o_trstart = o_trowner + (size_t)TRN * 4, o_fmore = o_trstart + ((size_t)TRN + 1) * 4, o_near = (o_fmore + R1 + 63) / 64 * 64,
+                         o_trstart = o_trowner + (size_t)TRN * 4, o_ntop = o_trstart + ((size_t)TRN + 1) * 4, o_fmore = o_ntop + (size_t)R1 * BandPack::NEAR_T * 4,
+                         o_near = (o_fmore + R1 + 63) / 64 * 64,
                          o_tr = o_near + (cap * 4 + 63) / 64 * 64;
             if (e == hipSuccess) e = ensure_pinned(&ctx->h_adj, &ctx->h_adj_cap, o_tr + cap * 4 + 64, 0);
             char *hb = (char *)ctx->h_adj, *db = nullptr;
@@ -345,7 +346,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                                         d_fdeg, d_fcur, d_totals, buf<uint32_t>(ctx, SB_FSTART), buf<uint32_t>(ctx, SB_FADJ),
                                         buf<uint32_t>(ctx, SB_TRCNT), buf<uint32_t>(ctx, SB_TRSTART), cap, (uint32_t *)(db + o_nstart), (uint32_t *)(db + o_nup),
                                         (uint32_t *)(db + o_ftop), (uint8_t *)(db + o_fmore), (uint32_t *)(db + o_near), (uint32_t *)(db + o_trowner),
-                                        (uint32_t *)(db + o_trstart), (uint32_t *)(db + o_tr), C);
+                                        (uint32_t *)(db + o_trstart), (uint32_t *)(db + o_tr), BandPack::NEAR_T, buf<uint32_t>(ctx, SB_BFTOP) + (size_t)R1 * FAR_T,
+                                        (uint32_t *)(db + o_ntop), C);
             if (e == hipSuccess) e = hipStreamSynchronize(C);
             if (e != hipSuccess) { hook_fail(e == hipErrorOutOfMemory ? HMK_ERR_OOM : HMK_ERR_DEVICE, std::string("band hand-over: ") + hipGetErrorString(e)); return nullptr; }
             const uint64_t n_near = ((const uint32_t *)(hb + o_nstart))[R1];
@@ -358,6 +360,7 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
             pack.near_up = (const uint32_t *)(hb + o_nup);
             pack.near = (const uint32_t *)(hb + o_near);
             pack.far_top = (const uint32_t *)(hb + o_ftop);
+            pack.near_top = (const uint32_t *)(hb + o_ntop);
             pack.far_more = (const uint8_t *)(hb + o_fmore);
             pack.tr_cnt = (const uint32_t *)(hb + o_trowner);
             pack.tr_start = (const uint32_t *)(hb + o_trstart);

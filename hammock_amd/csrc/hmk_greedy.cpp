@@ -110,7 +110,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
     }
     // HMK_PHASE1_HOST_BAND: the prepared band (BandPack) built here, literally, from the whole graph
     GreedyHooks hooks;
-    std::vector<uint32_t> b_near_start, b_near_up, b_near, b_far_top, b_tr_cnt, b_tr_start, b_tr;
+    std::vector<uint32_t> b_near_start, b_near_up, b_near, b_far_top, b_near_top, b_tr_cnt, b_tr_start, b_tr;
     std::vector<uint8_t> b_far_more;
     BandPack pack;
     bool use_pack = opt.host_band_rows > 0 && symmetric && n > 0;
@@ -130,18 +130,21 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
         b_near_start.assign((size_t)R1 + 1, 0);
         b_near_up.assign(R1, 0);
         b_far_top.assign((size_t)R1 * FT, ~0u);
+        b_near_top.assign((size_t)R1 * BandPack::NEAR_T, ~0u);
         b_far_more.assign(R1, 0);
         b_tr_start.assign((size_t)BandPack::TR_PER_ROW * R1 + 1, 0);
         b_tr_cnt.assign((size_t)BandPack::TR_PER_ROW * R1, 0);
         std::vector<int32_t> of_x(R1, INT_MIN);   // score(x, row) for the rows above x that are its neighbours
         for (uint32_t x = 0; x < R1; x++) {
-            std::vector<Nbr> far;
+            std::vector<Nbr> far, near_above;
             for (int pass = 0; pass < 2; pass++)   // the neighbours above x first
                 for (uint64_t q = start[x]; q < start[x + 1]; q++) {
                     const Nbr &a = adj[q];
                     if (a.m >= R1) { if (pass == 0) far.push_back(a); continue; }
-                    if ((pass == 0) == (a.m > x)) { b_near.push_back(ent(a.m, a.s)); if (pass == 0) b_near_up[x]++; }
+                    if ((pass == 0) == (a.m > x)) { b_near.push_back(ent(a.m, a.s)); if (pass == 0) { b_near_up[x]++; near_above.push_back(a); } }
                 }
+            std::sort(near_above.begin(), near_above.end(), [&](const Nbr &p, const Nbr &q) { return far_key(p) > far_key(q); });
+            for (uint32_t t = 0; t < BandPack::NEAR_T && t < near_above.size(); t++) b_near_top[(size_t)x * BandPack::NEAR_T + t] = ent(near_above[t].m, near_above[t].s);
             b_near_start[x + 1] = (uint32_t)b_near.size();
             std::sort(far.begin(), far.end(), [&](const Nbr &p, const Nbr &q) { return far_key(p) > far_key(q); });
             for (uint32_t t = 0; t < FT && t < far.size(); t++) b_far_top[(size_t)x * FT + t] = ent(far[t].m, far[t].s);
@@ -170,6 +173,7 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
         pack.rows = R1; pack.far_t = FT;
         pack.near_start = b_near_start.data(); pack.near_up = b_near_up.data(); pack.near = b_near.data();
         pack.far_top = b_far_top.data(); pack.far_more = b_far_more.data();
+        if (opt.host_band_far_t % 2 == 0) pack.near_top = b_near_top.data();   // (odd far_t: without the list, the plain scan)
         pack.tr_cnt = b_tr_cnt.data(); pack.tr_start = b_tr_start.data(); pack.tr = b_tr.data();
         hooks.band_pack = [&]() -> const BandPack * { return &pack; };
         hooks.far_row = [&](uint32_t id, std::vector<uint32_t> &out) -> bool { out.clear(); band_nbrs(id, out); return true; };
@@ -462,14 +466,25 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                 const uint32_t *ft = bp->far_top + (size_t)k * FT;
                 if (remaining - 1 == 0) B = Found{NEAR_DUMMY, -1, INT_MIN};
                 else {
+                    // the near neighbours above k: the device listed the best few in the reference's order -- the first one still free is
+                    // the best; the whole leading section only when every listed one has been taken and there are more
+                    bool scan = true;
+                    if (bp->near_top) {
+                        const uint32_t *nt = bp->near_top + (size_t)k * BandPack::NEAR_T;
+                        uint32_t t = 0;
+                        for (; t < BandPack::NEAR_T && nt[t] != ~0u; t++)
+                            if (state[nt[t] >> 8] == ST_FREE) { consider(B, nt[t] >> 8, (int32_t)(nt[t] & 0xFFu)); break; }
+                        scan = t == BandPack::NEAR_T && n_up > BandPack::NEAR_T;   // (ran off the list's end without a free one)
+                    }
                     // (whether a neighbour is still free is a coin toss: no branch on it -- a taken one only where a candidate can
                     // still win, which is rare after the first few)
                     int32_t bar = 0;
-                    for (uint32_t q = 0; q < n_up; q++) {
+                    for (uint32_t q = 0; scan && q < n_up; q++) {
                         const uint32_t m = row[q] >> 8;
                         const int32_t s = (int32_t)(row[q] & 0xFFu), s_free = state[m] == ST_FREE ? s : -1;
                         if (s_free >= bar) { consider(B, m, s); bar = B.score; }
                     }
+                    visited = scan ? n_up : 0;
                     uint32_t t = 0;
                     bool far_found = false;
                     for (; t < FT && ft[t] != ~0u; t++)
@@ -483,7 +498,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
                             if (state[e >> 8] == ST_FREE) consider(B, e >> 8, (int32_t)(e & 0xFFu));
                     }
                 }
-                sec_end(1, n_up);
+                sec_end(1, visited);
                 bool absorb = false;
                 int32_t joined = -1;
                 if (A.kind != NEAR_NULL) {                          // :94

@@ -111,6 +111,9 @@ using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::
 // hmk_cluster.cpp, k_band_* in k_edges.hip): what a step of the loop needs of row x < rows, split by where the neighbour lies.
 //   near        the neighbours with an id below `rows` (band rows themselves): near[near_start[x] .. near_start[x + 1]), the
 //               first near_up[x] of them with an id above x.  Entries are id << 8 | (score - base), as in the packed adjacency.
+//   near_top    the best NEAR_T of the row's near neighbours ABOVE it by the same key as far_top, best first, ~0u = no more: the first
+//               one still free is the best near candidate of :93; only when all listed ones have been taken (and the row has more)
+//               does the host scan the near row's leading section.  May be null (then it always scans).
 //   far_top     the row's best FAR neighbours (id >= rows) by the reference's key (score, Cluster.size(), smaller id --
 //               ClinkageSequenceClusterer.java:166-173, :275-289), best first, far_t per row, ~0u = no more; far_more[x] != 0:
 //               the row has far neighbours beyond the far_t listed.  A far sequence changes state in phase 1 only by being
@@ -124,9 +127,10 @@ using GreedyPrecheck = std::function<bool(const int32_t *cluster_of, const std::
 struct BandPack {
     static constexpr uint32_t TR_PER_ROW = 4;   // (2: a dozen lists per 25,000 steps had to be fetched on demand at 10^6 -- and a small copy issued while
                                                 // the pass runs waits milliseconds for a slot)
+    static constexpr uint32_t NEAR_T = 4;       // near_top entries per row
     uint32_t rows = 0, far_t = 0;
     const uint32_t *near_start = nullptr, *near_up = nullptr, *near = nullptr;
-    const uint32_t *far_top = nullptr;
+    const uint32_t *far_top = nullptr, *near_top = nullptr;
     const uint8_t *far_more = nullptr;
     const uint32_t *tr_cnt = nullptr, *tr_start = nullptr, *tr = nullptr;
 };

@@ -80,7 +80,8 @@ hipError_t launch_band_prepare(const uint64_t *bstart, const uint32_t *bup, cons
                                uint32_t tr_per_row, const int32_t *seq_size, uint32_t *near_cnt, uint32_t *near_up, uint32_t *near_start, uint32_t *far_top,
                                uint8_t *far_more, uint32_t *fdeg, uint32_t *fcur, uint32_t *totals, uint32_t *fstart, uint32_t *fadj,
                                uint32_t *tr_cnt, uint32_t *tr_start, uint64_t tr_cap, uint32_t *h_near_start, uint32_t *h_near_up, uint32_t *h_far_top,
-                               uint8_t *h_far_more, uint32_t *h_near, uint32_t *h_tr_cnt, uint32_t *h_tr_start, uint32_t *h_tr, hipStream_t s);
+                               uint8_t *h_far_more, uint32_t *h_near, uint32_t *h_tr_cnt, uint32_t *h_tr_start, uint32_t *h_tr, uint32_t nt,
+                               uint32_t *near_top, uint32_t *h_near_top, hipStream_t s);
 
 hipError_t launch_compact_edges(const uint64_t *edges, uint64_t cap_per_shard, const unsigned long long *counts,
                                 uint64_t *out, uint64_t out_capacity, unsigned long long *total, hipStream_t s);

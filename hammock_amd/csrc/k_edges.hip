@@ -1587,53 +1587,61 @@ constexpr uint32_t BAND_REG_KEYS = 8, BAND_REG_ROW = 64 * BAND_REG_KEYS;
 __global__ void __launch_bounds__(256)
 k_band_split(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bup, const uint32_t *__restrict__ badj, uint32_t R, uint32_t ft,
              const int32_t *__restrict__ seq_size, uint32_t *__restrict__ near_cnt, uint32_t *__restrict__ near_up,
-             uint32_t *__restrict__ far_top, uint8_t *__restrict__ far_more, uint32_t *__restrict__ fdeg) {
+             uint32_t *__restrict__ far_top, uint8_t *__restrict__ far_more, uint32_t *__restrict__ fdeg, uint32_t nt,
+             uint32_t *__restrict__ near_top) {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6); x < R; x += gridDim.x * 4) {   // wave-uniform
         const uint64_t b = bstart[x], e = bstart[x + 1];
         const uint32_t up = bup[x];
         const bool in_regs = up <= BAND_REG_ROW;   // wave-uniform
-        unsigned long long keys[BAND_REG_KEYS];
+        unsigned long long keys[BAND_REG_KEYS];   // of every upper entry; is_far: which side it is on
+        bool is_far[BAND_REG_KEYS];
 #pragma unroll
-        for (uint32_t j = 0; j < BAND_REG_KEYS; j++) keys[j] = 0;
+        for (uint32_t j = 0; j < BAND_REG_KEYS; j++) { keys[j] = 0; is_far[j] = false; }
         uint32_t n_near_up = 0, n_far = 0;
-        auto visit = [&](uint32_t k, unsigned long long *key_out) {
+        auto visit = [&](uint32_t k, unsigned long long *key_out, bool *far_out) {
             const uint32_t ent = k < up ? badj[b + k] : 0u;
             const bool far = k < up && (ent >> 8) >= R;
             if (far) atomicAdd(&fdeg[ent >> 8], 1u);
-            if (key_out) *key_out = far ? band_far_key(ent, seq_size) : 0ull;
+            if (key_out) { *key_out = k < up ? band_far_key(ent, seq_size) : 0ull; *far_out = far; }
             n_far += (uint32_t)__popcll(__ballot(far));
             n_near_up += (uint32_t)__popcll(__ballot(k < up && !far));
         };
         if (in_regs) {
 #pragma unroll
             for (uint32_t j = 0; j < BAND_REG_KEYS; j++)
-                if (j * 64 < up) visit(j * 64 + lane, &keys[j]);   // wave-uniform test
+                if (j * 64 < up) visit(j * 64 + lane, &keys[j], &is_far[j]);   // wave-uniform test
         } else {
-            for (uint32_t k0 = 0; k0 < up; k0 += 64) visit(k0 + lane, nullptr);
+            for (uint32_t k0 = 0; k0 < up; k0 += 64) visit(k0 + lane, nullptr, nullptr);
         }
         // the FT best far candidates, one per turn: the largest key below the last one taken (keys are unique: they end in the id;
         // a key is never 0: Cluster.size() >= 1)
-        unsigned long long bound = ~0ull;
-        for (uint32_t t = 0; t < ft; t++) {
-            unsigned long long best = 0;
-            if (t < n_far) {
-                if (in_regs) {
+        // (the same for the near neighbours above x -- the candidates whose state changes step by step: near_top lists the nt best, and the
+        // host scans the whole near row only when every listed one has been taken)
+        for (int side = 0; side < 2; side++) {   // 0: far, 1: near
+            const uint32_t cnt_side = side == 0 ? n_far : n_near_up, take = side == 0 ? ft : nt;
+            uint32_t *top = side == 0 ? far_top : near_top;
+            unsigned long long bound = ~0ull;
+            for (uint32_t t = 0; t < take; t++) {
+                unsigned long long best = 0;
+                if (t < cnt_side) {
+                    if (in_regs) {
 #pragma unroll
-                    for (uint32_t j = 0; j < BAND_REG_KEYS; j++)
-                        if (keys[j] < bound && keys[j] > best) best = keys[j];
-                } else {
-                    for (uint32_t k = lane; k < up; k += 64) {
-                        const uint32_t ent = badj[b + k];
-                        if ((ent >> 8) < R) continue;
-                        const unsigned long long key = band_far_key(ent, seq_size);
-                        if (key < bound && key > best) best = key;
+                        for (uint32_t j = 0; j < BAND_REG_KEYS; j++)
+                            if (is_far[j] == (side == 0) && keys[j] < bound && keys[j] > best) best = keys[j];
+                    } else {
+                        for (uint32_t k = lane; k < up; k += 64) {
+                            const uint32_t ent = badj[b + k];
+                            if (((ent >> 8) >= R) != (side == 0)) continue;
+                            const unsigned long long key = band_far_key(ent, seq_size);
+                            if (key < bound && key > best) best = key;
+                        }
                     }
+                    best = wave_max_u64(best);
                 }
-                best = wave_max_u64(best);
+                if (lane == 0) top[(size_t)x * take + t] = best ? ((uint32_t)(~best & 0xFFFFFFull) << 8) | (uint32_t)(best >> 56) : ~0u;
+                bound = best;   // (0 once the row has no more: nothing lies below it)
             }
-            if (lane == 0) far_top[(size_t)x * ft + t] = best ? ((uint32_t)(~best & 0xFFFFFFull) << 8) | (uint32_t)(best >> 56) : ~0u;
-            bound = best;   // (0 once the row has no more: nothing lies below it)
         }
         if (lane == 0) {
             near_up[x] = n_near_up;
@@ -1723,7 +1731,8 @@ k_band_fill(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bu
             const uint32_t *__restrict__ near_start, const uint32_t *__restrict__ near_up, const uint32_t *__restrict__ far_top,
             const uint8_t *__restrict__ far_more, uint32_t *__restrict__ near, const uint32_t *__restrict__ fstart,
             uint32_t *__restrict__ fcur, uint32_t *__restrict__ fadj, uint32_t *__restrict__ h_near_start, uint32_t *__restrict__ h_near_up,
-            uint32_t *__restrict__ h_far_top, uint8_t *__restrict__ h_far_more) {
+            uint32_t *__restrict__ h_far_top, uint8_t *__restrict__ h_far_more, uint32_t nt, const uint32_t *__restrict__ near_top,
+            uint32_t *__restrict__ h_near_top) {
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6); x < R; x += gridDim.x * 4) {   // wave-uniform
         const uint64_t b = bstart[x], e = bstart[x + 1];
@@ -1731,6 +1740,7 @@ k_band_fill(const uint64_t *__restrict__ bstart, const uint32_t *__restrict__ bu
         uint32_t w = near_start[x];
         if (lane == 0) { h_near_start[x] = w; h_near_up[x] = near_up[x]; h_far_more[x] = far_more[x]; if (x + 1 == R) h_near_start[R] = near_start[R]; }
         if (lane < ft) h_far_top[(size_t)x * ft + lane] = far_top[(size_t)x * ft + lane];
+        if (lane < nt) h_near_top[(size_t)x * nt + lane] = near_top[(size_t)x * nt + lane];
         for (uint32_t k0 = 0; k0 < len; k0 += 64) {
             const uint32_t k = k0 + lane;
             const uint32_t ent = k < len ? badj[b + k] : 0u;
@@ -1817,16 +1827,17 @@ hipError_t launch_band_prepare(const uint64_t *bstart, const uint32_t *bup, cons
                                uint32_t tr_per_row, const int32_t *seq_size, uint32_t *near_cnt, uint32_t *near_up, uint32_t *near_start, uint32_t *far_top,
                                uint8_t *far_more, uint32_t *fdeg, uint32_t *fcur, uint32_t *totals, uint32_t *fstart, uint32_t *fadj,
                                uint32_t *tr_cnt, uint32_t *tr_start, uint64_t tr_cap, uint32_t *h_near_start, uint32_t *h_near_up, uint32_t *h_far_top,
-                               uint8_t *h_far_more, uint32_t *h_near, uint32_t *h_tr_cnt, uint32_t *h_tr_start, uint32_t *h_tr, hipStream_t s) {
+                               uint8_t *h_far_more, uint32_t *h_near, uint32_t *h_tr_cnt, uint32_t *h_tr_start, uint32_t *h_tr, uint32_t nt,
+                               uint32_t *near_top, uint32_t *h_near_top, hipStream_t s) {
     if (R == 0) return hipSuccess;
     if (tr_per_row > 4) return hipErrorInvalidValue;   // (k_band_isect: one wave of its workgroup per candidate)
     const uint32_t *adj = (const uint32_t *)badj;
-    hipLaunchKernelGGL(k_band_split, dim3(band_prep_grid(entries, R)), dim3(256), 0, s, bstart, bup, adj, R, ft, seq_size, near_cnt, near_up, far_top, far_more, fdeg);
+    hipLaunchKernelGGL(k_band_split, dim3(band_prep_grid(entries, R)), dim3(256), 0, s, bstart, bup, adj, R, ft, seq_size, near_cnt, near_up, far_top, far_more, fdeg, nt, near_top);
     hipLaunchKernelGGL(k_band_falloc, dim3(std::max<uint32_t>(8, std::min<uint32_t>(256, n / 16384))), dim3(256), 0, s, fdeg, n, fstart, totals + 2,
                        far_top, R, ft, tr_per_row, near_up, tr_cnt);
     hipLaunchKernelGGL(k_band_offsets, dim3(1), dim3(256), 0, s, R, tr_per_row, near_cnt, near_start, tr_cnt, tr_start, totals);
     hipLaunchKernelGGL(k_band_fill, dim3(band_prep_grid(entries, R)), dim3(256), 0, s, bstart, bup, adj, R, ft, near_start, near_up, far_top, far_more, h_near,
-                       fstart, fcur, fadj, h_near_start, h_near_up, h_far_top, h_far_more);
+                       fstart, fcur, fadj, h_near_start, h_near_up, h_far_top, h_far_more, nt, near_top, h_near_top);
     hipLaunchKernelGGL(k_band_isect, dim3(std::min<uint32_t>(R, band_prep_grid(entries, R * 4))), dim3(256), 0, s, bstart, bup, adj, R, ft, tr_per_row, near_up,
                        far_top, fstart, fdeg, fadj, tr_start, tr_cap, h_tr, h_tr_start, h_tr_cnt);
     return hipGetLastError();
