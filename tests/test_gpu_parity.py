@@ -449,6 +449,34 @@ def test_greedy_device_loop_long_subscriber_lists(gpu, blosum62, coracle, monkey
         assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
 
 
+def test_greedy_band_rows_beyond_the_intersection_table(gpu, blosum62, coracle):
+    """The band's preparation (k_band_isect) hashes a row's near neighbours in an LDS table of 4,096 slots; a row with more than
+    2,800 of them is handed over unprepared (tr_cnt = ~0) and phase 1 then fetches the far candidate's whole list and filters it
+    against the row itself.  Here: 17,000 peptides (a band needs 16,384) over three letters at thresholds that 94 % / 88 % of all pairs reach, with a band of
+    4,224 rows -- the first rows have 3,000+ near neighbours above them, later ones fewer, so prepared and unprepared rows meet in one call; counts make the
+    size tie-breaks of the candidate lists (near_top, far_top) matter."""
+    rng = np.random.default_rng(77)
+    peps = random_peptides(rng, 17000, 12, 12, alphabet=3)
+    sizes = rng.integers(1, 5, size=len(peps)).astype(np.int32)
+    res, off = coracle.pack(peps)
+    perm = coracle.sort_order(res, off, sizes, "size")
+    peps = [peps[k] for k in perm]
+    sizes = sizes[perm]
+    res, off = coracle.pack(peps)
+    for thr, maxc in ((14, 1600), (16, 1600)):
+        st, ocid, oorder, ostats = coracle.greedy_cluster(blosum62, res, off, sizes, 0, 3, 0, thr, maxc, 16)
+        ctx, _, _ = ctx_for(blosum62, res=res, off=off, sizes=sizes)
+        if st != 0:
+            with pytest.raises(hammock_amd.ReferenceWouldCrash):
+                ctx.greedy_cluster(3, 0, thr, maxc)
+            continue
+        cid, order, stats = ctx.greedy_cluster(3, 0, thr, maxc)
+        assert ctx.greedy_phases()["band_bytes"] > 0
+        assert np.array_equal(cid, ocid) and np.array_equal(order, oorder)
+        assert np.array_equal(ctx.member_rank[:len(cid)], ostats.member_rank)
+        ctx.close()
+
+
 def test_greedy_3e5_vs_oracle(gpu, blosum62, coracle):
     """3 x 10^5 peptides (between BASELINE configs 3 and 5): the size at which the device-side second loop takes over
     by itself; identical membership, list order and member order against the oracle's literal greedy."""
