@@ -2,7 +2,7 @@
 """Long randomized sweep of hmk_greedy_cluster against the oracle's literal greedy: random sizes (counts),
 mixed lengths, thresholds around the reference default, cluster limits from tiny to large, shift penalty,
 asymmetric matrices, including the inputs on which the reference throws (crash parity).
-Usage: python tests/tools/fuzz_greedy.py [trials] [seed]"""
+Usage: python tests/tools/fuzz_greedy.py [trials] [seed] [band]     (band: every input large enough for the prepared band, one length)"""
 import json
 import os
 import sys
@@ -17,6 +17,7 @@ from oracle import c_oracle  # noqa: E402
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+BAND = len(sys.argv) > 3 and sys.argv[3] == "band"
 with open(os.path.join(ROOT, "tests", "golden", "matrices.json")) as fh:
     blosum62 = np.asarray(json.load(fh)["matrices"]["blosum62"], dtype=np.int32)
 rng = np.random.default_rng(seed)
@@ -30,6 +31,9 @@ for trial in range(trials):
     lo = int(rng.integers(6, 14))
     hi = int(min(32, lo + rng.integers(0, 9)))
     n = int(rng.integers(300, 5000)) if trial % 4 else int(rng.integers(5000, 30000))   # every fourth input is big enough for the band + device loop
+    if BAND:
+        n = int(rng.integers(16384, 36000))
+        hi = lo if trial % 3 else hi          # mostly one length (a bucket reordered by score bound has no band)
     alphabet_seed = int(rng.integers(1, 10 ** 6))
     res, off = synth_peptides(alphabet_seed, n, lo, hi)
     if trial % 3 == 0:   # families of near-duplicates: dense neighbourhoods, big clusters
@@ -54,6 +58,8 @@ for trial in range(trials):
     X = int(min(max(1, round(L.mean() / 4)), L.min() - 1))
     p = int(rng.choice([0, 0, -1, -2]))
     maxc = int(max(1, rng.choice([2, 10, int(n * 0.025) + 1, n // 8 + 1])))
+    if BAND:
+        maxc = int(max(1, rng.choice([10, int(n * 0.025) + 1, n // 10, n // 5])))
     st, ocid, oorder, ostats = c_oracle.greedy_cluster(M, res, off, sizes, 0, X, p, thr, maxc, 16)
     mode = [None, "device", "host", "host"][trial % 4 if trial % 8 >= 4 else 0]   # half the trials: the default path
     if mode:
