@@ -34,6 +34,7 @@ struct DevJob {
     unsigned long long pre_total = 0;
     uint64_t need_edges = 0, need_inbox = 0;   // (-2) what the next attempt must hold
     double t_band = 0, t_scored = 0, t_sent = 0, t_csr = 0, t_pre = 0;   // HMK_GREEDY_TIMING: ms since the call began
+    unsigned long long route_off[HMK_MAX_DEVICES + 1] = {0};   // (valid once sent_state is 1) where its block for owner t begins in its SB_ROUTE
 };
 
 int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int threshold, int max_clusters, int32_t *cluster_id,
@@ -203,10 +204,12 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                     J.band_total = h_rcnt[16];
                     if (J.band_total > J.band_region) set_state(&DevJob::band_state, J, -1);
                     else {
-                        if (J.band_total)
-                            e = hipMemcpyPeerAsync(root_band + J.band_off, ctx->device, buf<uint64_t>(c, SB_PEERBAND), c->device, J.band_total * sizeof(uint64_t), X);
-                        if (e == hipSuccess) e = hipMemcpyPeerAsync(root_cnt + HMK_MAX_SEGS + d, ctx->device, d_rcnt + HMK_MAX_DEVICES, c->device, 8, X);
-                        if (e == hipSuccess) e = hipStreamSynchronize(X);   // (landed: the root's copy stream needs no event of another device)
+                        if (c->device != ctx->device) {   // (a context on the root's own device is read where its block lies: below, band_segs)
+                            if (J.band_total)
+                                e = hipMemcpyPeerAsync(root_band + J.band_off, ctx->device, buf<uint64_t>(c, SB_PEERBAND), c->device, J.band_total * sizeof(uint64_t), X);
+                            if (e == hipSuccess) e = hipMemcpyPeerAsync(root_cnt + HMK_MAX_SEGS + d, ctx->device, d_rcnt + HMK_MAX_DEVICES, c->device, 8, X);
+                            if (e == hipSuccess) e = hipStreamSynchronize(X);   // (landed: the root's copy stream needs no event of another device)
+                        }
                         if (e != hipSuccess) { hip_fail("band hand-over", e); return; }
                         J.t_band = now_ms();
                         set_state(&DevJob::band_state, J, 1);
@@ -226,7 +229,7 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
             {
                 bool too_small = false;
                 for (uint32_t t = 0; t < G; t++)
-                    if (t != d && h_rcnt[t] > inbox_cap[t]) {   // (the owner's inbox is too small for this block: grown for the next attempt)
+                    if (t != d && dev(t)->device != c->device && h_rcnt[t] > inbox_cap[t]) {   // (the owner's inbox is too small for this block: grown for the next attempt)
                         std::lock_guard<std::mutex> l(mu);
                         jobs[t]->need_inbox = std::max<uint64_t>(jobs[t]->need_inbox, h_rcnt[t] + h_rcnt[t] / 8 + 65536);
                         too_small = true;
@@ -234,15 +237,19 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                 if (too_small) { set_state(&DevJob::sent_state, J, -2); return; }
             }
             std::vector<unsigned long long> off(G + 1, 0);
-            for (uint32_t t = 0; t < G; t++) off[t + 1] = off[t] + h_rcnt[t];
+            for (uint32_t t = 0; t < G; t++) { off[t + 1] = off[t] + h_rcnt[t]; J.route_off[t + 1] = off[t + 1]; }
             for (uint32_t t = 0; t < G && e == hipSuccess; t++) {
                 if (t == d) continue;
                 hmk_ctx *o = dev(t);
                 const uint32_t slot = d < t ? d : d - 1;   // this sender's place among the owner's G - 1 senders
                 const uint32_t o_r0 = jobs[t]->r0, o_len = jobs[t]->r1 - jobs[t]->r0;
-                if (h_rcnt[t])
-                    e = hipMemcpyPeerAsync(buf<uint64_t>(o, SB_PEER) + (uint64_t)slot * inbox_cap[t], o->device, d_route + off[t], c->device, h_rcnt[t] * sizeof(uint64_t), X);
-                if (e == hipSuccess) e = hipMemcpyPeerAsync(buf<unsigned long long>(o, SB_PEERCNT) + slot, o->device, d_rcnt + t, c->device, 8, X);
+                // (an owner on this very device -- a device list that names a GPU several times -- reads the block where it lies: a copy
+                // inside one device is a blit kernel that waits for workgroup slots beside every context's pass)
+                if (o->device != c->device) {
+                    if (h_rcnt[t])
+                        e = hipMemcpyPeerAsync(buf<uint64_t>(o, SB_PEER) + (uint64_t)slot * inbox_cap[t], o->device, d_route + off[t], c->device, h_rcnt[t] * sizeof(uint64_t), X);
+                    if (e == hipSuccess) e = hipMemcpyPeerAsync(buf<unsigned long long>(o, SB_PEERCNT) + slot, o->device, d_rcnt + t, c->device, 8, X);
+                }
                 if (e == hipSuccess && p_deg && o_len) {
                     uint32_t *slice = buf<uint32_t>(o, SB_PEERDEG) + (size_t)slot * 2 * rows_per;
                     e = hipMemcpyPeerAsync(slice, o->device, p_deg + o_r0, c->device, (size_t)o_len * 4, X);
@@ -260,7 +267,13 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
                 in.s[in.n++] = EdgeSeg{d_route + off[d], d_rcnt + d, h_rcnt[d]};
                 const uint32_t *slices[HMK_MAX_DEVICES] = {nullptr};
                 for (uint32_t k = 0; k + 1 < G; k++) {
-                    in.s[in.n++] = EdgeSeg{buf<uint64_t>(c, SB_PEER) + (uint64_t)k * inbox_cap[d], buf<unsigned long long>(c, SB_PEERCNT) + k, inbox_cap[d]};
+                    const uint32_t sender = k < d ? k : k + 1;
+                    hmk_ctx *sc = dev(sender);
+                    if (sc->device == c->device) {   // (its block, where the sender dealt it)
+                        const DevJob &SJ = *jobs[sender];
+                        in.s[in.n++] = EdgeSeg{buf<uint64_t>(sc, SB_ROUTE) + SJ.route_off[d], buf<unsigned long long>(sc, SB_ROUTECNT) + d, SJ.route_off[d + 1] - SJ.route_off[d]};
+                    } else
+                        in.s[in.n++] = EdgeSeg{buf<uint64_t>(c, SB_PEER) + (uint64_t)k * inbox_cap[d], buf<unsigned long long>(c, SB_PEERCNT) + k, inbox_cap[d]};
                     slices[k] = buf<uint32_t>(c, SB_PEERDEG) + (size_t)k * 2 * rows_per;
                 }
                 if (p_deg) e = launch_owned_degrees(p_deg, n, J.r0, J.r1, slices, G - 1, Q);
@@ -351,8 +364,13 @@ int greedy_cluster_multi(hmk_ctx *ctx, int max_shift, int shift_penalty, int thr
         for (auto &jp : jobs) src.pieces.push_back(EdgeSource::Piece{jp->c, jp->r0, jp->r1});
         src.seg_cap = ctx->d_edges_cap / HMK_EDGE_SHARDS;
         src.band_segs = shard_segments(ctx->d_edges, src.seg_cap, buf<unsigned long long>(ctx, SB_BCOUNTS));
-        for (uint32_t d = 1; d < G; d++)
-            src.band_segs.s[src.band_segs.n++] = EdgeSeg{root_band + jobs[d]->band_off, root_cnt + HMK_MAX_SEGS + d, jobs[d]->band_region};
+        for (uint32_t d = 1; d < G; d++) {
+            hmk_ctx *pc = dev(d);
+            if (pc->device == ctx->device)   // (a context on the root's own device: its compacted band block and that block's size, where they lie)
+                src.band_segs.s[src.band_segs.n++] = EdgeSeg{buf<uint64_t>(pc, SB_PEERBAND), buf<unsigned long long>(pc, SB_ROUTECNT) + HMK_MAX_DEVICES, jobs[d]->band_region};
+            else
+                src.band_segs.s[src.band_segs.n++] = EdgeSeg{root_band + jobs[d]->band_off, root_cnt + HMK_MAX_SEGS + d, jobs[d]->band_region};
+        }
         src.band_rows = (uint32_t)band_req;
         src.clink = clink;
         src.before_band = [&]() -> int { return wait_all(&DevJob::band_state) > 0 ? HMK_OK : -1; };
