@@ -36,7 +36,7 @@ if [ "$PART" = bench ]; then
     rm -rf "$O/trace" "$O/trace_local" "$O"/pmc_*/
 elif [ "$PART" = passes ]; then
     cd "$R"
-    timeout -k 10 300 python tools/bench_uniform.py 100000 6,7,8,9,10,11,12,13,14,15,16,17,18,19,20 > "$O/round5_uniform_lengths.jsonl" 2> /dev/null; echo uniform $?
+    timeout -k 10 300 python tools/bench_uniform.py 100000 6,7,8,9,10,11,12,13,14,15,16,17,18,19,20 > "$O/round5_uniform_lengths.jsonl" 2> /dev/null; cp "$O/round5_uniform_lengths.jsonl" "$O/round5_uniform_lengths_all.jsonl"; echo uniform $?
     for p in "12 3 20 60 26 14" "7 2 12 60" "9 2 15 60" "6 2 11 60" "8 2 14 60"; do timeout -k 10 100 python tools/rows_probe_lx.py $p 2> /dev/null; done > "$O/round5_rows_probe_thresholds.jsonl"; echo probe $?
     timeout -k 10 100 python tools/run_fasta_neighbors.py tests/golden/antibodies.fa.gz > "$O/round5_antibodies_neighbors.json" 2> /dev/null; echo antibodies $?
     timeout -k 10 120 python tools/run_config4a.py > "$O/round5_config4a.json" 2> /dev/null; echo 4a $?
