@@ -117,16 +117,17 @@ int greedy_from_edges(uint32_t n, const int32_t *sizes, const uint64_t *edges, u
     if (use_pack)
         for (const Nbr &a : adj)
             if (a.s - threshold < 0 || a.s - threshold > 255) { use_pack = false; break; }
+    // (what the hooks below call lives as long as they do: declared here, not inside the block that fills the pack)
+    const uint32_t R1 = std::min<uint32_t>((uint32_t)std::max(0, opt.host_band_rows), n), FT = (uint32_t)std::max(1, opt.host_band_far_t > 0 ? opt.host_band_far_t : 8);
+    auto ent = [&](uint32_t id, int32_t s) { return id << 8 | (uint32_t)(s - threshold); };
+    auto far_key = [&](const Nbr &a) {   // (score, Cluster.size(), smaller id), larger = better
+        return std::make_tuple(a.s, (int64_t)(sizes ? sizes[a.m] : 1), -(int64_t)a.m);
+    };
+    auto band_nbrs = [&](uint32_t id, std::vector<uint32_t> &out) {   // the rows below R1 that have `id` as a neighbour
+        for (uint64_t q = start[id]; q < start[id + 1]; q++)
+            if (adj[q].m < R1) out.push_back(ent(adj[q].m, adj[q].s));
+    };
     if (use_pack) {
-        const uint32_t R1 = std::min<uint32_t>((uint32_t)opt.host_band_rows, n), FT = (uint32_t)std::max(1, opt.host_band_far_t > 0 ? opt.host_band_far_t : 8);
-        auto ent = [&](uint32_t id, int32_t s) { return id << 8 | (uint32_t)(s - threshold); };
-        auto far_key = [&](const Nbr &a) {   // (score, Cluster.size(), smaller id), larger = better
-            return std::make_tuple(a.s, (int64_t)(sizes ? sizes[a.m] : 1), -(int64_t)a.m);
-        };
-        auto band_nbrs = [&](uint32_t id, std::vector<uint32_t> &out) {   // the rows below R1 that have `id` as a neighbour
-            for (uint64_t q = start[id]; q < start[id + 1]; q++)
-                if (adj[q].m < R1) out.push_back(ent(adj[q].m, adj[q].s));
-        };
         b_near_start.assign((size_t)R1 + 1, 0);
         b_near_up.assign(R1, 0);
         b_far_top.assign((size_t)R1 * FT, ~0u);

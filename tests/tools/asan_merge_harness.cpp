@@ -18,8 +18,15 @@ int main() {
         hmk_greedy_stats st;
         std::string err;
         const int mc = (int)(n / 40) + (trial % 4 == 0 ? 0 : 1);
+        hmk::GreedyOptions opt;
+        if (const char *t = getenv("HMK_PHASE1_THREADS")) opt.phase1_threads = atoi(t);
+        if (const char *w = getenv("HMK_PHASE1_WINDOW")) opt.phase1_window = atoi(w);
+        if (trial % 3 != 2) {   // phase 1 on a prepared band (built on the host): bands that end before, inside and after phase 1
+            opt.host_band_rows = (int)(1 + rng() % (n + 10));
+            opt.host_band_far_t = 1 + (int)(rng() % 5);
+        }
         int rc = hmk::greedy_from_edges(n, trial % 2 ? sizes.data() : nullptr, edges.data(), edges.size(), trial % 5 != 4, 20, mc,
-                                        cid.data(), order.data(), rank.data(), &st, &err);
+                                        cid.data(), order.data(), rank.data(), &st, &err, opt);
         printf("trial %d n %u edges %zu rc %d clusters %d result %d\n", trial, n, edges.size(), rc, st.n_multi, st.n_result_clusters);
     }
     return 0;
