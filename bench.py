@@ -540,27 +540,37 @@ def main():
                     phases.append(gctx.greedy_phases())
                 mid = int(np.argsort(walls)[1])
                 wall = walls[mid]
+                # ... and what a resident caller sees that issues its calls back to back: twenty calls with nothing between them (a GPU
+                # that has idled for a millisecond starts the next pass slower)
+                tight, tight_score = [], []
+                for _ in range(20):
+                    t = time.perf_counter()
+                    gctx.greedy_cluster(MAX_SHIFT, SHIFT_PENALTY, THRESHOLD, maxc)
+                    tight.append(time.perf_counter() - t)
+                    tight_score.append(gctx.greedy_phases()["score_ms"])
                 line["greedy_end_to_end"] = {
-                    "wall_s": wall, "wall_s_all": walls, "first_call_s": first["total_ms"] * 1e-3, "host_sort_s": sort_s, "clusters": int(gstats.n_multi),
+                    "wall_s": wall, "wall_s_all": walls, "wall_s_back_to_back": float(np.median(tight)), "wall_s_back_to_back_min": float(min(tight)),
+                    "score_ms_back_to_back": float(np.median(tight_score)),
+                    "first_call_s": first["total_ms"] * 1e-3, "host_sort_s": sort_s, "clusters": int(gstats.n_multi),
                     "result_list": int(gstats.n_result_clusters), "phases_ms": phases[mid],
                     "note": "hmk_greedy_cluster = the span of Hammock.java:409 on the sequences in the reference's default order "
                             "(-R size; host_sort_s = numpy's sort, the span of :407): scoring, CSR, phase 1 on the host over the "
                             "band rows while the rest is scored, second loop on the device; phases overlap (see "
                             "include/hammock_hip.h hmk_greedy_phases)"}
             if not args.no_configs and n == N_SEQ:
-                # (the clustering context's streams go first: a process has few hardware queues, every live stream is mapped onto
-                # one of them, and the mixed-length pass of config 4a -- 26 launches dealt to three streams -- loses 8 % of its
-                # overlap when its streams share queues with idle ones: 4.53 ms inside this run against 4.17 ms on its own)
-                if not args.no_greedy:
-                    gctx.close()
-                if world == 1:
-                    ctx.close()   # (N > 1 still needs it for the end-to-end extra below)
+                # (the clustering context and the bench context stay OPEN while the configs run: the mixed-length pass of config 4a used
+                # to lose 8 % when its streams shared hardware queues with other live streams of the process -- 4.53 ms inside this run
+                # against 4.17 ms on its own -- and rounds 3-4 closed these contexts first; its side streams are probed now, hmk_pass.cpp)
                 t = time.perf_counter()
                 try:
                     line["configs"] = other_configs(M, dev, stream)
                 except Exception as exc:   # reported in the line, never instead of it
                     line["configs"] = {"error": f"{type(exc).__name__}: {exc}"}
                 line["configs_wall_s"] = time.perf_counter() - t
+                if not args.no_greedy:
+                    gctx.close()
+                if world == 1:
+                    ctx.close()   # (N > 1 still needs it for the end-to-end extra below)
             if not args.no_cpu_baseline:
                 cores, why = usable_cores()
                 cores = min(cores, int(os.environ.get("HMK_BENCH_CPU_THREADS", "64")))   # the oracle's teams stop scaling well before that
