@@ -35,6 +35,7 @@ struct Group {
     int lbk;  // column-length capacity of the kernel instantiation
     uint32_t base, count;
     uint32_t band;  // the first `band` tiles of the group touch a "band" row (caller index < Plan::band_rows)
+    uint64_t work;  // cells its tiles add (pairs x cells per pair): what the launches of a forked pass are balanced by (hmk_pass.cpp)
 };
 
 // grow-only device scratch of the greedy tail (one hipMalloc per buffer and context, not per call)

@@ -91,11 +91,16 @@ int neighbors_dev_locked(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uin
     // biggest groups first
     std::vector<const Group *> order;
     for (const Group &g : pl.groups) order.push_back(&g);
-    std::stable_sort(order.begin(), order.end(), [](const Group *a, const Group *b) { return a->count > b->count; });
-    size_t q = 0;
+    std::stable_sort(order.begin(), order.end(), [](const Group *a, const Group *b) { return a->work > b->work; });
+    // each launch goes to the side stream with the least work so far (cells to add): dealt round-robin by tile count, one stream of
+    // BASELINE config 4a ran dry a millisecond before the other two (kernel trace: 3.1 / 4.1 / 4.1 ms of kernels per stream)
+    uint64_t load[hmk_ctx::N_SIDE] = {0};
     for (const Group *gp : order) {
         const Group &g = *gp;
-        hipStream_t s = fork ? sides[q++ % n_side] : stream;
+        int least = 0;
+        for (int k = 1; k < n_side; k++) if (load[k] < load[least]) least = k;
+        load[least] += g.work;
+        hipStream_t s = fork ? sides[least] : stream;
         const uint32_t t0 = which == LAUNCH_REST ? g.base + g.band : g.base;
         const uint32_t cnt = which == LAUNCH_ALL ? g.count : which == LAUNCH_BAND ? g.band : g.count - g.band;
         if (g.path == PATH_DIRECT)

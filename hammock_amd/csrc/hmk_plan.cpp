@@ -373,9 +373,15 @@ int build_plan(hmk_ctx *ctx, int X, int p, int thr, uint32_t part, uint32_t n_pa
             return (uint64_t)a.nrows * a.ncols > (uint64_t)b.nrows * b.ncols;
         });
         uint32_t n_band = 0;
-        for (const Tile &t : kv.second) n_band += t.pad0;
+        uint64_t work = 0;
+        for (const Tile &t : kv.second) {
+            n_band += t.pad0;
+            const TileClass &tc = classes[t.cls];
+            const int lb = std::min((int)tc.la, (int)tc.lb), d = std::abs((int)tc.la - (int)tc.lb);
+            work += (uint64_t)t.nrows * t.ncols * (uint64_t)std::max(1, lb * (2 * X + d + 1) - X * (X + 1));
+        }
         pl.groups.push_back(Group{std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),
-                                  (uint32_t)tiles.size(), (uint32_t)kv.second.size(), n_band});
+                                  (uint32_t)tiles.size(), (uint32_t)kv.second.size(), n_band, work});
         tiles.insert(tiles.end(), kv.second.begin(), kv.second.end());
     }
     S.n_tiles = (uint32_t)tiles.size();
