@@ -46,8 +46,11 @@ constexpr int ROWS_STAGE_CAPFORM = 320, ROWS_STAGE_EXACT = 640, ROWS_STAGE_SHORT
 constexpr int ROWS_INLOOP_MAXCELLS = 45;   // shapes of at most this many cells per pair keep the rescoring flush
 constexpr int rows_cells(int x, int cap) { return cap * (2 * x + 1) - x * (x + 1); }   // cells per pair of equal lengths
 constexpr bool rows_inloop(int x, int cap) { return rows_cells(x, cap) > ROWS_INLOOP_MAXCELLS; }
-constexpr int rows_stage(int x, int cap, bool exact) {
-    return !exact ? ROWS_STAGE_CAPFORM : rows_inloop(x, cap) ? ROWS_STAGE_EXACT : ROWS_STAGE_SHORT;
+// ... of a shape: a one-length form whose rows are LONGER than its columns (d > 0: a class of a mixed-length set, k_neighbors_rows_lens)
+// always extracts in the loop (its pairs have at least 44 cells)
+constexpr bool rows_inloop_shape(int x, int d, int cap, bool exact) { return (exact && d > 0) || rows_inloop(x, cap); }
+constexpr int rows_stage(int x, int d, int cap, bool exact) {
+    return !exact ? ROWS_STAGE_CAPFORM : rows_inloop_shape(x, d, cap, exact) ? ROWS_STAGE_EXACT : ROWS_STAGE_SHORT;
 }
 // groups of 8 rows per tile.  Capacity forms (a length bucket's short column runs): 1 / 2 / 3 / 4 groups measured 4.87 / 4.48 /
 // 4.58 / 4.74 ms on BASELINE config 4a.  One-length shapes: long column runs, one group (2.65-2.67 ms with 1 or 2 at length
@@ -57,7 +60,7 @@ constexpr int rows_groups(int x, int /*d*/, int cap, bool exact) {
     return !exact ? 2 : rows_inloop(x, cap) ? 1 : 2;
 }
 // the rescoring flush of a two-group one-length shape drains ONE group per wave-instruction (two-ended stage, see the kernel)
-constexpr bool rows_two_ended(int x, int cap, bool exact, int g) { return exact && !rows_inloop(x, cap) && g == 2; }
+constexpr bool rows_two_ended(int x, int d, int cap, bool exact, int g) { return exact && !rows_inloop_shape(x, d, cap, exact) && g == 2; }
 
 template <typename T>
 __device__ __forceinline__ T rows_table_read(uint32_t addr) {
@@ -77,7 +80,7 @@ constexpr int rows_tab_bytes(int x, int d, int cap, bool exact, int g) {
     return g * (cap + d + (exact ? 0 : 2 * x + d)) * 192;   // positions + (capacity form) the end table's ND - 1 positions
 }
 constexpr int rows_lds_bytes(int x, int d, int cap, bool exact, int g) {   // must match the kernel's LDS map
-    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * rows_stage(x, cap, exact) * 4;
+    return rows_tab_bytes(x, d, cap, exact, g) + 576 + 8 * g * 32 + 4 * rows_stage(x, d, cap, exact) * 4;
 }
 
 template <int N, class F, int... Is>
@@ -302,8 +305,8 @@ template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
 __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_t *stage_v, uint32_t cnt_v, uint32_t cnt_hi_v, uint32_t tab_addr,
                                                            uint32_t ka_lo, uint32_t ka_hi) {
     using S = RowsShape<X, D, CAP, EXACT_LB, G>;
-    constexpr bool TWO = rows_two_ended(X, CAP, EXACT_LB, G);
-    constexpr int STAGE_CAP = rows_stage(X, CAP, EXACT_LB);
+    constexpr bool TWO = rows_two_ended(X, D, CAP, EXACT_LB, G);
+    constexpr int STAGE_CAP = rows_stage(X, D, CAP, EXACT_LB);
     // (arguments arrive in vector registers; all of them are wave-uniform)
     const uint32_t cnt_lo = __builtin_amdgcn_readfirstlane(cnt_v);
     const uint32_t cnt_hi = TWO ? __builtin_amdgcn_readfirstlane(cnt_hi_v) : 0u;
@@ -357,7 +360,7 @@ __device__ __attribute__((noinline)) void flush_stage_rows(const HMK_LDS uint32_
         }
         if (ok && A.symmetric) atomicAdd(&A.deg[A.deg_m_offset + m], 1u);
     };
-    if constexpr (rows_inloop(X, CAP)) {
+    if constexpr (rows_inloop_shape(X, D, CAP, EXACT_LB)) {
         const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
         const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
         base = ((unsigned long long)bhi << 32) | blo;
@@ -548,18 +551,17 @@ __device__ __forceinline__ void rows_for_each_group(std::integer_sequence<int, I
     (f(std::integral_constant<int, Is>{}), ...);
 }
 
-// MODE: what a flush does beside storing the edge (hmk_device.h)
+// One tile (the workgroup's).  MODE: what a flush does beside storing the edge (hmk_device.h).  smem: the kernel's ONE static LDS object
+// (rows_lds_bytes of it are used): its base address is a compile-time constant, so table offsets fold into the ds_read immediate.
+// Inlined into its kernel (the flush reads the kernel's arguments through the kernarg pointer: P and tile_base must be the kernel's first two).
 template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
-__global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, EXACT_LB, G), EXACT_LB))
-k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
+__device__ __forceinline__ void rows_tile(const NeighborParams &P, const uint32_t tile_base, uint8_t *smem) {
     using S = RowsShape<X, D, CAP, EXACT_LB, G>;
     constexpr int ND = S::ND, NI = S::NI, NEND = S::NEND, TAB_BYTES = S::TAB_BYTES;
     constexpr int R = 8 * G;
-    constexpr int STAGE_CAP = rows_stage(X, CAP, EXACT_LB);  // records per wave; flushed when fewer than 64 slots are free
+    constexpr int STAGE_CAP = rows_stage(X, D, CAP, EXACT_LB);  // records per wave; flushed when fewer than 64 slots are free
     constexpr int LDS_BYTES = TAB_BYTES + 576 + R * 32 + 4 * STAGE_CAP * 4;
     static_assert(LDS_BYTES == rows_lds_bytes(X, D, CAP, EXACT_LB, G), "rows_lds_bytes must match the LDS map");
-    // one STATIC LDS object: its base address is a compile-time constant, so table offsets fold into the ds_read immediate
-    __shared__ __attribute__((aligned(16))) uint8_t smem[LDS_BYTES];
     uint8_t *tab = smem;
     uint8_t *mb = smem + TAB_BYTES;
     uint8_t *rowres = mb + 576;
@@ -613,7 +615,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
 #pragma unroll
     for (int u = 0; u < ND; u++) ci[u] = ((Cp->cinit[u >> 2] >> ((u & 3) * 8)) & 0xFFu) * 0x01010101u;
 
-    constexpr bool TWO = rows_two_ended(X, CAP, EXACT_LB, G);
+    constexpr bool TWO = rows_two_ended(X, D, CAP, EXACT_LB, G);
     uint32_t cnt = 0;     // staged records of this wave (wave-uniform); two-ended: group 0's, from the stage's bottom
     uint32_t cnt_hi = 0;  // two-ended: group 1's, from the stage's top
     const uint32_t col_end = T.col0 + T.ncols;
@@ -628,7 +630,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     const uint8_t *const res_sorted = P.res_sorted;
     const uint32_t lpad_s = P.lpad;
 
-    constexpr bool INLOOP = rows_inloop(X, CAP);
+    constexpr bool INLOOP = rows_inloop_shape(X, D, CAP, EXACT_LB);
     constexpr bool DEFER = EXACT_LB && !INLOOP;   // (mixed lengths: short column runs, two groups -- 1.3 % slower with it)
     // Hits are rare per pair (0.26 % at the default threshold of 12-mers) but not per step: a wave tests 512 pairs at a time.
     // DEFER: the test's result is only NOTED at every step -- the top bits of the eight rows' bytes, merged into one word per
@@ -735,54 +737,56 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     flush_stage_rows<X, D, CAP, EXACT_LB, G, MODE>(stage, cnt, cnt_hi, tab_addr, ka_lo, ka_hi);
 }
 
-
-// -----------------------------------------------------------------------------
-// shapes, parts and launchers
-// -----------------------------------------------------------------------------
-template <int X, int D, int CAP, bool EXACT_LB>
-static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
-    constexpr int G = rows_groups(X, D, CAP, EXACT_LB);
-    // the flush's mode is a template parameter: with the run-time form the counting branch's registers spill in every mode
-    if (P.deg)
-        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_COUNT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
-    else
-        hipLaunchKernelGGL((k_neighbors_rows<X, D, CAP, EXACT_LB, G, EDGES_PLAIN>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
-    return hipGetLastError();
+template <int X, int D, int CAP, bool EXACT_LB, int G, int MODE>
+__global__ void __launch_bounds__(256, rows_waves(2 * X + D + 1, CAP, rows_lds_bytes(X, D, CAP, EXACT_LB, G), EXACT_LB))
+k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[rows_lds_bytes(X, D, CAP, EXACT_LB, G)];
+    rows_tile<X, D, CAP, EXACT_LB, G, MODE>(P, tile_base, smem);
 }
 
-// The instantiations.  F(part, X, L): a set of ONE length L with max shift X (column length at compile time) -- every length
-// 6 .. 20 at the max shift the reference derives for it, round(L / 4) (Hammock.java:1421-1434).  C(part, X, D, CAP): the
-// capacity form, column length <= CAP at run time, rows D longer (mixed lengths; also what a uniform set with another -x
-// runs: D = 0).  `part` is the translation unit that holds the shape (k_rows_part.hip is compiled once per part, each a code
-// object of its own: a pass loads only the parts it launches from).
-#define HMK_ROWS_EXACT_LIST(F) \
-    F(0, 3, 10) F(0, 3, 11) F(0, 3, 12) F(0, 3, 13) \
-    F(3, 2, 6) F(3, 2, 7) F(3, 2, 8) F(3, 2, 9) \
-    F(4, 4, 14) F(4, 4, 15) F(4, 4, 16) F(4, 4, 17) \
-    F(6, 5, 18) F(6, 5, 19) F(6, 5, 20)
-#define HMK_ROWS_CAP_LIST(C) \
-    C(1, 3, 0, 12) C(1, 3, 1, 12) C(1, 3, 2, 12) C(1, 3, 3, 12) C(1, 3, 4, 12) C(1, 3, 5, 12) C(1, 3, 6, 12) C(1, 3, 7, 12) \
-    C(1, 3, 8, 12) C(1, 3, 9, 12) C(1, 3, 10, 12) C(1, 3, 11, 12) C(1, 3, 12, 12) C(1, 3, 13, 12) \
-    C(2, 3, 0, 16) C(2, 3, 1, 16) C(2, 3, 2, 16) C(2, 3, 3, 16) C(2, 3, 4, 16) C(2, 3, 5, 16) C(2, 3, 6, 16) C(2, 3, 7, 16) \
-    C(2, 3, 0, 20) C(2, 3, 1, 20) C(2, 3, 2, 20) C(2, 3, 3, 20) \
-    C(3, 1, 0, 12) C(3, 1, 1, 12) C(3, 1, 2, 12) C(3, 1, 3, 12) C(3, 1, 4, 12) \
-    C(3, 2, 0, 12) C(3, 2, 1, 12) C(3, 2, 2, 12) C(3, 2, 3, 12) C(3, 2, 4, 12) C(3, 2, 5, 12) C(3, 2, 6, 12) C(3, 2, 7, 12) \
-    C(3, 2, 0, 16) C(3, 2, 1, 16) C(3, 2, 2, 16) C(3, 2, 3, 16) \
-    C(4, 4, 0, 12) C(4, 4, 1, 12) C(4, 4, 2, 12) C(4, 4, 3, 12) C(4, 4, 4, 12) C(4, 4, 5, 12) C(4, 4, 6, 12) C(4, 4, 7, 12) \
-    C(4, 4, 8, 12) \
-    C(5, 4, 0, 16) C(5, 4, 1, 16) C(5, 4, 2, 16) C(5, 4, 3, 16) C(5, 4, 4, 16) C(5, 4, 5, 16) C(5, 4, 6, 16) C(5, 4, 7, 16) \
-    C(5, 4, 0, 20) C(5, 4, 1, 20) C(5, 4, 2, 20) C(5, 4, 3, 20) \
-    C(6, 5, 0, 12) C(6, 5, 1, 12) C(6, 5, 2, 12) \
-    C(6, 5, 0, 16) C(6, 5, 1, 16) C(6, 5, 2, 16) C(6, 5, 3, 16) C(6, 5, 4, 16) \
-    C(6, 5, 0, 20) C(6, 5, 1, 20) C(6, 5, 2, 20) C(6, 5, 3, 20) C(6, 5, 4, 20)
+// Mixed lengths, max shift 3 (BASELINE config 4a): the launch group of (row length - column length = D, column capacity CAPB) holds
+// tiles of several column lengths lb.  The capacity form takes lb at run time -- scalar-tested position pairs, the overlap's tail through
+// an end table, a second set of offsets: 2.2 VALU instructions per table read where the one-length form needs 1.85, and with three
+// launches resident the pass ran at 0.84-0.86 of its LDS bytes whatever the streams did (tools/trace_config4a.py).  Here the tile's class
+// picks the ONE-LENGTH form of its own lb (rows up to length ROWS_LENS_MAXLA; two row groups per tile: column runs are short), everything
+// compile-time; a length outside that range takes the capacity form as before.  One kernel per (D, CAPB) as before: same groups, same tiles.
+// BASELINE config 4a: 4.28-4.38 -> 4.12-4.17 ms (0.86-0.87 of its LDS bytes).  (The bodies are compiled for the capacity form's register
+// estimate, 5-7 waves per SIMD; asked for one, two or three waves more they fit without a spill -- and the pass takes the same time.)
+constexpr int ROWS_LENS_MAXLA = 20;
+constexpr int rows_lens_first(int capb) { return capb <= 12 ? 6 : capb <= 16 ? 13 : 17; }
+constexpr bool rows_lens_has(int x, int d, int capb, int lb) { return lb >= rows_lens_first(capb) && lb <= capb && lb >= 2 * x && lb + d <= ROWS_LENS_MAXLA; }
+constexpr int rows_lens_lds(int x, int d, int capb) {
+    int m = rows_lds_bytes(x, d, capb, false, 2);
+    for (int lb = rows_lens_first(capb); lb <= capb; lb++)
+        if (rows_lens_has(x, d, capb, lb) && rows_lds_bytes(x, d, lb, true, 2) > m) m = rows_lds_bytes(x, d, lb, true, 2);
+    return m;
+}
+constexpr int rows_lens_waves(int x, int d, int capb) {
+    const int lds = rows_lens_lds(x, d, capb);
+    int w = rows_waves(2 * x + d + 1, capb, lds, false);
+    for (int lb = rows_lens_first(capb); lb <= capb; lb++)
+        if (rows_lens_has(x, d, capb, lb) && rows_waves(2 * x + d + 1, lb, lds, true) < w) w = rows_waves(2 * x + d + 1, lb, lds, true);
+    return w;
+}
+template <int X, int D, int CAPB, int MODE, int LB>
+__device__ __forceinline__ void rows_lens_pick(const NeighborParams &P, const uint32_t tile_base, uint8_t *smem, int lb) {
+    if constexpr (LB > CAPB) {
+        rows_tile<X, D, CAPB, false, 2, MODE>(P, tile_base, smem);   // (a length without a form of its own)
+    } else {
+        if constexpr (rows_lens_has(X, D, CAPB, LB)) {
+            if (lb == LB) { rows_tile<X, D, LB, true, 2, MODE>(P, tile_base, smem); return; }   // wave-uniform
+        }
+        rows_lens_pick<X, D, CAPB, MODE, LB + 1>(P, tile_base, smem, lb);
+    }
+}
+template <int X, int D, int CAPB, int MODE>
+__global__ void __launch_bounds__(256, rows_lens_waves(X, D, CAPB))
+k_neighbors_rows_lens(const NeighborParams P, const uint32_t tile_base) {
+    __shared__ __attribute__((aligned(16))) uint8_t smem[rows_lens_lds(X, D, CAPB)];
+    const int lb = (int)P.classes[P.tiles[tile_base + blockIdx.x].cls].lb;   // (scalar loads)
+    rows_lens_pick<X, D, CAPB, MODE, rows_lens_first(CAPB)>(P, tile_base, smem, lb);
+}
 
-// one launcher per part (k_rows_part.hip, -DHMK_ROWS_PART=p); hipErrorInvalidValue: no such shape in that part
-#define HMK_ROWS_PART_DECL(p) \
-    hipError_t launch_rows_part_##p(int X, int d, int cap, bool exact, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s);
-HMK_ROWS_PART_DECL(0) HMK_ROWS_PART_DECL(1) HMK_ROWS_PART_DECL(2) HMK_ROWS_PART_DECL(3)
-HMK_ROWS_PART_DECL(4) HMK_ROWS_PART_DECL(5) HMK_ROWS_PART_DECL(6)
-#undef HMK_ROWS_PART_DECL
-hipError_t warm_rows_part_0();
 
 }  // namespace hmk
 #endif

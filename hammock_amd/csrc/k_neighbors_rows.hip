@@ -1,6 +1,6 @@
 // k_neighbors_rows.hip -- which row-packed instantiation (k_neighbors_rows.h) a (max shift, lengths) class runs, and the
 // dispatch to the part (k_rows_part.hip) that holds it.  Host code only.
-#include "k_neighbors_rows.h"
+#include "k_rows_shapes.h"
 
 namespace hmk {
 
@@ -39,7 +39,7 @@ hipError_t launch_neighbors_rows(int X, int d, int cap, bool exact, const Neighb
     if (n_tiles == 0) return hipSuccess;
     switch (rows_part_of(X, d, cap, exact)) {
 #define HMK_P(p) case p: return launch_rows_part_##p(X, d, cap, exact, P, tile_base, n_tiles, s);
-        HMK_P(0) HMK_P(1) HMK_P(2) HMK_P(3) HMK_P(4) HMK_P(5) HMK_P(6)
+        HMK_P(0) HMK_P(1) HMK_P(2) HMK_P(3) HMK_P(4) HMK_P(5) HMK_P(6) HMK_P(7) HMK_P(8) HMK_P(9) HMK_P(10)
 #undef HMK_P
     }
     return hipErrorInvalidValue;

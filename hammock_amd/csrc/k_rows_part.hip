@@ -1,7 +1,7 @@
 // k_rows_part.hip -- one part of the row-packed kernels' instantiations (k_neighbors_rows.h), compiled once per part with
 // -DHMK_ROWS_PART=p: every part is a code object of its own, loaded at the first launch from it, and the parts compile in
 // parallel.  Integer scoring only: no MFMA, no dense contraction.
-#include "k_neighbors_rows.h"
+#include "k_rows_shapes.h"
 
 #ifndef HMK_ROWS_PART
 #error "compile with -DHMK_ROWS_PART=<part>"
