@@ -216,7 +216,6 @@ int reserve_tail_buffers(hmk_ctx *ctx, uint32_t n, bool packed, uint32_t r1, boo
         HIPCHK(ctx, ensure_buf(ctx, SB_DIRTY, nl * 4));
         HIPCHK(ctx, ensure_buf(ctx, SB_CHOICE, nl * 4));
         HIPCHK(ctx, ensure_buf(ctx, SB_ACCEPTED, nl * 4));
-        HIPCHK(ctx, ensure_buf(ctx, SB_JSLOT, nl * 4));
         HIPCHK(ctx, ensure_buf(ctx, SB_LCOUNT, 64));
         HIPCHK(ctx, ensure_buf(ctx, SB_SEQSZ, (size_t)n * 4));
         HIPCHK(ctx, ensure_pinned(&ctx->h_stage, &ctx->h_stage_cap, HMK_PRE_REGIONS * sizeof(unsigned long long) + (size_t)n * 12 + ncl * 4 + 64, 0));
