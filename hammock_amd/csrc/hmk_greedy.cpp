@@ -800,12 +800,18 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         std::vector<Cand> cand;
         const bool fast = !clusters.empty() && nl > 512;
         bool have_cand = false;
-        bool device_done = false;
+        bool device_done = false, prefilled = false;
         std::vector<int32_t> join_slot;
         if (fast && symmetric_scores && hooks && hooks->device_loop) {   // large inputs: the whole loop on the GPU, in optimistic rounds
             std::vector<int32_t> usize(clusters.size()), cids(clusters.size());
             std::vector<int64_t> csize(clusters.size());
             for (size_t c = 0; c < clusters.size(); c++) { usize[c] = clusters[c].usize; csize[c] = clusters[c].size; cids[c] = clusters[c].id; }
+            // the result as it stands after phase 1, written NOW: the device is still scoring / building its CSR and the host has
+            // nothing to do -- after the loop only the leftovers that joined are patched (:67-68 below)
+            for (uint32_t q = 0; q < n; q++) cluster_id[q] = cluster_of[q] >= 0 ? clusters[cluster_of[q]].id : (int32_t)q;
+            if (result_order)
+                for (size_t c = 0; c < clusters.size(); c++) result_order[c] = clusters[c].id;
+            prefilled = true;
             device_done = hooks->device_loop(cluster_of.data(), usize, csize, cids, leftover, join_slot);
         }
         if (fast && !device_done && hooks && hooks->precheck) {   // the adjacency is still on the GPU: pre-check there
@@ -894,7 +900,7 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
             const uint32_t y = leftover[q];
             Found F{NEAR_NULL, -1, 0};                                              // :60
             if (device_done) {   // decided on the device (k_loop_*); joins are applied in loop order
-                if (join_slot[q] >= 0) insert_into(join_slot[q], y);                 // :61-62
+                if (join_slot[q] >= 0) { insert_into(join_slot[q], y); cluster_id[y] = clusters[join_slot[q]].id; }   // :61-62
                 else rest.push_back(y);                                              // :64
                 continue;
             }
@@ -952,16 +958,16 @@ static int greedy_from_csr_impl(uint32_t n, const int32_t *sizes, const uint64_t
         }
         // ---- :67-68 ---------------------------------------------------------
         int32_t out = 0;
+        const bool patched = prefilled && device_done;   // (ids and the clusters' part of the list were written before the loop)
         for (const ClusterRec &c : clusters) {
-            if (result_order) result_order[out] = c.id;
+            if (result_order && !patched) result_order[out] = c.id;
             out++;
         }
-        for (uint32_t y : rest) {
-            if (result_order) result_order[out] = (int32_t)y;
-            out++;
-        }
-        for (uint32_t q = 0; q < n; q++)
-            cluster_id[q] = cluster_of[q] >= 0 ? clusters[cluster_of[q]].id : (int32_t)q;
+        if (result_order && !rest.empty()) std::memcpy(result_order + out, rest.data(), rest.size() * sizeof(int32_t));   // (ids < 2^31)
+        out += (int32_t)rest.size();
+        if (!patched)
+            for (uint32_t q = 0; q < n; q++)
+                cluster_id[q] = cluster_of[q] >= 0 ? clusters[cluster_of[q]].id : (int32_t)q;
         st->n_result_clusters = out;
         st->n_multi = (int32_t)clusters.size();
     }
