@@ -736,7 +736,8 @@ int cluster_on_device(hmk_ctx *ctx, const EdgeSource &src, int max_clusters, int
                 r = hipStreamSynchronize(S);
                 done = r == hipSuccess && (uint32_t)*word == 0;
             }
-            if (r == hipSuccess) r = hipStreamSynchronize(S);       // drain the rounds enqueued past the end
+            // (the round enqueued past the last one changes nothing -- a round without a join is the end -- and is not waited for here:
+            // every join's slot was stored by a kernel that ended before the final round's began; cluster_on_device drains S before it returns)
         }
         if (r != hipSuccess || !done) return false;
         join_slot.resize(nl);
