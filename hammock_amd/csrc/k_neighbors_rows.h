@@ -744,7 +744,7 @@ k_neighbors_rows(const NeighborParams P, const uint32_t tile_base) {
     rows_tile<X, D, CAP, EXACT_LB, G, MODE>(P, tile_base, smem);
 }
 
-// Mixed lengths, max shift 3 (BASELINE config 4a): the launch group of (row length - column length = D, column capacity CAPB) holds
+// Mixed lengths, max shift 2 or 3 (BASELINE config 4a: 3): the launch group of (row length - column length = D, column capacity CAPB) holds
 // tiles of several column lengths lb.  The capacity form takes lb at run time -- scalar-tested position pairs, the overlap's tail through
 // an end table, a second set of offsets: 2.2 VALU instructions per table read where the one-length form needs 1.85, and with three
 // launches resident the pass ran at 0.84-0.86 of its LDS bytes whatever the streams did (tools/trace_config4a.py).  Here the tile's class

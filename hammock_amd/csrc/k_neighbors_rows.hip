@@ -39,7 +39,7 @@ hipError_t launch_neighbors_rows(int X, int d, int cap, bool exact, const Neighb
     if (n_tiles == 0) return hipSuccess;
     switch (rows_part_of(X, d, cap, exact)) {
 #define HMK_P(p) case p: return launch_rows_part_##p(X, d, cap, exact, P, tile_base, n_tiles, s);
-        HMK_P(0) HMK_P(1) HMK_P(2) HMK_P(3) HMK_P(4) HMK_P(5) HMK_P(6) HMK_P(7) HMK_P(8) HMK_P(9) HMK_P(10)
+        HMK_P(0) HMK_P(1) HMK_P(2) HMK_P(3) HMK_P(4) HMK_P(5) HMK_P(6) HMK_P(7) HMK_P(8) HMK_P(9) HMK_P(10) HMK_P(11) HMK_P(12)
 #undef HMK_P
     }
     return hipErrorInvalidValue;

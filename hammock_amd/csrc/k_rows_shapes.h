@@ -13,7 +13,7 @@ template <int X, int D, int CAP, bool EXACT_LB>
 static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s) {
     constexpr int G = rows_groups(X, D, CAP, EXACT_LB);
     // the flush's mode is a template parameter: with the run-time form the counting branch's registers spill in every mode
-    if constexpr (!EXACT_LB && X == 3) {   // mixed lengths at the shift BASELINE config 4a runs: a one-length form per tile (k_neighbors_rows_lens)
+    if constexpr (!EXACT_LB && (X == 2 || X == 3)) {   // mixed lengths at the max shifts of sets with mean length 6 .. 13.9: a one-length form per tile (k_neighbors_rows_lens)
         static_assert(G == 2, "the planner gives the capacity groups 16 rows per tile");
         if (P.deg) hipLaunchKernelGGL((k_neighbors_rows_lens<X, D, CAP, EDGES_COUNT>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
         else hipLaunchKernelGGL((k_neighbors_rows_lens<X, D, CAP, EDGES_PLAIN>), dim3(n_tiles), dim3(256), 0, s, P, tile_base);
@@ -43,7 +43,7 @@ static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uin
     C(2, 3, 0, 16) C(2, 3, 1, 16) C(2, 3, 2, 16) C(2, 3, 3, 16) C(10, 3, 4, 16) C(10, 3, 5, 16) C(10, 3, 6, 16) C(10, 3, 7, 16) \
     C(10, 3, 0, 20) C(10, 3, 1, 20) C(10, 3, 2, 20) C(10, 3, 3, 20) \
     C(3, 1, 0, 12) C(3, 1, 1, 12) C(3, 1, 2, 12) C(3, 1, 3, 12) C(3, 1, 4, 12) \
-    C(3, 2, 0, 12) C(3, 2, 1, 12) C(3, 2, 2, 12) C(3, 2, 3, 12) C(3, 2, 4, 12) C(3, 2, 5, 12) C(3, 2, 6, 12) C(3, 2, 7, 12) \
+    C(11, 2, 0, 12) C(11, 2, 1, 12) C(11, 2, 2, 12) C(11, 2, 3, 12) C(12, 2, 4, 12) C(12, 2, 5, 12) C(12, 2, 6, 12) C(12, 2, 7, 12) \
     C(3, 2, 0, 16) C(3, 2, 1, 16) C(3, 2, 2, 16) C(3, 2, 3, 16) \
     C(4, 4, 0, 12) C(4, 4, 1, 12) C(4, 4, 2, 12) C(4, 4, 3, 12) C(4, 4, 4, 12) C(4, 4, 5, 12) C(4, 4, 6, 12) C(4, 4, 7, 12) \
     C(4, 4, 8, 12) \
@@ -58,7 +58,7 @@ static hipError_t launch_rows_t(const NeighborParams &P, uint32_t tile_base, uin
     hipError_t launch_rows_part_##p(int X, int d, int cap, bool exact, const NeighborParams &P, uint32_t tile_base, uint32_t n_tiles, hipStream_t s);
 HMK_ROWS_PART_DECL(0) HMK_ROWS_PART_DECL(1) HMK_ROWS_PART_DECL(2) HMK_ROWS_PART_DECL(3)
 HMK_ROWS_PART_DECL(4) HMK_ROWS_PART_DECL(5) HMK_ROWS_PART_DECL(6) HMK_ROWS_PART_DECL(7)
-HMK_ROWS_PART_DECL(8) HMK_ROWS_PART_DECL(9) HMK_ROWS_PART_DECL(10)
+HMK_ROWS_PART_DECL(8) HMK_ROWS_PART_DECL(9) HMK_ROWS_PART_DECL(10) HMK_ROWS_PART_DECL(11) HMK_ROWS_PART_DECL(12)
 #undef HMK_ROWS_PART_DECL
 hipError_t warm_rows_part_0();
 
