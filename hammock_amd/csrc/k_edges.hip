@@ -1852,16 +1852,28 @@ hipError_t launch_band_prepare(const uint64_t *bstart, const uint32_t *bup, cons
 // xGMI link carries its own pair's traffic, none more than 2 / G of a shard) instead of all of them to one root.
 __global__ void __launch_bounds__(256)
 k_route_count(const EdgeSegs segs, uint32_t rows_per, uint32_t g, unsigned long long *__restrict__ cnt) {
+    // (per-thread counters in registers, folded per wave at the end: one LDS atomic per edge on a handful of addresses -- every lane of a
+    // wave hitting the same counter -- made this pass 1-5 ms for the 1.3 GB of a 1/8 shard at 10^6)
     __shared__ uint32_t hist[HMK_MAX_DEVICES];
     if (threadIdx.x < HMK_MAX_DEVICES) hist[threadIdx.x] = 0;
     __syncthreads();
     const EdgeSeg sg = segs.s[blockIdx.y];
     const uint64_t n_edges = min((uint64_t)*sg.count, sg.cap);
+    uint32_t c[HMK_MAX_DEVICES];
+#pragma unroll
+    for (uint32_t o = 0; o < HMK_MAX_DEVICES; o++) c[o] = 0;
     for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < n_edges; k += (uint64_t)gridDim.x * 256) {
         const uint64_t e = sg.edges[k];
         const uint32_t dx = min(HMK_EDGE_X(e) / rows_per, g - 1), dm = min(HMK_EDGE_M(e) / rows_per, g - 1);
-        atomicAdd(&hist[dx], 1u);
-        if (dm != dx) atomicAdd(&hist[dm], 1u);
+#pragma unroll
+        for (uint32_t o = 0; o < HMK_MAX_DEVICES; o++) c[o] += (uint32_t)(dx == o) + (uint32_t)((dm == o) & (dm != dx));
+    }
+#pragma unroll
+    for (uint32_t o = 0; o < HMK_MAX_DEVICES; o++) {
+        uint32_t v = c[o];
+#pragma unroll
+        for (int d = 32; d; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&hist[o], v);
     }
     __syncthreads();
     if (threadIdx.x < g && hist[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
@@ -1873,6 +1885,10 @@ __global__ void k_route_offsets(const unsigned long long *__restrict__ cnt, uint
     for (uint32_t d = 0; d < g; d++) { off[d] = run; run += cnt[d]; cur[d] = 0; }
     off[g] = run;
 }
+// ROUTE_ITEMS edges per thread and step: a step ends in one returning atomic per owner on the block cursors and three barriers, and with
+// 256 edges per step those were most of the kernel (7.4 ms for a 1/8 shard at 10^6, whatever else ran beside it); a block's share of a
+// step is a run of a few hundred edges now.
+constexpr int ROUTE_ITEMS = 8;
 __global__ void __launch_bounds__(256)
 k_route_fill(const EdgeSegs segs, uint32_t rows_per, uint32_t g, const unsigned long long *__restrict__ off, unsigned long long *__restrict__ cur,
              uint64_t *__restrict__ out, unsigned long long out_cap) {
@@ -1880,21 +1896,37 @@ k_route_fill(const EdgeSegs segs, uint32_t rows_per, uint32_t g, const unsigned 
     __shared__ unsigned long long base[HMK_MAX_DEVICES];
     const EdgeSeg sg = segs.s[blockIdx.y];
     const uint64_t n_edges = min((uint64_t)*sg.count, sg.cap);
-    for (uint64_t k0 = (uint64_t)blockIdx.x * 256; k0 < n_edges; k0 += (uint64_t)gridDim.x * 256) {   // workgroup-uniform
+    for (uint64_t k0 = (uint64_t)blockIdx.x * (256 * ROUTE_ITEMS); k0 < n_edges; k0 += (uint64_t)gridDim.x * (256 * ROUTE_ITEMS)) {   // workgroup-uniform
         if (threadIdx.x < HMK_MAX_DEVICES) hist[threadIdx.x] = 0;
         __syncthreads();
-        const uint64_t k = k0 + threadIdx.x;
-        const bool live = k < n_edges;
-        const uint64_t e = live ? sg.edges[k] : 0;
-        const uint32_t dx = min(HMK_EDGE_X(e) / rows_per, g - 1), dm = min(HMK_EDGE_M(e) / rows_per, g - 1);
-        uint32_t px = 0, pm = 0;
-        if (live) { px = atomicAdd(&hist[dx], 1u); if (dm != dx) pm = atomicAdd(&hist[dm], 1u); }
+        uint64_t e[ROUTE_ITEMS];
+        uint32_t px[ROUTE_ITEMS], pm[ROUTE_ITEMS];
+#pragma unroll
+        for (int u = 0; u < ROUTE_ITEMS; u++) {   // (all loads in flight before the first LDS atomic)
+            const uint64_t k = k0 + (uint64_t)u * 256 + threadIdx.x;
+            e[u] = k < n_edges ? sg.edges[k] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < ROUTE_ITEMS; u++) {
+            const uint64_t k = k0 + (uint64_t)u * 256 + threadIdx.x;
+            px[u] = pm[u] = 0;
+            if (k < n_edges) {
+                const uint32_t dx = min(HMK_EDGE_X(e[u]) / rows_per, g - 1), dm = min(HMK_EDGE_M(e[u]) / rows_per, g - 1);
+                px[u] = atomicAdd(&hist[dx], 1u);
+                if (dm != dx) pm[u] = atomicAdd(&hist[dm], 1u);
+            }
+        }
         __syncthreads();
         if (threadIdx.x < g && hist[threadIdx.x]) base[threadIdx.x] = off[threadIdx.x] + atomicAdd(&cur[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
         __syncthreads();
-        if (live) {
-            if (base[dx] + px < out_cap) out[base[dx] + px] = e;
-            if (dm != dx && base[dm] + pm < out_cap) out[base[dm] + pm] = e;
+#pragma unroll
+        for (int u = 0; u < ROUTE_ITEMS; u++) {
+            const uint64_t k = k0 + (uint64_t)u * 256 + threadIdx.x;
+            if (k < n_edges) {
+                const uint32_t dx = min(HMK_EDGE_X(e[u]) / rows_per, g - 1), dm = min(HMK_EDGE_M(e[u]) / rows_per, g - 1);
+                if (base[dx] + px[u] < out_cap) out[base[dx] + px[u]] = e[u];
+                if (dm != dx && base[dm] + pm[u] < out_cap) out[base[dm] + pm[u]] = e[u];
+            }
         }
         __syncthreads();
     }
