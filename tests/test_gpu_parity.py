@@ -898,6 +898,40 @@ def test_full_size_properties_other_shapes_1e5(gpu, blosum62, coracle, case):
     assert len(again) == len(first) and np.array_equal(again, first), (case, len(first), len(again))
 
 
+@pytest.mark.parametrize("case", [(7, 20, 3, -1, 23), (7, 12, 2, -1, 16)], ids=["7to20_X3", "7to12_X2"])
+def test_full_size_properties_mixed_lengths_1e5(gpu, blosum62, coracle, case):
+    """Mixed lengths at FULL size (10^5 peptides): every tile of a launch group runs the compile-time form of its own column length
+    (k_neighbors_rows_lens; max shift 3 = BASELINE config 4a, max shift 2 = sets of mean length 6 .. 9.9).  Every class on the
+    row-packed kernels, no edge twice, sampled edges carry the oracle's score (either orientation of a pair of unequal lengths:
+    ShiftedScorer.java:51-57 decides S / L by length), complete rows have the oracle's degree, and a second pass returns the same
+    edge set."""
+    lo, hi, X, p, thr = case
+    n = 100000
+    res, off = synth_peptides(1, n, lo, hi)
+    ctx, _, _ = ctx_for(blosum62, res=res, off=off)
+    edges, stats = ctx.neighbors_shifted(X, p, thr)
+    n_len = hi - lo + 1
+    assert stats.classes_rows == n_len * (n_len + 1) // 2, (case, stats.classes_rows, stats.classes_u8, stats.classes_u16)   # (+ a 16-bit class for the few rows above the score-bound limit)
+    assert stats.pairs_scored == n * (n - 1) // 2
+    first = np.sort(np.asarray(edges, dtype=np.uint64))
+    del edges
+    assert (first[1:] != first[:-1]).all(), "an edge was reported twice"
+    x, m, s = hammock_amd.edge_fields(first)
+    assert (x < m).all() and (s >= thr).all()
+    pick = np.random.default_rng(lo + hi).choice(len(first), min(200000, len(first)), replace=False)
+    st, want = coracle.score_pairs(blosum62, res, off, m[pick], x[pick], 0, X, p)
+    assert st == 0 and np.array_equal(want, s[pick]), case
+    deg = np.bincount(x, minlength=n) + np.bincount(m, minlength=n)
+    del x, m, s
+    for r in np.random.default_rng(lo + hi + 1).choice(n, 30, replace=False):
+        st, sc = coracle.score_pairs(blosum62, res, off, np.arange(n, dtype=np.uint32), np.full(n, r, np.uint32), 0, X, p)
+        sc[r] = -999
+        assert int((sc >= thr).sum()) == deg[r], (case, int(r))
+    again, _ = ctx.neighbors_shifted(X, p, thr)
+    again = np.sort(np.asarray(again, dtype=np.uint64))
+    assert len(again) == len(first) and np.array_equal(again, first), (case, len(first), len(again))
+
+
 def test_score_with_shift_vs_oracle(gpu, blosum62, coracle):
     """AligningSequenceScorer.scoreWithShift: score AND shift (first strict maximum, sign rule :91-93)."""
     rng = np.random.default_rng(8)
